@@ -1,0 +1,87 @@
+"""ctypes binding of the C-ABI library ``libotpose_hip.so`` (declared in include/otpose_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` (``make -C otpose_amd/csrc``).  There is
+no fallback: :func:`lib` raises if the shared object is missing, and every operator raises if its
+tensors are not on a GPU.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_float, c_int, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libotpose_hip.so")
+_lib = None
+
+OTP_OK = 0
+_ERRORS = {
+    -1: "OTP_ERR_BAD_ARG (null pointer or non-positive dimension)",
+    -2: "OTP_ERR_UNSUPPORTED (shape / dtype / stride combination not implemented)",
+    -3: "OTP_ERR_LAUNCH (HIP launch error)",
+    -4: "OTP_ERR_WORKSPACE (workspace too small)",
+}
+
+
+class ConvDesc(ctypes.Structure):
+    """Mirror of ``otp_conv_desc`` (include/otpose_hip.h)."""
+    _fields_ = [(n, c_int) for n in (
+        "N", "Cin", "H", "W", "Cout", "kh", "kw", "stride", "pad", "dil",
+        "in_ctot", "in_coff", "in2_ctot", "in2_coff", "out_ctot", "out_coff",
+        "res_ctot", "res_coff", "res_up", "act", "Ho", "Wo", "frame_split")]
+
+
+# name -> (restype, argtypes); kept in one table so tests can check every symbol is exported
+SIGNATURES = {
+    "otp_version": (c_int, []),
+    "otp_mdcn_forward": (c_int, [c_void_p] * 6 + [c_int] * 12 + [c_float, c_float, c_int, c_void_p]),
+    "otp_mdcn_backward_workspace": (c_size_t, [c_int] * 7),
+    "otp_mdcn_backward": (c_int, [c_void_p] * 10 + [c_void_p, c_size_t] + [c_int] * 12 + [c_int, c_void_p]),
+    "otp_conv2d": (c_int, [c_void_p] * 7 + [ctypes.POINTER(ConvDesc), c_void_p]),
+    "otp_conv2d_pack_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "otp_frames_split": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "otp_glue_total": (c_int, [c_void_p] + [c_void_p] * 3 + [c_int, c_int, c_int, c_void_p]),
+    "otp_glue_stack": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_void_p]),
+    "otp_add_pe": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "otp_ln_channel": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_float, c_void_p]),
+    "otp_dwconv_ln3": (c_int, [c_void_p] * 11 + [c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "otp_chan_attn_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "otp_chan_attn": (c_int, [c_void_p] * 4 + [c_void_p, c_size_t] + [c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "otp_residual_scale": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "otp_upsample_linear": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "otp_axpby": (c_int, [c_void_p, c_void_p, c_float, c_float, c_size_t, c_void_p]),
+    "otp_loss_st_ohkw": (c_int, [c_void_p] * 5 + [c_void_p, c_size_t] + [c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "otp_loss_workspace": (c_size_t, [c_int, c_int]),
+}
+
+
+def lib():
+    """Return the loaded library, loading it on first use; raise loudly when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise RuntimeError(
+                f"HIP library {LIB_PATH} is missing - run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C otpose_amd/csrc`). otpose_amd has no CPU or PyTorch-op fallback.")
+        _lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(_lib, name)
+            fn.restype = res
+            fn.argtypes = args
+    return _lib
+
+
+def check(status: int, what: str):
+    if status != OTP_OK:
+        raise RuntimeError(f"{what} failed: {_ERRORS.get(status, status)}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (``None`` -> NULL)."""
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def stream_of(t):
+    """The HIP stream PyTorch is currently enqueuing on for ``t``'s device."""
+    import torch
+    return c_void_p(torch.cuda.current_stream(t.device).cuda_stream)

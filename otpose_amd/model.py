@@ -1,0 +1,180 @@
+"""``OTPose`` - drop-in for reference model/OTPose.py:180 behind the HIP engine.
+
+Constructor, ``forward(x, margin=...)`` signature, 7-tuple output order and ``state_dict`` key set
+follow reference model/OTPose.py:181-257, 307-394.  The forward itself is a sequence of launches
+into the C-ABI library declared in include/otpose_hip.h (see :mod:`otpose_amd.engine`); there is
+no PyTorch-op or CPU fallback: without a GPU or without the built library the call raises.
+"""
+from __future__ import annotations
+
+import logging
+import os
+
+import torch
+from torch import nn
+
+from .modules import (CHAIN_RSB_BLOCKS, ConvTransformer, HRNet, _Container)
+from . import ops
+
+
+class ModulatedDeformConv(nn.Module):
+    """Modulated deformable convolution module (reference
+    thirdparty/deform_conv/modules/deform_conv.py:85-131): owns ``weight`` (Cout, Cin/groups, kh, kw)
+    and ``bias`` (Cout); ``forward(x, offset, mask)`` calls the HIP operator."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, deformable_groups=1, bias=True):
+        super().__init__()
+        ks = (kernel_size, kernel_size) if isinstance(kernel_size, int) else tuple(kernel_size)
+        self.in_channels, self.out_channels, self.kernel_size = in_channels, out_channels, ks
+        self.stride, self.padding, self.dilation = stride, padding, dilation
+        self.groups, self.deformable_groups, self.with_bias = groups, deformable_groups, bias
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels // groups, *ks))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        n = self.in_channels * self.kernel_size[0] * self.kernel_size[1]
+        bound = n ** -0.5
+        with torch.no_grad():
+            self.weight.uniform_(-bound, bound)
+            if self.bias is not None:
+                self.bias.zero_()
+
+    def forward(self, x, offset, mask):
+        return ops.modulated_deform_conv(x, offset, mask, self.weight, self.bias, self.stride,
+                                         self.padding, self.dilation, self.groups, self.deformable_groups)
+
+
+class DeformableCONV(nn.Module):
+    """reference model/layers.py:22-29: 3x3 modulated DCN, one deformable group per joint."""
+
+    def __init__(self, num_joints, k, dilation):
+        super().__init__()
+        self.deform_conv = ModulatedDeformConv(num_joints, num_joints, (k, k), stride=1,
+                                               padding=(k // 2) * dilation, dilation=dilation,
+                                               deformable_groups=num_joints)
+
+    def forward(self, x, offsets, mask):
+        return self.deform_conv(x, offsets, mask)
+
+
+def _plain_conv(cin, cout, dilation):
+    return nn.Conv2d(cin, cout, 3, 1, padding=dilation, dilation=dilation, bias=False)
+
+
+class OTPose(nn.Module):
+    def __init__(self, cfg, **kwargs):
+        super().__init__()
+        self.logger = logging.getLogger(__name__)
+        self.cfg = cfg
+        m = cfg.MODEL
+        extra = cfg["MODEL"]["EXTRA"]
+        self.num_frames = 8                       # feature maps stacked per joint (OTPose.py:188)
+        self.pe_w, self.pe_h = m.HEATMAP_SIZE
+        self.num_joints = m.NUM_JOINTS
+        self.num_patches = self.pe_h * self.pe_w
+        self.patch_dim = self.num_joints
+        self.temporal_encoding_dim = self.patch_dim * self.num_frames
+        self.freeze_hrnet_weights = m.FREEZE_HRNET_WEIGHTS
+        self.pretrained = m.PRETRAINED
+        self.pretrained_layers = extra["PRETRAINED_LAYERS"]
+
+        self.rough_pose_estimation_net = HRNet(cfg)
+        self.scale_arch, self.flow_scale_arch = (0, 6, 2), (0, 6, 0)
+        tkw = dict(n_embd_ks=3, max_len=self.num_patches, h=self.pe_h, proj_pdrop=0.1, path_pdrop=0.1)
+        d = self.temporal_encoding_dim
+        self.temporal_encoder1 = ConvTransformer(d, d, n_head=2, arch=self.scale_arch, **tkw)
+        self.temporal_encoder2 = ConvTransformer(d, d, n_head=2, arch=self.scale_arch, **tkw)
+        self.flow_encoder = ConvTransformer(self.patch_dim, self.patch_dim, n_head=1,
+                                            arch=self.flow_scale_arch, **tkw)
+
+        self.deformable_conv_dilations = list(m.DEFORMABLE_CONV.DILATION)
+        self.deformable_aggregation_type = m.DEFORMABLE_CONV.AGGREGATION_TYPE
+        assert self.deformable_aggregation_type == "weighted_sum"
+        fk = extra["FINAL_CONV_KERNEL"]
+        levels = self.scale_arch[-1] + 1
+        self.final_layer1 = nn.Conv2d(d * levels, self.num_joints, fk, 1, 1 if fk == 3 else 0)
+        self.final_layer2 = nn.Conv2d(d * levels, self.num_joints, fk, 1, 1 if fk == 3 else 0)
+
+        def_ch, n_blocks = m.DEFORMABLE_CONV_CH, m.OFFSET_MASK_COMBINE_CONV
+        self.offset_mask_combine_conv = CHAIN_RSB_BLOCKS(self.num_joints * 3, def_ch, n_blocks)
+        self.def_fuse = CHAIN_RSB_BLOCKS(self.num_joints, self.num_joints, n_blocks)
+        k, j = 3, self.num_joints
+        self.offsets_list = nn.ModuleList(
+            [nn.Sequential(_plain_conv(def_ch, j * 2 * k * k, dd)) for dd in self.deformable_conv_dilations])
+        self.masks_list = nn.ModuleList(
+            [nn.Sequential(_plain_conv(def_ch, j * k * k, dd)) for dd in self.deformable_conv_dilations])
+        self.modulated_deform_conv_list = nn.ModuleList(
+            [DeformableCONV(j, k, dd) for dd in self.deformable_conv_dilations])
+
+        self._engine = None
+        self.init_weights()
+
+    # ---- initialisation (reference model/OTPose.py:431-503) ---------------------------------
+    def init_weights(self):
+        with torch.no_grad():
+            for mod in self.modules():
+                if isinstance(mod, nn.Conv2d):
+                    mod.weight.normal_(0.0, 0.001)
+                    if mod.bias is not None:
+                        mod.bias.zero_()
+                elif isinstance(mod, nn.BatchNorm2d):
+                    mod.weight.fill_(1.0)
+                    mod.bias.zero_()
+                elif isinstance(mod, ModulatedDeformConv):
+                    mod.weight.zero_()
+                    c = mod.kernel_size[0] // 2
+                    for o in range(min(mod.weight.shape[0], mod.weight.shape[1])):
+                        mod.weight[o, o, c, c] = 1.0
+                    if mod.bias is not None:
+                        mod.bias.zero_()
+                elif isinstance(mod, nn.Conv1d) and mod.bias is not None:
+                    mod.bias.zero_()
+        if self.pretrained and os.path.isfile(self.pretrained):
+            self._load_pretrained(self.pretrained)
+        elif self.pretrained:
+            raise ValueError("{} is not exist!".format(self.pretrained))
+        if self.freeze_hrnet_weights:
+            self.rough_pose_estimation_net.freeze_weight()
+
+    def _load_pretrained(self, path):
+        """HRNet checkpoint import with the reference's prefix remap (model/OTPose.py:477-496)."""
+        sd = torch.load(path, map_location="cpu")
+        sd = sd.get("state_dict", sd)
+        tops = {n.split(".")[1] for n, _ in self.rough_pose_estimation_net.named_modules(prefix="r") if "." in n}
+        take = {}
+        for name, t in sd.items():
+            head = name.split(".")[0]
+            if not (head in self.pretrained_layers or self.pretrained_layers[0] == "*"):
+                continue
+            if head == "rough_pose_estimation_net":
+                take[name] = t
+            elif head in tops:
+                take["rough_pose_estimation_net." + name] = t
+        self.load_state_dict(take, strict=False)
+
+    # ---- forward -------------------------------------------------------------------------------
+    def forward(self, x, **kwargs):
+        assert "margin" in kwargs
+        margin = kwargs["margin"]
+        from .engine import InferenceEngine
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
+            raise NotImplementedError(
+                "OTPose training-mode forward/backward through the HIP engine is not built yet "
+                "(DESIGN.md, scope row 'train step'); operator-level backward exists for the DCN "
+                "(otpose_amd.ops.modulated_deform_conv) and the losses")
+        if self._engine is None or not self._engine.matches(x):
+            self._engine = InferenceEngine(self, x.shape[0], x.device)
+        return self._engine.run(x, margin)
+
+    def invalidate_engine(self):
+        """Drop packed weights (call after changing parameters, e.g. load_state_dict)."""
+        self._engine = None
+
+    def load_state_dict(self, *a, **k):
+        self._engine = None
+        return super().load_state_dict(*a, **k)

@@ -1,0 +1,121 @@
+"""Pin the CPU oracle against vectors produced by the reference itself (tests/golden/make_golden.py)."""
+import pytest
+import torch
+
+from oracle import otpose_oracle as O
+from otpose_amd import OTPose, cfg1, cfg2, tiny_cfg
+from otpose_amd import modules as M
+from otpose_amd import synthetic as S
+
+TOL = 2e-5   # fp32 re-association noise between the module graph and the functional restatement
+
+
+def _sd(module, seed):
+    S.fill_synthetic_(module, seed)
+    return {k: v.detach() for k, v in module.state_dict().items()}
+
+
+def _prefixed(sd, p):
+    return {p + "." + k: v for k, v in sd.items()}
+
+
+def _close(a, b, tol=TOL):
+    scale = max(1.0, float(b.abs().max()))
+    err = float((a - b).abs().max())
+    assert err <= tol * scale, f"max abs err {err} (scale {scale})"
+
+
+@pytest.mark.parametrize("tag,c,nh,stride", [("mhca_136_s1", 136, 2, 1), ("mhca_136_s2", 136, 2, 2),
+                                             ("mhca_17_s1", 17, 1, 1), ("mhca_136_s2_odd", 136, 2, 2)])
+def test_masked_mhca(golden, tag, c, nh, stride):
+    g = golden("blocks")
+    sd = _prefixed(_sd(M.MaskedMHCA(c, nh, stride, stride), 11), "a")
+    _close(O.masked_mhca(sd, "a", g[tag + "_x"], nh, stride), g[tag + "_y"])
+
+
+@pytest.mark.parametrize("tag,c,nh,stride", [("tblock_136_s1", 136, 2, 1), ("tblock_136_s2", 136, 2, 2),
+                                             ("tblock_17_s1", 17, 1, 1)])
+def test_transformer_block(golden, tag, c, nh, stride):
+    g = golden("blocks")
+    sd = _prefixed(_sd(M.TransformerBlock(c, nh, (stride, stride), proj_pdrop=0.1, path_pdrop=0.1), 12), "b")
+    _close(O.transformer_block(sd, "b", g[tag + "_x"], nh, stride), g[tag + "_y"])
+
+
+def test_channel_layernorm(golden):
+    g = golden("blocks")
+    sd = _prefixed(_sd(M.LayerNorm(136), 13), "ln")
+    _close(O.channel_layernorm(sd, "ln", g["ln_x"]), g["ln_y"])
+
+
+@pytest.mark.parametrize("tag,c,nh,arch", [("ct_136", 136, 2, (0, 6, 2)), ("ct_17", 17, 1, (0, 6, 0))])
+def test_conv_transformer(golden, tag, c, nh, arch):
+    g = golden("blocks")
+    mod = M.ConvTransformer(c, c, nh, 3, 108, arch, h=12, proj_pdrop=0.1, path_pdrop=0.1)
+    sd = _prefixed(_sd(mod, 14), "t")
+    ys = O.conv_transformer(sd, "t", g[tag + "_x"], nh, arch)
+    assert len(ys) == arch[2] + 1
+    for i, y in enumerate(ys):
+        _close(y, g[f"{tag}_y{i}"], 5e-5)
+
+
+@pytest.mark.parametrize("tag,cin,cout", [("rsb_51_32", 51, 32), ("rsb_17_17", 17, 17)])
+def test_rsb_chain(golden, tag, cin, cout):
+    g = golden("blocks")
+    sd = _prefixed(_sd(M.CHAIN_RSB_BLOCKS(cin, cout, 2), 15), "r")
+    _close(O.rsb_chain(sd, "r", g[tag + "_x"]), g[tag + "_y"])
+
+
+def test_hrnet_tiny(golden):
+    g = golden("hrnet_tiny")
+    cfg = tiny_cfg(8, (64, 96))
+    sd = _prefixed(_sd(M.HRNet(cfg), 31), "h")
+    stages = [cfg.MODEL.EXTRA[f"STAGE{s}"] for s in (2, 3, 4)]
+    _close(O.hrnet_forward(sd, "h", g["x"], stages), g["y"])
+
+
+def test_losses(golden):
+    g = golden("losses")
+    r = O.st_ohkw_mse_loss(g["s"], g["t"], g["g"], g["w"])
+    for k in ("ohkm_loss_s", "mse_loss_s", "final_loss"):
+        _close(r[k], g["st_" + k], 1e-6)
+    r = O.joints_ohkm_mse_loss(g["s"], g["g"], g["w"])
+    for k in ("ohkm_loss", "mse_loss", "final_loss"):
+        _close(r[k], g["ohkm_" + k], 1e-6)
+    _close(O.joint_mse_loss(g["s"], g["g"], g["w"]), g["jmse"], 1e-6)
+    s, t = g["s"].clone().requires_grad_(), g["t"].clone().requires_grad_()
+    O.st_ohkw_mse_loss(s, t, g["g"], g["w"])["final_loss"].backward()
+    _close(s.grad, g["st_grad_s"], 1e-6)
+    _close(t.grad, g["st_grad_t"], 1e-6)
+    # both branches of loss.py:47 are exercised by the fixture
+    flags = [bool(g["g"][:, j].max() == 1) for j in range(17)]
+    assert any(flags) and not all(flags)
+
+
+NAMES = ("output", "rough", "intersection", "prev_b", "context", "squeezed", "total_b")
+
+
+def _e2e(golden, name, cfg, batch, tol):
+    g = golden(name)
+    m = OTPose(cfg)
+    S.fill_synthetic_(m)
+    sd = {k: v.detach() for k, v in m.state_dict().items()}
+    x, margin = S.synthetic_clip(batch, cfg.MODEL.IMAGE_SIZE)
+    with torch.no_grad():
+        outs = O.otpose_forward(sd, cfg, x, margin)
+    for n, o in zip(NAMES, outs):
+        assert o.shape == g[n].shape
+        _close(o, g[n], tol)
+    # the calibrated recipe keeps every compared heatmap O(0.1 - 10): the 1e-3 bar is meaningful
+    assert 0.1 < float(g["output"].abs().max()) < 10 and float(g["output"].std()) > 0.1
+
+
+def test_e2e_tiny(golden):
+    _e2e(golden, "e2e_tiny", tiny_cfg(8, (64, 96)), 2, 5e-5)
+
+
+def test_e2e_cfg1(golden):
+    _e2e(golden, "e2e_cfg1", cfg1(), 1, 5e-5)
+
+
+def test_e2e_cfg2_one_clip(golden):
+    _e2e(golden, "e2e_cfg2_b1", cfg2(), 1, 5e-5)
