@@ -1,0 +1,180 @@
+#!/usr/bin/env python
+"""OTPose forward throughput on MI355X: frames/s at 384x288, 5-frame window, batch 16 per GPU.
+
+``python bench.py --gpus N --steps K --warmup W`` (N > 1 is launched by the driver through
+torch.distributed.run, one rank per GPU).  A step = one OTPose forward (HRNet-W48 + temporal encoders +
+RSB heads + 5x modulated DCN, fp32, eval) over 16 synthetic clips = 80 frames per rank, inputs resident
+in HBM.  Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from otpose_amd import OTPose, cfg2, hip, ops          # noqa: E402
+from otpose_amd import synthetic as S                  # noqa: E402
+
+FLOP_PER_CLIP = 409.0e9          # conv + bmm FLOPs of one 5-frame 384x288 W48 clip
+DCN_BYTES_PER_CLIP_DIL = 13_630_464   # x + offset + mask read, out written, fp32
+PEAK_F32_MATRIX = 157.3e12       # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+PEAK_HBM = 8.0e12                # MI355X_MICROARCH.md: HBM3E spec peak
+
+
+def event_time_ms(fn, iters, stream):
+    """Average duration of ``fn`` over ``iters`` back-to-back launches, HIP events on the launch stream."""
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(iters):
+        fn()
+    e1.record(stream)
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def kernel_rooflines(dev, batch):
+    """Per-kernel roofline points measured live: the dominant conv launch (MFMA-bound) and one DCN call
+    (HBM-bound), both at the shapes the forward uses."""
+    st = torch.cuda.current_stream(dev)
+    g = torch.Generator().manual_seed(7)
+    n = 5 * batch
+    # HRNet branch-0 BasicBlock conv: 48 -> 48, 3x3, 96x72, all frames of the batch (22.6 % of the MACs)
+    x = torch.randn(n, 48, 96, 72, generator=g).to(dev)
+    w = (torch.randn(48, 48, 3, 3, generator=g) * 0.05).to(dev)
+    sc, sh = torch.ones(48, device=dev), torch.zeros(48, device=dev)
+    out = torch.empty_like(x)
+    iv, ov = ops.View(x), ops.View(out)
+    wp = ops.pack_conv_weight(w)
+    d = ops.conv_desc(iv, ov, 48, 3, 3, 1, 1, 1, act=ops.ACT_RELU)
+    t_conv = event_time_ms(lambda: ops.conv2d_launch(iv, wp, sc, sh, ov, d), 20, st)
+    conv_flop = 2.0 * 48 * 48 * 9 * 96 * 72 * n
+    conv = {"kernel": "conv_igemm_kernel<3,9> 48->48 3x3 @96x72 x%d frames" % n, "bound": "mfma",
+            "achieved": conv_flop / (t_conv * 1e-3) / 1e12, "peak": PEAK_F32_MATRIX / 1e12, "unit": "TFLOP/s",
+            "frac": conv_flop / (t_conv * 1e-3) / PEAK_F32_MATRIX, "traffic": None, "ms_per_launch": t_conv}
+    # one DCN call (one dilation) over the batch
+    xd = torch.randn(batch, 17, 96, 72, generator=g).to(dev)
+    off = (torch.randn(batch, 306, 96, 72, generator=g) * 3).to(dev)
+    msk = torch.randn(batch, 153, 96, 72, generator=g).to(dev)
+    wd = (torch.randn(17, 17, 3, 3, generator=g) * 0.2).to(dev)
+    bd = torch.zeros(17, device=dev)
+    od = torch.empty(batch, 17, 96, 72, device=dev)
+    L = hip.lib()
+
+    def dcn():
+        hip.check(L.otp_mdcn_forward(hip.ptr(xd), hip.ptr(off), hip.ptr(msk), hip.ptr(wd), hip.ptr(bd), hip.ptr(od),
+                                     batch, 17, 96, 72, 17, 3, 3, 1, 6, 6, 1, 17, 0.2, 0.0, 0, hip.stream_of(xd)), "dcn")
+    t_dcn = event_time_ms(dcn, 20, st)
+    dcn_bytes = DCN_BYTES_PER_CLIP_DIL * batch
+    dcn_r = {"kernel": "mdcn_fwd_kernel<17,2,true> 17x96x72 x%d clips, one dilation" % batch, "bound": "hbm",
+             "achieved": dcn_bytes / (t_dcn * 1e-3) / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+             "frac": dcn_bytes / (t_dcn * 1e-3) / PEAK_HBM, "traffic": None, "ms_per_launch": t_dcn}
+    return conv, dcn_r
+
+
+def cpu_baseline():
+    """The oracle (CPU restatement of the reference graph) timed on the host cores: ONE clip of the same
+    workload (5 frames, 384x288, W48), median of 3 after a warm-up (a bounded sample, ~10-20 s)."""
+    from oracle import otpose_oracle as O
+    cfg = cfg2()
+    m = OTPose(cfg)
+    S.fill_synthetic_(m)
+    sd = {k: v.detach() for k, v in m.state_dict().items()}
+    x, margin = S.synthetic_clip(1, cfg.MODEL.IMAGE_SIZE)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    times = []
+    with torch.no_grad():
+        for i in range(4):
+            t0 = time.perf_counter()
+            O.otpose_forward(sd, cfg, x, margin)
+            times.append(time.perf_counter() - t0)
+    t = sorted(times[1:])[1]
+    return {"value": 5.0 / t, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "1 clip (5 frames) 384x288 HRNet-W48, oracle forward, median of 3 after 1 warm-up, %.2f s each" % t}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="clips per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    cfg = cfg2()
+    model = OTPose(cfg)
+    S.fill_synthetic_(model)                      # identical seeded weights on every rank
+    model = model.to(dev).eval()
+    x, margin = S.synthetic_clip(a.batch, cfg.MODEL.IMAGE_SIZE)
+    x, margin = x.to(dev), margin.to(dev)         # inputs resident in HBM before the timed region
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    with torch.no_grad():
+        for _ in range(max(a.warmup, 1)):
+            outs = model(x, margin=margin)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            outs = model(x, margin=margin)
+        barrier()
+        dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    finite = bool(torch.isfinite(outs[0]).all())
+
+    if rank == 0:
+        frames = 5 * a.batch * world * a.steps
+        fwd_per_s = a.steps / dt
+        line = {
+            "metric": "frames/sec at 384x288, 5-frame window, batch 16; heatmap max-abs delta vs ref",
+            "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: batch %d x 5-frame x 384x288, HRNet-W48 + DCN warp + "
+                                   "ConvVideoTransformer, fp32 forward (eval), seeded synthetic weights" % a.batch,
+                       "clips_per_gpu": a.batch, "frames_per_step_per_gpu": 5 * a.batch, "parallelism": "dp%d" % world,
+                       "outputs_finite": finite},
+            "roofline_forward": {"bound": "mfma", "achieved": FLOP_PER_CLIP * a.batch * fwd_per_s / 1e12,
+                                 "peak": PEAK_F32_MATRIX / 1e12, "unit": "TFLOP/s",
+                                 "frac": FLOP_PER_CLIP * a.batch * fwd_per_s / PEAK_F32_MATRIX, "traffic": None},
+        }
+        conv, dcn = kernel_rooflines(dev, a.batch)
+        line["roofline"] = conv
+        line["roofline_dcn"] = dcn
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,131 @@
+/* otpose_hip.h - C ABI of libotpose_hip.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for the OTPose hot path.  Plain pointers and sizes only:
+ * every pointer is a DEVICE pointer to a contiguous NCHW float32 tensor unless stated otherwise,
+ * `stream` is a hipStream_t passed as void*.  Functions never allocate, never synchronise, launch
+ * on `stream`, and return OTP_OK (0) or a negative OTP_ERR_* code (no exceptions cross the ABI).
+ *
+ * Reference interfaces replaced (paths relative to the reference repository):
+ *   otp_mdcn_forward   <- modulated_deform_conv_cuda_forward   thirdparty/deform_conv/src/deform_conv_cuda.cpp:474-549
+ *                         (+ modulated_deformable_im2col_cuda   src/deform_conv_cuda_kernel.cu:506-571, 707-737)
+ *   otp_mdcn_backward  <- modulated_deform_conv_cuda_backward  src/deform_conv_cuda.cpp:551-664
+ *                         (+ col2im / col2im_coord kernels      src/deform_conv_cuda_kernel.cu:574-705, 739-805)
+ *   everything else    <- the ATen calls issued by model/OTPose.py:307-394, model/HRNet.py:116-152,
+ *                         model/blocks.py:95-110,264-280,400-453, model/ConvVideoTransformer.py:123-184,
+ *                         model/RSB.py:77-103 and model/loss.py:25-92 (the reference has no native code
+ *                         for them; the C entry points below are what a native port of that graph binds).
+ */
+#ifndef OTPOSE_HIP_H
+#define OTPOSE_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OTP_OK 0
+#define OTP_ERR_BAD_ARG (-1)     /* null pointer / non-positive dimension */
+#define OTP_ERR_UNSUPPORTED (-2) /* shape, dtype or stride combination not implemented */
+#define OTP_ERR_LAUNCH (-3)      /* hipGetLastError() != hipSuccess after the launch */
+#define OTP_ERR_WORKSPACE (-4)   /* workspace_bytes too small */
+
+#define OTP_DTYPE_F32 0          /* the reference dispatches f64/f32/f16; f32 is what OTPose uses */
+
+#define OTP_ACT_NONE 0
+#define OTP_ACT_RELU 1
+#define OTP_ACT_GELU 2           /* exact erf GELU (nn.GELU default) */
+
+int otp_version(void);
+
+/* ---- modulated deformable convolution ------------------------------------------------------
+ * out[n,o,p] = beta*out[n,o,p] + alpha*( bias[o] + sum_{c,k} W[o,c,k] * mask[n,g(c)*K+k,p] *
+ *              bilinear(x[n,c], p*stride - pad + tap_k*dil + offset[n,g(c)*2K+2k(+1),p]) ),
+ * g(c) = c / (C/deformable_groups); sample zero outside the open interval (-1,H)x(-1,W), corners
+ * outside the image contribute zero.  alpha=1,beta=0 is the reference operator; alpha/beta fuse the
+ * reference's weighted sum over dilations (model/OTPose.py:387-392).  bias may be NULL. */
+int otp_mdcn_forward(const void* x, const void* offset, const void* mask, const void* weight,
+                     const void* bias, void* out,
+                     int N, int C, int H, int W, int Cout, int kh, int kw,
+                     int stride, int pad, int dil, int groups, int deformable_groups,
+                     float alpha, float beta, int dtype, void* stream);
+
+/* grad_x / grad_offset / grad_mask are overwritten, grad_weight / grad_bias are ACCUMULATED into
+ * (the reference accumulates them over the batch, cpp:638-650; the caller zeroes them, reference
+ * functions/deform_conv.py:152-156).  grad_bias may be NULL.  workspace: otp_mdcn_backward_workspace bytes. */
+size_t otp_mdcn_backward_workspace(int N, int C, int H, int W, int Cout, int kh, int kw);
+int otp_mdcn_backward(const void* x, const void* offset, const void* mask, const void* weight,
+                      const void* grad_out, void* grad_x, void* grad_offset, void* grad_mask,
+                      void* grad_weight, void* grad_bias, void* workspace, size_t workspace_bytes,
+                      int N, int C, int H, int W, int Cout, int kh, int kw,
+                      int stride, int pad, int dil, int groups, int deformable_groups,
+                      int dtype, void* stream);
+
+/* ---- dense convolution (implicit GEMM on the f32 matrix cores) --------------------------------
+ * out[n, out_coff+co, ho, wo] = act( scale[co] * conv(in (+ in2))[n,co,ho,wo] + shift[co] (+ res) )
+ * groups = 1.  Tensors may be channel slices of wider tensors: `*_ctot` is the channel count of the
+ * tensor the pointer addresses, `*_coff` the first channel used.  `res` may alias `out` (in-place
+ * accumulate).  res_up = f > 1: the conv result is nearest-upsampled by f and res/out live on the
+ * (Ho*f, Wo*f) grid (HRNet fuse layers, model/HRNet.py:426-439,488-494).  frame_split = B > 0: `in`
+ * is the (B, 5*Cin, H, W) clip tensor read as (5B, Cin, H, W) with image n = f*B + b taken from
+ * channels [f*Cin, (f+1)*Cin) of sample b (model/OTPose.py:317).
+ * `wpacked` comes from otp_conv2d_pack_weight ([kh*kw][Cin][Cout16] floats, Cout16 = Cout rounded up
+ * to 16).  scale / shift may be NULL (1 / 0). */
+typedef struct otp_conv_desc {
+    int N, Cin, H, W, Cout, kh, kw, stride, pad, dil;
+    int in_ctot, in_coff, in2_ctot, in2_coff, out_ctot, out_coff;
+    int res_ctot, res_coff, res_up, act, Ho, Wo, frame_split;
+} otp_conv_desc;
+
+/* tuning / test hook: force the (M-blocks, pixel-blocks, waves-in-M, waves-in-pixels) tile of otp_conv2d;
+ * all zeros restores the built-in choice.  Results never depend on it. */
+int otp_conv2d_set_tile(int MB, int PB, int WM, int WP);
+int otp_conv2d_pack_weight(const void* weight, void* wpacked, int Cout, int Cin, int kh, int kw, void* stream);
+int otp_conv2d(const void* in, const void* in2, const void* wpacked, const void* scale, const void* shift,
+               const void* res, void* out, const otp_conv_desc* desc, void* stream);
+
+/* ---- OTPose glue (model/OTPose.py:317-359) ------------------------------------------------------ */
+/* rough (5B,J,HW) -> total (B,J,HW), squeezed (B,J,HW), intersection (B,J,HW), flow_in = total + pe (pe: (J,HW)) */
+int otp_glue_total(const void* rough, void* total, void* squeezed, void* inter, void* flow_in, const void* pe,
+                   int B, int J, int HW, void* stream);
+/* builds x1, x2 (B, 8J, HW) (+ pe (8J,HW)) and prev_b (B,J,HW); margin is (B,4) float32 */
+int otp_glue_stack(const void* rough, const void* margin, const void* squeezed, const void* inter,
+                   const void* ctx, const void* pe1, const void* pe2, void* x1, void* x2, void* prev_b,
+                   int B, int J, int HW, void* stream);
+
+/* ---- ConvTransformer pieces (model/blocks.py) ---------------------------------------------------- */
+/* channel LayerNorm over C of (B,C,T) (blocks.py:95-110); optional second output
+ * pool = MaxPool1d(3,2,1)(x) (blocks.py:234-238) when pool != NULL (then T must be the input length) */
+int otp_ln_channel(const void* x, const void* gamma, const void* beta, void* y, void* pool,
+                   int B, int C, int T, float eps, void* stream);
+/* three depthwise k=3 convs (stride s, pad 1, no bias) of the same input, each followed by a channel
+ * LayerNorm (blocks.py:406-415): x (B,C,T) -> q,k,v (B,C,To), To = (T+2-3)/s+1.  dw* are (C,3). */
+int otp_dwconv_ln3(const void* x, const void* dwq, const void* dwk, const void* dwv,
+                   const void* gq, const void* bq, const void* gk, const void* bk, const void* gv, const void* bv,
+                   void* q, void* k, void* v, int B, int C, int T, int stride, float eps, void* stream);
+/* channel attention (blocks.py:427-447): per (b, head): S = (q*scale) k^T over T (hs x hs), P = softmax(S),
+ * O = P v, written as out[b][head][t][ch] (the transpose(2,3).contiguous().view(B,C,T) layout). */
+size_t otp_chan_attn_workspace(int B, int C, int T, int n_head);
+int otp_chan_attn(const void* q, const void* k, const void* v, void* out, void* workspace, size_t workspace_bytes,
+                  int B, int C, int T, int n_head, float scale, void* stream);
+/* nn.Upsample(scale_factor=f, mode='linear', align_corners=False) on (B,C,T) -> out (B, out_ctot, T*f) at
+ * channel offset out_coff (f = 1 copies) (ConvVideoTransformer.py:108,179; OTPose.py:362-369) */
+int otp_upsample_linear(const void* x, void* out, int B, int C, int T, int f, int out_ctot, int out_coff, void* stream);
+
+/* y = alpha*x + beta*y over n floats */
+int otp_axpby(const void* x, void* y, float alpha, float beta, size_t n, void* stream);
+
+/* ---- heatmap losses (model/loss.py) ------------------------------------------------------------- */
+/* ST_OHKW_MSELoss.forward (loss.py:25-92): s,t,g (B,J,HW), w (B,J); flags (J) int32 in/out: when
+ * flags_given == 0 the kernel computes flags[j] = (max_b,p g[b,j,p] == 1) itself; result[0..2] =
+ * {ohkm_loss_s, mse_loss_s, final_loss}.  grad_s / grad_t (optional, may be NULL) receive
+ * d final_loss / d s and d final_loss / d t. */
+size_t otp_loss_workspace(int B, int J);
+int otp_loss_st_ohkw(const void* s, const void* t, const void* g, const void* w, void* flags,
+                     void* result, void* grad_s, void* grad_t, void* workspace, size_t workspace_bytes,
+                     int B, int J, int HW, int topk, int flags_given, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OTPOSE_HIP_H */

@@ -1,0 +1,54 @@
+// Shared helpers for the gfx950 kernels of libotpose_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/otpose_hip.h"
+
+#define OTP_LDS_LIMIT (160 * 1024)
+
+static inline int otp_launch_status() {
+    return hipGetLastError() == hipSuccess ? OTP_OK : OTP_ERR_LAUNCH;
+}
+
+// Raise the dynamic-LDS limit of a kernel once per process and per kernel instantiation (the static lives
+// in the enclosing template instantiation); never called again, so launches stay graph-capturable.
+#define OTP_ALLOW_BIG_LDS(kern, bytes)                                                                      \
+    do {                                                                                                    \
+        static bool otp_done_ = false;                                                                      \
+        if (!otp_done_ && (bytes) > 64 * 1024) {                                                            \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                  \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, OTP_LDS_LIMIT);           \
+            otp_done_ = true;                                                                               \
+        }                                                                                                   \
+    } while (0)
+
+static inline int otp_ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// wave64 reductions (DPP-lowered __shfl_xor)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---- buffer (SRSRC) addressing: one VGPR byte offset + one SGPR byte offset per access -------------
+// gfx9-family dword3 (DST_SEL/format) constant for raw buffers
+#define OTP_BUFFER_DWORD3 0x00020000
+typedef __amdgpu_buffer_rsrc_t otp_rsrc;
+__device__ __forceinline__ otp_rsrc make_rsrc(const void* p, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0,
+                                             (int)(bytes > 0xffffffffull ? 0xffffffffull : bytes), OTP_BUFFER_DWORD3);
+}
+__device__ __forceinline__ float bload(otp_rsrc r, int voff_bytes, int soff_bytes) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff_bytes, soff_bytes, 0));
+}
+__device__ __forceinline__ void bstore(float v, otp_rsrc r, int voff_bytes, int soff_bytes) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, voff_bytes, soff_bytes, 0);
+}

@@ -1,0 +1,103 @@
+// OTPose glue between the backbone, the temporal encoders and the warp (model/OTPose.py:317-359):
+// elementwise / small-reduction kernels, one thread per heat-map pixel walking the 17 joints, so all
+// accesses are coalesced along the pixel axis and each input is read once.
+#include "common.h"
+
+namespace {
+
+// rough (5B, J, HW): frames [cur | prev | next | pprev | nnext] in blocks of B (OTPose.py:317-321)
+__global__ void glue_total_kernel(const float* __restrict__ rough, float* __restrict__ total,
+                                  float* __restrict__ squeezed, float* __restrict__ inter,
+                                  float* __restrict__ flow_in, const float* __restrict__ pe, int B, int J, int HW) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (p >= HW) return;
+    const size_t fs = (size_t)B * J * HW;                  // frame stride
+    const size_t base = (size_t)b * J * HW + p;
+    float sq = 0.f;
+    for (int j = 0; j < J; ++j) {
+        const size_t i = base + (size_t)j * HW;
+        // same association as the reference: (((cur + prev) + next) + pprev) + nnext  (OTPose.py:324)
+        float t = rough[i] + rough[fs + i] + rough[2 * fs + i] + rough[3 * fs + i] + rough[4 * fs + i];
+        total[i] = t;
+        flow_in[i] = t + pe[(size_t)j * HW + p];
+        sq += t;                                            // torch.sum over joints (OTPose.py:325)
+    }
+    for (int j = 0; j < J; ++j) {
+        const size_t i = base + (size_t)j * HW;
+        squeezed[i] = sq;
+        inter[i] = total[i] * sq;                           // OTPose.py:330
+    }
+}
+
+// x1/x2 channel = joint*8 + feature (OTPose.py:356-359); positional table added here (ConvVideoTransformer.py:144/155)
+__global__ void glue_stack_kernel(const float* __restrict__ rough, const float* __restrict__ margin,
+                                  const float* __restrict__ squeezed, const float* __restrict__ inter,
+                                  const float* __restrict__ ctx, const float* __restrict__ pe1,
+                                  const float* __restrict__ pe2, float* __restrict__ x1, float* __restrict__ x2,
+                                  float* __restrict__ prev_b_out, int B, int J, int HW) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (p >= HW) return;
+    const size_t fs = (size_t)B * J * HW;
+    const size_t base = (size_t)b * J * HW + p;
+    const float m0 = margin[b * 4] + 1.f, m1 = margin[b * 4 + 1] + 1.f, m2 = margin[b * 4 + 2] + 1.f,
+                m3 = margin[b * 4 + 3] + 1.f;
+    const float sq = squeezed[base];
+    for (int j = 0; j < J; ++j) {
+        const size_t i = base + (size_t)j * HW;
+        const float cur = rough[i];
+        const float prev = rough[fs + i] / m0, next = rough[2 * fs + i] / m1;      // OTPose.py:339-342
+        const float pprev = rough[3 * fs + i] / m2, nnext = rough[4 * fs + i] / m3;
+        const float prev_b = cur + (prev + pprev), next_b = cur + (next + nnext);   // OTPose.py:345-349
+        const float close_b = cur + (next + prev), far_b = cur + (nnext + pprev);
+        const float in = inter[i], cx = ctx[i];
+        prev_b_out[i] = prev_b;
+        const size_t o = ((size_t)b * J * 8 + (size_t)j * 8) * HW + p;
+        const size_t pj = (size_t)j * 8 * HW + p;
+        const float f1[8] = {in, cx, prev_b, far_b, close_b, prev_b * sq, far_b * sq, close_b * sq};
+        const float f2[8] = {in, cx, next_b, close_b, far_b, next_b * sq, close_b * sq, far_b * sq};
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+            x1[o + (size_t)f * HW] = f1[f] + pe1[pj + (size_t)f * HW];
+            x2[o + (size_t)f * HW] = f2[f] + pe2[pj + (size_t)f * HW];
+        }
+    }
+}
+
+__global__ void axpby_kernel(const float* __restrict__ x, float* __restrict__ y, float alpha, float beta, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        y[i] = beta == 0.f ? alpha * x[i] : alpha * x[i] + beta * y[i];
+}
+
+}  // namespace
+
+extern "C" int otp_glue_total(const void* rough, void* total, void* squeezed, void* inter, void* flow_in,
+                              const void* pe, int B, int J, int HW, void* stream) {
+    if (!rough || !total || !squeezed || !inter || !flow_in || !pe || B <= 0 || J <= 0 || HW <= 0) return OTP_ERR_BAD_ARG;
+    hipLaunchKernelGGL(glue_total_kernel, dim3(otp_ceil_div(HW, 256), B), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const float*>(rough), static_cast<float*>(total), static_cast<float*>(squeezed),
+                       static_cast<float*>(inter), static_cast<float*>(flow_in), static_cast<const float*>(pe), B, J, HW);
+    return otp_launch_status();
+}
+
+extern "C" int otp_glue_stack(const void* rough, const void* margin, const void* squeezed, const void* inter,
+                              const void* ctx, const void* pe1, const void* pe2, void* x1, void* x2, void* prev_b,
+                              int B, int J, int HW, void* stream) {
+    if (!rough || !margin || !squeezed || !inter || !ctx || !pe1 || !pe2 || !x1 || !x2 || !prev_b) return OTP_ERR_BAD_ARG;
+    if (B <= 0 || J <= 0 || HW <= 0) return OTP_ERR_BAD_ARG;
+    auto f = [](const void* p) { return static_cast<const float*>(p); };
+    hipLaunchKernelGGL(glue_stack_kernel, dim3(otp_ceil_div(HW, 256), B), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       f(rough), f(margin), f(squeezed), f(inter), f(ctx), f(pe1), f(pe2), static_cast<float*>(x1),
+                       static_cast<float*>(x2), static_cast<float*>(prev_b), B, J, HW);
+    return otp_launch_status();
+}
+
+extern "C" int otp_axpby(const void* x, void* y, float alpha, float beta, size_t n, void* stream) {
+    if (!x || !y) return OTP_ERR_BAD_ARG;
+    if (n == 0) return OTP_OK;
+    size_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(axpby_kernel, dim3(blocks > 2048 ? 2048 : (unsigned)blocks), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), static_cast<const float*>(x), static_cast<float*>(y), alpha, beta, n);
+    return otp_launch_status();
+}
+
+extern "C" int otp_version(void) { return 1; }

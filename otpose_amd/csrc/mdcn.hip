@@ -1,0 +1,469 @@
+// Modulated deformable convolution for gfx950 - forward and backward, fused (no im2col buffer).
+//
+// Replaces modulated_deform_conv_cuda_forward / _backward of the reference
+// (thirdparty/deform_conv/src/deform_conv_cuda.cpp:474-549, 551-664 and the kernels at
+// src/deform_conv_cuda_kernel.cu:403-432, 434-503, 506-571, 574-631, 634-705).  Not a translation:
+//   * forward: one launch for the whole batch.  A workgroup owns a contiguous range of output pixels
+//     of one image and walks the input planes; each plane (H x W floats, 27.6 KB at 96x72) is staged
+//     into LDS once with a one-pixel ZERO BORDER, so the data-dependent bilinear gather hits LDS and
+//     the per-corner bounds tests of the reference become plain reads of the border.  The 18 offset +
+//     9 mask streams of a plane (93 % of the op's bytes) are read exactly once, coalesced, straight
+//     into registers; the (Cout x C*K) contraction and the bias are accumulated in registers, so the
+//     reference's `columns` round trip (C*K*P floats per image), its per-image GEMM launches, its
+//     output.zero_() and its separate bias add disappear.  alpha/beta fold the weighted sum over
+//     dilations of model/OTPose.py:387-392 into the store.
+//   * backward: a workgroup owns (image, deformable group, pixel chunk).  grad_x is accumulated in an
+//     LDS copy of the plane (ds_add_f32) instead of global float atomics; grad_offset / grad_mask are
+//     written once, coalesced; grad_weight / grad_bias partial sums live in registers and are reduced
+//     with wavefront shuffles, one atomic per (o,c,k) per workgroup.
+//
+// HBM roofline: algorithmic bytes per (image, call) = (C + 2*dg*K + dg*K + Cout) * H*W * 4
+// (13,630,464 B at C=Cout=dg=17, K=9, 96x72).
+#include "common.h"
+
+namespace {
+
+constexpr int PADL = 4;      // LDS column PADL-1 holds x = -1 (zero); data starts 16-byte aligned at PADL
+constexpr int FWD_THREADS = 256;
+
+struct Geom {
+    int N, C, H, W, Co, K, kh, kw, stride, pad, dil, Ho, Wo, P;
+    int dg, cpg_dg, cin_g, cout_g;
+    int LW, plane;           // LDS row pitch (floats) and plane size (H+2)*LW
+};
+
+struct Tap {                 // one bilinear sample of the staged plane
+    float v1, v2, v3, v4;    // corner values (zero border supplies out-of-image corners)
+    float lh, lw;            // fractional parts
+    int addr;                // LDS index of the (h_low, w_low) corner
+    bool inside;             // h in (-1,H) and w in (-1,W)  (kernel.cu:556)
+};
+
+__device__ __forceinline__ Tap fetch_tap(const float* __restrict__ plane, float h_im, float w_im,
+                                         const Geom& g) {
+    Tap t;
+    t.inside = (h_im > -1.f) && (w_im > -1.f) && (h_im < (float)g.H) && (w_im < (float)g.W);
+    // Inside samples are untouched by the clamps below (floor is already in [-1, H-1]); outside / NaN
+    // samples only need a finite fraction and an address inside the padded plane - their value is dropped.
+    float hc = fminf(fmaxf(h_im, -2.f), (float)(g.H + 1));
+    float wc = fminf(fmaxf(w_im, -2.f), (float)(g.W + 1));
+    float hf = floorf(hc), wf = floorf(wc);
+    t.lh = hc - hf;
+    t.lw = wc - wf;
+    int hl = min(max((int)hf, -1), g.H - 1);
+    int wl = min(max((int)wf, -1), g.W - 1);
+    t.addr = (hl + 1) * g.LW + wl + PADL;
+    t.v1 = plane[t.addr];
+    t.v2 = plane[t.addr + 1];
+    t.v3 = plane[t.addr + g.LW];
+    t.v4 = plane[t.addr + g.LW + 1];
+    return t;
+}
+
+__device__ __forceinline__ float bilinear(const Tap& t) {
+    float hh = 1.f - t.lh, hw = 1.f - t.lw;
+    return hh * hw * t.v1 + hh * t.lw * t.v2 + t.lh * hw * t.v3 + t.lh * t.lw * t.v4;
+}
+
+// zero the padded plane once; the interior is overwritten per input plane, the border stays zero
+__device__ __forceinline__ void zero_plane(float* plane, int n, int tid, int nthreads) {
+    for (int i = tid; i < n; i += nthreads) plane[i] = 0.f;
+}
+
+__device__ __forceinline__ void stage_plane(float* __restrict__ plane, const float* __restrict__ src,
+                                            const Geom& g, int tid, int nthreads) {
+    if ((g.W & 3) == 0) {
+        const int wq = g.W >> 2, nq = g.H * wq;
+        const float4* s4 = reinterpret_cast<const float4*>(src);
+        for (int i = tid; i < nq; i += nthreads) {
+            int y = i / wq, xq = i - y * wq;
+            float4 v = s4[i];
+            *reinterpret_cast<float4*>(&plane[(y + 1) * g.LW + PADL + 4 * xq]) = v;
+        }
+    } else {
+        const int n = g.H * g.W;
+        for (int i = tid; i < n; i += nthreads) {
+            int y = i / g.W, xx = i - y * g.W;
+            plane[(y + 1) * g.LW + PADL + xx] = src[i];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+// CO_T : output channels accumulated per workgroup pass (blockIdx.z walks Cout in chunks of CO_T)
+// VEC  : output pixels per thread (pixel p = tile*256*VEC + v*256 + tid: coalesced dword streams,
+//        conflict-free LDS gathers for smooth offset fields)
+// K9   : kernel is 3x3 (taps unrolled, offset/mask streams of a plane prefetched into registers)
+template <int CO_T, int VEC, bool K9>
+__global__ __launch_bounds__(FWD_THREADS, 3) void mdcn_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ off, const float* __restrict__ msk,
+    const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ out, Geom g,
+    float alpha, float beta) {
+    constexpr int COP = (CO_T + 3) & ~3;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* plane = smem;                    // g.plane floats
+    float* wl = smem + g.plane;             // [C*K][COP] transposed weights, zero where groups differ
+    const int tid = threadIdx.x;
+    const int n = blockIdx.y;
+    const int co0 = blockIdx.z * CO_T;
+    const int nco = min(CO_T, g.Co - co0);
+    const int K = K9 ? 9 : g.K;
+
+    zero_plane(plane, g.plane, tid, FWD_THREADS);
+    for (int i = tid; i < g.C * K * COP; i += FWD_THREADS) {
+        int ck = i / COP, o = i - ck * COP;
+        int c = ck / K, k = ck - c * K;
+        float v = 0.f;
+        if (o < nco) {
+            int oo = co0 + o;
+            int grp = oo / g.cout_g;
+            if (c / g.cin_g == grp) v = w[((size_t)oo * g.cin_g + (c - grp * g.cin_g)) * K + k];
+        }
+        wl[i] = v;
+    }
+
+    int p[VEC], hin[VEC], win[VEC];
+    bool valid[VEC];
+    float acc[VEC][CO_T];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        p[v] = (blockIdx.x * VEC + v) * FWD_THREADS + tid;
+        valid[v] = p[v] < g.P;
+        int pp = valid[v] ? p[v] : 0;
+        int ho = pp / g.Wo, wo = pp - ho * g.Wo;
+        hin[v] = ho * g.stride - g.pad;
+        win[v] = wo * g.stride - g.pad;
+        p[v] = pp;
+#pragma unroll
+        for (int o = 0; o < CO_T; ++o) acc[v][o] = 0.f;
+    }
+
+    const float* xn = x + (size_t)n * g.C * g.H * g.W;
+    // per-image buffer resources: stream address = SGPR plane offset + one VGPR pixel offset
+    const otp_rsrc roff = make_rsrc(off + (size_t)n * g.dg * 2 * K * g.P, (size_t)g.dg * 2 * K * g.P * 4);
+    const otp_rsrc rmsk = make_rsrc(msk + (size_t)n * g.dg * K * g.P, (size_t)g.dg * K * g.P * 4);
+    int pb[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) pb[v] = p[v] * 4;
+    const int P4 = g.P * 4;
+
+    if (K9) {
+        // One "step" = one kernel row (3 taps) of one input plane.  The 9*VEC stream loads of step s+1
+        // are issued before step s is computed, so ~18 dword streams per wave are always in flight.
+        float cur[9][VEC], nxt[9][VEC];
+        auto load_step = [&](float (&dst)[9][VEC], int step) {
+            const int c = step / 3, i = step - c * 3;
+            const int grp = c / g.cpg_dg;
+            const int so = (grp * 18 + 6 * i) * P4, sm = (grp * 9 + 3 * i) * P4;
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    dst[3 * j + 0][v] = bload(roff, pb[v], so + (2 * j) * P4);
+                    dst[3 * j + 1][v] = bload(roff, pb[v], so + (2 * j + 1) * P4);
+                    dst[3 * j + 2][v] = bload(rmsk, pb[v], sm + j * P4);
+                }
+        };
+        const int nsteps = g.C * 3;
+        load_step(cur, 0);
+#pragma unroll 1
+        for (int step = 0; step < nsteps; ++step) {
+            const int c = step / 3, i = step - c * 3;
+            if (step + 1 < nsteps) load_step(nxt, step + 1);
+            if (i == 0) {
+                __syncthreads();                               // every wave finished gathering plane c-1
+                stage_plane(plane, xn + (size_t)c * g.H * g.W, g, tid, FWD_THREADS);
+                __syncthreads();
+            }
+            const int di = i * g.dil;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float* wrow = wl + (c * 9 + i * 3 + j) * COP;
+                float wr[COP];
+#pragma unroll
+                for (int q = 0; q < COP / 4; ++q)
+                    *reinterpret_cast<float4*>(&wr[4 * q]) = *reinterpret_cast<const float4*>(&wrow[4 * q]);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    Tap t = fetch_tap(plane, (float)(hin[v] + di) + cur[3 * j][v],
+                                      (float)(win[v] + j * g.dil) + cur[3 * j + 1][v], g);
+                    float col = t.inside ? bilinear(t) * cur[3 * j + 2][v] : 0.f;
+#pragma unroll
+                    for (int o = 0; o < CO_T; ++o) acc[v][o] = fmaf(wr[o], col, acc[v][o]);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 9; ++q)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) cur[q][v] = nxt[q][v];
+        }
+    } else {
+        for (int c = 0; c < g.C; ++c) {
+            const int grp = c / g.cpg_dg;
+            const int so = grp * 2 * K * P4, sm = grp * K * P4;
+            __syncthreads();
+            stage_plane(plane, xn + (size_t)c * g.H * g.W, g, tid, FWD_THREADS);
+            __syncthreads();
+            for (int k = 0; k < K; ++k) {
+                const float* wrow = wl + (c * K + k) * COP;
+                const int di = (k / g.kw) * g.dil, dj = (k % g.kw) * g.dil;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    float o_h = bload(roff, pb[v], so + (2 * k) * P4);
+                    float o_w = bload(roff, pb[v], so + (2 * k + 1) * P4);
+                    float m = bload(rmsk, pb[v], sm + k * P4);
+                    Tap t = fetch_tap(plane, (float)(hin[v] + di) + o_h, (float)(win[v] + dj) + o_w, g);
+                    float col = t.inside ? bilinear(t) * m : 0.f;
+#pragma unroll
+                    for (int o = 0; o < CO_T; ++o) acc[v][o] = fmaf(wrow[o], col, acc[v][o]);
+                }
+            }
+        }
+    }
+
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        if (!valid[v]) continue;
+#pragma unroll
+        for (int o = 0; o < CO_T; ++o) {
+            if (o < nco) {
+                size_t idx = ((size_t)n * g.Co + co0 + o) * g.P + p[v];
+                float r = alpha * (acc[v][o] + (bias ? bias[co0 + o] : 0.f));
+                if (beta != 0.f) r = fmaf(beta, out[idx], r);
+                out[idx] = r;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------------
+// grid = (pixel chunks S, deformable groups, N), 256 threads.  LDS: x plane + grad_x plane (both with
+// the zero border) + [K][COP] weights of the current channel + reduction scratch.
+// CO_T must cover Cout (host restricts the fast path to Cout <= CO_T).
+constexpr int BWD_THREADS = 256;
+
+template <int CO_T>
+__global__ __launch_bounds__(BWD_THREADS, 2) void mdcn_bwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ off, const float* __restrict__ msk,
+    const float* __restrict__ w, const float* __restrict__ gout, float* __restrict__ gx,
+    float* __restrict__ goff, float* __restrict__ gmsk, float* __restrict__ gw, float* __restrict__ gb,
+    Geom g, int chunk_px, int atomic_gx) {
+    constexpr int COP = (CO_T + 3) & ~3;
+    constexpr int K = 9;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* plane = smem;                       // x plane
+    float* gplane = smem + g.plane;            // grad_x accumulation plane
+    float* wl = gplane + g.plane;              // [K][COP] weights W[o][c][k] of channel c
+    float* red = wl + K * COP;                 // [4 waves][CO_T] reduction scratch
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = blockIdx.y, n = blockIdx.z;
+    const int p_begin = blockIdx.x * chunk_px;
+    const int p_end = min(g.P, p_begin + chunk_px);
+
+    zero_plane(plane, g.plane, tid, BWD_THREADS);
+    const float* xn = x + (size_t)n * g.C * g.H * g.W;
+    const int P4 = g.P * 4;
+    const otp_rsrc rog = make_rsrc(off + ((size_t)n * g.dg + grp) * 2 * K * g.P, (size_t)2 * K * P4);
+    const otp_rsrc rmg = make_rsrc(msk + ((size_t)n * g.dg + grp) * K * g.P, (size_t)K * P4);
+    const otp_rsrc rgog = make_rsrc(goff + ((size_t)n * g.dg + grp) * 2 * K * g.P, (size_t)2 * K * P4);
+    const otp_rsrc rgmg = make_rsrc(gmsk + ((size_t)n * g.dg + grp) * K * g.P, (size_t)K * P4);
+    const otp_rsrc rgon = make_rsrc(gout + (size_t)n * g.Co * g.P, (size_t)g.Co * P4);
+
+    for (int cl = 0; cl < g.cpg_dg; ++cl) {
+        const int c = grp * g.cpg_dg + cl;
+        const int wgrp = c / g.cin_g;          // conv group of this input channel
+        __syncthreads();
+        zero_plane(gplane, g.plane, tid, BWD_THREADS);
+        stage_plane(plane, xn + (size_t)c * g.H * g.W, g, tid, BWD_THREADS);
+        for (int i = tid; i < K * COP; i += BWD_THREADS) {
+            int k = i / COP, o = i - k * COP;
+            float v = 0.f;
+            if (o < g.Co && o / g.cout_g == wgrp) v = w[((size_t)o * g.cin_g + (c - wgrp * g.cin_g)) * K + k];
+            wl[i] = v;
+        }
+        __syncthreads();
+
+        float gbacc[CO_T];                     // sum_p gout[o,p] (reduced only by the channel-0 workgroups)
+#pragma unroll
+        for (int o = 0; o < CO_T; ++o) gbacc[o] = 0.f;
+#pragma unroll 1
+        for (int k = 0; k < K; ++k) {
+            float gwacc[CO_T];                 // sum_p gout[o,p] * col[c,k,p]
+            float wk[COP];
+#pragma unroll
+            for (int o = 0; o < CO_T; ++o) gwacc[o] = 0.f;
+#pragma unroll
+            for (int q = 0; q < COP / 4; ++q)
+                *reinterpret_cast<float4*>(&wk[4 * q]) = *reinterpret_cast<const float4*>(&wl[k * COP + 4 * q]);
+            const int di = (k / 3) * g.dil, dj = (k % 3) * g.dil;
+#pragma unroll 1
+            for (int p = p_begin + tid; p < p_end; p += BWD_THREADS) {
+                const float o_h = bload(rog, p * 4, (2 * k) * P4);
+                const float o_w = bload(rog, p * 4, (2 * k + 1) * P4);
+                const float m = bload(rmg, p * 4, k * P4);
+                float go[CO_T];
+#pragma unroll
+                for (int o = 0; o < CO_T; ++o) go[o] = bload(rgon, p * 4, o * P4);   // rows >= Cout read 0
+                float gcol = 0.f;              // (W^T gout)[c,k,p]   (cpp:602-605)
+#pragma unroll
+                for (int o = 0; o < CO_T; ++o) gcol = fmaf(wk[o], go[o], gcol);
+                if (k == 0) {
+#pragma unroll
+                    for (int o = 0; o < CO_T; ++o) gbacc[o] += go[o];
+                }
+                const int ho = p / g.Wo, wo = p - ho * g.Wo;
+                Tap t = fetch_tap(plane, (float)(ho * g.stride - g.pad + di) + o_h,
+                                  (float)(wo * g.stride - g.pad + dj) + o_w, g);
+                const float in = t.inside ? 1.f : 0.f;
+                const float hh = 1.f - t.lh, hw = 1.f - t.lw;
+                const float bil = bilinear(t);
+                // grad_mask, grad_offset (kernel.cu:634-705; the zero border supplies the dropped corners)
+                float gm = in * gcol * bil;
+                const float gc_m = in * gcol * m;
+                float d_h = gc_m * (hw * (t.v3 - t.v1) + t.lw * (t.v4 - t.v2));
+                float d_w = gc_m * (hh * (t.v2 - t.v1) + t.lh * (t.v4 - t.v3));
+                if (cl > 0) {                  // several channels share one offset group: accumulate
+                    gm += bload(rgmg, p * 4, k * P4);
+                    d_h += bload(rgog, p * 4, (2 * k) * P4);
+                    d_w += bload(rgog, p * 4, (2 * k + 1) * P4);
+                }
+                bstore(gm, rgmg, p * 4, k * P4);
+                bstore(d_h, rgog, p * 4, (2 * k) * P4);
+                bstore(d_w, rgog, p * 4, (2 * k + 1) * P4);
+                // grad_x: scatter to the four corners of the LDS plane (border cells are dropped later)
+                atomicAdd(&gplane[t.addr], gc_m * hh * hw);
+                atomicAdd(&gplane[t.addr + 1], gc_m * hh * t.lw);
+                atomicAdd(&gplane[t.addr + g.LW], gc_m * t.lh * hw);
+                atomicAdd(&gplane[t.addr + g.LW + 1], gc_m * t.lh * t.lw);
+                const float col = in * bil * m;
+#pragma unroll
+                for (int o = 0; o < CO_T; ++o) gwacc[o] = fmaf(go[o], col, gwacc[o]);
+            }
+            // grad_weight[:, c, k]: wave shuffle reduce, cross-wave through LDS, one atomic per output channel
+#pragma unroll
+            for (int o = 0; o < CO_T; ++o) {
+                float sred = wave_sum(gwacc[o]);
+                if (lane == 0) red[wave * CO_T + o] = sred;
+            }
+            __syncthreads();
+            if (tid < CO_T && tid < g.Co && tid / g.cout_g == wgrp) {
+                float sred = red[tid] + red[CO_T + tid] + red[2 * CO_T + tid] + red[3 * CO_T + tid];
+                atomicAdd(&gw[((size_t)tid * g.cin_g + (c - wgrp * g.cin_g)) * K + k], sred);
+            }
+            __syncthreads();
+        }
+        // ---- grad_x plane -> global ----------------------------------------------------------
+        float* gxc = gx + ((size_t)n * g.C + c) * g.H * g.W;
+        for (int i = tid; i < g.H * g.W; i += BWD_THREADS) {
+            int y = i / g.W, xx = i - y * g.W;
+            float v = gplane[(y + 1) * g.LW + PADL + xx];
+            if (atomic_gx) atomicAdd(&gxc[i], v); else gxc[i] = v;
+        }
+        // ---- grad_bias (channel-0 workgroups only) -------------------------------------------------
+        if (gb != nullptr && c == 0) {
+#pragma unroll
+            for (int o = 0; o < CO_T; ++o) {
+                float sred = wave_sum(gbacc[o]);
+                if (lane == 0) red[wave * CO_T + o] = sred;
+            }
+            __syncthreads();
+            if (tid < CO_T && tid < g.Co)
+                atomicAdd(&gb[tid], red[tid] + red[CO_T + tid] + red[2 * CO_T + tid] + red[3 * CO_T + tid]);
+        }
+    }
+}
+
+bool make_geom(Geom& g, int N, int C, int H, int W, int Co, int kh, int kw, int stride, int pad, int dil,
+               int groups, int dg) {
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || Co <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || pad < 0 ||
+        dil <= 0 || groups <= 0 || dg <= 0)
+        return false;
+    if (C % groups || Co % groups || C % dg) return false;
+    g.N = N; g.C = C; g.H = H; g.W = W; g.Co = Co; g.K = kh * kw; g.kh = kh; g.kw = kw;
+    g.stride = stride; g.pad = pad; g.dil = dil;
+    g.Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) / stride + 1;
+    g.Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) / stride + 1;
+    if (g.Ho <= 0 || g.Wo <= 0) return false;
+    g.P = g.Ho * g.Wo;
+    g.dg = dg; g.cpg_dg = C / dg; g.cin_g = C / groups; g.cout_g = Co / groups;
+    g.LW = (W + PADL + 1 + 3) & ~3;
+    g.plane = (H + 2) * g.LW;
+    return true;
+}
+
+template <int CO_T, int VEC, bool K9>
+int launch_fwd(const float* x, const float* off, const float* msk, const float* w, const float* bias,
+               float* out, const Geom& g, float alpha, float beta, hipStream_t st) {
+    constexpr int COP = (CO_T + 3) & ~3;
+    size_t lds = ((size_t)g.plane + (size_t)g.C * g.K * COP) * sizeof(float);
+    if (lds > OTP_LDS_LIMIT) return OTP_ERR_UNSUPPORTED;
+    auto kern = mdcn_fwd_kernel<CO_T, VEC, K9>;
+    OTP_ALLOW_BIG_LDS(kern, lds);
+    dim3 grid(otp_ceil_div(g.P, FWD_THREADS * VEC), g.N, otp_ceil_div(g.Co, CO_T));
+    hipLaunchKernelGGL(kern, grid, dim3(FWD_THREADS), lds, st, x, off, msk, w, bias, out, g, alpha, beta);
+    return otp_launch_status();
+}
+
+}  // namespace
+
+extern "C" int otp_mdcn_forward(const void* x, const void* offset, const void* mask, const void* weight,
+                                const void* bias, void* out, int N, int C, int H, int W, int Cout, int kh,
+                                int kw, int stride, int pad, int dil, int groups, int deformable_groups,
+                                float alpha, float beta, int dtype, void* stream) {
+    if (!x || !offset || !mask || !weight || !out) return OTP_ERR_BAD_ARG;
+    if (dtype != OTP_DTYPE_F32) return OTP_ERR_UNSUPPORTED;
+    Geom g;
+    if (!make_geom(g, N, C, H, W, Cout, kh, kw, stride, pad, dil, groups, deformable_groups)) return OTP_ERR_BAD_ARG;
+    auto st = static_cast<hipStream_t>(stream);
+    auto xf = static_cast<const float*>(x);
+    auto of = static_cast<const float*>(offset);
+    auto mf = static_cast<const float*>(mask);
+    auto wf = static_cast<const float*>(weight);
+    auto bf = static_cast<const float*>(bias);
+    auto outf = static_cast<float*>(out);
+    const bool k9 = (kh == 3 && kw == 3);
+    if (k9 && Cout == 17) return launch_fwd<17, 2, true>(xf, of, mf, wf, bf, outf, g, alpha, beta, st);
+    if (k9) return launch_fwd<16, 2, true>(xf, of, mf, wf, bf, outf, g, alpha, beta, st);
+    return launch_fwd<16, 1, false>(xf, of, mf, wf, bf, outf, g, alpha, beta, st);
+}
+
+extern "C" size_t otp_mdcn_backward_workspace(int, int, int, int, int, int, int) { return 0; }
+
+extern "C" int otp_mdcn_backward(const void* x, const void* offset, const void* mask, const void* weight,
+                                 const void* grad_out, void* grad_x, void* grad_offset, void* grad_mask,
+                                 void* grad_weight, void* grad_bias, void* /*workspace*/, size_t /*workspace_bytes*/,
+                                 int N, int C, int H, int W, int Cout, int kh, int kw, int stride, int pad,
+                                 int dil, int groups, int deformable_groups, int dtype, void* stream) {
+    if (!x || !offset || !mask || !weight || !grad_out || !grad_x || !grad_offset || !grad_mask || !grad_weight)
+        return OTP_ERR_BAD_ARG;
+    if (dtype != OTP_DTYPE_F32) return OTP_ERR_UNSUPPORTED;
+    Geom g;
+    if (!make_geom(g, N, C, H, W, Cout, kh, kw, stride, pad, dil, groups, deformable_groups)) return OTP_ERR_BAD_ARG;
+    if (kh != 3 || kw != 3 || Cout > 17) return OTP_ERR_UNSUPPORTED;   // OTPose uses 3x3, 17 -> 17
+    constexpr int CO_T = 17, COP = 20, K = 9;
+    size_t lds = ((size_t)2 * g.plane + K * COP + 4 * CO_T) * sizeof(float);
+    if (lds > OTP_LDS_LIMIT) return OTP_ERR_UNSUPPORTED;
+    auto st = static_cast<hipStream_t>(stream);
+    // pixel chunks: enough workgroups to fill 256 CUs a few times over
+    int wgs = N * deformable_groups;
+    int S = 1;
+    while (wgs * S < 1024 && g.P / (S * 2) >= 4 * BWD_THREADS) S *= 2;
+    int chunk = otp_ceil_div(otp_ceil_div(g.P, S), BWD_THREADS) * BWD_THREADS;
+    S = otp_ceil_div(g.P, chunk);
+    int atomic_gx = S > 1;
+    if (atomic_gx)
+        if (hipMemsetAsync(grad_x, 0, (size_t)N * C * H * W * sizeof(float), st) != hipSuccess) return OTP_ERR_LAUNCH;
+    auto kern = mdcn_bwd_kernel<CO_T>;
+    OTP_ALLOW_BIG_LDS(kern, lds);
+    hipLaunchKernelGGL(kern, dim3(S, deformable_groups, N), dim3(BWD_THREADS), lds, st,
+                       static_cast<const float*>(x), static_cast<const float*>(offset),
+                       static_cast<const float*>(mask), static_cast<const float*>(weight),
+                       static_cast<const float*>(grad_out), static_cast<float*>(grad_x),
+                       static_cast<float*>(grad_offset), static_cast<float*>(grad_mask),
+                       static_cast<float*>(grad_weight), static_cast<float*>(grad_bias), g, chunk, atomic_gx);
+    return otp_launch_status();
+}

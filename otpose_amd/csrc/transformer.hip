@@ -1,0 +1,373 @@
+// ConvTransformer kernels for gfx950: channel LayerNorm (+ MaxPool1d skip), fused 3x depthwise-conv +
+// LayerNorm, channel attention (hs x hs scores, contraction over T) on the f32 matrix cores, linear
+// up-sampling.  Reference: model/blocks.py:95-110 (LayerNorm), :234-238 (pool_skip), :400-453
+// (MaskedMHCA.forward), model/ConvVideoTransformer.py:108,163-184 (nn.Upsample linear).
+//
+// All tensors are (B, C, T) with T contiguous, so a thread owns one time step t and walks the C
+// channels: every global access of a wave is a coalesced 256-byte run along T.
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- channel LayerNorm ---------------------------------------------------------------------------
+// CREG > 0: the C <= CREG channel values of a time step are held in registers (one HBM read).
+template <int CREG>
+__global__ __launch_bounds__(256) void ln_channel_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ y,
+                                                          int C, int T, float eps) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const size_t base = (size_t)blockIdx.y * C * T + t;
+    const float inv_c = 1.f / (float)C;
+    if (CREG > 0) {
+        float v[CREG > 0 ? CREG : 1];
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < CREG; ++c) {
+            v[c] = c < C ? x[base + (size_t)c * T] : 0.f;
+            s += v[c];
+        }
+        const float mu = s * inv_c;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < CREG; ++c) {
+            v[c] -= mu;
+            q += c < C ? v[c] * v[c] : 0.f;
+        }
+        const float rs = 1.f / sqrtf(q * inv_c + eps);
+#pragma unroll
+        for (int c = 0; c < CREG; ++c)
+            if (c < C) y[base + (size_t)c * T] = v[c] * rs * gamma[c] + beta[c];
+    } else {
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s += x[base + (size_t)c * T];
+        const float mu = s * inv_c;
+        float q = 0.f;
+        for (int c = 0; c < C; ++c) {
+            float dlt = x[base + (size_t)c * T] - mu;
+            q += dlt * dlt;
+        }
+        const float rs = 1.f / sqrtf(q * inv_c + eps);
+        for (int c = 0; c < C; ++c) y[base + (size_t)c * T] = (x[base + (size_t)c * T] - mu) * rs * gamma[c] + beta[c];
+    }
+}
+
+// MaxPool1d(kernel 3, stride 2, padding 1): To = (T + 2 - 3) / 2 + 1
+__global__ void maxpool3s2_kernel(const float* __restrict__ x, float* __restrict__ y, int T, int To) {
+    const int to = blockIdx.x * blockDim.x + threadIdx.x;
+    if (to >= To) return;
+    const float* xr = x + (size_t)blockIdx.y * T;
+    const int t = 2 * to;
+    float m = xr[t];
+    if (t - 1 >= 0) m = fmaxf(m, xr[t - 1]);
+    if (t + 1 < T) m = fmaxf(m, xr[t + 1]);
+    y[(size_t)blockIdx.y * To + to] = m;
+}
+
+// ---- three depthwise convs (k=3, pad 1, stride s) each followed by a channel LayerNorm -------------
+__global__ __launch_bounds__(256) void dwconv_ln3_kernel(
+    const float* __restrict__ x, const float* __restrict__ dwq, const float* __restrict__ dwk,
+    const float* __restrict__ dwv, const float* __restrict__ gq, const float* __restrict__ bq,
+    const float* __restrict__ gk, const float* __restrict__ bk, const float* __restrict__ gv,
+    const float* __restrict__ bv, float* __restrict__ q, float* __restrict__ k, float* __restrict__ v,
+    int C, int T, int To, int stride, float eps) {
+    const int to = blockIdx.x * blockDim.x + threadIdx.x;
+    if (to >= To) return;
+    const float* xb = x + (size_t)blockIdx.y * C * T;
+    const size_t ob = (size_t)blockIdx.y * C * To + to;
+    const int t0 = to * stride - 1;
+    const bool l_ok = t0 >= 0, r_ok = t0 + 2 < T;
+    const float inv_c = 1.f / (float)C;
+    // pass 1: means
+    float sq = 0.f, sk = 0.f, sv = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float* xr = xb + (size_t)c * T + t0;
+        const float a = l_ok ? xr[0] : 0.f, b = xr[1], cc = r_ok ? xr[2] : 0.f;
+        sq += dwq[c * 3] * a + dwq[c * 3 + 1] * b + dwq[c * 3 + 2] * cc;
+        sk += dwk[c * 3] * a + dwk[c * 3 + 1] * b + dwk[c * 3 + 2] * cc;
+        sv += dwv[c * 3] * a + dwv[c * 3 + 1] * b + dwv[c * 3 + 2] * cc;
+    }
+    const float mq = sq * inv_c, mk = sk * inv_c, mv = sv * inv_c;
+    // pass 2: biased variances of the centred values (blocks.py:100-103)
+    float vq = 0.f, vk = 0.f, vv = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float* xr = xb + (size_t)c * T + t0;
+        const float a = l_ok ? xr[0] : 0.f, b = xr[1], cc = r_ok ? xr[2] : 0.f;
+        float d1 = dwq[c * 3] * a + dwq[c * 3 + 1] * b + dwq[c * 3 + 2] * cc - mq;
+        float d2 = dwk[c * 3] * a + dwk[c * 3 + 1] * b + dwk[c * 3 + 2] * cc - mk;
+        float d3 = dwv[c * 3] * a + dwv[c * 3 + 1] * b + dwv[c * 3 + 2] * cc - mv;
+        vq += d1 * d1; vk += d2 * d2; vv += d3 * d3;
+    }
+    const float rq = 1.f / sqrtf(vq * inv_c + eps), rk = 1.f / sqrtf(vk * inv_c + eps), rv = 1.f / sqrtf(vv * inv_c + eps);
+    // pass 3: write
+    for (int c = 0; c < C; ++c) {
+        const float* xr = xb + (size_t)c * T + t0;
+        const float a = l_ok ? xr[0] : 0.f, b = xr[1], cc = r_ok ? xr[2] : 0.f;
+        float d1 = dwq[c * 3] * a + dwq[c * 3 + 1] * b + dwq[c * 3 + 2] * cc - mq;
+        float d2 = dwk[c * 3] * a + dwk[c * 3 + 1] * b + dwk[c * 3 + 2] * cc - mk;
+        float d3 = dwv[c * 3] * a + dwv[c * 3 + 1] * b + dwv[c * 3 + 2] * cc - mv;
+        q[ob + (size_t)c * To] = d1 * rq * gq[c] + bq[c];
+        k[ob + (size_t)c * To] = d2 * rk * gk[c] + bk[c];
+        v[ob + (size_t)c * To] = d3 * rv * gv[c] + bv[c];
+    }
+}
+
+// ---- channel attention ---------------------------------------------------------------------------
+// Phase 1: partial scores.  grid (B*nh, NS); a workgroup (4 waves) owns a chunk of T, stages q and k
+// tiles [HSP][64] through LDS (coalesced rows) and accumulates the NB x NB 16x16 score tiles with
+// v_mfma_f32_16x16x4_f32 (A = q rows, B = k rows, K = time).  Wave w owns tiles w, w+4, ...
+constexpr int ATT_TC = 64;            // time steps per staged tile
+constexpr int ATT_TCP = ATT_TC + 2;   // LDS row pitch: (row*2 + k) mod 32 distinct inside each half wave
+
+template <int NB>                     // NB = HSP / 16 (5 for hs = 68, 2 for hs = 17)
+__global__ __launch_bounds__(256) void attn_scores_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                           float* __restrict__ slabs, int hs, int T, int chunk) {
+    constexpr int HSP = NB * 16, NT = NB * NB, TPW = (NT + 3) / 4;
+    __shared__ float ql[HSP * ATT_TCP];
+    __shared__ float kl[HSP * ATT_TCP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bh = blockIdx.x, s = blockIdx.y;
+    const float* qb = q + (size_t)bh * hs * T;
+    const float* kb = k + (size_t)bh * hs * T;
+    const int t_begin = s * chunk, t_end = min(T, t_begin + chunk);
+    f32x4 acc[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int r16 = lane & 15, kk = lane >> 4;
+    for (int t0 = t_begin; t0 < t_end; t0 += ATT_TC) {
+        __syncthreads();
+        for (int idx = tid; idx < HSP * ATT_TC; idx += 256) {
+            int row = idx / ATT_TC, tt = idx - row * ATT_TC;
+            int t = t0 + tt;
+            bool ok = row < hs && t < t_end;
+            ql[row * ATT_TCP + tt] = ok ? qb[(size_t)row * T + t] : 0.f;
+            kl[row * ATT_TCP + tt] = ok ? kb[(size_t)row * T + t] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int tile = wave + 4 * i;
+            if (tile < NT) {
+                const int ib = tile / NB, jb = tile - ib * NB;
+                const float* qa = ql + (ib * 16 + r16) * ATT_TCP + kk;
+                const float* ka = kl + (jb * 16 + r16) * ATT_TCP + kk;
+#pragma unroll
+                for (int ks = 0; ks < ATT_TC; ks += 4)
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[ks], ka[ks], acc[i], 0, 0, 0);
+            }
+        }
+    }
+    float* slab = slabs + ((size_t)bh * gridDim.y + s) * HSP * HSP;
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int tile = wave + 4 * i;
+        if (tile < NT) {
+            const int ib = tile / NB, jb = tile - ib * NB;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) slab[(ib * 16 + kk * 4 + r) * HSP + jb * 16 + r16] = acc[i][r];
+        }
+    }
+}
+
+// Phase 2: sum the slabs, scale, row softmax (one wave per row, shuffles for max / sum).
+// P (B*nh, HSP, HSP) with zero padding columns.
+__global__ __launch_bounds__(256) void attn_softmax_kernel(const float* __restrict__ slabs, float* __restrict__ P,
+                                                            int hs, int HSP, int NS, float scale) {
+    const int bh = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* sb = slabs + (size_t)bh * NS * HSP * HSP;
+    float* pb = P + (size_t)bh * HSP * HSP;
+    for (int row = wave; row < HSP; row += 4) {
+        float v[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int col = lane + 64 * h;
+            float a = 0.f;
+            if (row < hs && col < hs)
+                for (int s = 0; s < NS; ++s) a += sb[((size_t)s * HSP + row) * HSP + col];
+            v[h] = (row < hs && col < hs) ? a * scale : -INFINITY;
+        }
+        const float m = wave_max(fmaxf(v[0], v[1]));
+        float e0 = (row < hs && lane < hs) ? expf(v[0] - m) : 0.f;
+        float e1 = (row < hs && lane + 64 < hs) ? expf(v[1] - m) : 0.f;
+        const float den = wave_sum(e0 + e1);
+        if (lane < HSP) pb[row * HSP + lane] = row < hs ? e0 / den : 0.f;
+        if (lane + 64 < HSP) pb[row * HSP + lane + 64] = row < hs ? e1 / den : 0.f;
+    }
+}
+
+// Phase 3: O^T[t, i] = sum_j v[j, t] P[i, j], stored as out[bh][t][i] (i contiguous) - exactly the memory
+// image of `out.transpose(2,3).contiguous()` (blocks.py:447).  grid (B*nh, ceil(T / 256)); each wave owns
+// 64 time steps (4 row blocks) x all NB column blocks.  A = v^T from an LDS tile, B = P^T from LDS.
+constexpr int PV_TT = 256;            // time steps per workgroup
+template <int NB>
+__global__ __launch_bounds__(256) void attn_pv_kernel(const float* __restrict__ v, const float* __restrict__ P,
+                                                       float* __restrict__ out, int hs, int T) {
+    constexpr int HSP = NB * 16;
+    constexpr int PS = HSP + 2;       // P row pitch: (i*2 + k) distinct banks
+    constexpr int VS = PV_TT + 16;    // v row pitch == 16 (mod 32)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* pl = smem;                 // [HSP][PS]
+    float* vl = smem + HSP * PS;      // [HSP][VS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bh = blockIdx.x, t0 = blockIdx.y * PV_TT;
+    const float* vb = v + (size_t)bh * hs * T;
+    const float* pb = P + (size_t)bh * HSP * HSP;
+    for (int idx = tid; idx < HSP * HSP; idx += 256) {
+        int i = idx / HSP, j = idx - i * HSP;
+        pl[i * PS + j] = pb[idx];
+    }
+    for (int idx = tid; idx < HSP * PV_TT; idx += 256) {
+        int j = idx / PV_TT, tt = idx - j * PV_TT;
+        int t = t0 + tt;
+        vl[j * VS + tt] = (j < hs && t < T) ? vb[(size_t)j * T + t] : 0.f;
+    }
+    __syncthreads();
+    const int r16 = lane & 15, kk = lane >> 4;
+    f32x4 acc[4][NB];
+#pragma unroll
+    for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+        for (int ib = 0; ib < NB; ++ib) acc[tb][ib] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* va = vl + kk * VS + wave * 64 + r16;          // A[t][j]: lane (t = r16, k = kk)
+    const float* pa = pl + r16 * PS + kk;                      // B[j][i]: lane (k = kk, i = r16)
+    for (int j0 = 0; j0 < HSP; j0 += 4) {
+        float a[4], b[NB];
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb) a[tb] = va[j0 * VS + tb * 16];
+#pragma unroll
+        for (int ib = 0; ib < NB; ++ib) b[ib] = pa[ib * 16 * PS + j0];
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+            for (int ib = 0; ib < NB; ++ib)
+                acc[tb][ib] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tb], b[ib], acc[tb][ib], 0, 0, 0);
+    }
+    float* ob = out + (size_t)bh * T * hs;
+#pragma unroll
+    for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int t = t0 + wave * 64 + tb * 16 + kk * 4 + r;
+            if (t < T) {
+#pragma unroll
+                for (int ib = 0; ib < NB; ++ib) {
+                    const int i = ib * 16 + r16;
+                    if (i < hs) ob[(size_t)t * hs + i] = acc[tb][ib][r];
+                }
+            }
+        }
+}
+
+// ---- nn.Upsample(scale_factor = f, mode = 'linear', align_corners = False) on (B, C, T) ------------
+__global__ void upsample_linear_kernel(const float* __restrict__ x, float* __restrict__ out, int C, int T, int f,
+                                       int out_ctot, int out_coff) {
+    const int To = T * f;
+    const int to = blockIdx.x * blockDim.x + threadIdx.x;
+    if (to >= To) return;
+    const int c = blockIdx.y % C, b = blockIdx.y / C;
+    const float* xr = x + ((size_t)b * C + c) * T;
+    float r;
+    if (f == 1) {
+        r = xr[to];
+    } else {
+        float src = ((float)to + 0.5f) * (1.f / (float)f) - 0.5f;
+        src = src < 0.f ? 0.f : src;
+        int i0 = (int)src;
+        int i1 = i0 + (i0 < T - 1 ? 1 : 0);
+        float l1 = src - (float)i0, l0 = 1.f - l1;
+        r = l0 * xr[i0] + l1 * xr[i1];
+    }
+    out[((size_t)b * out_ctot + out_coff + c) * To + to] = r;
+}
+
+}  // namespace
+
+extern "C" int otp_ln_channel(const void* x, const void* gamma, const void* beta, void* y, void* pool, int B,
+                              int C, int T, float eps, void* stream) {
+    if (!x || !gamma || !beta || !y || B <= 0 || C <= 0 || T <= 0) return OTP_ERR_BAD_ARG;
+    auto st = static_cast<hipStream_t>(stream);
+    auto xf = static_cast<const float*>(x);
+    auto gf = static_cast<const float*>(gamma);
+    auto bf = static_cast<const float*>(beta);
+    auto yf = static_cast<float*>(y);
+    dim3 grid(otp_ceil_div(T, 256), B);
+    if (C <= 17) hipLaunchKernelGGL(ln_channel_kernel<17>, grid, dim3(256), 0, st, xf, gf, bf, yf, C, T, eps);
+    else if (C <= 136) hipLaunchKernelGGL(ln_channel_kernel<136>, grid, dim3(256), 0, st, xf, gf, bf, yf, C, T, eps);
+    else hipLaunchKernelGGL(ln_channel_kernel<0>, grid, dim3(256), 0, st, xf, gf, bf, yf, C, T, eps);
+    if (pool) {
+        int To = (T + 2 - 3) / 2 + 1;
+        hipLaunchKernelGGL(maxpool3s2_kernel, dim3(otp_ceil_div(To, 256), B * C), dim3(256), 0, st, xf,
+                           static_cast<float*>(pool), T, To);
+    }
+    return otp_launch_status();
+}
+
+extern "C" int otp_dwconv_ln3(const void* x, const void* dwq, const void* dwk, const void* dwv, const void* gq,
+                              const void* bq, const void* gk, const void* bk, const void* gv, const void* bv,
+                              void* q, void* k, void* v, int B, int C, int T, int stride, float eps, void* stream) {
+    if (!x || !dwq || !dwk || !dwv || !gq || !bq || !gk || !bk || !gv || !bv || !q || !k || !v) return OTP_ERR_BAD_ARG;
+    if (B <= 0 || C <= 0 || T <= 0 || stride <= 0) return OTP_ERR_BAD_ARG;
+    const int To = (T + 2 - 3) / stride + 1;
+    auto f = [](const void* p) { return static_cast<const float*>(p); };
+    hipLaunchKernelGGL(dwconv_ln3_kernel, dim3(otp_ceil_div(To, 256), B), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       f(x), f(dwq), f(dwk), f(dwv), f(gq), f(bq), f(gk), f(bk), f(gv), f(bv), static_cast<float*>(q),
+                       static_cast<float*>(k), static_cast<float*>(v), C, T, To, stride, eps);
+    return otp_launch_status();
+}
+
+namespace {
+int attn_splits(int BH, int T) {
+    int ns = 1;
+    while (BH * ns < 768 && T / (ns * 2) >= 2 * ATT_TC) ns *= 2;
+    return ns;
+}
+}  // namespace
+
+extern "C" size_t otp_chan_attn_workspace(int B, int C, int T, int n_head) {
+    if (B <= 0 || C <= 0 || T <= 0 || n_head <= 0 || C % n_head) return 0;
+    const int hs = C / n_head, HSP = (hs + 15) & ~15;
+    const size_t BH = (size_t)B * n_head;
+    return (BH * attn_splits((int)BH, T) + BH) * HSP * HSP * sizeof(float);
+}
+
+extern "C" int otp_chan_attn(const void* q, const void* k, const void* v, void* out, void* workspace,
+                             size_t workspace_bytes, int B, int C, int T, int n_head, float scale, void* stream) {
+    if (!q || !k || !v || !out || !workspace || B <= 0 || C <= 0 || T <= 0 || n_head <= 0) return OTP_ERR_BAD_ARG;
+    if (C % n_head) return OTP_ERR_BAD_ARG;
+    const int hs = C / n_head, HSP = (hs + 15) & ~15, NB = HSP / 16;
+    if (NB != 5 && NB != 2 && NB != 1) return OTP_ERR_UNSUPPORTED;      // hs in (64,80], (16,32], <=16
+    if (workspace_bytes < otp_chan_attn_workspace(B, C, T, n_head)) return OTP_ERR_WORKSPACE;
+    const int BH = B * n_head, NS = attn_splits(BH, T);
+    const int chunk = otp_ceil_div(otp_ceil_div(T, NS), ATT_TC) * ATT_TC;
+    auto st = static_cast<hipStream_t>(stream);
+    float* slabs = static_cast<float*>(workspace);
+    float* P = slabs + (size_t)BH * NS * HSP * HSP;
+    auto qf = static_cast<const float*>(q);
+    auto kf = static_cast<const float*>(k);
+    auto vf = static_cast<const float*>(v);
+    auto of = static_cast<float*>(out);
+    const size_t pv_lds = ((size_t)HSP * (HSP + 2) + (size_t)HSP * (PV_TT + 16)) * sizeof(float);
+    dim3 g1(BH, NS), g3(BH, otp_ceil_div(T, PV_TT));
+#define OTP_ATT(NB_)                                                                                           \
+    {                                                                                                          \
+        hipLaunchKernelGGL(attn_scores_kernel<NB_>, g1, dim3(256), 0, st, qf, kf, slabs, hs, T, chunk);        \
+        hipLaunchKernelGGL(attn_softmax_kernel, dim3(BH), dim3(256), 0, st, slabs, P, hs, HSP, NS, scale);     \
+        auto kern = attn_pv_kernel<NB_>;                                                                       \
+        OTP_ALLOW_BIG_LDS(kern, pv_lds);                                                                       \
+        hipLaunchKernelGGL(kern, g3, dim3(256), pv_lds, st, vf, P, of, hs, T);                                 \
+    }
+    if (NB == 5) OTP_ATT(5) else if (NB == 2) OTP_ATT(2) else OTP_ATT(1)
+#undef OTP_ATT
+    return otp_launch_status();
+}
+
+extern "C" int otp_upsample_linear(const void* x, void* out, int B, int C, int T, int f, int out_ctot, int out_coff,
+                                   void* stream) {
+    if (!x || !out || B <= 0 || C <= 0 || T <= 0 || f <= 0 || out_ctot < out_coff + C) return OTP_ERR_BAD_ARG;
+    hipLaunchKernelGGL(upsample_linear_kernel, dim3(otp_ceil_div(T * f, 256), B * C), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), static_cast<const float*>(x), static_cast<float*>(out), C, T,
+                       f, out_ctot, out_coff);
+    return otp_launch_status();
+}

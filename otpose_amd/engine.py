@@ -1,0 +1,379 @@
+"""Inference engine: the OTPose forward (reference model/OTPose.py:307-394) as a fixed list of HIP
+launches over pre-allocated HBM buffers, replayed as one hipGraph.
+
+Built once per (model, batch size): BatchNorm (eval statistics) and conv biases are folded into the
+per-channel scale/shift epilogue of ``otp_conv2d``, weights are re-laid-out for the kernels
+(``otp_conv2d_pack_weight``), every activation gets a static buffer (288 GB of HBM: nothing is
+recycled inside a forward, so the whole launch sequence is capturable), channel concatenations and
+splits become channel-offset views, residual adds / ReLU / GELU / nearest-upsample-accumulate /
+residual-scale live in conv epilogues, and the 5-dilation weighted sum is folded into the DCN store.
+
+Data layout: everything NCHW float32, frames of a clip stacked on the batch axis in the reference's
+order [cur | prev | next | pprev | nnext] x B (OTPose.py:317) without materialising the re-layout
+(``frame_split`` addressing in the stem conv).
+"""
+from __future__ import annotations
+
+import os
+import warnings
+from typing import Callable, List
+
+import torch
+
+from . import hip, ops
+from .ops import ACT_GELU, ACT_NONE, ACT_RELU, View
+
+BN_EPS = 1e-5
+
+
+class InferenceEngine:
+    def __init__(self, model, batch: int, device, use_graph: bool | None = None):
+        device = torch.device(device)
+        if device.type != "cuda" or not torch.cuda.is_available():
+            raise RuntimeError("otpose_amd.OTPose runs on an MI355X through libotpose_hip.so; "
+                               f"got device '{device}' (there is no CPU or PyTorch-op fallback)")
+        self.lib = hip.lib()
+        self.dev = device
+        self.B = batch
+        self.model = model
+        cfg = model.cfg
+        self.J = model.num_joints
+        self.W_img, self.H_img = cfg.MODEL.IMAGE_SIZE
+        self.h, self.w = model.pe_h, model.pe_w
+        self.ops: List[Callable] = []
+        self._keep = []                       # parameter-derived tensors that must outlive the ops
+        self._stream = None
+        if use_graph is None:
+            use_graph = os.environ.get("OTPOSE_HIP_GRAPH", "1") != "0"
+        self.use_graph = use_graph
+        self.graph = None
+        self.param_version = self._param_version()
+        with torch.no_grad():
+            self._build()
+
+    # ---------------------------------------------------------------------------------------------
+    def matches(self, x) -> bool:
+        return (x.shape[0] == self.B and x.device == self.dev and tuple(x.shape[2:]) == (self.H_img, self.W_img)
+                and self._param_version() == self.param_version)
+
+    def _param_version(self):
+        return sum(p._version for p in self.model.parameters())
+
+    def new(self, *shape):
+        return torch.empty(shape, dtype=torch.float32, device=self.dev)
+
+    def dev_param(self, t):
+        t = t.detach().to(self.dev, torch.float32).contiguous()
+        self._keep.append(t)
+        return t
+
+    # ---- op emitters ----------------------------------------------------------------------------
+    def conv(self, inp: View, weight, out: View, stride=1, pad=0, dil=1, bn=None, bias=None, act=ACT_NONE,
+             res: View = None, in2: View = None, res_up=1, frame_split=0, cin=None, scale=None, shift=None):
+        """Emit act(scale*conv(inp (+in2)) + shift (+res)) with BN / bias folded into scale / shift."""
+        w = self.dev_param(weight)
+        if w.dim() == 3:
+            w = w.unsqueeze(-1)
+        cout, _, kh, kw = w.shape
+        wp = ops.pack_conv_weight(w)
+        self._keep.append(wp)
+        if bn is not None:
+            g, b = self.dev_param(bn.weight), self.dev_param(bn.bias)
+            mu, var = self.dev_param(bn.running_mean), self.dev_param(bn.running_var)
+            sc = g / torch.sqrt(var + bn.eps)
+            sh = b - mu * sc
+            if bias is not None:
+                sh = sh + self.dev_param(bias) * sc
+        else:
+            sc = self.dev_param(scale) if scale is not None else None
+            sh = self.dev_param(bias) if bias is not None else None
+            if shift is not None:
+                sh = self.dev_param(shift)
+        if sc is not None:
+            sc = sc.contiguous()
+            self._keep.append(sc)
+        if sh is not None:
+            sh = sh.contiguous()
+            self._keep.append(sh)
+        d = ops.conv_desc(inp, out, cout, kh, kw, stride, pad, dil, act, in2, res, res_up, frame_split, cin)
+        self._keep.append(d)
+        L = self.lib
+        args = (hip.ptr(inp.t), hip.ptr(in2.t if in2 is not None else None), hip.ptr(wp), hip.ptr(sc), hip.ptr(sh),
+                hip.ptr(res.t if res is not None else None), hip.ptr(out.t), d)
+
+        def run():
+            hip.check(L.otp_conv2d(*args, self._stream), "otp_conv2d")
+        self.ops.append(run)
+        return out
+
+    def conv_bn(self, inp: View, conv_mod, bn_mod, act=ACT_NONE, res=None, out=None, res_up=1, **kw):
+        n, _, h, w = inp.t.shape
+        if kw.get("frame_split"):
+            n = n * (inp.ctot // kw["cin"])
+        k, s, p, dl = conv_mod.kernel_size[0], conv_mod.stride[0], conv_mod.padding[0], conv_mod.dilation[0]
+        ho = (h + 2 * p - (dl * (k - 1) + 1)) // s + 1
+        wo = (w + 2 * p - (dl * (k - 1) + 1)) // s + 1
+        if out is None:
+            f = max(res_up, 1)
+            out = View(self.new(n, conv_mod.out_channels, ho * f, wo * f))
+        return self.conv(inp, conv_mod.weight, out, s, p, dl, bn=bn_mod, bias=conv_mod.bias, act=act, res=res,
+                         res_up=res_up, **kw)
+
+    def call(self, fn, name, *args):
+        def run():
+            hip.check(fn(*args, self._stream), name)
+        self.ops.append(run)
+
+    # ---- HRNet (reference model/HRNet.py:116-152) -------------------------------------------------
+    def basic_block(self, blk, x: View) -> View:
+        y = self.conv_bn(x, blk.conv1, blk.bn1, ACT_RELU)
+        res = x
+        if blk.downsample is not None:
+            res = self.conv_bn(x, blk.downsample[0], blk.downsample[1])
+        return self.conv_bn(y, blk.conv2, blk.bn2, ACT_RELU, res=res)
+
+    def bottleneck(self, blk, x: View) -> View:
+        y = self.conv_bn(x, blk.conv1, blk.bn1, ACT_RELU)
+        y = self.conv_bn(y, blk.conv2, blk.bn2, ACT_RELU)
+        res = x
+        if blk.downsample is not None:
+            res = self.conv_bn(x, blk.downsample[0], blk.downsample[1])
+        return self.conv_bn(y, blk.conv3, blk.bn3, ACT_RELU, res=res)
+
+    def hr_module(self, mod, xs: List[View]) -> List[View]:
+        n = mod.num_branches
+        xs = list(xs)
+        for i in range(n):
+            for blk in mod.branches[i]:
+                xs[i] = self.basic_block(blk, xs[i])
+        if n == 1:
+            return xs
+        outs = []
+        for i in range(len(mod.fuse_layers)):
+            # y_i = sum_j f_ij(x_j), then ReLU (HRNet.py:487-494).  The identity term rides on the first
+            # emitted conv as its residual; later terms accumulate in place; the last one applies the ReLU.
+            terms = [j for j in range(n) if j != i]
+            y = None
+            for idx, j in enumerate(terms):
+                last = idx == len(terms) - 1
+                act = ACT_RELU if last else ACT_NONE
+                res = xs[i] if y is None else y
+                fl = mod.fuse_layers[i][j]
+                if j > i:
+                    f = 2 ** (j - i)
+                    tgt = y if y is not None else View(self.new(*xs[i].t.shape))
+                    y = self.conv_bn(xs[j], fl[0], fl[1], act, res=res, out=tgt, res_up=f)
+                else:
+                    t = xs[j]
+                    for k in range(len(fl) - 1):
+                        t = self.conv_bn(t, fl[k][0], fl[k][1], ACT_RELU)
+                    tgt = y if y is not None else View(self.new(*xs[i].t.shape))
+                    y = self.conv_bn(t, fl[-1][0], fl[-1][1], act, res=res, out=tgt)
+            outs.append(y)
+        return outs
+
+    def hrnet(self, net, x_in: View) -> View:
+        x = self.conv_bn(x_in, net.conv1, net.bn1, ACT_RELU, frame_split=self.B, cin=3)
+        x = self.conv_bn(x, net.conv2, net.bn2, ACT_RELU)
+        for blk in net.layer1:
+            x = self.bottleneck(blk, x)
+        ys = [x]
+        for s in (2, 3, 4):
+            trans = getattr(net, f"transition{s - 1}")
+            xs = []
+            for i, tr in enumerate(trans):
+                if tr is None:
+                    xs.append(ys[i])
+                elif isinstance(tr[0], torch.nn.Conv2d):          # same-resolution width change
+                    xs.append(self.conv_bn(ys[i], tr[0], tr[1], ACT_RELU))
+                else:                                              # new branch from the last tensor
+                    z = ys[-1]
+                    for step in tr:
+                        z = self.conv_bn(z, step[0], step[1], ACT_RELU)
+                    xs.append(z)
+            ys = xs
+            for mod in getattr(net, f"stage{s}"):
+                ys = self.hr_module(mod, ys)
+        fl = net.final_layer
+        rough = View(self.new(5 * self.B, self.J, self.h, self.w))
+        return self.conv(ys[0], fl.weight, rough, 1, fl.padding[0], 1, bias=fl.bias)
+
+    # ---- ConvTransformer (reference model/ConvVideoTransformer.py:123-184, model/blocks.py:264-280,400-453) ----
+    def v3(self, t3):
+        """(B, C, T) tensor as a 4-D view for the conv kernel."""
+        b, c, t = t3.shape
+        return View(t3.view(b, c, 1, t))
+
+    def tblock(self, blk, x, stride):
+        B, C, T = x.shape
+        To = T if stride == 1 else (T + 2 - 3) // 2 + 1
+        L = self.lib
+        a = blk.attn
+        ln1 = self.new(B, C, T)
+        skip = self.new(B, C, To) if stride > 1 else None
+        p = self.dev_param
+        self.call(L.otp_ln_channel, "otp_ln_channel", hip.ptr(x), hip.ptr(p(blk.ln1.weight)), hip.ptr(p(blk.ln1.bias)),
+                  hip.ptr(ln1), hip.ptr(skip), B, C, T, blk.ln1.eps)
+        qn, kn, vn = self.new(B, C, To), self.new(B, C, To), self.new(B, C, To)
+        self.call(L.otp_dwconv_ln3, "otp_dwconv_ln3", hip.ptr(ln1), hip.ptr(p(a.query_conv.weight)),
+                  hip.ptr(p(a.key_conv.weight)), hip.ptr(p(a.value_conv.weight)),
+                  hip.ptr(p(a.query_norm.weight)), hip.ptr(p(a.query_norm.bias)),
+                  hip.ptr(p(a.key_norm.weight)), hip.ptr(p(a.key_norm.bias)),
+                  hip.ptr(p(a.value_norm.weight)), hip.ptr(p(a.value_norm.bias)),
+                  hip.ptr(qn), hip.ptr(kn), hip.ptr(vn), B, C, T, stride, a.query_norm.eps)
+        q, k, v = self.new(B, C, To), self.new(B, C, To), self.new(B, C, To)
+        self.conv(self.v3(qn), a.query.weight, self.v3(q), bias=a.query.bias)
+        self.conv(self.v3(kn), a.key.weight, self.v3(k), bias=a.key.bias)
+        self.conv(self.v3(vn), a.value.weight, self.v3(v), bias=a.value.bias)
+        att = self.new(B, C, To)
+        nbytes = L.otp_chan_attn_workspace(B, C, To, a.n_head)
+        ws = self.new(max(nbytes // 4, 1))
+        self.call(L.otp_chan_attn, "otp_chan_attn", hip.ptr(q), hip.ptr(k), hip.ptr(v), hip.ptr(att), hip.ptr(ws),
+                  nbytes, B, C, To, a.n_head, a.scale)
+        # y = pool_skip(x) + scale_attn * (proj(att) + b)   (eval: dropout / drop-path are identities)
+        sa = blk.drop_path_attn.scale.detach().reshape(-1)
+        y = self.new(B, C, To)
+        self.conv(self.v3(att), a.proj.weight, self.v3(y), scale=sa, shift=a.proj.bias.detach() * sa.to(a.proj.bias.device),
+                  res=self.v3(skip if stride > 1 else x))
+        ln2 = self.new(B, C, To)
+        self.call(L.otp_ln_channel, "otp_ln_channel", hip.ptr(y), hip.ptr(p(blk.ln2.weight)), hip.ptr(p(blk.ln2.bias)),
+                  hip.ptr(ln2), None, B, C, To, blk.ln2.eps)
+        hdn = self.new(B, 4 * C, To)
+        self.conv(self.v3(ln2), blk.mlp[0].weight, self.v3(hdn), bias=blk.mlp[0].bias, act=ACT_GELU)
+        sm = blk.drop_path_mlp.scale.detach().reshape(-1)
+        out = self.new(B, C, To)
+        self.conv(self.v3(hdn), blk.mlp[3].weight, self.v3(out), scale=sm,
+                  shift=blk.mlp[3].bias.detach() * sm.to(blk.mlp[3].bias.device), res=self.v3(y))
+        return out
+
+    def conv_transformer(self, ct, x, stacked):
+        """x (B, C, T) already holds input + positional table; writes levels into stacked (B, L*C, T)."""
+        B, C, T = x.shape
+        L = self.lib
+        for blk in ct.stem:
+            x = self.tblock(blk, x, 1)
+        self.call(L.otp_upsample_linear, "otp_upsample_linear", hip.ptr(x), hip.ptr(stacked), B, C, T, 1,
+                  stacked.shape[1], 0)
+        for i, blk in enumerate(ct.branch):
+            x = self.tblock(blk, x, 2)
+            f = 2 ** (i + 1)
+            if x.shape[2] * f != T:
+                raise RuntimeError("heat-map size must make every pyramid level divide evenly (T % 4 == 0)")
+            self.call(L.otp_upsample_linear, "otp_upsample_linear", hip.ptr(x), hip.ptr(stacked), B, C, x.shape[2], f,
+                      stacked.shape[1], (i + 1) * C)
+
+    # ---- RSB heads (reference model/RSB.py:77-103) --------------------------------------------------
+    def rsb_block(self, blk, x: View) -> View:
+        n, _, h, w = x.t.shape
+        bc = blk.branch_ch
+        cbr = lambda m, inp, out, act, in2=None, res=None: self.conv(   # noqa: E731
+            inp, m.conv.weight, out, 1, m.conv.padding[0], 1, bn=m.bn, bias=m.conv.bias, act=act, in2=in2, res=res)
+        t = self.new(n, 4 * bc, h, w)
+        cat = self.new(n, 4 * bc, h, w)
+        cbr(blk.conv_bn_relu1, x, View(t), ACT_RELU)
+        s = [View(t, i * bc, bc) for i in range(4)]
+        tmp = lambda: View(self.new(n, bc, h, w))                       # noqa: E731
+        o11 = cbr(blk.conv_bn_relu2_1_1, s[0], View(cat, 0, bc), ACT_RELU)
+        o21 = cbr(blk.conv_bn_relu2_2_1, s[1], tmp(), ACT_RELU, in2=o11)
+        o22 = cbr(blk.conv_bn_relu2_2_2, o21, View(cat, bc, bc), ACT_RELU)
+        o31 = cbr(blk.conv_bn_relu2_3_1, s[2], tmp(), ACT_RELU, in2=o21)
+        o32 = cbr(blk.conv_bn_relu2_3_2, o31, tmp(), ACT_RELU, in2=o22)
+        o33 = cbr(blk.conv_bn_relu2_3_3, o32, View(cat, 2 * bc, bc), ACT_RELU)
+        o41 = cbr(blk.conv_bn_relu2_4_1, s[3], tmp(), ACT_RELU, in2=o31)
+        o42 = cbr(blk.conv_bn_relu2_4_2, o41, tmp(), ACT_RELU, in2=o32)
+        o43 = cbr(blk.conv_bn_relu2_4_3, o42, tmp(), ACT_RELU, in2=o33)
+        cbr(blk.conv_bn_relu2_4_4, o43, View(cat, 3 * bc, bc), ACT_RELU)
+        res = x
+        if blk.downsample is not None:
+            res = cbr(blk.downsample, x, View(self.new(n, blk.conv_bn_relu3.conv.out_channels, h, w)), ACT_NONE)
+        out = View(self.new(n, blk.conv_bn_relu3.conv.out_channels, h, w))
+        return cbr(blk.conv_bn_relu3, View(cat), out, ACT_RELU, res=res)
+
+    def rsb_chain(self, chain, x: View) -> View:
+        for blk in chain.layers:
+            x = self.rsb_block(blk, x)
+        return x
+
+    # ---- whole forward ------------------------------------------------------------------------------
+    def _build(self):
+        m, B, J, h, w = self.model, self.B, self.J, self.h, self.w
+        L, T = self.lib, self.h * self.w
+        self.inp = self.new(B, 15, self.H_img, self.W_img)
+        self.margin = self.new(B, 4)
+        rough = self.hrnet(m.rough_pose_estimation_net, View(self.inp)).t
+
+        total, squeezed, inter = self.new(B, J, h, w), self.new(B, J, h, w), self.new(B, J, h, w)
+        flow_in = self.new(B, J, T)
+        pe_f = self.dev_param(m.flow_encoder.pos_embd[0, :, :T])
+        self.call(L.otp_glue_total, "otp_glue_total", hip.ptr(rough), hip.ptr(total), hip.ptr(squeezed), hip.ptr(inter),
+                  hip.ptr(flow_in), hip.ptr(pe_f), B, J, T)
+        ctx = self.new(B, J, T)
+        self.conv_transformer(m.flow_encoder, flow_in, ctx)
+        D = 8 * J
+        x1, x2, prev_b = self.new(B, D, T), self.new(B, D, T), self.new(B, J, h, w)
+        pe1 = self.dev_param(m.temporal_encoder1.pos_embd[0, :, :T])
+        pe2 = self.dev_param(m.temporal_encoder2.pos_embd[0, :, :T])
+        self.call(L.otp_glue_stack, "otp_glue_stack", hip.ptr(rough), hip.ptr(self.margin), hip.ptr(squeezed),
+                  hip.ptr(inter), hip.ptr(ctx), hip.ptr(pe1), hip.ptr(pe2), hip.ptr(x1), hip.ptr(x2), hip.ptr(prev_b),
+                  B, J, T)
+        levels = m.scale_arch[-1] + 1
+        s1, s2 = self.new(B, levels * D, T), self.new(B, levels * D, T)
+        self.conv_transformer(m.temporal_encoder1, x1, s1)
+        self.conv_transformer(m.temporal_encoder2, x2, s2)
+        # final 1x1 layers write straight into the channel-concatenated tensor (OTPose.py:372-378)
+        cat3 = self.new(B, 3 * J, h, w)
+        for i, (fl, s) in enumerate(((m.final_layer1, s1), (m.final_layer2, s2))):
+            self.conv(View(s.view(B, levels * D, h, w)), fl.weight, View(cat3, i * J, J), 1, fl.padding[0], 1, bias=fl.bias)
+        def_h = self.rsb_chain(m.def_fuse, View(total))
+        # def_heatmaps feeds the DCN as a dense (B, J, h, w) tensor and the concat as a channel slice: copy once
+        self.copy_into(def_h, View(cat3, 2 * J, J))
+        trans = self.rsb_chain(m.offset_mask_combine_conv, View(cat3))
+        out = self.new(B, J, h, w)
+        off_buf, msk_buf = self.new(B, J * 18, h, w), self.new(B, J * 9, h, w)
+        nd = len(m.deformable_conv_dilations)
+        for i, d in enumerate(m.deformable_conv_dilations):
+            self.conv(trans, m.offsets_list[i][0].weight, View(off_buf), 1, d, d)
+            self.conv(trans, m.masks_list[i][0].weight, View(msk_buf), 1, d, d)
+            dc = m.modulated_deform_conv_list[i].deform_conv
+            wt, bs = self.dev_param(dc.weight), self.dev_param(dc.bias)
+            self.call(L.otp_mdcn_forward, "otp_mdcn_forward", hip.ptr(def_h.t), hip.ptr(off_buf), hip.ptr(msk_buf),
+                      hip.ptr(wt), hip.ptr(bs), hip.ptr(out), B, J, h, w, J, 3, 3, 1, d, d, 1, J,
+                      1.0 / nd, 0.0 if i == 0 else 1.0, 0)
+        self.outputs = (out, rough, inter, prev_b, ctx.view(B, J, h, w), squeezed, total)
+        torch.cuda.synchronize(self.dev)
+
+    def copy_into(self, src: View, dst: View):
+        """dst channels <- src (per-sample strided copy through the upsample kernel with f = 1)."""
+        n, _, h, w = src.t.shape
+        assert src.coff == 0 and src.C == src.ctot
+        self.call(self.lib.otp_upsample_linear, "otp_upsample_linear", hip.ptr(src.t), hip.ptr(dst.t), n, src.C, h * w, 1,
+                  dst.ctot, dst.coff)
+
+    # ---------------------------------------------------------------------------------------------
+    def _launch_all(self):
+        self._stream = hip.stream_of(self.inp)
+        for op in self.ops:
+            op()
+
+    def run(self, x, margin):
+        if not x.is_cuda:
+            raise RuntimeError("OTPose.forward expects CUDA (HIP) tensors; there is no CPU path")
+        self.inp.copy_(x)
+        self.margin.copy_(margin.to(torch.float32))
+        if self.use_graph and self.graph is None:
+            self._launch_all()                      # warm-up (sets kernel attributes) before capture
+            torch.cuda.synchronize(self.dev)
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._launch_all()
+                self.graph = g
+            except Exception as e:                  # pragma: no cover - depends on the runtime
+                warnings.warn(f"hipGraph capture failed ({e}); launching eagerly")
+                self.use_graph = False
+                torch.cuda.synchronize(self.dev)
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._launch_all()
+        return self.outputs

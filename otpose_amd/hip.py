@@ -37,21 +37,19 @@ SIGNATURES = {
     "otp_mdcn_forward": (c_int, [c_void_p] * 6 + [c_int] * 12 + [c_float, c_float, c_int, c_void_p]),
     "otp_mdcn_backward_workspace": (c_size_t, [c_int] * 7),
     "otp_mdcn_backward": (c_int, [c_void_p] * 10 + [c_void_p, c_size_t] + [c_int] * 12 + [c_int, c_void_p]),
-    "otp_conv2d": (c_int, [c_void_p] * 7 + [ctypes.POINTER(ConvDesc), c_void_p]),
     "otp_conv2d_pack_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
-    "otp_frames_split": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
-    "otp_glue_total": (c_int, [c_void_p] + [c_void_p] * 3 + [c_int, c_int, c_int, c_void_p]),
-    "otp_glue_stack": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_void_p]),
-    "otp_add_pe": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
-    "otp_ln_channel": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_float, c_void_p]),
-    "otp_dwconv_ln3": (c_int, [c_void_p] * 11 + [c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
-    "otp_chan_attn_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
-    "otp_chan_attn": (c_int, [c_void_p] * 4 + [c_void_p, c_size_t] + [c_int, c_int, c_int, c_int, c_float, c_void_p]),
-    "otp_residual_scale": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "otp_upsample_linear": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "otp_conv2d": (c_int, [c_void_p] * 7 + [ctypes.POINTER(ConvDesc), c_void_p]),
+    "otp_conv2d_set_tile": (c_int, [c_int] * 4),
+    "otp_glue_total": (c_int, [c_void_p] * 6 + [c_int] * 3 + [c_void_p]),
+    "otp_glue_stack": (c_int, [c_void_p] * 10 + [c_int] * 3 + [c_void_p]),
+    "otp_ln_channel": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_float, c_void_p]),
+    "otp_dwconv_ln3": (c_int, [c_void_p] * 13 + [c_int] * 4 + [c_float, c_void_p]),
+    "otp_chan_attn_workspace": (c_size_t, [c_int] * 4),
+    "otp_chan_attn": (c_int, [c_void_p] * 4 + [c_void_p, c_size_t] + [c_int] * 4 + [c_float, c_void_p]),
+    "otp_upsample_linear": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "otp_axpby": (c_int, [c_void_p, c_void_p, c_float, c_float, c_size_t, c_void_p]),
-    "otp_loss_st_ohkw": (c_int, [c_void_p] * 5 + [c_void_p, c_size_t] + [c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "otp_loss_workspace": (c_size_t, [c_int, c_int]),
+    "otp_loss_st_ohkw": (c_int, [c_void_p] * 8 + [c_void_p, c_size_t] + [c_int] * 5 + [c_void_p]),
 }
 
 

@@ -140,3 +140,161 @@ class ModulatedDeformConvFunction(Function):
 
 
 modulated_deform_conv = ModulatedDeformConvFunction.apply
+
+
+# ------------------------------------------------------------------------------------------------
+# thin functional wrappers over the remaining C entry points (used by the engine and the tests)
+# ------------------------------------------------------------------------------------------------
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+
+
+class View:
+    """A channel slice [coff, coff + C) of a contiguous (N, ctot, H, W) float32 tensor."""
+
+    __slots__ = ("t", "coff", "C")
+
+    def __init__(self, t, coff=0, C=None):
+        assert t.is_contiguous() and t.dtype == torch.float32 and t.dim() == 4
+        self.t, self.coff, self.C = t, coff, (t.shape[1] - coff if C is None else C)
+        assert 0 <= coff and coff + self.C <= t.shape[1]
+
+    @property
+    def ctot(self):
+        return self.t.shape[1]
+
+
+def pack_conv_weight(weight):
+    """(Cout, Cin, kh, kw) -> packed [kh*kw][Cin][Cout16] device tensor for :func:`conv2d`."""
+    _require_gpu(weight)
+    _check_f32(weight)
+    w = weight.detach().contiguous()
+    if w.dim() == 3:                      # Conv1d weight (Cout, Cin, k) with k == 1
+        w = w.unsqueeze(-1)
+    cout, cin, kh, kw = w.shape
+    cout16 = (cout + 15) // 16 * 16
+    wp = torch.empty(kh * kw * cin * cout16, dtype=torch.float32, device=w.device)
+    hip.check(hip.lib().otp_conv2d_pack_weight(hip.ptr(w), hip.ptr(wp), cout, cin, kh, kw, hip.stream_of(w)),
+              "otp_conv2d_pack_weight")
+    return wp
+
+
+def conv_desc(inp: View, out: View, cout, kh, kw, stride, pad, dil, act=ACT_NONE, in2: View = None,
+              res: View = None, res_up=1, frame_split=0, cin=None):
+    d = hip.ConvDesc()
+    n_in, _, h, w = inp.t.shape
+    d.N = out.t.shape[0]
+    d.Cin = inp.C if cin is None else cin
+    d.H, d.W, d.Cout, d.kh, d.kw, d.stride, d.pad, d.dil = h, w, cout, kh, kw, stride, pad, dil
+    d.in_ctot, d.in_coff = inp.ctot, inp.coff
+    d.in2_ctot, d.in2_coff = (in2.ctot, in2.coff) if in2 is not None else (0, 0)
+    d.out_ctot, d.out_coff = out.ctot, out.coff
+    d.res_ctot, d.res_coff = (res.ctot, res.coff) if res is not None else (0, 0)
+    d.res_up, d.act, d.frame_split = res_up, act, frame_split
+    d.Ho = (h + 2 * pad - (dil * (kh - 1) + 1)) // stride + 1
+    d.Wo = (w + 2 * pad - (dil * (kw - 1) + 1)) // stride + 1
+    f = max(res_up, 1)
+    assert out.t.shape[2] == d.Ho * f and out.t.shape[3] == d.Wo * f, (tuple(out.t.shape), d.Ho, d.Wo, f)
+    assert out.C == cout
+    if res is not None:
+        assert res.t.shape[2:] == out.t.shape[2:] and res.C == cout
+    if in2 is not None:
+        assert in2.t.shape[2:] == inp.t.shape[2:] and in2.C == d.Cin
+    if frame_split:
+        assert d.N == n_in * (inp.ctot // d.Cin)
+    else:
+        assert d.N == n_in
+    return d
+
+
+def conv2d_launch(inp: View, wpacked, scale, shift, out: View, desc, in2: View = None, res: View = None, stream=None):
+    st = hip.lib().otp_conv2d(hip.ptr(inp.t), hip.ptr(in2.t if in2 is not None else None), hip.ptr(wpacked),
+                              hip.ptr(scale), hip.ptr(shift), hip.ptr(res.t if res is not None else None),
+                              hip.ptr(out.t), desc, stream if stream is not None else hip.stream_of(out.t))
+    hip.check(st, "otp_conv2d")
+
+
+def conv2d(x, weight, scale=None, shift=None, stride=1, pad=0, dil=1, act=ACT_NONE, res=None, in2=None, res_up=1):
+    """Convenience form: out = act(scale * conv(x (+ in2), weight) + shift (+ res)), fresh output."""
+    _require_gpu(x, weight)
+    w4 = weight if weight.dim() == 4 else weight.unsqueeze(-1)
+    cout, cin, kh, kw = w4.shape
+    h, w = x.shape[2:]
+    ho = (h + 2 * pad - (dil * (kh - 1) + 1)) // stride + 1
+    wo = (w + 2 * pad - (dil * (kw - 1) + 1)) // stride + 1
+    out = torch.empty((x.shape[0], cout, ho * max(res_up, 1), wo * max(res_up, 1)), dtype=torch.float32, device=x.device)
+    iv, ov = View(x.contiguous()), View(out)
+    rv = View(res.contiguous()) if res is not None else None
+    i2 = View(in2.contiguous()) if in2 is not None else None
+    d = conv_desc(iv, ov, cout, kh, kw, stride, pad, dil, act, i2, rv, res_up)
+    conv2d_launch(iv, pack_conv_weight(w4), scale, shift, ov, d, i2, rv)
+    return out
+
+
+def ln_channel(x, gamma, beta, eps=1e-5, pool=False):
+    _require_gpu(x)
+    b, c, t = x.shape
+    y = torch.empty_like(x)
+    p = torch.empty((b, c, (t + 2 - 3) // 2 + 1), dtype=x.dtype, device=x.device) if pool else None
+    hip.check(hip.lib().otp_ln_channel(hip.ptr(x), hip.ptr(gamma), hip.ptr(beta), hip.ptr(y), hip.ptr(p), b, c, t,
+                                       eps, hip.stream_of(x)), "otp_ln_channel")
+    return (y, p) if pool else y
+
+
+def dwconv_ln3(x, dw, gammas, betas, stride, eps=1e-5):
+    """dw / gammas / betas: triples for (query, key, value)."""
+    _require_gpu(x)
+    b, c, t = x.shape
+    to = (t + 2 - 3) // stride + 1
+    outs = [torch.empty((b, c, to), dtype=x.dtype, device=x.device) for _ in range(3)]
+    hip.check(hip.lib().otp_dwconv_ln3(
+        hip.ptr(x), hip.ptr(dw[0]), hip.ptr(dw[1]), hip.ptr(dw[2]), hip.ptr(gammas[0]), hip.ptr(betas[0]),
+        hip.ptr(gammas[1]), hip.ptr(betas[1]), hip.ptr(gammas[2]), hip.ptr(betas[2]), hip.ptr(outs[0]),
+        hip.ptr(outs[1]), hip.ptr(outs[2]), b, c, t, stride, eps, hip.stream_of(x)), "otp_dwconv_ln3")
+    return outs
+
+
+def chan_attn(q, k, v, n_head, scale):
+    _require_gpu(q, k, v)
+    b, c, t = q.shape
+    out = torch.empty_like(q)
+    L = hip.lib()
+    nbytes = L.otp_chan_attn_workspace(b, c, t, n_head)
+    ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=q.device)
+    hip.check(L.otp_chan_attn(hip.ptr(q), hip.ptr(k), hip.ptr(v), hip.ptr(out), hip.ptr(ws), nbytes, b, c, t, n_head,
+                              scale, hip.stream_of(q)), "otp_chan_attn")
+    return out
+
+
+def upsample_linear(x, f, out=None, out_coff=0):
+    _require_gpu(x)
+    b, c, t = x.shape
+    if out is None:
+        out = torch.empty((b, c, t * f), dtype=x.dtype, device=x.device)
+    hip.check(hip.lib().otp_upsample_linear(hip.ptr(x), hip.ptr(out), b, c, t, f, out.shape[1], out_coff,
+                                            hip.stream_of(x)), "otp_upsample_linear")
+    return out
+
+
+def st_ohkw_loss(s, t, g, w, topk=8, flags=None, with_grad=False):
+    """ST_OHKW_MSELoss forward (+ analytic gradients) on the GPU; returns dict like the reference
+    (model/loss.py:89-91) plus ``flags`` and, when requested, ``grad_s`` / ``grad_t``."""
+    _require_gpu(s, t, g, w)
+    b, j = s.shape[:2]
+    hw = s[0, 0].numel()
+    s, t, g = s.contiguous(), t.contiguous(), g.contiguous()
+    wv = w.reshape(b, j).contiguous().float()
+    L = hip.lib()
+    nbytes = L.otp_loss_workspace(b, j)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=s.device)
+    res = torch.empty(3, dtype=torch.float32, device=s.device)
+    given = flags is not None
+    fl = flags.to(torch.int32).contiguous() if given else torch.empty(j, dtype=torch.int32, device=s.device)
+    gs = torch.empty_like(s) if with_grad else None
+    gt = torch.empty_like(t) if with_grad else None
+    hip.check(L.otp_loss_st_ohkw(hip.ptr(s), hip.ptr(t), hip.ptr(g), hip.ptr(wv), hip.ptr(fl), hip.ptr(res),
+                                 hip.ptr(gs), hip.ptr(gt), hip.ptr(ws), nbytes, b, j, hw, topk, int(given),
+                                 hip.stream_of(s)), "otp_loss_st_ohkw")
+    out = {"ohkm_loss_s": res[0], "mse_loss_s": res[1], "final_loss": res[2], "flags": fl}
+    if with_grad:
+        out["grad_s"], out["grad_t"] = gs, gt
+    return out

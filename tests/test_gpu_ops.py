@@ -1,0 +1,176 @@
+"""Every other C entry point vs plain PyTorch CPU / the oracle on seeded inputs (float32)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import otpose_oracle as O
+from otpose_amd import hip, ops
+from otpose_amd import modules as M
+from otpose_amd import synthetic as S
+from tests.conftest import seeded
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, tol=2e-5):
+    a = a.detach().cpu()
+    assert a.shape == b.shape
+    err = float((a - b).abs().max())
+    assert err <= tol * max(1.0, float(b.abs().max())), f"max abs err {err} (ref max {float(b.abs().max())})"
+
+
+CONV_CASES = [  # N, Cin, H, W, Cout, k, stride, pad, dil
+    (2, 48, 24, 18, 48, 3, 1, 1, 1),
+    (2, 3, 32, 24, 64, 3, 2, 1, 1),       # stem: Cin not a multiple of 4
+    (2, 64, 16, 12, 256, 1, 1, 0, 1),     # 1x1 (flat mode)
+    (1, 32, 24, 18, 306, 3, 1, 15, 15),   # offset conv, dilation 15
+    (1, 32, 24, 18, 153, 3, 1, 6, 6),
+    (3, 20, 12, 9, 20, 3, 1, 1, 1),       # RSB channel counts
+    (2, 6, 12, 9, 6, 3, 1, 1, 1),
+    (2, 96, 12, 9, 192, 3, 2, 1, 1),      # fuse down-sampling
+    (1, 408, 12, 9, 17, 1, 1, 0, 1),      # final layers
+    (2, 136, 1, 108, 544, 1, 1, 0, 1),    # MLP GEMM on (B, C, T)
+    (1, 17, 1, 50, 17, 1, 1, 0, 1),
+    (2, 13, 7, 5, 13, 3, 1, 1, 1),        # odd everything
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_matches_torch(case):
+    n, cin, h, w, cout, k, stride, pad, dil = case
+    x = seeded((n, cin, h, w), 1)
+    wt = seeded((cout, cin, k, k), 2, 1.0 / math.sqrt(cin * k * k))
+    sc, sh = 1.0 + 0.1 * seeded((cout,), 3), seeded((cout,), 4)
+    ref = F.conv2d(x, wt, None, stride, pad, dil) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    out = ops.conv2d(x.cuda(), wt.cuda(), sc.cuda(), sh.cuda(), stride, pad, dil)
+    _close(out, ref)
+    res = seeded(ref.shape, 5)
+    out = ops.conv2d(x.cuda(), wt.cuda(), sc.cuda(), sh.cuda(), stride, pad, dil, act=ops.ACT_RELU, res=res.cuda())
+    _close(out, F.relu(ref + res))
+    out = ops.conv2d(x.cuda(), wt.cuda(), None, sh.cuda(), stride, pad, dil, act=ops.ACT_GELU)
+    _close(out, F.gelu(F.conv2d(x, wt, sh, stride, pad, dil)))
+
+
+@pytest.mark.parametrize("tile", [(1, 7, 1, 1), (2, 8, 2, 2), (3, 9, 1, 4), (4, 7, 4, 1), (4, 9, 1, 3), (3, 8, 2, 1)])
+def test_conv2d_every_tile_shape(tile):
+    """Results do not depend on the workgroup tiling (forced through the tuning hook)."""
+    L = hip.lib()
+    x = seeded((2, 40, 20, 14), 1)
+    wt = seeded((100, 40, 3, 3), 2, 0.05)
+    ref = F.conv2d(x, wt, None, 1, 1, 1)
+    try:
+        assert L.otp_conv2d_set_tile(*tile) == 0
+        _close(ops.conv2d(x.cuda(), wt.cuda(), None, None, 1, 1, 1), ref)
+        _close(ops.conv2d(x.cuda(), wt[:, :, 1:2, 1:2].contiguous().cuda(), None, None, 1, 0, 1),
+               F.conv2d(x, wt[:, :, 1:2, 1:2]))
+    finally:
+        L.otp_conv2d_set_tile(0, 0, 0, 0)
+
+
+def test_conv2d_views_in2_upsample_framesplit():
+    # channel-sliced input/output + pre-added second input (RSB staircase)
+    t = seeded((2, 24, 12, 9), 1)
+    o11 = seeded((2, 6, 12, 9), 2)
+    wt = seeded((6, 6, 3, 3), 3, 0.2)
+    cat = torch.zeros(2, 24, 12, 9)
+    ref = cat.clone()
+    ref[:, 12:18] = F.conv2d(t[:, 6:12] + o11, wt, None, 1, 1)
+    tg, og, cg = t.cuda(), o11.cuda(), cat.cuda()
+    iv, i2, ov = ops.View(tg, 6, 6), ops.View(og), ops.View(cg, 12, 6)
+    d = ops.conv_desc(iv, ov, 6, 3, 3, 1, 1, 1, in2=i2)
+    ops.conv2d_launch(iv, ops.pack_conv_weight(wt.cuda()), None, None, ov, d, in2=i2)
+    _close(cg, ref)
+    # nearest-upsample accumulate (HRNet fuse): out = relu(res + up4(conv1x1(x)))
+    x = seeded((2, 32, 6, 4), 4)
+    w1 = seeded((16, 32, 1, 1), 5, 0.2)
+    hi = seeded((2, 16, 24, 16), 6)
+    ref = F.relu(hi + F.interpolate(F.conv2d(x, w1), scale_factor=4, mode="nearest"))
+    out = ops.conv2d(x.cuda(), w1.cuda(), act=ops.ACT_RELU, res=hi.cuda(), res_up=4)
+    _close(out, ref)
+    # in-place accumulate (res aliases out)
+    acc = hi.cuda().clone()
+    av = ops.View(acc)
+    xv = ops.View(x.cuda())
+    d = ops.conv_desc(xv, av, 16, 1, 1, 1, 0, 1, res=av, res_up=4)
+    ops.conv2d_launch(xv, ops.pack_conv_weight(w1.cuda()), None, None, av, d, res=av)
+    _close(acc, hi + F.interpolate(F.conv2d(x, w1), scale_factor=4, mode="nearest"))
+    # frame split: (B, 15, H, W) read as (5B, 3, H, W), model/OTPose.py:317
+    clip = seeded((2, 15, 16, 12), 7)
+    w3 = seeded((8, 3, 3, 3), 8, 0.3)
+    ref = F.conv2d(torch.cat(clip.split(3, dim=1), 0), w3, None, 2, 1)
+    out = torch.empty(10, 8, 8, 6, device="cuda")
+    cv, ov = ops.View(clip.cuda()), ops.View(out)
+    d = ops.conv_desc(cv, ov, 8, 3, 3, 2, 1, 1, frame_split=2, cin=3)
+    ops.conv2d_launch(cv, ops.pack_conv_weight(w3.cuda()), None, None, ov, d)
+    _close(out, ref)
+
+
+@pytest.mark.parametrize("c,t", [(136, 300), (17, 77), (200, 65)])
+def test_ln_channel_and_pool(c, t):
+    x = seeded((2, c, t), 1, 2.0) + 0.5
+    g, b = 1 + 0.1 * seeded((c,), 2), seeded((c,), 3)
+    sd = {"n.weight": g.view(1, c, 1), "n.bias": b.view(1, c, 1)}
+    y, p = ops.ln_channel(x.cuda(), g.cuda(), b.cuda(), pool=True)
+    _close(y, O.channel_layernorm(sd, "n", x))
+    _close(p, F.max_pool1d(x, 3, 2, 1))
+
+
+@pytest.mark.parametrize("c,nh,stride,t", [(136, 2, 1, 108), (136, 2, 2, 108), (17, 1, 1, 108), (136, 2, 2, 27)])
+def test_mhca_pipeline_matches_golden(golden, c, nh, stride, t):
+    """dwconv+LN -> q/k/v GEMMs -> channel attention (scores, softmax, PV with the scrambled store) ->
+    proj, against the vectors the reference's MaskedMHCA produced (tests/golden/blocks.npz)."""
+    tag = f"mhca_{c}_s{stride}" + ("_odd" if t == 27 else "")
+    g = golden("blocks")
+    mod = M.MaskedMHCA(c, nh, stride, stride)
+    S.fill_synthetic_(mod, 11)
+    x = g[tag + "_x"].cuda()
+    dev = lambda p: p.detach().cuda().contiguous()          # noqa: E731
+    qn, kn, vn = ops.dwconv_ln3(
+        x, [dev(mod.query_conv.weight), dev(mod.key_conv.weight), dev(mod.value_conv.weight)],
+        [dev(mod.query_norm.weight), dev(mod.key_norm.weight), dev(mod.value_norm.weight)],
+        [dev(mod.query_norm.bias), dev(mod.key_norm.bias), dev(mod.value_norm.bias)], stride)
+    lin = lambda m_, z: ops.conv2d(z.unsqueeze(2), dev(m_.weight), None, dev(m_.bias)).squeeze(2)   # noqa: E731
+    q, k, v = lin(mod.query, qn), lin(mod.key, kn), lin(mod.value, vn)
+    att = ops.chan_attn(q, k, v, nh, mod.scale)
+    y = lin(mod.proj, att)
+    _close(y, g[tag + "_y"], 5e-5)
+
+
+def test_chan_attn_full_size_vs_oracle_slice():
+    """cfg2 size (B=2 of 16, C=136, T=6912): compare with the CPU oracle arithmetic."""
+    b, c, t, nh = 2, 136, 6912, 2
+    q, k, v = seeded((b, c, t), 1, 0.3), seeded((b, c, t), 2, 0.3), seeded((b, c, t), 3)
+    hs = c // nh
+    att = (q.view(b, nh, hs, t) * (1 / math.sqrt(hs))) @ k.view(b, nh, hs, t).transpose(-2, -1)
+    ref = (F.softmax(att, -1) @ v.view(b, nh, hs, t)).transpose(2, 3).contiguous().view(b, c, t)
+    out = ops.chan_attn(q.cuda(), k.cuda(), v.cuda(), nh, 1 / math.sqrt(hs))
+    _close(out, ref, 1e-4)
+
+
+@pytest.mark.parametrize("f", [1, 2, 4])
+def test_upsample_linear(f):
+    x = seeded((2, 5, 27), 1)
+    ref = x if f == 1 else F.interpolate(x, scale_factor=f, mode="linear", align_corners=False)
+    _close(ops.upsample_linear(x.cuda(), f), ref, 1e-6)
+    big = torch.zeros(2, 12, 27 * f, device="cuda")
+    ops.upsample_linear(x.cuda(), f, big, 4)
+    _close(big[:, 4:9], ref, 1e-6)
+    assert float(big[:, :4].abs().max()) == 0 and float(big[:, 9:].abs().max()) == 0
+
+
+def test_loss_matches_golden_and_oracle(golden):
+    g = golden("losses")
+    r = ops.st_ohkw_loss(g["s"].cuda(), g["t"].cuda(), g["g"].cuda(), g["w"].cuda(), with_grad=True)
+    for k in ("ohkm_loss_s", "mse_loss_s", "final_loss"):
+        _close(r[k].reshape(()), g["st_" + k].reshape(()), 1e-5)
+    _close(r["grad_s"], g["st_grad_s"], 1e-5)
+    _close(r["grad_t"], g["st_grad_t"], 1e-5)
+    flags = [int(g["g"][:, j].max() == 1) for j in range(17)]
+    assert r["flags"].cpu().tolist() == flags
+    # externally supplied flags (multi-GPU: MAX-reduced over ranks) change the branch taken
+    forced = torch.zeros(17, dtype=torch.int32)
+    r2 = ops.st_ohkw_loss(g["s"].cuda(), g["t"].cuda(), g["g"].cuda(), g["w"].cuda(), flags=forced.cuda())
+    ref2 = O.st_ohkw_mse_loss(g["s"], g["t"], g["g"], g["w"], global_flags=forced)
+    _close(r2["final_loss"].reshape(()), ref2["final_loss"].reshape(()), 1e-5)
