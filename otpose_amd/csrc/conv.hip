@@ -242,8 +242,8 @@ bool choose_plan(ConvPlan& P) {
                 for (int WP = 1; WM * WP <= 4; ++WP) {
                     if (g_force[0] && (MB != g_force[0] || PB != g_force[1] || WM != g_force[2] || WP != g_force[3]))
                         continue;
-                    if (WM > 1 && MB * (WM - 1) >= mblk) continue;     // whole waves of padding
-                    if (WP > 1 && PB * (WP - 1) >= G) continue;
+                    if (!g_force[0] && WM > 1 && MB * (WM - 1) >= mblk) continue;     // whole waves of padding
+                    if (!g_force[0] && WP > 1 && PB * (WP - 1) >= G) continue;
                     long mt = (mblk + MB * WM - 1) / (MB * WM), pt = (G + PB * WP - 1) / (PB * WP);
                     long nwg = (long)d.N * mt * pt;
                     double padded = (double)nwg * WM * WP * MB * PB;          // MFMA tiles issued per K-step

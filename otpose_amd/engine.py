@@ -42,6 +42,7 @@ class InferenceEngine:
         self.h, self.w = model.pe_h, model.pe_w
         self.ops: List[Callable] = []
         self._keep = []                       # parameter-derived tensors that must outlive the ops
+        self._bufs = []                       # every activation buffer (see new())
         self._stream = None
         if use_graph is None:
             use_graph = os.environ.get("OTPOSE_HIP_GRAPH", "1") != "0"
@@ -60,7 +61,11 @@ class InferenceEngine:
         return sum(p._version for p in self.model.parameters())
 
     def new(self, *shape):
-        return torch.empty(shape, dtype=torch.float32, device=self.dev)
+        """A static activation / scratch buffer.  The engine owns it for its whole life: the launch list holds
+        raw device pointers, and torch.cuda.graph() empties the allocator cache before capturing."""
+        t = torch.empty(shape, dtype=torch.float32, device=self.dev)
+        self._bufs.append(t)
+        return t
 
     def dev_param(self, t):
         t = t.detach().to(self.dev, torch.float32).contiguous()
