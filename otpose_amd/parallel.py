@@ -1,0 +1,211 @@
+"""One-process-per-GPU data parallelism over RCCL, replacing the reference's single-process
+``torch.nn.DataParallel`` (reference train.py:78-79, eval.py:112-113).
+
+The OTPose hot path shards by clip (batch axis 0): nothing in ``forward`` mixes samples except
+train-mode BatchNorm statistics, which the reference also keeps per replica (DataParallel has no
+SyncBN).  So:
+
+* inference: every rank runs its own clips, **no collective** on the data path
+  (:func:`shard_clips`; :func:`gather_clips` only when a caller wants rank 0 to hold all heat-maps,
+  as DataParallel's gather did);
+* training: identical seeded replicas, gradients summed with **bucketed all-reduce** and scaled by
+  1/world (:class:`GradBuckets`) - the reference instead broadcasts 272 MB of parameters and reduces
+  272 MB of gradients to GPU 0 every iteration;
+* loss parity: ``ST_OHKW_MSELoss`` tests ``max(gt_j) == 1`` over the *global* batch (model/loss.py:47 runs
+  on the gathered outputs), so the 17 per-joint flags are MAX-reduced (:func:`allreduce_joint_flags`)
+  before the branch is chosen; the mean reductions compose exactly across equal shards
+  (:func:`allreduce_mean_`).
+
+Bucket sizing for xGMI: the 8 GPUs are fully connected by point-to-point links (7 x ~153 GB/s per GPU).
+RCCL's ring/tree algorithms are per-link bound, so few large buckets beat many small ones: the
+default is 64 MiB (5 buckets for the 272 MB of fp32 HRNet-W48 gradients), each launched as soon as its
+last gradient is ready so the reduction of bucket k overlaps the backward of bucket k+1.
+
+``backend`` is ``"nccl"`` (= RCCL on ROCm) on GPUs and ``"gloo"`` on CPU (the multi-process tests).
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterable, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+DEFAULT_BUCKET_BYTES = 64 << 20
+
+
+def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, torch.device]:
+    """Initialise the default process group from the launcher's environment (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR / MASTER_PORT, as set by ``python -m torch.distributed.run``).
+    Returns (rank, world, device).  With WORLD_SIZE unset or 1 nothing is initialised."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    use_gpu = torch.cuda.is_available()
+    device = torch.device("cuda", local) if use_gpu else torch.device("cpu")
+    if use_gpu:
+        torch.cuda.set_device(device)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        be = backend or ("nccl" if use_gpu else "gloo")
+        kw = {"device_id": device} if be == "nccl" else {}
+        dist.init_process_group(be, rank=rank, world_size=world, **kw)
+    return rank, world, device
+
+
+def world_size() -> int:
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank() -> int:
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def shard_range(n_clips: int, rank_: int, world: int) -> Tuple[int, int]:
+    """Contiguous [begin, end) of the clips rank ``rank_`` owns; earlier ranks take the remainder."""
+    if world <= 0 or not 0 <= rank_ < world:
+        raise ValueError(f"bad rank/world {rank_}/{world}")
+    base, rem = divmod(n_clips, world)
+    begin = rank_ * base + min(rank_, rem)
+    return begin, begin + base + (1 if rank_ < rem else 0)
+
+
+def shard_clips(x: torch.Tensor, margin: torch.Tensor, rank_: Optional[int] = None, world: Optional[int] = None):
+    """This rank's slice of a global batch: ``x`` (B,15,H,W), ``margin`` (B,4) -> views, no copy."""
+    r = rank() if rank_ is None else rank_
+    w = world_size() if world is None else world
+    b, e = shard_range(x.shape[0], r, w)
+    return x[b:e], margin[b:e]
+
+
+def gather_clips(t: torch.Tensor, dst: int = 0) -> Optional[torch.Tensor]:
+    """Concatenate equal-sized per-rank heat-map tensors on ``dst`` (what DataParallel's gather to GPU 0
+    did, eval.py:113 / Common.py:357).  Returns None on the other ranks.  Not on the timed path."""
+    w = world_size()
+    if w == 1:
+        return t
+    parts = [torch.empty_like(t) for _ in range(w)]
+    dist.all_gather(parts, t.contiguous())
+    return torch.cat(parts, 0) if rank() == dst else None
+
+
+def allreduce_joint_flags(flags: torch.Tensor) -> torch.Tensor:
+    """MAX over ranks of the per-joint "ground truth has an exact-1 peak" flags (model/loss.py:47)."""
+    if world_size() > 1:
+        dist.all_reduce(flags, op=dist.ReduceOp.MAX)
+    return flags
+
+
+def allreduce_mean_(t: torch.Tensor) -> torch.Tensor:
+    """In-place mean over ranks (loss scalars: the reference computes them on the gathered batch)."""
+    w = world_size()
+    if w > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        t.div_(w)
+    return t
+
+
+def broadcast_buffers(module: torch.nn.Module, src: int = 0) -> None:
+    """Replica ``src``'s buffers (BatchNorm running statistics) to every rank - the reference keeps
+    replica 0's (DataParallel); done at checkpoint time, not per step."""
+    if world_size() == 1:
+        return
+    for b in module.buffers():
+        if b.is_floating_point():
+            dist.broadcast(b, src)
+
+
+class GradBuckets:
+    """Flat-bucket gradient all-reduce.
+
+    Parameters are packed, in reverse registration order (the order backward produces gradients), into
+    flat buffers of about ``bucket_bytes``.  ``reduce()`` copies each gradient into its bucket, launches
+    one asynchronous all-reduce(SUM) per bucket, then scales by 1/world and copies back.  With
+    ``hooks=True`` every parameter gets a post-accumulate hook and a bucket is launched the moment its
+    last gradient lands, overlapping RCCL traffic with the rest of backward; ``finish()`` then waits.
+    """
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = DEFAULT_BUCKET_BYTES,
+                 hooks: bool = False):
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        self.world = world_size()
+        self.buckets: List[List[torch.nn.Parameter]] = []
+        self.flat: List[torch.Tensor] = []
+        cur: List[torch.nn.Parameter] = []
+        cur_bytes = 0
+        for p in reversed(self.params):
+            nbytes = p.numel() * p.element_size()
+            if cur and (cur_bytes + nbytes > bucket_bytes or p.dtype != cur[0].dtype or p.device != cur[0].device):
+                self.buckets.append(cur)
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nbytes
+        if cur:
+            self.buckets.append(cur)
+        for bk in self.buckets:
+            self.flat.append(torch.zeros(sum(p.numel() for p in bk), dtype=bk[0].dtype, device=bk[0].device))
+        self._where = {id(p): (i, j) for i, bk in enumerate(self.buckets) for j, p in enumerate(bk)}
+        self._pending: List[int] = [len(bk) for bk in self.buckets]
+        self._work: List[Optional[object]] = [None] * len(self.buckets)
+        self._handles = []
+        if hooks and self.world > 1:
+            for p in self.params:
+                self._handles.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    # ---- bookkeeping --------------------------------------------------------------------------
+    def _offsets(self, i: int) -> Sequence[int]:
+        offs, o = [], 0
+        for p in self.buckets[i]:
+            offs.append(o)
+            o += p.numel()
+        return offs
+
+    def _pack_and_launch(self, i: int) -> None:
+        flat = self.flat[i]
+        for p, o in zip(self.buckets[i], self._offsets(i)):
+            g = p.grad
+            if g is None:
+                flat[o:o + p.numel()].zero_()
+            else:
+                flat[o:o + p.numel()].copy_(g.reshape(-1))
+        self._work[i] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+
+    def _on_grad(self, p: torch.nn.Parameter) -> None:
+        i, _ = self._where[id(p)]
+        self._pending[i] -= 1
+        if self._pending[i] == 0:
+            self._pack_and_launch(i)
+
+    # ---- public -------------------------------------------------------------------------------
+    def reduce(self) -> None:
+        """All-reduce every bucket now (no-hook mode) and write the averaged gradients back."""
+        if self.world == 1:
+            return
+        for i in range(len(self.buckets)):
+            if self._work[i] is None:
+                self._pack_and_launch(i)
+        self.finish()
+
+    def finish(self) -> None:
+        """Wait for the launched buckets, scale by 1/world, scatter back into ``p.grad``."""
+        if self.world == 1:
+            return
+        for i, bk in enumerate(self.buckets):
+            if self._work[i] is None:          # hook mode: a parameter of this bucket got no gradient
+                self._pack_and_launch(i)
+            self._work[i].wait()
+            flat = self.flat[i]
+            flat.div_(self.world)
+            for p, o in zip(bk, self._offsets(i)):
+                if p.grad is None:
+                    p.grad = flat[o:o + p.numel()].view_as(p).clone()
+                else:
+                    p.grad.copy_(flat[o:o + p.numel()].view_as(p))
+            self._work[i] = None
+            self._pending[i] = len(bk)
+
+    def remove_hooks(self) -> None:
+        for h in self._handles:
+            h.remove()
+        self._handles = []
