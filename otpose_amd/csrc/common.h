@@ -49,6 +49,12 @@ __device__ __forceinline__ otp_rsrc make_rsrc(const void* p, size_t bytes) {
 __device__ __forceinline__ float bload(otp_rsrc r, int voff_bytes, int soff_bytes) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff_bytes, soff_bytes, 0));
 }
+typedef float otp_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int otp_u32x4 __attribute__((ext_vector_type(4)));
+// 16-byte buffer load: offsets at or past the descriptor's size return zeros (hardware range check)
+__device__ __forceinline__ otp_f32x4 bload4(otp_rsrc r, int voff_bytes) {
+    return __builtin_bit_cast(otp_f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff_bytes, 0, 0));
+}
 __device__ __forceinline__ void bstore(float v, otp_rsrc r, int voff_bytes, int soff_bytes) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, voff_bytes, soff_bytes, 0);
 }

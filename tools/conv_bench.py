@@ -61,6 +61,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="")
+    ap.add_argument("--sweep", action="store_true", help="try every (MB,PB,WM,WP) tile through the tuning hook")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     g = torch.Generator().manual_seed(3)
@@ -81,6 +82,26 @@ def main():
         wp = ops.pack_conv_weight(wt)
         desc = ops.conv_desc(iv, ov, cout, k, k, s, pad, d, act=ops.ACT_RELU)
         ms = time_ms(lambda: ops.conv2d_launch(iv, wp, sc, sh, ov, desc), a.iters)
+        if a.sweep:
+            L = hip.lib()
+            res = []
+            for MB in (1, 2, 3, 4):
+                for PB in (7, 8, 9):
+                    if MB * PB > 28:
+                        continue
+                    for WM in (1, 2, 4):
+                        for WP in (1, 2, 3, 4):
+                            if WM * WP > 4:
+                                continue
+                            L.otp_conv2d_set_tile(MB, PB, WM, WP)
+                            try:
+                                t = time_ms(lambda: ops.conv2d_launch(iv, wp, sc, sh, ov, desc), 5)
+                                res.append((t, (MB, PB, WM, WP)))
+                            except RuntimeError:
+                                pass
+            L.otp_conv2d_set_tile(0, 0, 0, 0)
+            res.sort()
+            print("   sweep best:", ", ".join("%s %.4f" % (t[1], t[0]) for t in res[:5]), " | chosen %.4f" % ms)
         flop = 2.0 * cin * cout * k * k * ho * wo * n
         tf = flop / (ms * 1e-3) / 1e12
         tot_ms += ms * calls
