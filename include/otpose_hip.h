@@ -80,6 +80,10 @@ typedef struct otp_conv_desc {
 /* tuning / test hook: force the (M-blocks, pixel-blocks, waves-in-M, waves-in-pixels) tile of otp_conv2d;
  * all zeros restores the built-in choice.  Results never depend on it. */
 int otp_conv2d_set_tile(int MB, int PB, int WM, int WP);
+/* tuning hook: {MB, PB, WM, WP, CK, grid, lds bytes, tiles} of the last otp_conv2d call (zeros: generic kernel) */
+int otp_conv2d_last_plan(int* out8);
+/* the same for a descriptor, without launching anything (host arithmetic only; usable without a GPU) */
+int otp_conv2d_plan(const otp_conv_desc* desc, int* out8);
 int otp_conv2d_pack_weight(const void* weight, void* wpacked, int Cout, int Cin, int kh, int kw, void* stream);
 int otp_conv2d(const void* in, const void* in2, const void* wpacked, const void* scale, const void* shift,
                const void* res, void* out, const otp_conv_desc* desc, void* stream);

@@ -46,6 +46,10 @@ __device__ __forceinline__ otp_rsrc make_rsrc(const void* p, size_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0,
                                              (int)(bytes > 0xffffffffull ? 0xffffffffull : bytes), OTP_BUFFER_DWORD3);
 }
+// same with a 32-bit size known to fit (no 64-bit clamp arithmetic)
+__device__ __forceinline__ otp_rsrc make_rsrc32(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, OTP_BUFFER_DWORD3);
+}
 __device__ __forceinline__ float bload(otp_rsrc r, int voff_bytes, int soff_bytes) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff_bytes, soff_bytes, 0));
 }

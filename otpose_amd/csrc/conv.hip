@@ -38,154 +38,207 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + er
 __device__ __forceinline__ uint32_t fdiv(uint32_t i, uint32_t magic) { return magic ? __umulhi(i, magic) : i; }
 uint32_t magic_of(uint32_t d) { return d <= 1 ? 0u : (uint32_t)((1ull << 32) / d) + 1u; }
 
-constexpr int MAXJI = 8, MAXJW = 8;   // float4 prefetch registers per thread: input windows / weight slab of a chunk
+constexpr int MAXJI_LIN = 8, MAXJI_GEN = 10, MAXJW = 6;   // float4 prefetch registers per thread: input windows / weight slab of a chunk
 
 struct WinPlan {
     // problem
     int N, Cin, H, W, HW, Cout, Cout16, stride, pad, dil, Ho, Wo, HoWo;
     int in_ctot, in_coff, in2_ctot, in2_coff, out_ctot, out_coff, res_ctot, res_coff, res_up, act, frame_split;
     // tiling
-    int WP, Mtile, Ptile, tiles_per_img, nP, nM, nthreads;
-    int CK, flat, vec;
+    int WP, Mtile, Ptile, tiles_per_img, nP, nM, nthreads, ntiles;
+    int CK, flat, lin;
     int L4;                      // window length per channel in float4
     int G;                       // guard floats in front of every channel window (>= pad, multiple of 4)
     int CS, MS, M4;              // LDS channel stride, weight-row stride, Mtile / 4
-    int NI4, NW4;                // float4 items per chunk: input, weights
-    uint32_t magicL4, magicM4, magicCK, magicWo;
+    int CKW, JR, NJI;            // input staging: channels per wave, 64-float4 pieces per window, items per thread
+    int NW4, NJW;                // weight staging: float4 per chunk, items per thread
+    int ep_vec;                  // epilogue may use 16-byte vectors (no upsample, Ho*Wo % 4 == 0, aligned out / res)
+    uint32_t magicM4, magicCK, magicWo, magicTpi;
 };
 
-template <int MB, int PB, int KS>
+// One workgroup = (a contiguous range of Ptile output pixels of one image) x (Mtile output channels); workgroups are
+// persistent and walk the tile list with stride gridDim.x.  The kernel is one flat pipeline over (tile, chunk)
+// steps: while step s is multiplied out of LDS, the global loads of step s+1 - the next chunk of this tile or the
+// first chunk of the next tile - are in flight into registers.
+//
+// On gfx950 the f32 MFMA shares the SIMD's vector issue with ordinary VALU work (measured: every VALU
+// instruction of either resident wave adds its ~4 cycles to the MFMA time), so the multiply loop is written to
+// need almost none.  LIN = the LDS offset of a pixel is linear in its flattened index (1x1 "flat" mode and every
+// stride-1 same-size conv): the 16-pixel blocks of a lane are then a compile-time 64 bytes apart, so one address
+// register + immediate offsets serve all B fragments, the edge-column masks are precomputed all-ones / zero words
+// applied with one v_and, and the centre tap column needs no mask at all.
+template <int MB, int PB, int KS, bool LIN>
 __global__ __launch_bounds__(256, 2) void conv_win_kernel(
-    const float* __restrict__ in, const float* __restrict__ in2, const float* __restrict__ wp,
-    const float* __restrict__ scale, const float* __restrict__ shift, const float* res, float* out,
-    const WinPlan P) {
+    const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* res, float* out, const WinPlan P) {
     constexpr int KK = KS * KS;
+    constexpr int MAXJI = LIN ? MAXJI_LIN : MAXJI_GEN;   // strided windows are ~4x larger per output pixel
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* inp = smem;                          // [CK][CS]
     float* wts = smem + P.CK * P.CS;            // [KK*CK][MS]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i16 = lane & 15, kl = lane >> 4;
-
-    // ---- block id -> (pixel tile, M tile): the nM tiles of one window share an XCD ------------------
-    int pt, mt;
-    {
-        const int per = 8 * P.nM;
-        const int g = blockIdx.x / per, r = blockIdx.x - g * per;
-        mt = r >> 3;
-        pt = g * 8 + (r & 7);
-        if (pt >= P.nP) return;                 // uniform per workgroup
-    }
-    const int n = pt / P.tiles_per_img;
-    const int q0 = (pt - n * P.tiles_per_img) * P.Ptile;
     const int wm = wave / P.WP, wpi = wave - wm * P.WP;
-    const int m_wg = mt * P.Mtile;
     const int m_wave = wm * 16 * MB;
-    const int pix_wave = q0 + wpi * 16 * PB;
 
-    // image n of the (possibly frame-split) input
-    size_t in_base, in2_base = 0;
-    if (P.frame_split > 0) {
-        const int b = n % P.frame_split, f = n / P.frame_split;
-        in_base = ((size_t)b * P.in_ctot + P.in_coff + (size_t)f * P.Cin) * P.HW;
-    } else {
-        in_base = ((size_t)n * P.in_ctot + P.in_coff) * P.HW;
-    }
-    if (in2) in2_base = ((size_t)n * P.in2_ctot + P.in2_coff) * P.HW;
-
-    // ---- window of the flattened input plane this pixel range needs ------------------------------------
-    const int y_first = P.flat ? 0 : (int)fdiv((uint32_t)q0, P.magicWo);
-    const int f0 = P.flat ? q0 : (y_first * P.stride - P.pad) * P.W;   // first needed position (may be < 0)
-    const int f0a = f0 & ~3;                                          // 16-byte aligned window start
-    // LDS offset (floats, inside a channel slot) of tap (0,0) of each of this lane's pixels + column masks
-    int poff[PB];
-    uint32_t cm0 = 0, cm1 = 0, cm2 = 0;          // bit pb of cm<tj>: tap column tj of pixel pb is inside the image
-#pragma unroll
-    for (int pb = 0; pb < PB; ++pb) {
-        int q = pix_wave + pb * 16 + i16;
-        q = q < P.HoWo ? q : q0;                 // padding lanes compute a valid pixel and are never stored
-        if (P.flat) {
-            poff[pb] = P.G + (q - q0);
-            cm0 |= 1u << pb;
-        } else {
-            const int y = (int)fdiv((uint32_t)q, P.magicWo), x = q - y * P.Wo;
-            poff[pb] = P.G + (f0 - f0a) - P.pad + (y - y_first) * P.stride * P.W + x * P.stride;
-            const int xi = x * P.stride - P.pad;
-            if (xi >= 0 && xi < P.W) cm0 |= 1u << pb;
-            if (xi + P.dil >= 0 && xi + P.dil < P.W) cm1 |= 1u << pb;
-            if (xi + 2 * P.dil >= 0 && xi + 2 * P.dil < P.W) cm2 |= 1u << pb;
-        }
-    }
-
-    f32x4 acc[MB][PB];
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-        for (int pb = 0; pb < PB; ++pb) acc[mb][pb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    // ---- chunk staging: item i of a chunk is one float4 of the input windows or of the weight slab --------
-    // Buffer (SRSRC) loads: one 32-bit byte offset per item, out-of-range offsets (rows outside the image,
-    // channels past Cin, columns past Cout16) return 0 from the hardware range check - no branches, no
-    // 64-bit addresses.  The descriptors are rebuilt per chunk so that the range check is exact.
-    f32x4 pfi[MAXJI], pfw[MAXJW];
-    const float* in_img = in + in_base;
-    const int wts_off = P.CK * P.CS;
-    // item -> (byte offset in the chunk's tensor slice or -1, LDS float offset or -1); straight-line, no branches
-    auto item_in = [&](uint32_t i, int& voff, int& dst) {
-        const uint32_t c = fdiv(i, P.magicL4), r = i - c * P.L4;
-        const int f = f0a + 4 * (int)r;
-        const bool live = i < (uint32_t)P.NI4;
-        voff = (live && f >= 0 && f < P.HW) ? (int)(c * P.HW + f) * 4 : -1;
-        dst = live ? (int)(c * P.CS + 4 * r) + P.G : -1;
+    // ---- tile id -> (image, first pixel, M tile): the nM tiles of one window are 8 ids apart = same XCD ---------
+    struct TileId { int n, q0, m_wg; };
+    auto tile_ok = [&](int t) {
+        const int per = 8 * P.nM;
+        const int g = t / per, r = t - g * per;
+        return t < P.ntiles && g * 8 + (r & 7) < P.nP;
     };
-    auto item_w = [&](uint32_t w, int& voff, int& dst) {
+    auto decode = [&](int t) {
+        TileId T;
+        const int per = 8 * P.nM;
+        const int g = t / per, r = t - g * per;
+        const int pt = g * 8 + (r & 7);
+        T.n = (int)fdiv((uint32_t)pt, P.magicTpi);
+        T.q0 = (pt - T.n * P.tiles_per_img) * P.Ptile;
+        T.m_wg = (r >> 3) * P.Mtile;
+        return T;
+    };
+
+    // ---- chunk staging ---------------------------------------------------------------------------------------
+    // Input: wave w owns channels [w*CKW, (w+1)*CKW) of the chunk; item (jc, jr) is float4 number lane + 64*jr of that
+    // channel's window.  One buffer descriptor per channel (base = the channel plane, size = H*W*4 or 0 past Cin):
+    // the hardware range check zero-fills rows above / below the image and missing channels, so a load costs one
+    // v_add.  Weights: item w = tid + j*nthreads of the [KK*CK][M4] slab of this M tile; byte offset inside the
+    // (chunk, M tile) slice of the packed tensor and LDS offset are computed once per kernel.
+    f32x4 pfi[MAXJI], pfw[MAXJW];
+    int wvoff[MAXJW], wdst[MAXJW];
+#pragma unroll
+    for (int j = 0; j < MAXJW; ++j) {
+        const uint32_t w = tid + j * P.nthreads;
         const uint32_t row = fdiv(w, P.magicM4), m4 = w - row * P.M4;
         const uint32_t tap = fdiv(row, P.magicCK), c = row - tap * P.CK;
-        const int m = m_wg + 4 * (int)m4;
-        const bool live = w < (uint32_t)P.NW4;
-        voff = (live && m < P.Cout16) ? (int)((tap * P.Cin + c) * P.Cout16 + m) * 4 : -1;
-        dst = live ? wts_off + (int)(row * P.MS + 4 * m4) : -1;
-    };
-    auto load_items = [&](int c0) {
-        const otp_rsrc rin = make_rsrc(in_img + (size_t)c0 * P.HW, (size_t)(P.Cin - c0) * P.HW * 4);
-        const otp_rsrc rw = make_rsrc(wp + (size_t)c0 * P.Cout16, ((size_t)KK * P.Cin - c0) * P.Cout16 * 4);
-        uint32_t t0 = tid;
-        asm volatile("" : "+v"(t0));             // keep the (chunk-invariant) item arithmetic out of the MFMA loop's registers
+        const bool live = j < P.NJW && w < (uint32_t)P.NW4;
+        wvoff[j] = live ? (int)((tap * P.Cin + c) * P.Cout16 + 4 * m4) * 4 : -1;
+        wdst[j] = live ? (int)(P.CK * P.CS + row * P.MS + 4 * m4) : -1;
+    }
+    auto load_items = [&](int t, int c0) {
+        const TileId T = decode(t);
+        const float* img;
+        if (P.frame_split > 0) {
+            const int b = T.n % P.frame_split, f = T.n / P.frame_split;
+            img = in + ((size_t)b * P.in_ctot + P.in_coff + (size_t)f * P.Cin) * P.HW;
+        } else {
+            img = in + ((size_t)T.n * P.in_ctot + P.in_coff) * P.HW;
+        }
+        // first needed position of the flattened plane, rounded down to 16 bytes (may be negative)
+        const int y_first = P.flat ? 0 : (int)fdiv((uint32_t)T.q0, P.magicWo);
+        const int f0a = (P.flat ? T.q0 : (y_first * P.stride - P.pad) * P.W) & ~3;
+        const int vbase = (f0a + 4 * lane) * 4;
+        int jc = 0, jr = 0;
 #pragma unroll
         for (int j = 0; j < MAXJI; ++j) {
-            int voff, dst;
-            item_in(t0 + j * P.nthreads, voff, dst);
-            pfi[j] = bload4(rin, voff);
+            if (j < P.NJI) {
+                const int c = wave * P.CKW + jc, ch = c0 + c;
+                const bool live = c < P.CK && ch < P.Cin;
+                const otp_rsrc r = make_rsrc32(img + (size_t)(live ? ch : 0) * P.HW, live ? (unsigned)P.HW * 4u : 0u);
+                pfi[j] = bload4(r, vbase + jr * 1024);
+                if (++jr == P.JR) { jr = 0; ++jc; }
+            }
         }
+        // weight slice of (chunk, M tile): rows past Cin alias later rows (finite, multiplied by zero input) or fall
+        // off the end of the tensor (range check -> 0)
+        const otp_rsrc rw = make_rsrc32(wp + (size_t)c0 * P.Cout16 + T.m_wg,
+                                        ((unsigned)(KK * P.Cin - c0) * (unsigned)P.Cout16 - (unsigned)T.m_wg) * 4u);
 #pragma unroll
-        for (int j = 0; j < MAXJW; ++j) {
-            int voff, dst;
-            item_w(t0 + j * P.nthreads, voff, dst);
-            pfw[j] = bload4(rw, voff);
-        }
+        for (int j = 0; j < MAXJW; ++j)
+            if (j < P.NJW) pfw[j] = bload4(rw, wvoff[j]);
+        asm volatile("" ::: "memory");           // the loads are issued HERE (not sunk towards their use after the MFMAs)
     };
-    auto store_items = [&](int c0) {
-        uint32_t t1 = tid;
-        asm volatile("" : "+v"(t1));
-        if (in2) {                               // pre-added second input (RSB staircase): fetched here, unpipelined
-            const otp_rsrc rin2 = make_rsrc(in2 + in2_base + (size_t)c0 * P.HW, (size_t)(P.Cin - c0) * P.HW * 4);
+    auto store_items = [&]() {
+        int jc = 0, jr = 0;
 #pragma unroll
-            for (int j = 0; j < MAXJI; ++j) {
-                int voff, dst;
-                item_in(t1 + j * P.nthreads, voff, dst);
-                pfi[j] += bload4(rin2, voff);
+        for (int j = 0; j < MAXJI; ++j) {
+            if (j < P.NJI) {
+                const int c = wave * P.CKW + jc, r4 = lane + 64 * jr;
+                if (c < P.CK && r4 < P.L4) *reinterpret_cast<f32x4*>(inp + c * P.CS + P.G + 4 * r4) = pfi[j];
+                if (++jr == P.JR) { jr = 0; ++jc; }
             }
         }
 #pragma unroll
-        for (int j = 0; j < MAXJI; ++j) {
-            int voff, dst;
-            item_in(t1 + j * P.nthreads, voff, dst);
-            if (dst >= 0) *reinterpret_cast<f32x4*>(smem + dst) = pfi[j];
-        }
+        for (int j = 0; j < MAXJW; ++j)
+            if (j < P.NJW && wdst[j] >= 0) *reinterpret_cast<f32x4*>(smem + wdst[j]) = pfw[j];
+    };
+
+    // ---- lane geometry of the current tile ------------------------------------------------------------------------
+    // LIN: pl0 = LDS offset of tap (0,0) of pixel block 0 (block pb adds 16 floats); keepL / keepR = all-ones words
+    // unless the left / right tap column of the block's pixel falls off the image.  General: one offset per block
+    // and three bit masks (tap columns 0, 1, 2).
+    int pl0 = 0;
+    int keepL[PB], keepR[PB];
+    int poff[PB];
+    uint32_t cm0 = 0, cm1 = 0, cm2 = 0;
+
+    f32x4 acc[MB][PB];
+
+    // ---- epilogue: scale/shift (+res) (+act), optional nearest-upsample accumulate --------------------------
+    // The accumulators of one 16-row block go through a per-wave LDS tile [16][RS] (lane = pixel column, so a
+    // register is a 64-byte run; LDS turns it into rows), then leave as 16-byte vectors along the pixel axis in a
+    // short runtime loop: few instructions, few live registers, full-line stores.
+    constexpr int RS = 16 * PB + 4;              // row pitch: == 4 (mod 8) floats -> conflict-free transposing writes
+    auto epilogue = [&](const TileId& T) {
+        float* ep = smem + wave * (16 * RS);
+        const int pix_wave = T.q0 + wpi * 16 * PB;
+        const int f = P.res_up > 1 ? P.res_up : 1;
 #pragma unroll
-        for (int j = 0; j < MAXJW; ++j) {
-            int voff, dst;
-            item_w(t1 + j * P.nthreads, voff, dst);
-            if (dst >= 0) *reinterpret_cast<f32x4*>(smem + dst) = pfw[j];
+        for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ep[(kl * 4 + r) * RS + pb * 16 + i16] = acc[mb][pb][r];
+            const int co_base = T.m_wg + m_wave + mb * 16;
+            if (P.ep_vec) {
+#pragma unroll 1
+                for (int i = lane; i < 16 * 4 * PB; i += 64) {
+                    const int row = i / (4 * PB), c4 = i - row * (4 * PB);
+                    const int co = co_base + row, q = pix_wave + 4 * c4;
+                    if (co < P.Cout && q < P.HoWo) {
+                        f32x4 v = *reinterpret_cast<const f32x4*>(ep + row * RS + 4 * c4);
+                        const float sc = scale ? scale[co] : 1.f, sh = shift ? shift[co] : 0.f;
+                        v = v * sc + sh;
+                        if (res) v += *reinterpret_cast<const f32x4*>(
+                            res + ((size_t)T.n * P.res_ctot + P.res_coff + co) * P.HoWo + q);
+                        if (P.act == OTP_ACT_RELU) {
+                            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                        } else if (P.act == OTP_ACT_GELU) {
+                            v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
+                        }
+                        *reinterpret_cast<f32x4*>(out + ((size_t)T.n * P.out_ctot + P.out_coff + co) * P.HoWo + q) = v;
+                    }
+                }
+            } else {
+                const int HWo_hi = P.HoWo * f * f, Wo_hi = P.Wo * f;
+#pragma unroll 1
+                for (int i = lane; i < 16 * 16 * PB; i += 64) {
+                    const int row = i / (16 * PB), col = i - row * (16 * PB);
+                    const int co = co_base + row, q = pix_wave + col;
+                    if (co < P.Cout && q < P.HoWo) {
+                        const float sc = scale ? scale[co] : 1.f, sh = shift ? shift[co] : 0.f;
+                        const float v0 = fmaf(ep[row * RS + col], sc, sh);
+                        int qhi = q;
+                        if (f > 1) {
+                            const int y = q / P.Wo, x = q - y * P.Wo;
+                            qhi = y * f * Wo_hi + x * f;
+                        }
+                        const size_t ob = ((size_t)T.n * P.out_ctot + P.out_coff + co) * HWo_hi + qhi;
+                        const size_t rb = ((size_t)T.n * P.res_ctot + P.res_coff + co) * HWo_hi + qhi;
+                        for (int dy = 0; dy < f; ++dy)
+                            for (int dx = 0; dx < f; ++dx) {
+                                const int sub = dy * Wo_hi + dx;
+                                float v = v0;
+                                if (res) v += res[rb + sub];
+                                if (P.act == OTP_ACT_RELU) v = fmaxf(v, 0.f);
+                                else if (P.act == OTP_ACT_GELU) v = gelu_erf(v);
+                                out[ob + sub] = v;
+                            }
+                    }
+                }
+            }
         }
     };
 
@@ -193,92 +246,135 @@ __global__ __launch_bounds__(256, 2) void conv_win_kernel(
     const float* ibase = inp + kl * P.CS;
     const int dW = P.dil * P.W;
 
-    load_items(0);
-    store_items(0);
+    int tile = blockIdx.x, c0 = 0;
+    if (!tile_ok(tile)) return;                  // uniform per workgroup
+    load_items(tile, 0);
+    store_items();
     __syncthreads();
-    for (int c0 = 0; c0 < P.Cin; c0 += P.CK) {
-        const bool more = c0 + P.CK < P.Cin;
-        if (more) load_items(c0 + P.CK);        // in flight while this chunk is multiplied
-        // ---- MFMA over the chunk in LDS ------------------------------------------------------------
-#pragma unroll 1
-        for (int tap = 0; tap < KK; ++tap) {
-            const int ti = tap / KS, tj = tap - ti * KS;
-            const uint32_t cm = tj == 0 ? cm0 : (tj == 1 ? cm1 : cm2);
-            const float* wrow = wbase + tap * P.CK * P.MS;
-            const float* irow = ibase + (KS == 1 ? 0 : ti * dW + tj * P.dil);
-            auto step = [&](int kc) {
-                float a[MB], b[PB];
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb) a[mb] = wrow[kc * P.MS + mb * 16];
+    bool new_tile = true;
+    while (true) {
+        if (new_tile) {
+            // ---- per-tile lane geometry and fresh accumulators ------------------------------------------------------
+            const TileId T = decode(tile);
+            const int pix_wave = T.q0 + wpi * 16 * PB;
+            const int y_first = P.flat ? 0 : (int)fdiv((uint32_t)T.q0, P.magicWo);
+            const int f0 = P.flat ? T.q0 : (y_first * P.stride - P.pad) * P.W;
+            const int f0a = f0 & ~3;
+            if (LIN) {
+                // offset(q) = G + (f0 - f0a) - pad + (q - y_first * W)   (flat: G + q - q0)
+                pl0 = P.flat ? P.G + (pix_wave + i16 - T.q0)
+                             : P.G + (f0 - f0a) - P.pad + (pix_wave + i16 - y_first * P.W);
 #pragma unroll
                 for (int pb = 0; pb < PB; ++pb) {
-                    const float v = irow[kc * P.CS + poff[pb]];
-                    // all-ones / zero word from bit pb of the column mask: 0 for taps that cross the image edge
-                    const int keep = __builtin_amdgcn_sbfe(cm, pb, 1);
-                    b[pb] = __builtin_bit_cast(float, __builtin_bit_cast(int, v) & keep);
+                    if (KS == 1) {
+                        keepL[pb] = keepR[pb] = -1;
+                    } else {
+                        const int q = pix_wave + pb * 16 + i16;
+                        const int y = (int)fdiv((uint32_t)q, P.magicWo), x = q - y * P.Wo;
+                        keepL[pb] = (x - P.dil >= 0) ? -1 : 0;
+                        keepR[pb] = (x + P.dil < P.W) ? -1 : 0;
+                    }
                 }
+            } else {
+                uint32_t m0 = 0, m1 = 0, m2 = 0;
 #pragma unroll
-                for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                    for (int pb = 0; pb < PB; ++pb)
-                        acc[mb][pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb], b[pb], acc[mb][pb], 0, 0, 0);
-            };
-            int kc = 0;
-            for (; kc + 8 <= P.CK; kc += 8) {
-                step(kc);
-                step(kc + 4);
+                for (int pb = 0; pb < PB; ++pb) {
+                    int q = pix_wave + pb * 16 + i16;
+                    q = q < P.HoWo ? q : T.q0;   // padding lanes compute a valid pixel and are never stored
+                    const int y = (int)fdiv((uint32_t)q, P.magicWo), x = q - y * P.Wo;
+                    poff[pb] = P.G + (f0 - f0a) - P.pad + (y - y_first) * P.stride * P.W + x * P.stride;
+                    const int xi = x * P.stride - P.pad;
+                    m0 |= (xi >= 0 && xi < P.W) ? 1u << pb : 0u;
+                    m1 |= (xi + P.dil >= 0 && xi + P.dil < P.W) ? 1u << pb : 0u;
+                    m2 |= (xi + 2 * P.dil >= 0 && xi + 2 * P.dil < P.W) ? 1u << pb : 0u;
+                }
+                cm0 = m0; cm1 = m1; cm2 = m2;
             }
-            if (kc < P.CK) step(kc);
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int pb = 0; pb < PB; ++pb) acc[mb][pb] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        if (more) {
-            __syncthreads();                    // every wave finished reading this chunk
-            store_items(c0 + P.CK);
-            __syncthreads();
-        }
-    }
+        // ---- next step: next chunk of this tile, else first chunk of the next tile, else none ---------------------
+        const bool last_chunk = c0 + P.CK >= P.Cin;
+        const int tile_n = last_chunk ? tile + (int)gridDim.x : tile;
+        const int c0_n = last_chunk ? 0 : c0 + P.CK;
+        const bool have_next = !last_chunk || tile_ok(tile_n);
+        if (have_next) load_items(tile_n, c0_n);  // in flight while this chunk is multiplied
 
-    // ---- epilogue: scale/shift (+res) (+act), optional nearest-upsample accumulate -------------------
-    const int f = P.res_up > 1 ? P.res_up : 1;
-    const int HWo_hi = P.HoWo * f * f, Wo_hi = P.Wo * f;
-    int qhi[PB];                                 // index of the (dy=0, dx=0) target pixel on the output grid
-    bool qok[PB];
+        // ---- MFMA over the chunk in LDS --------------------------------------------------------------------
+        if (LIN) {
+            // (hand-pipelining the fragment reads one step ahead behind sched_barriers measured 5-10 % SLOWER than
+            // letting the compiler interleave reads, masks and MFMAs of one step: profiles/r01c_conv_notes.txt)
+            const int aS = 4 * P.MS, bS = 4 * P.CS;                  // one k-step = 4 channels
+            const float* ip0 = ibase + pl0;
+#pragma unroll 1
+            for (int ti = 0; ti < KS; ++ti) {
 #pragma unroll
-    for (int pb = 0; pb < PB; ++pb) {
-        const int q = pix_wave + pb * 16 + i16;
-        qok[pb] = q < P.HoWo && q < q0 + P.Ptile;
-        if (f == 1) {
-            qhi[pb] = q;
-        } else {
-            const int y = q / P.Wo, x = q - y * P.Wo;
-            qhi[pb] = y * f * Wo_hi + x * f;
-        }
-    }
-    for (int dy = 0; dy < f; ++dy)
-        for (int dx = 0; dx < f; ++dx) {
-            const int sub = dy * Wo_hi + dx;
+                for (int tj = 0; tj < KS; ++tj) {
+                    const float* wrow = wbase + (ti * KS + tj) * P.CK * P.MS;
+                    const float* irow = ip0 + (KS == 1 ? 0 : ti * dW + tj * P.dil);
+#pragma unroll 1
+                    for (int kc = 0; kc < P.CK; kc += 4) {
+                        float a[MB], b[PB];
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb) {
+                        for (int mb = 0; mb < MB; ++mb) a[mb] = wrow[mb * 16];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int co = m_wg + m_wave + mb * 16 + kl * 4 + r;
-                    const bool co_ok = co < P.Cout && m_wave + mb * 16 < P.Mtile;
-                    const float sc = (co_ok && scale) ? scale[co] : 1.f;
-                    const float sh = (co_ok && shift) ? shift[co] : 0.f;
-                    const size_t obase = ((size_t)n * P.out_ctot + P.out_coff + co) * HWo_hi + sub;
-                    const size_t rbase = ((size_t)n * P.res_ctot + P.res_coff + co) * HWo_hi + sub;
-#pragma unroll
-                    for (int pb = 0; pb < PB; ++pb) {
-                        if (co_ok && qok[pb]) {
-                            float v = fmaf(acc[mb][pb][r], sc, sh);
-                            if (res) v += res[rbase + qhi[pb]];
-                            if (P.act == OTP_ACT_RELU) v = fmaxf(v, 0.f);
-                            else if (P.act == OTP_ACT_GELU) v = gelu_erf(v);
-                            out[obase + qhi[pb]] = v;
+                        for (int pb = 0; pb < PB; ++pb) {
+                            const float v = irow[pb * 16];
+                            if (KS == 3 && tj == 0) b[pb] = __builtin_bit_cast(float, __builtin_bit_cast(int, v) & keepL[pb]);
+                            else if (KS == 3 && tj == 2) b[pb] = __builtin_bit_cast(float, __builtin_bit_cast(int, v) & keepR[pb]);
+                            else b[pb] = v;
                         }
+#pragma unroll
+                        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                            for (int pb = 0; pb < PB; ++pb)
+                                acc[mb][pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb], b[pb], acc[mb][pb], 0, 0, 0);
+                        wrow += aS;
+                        irow += bS;
                     }
                 }
             }
+        } else {
+#pragma unroll 1
+            for (int tap = 0; tap < KK; ++tap) {
+                const int ti = tap / KS, tj = tap - ti * KS;
+                const uint32_t cm = tj == 0 ? cm0 : (tj == 1 ? cm1 : cm2);
+                const float* wrow = wbase + tap * P.CK * P.MS;
+                const float* irow = ibase + (KS == 1 ? 0 : ti * dW + tj * P.dil);
+#pragma unroll 1
+                for (int kc = 0; kc < P.CK; kc += 4) {
+                    float a[MB], b[PB];
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) a[mb] = wrow[kc * P.MS + mb * 16];
+#pragma unroll
+                    for (int pb = 0; pb < PB; ++pb) {
+                        const float v = irow[kc * P.CS + poff[pb]];
+                        // all-ones / zero word from bit pb of the column mask: 0 for taps that cross the image edge
+                        const int keep = __builtin_amdgcn_sbfe(cm, pb, 1);
+                        b[pb] = __builtin_bit_cast(float, __builtin_bit_cast(int, v) & keep);
+                    }
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                        for (int pb = 0; pb < PB; ++pb)
+                            acc[mb][pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb], b[pb], acc[mb][pb], 0, 0, 0);
+                }
+            }
         }
+        __syncthreads();                         // every wave finished reading this chunk
+        if (last_chunk) {
+            epilogue(decode(tile));
+            if (!have_next) break;
+            __syncthreads();                     // epilogue tiles are read before the next chunk overwrites the LDS
+        }
+        store_items();
+        __syncthreads();
+        new_tile = last_chunk;
+        tile = tile_n;
+        c0 = c0_n;
+    }
 }
 
 __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin,
@@ -299,6 +395,7 @@ int pad_stride(int n, int want_mod32) {
 }
 
 int g_force[4] = {0, 0, 0, 0};   // test / tuning hook: forced (MB, PB, WM, WP)
+int g_last[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // tuning hook: plan of the last otp_conv2d call
 
 
 // ------------------------------------------------------------------------------------------------
@@ -501,6 +598,7 @@ bool fill_plan(WinPlan& P, const Tile& t, int KS, size_t& lds_bytes) {
     P.tiles_per_img = (P.HoWo + P.Ptile - 1) / P.Ptile;
     P.nP = P.N * P.tiles_per_img;
     P.nM = (P.Cout16 + P.Mtile - 1) / P.Mtile;
+    if (P.Cout16 % P.Mtile) return false;                  // weight rows are staged whole: no ragged last M tile
     P.M4 = P.Mtile / 4;
     P.MS = pad_stride(P.Mtile, 16);
     P.G = ((P.pad + 3) & ~3) < 16 ? 16 : ((P.pad + 3) & ~3);
@@ -509,7 +607,7 @@ bool fill_plan(WinPlan& P, const Tile& t, int KS, size_t& lds_bytes) {
         L = P.Ptile;
     } else {
         int rows = (P.Ptile % P.Wo == 0) ? P.Ptile / P.Wo : (P.Ptile + P.Wo - 2) / P.Wo + 1;
-        if (rows > P.Ho) rows = P.Ho;
+        if (rows > P.Ho && !P.lin) rows = P.Ho;            // LIN reads the (zero) rows of its padding pixels too
         const int NR = (rows - 1) * P.stride + (KS - 1) * P.dil + 1;
         L = NR * P.W + 3;                                  // + alignment slack of the window start
     }
@@ -519,69 +617,104 @@ bool fill_plan(WinPlan& P, const Tile& t, int KS, size_t& lds_bytes) {
     // chunk size: a small Cin is one chunk; otherwise 16 / 8 / 4 channels, preferring the one that wastes the
     // fewest zero-padded channels in the last chunk (Cin = 136 -> 17 x 8), then the larger
     const int cands[4] = {cin4 <= 32 ? cin4 : 16, 16, 8, 4};
+    const int nwaves = P.nthreads / 64;
+    P.JR = (P.L4 + 63) / 64;
     int best_c = 0;
     long best_waste = 0;
     size_t best_lds = 0;
     for (int ci = 0; ci < 4; ++ci) {
         const int c = cands[ci] > cin4 ? cin4 : cands[ci];
         const size_t lds = ((size_t)c * P.CS + (size_t)KK * c * P.MS) * sizeof(float);
-        if (lds > 80 * 1024 || (long)c * P.L4 > (long)MAXJI * P.nthreads || (long)KK * c * P.M4 > (long)MAXJW * P.nthreads) continue;
+        const int ckw = (c + nwaves - 1) / nwaves;
+        if (lds > 80 * 1024 || ckw * P.JR > (P.lin ? MAXJI_LIN : MAXJI_GEN) || (long)KK * c * P.M4 > (long)MAXJW * P.nthreads) continue;
         const long waste = (long)((cin4 + c - 1) / c) * c - cin4;
         if (!best_c || waste < best_waste) { best_c = c; best_waste = waste; best_lds = lds; }
     }
     if (!best_c) return false;
     P.CK = best_c;
-    P.NI4 = best_c * P.L4;
+    P.CKW = (best_c + nwaves - 1) / nwaves;
+    P.NJI = P.CKW * P.JR;
     P.NW4 = KK * best_c * P.M4;
-    lds_bytes = best_lds;
-    P.magicL4 = magic_of(P.L4);
+    P.NJW = (P.NW4 + P.nthreads - 1) / P.nthreads;
+    P.ntiles = ((P.nP + 7) / 8) * 8 * P.nM;
+    const size_t ep_lds = (size_t)nwaves * 16 * (16 * t.PB + 4) * sizeof(float);
+    lds_bytes = best_lds > ep_lds ? best_lds : ep_lds;
     P.magicM4 = magic_of(P.M4);
     P.magicCK = magic_of(P.CK);
     P.magicWo = magic_of(P.Wo);
+    P.magicTpi = magic_of(P.tiles_per_img);
     return true;
 }
 
-// Relative time of a candidate: MFMA tile-steps on the busiest SIMD, inflated by what the tile cannot hide.
+// Persistent grid of a plan: two waves per SIMD resident (<= 256 registers), bounded by LDS, a multiple of 8 so that a
+// workgroup keeps its XCD label while it walks its tiles.
+int resident_wgs(const WinPlan& P, size_t lds) {
+    int resident = 256 * (8 / (P.nthreads / 64));
+    const int by_lds = 256 * (int)((160 * 1024) / (lds ? lds : 1));
+    if (by_lds < resident) resident = by_lds;
+    resident &= ~7;
+    return P.ntiles < resident ? P.ntiles : resident;
+}
+
+// Relative time of a candidate, in cycles of the busiest SIMD.  On gfx950 the f32 MFMA and the VALU work of the
+// waves resident on a SIMD do not overlap (measured: profiles/r01c_*), so the time is the sum of the MFMA
+// cycles and ~4 cycles per vector instruction; what is left of barrier / memory latency is hidden when two waves
+// share the SIMD and exposed when one wave has it alone.
 double tile_cost(const WinPlan& P, const Tile& t, int KS, size_t lds) {
     const int wpw = t.WM * t.WP;                                   // waves per workgroup
-    const long nwg = (long)P.nP * P.nM;
-    const long wg_per_cu = (nwg + 255) / 256;                      // busiest CU
-    const long waves_per_simd = (wg_per_cu * wpw + 3) / 4;
-    double cost = (double)waves_per_simd * t.MB * t.PB;
-    // concurrency available to hide LDS latency and the chunk hand-over: resident waves per SIMD
-    int resident = (int)((160 * 1024) / (lds ? lds : 1));
-    if (resident > 8 / wpw) resident = 8 / wpw;                    // <= 2 waves per SIMD (256 registers)
-    if (resident < 1) resident = 1;
-    long conc = resident < wg_per_cu ? resident : wg_per_cu;
-    const double simd_waves = (double)conc * wpw / 4.0;
-    const double chunk_cycles = 32.0 * KS * KS * (P.CK / 4.0) * t.MB * t.PB;
-    const double handover = 900.0 / chunk_cycles;                  // barriers + LDS write of the next chunk
-    cost *= 1.0 + handover / (simd_waves >= 2.0 ? 3.0 : 1.0);
-    cost *= 1.0 + 0.10 / (simd_waves >= 2.0 ? 2.0 : 1.0) * (12.0 / (t.MB * t.PB));   // exposed LDS latency per step
-    cost *= 1.0 + 0.03 / t.MB;                                     // A-fragment reuse
-    if (wpw == 3) cost *= 1.15;                                    // one SIMD idles
+    const int R = resident_wgs(P, lds);
+    // workgroup b walks tiles b, b+R, ...; workgroups b, b+256, ... share a CU and run concurrently, so the busiest
+    // SIMD hosts ceil(workgroups x waves / 4) waves that take turns on its pipe
+    const long T = P.ntiles;
+    const long tiles_per_wg = (T + R - 1) / R;
+    const int cu_wgs = (R + 255) / 256;
+    const int simd_waves = (cu_wgs * wpw + 3) / 4;
+    const double waves_per_simd = simd_waves;
+    const int nchunks = (P.Cin + P.CK - 1) / P.CK, steps = KS * KS * (P.CK / 4);
+    double step_valu = 2.0;                                        // address bumps
+    if (!P.lin) step_valu += 2.0 * t.PB;                           // per-block address + mask
+    else if (KS == 3) step_valu += t.PB * (2.0 / 3.0);             // edge-column masks on 2 of 3 tap columns
+    // per step: the MFMAs, the vector instructions, and what is left of the LDS round trip of the fragment reads
+    // (fitted to the tile sweeps in profiles/: ~200 cycles with a second wave on the SIMD, ~330 without)
+    const double step = 32.0 * t.MB * t.PB + 4.0 * step_valu + (waves_per_simd >= 2.0 ? 200.0 : 330.0);
+    const double chunk = steps * step + 4.0 * (6.0 * P.NJI + 3.0 * P.NJW + 60.0) + 16.0 * (P.NJI + P.NJW) +
+                         (waves_per_simd >= 2.0 ? 400.0 : 1500.0);   // barriers + load wait
+    const double ep_items = 16.0 * 4 * t.PB * t.MB / 64.0;         // float4 stores per lane
+    const double tile_fixed = 4.0 * (ep_items * (P.ep_vec ? 45.0 : 160.0) + 4.0 * t.MB * t.PB + 300.0);
+    // a CU pulls the staged bytes of all its workgroups through one ~16 B/clk load path (L2-resident windows and
+    // weights); stride-2 windows with narrow M tiles are bound by it
+    const double chunk_bytes = 16.0 * ((double)P.CK * P.L4 + (double)P.NW4);
+    const double chunk_cu = fmax(simd_waves * chunk, cu_wgs * chunk_bytes / 16.0);
+    double cost = (double)tiles_per_wg * (nchunks * chunk_cu + simd_waves * tile_fixed);
+    // measured on the sweeps: at equal tile shape 2-wave workgroups run 7-24 % and 1-wave workgroups 17-26 % behind
+    // 4-wave ones (the weight slab is staged once per workgroup)
+    if (!P.lin) cost *= 1.0 + 0.2 * (P.nM - 1);                   // strided windows: re-staged by every M tile
+    if (wpw == 2) cost *= 1.12;
+    else if (wpw == 1 || wpw == 3) cost *= 1.2;
     return cost;
 }
 
-template <int MB, int PB, int KS>
-int launch_win(const float* in, const float* in2, const float* wp, const float* scale, const float* shift,
+template <int MB, int PB, int KS, bool LIN>
+int launch_win(const float* in, const float* wp, const float* scale, const float* shift,
                const float* res, float* out, const WinPlan& P, size_t lds, hipStream_t st) {
-    auto kern = conv_win_kernel<MB, PB, KS>;
+    auto kern = conv_win_kernel<MB, PB, KS, LIN>;
     OTP_ALLOW_BIG_LDS(kern, lds);
-    const int groups = (P.nP + 7) / 8;
-    dim3 grid(groups * 8 * P.nM);
-    hipLaunchKernelGGL(kern, grid, dim3(P.nthreads), lds, st, in, in2, wp, scale, shift, res, out, P);
+    dim3 grid(resident_wgs(P, lds));
+    g_last[4] = P.CK; g_last[5] = (int)grid.x; g_last[6] = (int)lds; g_last[7] = P.ntiles;
+    hipLaunchKernelGGL(kern, grid, dim3(P.nthreads), lds, st, in, wp, scale, shift, res, out, P);
     return otp_launch_status();
 }
 
 template <int KS>
-int dispatch_win(int MB, int PB, const float* in, const float* in2, const float* wp, const float* scale,
+int dispatch_win(int MB, int PB, const float* in, const float* wp, const float* scale,
                  const float* shift, const float* res, float* out, const WinPlan& P, size_t lds, hipStream_t st) {
-#define OTP_CASE(M_, P_) if (MB == M_ && PB == P_) return launch_win<M_, P_, KS>(in, in2, wp, scale, shift, res, out, P, lds, st);
-    OTP_CASE(1, 7) OTP_CASE(1, 8) OTP_CASE(1, 9)
-    OTP_CASE(2, 7) OTP_CASE(2, 8) OTP_CASE(2, 9)
-    OTP_CASE(3, 7) OTP_CASE(3, 8) OTP_CASE(3, 9)
-    OTP_CASE(4, 7)
+#define OTP_CASE(M_, P_)                                                                              \
+    if (MB == M_ && PB == P_)                                                                         \
+        return P.lin ? launch_win<M_, P_, KS, true>(in, wp, scale, shift, res, out, P, lds, st)       \
+                     : launch_win<M_, P_, KS, false>(in, wp, scale, shift, res, out, P, lds, st);
+    OTP_CASE(1, 7) OTP_CASE(1, 9)
+    OTP_CASE(2, 7) OTP_CASE(2, 9)
+    OTP_CASE(3, 7)
 #undef OTP_CASE
     return OTP_ERR_UNSUPPORTED;
 }
@@ -633,10 +766,76 @@ int launch_generic(const float* in, const float* in2, const float* wp, const flo
     return otp_launch_status();
 }
 
+// Choose the window-kernel plan for a descriptor; false when the window kernel does not apply (then the generic
+// kernel runs).  Pure host arithmetic: also exported as otp_conv2d_plan for tuning without a GPU.
+bool plan_window(const otp_conv_desc& d, const void* in, const void* in2, const void* wpacked, const void* res,
+                 const void* out, WinPlan& P, Tile& best, size_t& lds) {
+    // the window kernel stages 16-byte vectors: channel planes must be 16-byte aligned (H*W % 4 == 0, aligned bases);
+    // a pre-added second input (the RSB staircase, tiny convs) takes the generic kernel
+    const bool vec_ok = ((d.H * d.W) & 3) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0 &&
+                        (reinterpret_cast<uintptr_t>(wpacked) & 15) == 0;
+    if (!vec_ok || in2 || d.kh != d.kw || (d.kh != 1 && d.kh != 3) || (long)d.H * d.W >= (1l << 24)) return false;
+    P = WinPlan{};
+    P.N = d.N; P.Cin = d.Cin; P.H = d.H; P.W = d.W; P.HW = d.H * d.W; P.Cout = d.Cout;
+    P.Cout16 = (d.Cout + 15) & ~15; P.stride = d.stride; P.pad = d.pad; P.dil = d.dil;
+    P.Ho = d.Ho; P.Wo = d.Wo; P.HoWo = d.Ho * d.Wo;
+    P.in_ctot = d.in_ctot; P.in_coff = d.in_coff; P.in2_ctot = d.in2_ctot; P.in2_coff = d.in2_coff;
+    P.out_ctot = d.out_ctot; P.out_coff = d.out_coff; P.res_ctot = d.res_ctot; P.res_coff = d.res_coff;
+    P.res_up = d.res_up; P.act = d.act; P.frame_split = d.frame_split;
+    P.flat = (d.kh == 1 && d.stride == 1 && d.pad == 0) ? 1 : 0;
+    P.lin = (P.flat || (d.stride == 1 && d.Wo == d.W && 2 * d.pad == d.dil * (d.kh - 1))) ? 1 : 0;
+    P.ep_vec = (d.res_up <= 1 && ((d.Ho * d.Wo) & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
+                (!res || (reinterpret_cast<uintptr_t>(res) & 15) == 0)) ? 1 : 0;
+    const int mblk = P.Cout16 / 16, G = (P.HoWo + 15) / 16;
+    best = Tile{0, 0, 0, 0};
+    double best_cost = 1e300;
+    static const int wms[] = {1, 2, 4}, pbs[] = {7, 9};
+    for (int MB = 1; MB <= 3; ++MB)
+        for (int PB : pbs)
+            for (int WM : wms)
+                for (int WP = 1; WM * WP <= 4; ++WP) {
+                    if (MB * PB > 21) continue;                  // registers: acc + prefetch + addressing <= 256
+                    const Tile t{MB, PB, WM, WP};
+                    if (g_force[0]) {
+                        if (MB != g_force[0] || PB != g_force[1] || WM != g_force[2] || WP != g_force[3]) continue;
+                    } else {
+                        if (WM > 1 && MB * (WM - 1) >= mblk) continue;            // whole waves of padding
+                        if (WP > 1 && PB * (WP - 1) >= G) continue;
+                    }
+                    WinPlan C = P;
+                    size_t l = 0;
+                    if (!fill_plan(C, t, d.kh, l)) continue;
+                    const double cost = tile_cost(C, t, d.kh, l);
+                    if (cost < best_cost) { best_cost = cost; best = t; }
+                }
+    if (!best.MB) return false;
+    fill_plan(P, best, d.kh, lds);
+    return true;
+}
+
 }  // namespace
 
 extern "C" int otp_conv2d_set_tile(int MB, int PB, int WM, int WP) {
     g_force[0] = MB; g_force[1] = PB; g_force[2] = WM; g_force[3] = WP;
+    return OTP_OK;
+}
+
+extern "C" int otp_conv2d_plan(const otp_conv_desc* desc, int* out8) {
+    if (!desc || !out8) return OTP_ERR_BAD_ARG;
+    WinPlan P{};
+    Tile best{0, 0, 0, 0};
+    size_t lds = 0;
+    for (int i = 0; i < 8; ++i) out8[i] = 0;
+    // alignment is assumed (aligned dummy pointers): this is the plan the engine's own buffers get
+    if (!plan_window(*desc, nullptr, nullptr, nullptr, nullptr, nullptr, P, best, lds)) return OTP_OK;
+    out8[0] = best.MB; out8[1] = best.PB; out8[2] = best.WM; out8[3] = best.WP;
+    out8[4] = P.CK; out8[5] = resident_wgs(P, lds); out8[6] = (int)lds; out8[7] = P.ntiles;
+    return OTP_OK;
+}
+
+extern "C" int otp_conv2d_last_plan(int* out8) {
+    if (!out8) return OTP_ERR_BAD_ARG;
+    for (int i = 0; i < 8; ++i) out8[i] = g_last[i];
     return OTP_OK;
 }
 
@@ -670,55 +869,20 @@ extern "C" int otp_conv2d(const void* in, const void* in2, const void* wpacked, 
     auto r = static_cast<const float*>(res);
     auto o = static_cast<float*>(out);
 
-    // the window kernel stages 16-byte vectors: channel planes must be 16-byte aligned (H*W % 4 == 0, aligned bases)
-    const bool vec_ok = ((d.H * d.W) & 3) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0 &&
-                        (!in2 || (reinterpret_cast<uintptr_t>(in2) & 15) == 0) &&
-                        (reinterpret_cast<uintptr_t>(wpacked) & 15) == 0;
-    const bool win_ok = vec_ok && d.kh == d.kw && (d.kh == 1 || d.kh == 3) && (long)d.H * d.W < (1l << 24);
-    if (win_ok) {
-        WinPlan P{};
-        P.N = d.N; P.Cin = d.Cin; P.H = d.H; P.W = d.W; P.HW = d.H * d.W; P.Cout = d.Cout;
-        P.Cout16 = (d.Cout + 15) & ~15; P.stride = d.stride; P.pad = d.pad; P.dil = d.dil;
-        P.Ho = d.Ho; P.Wo = d.Wo; P.HoWo = d.Ho * d.Wo;
-        P.in_ctot = d.in_ctot; P.in_coff = d.in_coff; P.in2_ctot = d.in2_ctot; P.in2_coff = d.in2_coff;
-        P.out_ctot = d.out_ctot; P.out_coff = d.out_coff; P.res_ctot = d.res_ctot; P.res_coff = d.res_coff;
-        P.res_up = d.res_up; P.act = d.act; P.frame_split = d.frame_split;
-        P.flat = (d.kh == 1 && d.stride == 1 && d.pad == 0) ? 1 : 0;
-        P.vec = 1;
-        const int mblk = P.Cout16 / 16, G = (P.HoWo + 15) / 16;
-        Tile best{0, 0, 0, 0};
-        double best_cost = 1e300;
-        static const int wms[] = {1, 2, 4}, pbs[] = {7, 8, 9};
-        for (int MB = 1; MB <= 4; ++MB)
-            for (int PB : pbs)
-                for (int WM : wms)
-                    for (int WP = 1; WM * WP <= 4; ++WP) {
-                        if (MB * PB > 28) continue;
-                        const Tile t{MB, PB, WM, WP};
-                        if (g_force[0]) {
-                            if (MB != g_force[0] || PB != g_force[1] || WM != g_force[2] || WP != g_force[3]) continue;
-                        } else {
-                            if (WM > 1 && MB * (WM - 1) >= mblk) continue;        // whole waves of padding
-                            if (WP > 1 && PB * (WP - 1) >= G) continue;
-                        }
-                        WinPlan C = P;
-                        size_t lds = 0;
-                        if (!fill_plan(C, t, d.kh, lds)) continue;
-                        const double cost = tile_cost(C, t, d.kh, lds);
-                        if (cost < best_cost) { best_cost = cost; best = t; }
-                    }
-        if (best.MB) {
-            size_t lds = 0;
-            fill_plan(P, best, d.kh, lds);
-            if (d.kh == 1) return dispatch_win<1>(best.MB, best.PB, a, b, w, sc, sh, r, o, P, lds, st);
-            return dispatch_win<3>(best.MB, best.PB, a, b, w, sc, sh, r, o, P, lds, st);
-        }
+    WinPlan P{};
+    Tile best{0, 0, 0, 0};
+    size_t lds = 0;
+    if (plan_window(d, in, in2, wpacked, res, out, P, best, lds)) {
+        g_last[0] = best.MB; g_last[1] = best.PB; g_last[2] = best.WM; g_last[3] = best.WP;
+        if (d.kh == 1) return dispatch_win<1>(best.MB, best.PB, a, w, sc, sh, r, o, P, lds, st);
+        return dispatch_win<3>(best.MB, best.PB, a, w, sc, sh, r, o, P, lds, st);
     }
-    ConvPlan P;
-    P.d = d;
-    if (!choose_generic(P)) return OTP_ERR_UNSUPPORTED;
-    const int MB = P.Mtile / 16;
-    if (MB == 1) return launch_generic<1>(a, b, w, sc, sh, r, o, P, st);
-    if (MB == 2) return launch_generic<2>(a, b, w, sc, sh, r, o, P, st);
-    return launch_generic<3>(a, b, w, sc, sh, r, o, P, st);
+    ConvPlan G;
+    G.d = d;
+    for (int i = 0; i < 8; ++i) g_last[i] = 0;       // generic kernel
+    if (!choose_generic(G)) return OTP_ERR_UNSUPPORTED;
+    const int MB = G.Mtile / 16;
+    if (MB == 1) return launch_generic<1>(a, b, w, sc, sh, r, o, G, st);
+    if (MB == 2) return launch_generic<2>(a, b, w, sc, sh, r, o, G, st);
+    return launch_generic<3>(a, b, w, sc, sh, r, o, G, st);
 }

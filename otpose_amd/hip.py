@@ -11,7 +11,7 @@ import os
 from ctypes import c_float, c_int, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libotpose_hip.so")
+LIB_PATH = os.environ.get("OTPOSE_HIP_LIB") or os.path.join(_HERE, "csrc", "libotpose_hip.so")   # env: dev builds
 _lib = None
 
 OTP_OK = 0
@@ -40,6 +40,8 @@ SIGNATURES = {
     "otp_conv2d_pack_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "otp_conv2d": (c_int, [c_void_p] * 7 + [ctypes.POINTER(ConvDesc), c_void_p]),
     "otp_conv2d_set_tile": (c_int, [c_int] * 4),
+    "otp_conv2d_last_plan": (c_int, [ctypes.POINTER(c_int)]),
+    "otp_conv2d_plan": (c_int, [ctypes.POINTER(ConvDesc), ctypes.POINTER(c_int)]),
     "otp_glue_total": (c_int, [c_void_p] * 6 + [c_int] * 3 + [c_void_p]),
     "otp_glue_stack": (c_int, [c_void_p] * 10 + [c_int] * 3 + [c_void_p]),
     "otp_ln_channel": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_float, c_void_p]),

@@ -61,14 +61,30 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="")
+    ap.add_argument("--dbg", type=int, default=0, help="ablation bits (needs a -DOTP_CONV_DEBUG build)")
+    ap.add_argument("--tile", default="", help="force MB,PB,WM,WP")
+    ap.add_argument("--shape", action="append", default=[], help="extra shape N,Cin,Cout,k,s,d,H,W (repeatable)")
     ap.add_argument("--sweep", action="store_true", help="try every (MB,PB,WM,WP) tile through the tuning hook")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
+    if a.dbg:
+        hip.lib()
+        import ctypes
+        hip._lib.otp_conv2d_debug.argtypes = [ctypes.c_int]
+        hip._lib.otp_conv2d_debug(a.dbg)
+    if a.tile:
+        hip.lib().otp_conv2d_set_tile(*[int(v) for v in a.tile.split(",")])
     g = torch.Generator().manual_seed(3)
     tot_ms = 0.0
     tot_flop = 0.0
-    print("%-28s %9s %9s %7s %9s" % ("shape", "ms/call", "TFLOP/s", "frac", "ms/fwd"))
-    for name, n, cin, cout, k, s, d, h, w, calls in SHAPES:
+    print("%-58s %9s %9s %7s %9s" % ("shape", "ms/call", "TFLOP/s", "frac", "ms/fwd"))
+    shapes = SHAPES
+    if a.shape:
+        shapes = []
+        for sp in a.shape:
+            v = [int(t) for t in sp.split(",")]
+            shapes.append(("custom " + sp, *v, 1))
+    for name, n, cin, cout, k, s, d, h, w, calls in shapes:
         if a.only and a.only not in name:
             continue
         pad = d * (k // 2)
@@ -82,6 +98,10 @@ def main():
         wp = ops.pack_conv_weight(wt)
         desc = ops.conv_desc(iv, ov, cout, k, k, s, pad, d, act=ops.ACT_RELU)
         ms = time_ms(lambda: ops.conv2d_launch(iv, wp, sc, sh, ov, desc), a.iters)
+        import ctypes
+        plan = (ctypes.c_int * 8)()
+        hip.lib().otp_conv2d_last_plan(plan)
+        name = name + " " + str(list(plan)[:6])
         if a.sweep:
             L = hip.lib()
             res = []
@@ -106,7 +126,7 @@ def main():
         tf = flop / (ms * 1e-3) / 1e12
         tot_ms += ms * calls
         tot_flop += flop * calls
-        print("%-28s %9.4f %9.2f %7.3f %9.3f" % (name, ms, tf, tf * 1e12 / PEAK, ms * calls))
+        print("%-58s %9.4f %9.2f %7.3f %9.3f" % (name, ms, tf, tf * 1e12 / PEAK, ms * calls))
     print("sum over listed shapes: %.2f ms per forward, %.2f TFLOP -> %.1f TFLOP/s" %
           (tot_ms, tot_flop / 1e12, tot_flop / (tot_ms * 1e-3) / 1e12))
 
