@@ -38,7 +38,7 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + er
 __device__ __forceinline__ uint32_t fdiv(uint32_t i, uint32_t magic) { return magic ? __umulhi(i, magic) : i; }
 uint32_t magic_of(uint32_t d) { return d <= 1 ? 0u : (uint32_t)((1ull << 32) / d) + 1u; }
 
-constexpr int MAXJI_LIN = 8, MAXJI_GEN = 10, MAXJW = 6;   // float4 prefetch registers per thread: input windows / weight slab of a chunk
+constexpr int MAXJI_LIN = 10, MAXJI_GEN = 10, MAXJW = 5;   // float4 prefetch registers per thread: input windows / weight slab of a chunk
 
 struct WinPlan {
     // problem
@@ -52,6 +52,7 @@ struct WinPlan {
     int CS, MS, M4;              // LDS channel stride, weight-row stride, Mtile / 4
     int CKW, JR, NJI;            // input staging: channels per wave, 64-float4 pieces per window, items per thread
     int NW4, NJW;                // weight staging: float4 per chunk, items per thread
+    int prio;                    // tuning: static wave priority by dispatch round (see kernel)
     int ep_vec;                  // epilogue may use 16-byte vectors (no upsample, Ho*Wo % 4 == 0, aligned out / res)
     uint32_t magicM4, magicCK, magicWo, magicTpi;
 };
@@ -185,6 +186,16 @@ __global__ __launch_bounds__(256, 2) void conv_win_kernel(
         float* ep = smem + wave * (16 * RS);
         const int pix_wave = T.q0 + wpi * 16 * PB;
         const int f = P.res_up > 1 ? P.res_up : 1;
+        // scale / shift of this wave's 16*MB output channels: lane l holds channel l (one global round trip per tile;
+        // the store loops fetch them with a lane shuffle)
+        float sc_l = 1.f, sh_l = 0.f;
+        {
+            const int co = T.m_wg + m_wave + lane;
+            if (lane < 16 * MB && co < P.Cout) {
+                if (scale) sc_l = scale[co];
+                if (shift) sh_l = shift[co];
+            }
+        }
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
@@ -193,22 +204,42 @@ __global__ __launch_bounds__(256, 2) void conv_win_kernel(
                 for (int r = 0; r < 4; ++r) ep[(kl * 4 + r) * RS + pb * 16 + i16] = acc[mb][pb][r];
             const int co_base = T.m_wg + m_wave + mb * 16;
             if (P.ep_vec) {
-#pragma unroll 1
-                for (int i = lane; i < 16 * 4 * PB; i += 64) {
-                    const int row = i / (4 * PB), c4 = i - row * (4 * PB);
-                    const int co = co_base + row, q = pix_wave + 4 * c4;
-                    if (co < P.Cout && q < P.HoWo) {
-                        f32x4 v = *reinterpret_cast<const f32x4*>(ep + row * RS + 4 * c4);
-                        const float sc = scale ? scale[co] : 1.f, sh = shift ? shift[co] : 0.f;
-                        v = v * sc + sh;
-                        if (res) v += *reinterpret_cast<const f32x4*>(
-                            res + ((size_t)T.n * P.res_ctot + P.res_coff + co) * P.HoWo + q);
-                        if (P.act == OTP_ACT_RELU) {
-                            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                        } else if (P.act == OTP_ACT_GELU) {
-                            v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
+                // 16 rows x 4*PB float4 = PB float4 per lane, in batches of EB: the loads of a batch (LDS tile,
+                // residual) are all issued before its first store, so a batch costs one memory round trip
+                constexpr int EB = 2;
+#pragma unroll
+                for (int it0 = 0; it0 < PB; it0 += EB) {
+                    f32x4 v[EB], rv[EB];
+#pragma unroll
+                    for (int e = 0; e < EB; ++e) {
+                        if (it0 + e < PB) {
+                            const int i = lane + 64 * (it0 + e);
+                            const int row = i / (4 * PB), c4 = i - row * (4 * PB);
+                            const int co = co_base + row, q = pix_wave + 4 * c4;
+                            v[e] = *reinterpret_cast<const f32x4*>(ep + row * RS + 4 * c4);
+                            if (res && co < P.Cout && q < P.HoWo)
+                                rv[e] = *reinterpret_cast<const f32x4*>(
+                                    res + ((size_t)T.n * P.res_ctot + P.res_coff + co) * P.HoWo + q);
                         }
-                        *reinterpret_cast<f32x4*>(out + ((size_t)T.n * P.out_ctot + P.out_coff + co) * P.HoWo + q) = v;
+                    }
+#pragma unroll
+                    for (int e = 0; e < EB; ++e) {
+                        if (it0 + e < PB) {
+                            const int i = lane + 64 * (it0 + e);
+                            const int row = i / (4 * PB), c4 = i - row * (4 * PB);
+                            const int co = co_base + row, q = pix_wave + 4 * c4;
+                            const float sc = __shfl(sc_l, mb * 16 + row, 64), sh = __shfl(sh_l, mb * 16 + row, 64);
+                            f32x4 o = v[e] * sc + sh;
+                            const bool ok = co < P.Cout && q < P.HoWo;
+                            if (res && ok) o += rv[e];
+                            if (P.act == OTP_ACT_RELU) {
+                                o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+                            } else if (P.act == OTP_ACT_GELU) {
+                                o.x = gelu_erf(o.x); o.y = gelu_erf(o.y); o.z = gelu_erf(o.z); o.w = gelu_erf(o.w);
+                            }
+                            if (ok)
+                                *reinterpret_cast<f32x4*>(out + ((size_t)T.n * P.out_ctot + P.out_coff + co) * P.HoWo + q) = o;
+                        }
                     }
                 }
             } else {
@@ -217,8 +248,8 @@ __global__ __launch_bounds__(256, 2) void conv_win_kernel(
                 for (int i = lane; i < 16 * 16 * PB; i += 64) {
                     const int row = i / (16 * PB), col = i - row * (16 * PB);
                     const int co = co_base + row, q = pix_wave + col;
+                    const float sc = __shfl(sc_l, mb * 16 + row, 64), sh = __shfl(sh_l, mb * 16 + row, 64);
                     if (co < P.Cout && q < P.HoWo) {
-                        const float sc = scale ? scale[co] : 1.f, sh = shift ? shift[co] : 0.f;
                         const float v0 = fmaf(ep[row * RS + col], sc, sh);
                         int qhi = q;
                         if (f > 1) {
@@ -248,6 +279,10 @@ __global__ __launch_bounds__(256, 2) void conv_win_kernel(
 
     int tile = blockIdx.x, c0 = 0;
     if (!tile_ok(tile)) return;                  // uniform per workgroup
+    // Workgroups b and b + 256 land on the same CU and their waves share SIMDs.  With equal priority the two
+    // waves of a SIMD interleave MFMA by MFMA, drift into lockstep and then wait on LDS / barriers together; a
+    // static priority for the second dispatch round lets one wave run its MFMA batch while the other fills the gaps.
+    if (P.prio && ((blockIdx.x >> 8) & 1)) __builtin_amdgcn_s_setprio(1);
     load_items(tile, 0);
     store_items();
     __syncthreads();
@@ -395,6 +430,7 @@ int pad_stride(int n, int want_mod32) {
 }
 
 int g_force[4] = {0, 0, 0, 0};   // test / tuning hook: forced (MB, PB, WM, WP)
+int g_prio = 0;                  // tuning hook (OTPOSE_CONV_PRIO=0 disables the static wave priority)
 int g_last[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // tuning hook: plan of the last otp_conv2d call
 
 
@@ -586,7 +622,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
 }
 
 
-struct Tile { int MB, PB, WM, WP; };
+struct Tile { int MB, PB, WM, WP, CK; };
 
 // Fill every tiling-dependent field of P for a candidate tile; false when it does not fit (LDS / prefetch registers).
 bool fill_plan(WinPlan& P, const Tile& t, int KS, size_t& lds_bytes) {
@@ -613,28 +649,21 @@ bool fill_plan(WinPlan& P, const Tile& t, int KS, size_t& lds_bytes) {
     }
     P.L4 = (L + 3) / 4;
     P.CS = pad_stride(P.G + 4 * P.L4 + P.G, 16);           // == 16 (mod 32): the 4 k-rows of a fragment hit distinct banks
+    // chunk of t.CK input channels (a multiple of 4, at most Cin rounded up): must fit the LDS budget of two
+    // workgroups per CU and the prefetch registers
     const int cin4 = (P.Cin + 3) & ~3;
-    // chunk size: a small Cin is one chunk; otherwise 16 / 8 / 4 channels, preferring the one that wastes the
-    // fewest zero-padded channels in the last chunk (Cin = 136 -> 17 x 8), then the larger
-    const int cands[4] = {cin4 <= 32 ? cin4 : 16, 16, 8, 4};
+    const int c = t.CK > cin4 ? cin4 : t.CK;
     const int nwaves = P.nthreads / 64;
     P.JR = (P.L4 + 63) / 64;
-    int best_c = 0;
-    long best_waste = 0;
-    size_t best_lds = 0;
-    for (int ci = 0; ci < 4; ++ci) {
-        const int c = cands[ci] > cin4 ? cin4 : cands[ci];
-        const size_t lds = ((size_t)c * P.CS + (size_t)KK * c * P.MS) * sizeof(float);
-        const int ckw = (c + nwaves - 1) / nwaves;
-        if (lds > 80 * 1024 || ckw * P.JR > (P.lin ? MAXJI_LIN : MAXJI_GEN) || (long)KK * c * P.M4 > (long)MAXJW * P.nthreads) continue;
-        const long waste = (long)((cin4 + c - 1) / c) * c - cin4;
-        if (!best_c || waste < best_waste) { best_c = c; best_waste = waste; best_lds = lds; }
-    }
-    if (!best_c) return false;
-    P.CK = best_c;
-    P.CKW = (best_c + nwaves - 1) / nwaves;
+    const size_t best_lds = ((size_t)c * P.CS + (size_t)KK * c * P.MS) * sizeof(float);
+    const int ckw = (c + nwaves - 1) / nwaves;
+    if (c < 4 || (c & 3) || best_lds > 80 * 1024 || ckw * P.JR > (P.lin ? MAXJI_LIN : MAXJI_GEN) ||
+        (long)KK * c * P.M4 > (long)MAXJW * P.nthreads)
+        return false;
+    P.CK = c;
+    P.CKW = ckw;
     P.NJI = P.CKW * P.JR;
-    P.NW4 = KK * best_c * P.M4;
+    P.NW4 = KK * c * P.M4;
     P.NJW = (P.NW4 + P.nthreads - 1) / P.nthreads;
     P.ntiles = ((P.nP + 7) / 8) * 8 * P.nM;
     const size_t ep_lds = (size_t)nwaves * 16 * (16 * t.PB + 4) * sizeof(float);
@@ -677,12 +706,15 @@ double tile_cost(const WinPlan& P, const Tile& t, int KS, size_t lds) {
     // per step: the MFMAs, the vector instructions, and what is left of the LDS round trip of the fragment reads
     // (fitted to the tile sweeps in profiles/: ~200 cycles with a second wave on the SIMD, ~330 without)
     const double step = 32.0 * t.MB * t.PB + 4.0 * step_valu + (waves_per_simd >= 2.0 ? 200.0 : 330.0);
-    const double chunk = steps * step + 4.0 * (6.0 * P.NJI + 3.0 * P.NJW + 60.0) + 16.0 * (P.NJI + P.NJW) +
+    double chunk = steps * step + 4.0 * (6.0 * P.NJI + 3.0 * P.NJW + 60.0) + 16.0 * (P.NJI + P.NJW) +
                          (waves_per_simd >= 2.0 ? 400.0 : 1500.0);   // barriers + load wait
     const double ep_items = 16.0 * 4 * t.PB * t.MB / 64.0;         // float4 stores per lane
     const double tile_fixed = 4.0 * (ep_items * (P.ep_vec ? 45.0 : 160.0) + 4.0 * t.MB * t.PB + 300.0);
     // a CU pulls the staged bytes of all its workgroups through one ~16 B/clk load path (L2-resident windows and
     // weights); stride-2 windows with narrow M tiles are bound by it
+    // the loads of a chunk are issued one chunk ahead: a chunk shorter than the ~2500-cycle L2/HBM round trip leaves
+    // the rest of it exposed at the LDS write (half of it when a second workgroup shares the CU)
+    chunk += fmax(0.0, 2500.0 - chunk) * (waves_per_simd >= 2.0 ? 0.5 : 1.0);
     const double chunk_bytes = 16.0 * ((double)P.CK * P.L4 + (double)P.NW4);
     const double chunk_cu = fmax(simd_waves * chunk, cu_wgs * chunk_bytes / 16.0);
     double cost = (double)tiles_per_wg * (nchunks * chunk_cu + simd_waves * tile_fixed);
@@ -782,12 +814,13 @@ bool plan_window(const otp_conv_desc& d, const void* in, const void* in2, const 
     P.in_ctot = d.in_ctot; P.in_coff = d.in_coff; P.in2_ctot = d.in2_ctot; P.in2_coff = d.in2_coff;
     P.out_ctot = d.out_ctot; P.out_coff = d.out_coff; P.res_ctot = d.res_ctot; P.res_coff = d.res_coff;
     P.res_up = d.res_up; P.act = d.act; P.frame_split = d.frame_split;
+    P.prio = g_prio;
     P.flat = (d.kh == 1 && d.stride == 1 && d.pad == 0) ? 1 : 0;
     P.lin = (P.flat || (d.stride == 1 && d.Wo == d.W && 2 * d.pad == d.dil * (d.kh - 1))) ? 1 : 0;
     P.ep_vec = (d.res_up <= 1 && ((d.Ho * d.Wo) & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
                 (!res || (reinterpret_cast<uintptr_t>(res) & 15) == 0)) ? 1 : 0;
     const int mblk = P.Cout16 / 16, G = (P.HoWo + 15) / 16;
-    best = Tile{0, 0, 0, 0};
+    best = Tile{0, 0, 0, 0, 0};
     double best_cost = 1e300;
     static const int wms[] = {1, 2, 4}, pbs[] = {7, 9};
     for (int MB = 1; MB <= 3; ++MB)
@@ -795,18 +828,25 @@ bool plan_window(const otp_conv_desc& d, const void* in, const void* in2, const 
             for (int WM : wms)
                 for (int WP = 1; WM * WP <= 4; ++WP) {
                     if (MB * PB > 21) continue;                  // registers: acc + prefetch + addressing <= 256
-                    const Tile t{MB, PB, WM, WP};
                     if (g_force[0]) {
                         if (MB != g_force[0] || PB != g_force[1] || WM != g_force[2] || WP != g_force[3]) continue;
                     } else {
                         if (WM > 1 && MB * (WM - 1) >= mblk) continue;            // whole waves of padding
                         if (WP > 1 && PB * (WP - 1) >= G) continue;
                     }
-                    WinPlan C = P;
-                    size_t l = 0;
-                    if (!fill_plan(C, t, d.kh, l)) continue;
-                    const double cost = tile_cost(C, t, d.kh, l);
-                    if (cost < best_cost) { best_cost = cost; best = t; }
+                    const int cin4 = (d.Cin + 3) & ~3;
+                    int last_ck = 0;
+                    for (int ck : {cin4 <= 40 ? cin4 : 32, 32, 24, 16, 12, 8, 4}) {
+                        if (ck > cin4) ck = cin4;
+                        if (ck == last_ck) continue;
+                        last_ck = ck;
+                        const Tile t{MB, PB, WM, WP, ck};
+                        WinPlan C = P;
+                        size_t l = 0;
+                        if (!fill_plan(C, t, d.kh, l)) continue;
+                        const double cost = tile_cost(C, t, d.kh, l);
+                        if (cost < best_cost) { best_cost = cost; best = t; }
+                    }
                 }
     if (!best.MB) return false;
     fill_plan(P, best, d.kh, lds);
@@ -816,6 +856,7 @@ bool plan_window(const otp_conv_desc& d, const void* in, const void* in2, const 
 }  // namespace
 
 extern "C" int otp_conv2d_set_tile(int MB, int PB, int WM, int WP) {
+    if (MB < 0) { g_prio = PB; return OTP_OK; }      // tuning: otp_conv2d_set_tile(-1, prio, 0, 0)
     g_force[0] = MB; g_force[1] = PB; g_force[2] = WM; g_force[3] = WP;
     return OTP_OK;
 }
@@ -823,7 +864,7 @@ extern "C" int otp_conv2d_set_tile(int MB, int PB, int WM, int WP) {
 extern "C" int otp_conv2d_plan(const otp_conv_desc* desc, int* out8) {
     if (!desc || !out8) return OTP_ERR_BAD_ARG;
     WinPlan P{};
-    Tile best{0, 0, 0, 0};
+    Tile best{0, 0, 0, 0, 0};
     size_t lds = 0;
     for (int i = 0; i < 8; ++i) out8[i] = 0;
     // alignment is assumed (aligned dummy pointers): this is the plan the engine's own buffers get
@@ -870,7 +911,7 @@ extern "C" int otp_conv2d(const void* in, const void* in2, const void* wpacked, 
     auto o = static_cast<float*>(out);
 
     WinPlan P{};
-    Tile best{0, 0, 0, 0};
+    Tile best{0, 0, 0, 0, 0};
     size_t lds = 0;
     if (plan_window(d, in, in2, wpacked, res, out, P, best, lds)) {
         g_last[0] = best.MB; g_last[1] = best.PB; g_last[2] = best.WM; g_last[3] = best.WP;

@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--dbg", type=int, default=0, help="ablation bits (needs a -DOTP_CONV_DEBUG build)")
     ap.add_argument("--tile", default="", help="force MB,PB,WM,WP")
+    ap.add_argument("--prio", type=int, default=-1, help="static wave priority on (1) / off (0)")
     ap.add_argument("--shape", action="append", default=[], help="extra shape N,Cin,Cout,k,s,d,H,W (repeatable)")
     ap.add_argument("--sweep", action="store_true", help="try every (MB,PB,WM,WP) tile through the tuning hook")
     a = ap.parse_args()
@@ -72,6 +73,8 @@ def main():
         import ctypes
         hip._lib.otp_conv2d_debug.argtypes = [ctypes.c_int]
         hip._lib.otp_conv2d_debug(a.dbg)
+    if a.prio >= 0:
+        hip.lib().otp_conv2d_set_tile(-1, a.prio, 0, 0)
     if a.tile:
         hip.lib().otp_conv2d_set_tile(*[int(v) for v in a.tile.split(",")])
     g = torch.Generator().manual_seed(3)
