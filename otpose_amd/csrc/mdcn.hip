@@ -60,6 +60,20 @@ __device__ __forceinline__ Tap fetch_tap(const float* __restrict__ plane, float 
     return t;
 }
 
+// Forward-only sample: the coordinate is clamped into the zero border ([-1, H] x [-1, W]), where the bilinear blend is
+// exactly zero, so no inside test and no select are needed; inside the image the arithmetic is the reference's
+// (hh*hw*v1 + hh*lw*v2 + lh*hw*v3 + lh*lw*v4, kernel.cu:403-432).  NaN offsets clamp like -inf (value 0).
+__device__ __forceinline__ float sample_zero_border(const float* __restrict__ plane, float h_im, float w_im,
+                                                    const Geom& g) {
+    const float hc = fminf(fmaxf(h_im, -1.f), (float)g.H);
+    const float wc = fminf(fmaxf(w_im, -1.f), (float)g.W);
+    const float hf = fminf(floorf(hc), (float)(g.H - 1)), wf = fminf(floorf(wc), (float)(g.W - 1));
+    const float lh = hc - hf, lw = wc - wf, hh = 1.f - lh, hw = 1.f - lw;
+    const int addr = ((int)hf + 1) * g.LW + (int)wf + PADL;
+    const float v1 = plane[addr], v2 = plane[addr + 1], v3 = plane[addr + g.LW], v4 = plane[addr + g.LW + 1];
+    return hh * hw * v1 + hh * lw * v2 + lh * hw * v3 + lh * lw * v4;
+}
+
 __device__ __forceinline__ float bilinear(const Tap& t) {
     float hh = 1.f - t.lh, hw = 1.f - t.lw;
     return hh * hw * t.v1 + hh * t.lw * t.v2 + t.lh * hw * t.v3 + t.lh * t.lw * t.v4;
@@ -97,21 +111,21 @@ __device__ __forceinline__ void stage_plane(float* __restrict__ plane, const flo
 //        conflict-free LDS gathers for smooth offset fields)
 // K9   : kernel is 3x3 (taps unrolled, offset/mask streams of a plane prefetched into registers)
 template <int CO_T, int VEC, bool K9>
-__global__ __launch_bounds__(FWD_THREADS, 3) void mdcn_fwd_kernel(
+__global__ __launch_bounds__(FWD_THREADS, 2) void mdcn_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ off, const float* __restrict__ msk,
     const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ out, Geom g,
     float alpha, float beta) {
     constexpr int COP = (CO_T + 3) & ~3;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* plane = smem;                    // g.plane floats
-    float* wl = smem + g.plane;             // [C*K][COP] transposed weights, zero where groups differ
+    float* plane = smem;                    // g.plane floats (K9: two buffers, the next plane is written while this one is read)
+    float* wl = smem + (K9 ? 2 : 1) * g.plane;   // [C*K][COP] transposed weights, zero where groups differ
     const int tid = threadIdx.x;
     const int n = blockIdx.y;
     const int co0 = blockIdx.z * CO_T;
     const int nco = min(CO_T, g.Co - co0);
     const int K = K9 ? 9 : g.K;
 
-    zero_plane(plane, g.plane, tid, FWD_THREADS);
+    zero_plane(plane, (K9 ? 2 : 1) * g.plane, tid, FWD_THREADS);
     for (int i = tid; i < g.C * K * COP; i += FWD_THREADS) {
         int ck = i / COP, o = i - ck * COP;
         int c = ck / K, k = ck - c * K;
@@ -150,10 +164,11 @@ __global__ __launch_bounds__(FWD_THREADS, 3) void mdcn_fwd_kernel(
     const int P4 = g.P * 4;
 
     if (K9) {
-        // One "step" = one kernel row (3 taps) of one input plane.  The 9*VEC stream loads of step s+1
-        // are issued before step s is computed, so ~18 dword streams per wave are always in flight.
-        float cur[9][VEC], nxt[9][VEC];
-        auto load_step = [&](float (&dst)[9][VEC], int step) {
+        // One "step" = one kernel row (3 taps) of one input plane.  The 9*VEC stream loads of steps s+1 and s+2 are in
+        // flight while step s is computed: ~27 dword streams per thread keep enough bytes in the air to cover the
+        // HBM round trip at 2-3 waves per SIMD.
+        float r0[9][VEC], r1[9][VEC], r2[9][VEC];
+        auto load_step = [&](float (&dst)[9][VEC], int step) __attribute__((always_inline)) {
             const int c = step / 3, i = step - c * 3;
             const int grp = c / g.cpg_dg;
             const int so = (grp * 18 + 6 * i) * P4, sm = (grp * 9 + 3 * i) * P4;
@@ -166,13 +181,35 @@ __global__ __launch_bounds__(FWD_THREADS, 3) void mdcn_fwd_kernel(
                     dst[3 * j + 2][v] = bload(rmsk, pb[v], sm + j * P4);
                 }
         };
-        const int nsteps = g.C * 3;
-        load_step(cur, 0);
-#pragma unroll 1
-        for (int step = 0; step < nsteps; ++step) {
+        // Plane pipeline: while plane c is gathered out of one LDS buffer, plane c+1 travels global -> registers ->
+        // the other buffer, so a plane change costs one barrier and no exposed memory round trip.  (W % 4 == 0 and
+        // planes of at most MAXQ*256 float4; otherwise the plane is staged in place between two barriers.)
+        constexpr int MAXQ = 8;
+        const int wq = g.W >> 2, nq = g.H * wq;
+        const bool piped = (g.W & 3) == 0 && nq <= MAXQ * FWD_THREADS;
+        otp_f32x4 pq[MAXQ];                                    // (ext-vector type: stays in registers)
+#define OTP_LOAD_PLANE(c_)                                                                                   \
+    {                                                                                                        \
+        const otp_f32x4* s4_ = reinterpret_cast<const otp_f32x4*>(xn + (size_t)(c_) * g.H * g.W);            \
+        _Pragma("unroll") for (int k_ = 0; k_ < MAXQ; ++k_) {                                                \
+            const int i_ = tid + k_ * FWD_THREADS;                                                           \
+            pq[k_] = s4_[i_ < nq ? i_ : 0];              /* unconditional: keeps pq in registers */          \
+        }                                                                                                    \
+    }
+#define OTP_STORE_PLANE(dst_)                                                                                \
+    {                                                                                                        \
+        _Pragma("unroll") for (int k_ = 0; k_ < MAXQ; ++k_) {                                                \
+            const int i_ = tid + k_ * FWD_THREADS;                                                           \
+            if (i_ < nq) {                                                                                   \
+                const int y_ = i_ / wq, xq_ = i_ - y_ * wq;                                                  \
+                *reinterpret_cast<otp_f32x4*>(&(dst_)[(y_ + 1) * g.LW + PADL + 4 * xq_]) = pq[k_];           \
+            }                                                                                                \
+        }                                                                                                    \
+    }
+        auto compute_step = [&](const float (&cur)[9][VEC], int step) __attribute__((always_inline)) {
             const int c = step / 3, i = step - c * 3;
-            if (step + 1 < nsteps) load_step(nxt, step + 1);
-            if (i == 0) {
+            const float* pl = plane + (piped ? (c & 1) * g.plane : 0);
+            if (i == 0 && !piped) {
                 __syncthreads();                               // every wave finished gathering plane c-1
                 stage_plane(plane, xn + (size_t)c * g.H * g.W, g, tid, FWD_THREADS);
                 __syncthreads();
@@ -187,18 +224,52 @@ __global__ __launch_bounds__(FWD_THREADS, 3) void mdcn_fwd_kernel(
                     *reinterpret_cast<float4*>(&wr[4 * q]) = *reinterpret_cast<const float4*>(&wrow[4 * q]);
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) {
-                    Tap t = fetch_tap(plane, (float)(hin[v] + di) + cur[3 * j][v],
-                                      (float)(win[v] + j * g.dil) + cur[3 * j + 1][v], g);
-                    float col = t.inside ? bilinear(t) * cur[3 * j + 2][v] : 0.f;
+                    const float col = sample_zero_border(pl, (float)(hin[v] + di) + cur[3 * j][v],
+                                                         (float)(win[v] + j * g.dil) + cur[3 * j + 1][v], g) *
+                                      cur[3 * j + 2][v];
+                    // packed f32 FMAs (v_pk_fma_f32): two output channels per instruction
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    const f32x2 col2 = {col, col};
 #pragma unroll
-                    for (int o = 0; o < CO_T; ++o) acc[v][o] = fmaf(wr[o], col, acc[v][o]);
+                    for (int o = 0; o + 1 < CO_T; o += 2) {
+                        f32x2 a2 = {acc[v][o], acc[v][o + 1]};
+                        const f32x2 w2 = {wr[o], wr[o + 1]};
+                        a2 = __builtin_elementwise_fma(w2, col2, a2);
+                        acc[v][o] = a2.x;
+                        acc[v][o + 1] = a2.y;
+                    }
+                    if (CO_T & 1) acc[v][CO_T - 1] = fmaf(wr[CO_T - 1], col, acc[v][CO_T - 1]);
                 }
             }
-#pragma unroll
-            for (int q = 0; q < 9; ++q)
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) cur[q][v] = nxt[q][v];
+        };
+        const int nsteps = g.C * 3;                            // a multiple of 3: the rotation below is static
+        load_step(r0, 0);
+        if (nsteps > 1) load_step(r1, 1);
+        if (piped) {
+            OTP_LOAD_PLANE(0)
+            __syncthreads();                                   // borders zeroed, weights staged
+            OTP_STORE_PLANE(plane)
+            __syncthreads();
         }
+#pragma unroll 1
+        for (int step = 0; step < nsteps; step += 3) {         // one trip = one input plane
+            const int c = step / 3;
+            const bool next = piped && c + 1 < g.C;
+            if (next) OTP_LOAD_PLANE(c + 1)                    // in flight during the three steps of plane c
+            if (step + 2 < nsteps) load_step(r2, step + 2);
+            compute_step(r0, step);
+            if (step + 3 < nsteps) load_step(r0, step + 3);
+            if (step + 1 < nsteps) compute_step(r1, step + 1);
+            if (step + 4 < nsteps) load_step(r1, step + 4);
+            if (step + 2 < nsteps) compute_step(r2, step + 2);
+            if (next) {
+                float* other = plane + ((c + 1) & 1) * g.plane;   // last read before the previous barrier
+                OTP_STORE_PLANE(other)
+                __syncthreads();
+            }
+        }
+#undef OTP_LOAD_PLANE
+#undef OTP_STORE_PLANE
     } else {
         for (int c = 0; c < g.C; ++c) {
             const int grp = c / g.cpg_dg;
@@ -399,7 +470,7 @@ template <int CO_T, int VEC, bool K9>
 int launch_fwd(const float* x, const float* off, const float* msk, const float* w, const float* bias,
                float* out, const Geom& g, float alpha, float beta, hipStream_t st) {
     constexpr int COP = (CO_T + 3) & ~3;
-    size_t lds = ((size_t)g.plane + (size_t)g.C * g.K * COP) * sizeof(float);
+    size_t lds = ((size_t)(K9 ? 2 : 1) * g.plane + (size_t)g.C * g.K * COP) * sizeof(float);
     if (lds > OTP_LDS_LIMIT) return OTP_ERR_UNSUPPORTED;
     auto kern = mdcn_fwd_kernel<CO_T, VEC, K9>;
     OTP_ALLOW_BIG_LDS(kern, lds);
@@ -426,8 +497,8 @@ extern "C" int otp_mdcn_forward(const void* x, const void* offset, const void* m
     auto bf = static_cast<const float*>(bias);
     auto outf = static_cast<float*>(out);
     const bool k9 = (kh == 3 && kw == 3);
-    if (k9 && Cout == 17) return launch_fwd<17, 2, true>(xf, of, mf, wf, bf, outf, g, alpha, beta, st);
-    if (k9) return launch_fwd<16, 2, true>(xf, of, mf, wf, bf, outf, g, alpha, beta, st);
+    if (k9 && Cout == 17) return launch_fwd<17, 1, true>(xf, of, mf, wf, bf, outf, g, alpha, beta, st);
+    if (k9) return launch_fwd<16, 1, true>(xf, of, mf, wf, bf, outf, g, alpha, beta, st);
     return launch_fwd<16, 1, false>(xf, of, mf, wf, bf, outf, g, alpha, beta, st);
 }
 
