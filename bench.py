@@ -62,9 +62,21 @@ def event_time_ms(fn, iters, stream):
     return e0.elapsed_time(e1) / iters
 
 
+def measured_traffic(key):
+    """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE / WRITE_SIZE collected
+    in separate passes and corrected as MI355X_MICROARCH.md prescribes; see profiles/r01_traffic.json).  None when the
+    file or the key is absent: PMC counters cannot be read from inside this process."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            return json.load(f).get(key, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
 def kernel_rooflines(dev, batch):
-    """Per-kernel roofline points measured live: the dominant conv launch (MFMA-bound) and one DCN call
-    (HBM-bound), both at the shapes the forward uses."""
+    """Per-kernel roofline points measured live with HIP events on the launch stream: the dominant conv launch
+    (MFMA-bound; 48->48 3x3 on the 96x72 branch, 64 of the 553 conv launches of a forward and the largest single
+    share of its MACs together with the 96->96 twin) and one DCN call (HBM-bound), both at the shapes the forward uses."""
     st = torch.cuda.current_stream(dev)
     g = torch.Generator().manual_seed(7)
     n = 5 * batch
@@ -77,10 +89,16 @@ def kernel_rooflines(dev, batch):
     wp = ops.pack_conv_weight(w)
     d = ops.conv_desc(iv, ov, 48, 3, 3, 1, 1, 1, act=ops.ACT_RELU)
     t_conv = event_time_ms(lambda: ops.conv2d_launch(iv, wp, sc, sh, ov, d), 20, st)
+    import ctypes
+    plan = (ctypes.c_int * 8)()
+    hip.lib().otp_conv2d_last_plan(plan)
     conv_flop = 2.0 * 48 * 48 * 9 * 96 * 72 * n
-    conv = {"kernel": "conv_igemm_kernel<3,9> 48->48 3x3 @96x72 x%d frames" % n, "bound": "mfma",
-            "achieved": conv_flop / (t_conv * 1e-3) / 1e12, "peak": PEAK_F32_MATRIX / 1e12, "unit": "TFLOP/s",
-            "frac": conv_flop / (t_conv * 1e-3) / PEAK_F32_MATRIX, "traffic": None, "ms_per_launch": t_conv}
+    conv = {"kernel": "conv_win_kernel<%d,%d,3,true> 48->48 3x3 @96x72 x%d frames (grid %d x %d threads)"
+                      % (plan[0], plan[1], n, plan[5], 64 * plan[2] * plan[3]),
+            "bound": "mfma", "achieved": conv_flop / (t_conv * 1e-3) / 1e12, "peak": PEAK_F32_MATRIX / 1e12,
+            "unit": "TFLOP/s", "frac": conv_flop / (t_conv * 1e-3) / PEAK_F32_MATRIX,
+            "traffic": measured_traffic("conv_48_48_3x3_96x72_x80"), "ms_per_launch": t_conv,
+            "algorithmic_flop_per_launch": conv_flop}
     # one DCN call (one dilation) over the batch
     xd = torch.randn(batch, 17, 96, 72, generator=g).to(dev)
     off = (torch.randn(batch, 306, 96, 72, generator=g) * 3).to(dev)
@@ -95,9 +113,10 @@ def kernel_rooflines(dev, batch):
                                      batch, 17, 96, 72, 17, 3, 3, 1, 6, 6, 1, 17, 0.2, 0.0, 0, hip.stream_of(xd)), "dcn")
     t_dcn = event_time_ms(dcn, 20, st)
     dcn_bytes = DCN_BYTES_PER_CLIP_DIL * batch
-    dcn_r = {"kernel": "mdcn_fwd_kernel<17,2,true> 17x96x72 x%d clips, one dilation" % batch, "bound": "hbm",
+    dcn_r = {"kernel": "mdcn_fwd_kernel<17,1,true> 17x96x72 x%d clips, one dilation" % batch, "bound": "hbm",
              "achieved": dcn_bytes / (t_dcn * 1e-3) / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
-             "frac": dcn_bytes / (t_dcn * 1e-3) / PEAK_HBM, "traffic": None, "ms_per_launch": t_dcn}
+             "frac": dcn_bytes / (t_dcn * 1e-3) / PEAK_HBM, "traffic": measured_traffic("mdcn_fwd_17x96x72_x16"),
+             "ms_per_launch": t_dcn, "algorithmic_bytes_per_launch": dcn_bytes}
     return conv, dcn_r
 
 
