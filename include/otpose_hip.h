@@ -119,6 +119,16 @@ int otp_upsample_linear(const void* x, void* out, int B, int C, int T, int f, in
 /* y = alpha*x + beta*y over n floats */
 int otp_axpby(const void* x, void* y, float alpha, float beta, size_t n, void* stream);
 
+/* ---- heat-map decode (the step right after the path: utils/heatmap.py:143-171 get_max_preds, :108-132 get_final_preds,
+ * called per iteration at script/Common.py:147,371,424 after a full device-to-host copy) ------------------------------
+ * heatmaps (N,J,H,W) -> preds (N,J,2) = (x, y) of the first maximum times (max > 0), maxvals (N,J).  refine != 0 adds
+ * the reference's +-0.25 px shift towards the higher neighbour (strict 1 < px < W-1, 1 < py < H-1 test included).
+ * center / scale ((N,2) each, both or neither): transform_preds for rot = 0, i.e. the similarity
+ * center + (p - (W/2, H/2)) * 200 * scale_x / W  (utils/transform.py:76-105 feeds cv2.getAffineTransform three points
+ * of exactly that map). */
+int otp_heatmap_decode(const void* heatmaps, void* preds, void* maxvals, const void* center, const void* scale,
+                       int N, int J, int H, int W, int refine, void* stream);
+
 /* ---- heatmap losses (model/loss.py) ------------------------------------------------------------- */
 /* ST_OHKW_MSELoss.forward (loss.py:25-92): s,t,g (B,J,HW), w (B,J); flags (J) int32 in/out: when
  * flags_given == 0 the kernel computes flags[j] = (max_b,p g[b,j,p] == 1) itself; result[0..2] =

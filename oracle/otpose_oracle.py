@@ -430,3 +430,47 @@ def joint_mse_loss(o, g, w):
     B, J = o.shape[:2]
     o, g = o.reshape(B, J, -1), g.reshape(B, J, -1)
     return (((o * w - g * w) ** 2).mean(dim=(0, 2))).sum() / J
+
+
+# ------------------------------------------------------------------------------------------------
+# heat-map decode (the step after the path)
+# ------------------------------------------------------------------------------------------------
+def get_max_preds(hm):
+    """utils/heatmap.py:143-171 (numpy semantics: first maximum, coordinates zeroed where max <= 0)."""
+    import numpy as np
+    hm = np.asarray(hm)
+    n, j, h, w = hm.shape
+    flat = hm.reshape(n, j, -1)
+    idx = np.argmax(flat, 2)
+    maxvals = np.amax(flat, 2).reshape(n, j, 1)
+    preds = np.zeros((n, j, 2), np.float32)
+    preds[:, :, 0] = idx % w
+    preds[:, :, 1] = np.floor(idx / w)
+    preds *= (maxvals > 0.0).astype(np.float32)
+    return preds, maxvals
+
+
+def get_final_preds(hm, center=None, scale=None):
+    """utils/heatmap.py:108-132; transform_preds restated for rot = 0 as the similarity the three points of
+    utils/transform.py:76-105 define (cv2 is not available in this image, so that last step is unpinned)."""
+    import math
+    import numpy as np
+    hm = np.asarray(hm)
+    coords, maxvals = get_max_preds(hm)
+    n, j, h, w = hm.shape
+    for a in range(n):
+        for b in range(j):
+            m = hm[a][b]
+            px = int(math.floor(coords[a][b][0] + 0.5))
+            py = int(math.floor(coords[a][b][1] + 0.5))
+            if 1 < px < w - 1 and 1 < py < h - 1:
+                diff = np.array([m[py][px + 1] - m[py][px - 1], m[py + 1][px] - m[py - 1][px]])
+                coords[a][b] += np.sign(diff) * .25
+    preds = coords.copy()
+    if center is not None:
+        center, scale = np.asarray(center, np.float32), np.asarray(scale, np.float32)
+        for a in range(n):
+            k = 200.0 * scale[a][0] / w
+            preds[a, :, 0] = center[a][0] + (coords[a, :, 0] - 0.5 * w) * k
+            preds[a, :, 1] = center[a][1] + (coords[a, :, 1] - 0.5 * h) * k
+    return preds, maxvals

@@ -68,6 +68,62 @@ __global__ void axpby_kernel(const float* __restrict__ x, float* __restrict__ y,
         y[i] = beta == 0.f ? alpha * x[i] : alpha * x[i] + beta * y[i];
 }
 
+
+// ---- heat-map decode: get_max_preds + the quarter-pixel shift of get_final_preds (utils/heatmap.py:143-171, 108-125) ----
+// One wave per (sample, joint) plane.  argmax = FIRST maximum (numpy argmax), carried through the wavefront
+// reduction as a (value, index) pair; a NaN anywhere makes the first NaN the arg-maximum, as numpy does.
+__device__ __forceinline__ bool better(float v, int i, float bv, int bi) {
+    const bool vn = v != v, bn = bv != bv;
+    if (vn || bn) return vn && (!bn || i < bi);
+    return v > bv || (v == bv && i < bi);
+}
+
+__global__ __launch_bounds__(256) void heatmap_decode_kernel(const float* __restrict__ hm, float* __restrict__ preds,
+                                                              float* __restrict__ maxvals, const float* __restrict__ center,
+                                                              const float* __restrict__ scale, int NJ, int J, int H, int W,
+                                                              int refine) {
+    const int lane = threadIdx.x & 63, plane = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (plane >= NJ) return;
+    const int HW = H * W;
+    const float* p = hm + (size_t)plane * HW;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = lane; i < HW; i += 64) {
+        const float v = p[i];
+        if (bi == 0x7fffffff || better(v, i, bv, bi)) { bv = v; bi = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (oi != 0x7fffffff && (bi == 0x7fffffff || better(ov, oi, bv, bi))) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) {
+        const float m = bv > 0.f ? 1.f : 0.f;                      // pred_mask = maxvals > 0 (NaN -> 0)
+        float x = (float)(bi % W) * m, y = (float)(bi / W) * m;     // idx % width, floor(idx / width)
+        if (refine) {
+            const int px = (int)floorf(x + 0.5f), py = (int)floorf(y + 0.5f);
+            if (1 < px && px < W - 1 && 1 < py && py < H - 1) {      // the reference's strict bounds (heatmap.py:120)
+                const float dx = p[py * W + px + 1] - p[py * W + px - 1];
+                const float dy = p[(py + 1) * W + px] - p[(py - 1) * W + px];
+                x += dx > 0.f ? 0.25f : (dx < 0.f ? -0.25f : 0.f);    // np.sign(diff) * .25
+                y += dy > 0.f ? 0.25f : (dy < 0.f ? -0.25f : 0.f);
+            }
+        }
+        if (center && scale) {
+            // transform_preds with rot = 0: cv2.getAffineTransform of the three points of get_affine_transform(inv=1)
+            // (utils/transform.py:76-105) is the similarity  src = center + (dst - (W/2, H/2)) * (200 * scale_x / W)
+            const int n = plane / J;
+            const float k = 200.f * scale[2 * n] / (float)W;
+            x = center[2 * n] + (x - 0.5f * (float)W) * k;
+            y = center[2 * n + 1] + (y - 0.5f * (float)H) * k;
+        }
+        preds[2 * plane] = x;
+        preds[2 * plane + 1] = y;
+        maxvals[plane] = bv;
+    }
+}
+
 }  // namespace
 
 extern "C" int otp_glue_total(const void* rough, void* total, void* squeezed, void* inter, void* flow_in,
@@ -97,6 +153,17 @@ extern "C" int otp_axpby(const void* x, void* y, float alpha, float beta, size_t
     size_t blocks = (n + 255) / 256;
     hipLaunchKernelGGL(axpby_kernel, dim3(blocks > 2048 ? 2048 : (unsigned)blocks), dim3(256), 0,
                        static_cast<hipStream_t>(stream), static_cast<const float*>(x), static_cast<float*>(y), alpha, beta, n);
+    return otp_launch_status();
+}
+
+extern "C" int otp_heatmap_decode(const void* heatmaps, void* preds, void* maxvals, const void* center, const void* scale,
+                                  int N, int J, int H, int W, int refine, void* stream) {
+    if (!heatmaps || !preds || !maxvals || N <= 0 || J <= 0 || H <= 0 || W <= 0) return OTP_ERR_BAD_ARG;
+    if ((center == nullptr) != (scale == nullptr)) return OTP_ERR_BAD_ARG;
+    const int NJ = N * J;
+    hipLaunchKernelGGL(heatmap_decode_kernel, dim3(otp_ceil_div(NJ, 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const float*>(heatmaps), static_cast<float*>(preds), static_cast<float*>(maxvals),
+                       static_cast<const float*>(center), static_cast<const float*>(scale), NJ, J, H, W, refine);
     return otp_launch_status();
 }
 

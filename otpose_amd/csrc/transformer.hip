@@ -172,29 +172,30 @@ __global__ __launch_bounds__(256) void attn_scores_kernel(const float* __restric
 }
 
 // Phase 2: sum the slabs, scale, row softmax (one wave per row, shuffles for max / sum).
-// P (B*nh, HSP, HSP) with zero padding columns.
+// P (B*nh, HSP, HSP) with zero padding columns.  grid (B*nh, ceil(HSP / 4)): every wave of the chip gets a row
+// (a grid of B*nh workgroups alone left 7/8 of the CUs idle for 120 us).
 __global__ __launch_bounds__(256) void attn_softmax_kernel(const float* __restrict__ slabs, float* __restrict__ P,
                                                             int hs, int HSP, int NS, float scale) {
     const int bh = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.y * 4 + wave;
+    if (row >= HSP) return;
     const float* sb = slabs + (size_t)bh * NS * HSP * HSP;
     float* pb = P + (size_t)bh * HSP * HSP;
-    for (int row = wave; row < HSP; row += 4) {
-        float v[2];
+    float v[2];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int col = lane + 64 * h;
-            float a = 0.f;
-            if (row < hs && col < hs)
-                for (int s = 0; s < NS; ++s) a += sb[((size_t)s * HSP + row) * HSP + col];
-            v[h] = (row < hs && col < hs) ? a * scale : -INFINITY;
-        }
-        const float m = wave_max(fmaxf(v[0], v[1]));
-        float e0 = (row < hs && lane < hs) ? expf(v[0] - m) : 0.f;
-        float e1 = (row < hs && lane + 64 < hs) ? expf(v[1] - m) : 0.f;
-        const float den = wave_sum(e0 + e1);
-        if (lane < HSP) pb[row * HSP + lane] = row < hs ? e0 / den : 0.f;
-        if (lane + 64 < HSP) pb[row * HSP + lane + 64] = row < hs ? e1 / den : 0.f;
+    for (int h = 0; h < 2; ++h) {
+        const int col = lane + 64 * h;
+        float a = 0.f;
+        if (row < hs && col < hs)
+            for (int s = 0; s < NS; ++s) a += sb[((size_t)s * HSP + row) * HSP + col];
+        v[h] = (row < hs && col < hs) ? a * scale : -INFINITY;
     }
+    const float m = wave_max(fmaxf(v[0], v[1]));
+    float e0 = (row < hs && lane < hs) ? expf(v[0] - m) : 0.f;
+    float e1 = (row < hs && lane + 64 < hs) ? expf(v[1] - m) : 0.f;
+    const float den = wave_sum(e0 + e1);
+    if (lane < HSP) pb[row * HSP + lane] = row < hs ? e0 / den : 0.f;
+    if (lane + 64 < HSP) pb[row * HSP + lane + 64] = row < hs ? e1 / den : 0.f;
 }
 
 // Phase 3: O^T[t, i] = sum_j v[j, t] P[i, j], stored as out[bh][t][i] (i contiguous) - exactly the memory
@@ -353,7 +354,7 @@ extern "C" int otp_chan_attn(const void* q, const void* k, const void* v, void* 
 #define OTP_ATT(NB_)                                                                                           \
     {                                                                                                          \
         hipLaunchKernelGGL(attn_scores_kernel<NB_>, g1, dim3(256), 0, st, qf, kf, slabs, hs, T, chunk);        \
-        hipLaunchKernelGGL(attn_softmax_kernel, dim3(BH), dim3(256), 0, st, slabs, P, hs, HSP, NS, scale);     \
+        hipLaunchKernelGGL(attn_softmax_kernel, dim3(BH, otp_ceil_div(HSP, 4)), dim3(256), 0, st, slabs, P, hs, HSP, NS, scale);      \
         auto kern = attn_pv_kernel<NB_>;                                                                       \
         OTP_ALLOW_BIG_LDS(kern, pv_lds);                                                                       \
         hipLaunchKernelGGL(kern, g3, dim3(256), pv_lds, st, vf, P, of, hs, T);                                 \

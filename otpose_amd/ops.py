@@ -275,6 +275,36 @@ def upsample_linear(x, f, out=None, out_coff=0):
     return out
 
 
+def get_max_preds(batch_heatmaps):
+    """Device form of reference utils/heatmap.py:143-171: (N,J,H,W) heat-maps -> (preds (N,J,2), maxvals (N,J,1)),
+    no device-to-host copy of the maps."""
+    return _decode(batch_heatmaps, None, None, refine=False)
+
+
+def get_final_preds(batch_heatmaps, center=None, scale=None):
+    """Device form of reference utils/heatmap.py:108-132: argmax, +-0.25 px shift towards the higher neighbour, and
+    (when ``center`` / ``scale`` (N,2) are given) the rot = 0 inverse crop transform of transform_preds."""
+    return _decode(batch_heatmaps, center, scale, refine=True)
+
+
+def _decode(hm, center, scale, refine):
+    _require_gpu(hm)
+    _check_f32(hm)
+    if hm.dim() != 4:
+        raise AssertionError("batch_images should be 4-ndim")
+    hm = hm.contiguous()
+    n, j, h, w = hm.shape
+    preds = torch.empty((n, j, 2), dtype=torch.float32, device=hm.device)
+    maxvals = torch.empty((n, j, 1), dtype=torch.float32, device=hm.device)
+    c = s_ = None
+    if center is not None:
+        c = torch.as_tensor(center, dtype=torch.float32, device=hm.device).reshape(n, 2).contiguous()
+        s_ = torch.as_tensor(scale, dtype=torch.float32, device=hm.device).reshape(n, 2).contiguous()
+    hip.check(hip.lib().otp_heatmap_decode(hip.ptr(hm), hip.ptr(preds), hip.ptr(maxvals), hip.ptr(c), hip.ptr(s_),
+                                           n, j, h, w, int(refine), hip.stream_of(hm)), "otp_heatmap_decode")
+    return preds, maxvals
+
+
 def st_ohkw_loss(s, t, g, w, topk=8, flags=None, with_grad=False):
     """ST_OHKW_MSELoss forward (+ analytic gradients) on the GPU; returns dict like the reference
     (model/loss.py:89-91) plus ``flags`` and, when requested, ``grad_s`` / ``grad_t``."""

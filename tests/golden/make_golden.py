@@ -171,6 +171,23 @@ def gen_losses():
     save("losses", **out)
 
 
+def gen_decode():
+    """get_max_preds / get_final_preds of the reference (utils/heatmap.py) on seeded maps; transform_preds needs cv2
+    (absent here) and is replaced by the identity, so the vectors pin the argmax and the quarter-pixel shift only."""
+    import_reference()
+    import utils.heatmap as H
+    H.transform_preds = lambda coords, center, scale, output_size: coords
+    hm = seeded((3, 17, 24, 18), 41).numpy().copy()
+    hm[0, 0] = -1.0                                   # all-negative plane: coordinates masked to 0
+    hm[0, 1, 5, 7] = hm[0, 1, 9, 3] = 9.0             # tie: first maximum wins
+    hm[1, 2, 0, 0] = 50.0                             # corner peak: no refinement
+    hm[1, 3, 2, 2] = 50.0                             # px = 2 passes the strict 1 < px test
+    hm[1, 4, 1, 9] = 50.0                             # py = 1 does not
+    p0, m0 = H.get_max_preds(hm.copy())
+    p1, m1 = H.get_final_preds(hm.copy(), [None] * 3, [None] * 3)
+    save("decode", hm=hm, max_preds=p0, maxvals=m0, final_preds=p1)
+
+
 def _e2e(cfg, batch, name, keep_rough=True):
     with torch.no_grad():
         m = ref_otpose(cfg)
@@ -237,7 +254,7 @@ def calibrate():
 
 
 GENS = {"keys": gen_state_dict_keys, "blocks": gen_blocks, "hrnet_tiny": gen_hrnet_tiny,
-        "losses": gen_losses, "e2e_tiny": gen_e2e_tiny, "e2e_cfg1": gen_e2e_cfg1, "e2e_cfg2": gen_e2e_cfg2}
+        "losses": gen_losses, "decode": gen_decode, "e2e_tiny": gen_e2e_tiny, "e2e_cfg1": gen_e2e_cfg1, "e2e_cfg2": gen_e2e_cfg2}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
