@@ -243,10 +243,11 @@ def _mdcn_sample(x, offset, mask, kh, kw, stride, pad, dil, dg):
     cpg = C // dg
     dt = x.dtype
     off = offset.reshape(N, dg, K, 2, Ho, Wo)
-    ki = torch.arange(K) // kw
-    kj = torch.arange(K) % kw
-    hb = (torch.arange(Ho) * stride - pad).to(dt)[None, None, None, :, None]
-    wb = (torch.arange(Wo) * stride - pad).to(dt)[None, None, None, None, :]
+    dev = x.device                       # device-agnostic: also run as the eager-GPU timing baseline (tools/)
+    ki = torch.arange(K, device=dev) // kw
+    kj = torch.arange(K, device=dev) % kw
+    hb = (torch.arange(Ho, device=dev) * stride - pad).to(dt)[None, None, None, :, None]
+    wb = (torch.arange(Wo, device=dev) * stride - pad).to(dt)[None, None, None, None, :]
     hs = hb + (ki * dil).to(dt)[None, None, :, None, None] + off[:, :, :, 0]     # (N, dg, K, Ho, Wo)
     ws = wb + (kj * dil).to(dt)[None, None, :, None, None] + off[:, :, :, 1]
     inside = (hs > -1) & (ws > -1) & (hs < H) & (ws < W)

@@ -204,41 +204,43 @@ __global__ __launch_bounds__(256, 2) void conv_win_kernel(
                 for (int r = 0; r < 4; ++r) ep[(kl * 4 + r) * RS + pb * 16 + i16] = acc[mb][pb][r];
             const int co_base = T.m_wg + m_wave + mb * 16;
             if (P.ep_vec) {
-                // 16 rows x 4*PB float4 = PB float4 per lane, in batches of EB: the loads of a batch (LDS tile,
-                // residual) are all issued before its first store, so a batch costs one memory round trip
-                constexpr int EB = 2;
+                // lane = (row = lane / 4, float4 column = lane % 4 + 4 * it): one output channel per lane, so its
+                // scale / shift are fetched once and the LDS / global offsets advance by constants (64 B per step).
+                // Buffer descriptors over this image's out / res slices: channels past Cout fall off the end and are
+                // dropped by the range check; pixels past Ho*Wo are masked to an out-of-range offset.
+                const int row = lane >> 2, c40 = lane & 3;
+                const float sc = __shfl(sc_l, mb * 16 + row, 64), sh = __shfl(sh_l, mb * 16 + row, 64);
+                const int co = co_base + row;
+                const unsigned obytes = co < P.Cout ? (unsigned)P.HoWo * 4u : 0u;
+                const float* ep_row = ep + row * RS + 4 * c40;
+                const int q_lane = pix_wave + 4 * c40;
+                float* orow = out + ((size_t)T.n * P.out_ctot + P.out_coff + co) * P.HoWo;
+                const float* rrow = res ? res + ((size_t)T.n * P.res_ctot + P.res_coff + co) * P.HoWo : nullptr;
+                constexpr int EB = 2;                  // loads of a batch are issued before its first store
 #pragma unroll
                 for (int it0 = 0; it0 < PB; it0 += EB) {
                     f32x4 v[EB], rv[EB];
 #pragma unroll
                     for (int e = 0; e < EB; ++e) {
                         if (it0 + e < PB) {
-                            const int i = lane + 64 * (it0 + e);
-                            const int row = i / (4 * PB), c4 = i - row * (4 * PB);
-                            const int co = co_base + row, q = pix_wave + 4 * c4;
-                            v[e] = *reinterpret_cast<const f32x4*>(ep + row * RS + 4 * c4);
-                            if (res && co < P.Cout && q < P.HoWo)
-                                rv[e] = *reinterpret_cast<const f32x4*>(
-                                    res + ((size_t)T.n * P.res_ctot + P.res_coff + co) * P.HoWo + q);
+                            const int q = q_lane + 16 * (it0 + e);
+                            v[e] = *reinterpret_cast<const f32x4*>(ep_row + 16 * (it0 + e));
+                            if (res && obytes && q < P.HoWo) rv[e] = *reinterpret_cast<const f32x4*>(rrow + q);
                         }
                     }
 #pragma unroll
                     for (int e = 0; e < EB; ++e) {
                         if (it0 + e < PB) {
-                            const int i = lane + 64 * (it0 + e);
-                            const int row = i / (4 * PB), c4 = i - row * (4 * PB);
-                            const int co = co_base + row, q = pix_wave + 4 * c4;
-                            const float sc = __shfl(sc_l, mb * 16 + row, 64), sh = __shfl(sh_l, mb * 16 + row, 64);
+                            const int q = q_lane + 16 * (it0 + e);
+                            const bool ok = obytes && q < P.HoWo;
                             f32x4 o = v[e] * sc + sh;
-                            const bool ok = co < P.Cout && q < P.HoWo;
                             if (res && ok) o += rv[e];
                             if (P.act == OTP_ACT_RELU) {
                                 o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
                             } else if (P.act == OTP_ACT_GELU) {
                                 o.x = gelu_erf(o.x); o.y = gelu_erf(o.y); o.z = gelu_erf(o.z); o.w = gelu_erf(o.w);
                             }
-                            if (ok)
-                                *reinterpret_cast<f32x4*>(out + ((size_t)T.n * P.out_ctot + P.out_coff + co) * P.HoWo + q) = o;
+                            if (ok) *reinterpret_cast<f32x4*>(orow + q) = o;
                         }
                     }
                 }
