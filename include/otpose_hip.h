@@ -116,6 +116,11 @@ int otp_chan_attn(const void* q, const void* k, const void* v, void* out, void* 
  * channel offset out_coff (f = 1 copies) (ConvVideoTransformer.py:108,179; OTPose.py:362-369) */
 int otp_upsample_linear(const void* x, void* out, int B, int C, int T, int f, int out_ctot, int out_coff, void* stream);
 
+/* out = act(res + nearest_upsample_f(low)) on channel slices (HRNet fuse layers with f >= 4, model/HRNet.py:426-439,
+ * 488-494; `res` may alias `out`); low (N, low_ctot, Hl, Wl), res / out (N, *_ctot, Hl*f, Wl*f); relu != 0 applies ReLU */
+int otp_upsample_add(const void* low, const void* res, void* out, int N, int C, int Hl, int Wl, int f, int relu,
+                     int low_ctot, int low_coff, int res_ctot, int res_coff, int out_ctot, int out_coff, void* stream);
+
 /* y = alpha*x + beta*y over n floats */
 int otp_axpby(const void* x, void* y, float alpha, float beta, size_t n, void* stream);
 

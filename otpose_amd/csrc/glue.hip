@@ -124,6 +124,36 @@ __global__ __launch_bounds__(256) void heatmap_decode_kernel(const float* __rest
     }
 }
 
+// ---- nearest-upsample accumulate: out = act(res + up_f(low)) (HRNet fuse layers, model/HRNet.py:426-439,488-494) --------
+// For f >= 4 the upsampled tensor is f*f >= 16 times larger than the conv result, so the accumulate is a streaming
+// kernel of its own (one float4 of out / res per thread, 256 B per wave-instruction) instead of a conv epilogue.
+__global__ __launch_bounds__(256) void upsample_add_kernel(const float* __restrict__ low, const float* res,
+                                                            float* out, int C, int Hl, int Wl, int f, int relu,
+                                                            int low_ctot, int low_coff, int res_ctot, int res_coff,
+                                                            int out_ctot, int out_coff, size_t total4) {
+    const int Wh = Wl * f, Hh = Hl * f, Wh4 = Wh >> 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        const int x4 = (int)(i % Wh4);
+        size_t r = i / Wh4;
+        const int y = (int)(r % Hh);
+        r /= Hh;
+        const int c = (int)(r % C), n = (int)(r / C);
+        const size_t hi = ((size_t)y * Wh + 4 * x4);
+        const float* lrow = low + (((size_t)n * low_ctot + low_coff + c) * Hl + y / f) * Wl;
+        const otp_f32x4 rv = *reinterpret_cast<const otp_f32x4*>(res + ((size_t)n * res_ctot + res_coff + c) * Hh * Wh + hi);
+        otp_f32x4 o;
+        if (f >= 4) {
+            const float l = lrow[(4 * x4) / f];
+            o = rv + l;
+        } else {                                                     // f == 2: two low-resolution pixels per float4
+            const float l0 = lrow[2 * x4], l1 = lrow[2 * x4 + 1];
+            o = rv + (otp_f32x4){l0, l0, l1, l1};
+        }
+        if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        *reinterpret_cast<otp_f32x4*>(out + ((size_t)n * out_ctot + out_coff + c) * Hh * Wh + hi) = o;
+    }
+}
+
 }  // namespace
 
 extern "C" int otp_glue_total(const void* rough, void* total, void* squeezed, void* inter, void* flow_in,
@@ -153,6 +183,23 @@ extern "C" int otp_axpby(const void* x, void* y, float alpha, float beta, size_t
     size_t blocks = (n + 255) / 256;
     hipLaunchKernelGGL(axpby_kernel, dim3(blocks > 2048 ? 2048 : (unsigned)blocks), dim3(256), 0,
                        static_cast<hipStream_t>(stream), static_cast<const float*>(x), static_cast<float*>(y), alpha, beta, n);
+    return otp_launch_status();
+}
+
+extern "C" int otp_upsample_add(const void* low, const void* res, void* out, int N, int C, int Hl, int Wl, int f, int relu,
+                                int low_ctot, int low_coff, int res_ctot, int res_coff, int out_ctot, int out_coff,
+                                void* stream) {
+    if (!low || !res || !out || N <= 0 || C <= 0 || Hl <= 0 || Wl <= 0) return OTP_ERR_BAD_ARG;
+    if (f != 2 && f != 4 && f != 8 && f != 16) return OTP_ERR_UNSUPPORTED;
+    if ((Wl * f) & 3) return OTP_ERR_UNSUPPORTED;                    // rows of whole float4
+    if (low_ctot < low_coff + C || res_ctot < res_coff + C || out_ctot < out_coff + C) return OTP_ERR_BAD_ARG;
+    if ((reinterpret_cast<uintptr_t>(res) & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) return OTP_ERR_UNSUPPORTED;
+    const size_t total4 = (size_t)N * C * Hl * f * (Wl * f / 4);
+    const size_t blocks = (total4 + 255) / 256;
+    hipLaunchKernelGGL(upsample_add_kernel, dim3(blocks > 8192 ? 8192 : (unsigned)blocks), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), static_cast<const float*>(low), static_cast<const float*>(res),
+                       static_cast<float*>(out), C, Hl, Wl, f, relu, low_ctot, low_coff, res_ctot, res_coff, out_ctot,
+                       out_coff, total4);
     return otp_launch_status();
 }
 

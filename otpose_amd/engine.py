@@ -167,7 +167,17 @@ class InferenceEngine:
                 if j > i:
                     f = 2 ** (j - i)
                     tgt = y if y is not None else View(self.new(*xs[i].t.shape))
-                    y = self.conv_bn(xs[j], fl[0], fl[1], act, res=res, out=tgt, res_up=f)
+                    if f >= 4:
+                        # the upsampled tensor is >= 16x the conv result: conv at low resolution, then one
+                        # streaming accumulate kernel (a conv epilogue would be store-bound on a handful of waves)
+                        low = self.conv_bn(xs[j], fl[0], fl[1], ACT_NONE)
+                        n_, c_, hl, wl = low.t.shape
+                        self.call(self.lib.otp_upsample_add, "otp_upsample_add", hip.ptr(low.t), hip.ptr(res.t),
+                                  hip.ptr(tgt.t), n_, c_, hl, wl, f, int(act == ACT_RELU), low.ctot, low.coff,
+                                  res.ctot, res.coff, tgt.ctot, tgt.coff)
+                        y = tgt
+                    else:
+                        y = self.conv_bn(xs[j], fl[0], fl[1], act, res=res, out=tgt, res_up=f)
                 else:
                     t = xs[j]
                     for k in range(len(fl) - 1):

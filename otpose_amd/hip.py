@@ -49,6 +49,7 @@ SIGNATURES = {
     "otp_chan_attn_workspace": (c_size_t, [c_int] * 4),
     "otp_chan_attn": (c_int, [c_void_p] * 4 + [c_void_p, c_size_t] + [c_int] * 4 + [c_float, c_void_p]),
     "otp_upsample_linear": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "otp_upsample_add": (c_int, [c_void_p] * 3 + [c_int] * 12 + [c_void_p]),
     "otp_axpby": (c_int, [c_void_p, c_void_p, c_float, c_float, c_size_t, c_void_p]),
     "otp_heatmap_decode": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
     "otp_loss_workspace": (c_size_t, [c_int, c_int]),

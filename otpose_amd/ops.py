@@ -230,6 +230,17 @@ def conv2d(x, weight, scale=None, shift=None, stride=1, pad=0, dil=1, act=ACT_NO
     return out
 
 
+def upsample_add(low, res, f, relu=False, out=None):
+    """out = act(res + nearest_upsample_f(low)) (HRNet fuse accumulate for f >= 4); ``out`` may be ``res``."""
+    _require_gpu(low, res)
+    n, c, hl, wl = low.shape
+    if out is None:
+        out = torch.empty_like(res)
+    hip.check(hip.lib().otp_upsample_add(hip.ptr(low), hip.ptr(res), hip.ptr(out), n, c, hl, wl, f, int(relu),
+                                         c, 0, c, 0, c, 0, hip.stream_of(low)), "otp_upsample_add")
+    return out
+
+
 def ln_channel(x, gamma, beta, eps=1e-5, pool=False):
     _require_gpu(x)
     b, c, t = x.shape

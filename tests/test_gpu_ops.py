@@ -107,6 +107,18 @@ def test_conv2d_views_in2_upsample_framesplit():
     _close(out, ref)
 
 
+@pytest.mark.parametrize("f,relu", [(2, True), (4, False), (8, True)])
+def test_upsample_add(f, relu):
+    low = seeded((3, 5, 6, 4), 1)
+    res = seeded((3, 5, 6 * f, 4 * f), 2)
+    ref = res + F.interpolate(low, scale_factor=f, mode="nearest")
+    ref = F.relu(ref) if relu else ref
+    _close(ops.upsample_add(low.cuda(), res.cuda(), f, relu), ref, 1e-6)
+    acc = res.cuda().clone()
+    ops.upsample_add(low.cuda(), acc, f, relu, out=acc)                      # in place, like the fuse layers
+    _close(acc, ref, 1e-6)
+
+
 @pytest.mark.parametrize("c,t", [(136, 300), (17, 77), (200, 65)])
 def test_ln_channel_and_pool(c, t):
     x = seeded((2, c, t), 1, 2.0) + 0.5
