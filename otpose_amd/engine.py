@@ -167,9 +167,9 @@ class InferenceEngine:
                 if j > i:
                     f = 2 ** (j - i)
                     tgt = y if y is not None else View(self.new(*xs[i].t.shape))
-                    if f >= 4:
-                        # the upsampled tensor is >= 16x the conv result: conv at low resolution, then one
-                        # streaming accumulate kernel (a conv epilogue would be store-bound on a handful of waves)
+                    if f >= 2 and (xs[j].t.shape[3] * f) % 4 == 0:
+                        # the upsampled tensor is f*f x the conv result: conv at low resolution, then one streaming
+                        # accumulate kernel (measured faster than the conv kernel's element-wise upsample epilogue)
                         low = self.conv_bn(xs[j], fl[0], fl[1], ACT_NONE)
                         n_, c_, hl, wl = low.t.shape
                         self.call(self.lib.otp_upsample_add, "otp_upsample_add", hip.ptr(low.t), hip.ptr(res.t),
