@@ -125,6 +125,8 @@ template <int NB>                     // NB = HSP / 16 (5 for hs = 68, 2 for hs 
 __global__ __launch_bounds__(256) void attn_scores_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                            float* __restrict__ slabs, int hs, int T, int chunk) {
     constexpr int HSP = NB * 16, NT = NB * NB, TPW = (NT + 3) / 4;
+    // float4 items of one [HSP][64] tile: 16 per row; NQ per thread and matrix
+    constexpr int NQ = (HSP * (ATT_TC / 4) + 255) / 256;
     __shared__ float ql[HSP * ATT_TCP];
     __shared__ float kl[HSP * ATT_TCP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -136,16 +138,52 @@ __global__ __launch_bounds__(256) void attn_scores_kernel(const float* __restric
 #pragma unroll
     for (int i = 0; i < TPW; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int r16 = lane & 15, kk = lane >> 4;
-    for (int t0 = t_begin; t0 < t_end; t0 += ATT_TC) {
-        __syncthreads();
-        for (int idx = tid; idx < HSP * ATT_TC; idx += 256) {
-            int row = idx / ATT_TC, tt = idx - row * ATT_TC;
-            int t = t0 + tt;
-            bool ok = row < hs && t < t_end;
-            ql[row * ATT_TCP + tt] = ok ? qb[(size_t)row * T + t] : 0.f;
-            kl[row * ATT_TCP + tt] = ok ? kb[(size_t)row * T + t] : 0.f;
+    // rows are T floats apart; 16-byte vectors need T % 4 == 0 (and the chunk start is a multiple of 64)
+    const bool vec = (T & 3) == 0 && ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k)) & 15) == 0;
+    f32x4 pq[NQ], pk[NQ];
+    auto load_tile = [&](int t0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const int idx = tid + j * 256;
+            const int row = idx / (ATT_TC / 4), t = t0 + 4 * (idx - row * (ATT_TC / 4));
+            f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+            if (row < hs && idx < HSP * (ATT_TC / 4)) {
+                const float* qp = qb + (size_t)row * T + t;
+                const float* kp = kb + (size_t)row * T + t;
+                if (vec && t + 3 < t_end) {
+                    a = *reinterpret_cast<const f32x4*>(qp);
+                    b = *reinterpret_cast<const f32x4*>(kp);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (t + e < t_end) { a[e] = qp[e]; b[e] = kp[e]; }
+                }
+            }
+            pq[j] = a;
+            pk[j] = b;
         }
+    };
+    auto store_tile = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const int idx = tid + j * 256;
+            if (idx < HSP * (ATT_TC / 4)) {
+                const int row = idx / (ATT_TC / 4), tt = 4 * (idx - row * (ATT_TC / 4));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {                  // pitch ATT_TCP = 66 floats: rows are not 16-byte aligned
+                    ql[row * ATT_TCP + tt + e] = pq[j][e];
+                    kl[row * ATT_TCP + tt + e] = pk[j][e];
+                }
+            }
+        }
+    };
+    // tile pipeline: the global loads of tile i+1 are in flight while tile i is multiplied
+    load_tile(t_begin);
+    for (int t0 = t_begin; t0 < t_end; t0 += ATT_TC) {
+        __syncthreads();                                       // previous tile fully read
+        store_tile();
         __syncthreads();
+        if (t0 + ATT_TC < t_end) load_tile(t0 + ATT_TC);
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
             const int tile = wave + 4 * i;
@@ -215,14 +253,50 @@ __global__ __launch_bounds__(256) void attn_pv_kernel(const float* __restrict__ 
     const int bh = blockIdx.x, t0 = blockIdx.y * PV_TT;
     const float* vb = v + (size_t)bh * hs * T;
     const float* pb = P + (size_t)bh * HSP * HSP;
-    for (int idx = tid; idx < HSP * HSP; idx += 256) {
-        int i = idx / HSP, j = idx - i * HSP;
-        pl[i * PS + j] = pb[idx];
-    }
-    for (int idx = tid; idx < HSP * PV_TT; idx += 256) {
-        int j = idx / PV_TT, tt = idx - j * PV_TT;
-        int t = t0 + tt;
-        vl[j * VS + tt] = (j < hs && t < T) ? vb[(size_t)j * T + t] : 0.f;
+    // 16-byte vector loads, all issued before the first LDS write (one memory round trip for the whole tile)
+    {
+        constexpr int NP4 = (HSP * HSP / 4 + 255) / 256, NV4 = (HSP * (PV_TT / 4) + 255) / 256;
+        const bool vecv = (T & 3) == 0 && (reinterpret_cast<uintptr_t>(v) & 15) == 0;
+        f32x4 rp[NP4], rv[NV4];
+#pragma unroll
+        for (int j = 0; j < NP4; ++j) {
+            const int idx = tid + j * 256;
+            rp[j] = idx < HSP * HSP / 4 ? reinterpret_cast<const f32x4*>(pb)[idx] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < NV4; ++j) {
+            const int idx = tid + j * 256;
+            const int row = idx / (PV_TT / 4), t = t0 + 4 * (idx - row * (PV_TT / 4));
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            if (row < hs && idx < HSP * (PV_TT / 4)) {
+                const float* vp = vb + (size_t)row * T + t;
+                if (vecv && t + 3 < T) {
+                    a = *reinterpret_cast<const f32x4*>(vp);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (t + e < T) a[e] = vp[e];
+                }
+            }
+            rv[j] = a;
+        }
+#pragma unroll
+        for (int j = 0; j < NP4; ++j) {
+            const int idx = tid + j * 256;
+            if (idx < HSP * HSP / 4) {
+                const int i = (4 * idx) / HSP, jj = 4 * idx - i * HSP;    // HSP % 4 == 0: a float4 stays in one row
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pl[i * PS + jj + e] = rp[j][e];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NV4; ++j) {
+            const int idx = tid + j * 256;
+            if (idx < HSP * (PV_TT / 4)) {
+                const int row = idx / (PV_TT / 4), tt = 4 * (idx - row * (PV_TT / 4));
+                *reinterpret_cast<f32x4*>(vl + row * VS + tt) = rv[j];
+            }
+        }
     }
     __syncthreads();
     const int r16 = lane & 15, kk = lane >> 4;
