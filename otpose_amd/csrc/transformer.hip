@@ -67,7 +67,77 @@ __global__ void maxpool3s2_kernel(const float* __restrict__ x, float* __restrict
 }
 
 // ---- three depthwise convs (k=3, pad 1, stride s) each followed by a channel LayerNorm -------------
+// Workgroup = 64 output time steps (lane = time step: 256-byte coalesced rows) x 4 waves that split the channels;
+// every conv output is computed once and kept in registers (CW channels x 3 per lane), the channel statistics are
+// reduced across the four waves through LDS: mean first, then the biased variance of the centred values
+// (the two-pass form of blocks.py:100-103).
+template <int CW>
 __global__ __launch_bounds__(256) void dwconv_ln3_kernel(
+    const float* __restrict__ x, const float* __restrict__ dwq, const float* __restrict__ dwk,
+    const float* __restrict__ dwv, const float* __restrict__ gq, const float* __restrict__ bq,
+    const float* __restrict__ gk, const float* __restrict__ bk, const float* __restrict__ gv,
+    const float* __restrict__ bv, float* __restrict__ q, float* __restrict__ k, float* __restrict__ v,
+    int C, int T, int To, int stride, float eps) {
+    __shared__ float red[3][4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int to = blockIdx.x * 64 + lane;
+    const bool live = to < To;
+    const float* xb = x + (size_t)blockIdx.y * C * T;
+    const size_t ob = (size_t)blockIdx.y * C * To + to;
+    const int t0 = (live ? to : 0) * stride - 1;
+    const bool l_ok = t0 >= 0, r_ok = t0 + 2 < T;
+    const float inv_c = 1.f / (float)C;
+    const int cw = (C + 3) / 4;                 // channels per wave (<= CW)
+    const int cbeg = wave * cw;
+    float dq[CW], dk[CW], dv[CW];
+    float sq = 0.f, sk = 0.f, sv = 0.f;
+#pragma unroll
+    for (int i = 0; i < CW; ++i) {
+        const int c = cbeg + i;
+        dq[i] = dk[i] = dv[i] = 0.f;
+        if (i < cw && c < C) {
+            const float* xr = xb + (size_t)c * T + t0;
+            const float a = l_ok ? xr[0] : 0.f, b = xr[1], cc = r_ok ? xr[2] : 0.f;
+            dq[i] = dwq[c * 3] * a + dwq[c * 3 + 1] * b + dwq[c * 3 + 2] * cc;
+            dk[i] = dwk[c * 3] * a + dwk[c * 3 + 1] * b + dwk[c * 3 + 2] * cc;
+            dv[i] = dwv[c * 3] * a + dwv[c * 3 + 1] * b + dwv[c * 3 + 2] * cc;
+            sq += dq[i]; sk += dk[i]; sv += dv[i];
+        }
+    }
+    red[0][wave][lane] = sq; red[1][wave][lane] = sk; red[2][wave][lane] = sv;
+    __syncthreads();
+    const float mq = (red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane]) * inv_c;
+    const float mk = (red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane]) * inv_c;
+    const float mv = (red[2][0][lane] + red[2][1][lane] + red[2][2][lane] + red[2][3][lane]) * inv_c;
+    __syncthreads();
+    float vq = 0.f, vk = 0.f, vv = 0.f;
+#pragma unroll
+    for (int i = 0; i < CW; ++i) {
+        const int c = cbeg + i;
+        if (i < cw && c < C) {
+            dq[i] -= mq; dk[i] -= mk; dv[i] -= mv;
+            vq += dq[i] * dq[i]; vk += dk[i] * dk[i]; vv += dv[i] * dv[i];
+        }
+    }
+    red[0][wave][lane] = vq; red[1][wave][lane] = vk; red[2][wave][lane] = vv;
+    __syncthreads();
+    const float rq = 1.f / sqrtf((red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane]) * inv_c + eps);
+    const float rk = 1.f / sqrtf((red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane]) * inv_c + eps);
+    const float rv = 1.f / sqrtf((red[2][0][lane] + red[2][1][lane] + red[2][2][lane] + red[2][3][lane]) * inv_c + eps);
+    if (!live) return;
+#pragma unroll
+    for (int i = 0; i < CW; ++i) {
+        const int c = cbeg + i;
+        if (i < cw && c < C) {
+            q[ob + (size_t)c * To] = dq[i] * rq * gq[c] + bq[c];
+            k[ob + (size_t)c * To] = dk[i] * rk * gk[c] + bk[c];
+            v[ob + (size_t)c * To] = dv[i] * rv * gv[c] + bv[c];
+        }
+    }
+}
+
+// any channel count: one thread per time step, three passes over the channels
+__global__ __launch_bounds__(256) void dwconv_ln3_generic_kernel(
     const float* __restrict__ x, const float* __restrict__ dwq, const float* __restrict__ dwk,
     const float* __restrict__ dwv, const float* __restrict__ gq, const float* __restrict__ bq,
     const float* __restrict__ gk, const float* __restrict__ bk, const float* __restrict__ gv,
@@ -80,7 +150,6 @@ __global__ __launch_bounds__(256) void dwconv_ln3_kernel(
     const int t0 = to * stride - 1;
     const bool l_ok = t0 >= 0, r_ok = t0 + 2 < T;
     const float inv_c = 1.f / (float)C;
-    // pass 1: means
     float sq = 0.f, sk = 0.f, sv = 0.f;
     for (int c = 0; c < C; ++c) {
         const float* xr = xb + (size_t)c * T + t0;
@@ -90,7 +159,6 @@ __global__ __launch_bounds__(256) void dwconv_ln3_kernel(
         sv += dwv[c * 3] * a + dwv[c * 3 + 1] * b + dwv[c * 3 + 2] * cc;
     }
     const float mq = sq * inv_c, mk = sk * inv_c, mv = sv * inv_c;
-    // pass 2: biased variances of the centred values (blocks.py:100-103)
     float vq = 0.f, vk = 0.f, vv = 0.f;
     for (int c = 0; c < C; ++c) {
         const float* xr = xb + (size_t)c * T + t0;
@@ -101,7 +169,6 @@ __global__ __launch_bounds__(256) void dwconv_ln3_kernel(
         vq += d1 * d1; vk += d2 * d2; vv += d3 * d3;
     }
     const float rq = 1.f / sqrtf(vq * inv_c + eps), rk = 1.f / sqrtf(vk * inv_c + eps), rv = 1.f / sqrtf(vv * inv_c + eps);
-    // pass 3: write
     for (int c = 0; c < C; ++c) {
         const float* xr = xb + (size_t)c * T + t0;
         const float a = l_ok ? xr[0] : 0.f, b = xr[1], cc = r_ok ? xr[2] : 0.f;
@@ -386,9 +453,16 @@ extern "C" int otp_dwconv_ln3(const void* x, const void* dwq, const void* dwk, c
     if (B <= 0 || C <= 0 || T <= 0 || stride <= 0) return OTP_ERR_BAD_ARG;
     const int To = (T + 2 - 3) / stride + 1;
     auto f = [](const void* p) { return static_cast<const float*>(p); };
-    hipLaunchKernelGGL(dwconv_ln3_kernel, dim3(otp_ceil_div(To, 256), B), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       f(x), f(dwq), f(dwk), f(dwv), f(gq), f(bq), f(gk), f(bk), f(gv), f(bv), static_cast<float*>(q),
-                       static_cast<float*>(k), static_cast<float*>(v), C, T, To, stride, eps);
+    auto st = static_cast<hipStream_t>(stream);
+#define OTP_DW_ARGS f(x), f(dwq), f(dwk), f(dwv), f(gq), f(bq), f(gk), f(bk), f(gv), f(bv), static_cast<float*>(q), \
+                    static_cast<float*>(k), static_cast<float*>(v), C, T, To, stride, eps
+    if (C <= 4 * 5)
+        hipLaunchKernelGGL(dwconv_ln3_kernel<5>, dim3(otp_ceil_div(To, 64), B), dim3(256), 0, st, OTP_DW_ARGS);
+    else if (C <= 4 * 34)
+        hipLaunchKernelGGL(dwconv_ln3_kernel<34>, dim3(otp_ceil_div(To, 64), B), dim3(256), 0, st, OTP_DW_ARGS);
+    else
+        hipLaunchKernelGGL(dwconv_ln3_generic_kernel, dim3(otp_ceil_div(To, 256), B), dim3(256), 0, st, OTP_DW_ARGS);
+#undef OTP_DW_ARGS
     return otp_launch_status();
 }
 
