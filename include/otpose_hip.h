@@ -88,6 +88,39 @@ int otp_conv2d_pack_weight(const void* weight, void* wpacked, int Cout, int Cin,
 int otp_conv2d(const void* in, const void* in2, const void* wpacked, const void* scale, const void* shift,
                const void* res, void* out, const otp_conv_desc* desc, void* stream);
 
+/* ---- training-step building blocks for the convolutional layers (script/Common.py:91,136-144 run the reference under
+ * model.train(): BatchNorm2d uses batch statistics, every conv needs both gradients) -----------------------------
+ * Gradient w.r.t. the input of a stride-1 conv = otp_conv2d of grad_out with the weights packed by
+ * otp_conv2d_pack_weight_dgrad (flipped taps, channels transposed: a Cout -> Cin conv, pad' = dil*(k-1) - pad);
+ * for stride s > 1 grad_out is first zero-inserted to the input resolution with otp_dilate. */
+int otp_conv2d_pack_weight_dgrad(const void* weight, void* wpacked, int Cout, int Cin, int kh, int kw, void* stream);
+/* out (planes, H, W) = 0 except out[:, y*s, x*s] = in[:, y, x]; in (planes, Hi, Wi) */
+int otp_dilate(const void* in, void* out, int planes, int Hi, int Wi, int s, int H, int W, void* stream);
+/* grad_weight (Cout, Cin, kh, kw) += sum over batch and pixels of grad_out x shifted input (ACCUMULATES: zero it first).
+ * x (N, x_ctot, H, W) channels [x_coff, x_coff+Cin); grad_out (N, dy_ctot, Ho, Wo) channels [dy_coff, dy_coff+Cout).
+ * 1x1 and 3x3 kernels, any stride / padding / dilation. */
+int otp_conv2d_wgrad(const void* x, const void* grad_out, void* grad_weight, int N, int Cin, int H, int W, int Cout,
+                     int kh, int kw, int stride, int pad, int dil, int x_ctot, int x_coff, int dy_ctot, int dy_coff,
+                     void* stream);
+/* BatchNorm2d, training mode (torch semantics: biased variance for normalisation, unbiased for running_var,
+ * running = (1-momentum)*running + momentum*batch), fused with the residual add and ReLU that follow it:
+ *   y = relu?( (x - mean_c) * rstd_c * gamma_c + beta_c (+ res) );  save_mean / save_rstd (C) feed the backward.
+ * running_mean / running_var may be NULL.  workspace: otp_bn_workspace bytes. */
+size_t otp_bn_workspace(int N, int C, int HW);
+int otp_bn_train_forward(const void* x, const void* gamma, const void* beta, const void* res, void* y, void* save_mean,
+                         void* save_rstd, void* running_mean, void* running_var, void* workspace, size_t workspace_bytes,
+                         int N, int C, int HW, float eps, float momentum, int relu, int x_ctot, int x_coff, int res_ctot,
+                         int res_coff, int y_ctot, int y_coff, void* stream);
+/* g = grad_y * (y_relu > 0) (y_relu NULL: no ReLU);  grad_res (optional, dense (N,C,HW)) = g;
+ * grad_gamma = sum g*xhat, grad_beta = sum g (overwritten);  grad_x (dense) = gamma*rstd*(g - grad_beta/n - xhat*grad_gamma/n) */
+int otp_bn_train_backward(const void* grad_y, const void* x, const void* y_relu, const void* save_mean,
+                          const void* save_rstd, const void* gamma, void* grad_x, void* grad_res, void* grad_gamma,
+                          void* grad_beta, void* workspace, size_t workspace_bytes, int N, int C, int HW, int dy_ctot,
+                          int dy_coff, int x_ctot, int x_coff, int y_ctot, int y_coff, void* stream);
+/* out[c] = sum over (n, p) of a[n, a_coff + c, p] (conv bias gradients); workspace: otp_bn_workspace + C*4 bytes */
+int otp_channel_sum(const void* a, void* out, void* workspace, size_t workspace_bytes, int N, int C, int HW, int a_ctot,
+                    int a_coff, void* stream);
+
 /* ---- OTPose glue (model/OTPose.py:317-359) ------------------------------------------------------ */
 /* rough (5B,J,HW) -> total (B,J,HW), squeezed (B,J,HW), intersection (B,J,HW), flow_in = total + pe (pe: (J,HW)) */
 int otp_glue_total(const void* rough, void* total, void* squeezed, void* inter, void* flow_in, const void* pe,

@@ -42,6 +42,14 @@ SIGNATURES = {
     "otp_conv2d_set_tile": (c_int, [c_int] * 4),
     "otp_conv2d_last_plan": (c_int, [ctypes.POINTER(c_int)]),
     "otp_conv2d_plan": (c_int, [ctypes.POINTER(ConvDesc), ctypes.POINTER(c_int)]),
+    "otp_conv2d_pack_weight_dgrad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "otp_dilate": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "otp_conv2d_wgrad": (c_int, [c_void_p] * 3 + [c_int] * 14 + [c_void_p]),
+    "otp_bn_workspace": (c_size_t, [c_int] * 3),
+    "otp_bn_train_forward": (c_int, [c_void_p] * 9 + [c_void_p, c_size_t] + [c_int] * 3 + [c_float, c_float] +
+                             [c_int] * 7 + [c_void_p]),
+    "otp_bn_train_backward": (c_int, [c_void_p] * 10 + [c_void_p, c_size_t] + [c_int] * 9 + [c_void_p]),
+    "otp_channel_sum": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t] + [c_int] * 5 + [c_void_p]),
     "otp_glue_total": (c_int, [c_void_p] * 6 + [c_int] * 3 + [c_void_p]),
     "otp_glue_stack": (c_int, [c_void_p] * 10 + [c_int] * 3 + [c_void_p]),
     "otp_ln_channel": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_float, c_void_p]),
