@@ -154,6 +154,35 @@ int otp_upsample_linear(const void* x, void* out, int B, int C, int T, int f, in
 int otp_upsample_add(const void* low, const void* res, void* out, int N, int C, int Hl, int Wl, int f, int relu,
                      int low_ctot, int low_coff, int res_ctot, int res_coff, int out_ctot, int out_coff, void* stream);
 
+/* ---- ConvTransformer backward pieces (training step; model/blocks.py:95-110,234-254,359-381,400-453) -------------
+ * Channel attention backward is assembled on the host side from these (otpose_amd/train_ops.py): with O^T = the
+ * transposed-contiguous image otp_chan_attn writes, dO = transpose(d_out), dP = dO v^T (scores + slab sum),
+ * dS = softmax'(P, dP), dq = scale * dS k, dk = scale * dS^T q, dv = P^T dO (three otp_chan_attn_apply + transposes). */
+int otp_chan_attn_splits(int BH, int T);
+int otp_chan_attn_scores(const void* a, const void* b, void* slabs, int BH, int hs, int T, void* stream);
+int otp_chan_attn_apply(const void* v, const void* M, void* out, int BH, int hs, int T, void* stream);
+/* per batch: in (R, Cc) row-major -> out (Cc, R) row-major times scale */
+int otp_transpose_scale(const void* in, void* out, int batches, int R, int Cc, float scale, void* stream);
+/* slabs (BH, NS, HSP, HSP) partial dP, P (BH, HSP, HSP) -> dS, dS^T, P^T (BH, HSP, HSP), HSP = hs rounded up to 16 */
+int otp_softmax_backward(const void* slabs, const void* P, void* dS, void* dST, void* PT, int BH, int hs, int NS,
+                         void* stream);
+/* channel LayerNorm backward: grad_x, and dy_xhat = grad_y * xhat so that grad_gamma = otp_channel_sum(dy_xhat),
+ * grad_beta = otp_channel_sum(grad_y) */
+int otp_ln_channel_backward(const void* x, const void* grad_y, const void* gamma, void* grad_x, void* dy_xhat, int B, int C,
+                            int T, float eps, void* stream);
+/* depthwise Conv1d(C, C, 3, stride, padding 1, groups C, bias False): w (C,3); grad_w is ACCUMULATED into */
+int otp_dwconv3_forward(const void* x, const void* w, void* y, int B, int C, int T, int stride, void* stream);
+int otp_dwconv3_backward(const void* x, const void* w, const void* grad_y, void* grad_x, void* grad_w, int B, int C, int T,
+                         int stride, void* stream);
+int otp_gelu_forward(const void* x, void* y, size_t n, void* stream);
+int otp_gelu_backward(const void* x, const void* grad_y, void* grad_x, size_t n, void* stream);
+/* MaxPool1d(3, 2, 1) on `rows` rows of length T; backward sends the gradient to the first maximum of each window */
+int otp_maxpool3s2_forward(const void* x, void* y, int rows, int T, void* stream);
+int otp_maxpool3s2_backward(const void* x, const void* grad_y, void* grad_x, int rows, int T, void* stream);
+/* backward of otp_upsample_linear: grad_out is the channel slice [out_coff, out_coff+C) of a (B, out_ctot, T*f) tensor */
+int otp_upsample_linear_backward(const void* grad_out, void* grad_x, int B, int C, int T, int f, int out_ctot, int out_coff,
+                                 void* stream);
+
 /* y = alpha*x + beta*y over n floats */
 int otp_axpby(const void* x, void* y, float alpha, float beta, size_t n, void* stream);
 

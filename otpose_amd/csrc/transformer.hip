@@ -512,6 +512,58 @@ extern "C" int otp_chan_attn(const void* q, const void* k, const void* v, void* 
     return otp_launch_status();
 }
 
+// ---- pieces of the channel attention exposed for its backward (otpose_amd/train_ops.py) -------------------------
+// number of T-splits / score slabs the kernels use for (BH, T), and where otp_chan_attn leaves P inside its workspace
+extern "C" int otp_chan_attn_splits(int BH, int T) { return (BH > 0 && T > 0) ? attn_splits(BH, T) : 0; }
+
+// slabs[bh][s] (HSP x HSP, zero padded) = partial a . b^T over the s-th slice of T, no scale: sum the slabs for a . b^T
+extern "C" int otp_chan_attn_scores(const void* a, const void* b, void* slabs, int BH, int hs, int T, void* stream) {
+    if (!a || !b || !slabs || BH <= 0 || hs <= 0 || T <= 0) return OTP_ERR_BAD_ARG;
+    const int HSP = (hs + 15) & ~15, NB = HSP / 16;
+    if (NB != 5 && NB != 2 && NB != 1) return OTP_ERR_UNSUPPORTED;
+    const int NS = attn_splits(BH, T);
+    const int chunk = otp_ceil_div(otp_ceil_div(T, NS), ATT_TC) * ATT_TC;
+    auto st = static_cast<hipStream_t>(stream);
+    dim3 g1(BH, NS);
+    auto af = static_cast<const float*>(a);
+    auto bf = static_cast<const float*>(b);
+    auto sf = static_cast<float*>(slabs);
+    if (NB == 5) hipLaunchKernelGGL(attn_scores_kernel<5>, g1, dim3(256), 0, st, af, bf, sf, hs, T, chunk);
+    else if (NB == 2) hipLaunchKernelGGL(attn_scores_kernel<2>, g1, dim3(256), 0, st, af, bf, sf, hs, T, chunk);
+    else hipLaunchKernelGGL(attn_scores_kernel<1>, g1, dim3(256), 0, st, af, bf, sf, hs, T, chunk);
+    return otp_launch_status();
+}
+
+// out[bh][t][i] = sum_j M[bh][i][j] * v[bh][j][t]   (M: HSP x HSP zero padded; the transposed-contiguous output image)
+extern "C" int otp_chan_attn_apply(const void* v, const void* M, void* out, int BH, int hs, int T, void* stream) {
+    if (!v || !M || !out || BH <= 0 || hs <= 0 || T <= 0) return OTP_ERR_BAD_ARG;
+    const int HSP = (hs + 15) & ~15, NB = HSP / 16;
+    if (NB != 5 && NB != 2 && NB != 1) return OTP_ERR_UNSUPPORTED;
+    auto st = static_cast<hipStream_t>(stream);
+    const size_t pv_lds = ((size_t)HSP * (HSP + 2) + (size_t)HSP * (PV_TT + 16)) * sizeof(float);
+    dim3 g3(BH, otp_ceil_div(T, PV_TT));
+    auto vf = static_cast<const float*>(v);
+    auto mf = static_cast<const float*>(M);
+    auto of = static_cast<float*>(out);
+#define OTP_APPLY(NB_)                                                          \
+    {                                                                           \
+        auto kern = attn_pv_kernel<NB_>;                                        \
+        OTP_ALLOW_BIG_LDS(kern, pv_lds);                                        \
+        hipLaunchKernelGGL(kern, g3, dim3(256), pv_lds, st, vf, mf, of, hs, T); \
+    }
+    if (NB == 5) OTP_APPLY(5) else if (NB == 2) OTP_APPLY(2) else OTP_APPLY(1)
+#undef OTP_APPLY
+    return otp_launch_status();
+}
+
+extern "C" int otp_maxpool3s2_forward(const void* x, void* y, int rows, int T, void* stream) {
+    if (!x || !y || rows <= 0 || T <= 0) return OTP_ERR_BAD_ARG;
+    const int To = (T + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(maxpool3s2_kernel, dim3(otp_ceil_div(To, 256), rows), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const float*>(x), static_cast<float*>(y), T, To);
+    return otp_launch_status();
+}
+
 extern "C" int otp_upsample_linear(const void* x, void* out, int B, int C, int T, int f, int out_ctot, int out_coff,
                                    void* stream) {
     if (!x || !out || B <= 0 || C <= 0 || T <= 0 || f <= 0 || out_ctot < out_coff + C) return OTP_ERR_BAD_ARG;

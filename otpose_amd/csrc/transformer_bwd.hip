@@ -1,0 +1,300 @@
+// Backward kernels of the ConvTransformer pieces (training step; forward counterparts in transformer.hip):
+// channel LayerNorm, depthwise k=3 conv (forward + both gradients), exact-erf GELU, MaxPool1d(3,2,1), linear
+// up-sampling, and the helpers the channel-attention backward is assembled from (layout transpose, slab sum,
+// softmax backward).  Reference: model/blocks.py:95-110, 234-254, 359-381, 400-453; ConvVideoTransformer.py:108.
+// All tensors (B, C, T) fp32 with T contiguous; a thread owns one time step, so wave accesses are 256-byte rows.
+#include "common.h"
+
+namespace {
+
+// ---- channel LayerNorm backward ------------------------------------------------------------------------
+// dx = r * (dyg - mean_c(dyg) - xhat * mean_c(dyg * xhat)), dyg = dy * gamma;  dyxh = dy * xhat is written out so that
+// dgamma = channel_sum(dyxh), dbeta = channel_sum(dy) (otp_channel_sum)
+__global__ __launch_bounds__(256) void ln_channel_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                              const float* __restrict__ gamma, float* __restrict__ dx,
+                                                              float* __restrict__ dyxh, int C, int T, float eps) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const size_t base = (size_t)blockIdx.y * C * T + t;
+    const float inv_c = 1.f / (float)C;
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += x[base + (size_t)c * T];
+    const float mu = s * inv_c;
+    float q = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float d = x[base + (size_t)c * T] - mu;
+        q += d * d;
+    }
+    const float r = 1.f / sqrtf(q * inv_c + eps);
+    float m1 = 0.f, m2 = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float xh = (x[base + (size_t)c * T] - mu) * r, g = dy[base + (size_t)c * T] * gamma[c];
+        m1 += g;
+        m2 += g * xh;
+    }
+    m1 *= inv_c;
+    m2 *= inv_c;
+    for (int c = 0; c < C; ++c) {
+        const float xh = (x[base + (size_t)c * T] - mu) * r, d = dy[base + (size_t)c * T];
+        dx[base + (size_t)c * T] = r * (d * gamma[c] - m1 - xh * m2);
+        dyxh[base + (size_t)c * T] = d * xh;
+    }
+}
+
+// ---- depthwise conv, k = 3, pad 1, stride s, no bias ------------------------------------------------------
+__global__ void dwconv3_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int C,
+                                   int T, int To, int stride) {
+    const int to = blockIdx.x * blockDim.x + threadIdx.x;
+    if (to >= To) return;
+    const int c = blockIdx.y % C;
+    const float* xr = x + (size_t)blockIdx.y * T;
+    const int t0 = to * stride - 1;
+    const float a = t0 >= 0 ? xr[t0] : 0.f, b = xr[t0 + 1], cc = t0 + 2 < T ? xr[t0 + 2] : 0.f;
+    y[(size_t)blockIdx.y * To + to] = w[c * 3] * a + w[c * 3 + 1] * b + w[c * 3 + 2] * cc;
+}
+
+// dx[t] = sum_k w[k] * dy[to] over the outputs with to*s - 1 + k == t
+__global__ void dwconv3_bwd_x_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
+                                     int C, int T, int To, int stride) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const int c = blockIdx.y % C;
+    const float* dr = dy + (size_t)blockIdx.y * To;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int num = t + 1 - k;                 // to * stride
+        if (num >= 0 && num % stride == 0 && num / stride < To) s += w[c * 3 + k] * dr[num / stride];
+    }
+    dx[(size_t)blockIdx.y * T + t] = s;
+}
+
+// dw[c][k] = sum_{b, to} dy[b,c,to] * x[b,c,to*s-1+k]; grid (C, splits), accumulated with atomics (dw zeroed by the caller)
+__global__ __launch_bounds__(256) void dwconv3_bwd_w_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                             float* __restrict__ dw, int B, int C, int T, int To,
+                                                             int stride) {
+    __shared__ float red[3][4];
+    const int c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t total = (size_t)B * To;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (size_t i = (size_t)blockIdx.y * 256 + threadIdx.x; i < total; i += (size_t)gridDim.y * 256) {
+        const int b = (int)(i / To), to = (int)(i - (size_t)b * To);
+        const float* xr = x + ((size_t)b * C + c) * T;
+        const float g = dy[((size_t)b * C + c) * To + to];
+        const int t0 = to * stride - 1;
+        if (t0 >= 0) s0 += g * xr[t0];
+        s1 += g * xr[t0 + 1];
+        if (t0 + 2 < T) s2 += g * xr[t0 + 2];
+    }
+    s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if (lane == 0) { red[0][wave] = s0; red[1][wave] = s1; red[2][wave] = s2; }
+    __syncthreads();
+    if (threadIdx.x < 3)
+        atomicAdd(&dw[c * 3 + threadIdx.x], red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+// ---- GELU (exact erf) --------------------------------------------------------------------------------------
+__global__ void gelu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        y[i] = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+    }
+}
+__global__ void gelu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752440f));
+        const float pdf = 0.39894228040143267794f * expf(-0.5f * v * v);
+        dx[i] = dy[i] * (cdf + v * pdf);
+    }
+}
+
+// ---- MaxPool1d(kernel 3, stride 2, padding 1) backward: the gradient goes to the FIRST maximum of each window ---------
+__device__ __forceinline__ int pool_argmax(const float* xr, int to, int T) {
+    const int t = 2 * to;
+    int best = t - 1 >= 0 ? t - 1 : t;
+    float bv = xr[best];
+    if (best != t && xr[t] > bv) { bv = xr[t]; best = t; }
+    if (t + 1 < T && xr[t + 1] > bv) best = t + 1;
+    return best;
+}
+__global__ void maxpool3s2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+                                      int T, int To) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const float* xr = x + (size_t)blockIdx.y * T;
+    const float* dr = dy + (size_t)blockIdx.y * To;
+    float s = 0.f;
+    // windows containing t: to = t/2 (t even or odd) and, for odd t, also (t+1)/2
+    const int a = t >> 1;
+    if (a < To && pool_argmax(xr, a, T) == t) s += dr[a];
+    if (t & 1) {
+        const int b = (t + 1) >> 1;
+        if (b < To && pool_argmax(xr, b, T) == t) s += dr[b];
+    }
+    dx[(size_t)blockIdx.y * T + t] = s;
+}
+
+// ---- nn.Upsample(scale f, linear, align_corners=False) backward: dy is a channel slice of a wider tensor -------------
+__global__ void upsample_linear_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int C, int T, int f,
+                                           int dy_ctot, int dy_coff) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T) return;
+    const int c = blockIdx.y % C, b = blockIdx.y / C;
+    const int To = T * f;
+    const float* dr = dy + ((size_t)b * dy_ctot + dy_coff + c) * To;
+    float s = 0.f;
+    if (f == 1) {
+        s = dr[i];
+    } else {
+        const int lo = max(0, f * i - f), hi = min(To - 1, f * i + 2 * f);
+        for (int to = lo; to <= hi; ++to) {
+            float src = ((float)to + 0.5f) * (1.f / (float)f) - 0.5f;
+            src = src < 0.f ? 0.f : src;
+            const int i0 = (int)src;
+            const int i1 = i0 + (i0 < T - 1 ? 1 : 0);
+            const float l1 = src - (float)i0, l0 = 1.f - l1;
+            if (i0 == i) s += l0 * dr[to];
+            if (i1 == i) s += l1 * dr[to];
+        }
+    }
+    dx[((size_t)b * C + c) * T + i] = s;
+}
+
+// ---- attention backward helpers ------------------------------------------------------------------------
+// per (b, head): in (R, Cc) row-major -> out (Cc, R) row-major, scaled (the O <-> out.transpose(2,3).contiguous() image)
+__global__ void transpose_scale_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int Cc, float scale) {
+    __shared__ float tile[32][33];
+    const float* ib = in + (size_t)blockIdx.z * R * Cc;
+    float* ob = out + (size_t)blockIdx.z * R * Cc;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        const int r = r0 + j, c = c0 + threadIdx.x;
+        tile[j][threadIdx.x] = (r < R && c < Cc) ? ib[(size_t)r * Cc + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        const int c = c0 + j, r = r0 + threadIdx.x;
+        if (c < Cc && r < R) ob[(size_t)c * R + r] = tile[threadIdx.x][j] * scale;
+    }
+}
+
+// dP = sum of the NS score slabs (padded HSP x HSP); dS = P o (dP - rowsum(dP o P)); also writes dS^T and P^T
+__global__ __launch_bounds__(64) void softmax_bwd_kernel(const float* __restrict__ slabs, const float* __restrict__ P,
+                                                          float* __restrict__ dS, float* __restrict__ dST,
+                                                          float* __restrict__ PT, int hs, int HSP, int NS) {
+    const int bh = blockIdx.x, row = blockIdx.y, lane = threadIdx.x;
+    const float* sb = slabs + (size_t)bh * NS * HSP * HSP;
+    const float* pb = P + (size_t)bh * HSP * HSP;
+    float dp[2], pv[2], acc = 0.f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int col = lane + 64 * h;
+        dp[h] = 0.f;
+        pv[h] = 0.f;
+        if (row < hs && col < hs) {
+            for (int s = 0; s < NS; ++s) dp[h] += sb[((size_t)s * HSP + row) * HSP + col];
+            pv[h] = pb[row * HSP + col];
+        }
+        acc += dp[h] * pv[h];
+    }
+    acc = wave_sum(acc);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int col = lane + 64 * h;
+        if (col < HSP) {
+            const float v = (row < hs && col < hs) ? pv[h] * (dp[h] - acc) : 0.f;
+            dS[((size_t)bh * HSP + row) * HSP + col] = v;
+            dST[((size_t)bh * HSP + col) * HSP + row] = v;
+            PT[((size_t)bh * HSP + col) * HSP + row] = (row < hs && col < hs) ? pv[h] : 0.f;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int otp_ln_channel_backward(const void* x, const void* grad_y, const void* gamma, void* grad_x, void* dy_xhat,
+                                       int B, int C, int T, float eps, void* stream) {
+    if (!x || !grad_y || !gamma || !grad_x || !dy_xhat || B <= 0 || C <= 0 || T <= 0) return OTP_ERR_BAD_ARG;
+    hipLaunchKernelGGL(ln_channel_bwd_kernel, dim3(otp_ceil_div(T, 256), B), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const float*>(x), static_cast<const float*>(grad_y), static_cast<const float*>(gamma),
+                       static_cast<float*>(grad_x), static_cast<float*>(dy_xhat), C, T, eps);
+    return otp_launch_status();
+}
+
+extern "C" int otp_dwconv3_forward(const void* x, const void* w, void* y, int B, int C, int T, int stride, void* stream) {
+    if (!x || !w || !y || B <= 0 || C <= 0 || T <= 0 || stride <= 0) return OTP_ERR_BAD_ARG;
+    const int To = (T + 2 - 3) / stride + 1;
+    hipLaunchKernelGGL(dwconv3_fwd_kernel, dim3(otp_ceil_div(To, 256), B * C), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const float*>(x), static_cast<const float*>(w), static_cast<float*>(y), C, T, To, stride);
+    return otp_launch_status();
+}
+
+extern "C" int otp_dwconv3_backward(const void* x, const void* w, const void* grad_y, void* grad_x, void* grad_w, int B,
+                                    int C, int T, int stride, void* stream) {
+    if (!x || !w || !grad_y || !grad_x || !grad_w || B <= 0 || C <= 0 || T <= 0 || stride <= 0) return OTP_ERR_BAD_ARG;
+    const int To = (T + 2 - 3) / stride + 1;
+    auto st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(dwconv3_bwd_x_kernel, dim3(otp_ceil_div(T, 256), B * C), dim3(256), 0, st,
+                       static_cast<const float*>(grad_y), static_cast<const float*>(w), static_cast<float*>(grad_x), C, T, To,
+                       stride);
+    int splits = 1;
+    while (C * splits < 1024 && (size_t)B * To / (splits * 2) >= 1024) splits *= 2;
+    hipLaunchKernelGGL(dwconv3_bwd_w_kernel, dim3(C, splits), dim3(256), 0, st, static_cast<const float*>(x),
+                       static_cast<const float*>(grad_y), static_cast<float*>(grad_w), B, C, T, To, stride);
+    return otp_launch_status();
+}
+
+extern "C" int otp_gelu_forward(const void* x, void* y, size_t n, void* stream) {
+    if (!x || !y) return OTP_ERR_BAD_ARG;
+    if (n == 0) return OTP_OK;
+    const size_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(gelu_fwd_kernel, dim3(blocks > 8192 ? 8192 : (unsigned)blocks), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), static_cast<const float*>(x), static_cast<float*>(y), n);
+    return otp_launch_status();
+}
+
+extern "C" int otp_gelu_backward(const void* x, const void* grad_y, void* grad_x, size_t n, void* stream) {
+    if (!x || !grad_y || !grad_x) return OTP_ERR_BAD_ARG;
+    if (n == 0) return OTP_OK;
+    const size_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3(blocks > 8192 ? 8192 : (unsigned)blocks), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), static_cast<const float*>(x), static_cast<const float*>(grad_y),
+                       static_cast<float*>(grad_x), n);
+    return otp_launch_status();
+}
+
+extern "C" int otp_maxpool3s2_backward(const void* x, const void* grad_y, void* grad_x, int rows, int T, void* stream) {
+    if (!x || !grad_y || !grad_x || rows <= 0 || T <= 0) return OTP_ERR_BAD_ARG;
+    const int To = (T + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(maxpool3s2_bwd_kernel, dim3(otp_ceil_div(T, 256), rows), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const float*>(x), static_cast<const float*>(grad_y), static_cast<float*>(grad_x), T, To);
+    return otp_launch_status();
+}
+
+extern "C" int otp_upsample_linear_backward(const void* grad_out, void* grad_x, int B, int C, int T, int f, int out_ctot,
+                                            int out_coff, void* stream) {
+    if (!grad_out || !grad_x || B <= 0 || C <= 0 || T <= 0 || f <= 0 || out_ctot < out_coff + C) return OTP_ERR_BAD_ARG;
+    hipLaunchKernelGGL(upsample_linear_bwd_kernel, dim3(otp_ceil_div(T, 256), B * C), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), static_cast<const float*>(grad_out), static_cast<float*>(grad_x), C, T,
+                       f, out_ctot, out_coff);
+    return otp_launch_status();
+}
+
+extern "C" int otp_transpose_scale(const void* in, void* out, int batches, int R, int Cc, float scale, void* stream) {
+    if (!in || !out || batches <= 0 || R <= 0 || Cc <= 0) return OTP_ERR_BAD_ARG;
+    hipLaunchKernelGGL(transpose_scale_kernel, dim3(otp_ceil_div(Cc, 32), otp_ceil_div(R, 32), batches), dim3(32, 8), 0,
+                       static_cast<hipStream_t>(stream), static_cast<const float*>(in), static_cast<float*>(out), R, Cc, scale);
+    return otp_launch_status();
+}
+
+extern "C" int otp_softmax_backward(const void* slabs, const void* P, void* dS, void* dST, void* PT, int BH, int hs, int NS,
+                                    void* stream) {
+    if (!slabs || !P || !dS || !dST || !PT || BH <= 0 || hs <= 0 || NS <= 0) return OTP_ERR_BAD_ARG;
+    const int HSP = (hs + 15) & ~15;
+    if (HSP > 128) return OTP_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(softmax_bwd_kernel, dim3(BH, HSP), dim3(64), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const float*>(slabs), static_cast<const float*>(P), static_cast<float*>(dS),
+                       static_cast<float*>(dST), static_cast<float*>(PT), hs, HSP, NS);
+    return otp_launch_status();
+}

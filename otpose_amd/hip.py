@@ -56,6 +56,19 @@ SIGNATURES = {
     "otp_dwconv_ln3": (c_int, [c_void_p] * 13 + [c_int] * 4 + [c_float, c_void_p]),
     "otp_chan_attn_workspace": (c_size_t, [c_int] * 4),
     "otp_chan_attn": (c_int, [c_void_p] * 4 + [c_void_p, c_size_t] + [c_int] * 4 + [c_float, c_void_p]),
+    "otp_chan_attn_splits": (c_int, [c_int, c_int]),
+    "otp_chan_attn_scores": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p]),
+    "otp_chan_attn_apply": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p]),
+    "otp_transpose_scale": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
+    "otp_softmax_backward": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_void_p]),
+    "otp_ln_channel_backward": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_float, c_void_p]),
+    "otp_dwconv3_forward": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),
+    "otp_dwconv3_backward": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
+    "otp_gelu_forward": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "otp_gelu_backward": (c_int, [c_void_p] * 3 + [c_size_t, c_void_p]),
+    "otp_maxpool3s2_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "otp_maxpool3s2_backward": (c_int, [c_void_p] * 3 + [c_int, c_int, c_void_p]),
+    "otp_upsample_linear_backward": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "otp_upsample_linear": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "otp_upsample_add": (c_int, [c_void_p] * 3 + [c_int] * 12 + [c_void_p]),
     "otp_axpby": (c_int, [c_void_p, c_void_p, c_float, c_float, c_size_t, c_void_p]),

@@ -148,3 +148,207 @@ class BatchNormReluFunction(Function):
 
 def batch_norm_relu(x, gamma, beta, res=None, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, relu=True):
     return BatchNormReluFunction.apply(x, gamma, beta, res, running_mean, running_var, momentum, eps, relu)
+
+
+# ------------------------------------------------------------------------------------------------
+# ConvTransformer pieces (reference model/blocks.py), tensors (B, C, T)
+# ------------------------------------------------------------------------------------------------
+def _chan_sum3(t):
+    b, c, n = t.shape
+    return channel_sum(t.reshape(b, c, 1, n))
+
+
+class LayerNormFunction(Function):
+    """Channel LayerNorm of (B, C, T) (model/blocks.py:95-110): biased variance over C, weight / bias (C)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        _require_gpu(x)
+        _check_f32(x)
+        x = x.contiguous()
+        b, c, t = x.shape
+        y = torch.empty_like(x)
+        g, be = gamma.reshape(-1).contiguous(), beta.reshape(-1).contiguous()
+        hip.check(hip.lib().otp_ln_channel(hip.ptr(x), hip.ptr(g), hip.ptr(be), hip.ptr(y), None, b, c, t, eps,
+                                           hip.stream_of(x)), "otp_ln_channel")
+        ctx.save_for_backward(x, g)
+        ctx.eps, ctx.pshape = eps, gamma.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, g = ctx.saved_tensors
+        gy = gy.contiguous()
+        b, c, t = x.shape
+        gx, dyxh = torch.empty_like(x), torch.empty_like(x)
+        hip.check(hip.lib().otp_ln_channel_backward(hip.ptr(x), hip.ptr(gy), hip.ptr(g), hip.ptr(gx), hip.ptr(dyxh), b, c, t,
+                                                    ctx.eps, hip.stream_of(x)), "otp_ln_channel_backward")
+        return gx, _chan_sum3(dyxh).reshape(ctx.pshape), _chan_sum3(gy).reshape(ctx.pshape), None
+
+
+def layer_norm(x, gamma, beta, eps=1e-5):
+    return LayerNormFunction.apply(x, gamma, beta, eps)
+
+
+class DwConv3Function(Function):
+    """``F.conv1d(x, w (C,1,3), None, stride, 1, 1, groups=C)`` (model/blocks.py:359-381)."""
+
+    @staticmethod
+    def forward(ctx, x, w, stride):
+        _require_gpu(x, w)
+        x, w = x.contiguous(), w.contiguous()
+        b, c, t = x.shape
+        to = (t + 2 - 3) // stride + 1
+        y = torch.empty((b, c, to), dtype=torch.float32, device=x.device)
+        hip.check(hip.lib().otp_dwconv3_forward(hip.ptr(x), hip.ptr(w), hip.ptr(y), b, c, t, stride, hip.stream_of(x)),
+                  "otp_dwconv3_forward")
+        ctx.save_for_backward(x, w)
+        ctx.stride = stride
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        b, c, t = x.shape
+        gx, gw = torch.empty_like(x), torch.zeros_like(w)
+        hip.check(hip.lib().otp_dwconv3_backward(hip.ptr(x), hip.ptr(w), hip.ptr(gy.contiguous()), hip.ptr(gx), hip.ptr(gw),
+                                                 b, c, t, ctx.stride, hip.stream_of(x)), "otp_dwconv3_backward")
+        return gx, gw, None
+
+
+def dwconv3(x, w, stride=1):
+    return DwConv3Function.apply(x, w, stride)
+
+
+class GeluFunction(Function):
+    @staticmethod
+    def forward(ctx, x):
+        _require_gpu(x)
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        hip.check(hip.lib().otp_gelu_forward(hip.ptr(x), hip.ptr(y), x.numel(), hip.stream_of(x)), "otp_gelu_forward")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        gx = torch.empty_like(x)
+        hip.check(hip.lib().otp_gelu_backward(hip.ptr(x), hip.ptr(gy.contiguous()), hip.ptr(gx), x.numel(),
+                                              hip.stream_of(x)), "otp_gelu_backward")
+        return gx
+
+
+gelu = GeluFunction.apply
+
+
+class MaxPool3s2Function(Function):
+    """``nn.MaxPool1d(3, 2, 1)`` on (B, C, T) (model/blocks.py:234-238)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _require_gpu(x)
+        x = x.contiguous()
+        b, c, t = x.shape
+        y = torch.empty((b, c, (t + 2 - 3) // 2 + 1), dtype=torch.float32, device=x.device)
+        hip.check(hip.lib().otp_maxpool3s2_forward(hip.ptr(x), hip.ptr(y), b * c, t, hip.stream_of(x)),
+                  "otp_maxpool3s2_forward")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        b, c, t = x.shape
+        gx = torch.empty_like(x)
+        hip.check(hip.lib().otp_maxpool3s2_backward(hip.ptr(x), hip.ptr(gy.contiguous()), hip.ptr(gx), b * c, t,
+                                                    hip.stream_of(x)), "otp_maxpool3s2_backward")
+        return gx
+
+
+maxpool3s2 = MaxPool3s2Function.apply
+
+
+class UpsampleLinearFunction(Function):
+    """``nn.Upsample(scale_factor=f, mode='linear', align_corners=False)`` on (B, C, T)."""
+
+    @staticmethod
+    def forward(ctx, x, f):
+        _require_gpu(x)
+        x = x.contiguous()
+        b, c, t = x.shape
+        y = torch.empty((b, c, t * f), dtype=torch.float32, device=x.device)
+        hip.check(hip.lib().otp_upsample_linear(hip.ptr(x), hip.ptr(y), b, c, t, f, c, 0, hip.stream_of(x)),
+                  "otp_upsample_linear")
+        ctx.f, ctx.shape = f, (b, c, t)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        b, c, t = ctx.shape
+        gy = gy.contiguous()
+        gx = torch.empty((b, c, t), dtype=torch.float32, device=gy.device)
+        hip.check(hip.lib().otp_upsample_linear_backward(hip.ptr(gy), hip.ptr(gx), b, c, t, ctx.f, c, 0,
+                                                         hip.stream_of(gy)), "otp_upsample_linear_backward")
+        return gx, None
+
+
+def upsample_linear(x, f):
+    return UpsampleLinearFunction.apply(x, f)
+
+
+class ChanAttnFunction(Function):
+    """Channel attention of model/blocks.py:427-447: per (b, head) S = (q*scale) k^T (hs x hs, contraction over T),
+    P = softmax(S), O = P v, returned in the ``transpose(2,3).contiguous().view(B, C, T)`` memory image."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, n_head, scale):
+        _require_gpu(q, k, v)
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        b, c, t = q.shape
+        L = hip.lib()
+        nbytes = L.otp_chan_attn_workspace(b, c, t, n_head)
+        ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=q.device)
+        out = torch.empty_like(q)
+        hip.check(L.otp_chan_attn(hip.ptr(q), hip.ptr(k), hip.ptr(v), hip.ptr(out), hip.ptr(ws), nbytes, b, c, t, n_head,
+                                  scale, hip.stream_of(q)), "otp_chan_attn")
+        bh, hs = b * n_head, c // n_head
+        hsp = (hs + 15) // 16 * 16
+        ns = L.otp_chan_attn_splits(bh, t)
+        p = ws[bh * ns * hsp * hsp: bh * ns * hsp * hsp + bh * hsp * hsp].clone()     # softmax matrix, zero padded
+        ctx.save_for_backward(q, k, v, p)
+        ctx.cfg = (n_head, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        q, k, v, p = ctx.saved_tensors
+        n_head, scale = ctx.cfg
+        b, c, t = q.shape
+        bh, hs = b * n_head, c // n_head
+        hsp = (hs + 15) // 16 * 16
+        L = hip.lib()
+        st = hip.stream_of(q)
+        dev = q.device
+        new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)       # noqa: E731
+        gout = gout.contiguous()
+        d_o = new(bh, hs, t)                                   # dO[bh][i][t] from the [bh][t][i] image
+        hip.check(L.otp_transpose_scale(hip.ptr(gout), hip.ptr(d_o), bh, t, hs, 1.0, st), "otp_transpose_scale")
+        ns = L.otp_chan_attn_splits(bh, t)
+        slabs = new(bh * ns * hsp * hsp)
+        hip.check(L.otp_chan_attn_scores(hip.ptr(d_o), hip.ptr(v), hip.ptr(slabs), bh, hs, t, st), "otp_chan_attn_scores")
+        d_s, d_st, p_t = new(bh, hsp, hsp), new(bh, hsp, hsp), new(bh, hsp, hsp)
+        hip.check(L.otp_softmax_backward(hip.ptr(slabs), hip.ptr(p), hip.ptr(d_s), hip.ptr(d_st), hip.ptr(p_t), bh, hs, ns,
+                                         st), "otp_softmax_backward")
+        tmp = new(bh, t, hs)
+        grads = []
+        for src, mat, sc in ((k, d_s, scale), (q, d_st, scale), (d_o, p_t, 1.0)):
+            hip.check(L.otp_chan_attn_apply(hip.ptr(src), hip.ptr(mat), hip.ptr(tmp), bh, hs, t, st), "otp_chan_attn_apply")
+            g = new(b, c, t)
+            hip.check(L.otp_transpose_scale(hip.ptr(tmp), hip.ptr(g), bh, t, hs, sc, st), "otp_transpose_scale")
+            grads.append(g)
+        return grads[0], grads[1], grads[2], None, None
+
+
+def chan_attn(q, k, v, n_head, scale):
+    return ChanAttnFunction.apply(q, k, v, n_head, scale)

@@ -127,3 +127,66 @@ def test_full_size_wgrad_properties():
     wc = torch.zeros(48, 48, 3, 3, requires_grad=True)
     F.conv2d(xc, wc, None, 1, 1).backward(go[:1].cpu())
     _close(T.conv2d_grad_weight(x[:1], go[:1], (48, 48, 3, 3), 1, 1, 1), wc.grad, 2e-4)
+
+
+# ---- ConvTransformer pieces vs torch autograd -----------------------------------------------------------------
+def _grads(fn, inputs, go):
+    leaves = [t.clone().requires_grad_() for t in inputs]
+    out = fn(*leaves)
+    out.backward(go)
+    return out.detach(), [t.grad for t in leaves]
+
+
+def _check_op(ref_fn, hip_fn, inputs, tol=1e-4):
+    out_ref = ref_fn(*inputs)
+    go = seeded(out_ref.shape, 99)
+    ref_out, ref_g = _grads(ref_fn, inputs, go)
+    out, g = _grads(hip_fn, [t.cuda() for t in inputs], go.cuda())
+    _close(out, ref_out, tol)
+    for a, b in zip(g, ref_g):
+        _close(a, b, tol)
+
+
+@pytest.mark.parametrize("c,t", [(136, 300), (17, 77)])
+def test_layer_norm_backward(c, t):
+    from otpose_amd import train_ops as T
+    x, g, b = seeded((3, c, t), 1) * 2 + 0.3, 1 + 0.1 * seeded((1, c, 1), 2), seeded((1, c, 1), 3)
+
+    def ref(x, g, b):
+        mu = x.mean(1, keepdim=True)
+        r = x - mu
+        return r / torch.sqrt((r ** 2).mean(1, keepdim=True) + 1e-5) * g + b
+    _check_op(ref, lambda x, g, b: T.layer_norm(x, g, b, 1e-5), [x, g, b])
+
+
+@pytest.mark.parametrize("stride", [1, 2])
+def test_dwconv3_backward(stride):
+    from otpose_amd import train_ops as T
+    x, w = seeded((2, 40, 101), 1), seeded((40, 1, 3), 2, 0.5)
+    _check_op(lambda x, w: F.conv1d(x, w, None, stride, 1, 1, 40), lambda x, w: T.dwconv3(x, w, stride), [x, w])
+
+
+def test_gelu_maxpool_upsample_backward():
+    from otpose_amd import train_ops as T
+    x = seeded((2, 17, 96), 1) * 2
+    _check_op(F.gelu, T.gelu, [x])
+    _check_op(lambda t: F.max_pool1d(t, 3, 2, 1), T.maxpool3s2, [x])
+    _check_op(lambda t: F.max_pool1d(t, 3, 2, 1), T.maxpool3s2, [seeded((2, 5, 77), 2)])
+    for f in (2, 4):
+        _check_op(lambda t: F.interpolate(t, scale_factor=f, mode="linear", align_corners=False),
+                  lambda t: T.upsample_linear(t, f), [seeded((2, 9, 60), 3)])
+
+
+@pytest.mark.parametrize("c,nh,t", [(136, 2, 520), (17, 1, 300), (34, 2, 70)])
+def test_chan_attn_backward(c, nh, t):
+    from otpose_amd import train_ops as T
+    hs = c // nh
+    scale = 1.0 / math.sqrt(hs)
+    q, k, v = seeded((2, c, t), 1) * 0.3, seeded((2, c, t), 2) * 0.3, seeded((2, c, t), 3)
+
+    def ref(q, k, v):
+        b = q.shape[0]
+        qq, kk, vv = (z.view(b, nh, hs, -1) for z in (q, k, v))
+        att = F.softmax((qq * scale) @ kk.transpose(-2, -1), dim=-1)
+        return (att @ vv).transpose(2, 3).contiguous().view(b, c, -1)
+    _check_op(ref, lambda q, k, v: T.chan_attn(q, k, v, nh, scale), [q, k, v], 2e-4)
