@@ -183,6 +183,11 @@ int otp_maxpool3s2_backward(const void* x, const void* grad_y, void* grad_x, int
 int otp_upsample_linear_backward(const void* grad_out, void* grad_x, int B, int C, int T, int f, int out_ctot, int out_coff,
                                  void* stream);
 
+/* backward of otp_upsample_add on dense (planes, Hl*f, Wl*f) tensors: g = grad_out * (out_relu > 0) (out_relu NULL: no ReLU),
+ * grad_res (optional) = g, grad_low (planes, Hl, Wl) = sum of g over each f x f cell */
+int otp_upsample_add_backward(const void* grad_out, const void* out_relu, void* grad_res, void* grad_low, int planes, int Hl,
+                              int Wl, int f, void* stream);
+
 /* y = alpha*x + beta*y over n floats */
 int otp_axpby(const void* x, void* y, float alpha, float beta, size_t n, void* stream);
 
@@ -202,6 +207,11 @@ int otp_heatmap_decode(const void* heatmaps, void* preds, void* maxvals, const v
  * {ohkm_loss_s, mse_loss_s, final_loss}.  grad_s / grad_t (optional, may be NULL) receive
  * d final_loss / d s and d final_loss / d t. */
 size_t otp_loss_workspace(int B, int J);
+/* the same with d final_loss / d g as well (the second criterion call of script/Common.py:128-130 feeds a target that
+ * depends on the model); grad_s / grad_t / grad_g each optional */
+int otp_loss_st_ohkw_grads(const void* s, const void* t, const void* g, const void* w, void* flags, void* result,
+                           void* grad_s, void* grad_t, void* grad_g, void* workspace, size_t workspace_bytes, int B, int J,
+                           int HW, int topk, int flags_given, void* stream);
 int otp_loss_st_ohkw(const void* s, const void* t, const void* g, const void* w, void* flags,
                      void* result, void* grad_s, void* grad_t, void* workspace, size_t workspace_bytes,
                      int B, int J, int HW, int topk, int flags_given, void* stream);

@@ -154,6 +154,49 @@ __global__ __launch_bounds__(256) void upsample_add_kernel(const float* __restri
     }
 }
 
+// the same, one element per thread (rows that are not whole float4)
+__global__ __launch_bounds__(256) void upsample_add_scalar_kernel(const float* __restrict__ low, const float* res, float* out,
+                                                                   int C, int Hl, int Wl, int f, int relu, int low_ctot,
+                                                                   int low_coff, int res_ctot, int res_coff, int out_ctot,
+                                                                   int out_coff, size_t total) {
+    const int Wh = Wl * f, Hh = Hl * f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % Wh);
+        size_t r = i / Wh;
+        const int y = (int)(r % Hh);
+        r /= Hh;
+        const int c = (int)(r % C), n = (int)(r / C);
+        const size_t hi = (size_t)y * Wh + x;
+        float v = res[((size_t)n * res_ctot + res_coff + c) * Hh * Wh + hi] +
+                  low[(((size_t)n * low_ctot + low_coff + c) * Hl + y / f) * Wl + x / f];
+        if (relu) v = fmaxf(v, 0.f);
+        out[((size_t)n * out_ctot + out_coff + c) * Hh * Wh + hi] = v;
+    }
+}
+
+// backward of out = relu?(res + up_f(low)): g = dy * (out > 0 if relu); grad_res = g; grad_low = sum of g over each f x f cell
+__global__ __launch_bounds__(256) void upsample_add_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ out_relu,
+                                                                float* __restrict__ dres, float* __restrict__ dlow, int Hl,
+                                                                int Wl, int f, size_t total_low) {
+    const int Wh = Wl * f, Hh = Hl * f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_low; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % Wl);
+        size_t r = i / Wl;
+        const int y = (int)(r % Hl);
+        const size_t plane = r / Hl;
+        float s = 0.f;
+        for (int dyy = 0; dyy < f; ++dyy)
+            for (int dxx = 0; dxx < f; ++dxx) {
+                const size_t o = (plane * Hh + (size_t)y * f + dyy) * Wh + (size_t)x * f + dxx;
+                float g = dy[o];
+                if (out_relu && !(out_relu[o] > 0.f)) g = 0.f;
+                if (dres) dres[o] = g;
+                s += g;
+            }
+        dlow[i] = s;
+    }
+}
+
 }  // namespace
 
 extern "C" int otp_glue_total(const void* rough, void* total, void* squeezed, void* inter, void* flow_in,
@@ -190,16 +233,35 @@ extern "C" int otp_upsample_add(const void* low, const void* res, void* out, int
                                 int low_ctot, int low_coff, int res_ctot, int res_coff, int out_ctot, int out_coff,
                                 void* stream) {
     if (!low || !res || !out || N <= 0 || C <= 0 || Hl <= 0 || Wl <= 0) return OTP_ERR_BAD_ARG;
-    if (f != 2 && f != 4 && f != 8 && f != 16) return OTP_ERR_UNSUPPORTED;
-    if ((Wl * f) & 3) return OTP_ERR_UNSUPPORTED;                    // rows of whole float4
+    if (f < 1) return OTP_ERR_BAD_ARG;
     if (low_ctot < low_coff + C || res_ctot < res_coff + C || out_ctot < out_coff + C) return OTP_ERR_BAD_ARG;
-    if ((reinterpret_cast<uintptr_t>(res) & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) return OTP_ERR_UNSUPPORTED;
+    const bool vec = (f == 2 || f == 4 || f == 8 || f == 16) && ((Wl * f) & 3) == 0 &&
+                     !(reinterpret_cast<uintptr_t>(res) & 15) && !(reinterpret_cast<uintptr_t>(out) & 15);
+    if (!vec) {
+        const size_t total = (size_t)N * C * Hl * f * Wl * f, nb = (total + 255) / 256;
+        hipLaunchKernelGGL(upsample_add_scalar_kernel, dim3(nb > 8192 ? 8192 : (unsigned)nb), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), static_cast<const float*>(low), static_cast<const float*>(res),
+                           static_cast<float*>(out), C, Hl, Wl, f, relu, low_ctot, low_coff, res_ctot, res_coff, out_ctot,
+                           out_coff, total);
+        return otp_launch_status();
+    }
     const size_t total4 = (size_t)N * C * Hl * f * (Wl * f / 4);
     const size_t blocks = (total4 + 255) / 256;
     hipLaunchKernelGGL(upsample_add_kernel, dim3(blocks > 8192 ? 8192 : (unsigned)blocks), dim3(256), 0,
                        static_cast<hipStream_t>(stream), static_cast<const float*>(low), static_cast<const float*>(res),
                        static_cast<float*>(out), C, Hl, Wl, f, relu, low_ctot, low_coff, res_ctot, res_coff, out_ctot,
                        out_coff, total4);
+    return otp_launch_status();
+}
+
+extern "C" int otp_upsample_add_backward(const void* grad_out, const void* out_relu, void* grad_res, void* grad_low,
+                                         int planes, int Hl, int Wl, int f, void* stream) {
+    if (!grad_out || !grad_low || planes <= 0 || Hl <= 0 || Wl <= 0 || f <= 0) return OTP_ERR_BAD_ARG;
+    const size_t total = (size_t)planes * Hl * Wl, blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(upsample_add_bwd_kernel, dim3(blocks > 8192 ? 8192 : (unsigned)blocks), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), static_cast<const float*>(grad_out),
+                       static_cast<const float*>(out_relu), static_cast<float*>(grad_res), static_cast<float*>(grad_low), Hl, Wl,
+                       f, total);
     return otp_launch_status();
 }
 

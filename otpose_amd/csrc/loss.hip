@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restric
 
 __global__ void loss_grad_kernel(const float* __restrict__ s, const float* __restrict__ t, const float* __restrict__ g,
                                  const float* __restrict__ w, const float* __restrict__ coef, float* __restrict__ gs,
-                                 float* __restrict__ gt, int HW) {
+                                 float* __restrict__ gt, float* __restrict__ gg, int HW) {
     const int bj = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= HW) return;
     const size_t i = (size_t)bj * HW + p;
@@ -113,6 +113,7 @@ __global__ void loss_grad_kernel(const float* __restrict__ s, const float* __res
     const float cg = coef[bj * 2], ct = coef[bj * 2 + 1];
     if (gs) gs[i] = wt * (cg * dg + ct * dt);
     if (gt) gt[i] = -wt * ct * dt;
+    if (gg) gg[i] = -wt * cg * dg;              // the 2nd criterion call's target depends on the model (Common.py:128-130)
 }
 
 }  // namespace
@@ -122,8 +123,8 @@ extern "C" size_t otp_loss_workspace(int B, int J) {
     return (size_t)B * J * 5 * sizeof(float);
 }
 
-extern "C" int otp_loss_st_ohkw(const void* s, const void* t, const void* g, const void* w, void* flags, void* result,
-                                void* grad_s, void* grad_t, void* workspace, size_t workspace_bytes, int B, int J,
+extern "C" int otp_loss_st_ohkw_grads(const void* s, const void* t, const void* g, const void* w, void* flags, void* result,
+                                void* grad_s, void* grad_t, void* grad_g, void* workspace, size_t workspace_bytes, int B, int J,
                                 int HW, int topk, int flags_given, void* stream) {
     if (!s || !t || !g || !w || !flags || !result || !workspace || B <= 0 || J <= 0 || HW <= 0 || topk <= 0 || topk > J)
         return OTP_ERR_BAD_ARG;
@@ -134,12 +135,19 @@ extern "C" int otp_loss_st_ohkw(const void* s, const void* t, const void* g, con
     auto f = [](const void* p) { return static_cast<const float*>(p); };
     float* stats = static_cast<float*>(workspace);
     float* coef = stats + (size_t)B * J * 3;
-    const bool want_grad = grad_s || grad_t;
+    const bool want_grad = grad_s || grad_t || grad_g;
     hipLaunchKernelGGL(loss_stats_kernel, dim3(B * J), dim3(256), 0, st, f(s), f(t), f(g), f(w), stats, HW);
     hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), lds, st, stats, static_cast<int*>(flags),
                        static_cast<float*>(result), want_grad ? coef : nullptr, B, J, HW, topk, flags_given);
     if (want_grad)
         hipLaunchKernelGGL(loss_grad_kernel, dim3(otp_ceil_div(HW, 256), B * J), dim3(256), 0, st, f(s), f(t), f(g), f(w),
-                           coef, static_cast<float*>(grad_s), static_cast<float*>(grad_t), HW);
+                           coef, static_cast<float*>(grad_s), static_cast<float*>(grad_t), static_cast<float*>(grad_g), HW);
     return otp_launch_status();
+}
+
+extern "C" int otp_loss_st_ohkw(const void* s, const void* t, const void* g, const void* w, void* flags, void* result,
+                                void* grad_s, void* grad_t, void* workspace, size_t workspace_bytes, int B, int J,
+                                int HW, int topk, int flags_given, void* stream) {
+    return otp_loss_st_ohkw_grads(s, t, g, w, flags, result, grad_s, grad_t, nullptr, workspace, workspace_bytes, B, J, HW,
+                                  topk, flags_given, stream);
 }

@@ -57,9 +57,10 @@ constexpr int WG_CO = 48, WG_CI = 48, WG_GROUPS = 7;
 struct WgradPlan {
     int N, Cin, H, W, Cout, KS, stride, pad, dil, Ho, Wo;
     int x_ctot, x_coff, dy_ctot, dy_coff;
-    int RT, PT, PS;           // output rows / pixels per tile, dY row pitch (floats, PS % 32 == 2)
-    int NRX, LWP, CSX;        // staged input rows, padded row pitch, channel stride (CSX % 32 == 2)
-    int tiles_per_img, ntiles;
+    int RT, WT, PT, PS;       // output rows x columns per tile, pixels (rounded to 4), dY row pitch (PS % 32 == 2)
+    int NRX, LWP, CSX;        // staged input rows, staged row pitch, channel stride (CSX % 32 == 2)
+    int sparse;               // dilated kernels: stage only the KS rows a tap row touches per output row (r = ti*RT + yl)
+    int tiles_x, tiles_per_img, ntiles;
 };
 
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
@@ -83,25 +84,27 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restr
 
     // pixel -> input offset table (tile-invariant: local row * stride * LWP + column * stride)
     for (int p = tid; p < P.PT; p += 256) {
-        const int yl = p / P.Wo, xq = p - yl * P.Wo;
-        poff[p] = yl < P.RT ? yl * P.stride * P.LWP + xq * P.stride : 0;   // rounding pixels: any staged (finite) word
+        const int yl = p / P.WT, xq = p - yl * P.WT;
+        poff[p] = yl < P.RT ? yl * (P.sparse ? 1 : P.stride) * P.LWP + xq * P.stride : 0;   // rounding pixels: any staged word
     }
 
     for (int tile = blockIdx.x; tile < P.ntiles; tile += gridDim.x) {
         const int n = tile / P.tiles_per_img;
-        const int y0 = (tile - n * P.tiles_per_img) * P.RT;            // first output row of the tile
-        const int rows = min(P.RT, P.Ho - y0);
+        const int tin = tile - n * P.tiles_per_img;
+        const int yb = tin / P.tiles_x, xb = tin - yb * P.tiles_x;
+        const int y0 = yb * P.RT, x0 = xb * P.WT;                      // first output row / column of the tile
+        const int rows = min(P.RT, P.Ho - y0), cols = min(P.WT, P.Wo - x0);
         __syncthreads();                                               // previous tile fully consumed
         // ---- stage dY rows: [co][p], zero past the image rows / channels --------------------------------------
         {
             const otp_rsrc rdy = make_rsrc32(dy + ((size_t)n * P.dy_ctot + P.dy_coff) * P.Ho * P.Wo,
                                              (unsigned)P.Cout * (unsigned)(P.Ho * P.Wo) * 4u);
-            const int valid_px = rows * P.Wo;
             for (int i = tid; i < WG_CO * P.PT; i += 256) {
                 const int c = i / P.PT, p = i - c * P.PT;
+                const int yl = p / P.WT, xq = p - yl * P.WT;
                 const int co = co0 + c;
-                const int voff = (co < P.Cout && p < valid_px) ? (co * P.Ho * P.Wo + y0 * P.Wo + p) * 4 : -1;
-                dys[c * P.PS + p] = bload(rdy, voff, 0);
+                const bool ok = co < P.Cout && yl < rows && xq < cols;
+                dys[c * P.PS + p] = bload(rdy, ok ? (co * P.Ho * P.Wo + (y0 + yl) * P.Wo + x0 + xq) * 4 : -1, 0);
             }
         }
         // ---- stage the input rows with a zero halo: [ci][r][col], col 0 = image column -pad ------------------
@@ -113,14 +116,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restr
             for (int i = tid; i < WG_CI * per_c; i += 256) {
                 const int c = i / per_c, rem = i - c * per_c;
                 const int r = rem / P.LWP, col = rem - r * P.LWP;
-                const int yy = r0 + r, xx = col - P.pad, ci = ci0 + c;
+                const int yy = P.sparse ? (y0 + r % P.RT) * P.stride - P.pad + (r / P.RT) * P.dil : r0 + r;
+                const int xx = x0 * P.stride - P.pad + col, ci = ci0 + c;
                 const bool ok = ci < P.Cin && yy >= 0 && yy < P.H && xx >= 0 && xx < P.W;
                 xs[c * P.CSX + rem] = bload(rx, ok ? (ci * P.H * P.W + yy * P.W + xx) * 4 : -1, 0);
             }
         }
         __syncthreads();
         // ---- MFMA over the tile's pixels --------------------------------------------------------------------
-        const int steps = (rows * P.Wo + 3) >> 2;
+        const int steps = (rows * P.WT + 3) >> 2;
 #pragma unroll
         for (int g = 0; g < WG_GROUPS; ++g) {
             const int grp = wave + 4 * g;
@@ -128,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restr
                 const int tap = grp / 3, cb = grp - tap * 3;
                 const int ti = tap / P.KS, tj = tap - ti * P.KS;
                 const float* arow = dys + (cb * 16 + i16) * P.PS + kl;
-                const float* brow = xs + i16 * P.CSX + ti * P.dil * P.LWP + tj * P.dil;
+                const float* brow = xs + i16 * P.CSX + ti * (P.sparse ? P.RT : P.dil) * P.LWP + tj * P.dil;
 #pragma unroll 2
                 for (int s = 0; s < steps; ++s) {
                     const int p = 4 * s + kl;
@@ -325,20 +329,24 @@ extern "C" int otp_conv2d_wgrad(const void* x, const void* grad_out, void* grad_
     if (P.Ho <= 0 || P.Wo <= 0) return OTP_ERR_BAD_ARG;
     if ((long)Cin * H * W >= (1l << 29) || (long)Cout * P.Ho * P.Wo >= (1l << 29)) return OTP_ERR_UNSUPPORTED;
     P.x_ctot = x_ctot; P.x_coff = x_coff; P.dy_ctot = dy_ctot; P.dy_coff = dy_coff;
-    P.LWP = W + 2 * pad;
-    // rows per tile: as many as fit ~72 KB of LDS (two workgroups per CU)
+    // tile = RT output rows x WT output columns: whole rows when they are short, 128-column pieces of long rows
+    // (the (B, C, 1, T) tensors of the ConvTransformers), as many rows as fit ~72 KB of LDS (two workgroups per CU)
+    P.sparse = (dil > 1 && kh > 1) ? 1 : 0;
+    P.WT = P.Wo <= 160 ? P.Wo : 128;
+    P.tiles_x = otp_ceil_div(P.Wo, P.WT);
+    P.LWP = (P.WT - 1) * stride + (kw - 1) * dil + 1;
     size_t lds = 0;
     for (int rt = P.Ho; rt >= 1; --rt) {
         P.RT = rt;
-        P.PT = (rt * P.Wo + 3) & ~3;
+        P.PT = (rt * P.WT + 3) & ~3;
         P.PS = pad2(P.PT + 4);
-        P.NRX = (rt - 1) * stride + (kh - 1) * dil + 1;
-        P.CSX = pad2(P.NRX * P.LWP + (kw - 1) * dil + 4);
+        P.NRX = P.sparse ? kh * rt : (rt - 1) * stride + (kh - 1) * dil + 1;
+        P.CSX = pad2(P.NRX * P.LWP + 4);
         lds = ((size_t)WG_CO * P.PS + (size_t)WG_CI * P.CSX + P.PT) * sizeof(float);
         if (lds <= 72 * 1024) break;
         if (rt == 1 && lds > OTP_LDS_LIMIT) return OTP_ERR_UNSUPPORTED;
     }
-    P.tiles_per_img = otp_ceil_div(P.Ho, P.RT);
+    P.tiles_per_img = otp_ceil_div(P.Ho, P.RT) * P.tiles_x;
     P.ntiles = N * P.tiles_per_img;
     const int gy = otp_ceil_div(Cout, WG_CO), gz = otp_ceil_div(Cin, WG_CI);
     int gx = 512 / (gy * gz);

@@ -162,11 +162,11 @@ class OTPose(nn.Module):
         assert "margin" in kwargs
         margin = kwargs["margin"]
         from .engine import InferenceEngine
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
-            raise NotImplementedError(
-                "OTPose training-mode forward/backward through the HIP engine is not built yet "
-                "(DESIGN.md, scope row 'train step'); operator-level backward exists for the DCN "
-                "(otpose_amd.ops.modulated_deform_conv) and the losses")
+        if self.training:
+            # model.train(): BatchNorm batch statistics + an autograd tape over HIP kernels (otpose_amd/train.py)
+            from .train import forward_train
+            self._engine = None
+            return forward_train(self, x, margin)
         if self._engine is None or not self._engine.matches(x):
             self._engine = InferenceEngine(self, x.shape[0], x.device)
         return self._engine.run(x, margin)

@@ -1,0 +1,322 @@
+"""Training-mode forward of OTPose (reference model/OTPose.py:307-394 under ``model.train()``, called from
+script/Common.py:118) as a composition of autograd Functions whose forward AND backward are HIP launches
+(:mod:`otpose_amd.train_ops`, :func:`otpose_amd.ops.modulated_deform_conv`), so ``loss.backward()`` walks HIP kernels.
+
+Semantics: BatchNorm2d uses batch statistics over this replica's 5B frames and updates its running statistics (the
+reference's DataParallel has no SyncBN either); Dropout(0.1) / drop-path(0.1) of the ConvTransformers are NOT applied
+(deterministic step; the reference's stochastic masks have no counterpart to check against - DESIGN.md section 6).
+What PyTorch itself executes here is plumbing: tensor views / cat / stack, and the handful of element-wise adds,
+products and per-sample divisions of the glue (model/OTPose.py:320-359); every convolution, normalisation, attention,
+pooling, up-sampling, DCN and loss kernel is in libotpose_hip.so.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+from torch.autograd import Function
+
+from . import hip, ops
+from . import train_ops as T
+
+
+class UpsampleAddFunction(Function):
+    """``relu?(res + nearest_upsample_f(low))`` (HRNet fuse rows, model/HRNet.py:426-439,488-494)."""
+
+    @staticmethod
+    def forward(ctx, low, res, f, relu):
+        low, res = low.contiguous(), res.contiguous()
+        n, c, hl, wl = low.shape
+        out = torch.empty_like(res)
+        hip.check(hip.lib().otp_upsample_add(hip.ptr(low), hip.ptr(res), hip.ptr(out), n, c, hl, wl, f, int(relu),
+                                             c, 0, c, 0, c, 0, hip.stream_of(low)), "otp_upsample_add")
+        ctx.save_for_backward(out if relu else None)
+        ctx.cfg = (f, low.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        (out,) = ctx.saved_tensors
+        f, (n, c, hl, wl) = ctx.cfg
+        gy = gy.contiguous()
+        gres = torch.empty_like(gy)
+        glow = torch.empty((n, c, hl, wl), dtype=torch.float32, device=gy.device)
+        hip.check(hip.lib().otp_upsample_add_backward(hip.ptr(gy), hip.ptr(out), hip.ptr(gres), hip.ptr(glow), n * c, hl, wl,
+                                                      f, hip.stream_of(gy)), "otp_upsample_add_backward")
+        return glow, gres, None, None
+
+
+class StOhkwLossFunction(Function):
+    """``ST_OHKW_MSELoss`` final loss (model/loss.py:25-92) with analytic gradients w.r.t. student, teacher and target
+    from one fused launch; ``flags`` (J) optionally carries the globally MAX-reduced "GT has an exact-1 peak" flags."""
+
+    @staticmethod
+    def forward(ctx, s, t, g, w, flags):
+        b, j = s.shape[:2]
+        hw = s[0, 0].numel()
+        s, t, g = s.contiguous(), t.contiguous(), g.contiguous()
+        wv = w.reshape(b, j).contiguous().float()
+        L = hip.lib()
+        nbytes = L.otp_loss_workspace(b, j)
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=s.device)
+        res = torch.empty(3, dtype=torch.float32, device=s.device)
+        given = flags is not None
+        fl = flags.to(torch.int32).contiguous() if given else torch.empty(j, dtype=torch.int32, device=s.device)
+        gs, gt, gg = torch.empty_like(s), torch.empty_like(t), torch.empty_like(g)
+        hip.check(L.otp_loss_st_ohkw_grads(hip.ptr(s), hip.ptr(t), hip.ptr(g), hip.ptr(wv), hip.ptr(fl), hip.ptr(res),
+                                           hip.ptr(gs), hip.ptr(gt), hip.ptr(gg), hip.ptr(ws), nbytes, b, j, hw, 8,
+                                           int(given), hip.stream_of(s)), "otp_loss_st_ohkw_grads")
+        ctx.save_for_backward(gs, gt, gg)
+        return res[2].clone()
+
+    @staticmethod
+    def backward(ctx, gl):
+        gs, gt, gg = ctx.saved_tensors
+        return gs * gl, gt * gl, gg * gl, None, None
+
+
+def st_ohkw_loss(s, t, g, w, flags=None):
+    return StOhkwLossFunction.apply(s, t, g, w, flags)
+
+
+class TrainGraph:
+    """Functional walk over the module's own parameters / buffers (same names as the reference state dict)."""
+
+    def __init__(self, model):
+        self.model = model
+        self.P = dict(model.named_parameters())
+        self.Bf = dict(model.named_buffers())
+        self.cfg = model.cfg
+        self.taps = None                      # dict -> forward() records named intermediates (tools/grad_noise.py)
+
+    # ---- conv / BN helpers ------------------------------------------------------------------------------------
+    def has(self, name):
+        return name in self.P
+
+    def conv(self, p, x, stride=1, pad=0, dil=1):
+        return T.conv2d(x, self.P[p + ".weight"], self.P.get(p + ".bias"), stride, pad, dil)
+
+    def bn(self, p, x, res=None, relu=False):
+        nbt = self.Bf.get(p + ".num_batches_tracked")
+        if nbt is not None:
+            nbt += 1
+        return T.batch_norm_relu(x, self.P[p + ".weight"], self.P[p + ".bias"], res, self.Bf[p + ".running_mean"],
+                                 self.Bf[p + ".running_var"], 0.1, 1e-5, relu)
+
+    def conv_bn(self, conv, bn, x, stride=1, pad=0, relu=False, res=None):
+        return self.bn(bn, self.conv(conv, x, stride, pad), res, relu)
+
+    def conv1d(self, p, x):
+        """nn.Conv1d(k=1) on (B, C, T)."""
+        return T.conv2d(x.unsqueeze(2), self.P[p + ".weight"].unsqueeze(-1), self.P.get(p + ".bias"), 1, 0, 1).squeeze(2)
+
+    # ---- HRNet (model/HRNet.py:116-152, 478-496, 514-571) -------------------------------------------------------
+    def basic_block(self, p, x):
+        y = self.conv_bn(p + ".conv1", p + ".bn1", x, 1, 1, True)
+        res = x
+        if self.has(p + ".downsample.0.weight"):
+            res = self.conv_bn(p + ".downsample.0", p + ".downsample.1", x, 1, 0, False)
+        return self.conv_bn(p + ".conv2", p + ".bn2", y, 1, 1, True, res)
+
+    def bottleneck(self, p, x):
+        y = self.conv_bn(p + ".conv1", p + ".bn1", x, 1, 0, True)
+        y = self.conv_bn(p + ".conv2", p + ".bn2", y, 1, 1, True)
+        res = x
+        if self.has(p + ".downsample.0.weight"):
+            res = self.conv_bn(p + ".downsample.0", p + ".downsample.1", x, 1, 0, False)
+        return self.conv_bn(p + ".conv3", p + ".bn3", y, 1, 0, True, res)
+
+    def hr_module(self, p, xs, n_out):
+        n = len(xs)
+        xs = list(xs)
+        for i in range(n):
+            b = 0
+            while self.has(f"{p}.branches.{i}.{b}.conv1.weight"):
+                xs[i] = self.basic_block(f"{p}.branches.{i}.{b}", xs[i])
+                b += 1
+        if n == 1:
+            return xs
+        outs = []
+        for i in range(n_out):
+            # y = relu(sum_j f_ij(x_j)) (HRNet.py:487-494).  The identity term seeds the sum and every other term rides
+            # on a fused add (BatchNorm residual input / up-sample accumulate); the last one applies the ReLU.
+            y = xs[i]
+            terms = [j for j in range(n) if j != i]
+            for idx, j in enumerate(terms):
+                last = idx == len(terms) - 1
+                q = f"{p}.fuse_layers.{i}.{j}"
+                if j > i:
+                    low = self.conv_bn(q + ".0", q + ".1", xs[j], 1, 0, False)
+                    y = UpsampleAddFunction.apply(low, y, 2 ** (j - i), last)
+                else:
+                    t = xs[j]
+                    for k in range(i - j - 1):
+                        t = self.conv_bn(f"{q}.{k}.0", f"{q}.{k}.1", t, 2, 1, True)
+                    k = i - j - 1
+                    y = self.conv_bn(f"{q}.{k}.0", f"{q}.{k}.1", t, 2, 1, relu=last, res=y)
+            outs.append(y)
+        return outs
+
+    def hrnet(self, p, x):
+        m = self.cfg["MODEL"]
+        stages = [m["EXTRA"][f"STAGE{s}"] for s in (2, 3, 4)]
+        x = self.conv_bn(p + ".conv1", p + ".bn1", x, 2, 1, True)
+        x = self.conv_bn(p + ".conv2", p + ".bn2", x, 2, 1, True)
+        for b in range(4):
+            x = self.bottleneck(f"{p}.layer1.{b}", x)
+        ys = [x]
+        for si, scfg in enumerate(stages):
+            s = si + 2
+            nb = scfg["NUM_BRANCHES"]
+            xs = []
+            for i in range(nb):
+                t = f"{p}.transition{s - 1}.{i}"
+                if self.has(t + ".0.weight"):
+                    xs.append(self.conv_bn(t + ".0", t + ".1", ys[i], 1, 1, True))
+                elif self.has(t + ".0.0.weight"):
+                    z, k = ys[-1], 0
+                    while self.has(f"{t}.{k}.0.weight"):
+                        z = self.conv_bn(f"{t}.{k}.0", f"{t}.{k}.1", z, 2, 1, True)
+                        k += 1
+                    xs.append(z)
+                else:
+                    xs.append(ys[i])
+            ys = xs
+            nm = scfg["NUM_MODULES"]
+            for mi in range(nm):
+                n_out = 1 if (s == 4 and mi == nm - 1) else nb
+                ys = self.hr_module(f"{p}.stage{s}.{mi}", ys, n_out)
+        return self.conv(p + ".final_layer", ys[0])
+
+    # ---- ConvTransformer (model/blocks.py:264-280, 400-453; ConvVideoTransformer.py:123-184) ------------------------
+    def layer_norm(self, p, x):
+        return T.layer_norm(x, self.P[p + ".weight"], self.P[p + ".bias"], 1e-5)
+
+    def mhca(self, p, x, n_head, stride):
+        c = x.shape[1]
+        hs = c // n_head
+
+        def branch(name):
+            y = T.dwconv3(x, self.P[f"{p}.{name}_conv.weight"], stride)
+            y = self.layer_norm(f"{p}.{name}_norm", y)
+            return self.conv1d(f"{p}.{name}", y)
+
+        q, k, v = branch("query"), branch("key"), branch("value")
+        out = T.chan_attn(q, k, v, n_head, 1.0 / math.sqrt(hs))
+        return self.conv1d(p + ".proj", out)
+
+    def tblock(self, p, x, n_head, stride):
+        a = self.mhca(p + ".attn", self.layer_norm(p + ".ln1", x), n_head, stride)
+        skip = x if stride == 1 else T.maxpool3s2(x)
+        y = skip + self.P[p + ".drop_path_attn.scale"] * a
+        h = self.conv1d(p + ".mlp.0", self.layer_norm(p + ".ln2", y))
+        h = self.conv1d(p + ".mlp.3", T.gelu(h))
+        return y + self.P[p + ".drop_path_mlp.scale"] * h
+
+    def conv_transformer(self, p, x4, n_head, arch):
+        b, c, h, w = x4.shape
+        t = h * w
+        x = x4.reshape(b, c, t) + self.Bf[p + ".pos_embd"][:, :, :t]
+        for i in range(arch[1]):
+            x = self.tblock(f"{p}.stem.{i}", x, n_head, 1)
+        outs = [x]
+        for i in range(arch[2]):
+            x = self.tblock(f"{p}.branch.{i}", x, n_head, 2)
+            outs.append(T.upsample_linear(x, 2 ** (i + 1)))
+        return outs
+
+    # ---- RSB heads (model/RSB.py:77-103) ---------------------------------------------------------------------------
+    def cbr(self, p, x, pad, relu=True, res=None):
+        y = self.bn(p + ".bn", self.conv(p + ".conv", x, 1, pad), res, relu)
+        if self.taps is not None:
+            self.taps["cbr:" + p] = y
+        return y
+
+    def rsb_block(self, p, x):
+        bc = self.P[p + ".conv_bn_relu2_1_1.conv.weight"].shape[0]
+        s = torch.split(self.cbr(p + ".conv_bn_relu1", x, 0), bc, 1)
+        c = lambda name, t: self.cbr(f"{p}.conv_bn_relu2_{name}", t, 1)      # noqa: E731
+        o11 = c("1_1", s[0])
+        o21 = c("2_1", s[1] + o11)
+        o22 = c("2_2", o21)
+        o31 = c("3_1", s[2] + o21)
+        o32 = c("3_2", o31 + o22)
+        o33 = c("3_3", o32)
+        o41 = c("4_1", s[3] + o31)
+        o42 = c("4_2", o41 + o32)
+        o43 = c("4_3", o42 + o33)
+        o44 = c("4_4", o43)
+        res = x
+        if self.has(p + ".downsample.conv.weight"):
+            res = self.cbr(p + ".downsample", x, 0, False)
+        return self.cbr(p + ".conv_bn_relu3", torch.cat((o11, o22, o33, o44), 1), 0, True, res)
+
+    def rsb_chain(self, p, x):
+        i = 0
+        while self.has(f"{p}.layers.{i}.conv_bn_relu1.conv.weight"):
+            x = self.rsb_block(f"{p}.layers.{i}", x)
+            i += 1
+        return x
+
+    # ---- whole forward (model/OTPose.py:307-394) ---------------------------------------------------------------
+    def forward(self, x, margin):
+        m = self.cfg["MODEL"]
+        J = m["NUM_JOINTS"]
+        pe_w, pe_h = m["HEATMAP_SIZE"]
+        dils = list(m["DEFORMABLE_CONV"]["DILATION"])
+        x = torch.cat(x.split(3, dim=1), 0).contiguous()
+        B = x.shape[0] // 5
+        rough = self.hrnet("rough_pose_estimation_net", x)
+        cur, prev, nxt, pprev, nnext = rough.split(B, dim=0)
+        total_b = cur + prev + nxt + pprev + nnext
+        squeezed = total_b.sum(1, keepdim=True).expand(-1, J, -1, -1).contiguous()
+        inter = total_b * squeezed
+        ctx = self.conv_transformer("flow_encoder", total_b, 1, (0, 6, 0))[0].reshape(B, J, pe_h, pe_w)
+        mg = margin.to(x.dtype)
+        div = lambda t, k: t / (mg[:, k] + 1)[:, None, None, None]           # noqa: E731
+        prev, nxt, pprev, nnext = div(prev, 0), div(nxt, 1), div(pprev, 2), div(nnext, 3)
+        prev_b = cur + (prev + pprev)
+        next_b = cur + (nxt + nnext)
+        close_b = cur + (nxt + prev)
+        far_b = cur + (nnext + pprev)
+        prev_i, next_i, close_i, far_i = (t * squeezed for t in (prev_b, next_b, close_b, far_b))
+        x1 = torch.stack((inter, ctx, prev_b, far_b, close_b, prev_i, far_i, close_i), 2).flatten(1, 2)
+        x2 = torch.stack((inter, ctx, next_b, close_b, far_b, next_i, close_i, far_i), 2).flatten(1, 2)
+        t1 = self.conv_transformer("temporal_encoder1", x1, 2, (0, 6, 2))
+        t2 = self.conv_transformer("temporal_encoder2", x2, 2, (0, 6, 2))
+        s1 = torch.stack(t1, 1).contiguous().view(B, -1, pe_h, pe_w)
+        s2 = torch.stack(t2, 1).contiguous().view(B, -1, pe_h, pe_w)
+        fk = self.P["final_layer1.weight"].shape[-1]
+        f1 = self.conv("final_layer1", s1, 1, fk // 2)
+        f2 = self.conv("final_layer2", s2, 1, fk // 2)
+        def_h = self.rsb_chain("def_fuse", total_b)
+        trans = self.rsb_chain("offset_mask_combine_conv", torch.cat([f1, f2, def_h], 1))
+        out = None
+        if self.taps is not None:
+            self.taps.update(x1=x1, x2=x2, t1_0=t1[0], t2_0=t2[0], f1=f1, f2=f2, def_h=def_h, trans=trans)
+        for i, d in enumerate(dils):
+            off = T.conv2d(trans, self.P[f"offsets_list.{i}.0.weight"], None, 1, d, d)
+            msk = T.conv2d(trans, self.P[f"masks_list.{i}.0.weight"], None, 1, d, d)
+            p = f"modulated_deform_conv_list.{i}.deform_conv"
+            wrp = ops.modulated_deform_conv(def_h, off, msk, self.P[p + ".weight"], self.P[p + ".bias"], 1, d, d, 1, J)
+            out = (1.0 / len(dils)) * wrp if out is None else out + (1.0 / len(dils)) * wrp
+            if self.taps is not None:
+                self.taps.update({f"off{i}": off, f"msk{i}": msk, f"wrp{i}": wrp})
+        return out, rough, inter, prev_b, ctx, squeezed, total_b
+
+
+def forward_train(model, x, margin, taps=None):
+    if not x.is_cuda:
+        raise RuntimeError("OTPose training forward expects CUDA (HIP) tensors; there is no CPU path")
+    graph = TrainGraph(model)
+    graph.taps = taps
+    return graph.forward(x, margin)
+
+
+def criterion(outputs, target, target_weight, flags=None):
+    """The two ST_OHKW terms of the reference training loop (script/Common.py:122-130)."""
+    B = target.shape[0]
+    pred_t = outputs[1].split(B)[0]
+    loss = st_ohkw_loss(outputs[0], pred_t, target, target_weight, flags)
+    occlusion = (target + outputs[2]) / 2
+    return loss + st_ohkw_loss(outputs[4], outputs[4], occlusion, target_weight, flags)

@@ -1,0 +1,91 @@
+"""Whole-model training step through the HIP autograd path vs the CPU oracle under torch autograd (tiny W8 model,
+BatchNorm batch statistics, dropout / drop-path off): the 7 outputs, the two-term ST_OHKW loss of
+script/Common.py:122-130 and the gradient of every parameter."""
+import pytest
+import torch
+
+from oracle import otpose_oracle as O
+from otpose_amd import OTPose, tiny_cfg
+from otpose_amd import synthetic as S
+from otpose_amd import train as TR
+from tests.conftest import seeded
+
+pytestmark = pytest.mark.gpu
+
+
+def _targets(b, j, h, w):
+    g = seeded((b, j, h, w), 11).abs() * 0.2
+    g[:, ::2, 3, 4] = 1.0                                   # exact-1 peaks for every second joint
+    g.clamp_(max=1.0)
+    wt = (seeded((b, j, 1), 12) > -1.0).float()
+    return g, wt
+
+
+def test_train_step_matches_oracle_autograd():
+    cfg = tiny_cfg(8, (64, 96))
+    model = OTPose(cfg)
+    S.fill_synthetic_(model)
+    sd_cpu = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    # float64 reference: a float32 CPU graph carries rounding noise of the same size as the path under test
+    leaves = {k: v.double().requires_grad_() for k, v in sd_cpu.items()
+              if v.is_floating_point() and k in dict(model.named_parameters())}
+    sd_ref = {k: (v.double() if v.is_floating_point() else v) for k, v in sd_cpu.items()}
+    sd_ref.update(leaves)
+    x, margin = S.synthetic_clip(2, cfg.MODEL.IMAGE_SIZE)
+    outs_ref = O.otpose_forward(sd_ref, cfg, x.double(), margin, training_bn=True)
+    B, J, h, w = outs_ref[0].shape
+    g, wt = _targets(B, J, h, w)
+    gd, wd = g.double(), wt.double()
+    l1 = O.st_ohkw_mse_loss(outs_ref[0], outs_ref[1][:B], gd, wd)["final_loss"]
+    l2 = O.st_ohkw_mse_loss(outs_ref[4], outs_ref[4], (gd + outs_ref[2]) / 2, wd)["final_loss"]
+    loss_ref = l1 + l2
+    loss_ref.backward()
+
+    model = model.cuda().train()
+    outs = model(x.cuda(), margin=margin.cuda())
+    for name, o, r in zip(("output", "rough", "intersection", "prev_b", "context", "squeezed", "total_b"), outs, outs_ref):
+        err = float((o.detach().cpu().double() - r.detach()).abs().max())
+        assert err <= 1e-3 * max(1.0, float(r.detach().abs().max())), f"{name}: {err}"
+    loss = TR.criterion(outs, g.cuda(), wt.cuda())
+    assert abs(float(loss) - float(loss_ref.detach())) <= 1e-3 * max(1.0, abs(float(loss_ref.detach()))), (float(loss), float(loss_ref.detach()))
+    loss.backward()
+    # fp32 on both sides: a ReLU / max-pool / top-k decision that flips on a last-bit difference moves single gradient
+    # entries by O(1) of their size, so tensors are compared in the L2 sense (relative error and cosine)
+    stats = []
+    for name, p in model.named_parameters():
+        ref = leaves[name].grad
+        if ref is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+            continue
+        assert p.grad is not None, name
+        g = p.grad.cpu().double().flatten()
+        r = ref.double().flatten()
+        nr = float(r.norm())
+        rel = float((g - r).norm()) / max(nr, 1e-12)
+        cos = float(torch.dot(g, r)) / max(float(g.norm()) * nr, 1e-24)
+        stats.append((rel, cos, name, nr))
+    stats.sort(reverse=True)
+    print("params checked", len(stats))
+    for rel, cos, name, nr in [s_ for s_ in stats if s_[3] > 1e-6][:8]:
+        print("  rel L2 err %.3e  cos %.6f  |ref| %.3e  %s" % (rel, cos, nr, name))
+    assert len(stats) > 300
+    med = sorted(s_[0] for s_ in stats)[len(stats) // 2]
+    print("median rel L2 err %.3e" % med)
+    # calibration (tools/grad_noise.py, 5 input seeds): against the float64 gradients the oracle in float32 on the CPU,
+    # the oracle through PyTorch-ROCm eager in float32 and this HIP path all scatter in the same band - median relative L2
+    # 4e-5 .. 6e-3, worst tensor 3e-2 .. 1e-1 - because the gradients reaching the encoders pass the offset branch of the
+    # DCN (differences of neighbouring samples) and 40 BatchNorm+ReLU stages at batch 2.  That band is the rounding floor
+    # of this fixture; the per-op tests (test_gpu_train_ops.py) hold each kernel to 1e-4-level tolerances.
+    assert med <= 8e-3
+    num = sum(((p.grad.cpu().double() - leaves[n].grad) ** 2).sum() for n, p in model.named_parameters()
+              if leaves[n].grad is not None)
+    den = sum((leaves[n].grad ** 2).sum() for n, p in model.named_parameters() if leaves[n].grad is not None)
+    glob = float(num / den) ** 0.5
+    print("whole-gradient rel L2 err %.3e" % glob)
+    assert glob <= 3e-3
+    for rel, cos, name, nr in stats:
+        if nr > 1e-6:
+            assert rel <= 0.15 and cos >= 0.99, f"{name}: rel L2 {rel}, cos {cos}"
+    # BatchNorm running statistics were updated like nn.BatchNorm2d does
+    rm = model.state_dict()["rough_pose_estimation_net.bn1.running_mean"].cpu()
+    assert float((rm - sd_cpu["rough_pose_estimation_net.bn1.running_mean"]).abs().max()) > 0

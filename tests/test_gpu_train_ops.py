@@ -28,6 +28,9 @@ CASES = [  # N, Cin, H, W, Cout, k, stride, pad, dil
     (2, 3, 32, 24, 64, 3, 2, 1, 1),       # stem
     (1, 32, 24, 18, 40, 3, 1, 6, 6),      # dilated offset conv
     (2, 13, 7, 5, 13, 3, 1, 1, 1),        # odd everything
+    (2, 136, 1, 700, 136, 1, 1, 0, 1),    # Conv1d(k=1) of the ConvTransformers as (B, C, 1, T): column-tiled rows
+    (1, 24, 5, 300, 40, 3, 1, 1, 1),      # wide image: column tiles with halo
+    (2, 32, 16, 24, 34, 3, 1, 15, 15),    # dilation 15 on a small map (sparse row staging)
 ]
 
 
