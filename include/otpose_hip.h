@@ -98,10 +98,14 @@ int otp_conv2d_pack_weight_dgrad(const void* weight, void* wpacked, int Cout, in
 int otp_dilate(const void* in, void* out, int planes, int Hi, int Wi, int s, int H, int W, void* stream);
 /* grad_weight (Cout, Cin, kh, kw) += sum over batch and pixels of grad_out x shifted input (ACCUMULATES: zero it first).
  * x (N, x_ctot, H, W) channels [x_coff, x_coff+Cin); grad_out (N, dy_ctot, Ho, Wo) channels [dy_coff, dy_coff+Cout).
- * 1x1 and 3x3 kernels, any stride / padding / dilation. */
+ * 1x1 and 3x3 kernels, any stride / padding / dilation.
+ * workspace (otp_conv2d_wgrad_workspace(Cin, Cout) bytes, contents irrelevant) holds the per-workgroup partial sums
+ * that a second launch folds into grad_weight; workspace == NULL selects one float atomic per weight and workgroup
+ * instead (same result up to summation order, several times slower at the HRNet sizes). */
+size_t otp_conv2d_wgrad_workspace(int Cin, int Cout);
 int otp_conv2d_wgrad(const void* x, const void* grad_out, void* grad_weight, int N, int Cin, int H, int W, int Cout,
                      int kh, int kw, int stride, int pad, int dil, int x_ctot, int x_coff, int dy_ctot, int dy_coff,
-                     void* stream);
+                     void* workspace, size_t workspace_bytes, void* stream);
 /* BatchNorm2d, training mode (torch semantics: biased variance for normalisation, unbiased for running_var,
  * running = (1-momentum)*running + momentum*batch), fused with the residual add and ReLU that follow it:
  *   y = relu?( (x - mean_c) * rstd_c * gamma_c + beta_c (+ res) );  save_mean / save_rstd (C) feed the backward.

@@ -50,9 +50,12 @@ __global__ void dilate_kernel(const float* __restrict__ in, float* __restrict__ 
 // D[co][ci] += A[co][pixel] * B[pixel][ci], contraction over the pixels in steps of 4 (v_mfma_f32_16x16x4_f32).
 // LDS: dY rows of the tile [48][PS] and the input rows it touches [48][NRX][LWP] with a ZERO halo (so the taps
 // that fall off the image multiply zeros), plus a per-pixel table of input offsets (any width, any stride).
-// A wave owns up to 7 (tap, co-block) groups x 3 ci-blocks = 21 accumulator tiles, kept in registers over every tile
-// the workgroup walks; they leave through one float atomic per weight at the end.
-constexpr int WG_CO = 48, WG_CI = 48, WG_GROUPS = 7;
+// 3x3: a wave owns up to 7 of the 27 (tap, ci-block) combinations x 3 co-blocks = 21 accumulator tiles; per 4-pixel
+// step it reads the three dY fragments once and one input fragment per combination (11 LDS reads : 21 MFMAs).
+// 1x1: every wave owns all (ci-block, co-block) tiles and takes every fourth pixel step.
+// The accumulators stay in registers over every tile the workgroup walks and leave through one float atomic per
+// weight at the end.
+constexpr int WG_CO = 48, WG_CI = 48, WG_GROUPS = 7, SU = 8, SV = 6;
 
 struct WgradPlan {
     int N, Cin, H, W, Cout, KS, stride, pad, dil, Ho, Wo;
@@ -61,10 +64,45 @@ struct WgradPlan {
     int NRX, LWP, CSX;        // staged input rows, staged row pitch, channel stride (CSX % 32 == 2)
     int sparse;               // dilated kernels: stage only the KS rows a tap row touches per output row (r = ti*RT + yl)
     int tiles_x, tiles_per_img, ntiles;
+    int vec, GX, GD;          // 16-byte staging path; float4 groups per staged input row / per dY row
+    unsigned magicRT, magicNRX, magicWT, magicLWP, magicGX, magicGD;   // ceil(2^32 / d): exact quotients of the small (< 2^16) staging indices
 };
 
+__device__ __forceinline__ int magic_div(int n, unsigned magic, int d) {
+    return d == 1 ? n : (int)__umulhi((unsigned)n, magic);
+}
+
+// the MFMA loop of one wave over one staged tile: NG (tap, ci-block) combinations x up to 3 co-blocks
+template <int NG>
+__device__ __forceinline__ void wgrad_steps(f32x4 (&acc)[WG_GROUPS][3], const float* __restrict__ dys,
+                                            const float* __restrict__ xs, const int* __restrict__ poff,
+                                            const int (&bbase)[WG_GROUPS], int abase, int PS16, int s0, int ds, int steps,
+                                            int ncob) {
+    const int kl = (threadIdx.x & 63) >> 4;
+    for (int s = s0; s < steps; s += ds) {
+        const int xo = poff[4 * s + kl];
+        const int ao = abase + 4 * s;
+        const float a0 = dys[ao];
+        const float a1 = ncob > 1 ? dys[ao + PS16] : 0.f;
+        const float a2 = ncob > 2 ? dys[ao + 2 * PS16] : 0.f;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const float b = xs[bbase[g] + xo];
+            acc[g][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc[g][0], 0, 0, 0);
+            if (ncob > 1) acc[g][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc[g][1], 0, 0, 0);
+            if (ncob > 2) acc[g][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b, acc[g][2], 0, 0, 0);
+        }
+    }
+}
+
+// partial sums: part != nullptr -> each workgroup stores its accumulators in fragment order
+// [workgroup][wave][g][co-block][r][lane] (coalesced) and wgrad_reduce_kernel folds them into dW; part == nullptr ->
+// one float atomic per weight and workgroup (512 atomics per weight cost more than the whole MFMA loop at the HRNet sizes)
+constexpr int WG_SLOTS = 4 * WG_GROUPS * 3 * 4 * 64;
+
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                              float* __restrict__ dw, const WgradPlan P) {
+                                                              float* __restrict__ dw, float* __restrict__ part,
+                                                              const WgradPlan P) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* dys = smem;                                   // [48][PS]
     float* xs = smem + WG_CO * P.PS;                     // [48][CSX]
@@ -74,18 +112,35 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restr
     const int i16 = lane & 15, kl = lane >> 4;
     const int co0 = blockIdx.y * WG_CO, ci0 = blockIdx.z * WG_CI;
     const int KK = P.KS * P.KS;
-    const int ngroups = KK * 3;                          // (tap, co-block) groups, dealt round-robin to the waves
+    const int ncib = min(3, (P.Cin - ci0 + 15) >> 4), ncob = min(3, (P.Cout - co0 + 15) >> 4);
+    // combinations (tap, ci-block) of this wave: 3x3 -> round-robin over the waves; 1x1 -> all of them, split pixel steps
+    const bool split_steps = KK == 1;
+    const int ncombo = KK * ncib;
+    const int ng = split_steps ? ncombo : (ncombo > wave ? (ncombo - wave + 3) >> 2 : 0);
+    const int s0 = split_steps ? wave : 0, ds = split_steps ? 4 : 1;
 
     f32x4 acc[WG_GROUPS][3];
+    int bbase[WG_GROUPS];                                 // LDS word of the input fragment of combination g, pixel offset 0
 #pragma unroll
-    for (int g = 0; g < WG_GROUPS; ++g)
+    for (int g = 0; g < WG_GROUPS; ++g) {
 #pragma unroll
         for (int b = 0; b < 3; ++b) acc[g][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int combo = split_steps ? g : wave + 4 * g;
+        const int tap = combo / ncib, cib = combo - tap * ncib;
+        const int ti = tap / P.KS, tj = tap - ti * P.KS;
+        bbase[g] = (cib * 16 + i16) * P.CSX + ti * (P.sparse ? P.RT : P.dil) * P.LWP + tj * P.dil;
+    }
+    const int abase = i16 * P.PS + kl, PS16 = 16 * P.PS;
 
     // pixel -> input offset table (tile-invariant: local row * stride * LWP + column * stride)
     for (int p = tid; p < P.PT; p += 256) {
         const int yl = p / P.WT, xq = p - yl * P.WT;
         poff[p] = yl < P.RT ? yl * (P.sparse ? 1 : P.stride) * P.LWP + xq * P.stride : 0;   // rounding pixels: any staged word
+    }
+    // the rounding pixels of the dY rows (PT - RT*WT <= 3 per channel) are never staged: zero them once
+    for (int i = tid; i < WG_CO * (P.PT - P.RT * P.WT); i += 256) {
+        const int c = i / (P.PT - P.RT * P.WT), q = i - c * (P.PT - P.RT * P.WT);
+        dys[c * P.PS + P.RT * P.WT + q] = 0.f;
     }
 
     for (int tile = blockIdx.x; tile < P.ntiles; tile += gridDim.x) {
@@ -95,72 +150,183 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restr
         const int y0 = yb * P.RT, x0 = xb * P.WT;                      // first output row / column of the tile
         const int rows = min(P.RT, P.Ho - y0), cols = min(P.WT, P.Wo - x0);
         __syncthreads();                                               // previous tile fully consumed
-        // ---- stage dY rows: [co][p], zero past the image rows / channels --------------------------------------
+        if (P.vec) {
+            // ---- 16-byte staging (stride 1, W % 4 == 0): one buffer load per 4 columns, SV groups in flight per lane ----
+            const otp_rsrc rdy = make_rsrc32(dy + ((size_t)n * P.dy_ctot + P.dy_coff) * P.Ho * P.Wo,
+                                             (unsigned)P.Cout * (unsigned)(P.Ho * P.Wo) * 4u);
+            const otp_rsrc rx = make_rsrc32(x + ((size_t)n * P.x_ctot + P.x_coff) * P.H * P.W,
+                                            (unsigned)P.Cin * (unsigned)(P.H * P.W) * 4u);
+            const int totd = WG_CO * P.RT * P.GD, totx = WG_CI * P.NRX * P.GX;
+            const int r0 = y0 * P.stride - P.pad, xx0 = x0 - P.pad;
+            const int xg0 = (x0 - P.pad) & ~3;                         // first (aligned) image column of group 0; may be < 0
+            for (int base = tid; base < totd; base += 256 * SV) {
+                otp_f32x4 v[SV];
+                int dst[SV];
+#pragma unroll
+                for (int u = 0; u < SV; ++u) {
+                    const int i = base + u * 256;
+                    const int cr = magic_div(i, P.magicGD, P.GD), xq = (i - cr * P.GD) * 4;
+                    const int c = magic_div(cr, P.magicRT, P.RT), yl = cr - c * P.RT;
+                    const bool ok = i < totd && co0 + c < P.Cout && yl < rows && xq < cols;
+                    v[u] = bload4(rdy, ok ? (((co0 + c) * P.Ho + y0 + yl) * P.Wo + x0 + xq) * 4 : -1);
+                    dst[u] = i < totd ? c * P.PS + yl * P.WT + xq : -1;
+                }
+#pragma unroll
+                for (int u = 0; u < SV; ++u)
+                    if (dst[u] >= 0) {
+                        *reinterpret_cast<float2*>(dys + dst[u]) = make_float2(v[u][0], v[u][1]);
+                        *reinterpret_cast<float2*>(dys + dst[u] + 2) = make_float2(v[u][2], v[u][3]);
+                    }
+            }
+            for (int base = tid; base < totx; base += 256 * SV) {
+                otp_f32x4 v[SV];
+                int dst[SV];
+#pragma unroll
+                for (int u = 0; u < SV; ++u) {
+                    const int i = base + u * 256;
+                    const int cr = magic_div(i, P.magicGX, P.GX), j = i - cr * P.GX;
+                    const int c = magic_div(cr, P.magicNRX, P.NRX), r = cr - c * P.NRX;
+                    const int yy = r0 + r, xg = xg0 + 4 * j;
+                    const bool ok = i < totx && ci0 + c < P.Cin && yy >= 0 && yy < P.H && xg >= 0 && xg < P.W;
+                    v[u] = bload4(rx, ok ? (((ci0 + c) * P.H + yy) * P.W + xg) * 4 : -1);
+                    dst[u] = i < totx ? c * P.CSX + r * P.LWP + (xg - xx0) : -(1 << 20);   // LDS word of element 0 (col may be < 0)
+                }
+#pragma unroll
+                for (int u = 0; u < SV; ++u)
+                    if (dst[u] > -(1 << 19)) {
+                        const int i = base + u * 256;
+                        const int cr = magic_div(i, P.magicGX, P.GX), j = i - cr * P.GX;
+                        const int col = xg0 - xx0 + 4 * j;                 // staged column of element 0 (-3 .. LWP-1)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (col + e >= 0 && col + e < P.LWP) xs[dst[u] + e] = v[u][e];
+                    }
+            }
+        } else {
+        // ---- stage dY rows: [co][yl * WT + xq], zero past the image rows / columns / channels ---------------------
+        // (flat item index, SU loads in flight per lane before the first LDS store: the loop is latency-bound otherwise)
         {
             const otp_rsrc rdy = make_rsrc32(dy + ((size_t)n * P.dy_ctot + P.dy_coff) * P.Ho * P.Wo,
                                              (unsigned)P.Cout * (unsigned)(P.Ho * P.Wo) * 4u);
-            for (int i = tid; i < WG_CO * P.PT; i += 256) {
-                const int c = i / P.PT, p = i - c * P.PT;
-                const int yl = p / P.WT, xq = p - yl * P.WT;
-                const int co = co0 + c;
-                const bool ok = co < P.Cout && yl < rows && xq < cols;
-                dys[c * P.PS + p] = bload(rdy, ok ? (co * P.Ho * P.Wo + (y0 + yl) * P.Wo + x0 + xq) * 4 : -1, 0);
+            const int total = WG_CO * P.RT * P.WT;
+            for (int base = tid; base < total; base += 256 * SU) {
+                float v[SU];
+                int dst[SU];
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    const int i = base + u * 256;
+                    const int cr = magic_div(i, P.magicWT, P.WT), xq = i - cr * P.WT;
+                    const int c = magic_div(cr, P.magicRT, P.RT), yl = cr - c * P.RT;
+                    const bool ok = i < total && co0 + c < P.Cout && yl < rows && xq < cols;
+                    v[u] = bload(rdy, ok ? (((co0 + c) * P.Ho + y0 + yl) * P.Wo + x0 + xq) * 4 : -1, 0);
+                    dst[u] = i < total ? c * P.PS + yl * P.WT + xq : -1;
+                }
+#pragma unroll
+                for (int u = 0; u < SU; ++u)
+                    if (dst[u] >= 0) dys[dst[u]] = v[u];
             }
         }
-        // ---- stage the input rows with a zero halo: [ci][r][col], col 0 = image column -pad ------------------
+        // ---- stage the input rows with a zero halo: [ci][r][col], col 0 = image column x0*stride - pad ----------------
         {
             const otp_rsrc rx = make_rsrc32(x + ((size_t)n * P.x_ctot + P.x_coff) * P.H * P.W,
                                             (unsigned)P.Cin * (unsigned)(P.H * P.W) * 4u);
-            const int r0 = y0 * P.stride - P.pad;
-            const int per_c = P.NRX * P.LWP;
-            for (int i = tid; i < WG_CI * per_c; i += 256) {
-                const int c = i / per_c, rem = i - c * per_c;
-                const int r = rem / P.LWP, col = rem - r * P.LWP;
-                const int yy = P.sparse ? (y0 + r % P.RT) * P.stride - P.pad + (r / P.RT) * P.dil : r0 + r;
-                const int xx = x0 * P.stride - P.pad + col, ci = ci0 + c;
-                const bool ok = ci < P.Cin && yy >= 0 && yy < P.H && xx >= 0 && xx < P.W;
-                xs[c * P.CSX + rem] = bload(rx, ok ? (ci * P.H * P.W + yy * P.W + xx) * 4 : -1, 0);
+            const int r0 = y0 * P.stride - P.pad, xx0 = x0 * P.stride - P.pad;
+            const int total = WG_CI * P.NRX * P.LWP;
+            for (int base = tid; base < total; base += 256 * SU) {
+                float v[SU];
+                int dst[SU];
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    const int i = base + u * 256;
+                    const int cr = magic_div(i, P.magicLWP, P.LWP), col = i - cr * P.LWP;
+                    const int c = magic_div(cr, P.magicNRX, P.NRX), r = cr - c * P.NRX;
+                    int yy = r0 + r;
+                    if (P.sparse) {
+                        const int rt = magic_div(r, P.magicRT, P.RT);          // tap row
+                        yy = (y0 + r - rt * P.RT) * P.stride - P.pad + rt * P.dil;
+                    }
+                    const int xx = xx0 + col;
+                    const bool ok = i < total && ci0 + c < P.Cin && yy >= 0 && yy < P.H && xx >= 0 && xx < P.W;
+                    v[u] = bload(rx, ok ? (((ci0 + c) * P.H + yy) * P.W + xx) * 4 : -1, 0);
+                    dst[u] = i < total ? c * P.CSX + cr * P.LWP - c * P.NRX * P.LWP + col : -1;
+                }
+#pragma unroll
+                for (int u = 0; u < SU; ++u)
+                    if (dst[u] >= 0) xs[dst[u]] = v[u];
             }
+        }
         }
         __syncthreads();
         // ---- MFMA over the tile's pixels --------------------------------------------------------------------
         const int steps = (rows * P.WT + 3) >> 2;
-#pragma unroll
-        for (int g = 0; g < WG_GROUPS; ++g) {
-            const int grp = wave + 4 * g;
-            if (grp < ngroups) {
-                const int tap = grp / 3, cb = grp - tap * 3;
-                const int ti = tap / P.KS, tj = tap - ti * P.KS;
-                const float* arow = dys + (cb * 16 + i16) * P.PS + kl;
-                const float* brow = xs + i16 * P.CSX + ti * (P.sparse ? P.RT : P.dil) * P.LWP + tj * P.dil;
-#pragma unroll 2
-                for (int s = 0; s < steps; ++s) {
-                    const int p = 4 * s + kl;
-                    const float a = arow[4 * s];                       // dY[co][p]  (zero past the tile)
-                    const int xo = poff[p < P.PT ? p : 0];
-                    const float b0 = brow[xo], b1 = brow[16 * P.CSX + xo], b2 = brow[32 * P.CSX + xo];
-                    acc[g][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, acc[g][0], 0, 0, 0);
-                    acc[g][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, acc[g][1], 0, 0, 0);
-                    acc[g][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b2, acc[g][2], 0, 0, 0);
-                }
-            }
+        switch (ng) {
+            case 7: wgrad_steps<7>(acc, dys, xs, poff, bbase, abase, PS16, s0, ds, steps, ncob); break;
+            case 6: wgrad_steps<6>(acc, dys, xs, poff, bbase, abase, PS16, s0, ds, steps, ncob); break;
+            case 5: wgrad_steps<5>(acc, dys, xs, poff, bbase, abase, PS16, s0, ds, steps, ncob); break;
+            case 4: wgrad_steps<4>(acc, dys, xs, poff, bbase, abase, PS16, s0, ds, steps, ncob); break;
+            case 3: wgrad_steps<3>(acc, dys, xs, poff, bbase, abase, PS16, s0, ds, steps, ncob); break;
+            case 2: wgrad_steps<2>(acc, dys, xs, poff, bbase, abase, PS16, s0, ds, steps, ncob); break;
+            case 1: wgrad_steps<1>(acc, dys, xs, poff, bbase, abase, PS16, s0, ds, steps, ncob); break;
+            default: break;
         }
     }
-    // ---- flush: D[row = co (kl*4 + r)][col = ci (i16)] -> dW (Cout, Cin, kh, kw), one atomic per weight ---------
+    // ---- flush: D[row = co (kl*4 + r)][col = ci (i16)] -> partial buffer (fragment order) or dW atomics ----------
+    if (part) {
+        float* dst = part + ((size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) *
+                                (WG_GROUPS * 3 * 4 * 64) + lane;
+#pragma unroll
+        for (int g = 0; g < WG_GROUPS; ++g)
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[((g * 3 + b) * 4 + r) * 64] = acc[g][b][r];
+        return;
+    }
 #pragma unroll
     for (int g = 0; g < WG_GROUPS; ++g) {
-        const int grp = wave + 4 * g;
-        if (grp < ngroups) {
-            const int tap = grp / 3, cb = grp - tap * 3;
+        if (g < ng) {
+            const int combo = split_steps ? g : wave + 4 * g;
+            const int tap = combo / ncib, cib = combo - tap * ncib;
 #pragma unroll
             for (int b = 0; b < 3; ++b)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int co = co0 + cb * 16 + kl * 4 + r, ci = ci0 + b * 16 + i16;
-                    if (co < P.Cout && ci < P.Cin) atomicAdd(&dw[((size_t)co * P.Cin + ci) * KK + tap], acc[g][b][r]);
+                    const int co = co0 + b * 16 + kl * 4 + r, ci = ci0 + cib * 16 + i16;
+                    if (b < ncob && co < P.Cout && ci < P.Cin)
+                        atomicAdd(&dw[((size_t)co * P.Cin + ci) * KK + tap], acc[g][b][r]);
                 }
         }
     }
+}
+
+// dW[co][ci][tap] += sum over the gx workgroups of one (co-group, ci-group) of their partial accumulators.
+// grid (slot blocks, 8 segments of the workgroup range, co-group * ci-group); a thread owns one fragment slot.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int gx,
+                                                            int gy, int Cout, int Cin, int KS) {
+    const int slot = blockIdx.x * 256 + threadIdx.x;                    // [wave][g][b][r][lane]
+    if (slot >= WG_SLOTS) return;
+    const int lane = slot & 63, r = (slot >> 6) & 3, gb = slot >> 8;    // gb = (wave * 7 + g) * 3 + b
+    const int b = gb % 3, wg = gb / 3, g = wg % WG_GROUPS, wave = wg / WG_GROUPS;
+    const int by = blockIdx.z % gy, bz = blockIdx.z / gy;
+    const int co0 = by * WG_CO, ci0 = bz * WG_CI, KK = KS * KS;
+    const int ncib = min(3, (Cin - ci0 + 15) >> 4), ncob = min(3, (Cout - co0 + 15) >> 4);
+    const bool split_steps = KK == 1;
+    const int ncombo = KK * ncib;
+    const int combo = split_steps ? g : wave + 4 * g;
+    if (combo >= ncombo || b >= ncob) return;
+    const int tap = combo / ncib, cib = combo - tap * ncib;
+    const int co = co0 + b * 16 + (lane >> 4) * 4 + r, ci = ci0 + cib * 16 + (lane & 15);
+    if (co >= Cout || ci >= Cin) return;
+    const int seg = (gx + gridDim.y - 1) / gridDim.y;
+    const int w0 = blockIdx.y * seg, w1 = min(gx, w0 + seg);
+    const float* src = part + ((size_t)blockIdx.z * gx + w0) * WG_SLOTS + slot;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int w = w0;
+    for (; w + 3 < w1; w += 4, src += 4 * (size_t)WG_SLOTS) {
+        s0 += src[0]; s1 += src[WG_SLOTS]; s2 += src[2 * (size_t)WG_SLOTS]; s3 += src[3 * (size_t)WG_SLOTS];
+    }
+    for (; w < w1; ++w, src += WG_SLOTS) s0 += src[0];
+    if (w1 > w0) atomicAdd(&dw[((size_t)co * Cin + ci) * KK + tap], (s0 + s1) + (s2 + s3));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -314,9 +480,20 @@ extern "C" int otp_dilate(const void* in, void* out, int planes, int Hi, int Wi,
     return otp_launch_status();
 }
 
+static int wgrad_grid_x(int Cout, int Cin) {
+    const int gy = otp_ceil_div(Cout, WG_CO), gz = otp_ceil_div(Cin, WG_CI);
+    int gx = 512 / (gy * gz);
+    return gx < 8 ? 8 : gx;
+}
+
+extern "C" size_t otp_conv2d_wgrad_workspace(int Cin, int Cout) {
+    if (Cin <= 0 || Cout <= 0) return 0;
+    return (size_t)wgrad_grid_x(Cout, Cin) * otp_ceil_div(Cout, WG_CO) * otp_ceil_div(Cin, WG_CI) * WG_SLOTS * sizeof(float);
+}
+
 extern "C" int otp_conv2d_wgrad(const void* x, const void* grad_out, void* grad_weight, int N, int Cin, int H, int W,
                                 int Cout, int kh, int kw, int stride, int pad, int dil, int x_ctot, int x_coff,
-                                int dy_ctot, int dy_coff, void* stream) {
+                                int dy_ctot, int dy_coff, void* workspace, size_t workspace_bytes, void* stream) {
     if (!x || !grad_out || !grad_weight || N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || stride <= 0 ||
         pad < 0 || dil <= 0)
         return OTP_ERR_BAD_ARG;
@@ -332,30 +509,55 @@ extern "C" int otp_conv2d_wgrad(const void* x, const void* grad_out, void* grad_
     // tile = RT output rows x WT output columns: whole rows when they are short, 128-column pieces of long rows
     // (the (B, C, 1, T) tensors of the ConvTransformers), as many rows as fit ~72 KB of LDS (two workgroups per CU)
     P.sparse = (dil > 1 && kh > 1) ? 1 : 0;
-    P.WT = P.Wo <= 160 ? P.Wo : 128;
-    P.tiles_x = otp_ceil_div(P.Wo, P.WT);
-    P.LWP = (P.WT - 1) * stride + (kw - 1) * dil + 1;
     size_t lds = 0;
-    for (int rt = P.Ho; rt >= 1; --rt) {
-        P.RT = rt;
-        P.PT = (rt * P.WT + 3) & ~3;
+    auto size_for = [&](int wt, int rt) {
+        P.WT = wt; P.RT = rt;
+        P.tiles_x = otp_ceil_div(P.Wo, wt);
+        P.LWP = (wt - 1) * stride + (kw - 1) * dil + 1;
+        P.PT = (rt * wt + 3) & ~3;
         P.PS = pad2(P.PT + 4);
         P.NRX = P.sparse ? kh * rt : (rt - 1) * stride + (kh - 1) * dil + 1;
         P.CSX = pad2(P.NRX * P.LWP + 4);
-        lds = ((size_t)WG_CO * P.PS + (size_t)WG_CI * P.CSX + P.PT) * sizeof(float);
+        return ((size_t)WG_CO * P.PS + (size_t)WG_CI * P.CSX + P.PT) * sizeof(float);
+    };
+    int wt = P.Wo <= 160 ? P.Wo : 128;
+    while (wt > 16 && size_for(wt, 1) > 72 * 1024) wt = (wt / 2 + 3) & ~3;   // wide strided rows (the 384x288 stem)
+    for (int rt = P.Ho; rt >= 1; --rt) {
+        lds = size_for(wt, rt);
         if (lds <= 72 * 1024) break;
         if (rt == 1 && lds > OTP_LDS_LIMIT) return OTP_ERR_UNSUPPORTED;
     }
+    P.magicRT = (unsigned)((0x100000000ull + P.RT - 1) / P.RT);
+    P.magicNRX = (unsigned)((0x100000000ull + P.NRX - 1) / P.NRX);
+    P.magicWT = (unsigned)((0x100000000ull + P.WT - 1) / P.WT);
+    P.magicLWP = (unsigned)((0x100000000ull + P.LWP - 1) / P.LWP);
+    // 16-byte staging: stride 1, rows and tiles that are multiples of 4 columns, halo of at most 4 columns either side
+    P.vec = (stride == 1 && !P.sparse && W % 4 == 0 && P.Wo % 4 == 0 && P.WT % 4 == 0 && pad <= 4 &&
+             (kw - 1) * dil - pad <= 4 && (x_coff * H * W) % 4 == 0)
+                ? 1 : 0;
+    P.GD = P.WT / 4 > 0 ? P.WT / 4 : 1;
+    P.GX = (((4 - pad % 4) % 4) + P.LWP + 3) / 4;
+    P.magicGD = (unsigned)((0x100000000ull + P.GD - 1) / P.GD);
+    P.magicGX = (unsigned)((0x100000000ull + P.GX - 1) / P.GX);
     P.tiles_per_img = otp_ceil_div(P.Ho, P.RT) * P.tiles_x;
     P.ntiles = N * P.tiles_per_img;
     const int gy = otp_ceil_div(Cout, WG_CO), gz = otp_ceil_div(Cin, WG_CI);
-    int gx = 512 / (gy * gz);
-    if (gx < 8) gx = 8;
+    int gx = wgrad_grid_x(Cout, Cin);
     if (gx > P.ntiles) gx = P.ntiles;
+    // workspace given: per-workgroup partial sums + a reduction (no contended atomics); NULL: atomics straight into dW
+    float* part = static_cast<float*>(workspace);
+    if (part && workspace_bytes < (size_t)gx * gy * gz * WG_SLOTS * sizeof(float)) return OTP_ERR_WORKSPACE;
+    if (gx < 4) part = nullptr;                           // a handful of workgroups: the atomics are not contended
     auto kern = conv_wgrad_kernel;
     OTP_ALLOW_BIG_LDS(kern, lds);
-    hipLaunchKernelGGL(kern, dim3(gx, gy, gz), dim3(256), lds, static_cast<hipStream_t>(stream),
-                       static_cast<const float*>(x), static_cast<const float*>(grad_out), static_cast<float*>(grad_weight), P);
+    auto st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(kern, dim3(gx, gy, gz), dim3(256), lds, st, static_cast<const float*>(x),
+                       static_cast<const float*>(grad_out), static_cast<float*>(grad_weight), part, P);
+    if (part) {
+        const int segs = gx >= 64 ? 8 : (gx >= 16 ? 4 : 1);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(WG_SLOTS / 256, segs, gy * gz), dim3(256), 0, st, part,
+                           static_cast<float*>(grad_weight), gx, gy, Cout, Cin, kh);
+    }
     return otp_launch_status();
 }
 

@@ -44,7 +44,8 @@ SIGNATURES = {
     "otp_conv2d_plan": (c_int, [ctypes.POINTER(ConvDesc), ctypes.POINTER(c_int)]),
     "otp_conv2d_pack_weight_dgrad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "otp_dilate": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
-    "otp_conv2d_wgrad": (c_int, [c_void_p] * 3 + [c_int] * 14 + [c_void_p]),
+    "otp_conv2d_wgrad_workspace": (c_size_t, [c_int] * 2),
+    "otp_conv2d_wgrad": (c_int, [c_void_p] * 3 + [c_int] * 14 + [c_void_p, c_size_t, c_void_p]),
     "otp_bn_workspace": (c_size_t, [c_int] * 3),
     "otp_bn_train_forward": (c_int, [c_void_p] * 9 + [c_void_p, c_size_t] + [c_int] * 3 + [c_float, c_float] +
                              [c_int] * 7 + [c_void_p]),

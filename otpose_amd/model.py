@@ -163,7 +163,8 @@ class OTPose(nn.Module):
         margin = kwargs["margin"]
         from .engine import InferenceEngine
         if self.training:
-            # model.train(): BatchNorm batch statistics + an autograd tape over HIP kernels (otpose_amd/train.py)
+            # model.train(): BatchNorm batch statistics + an autograd tape over HIP kernels (otpose_amd/train.py);
+            # self.train_dropout = False switches Dropout / drop-path off (deterministic comparison with the oracle)
             from .train import forward_train
             self._engine = None
             return forward_train(self, x, margin)

@@ -3,8 +3,10 @@ script/Common.py:118) as a composition of autograd Functions whose forward AND b
 (:mod:`otpose_amd.train_ops`, :func:`otpose_amd.ops.modulated_deform_conv`), so ``loss.backward()`` walks HIP kernels.
 
 Semantics: BatchNorm2d uses batch statistics over this replica's 5B frames and updates its running statistics (the
-reference's DataParallel has no SyncBN either); Dropout(0.1) / drop-path(0.1) of the ConvTransformers are NOT applied
-(deterministic step; the reference's stochastic masks have no counterpart to check against - DESIGN.md section 6).
+reference's DataParallel has no SyncBN either).  Dropout(proj_pdrop) after ``proj`` and inside the MLP (blocks.py:251-253,
+450) and the per-sample drop-path of both residual branches (blocks.py:298-316) are applied with masks drawn from
+PyTorch's generator, like the reference's; ``model.train_dropout = False`` switches them off for the deterministic
+comparison against the oracle (the masks themselves have no counterpart to check against).
 What PyTorch itself executes here is plumbing: tensor views / cat / stack, and the handful of element-wise adds,
 products and per-sample divisions of the glue (model/OTPose.py:320-359); every convolution, normalisation, attention,
 pooling, up-sampling, DCN and loss kernel is in libotpose_hip.so.
@@ -88,6 +90,8 @@ class TrainGraph:
         self.Bf = dict(model.named_buffers())
         self.cfg = model.cfg
         self.taps = None                      # dict -> forward() records named intermediates (tools/grad_noise.py)
+        self.stochastic = bool(getattr(model, "train_dropout", True))
+        self.mods = dict(model.named_modules())
 
     # ---- conv / BN helpers ------------------------------------------------------------------------------------
     def has(self, name):
@@ -202,16 +206,31 @@ class TrainGraph:
             return self.conv1d(f"{p}.{name}", y)
 
         q, k, v = branch("query"), branch("key"), branch("value")
-        out = T.chan_attn(q, k, v, n_head, 1.0 / math.sqrt(hs))
-        return self.conv1d(p + ".proj", out)
+        out = T.chan_attn(q, k, v, n_head, 1.0 / math.sqrt(hs))          # attn_pdrop is 0 in OTPose.py:209-216
+        return self.dropout(self.conv1d(p + ".proj", out), self.mods[p].proj_pdrop)
+
+    def dropout(self, x, rate):
+        if self.stochastic and rate > 0.0:
+            return torch.nn.functional.dropout(x, rate, True)
+        return x
+
+    def drop_path(self, x, rate):
+        """blocks.py:303-316: one Bernoulli(keep) draw per sample, survivors scaled by 1/keep."""
+        if not (self.stochastic and rate > 0.0):
+            return x
+        keep = 1.0 - rate
+        mask = (keep + torch.rand((x.shape[0],) + (1,) * (x.dim() - 1), dtype=x.dtype, device=x.device)).floor_()
+        return x.div(keep) * mask
 
     def tblock(self, p, x, n_head, stride):
         a = self.mhca(p + ".attn", self.layer_norm(p + ".ln1", x), n_head, stride)
         skip = x if stride == 1 else T.maxpool3s2(x)
-        y = skip + self.P[p + ".drop_path_attn.scale"] * a
+        blk = self.mods[p]
+        y = skip + self.drop_path(self.P[p + ".drop_path_attn.scale"] * a, blk.path_pdrop)
         h = self.conv1d(p + ".mlp.0", self.layer_norm(p + ".ln2", y))
-        h = self.conv1d(p + ".mlp.3", T.gelu(h))
-        return y + self.P[p + ".drop_path_mlp.scale"] * h
+        h = self.conv1d(p + ".mlp.3", self.dropout(T.gelu(h), blk.proj_pdrop))
+        h = self.dropout(h, blk.proj_pdrop)
+        return y + self.drop_path(self.P[p + ".drop_path_mlp.scale"] * h, blk.path_pdrop)
 
     def conv_transformer(self, p, x4, n_head, arch):
         b, c, h, w = x4.shape

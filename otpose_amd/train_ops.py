@@ -53,13 +53,29 @@ def conv2d_grad_input(grad_out, weight, in_shape, stride, pad, dil):
     return gx
 
 
+_WS = {}
+
+
+def _workspace(device, nbytes):
+    """One grow-only scratch buffer per device for the wgrad partial sums (stream-ordered reuse: every user launches on
+    the current stream)."""
+    buf = _WS.get(device)
+    if buf is None or buf.numel() * 4 < nbytes:
+        buf = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+        _WS[device] = buf
+    return buf
+
+
 def conv2d_grad_weight(x, grad_out, weight_shape, stride, pad, dil):
     cout, cin, kh, kw = weight_shape
     gw = torch.zeros(weight_shape, dtype=torch.float32, device=x.device)
     x, g = x.contiguous(), grad_out.contiguous()
-    hip.check(hip.lib().otp_conv2d_wgrad(hip.ptr(x), hip.ptr(g), hip.ptr(gw), x.shape[0], cin, x.shape[2], x.shape[3],
-                                         cout, kh, kw, stride, pad, dil, cin, 0, cout, 0, hip.stream_of(x)),
-              "otp_conv2d_wgrad")
+    L = hip.lib()
+    nbytes = L.otp_conv2d_wgrad_workspace(cin, cout)
+    ws = _workspace(x.device, nbytes)
+    hip.check(L.otp_conv2d_wgrad(hip.ptr(x), hip.ptr(g), hip.ptr(gw), x.shape[0], cin, x.shape[2], x.shape[3],
+                                 cout, kh, kw, stride, pad, dil, cin, 0, cout, 0, hip.ptr(ws), nbytes,
+                                 hip.stream_of(x)), "otp_conv2d_wgrad")
     return gw
 
 

@@ -42,6 +42,7 @@ def test_train_step_matches_oracle_autograd():
     loss_ref.backward()
 
     model = model.cuda().train()
+    model.train_dropout = False
     outs = model(x.cuda(), margin=margin.cuda())
     for name, o, r in zip(("output", "rough", "intersection", "prev_b", "context", "squeezed", "total_b"), outs, outs_ref):
         err = float((o.detach().cpu().double() - r.detach()).abs().max())
@@ -89,3 +90,33 @@ def test_train_step_matches_oracle_autograd():
     # BatchNorm running statistics were updated like nn.BatchNorm2d does
     rm = model.state_dict()["rough_pose_estimation_net.bn1.running_mean"].cpu()
     assert float((rm - sd_cpu["rough_pose_estimation_net.bn1.running_mean"]).abs().max()) > 0
+
+
+def test_train_forward_dropout_and_drop_path():
+    """Dropout(0.1) / drop-path(0.1) of the ConvTransformers (blocks.py:251-253, 298-316, 450) are active under
+    model.train(): seeded draws repeat, different draws change the DCN output but not the HRNet heat-maps, and the
+    gradients still reach every encoder parameter."""
+    cfg = tiny_cfg(8, (64, 96))
+    model = OTPose(cfg)
+    S.fill_synthetic_(model)
+    model = model.cuda().train()
+    x, margin = S.synthetic_clip(2, cfg.MODEL.IMAGE_SIZE)
+    x, margin = x.cuda(), margin.cuda()
+    torch.manual_seed(5)
+    a = model(x, margin=margin)
+    torch.manual_seed(5)
+    b = model(x, margin=margin)
+    torch.manual_seed(6)
+    c = model(x, margin=margin)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[4], b[4])
+    assert torch.equal(a[1], c[1])                                    # HRNet has no stochastic layer
+    assert float((a[0] - c[0]).abs().max()) > 0 and float((a[4] - c[4]).abs().max()) > 0
+    model.train_dropout = False
+    d = model(x, margin=margin)
+    assert float((a[0] - d[0]).abs().max()) > 0
+    B, J, h, w = c[0].shape
+    g, wt = _targets(B, J, h, w)
+    TR.criterion(c, g.cuda(), wt.cuda()).backward()
+    for name, p in model.named_parameters():
+        if name.startswith(("temporal_encoder", "flow_encoder")):
+            assert p.grad is not None and bool(torch.isfinite(p.grad).all()), name

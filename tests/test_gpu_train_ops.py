@@ -31,6 +31,8 @@ CASES = [  # N, Cin, H, W, Cout, k, stride, pad, dil
     (2, 136, 1, 700, 136, 1, 1, 0, 1),    # Conv1d(k=1) of the ConvTransformers as (B, C, 1, T): column-tiled rows
     (1, 24, 5, 300, 40, 3, 1, 1, 1),      # wide image: column tiles with halo
     (2, 32, 16, 24, 34, 3, 1, 15, 15),    # dilation 15 on a small map (sparse row staging)
+    (1, 3, 24, 288, 20, 3, 2, 1, 1),      # full-width 384x288 stem rows: strided rows split into column tiles
+    (1, 20, 12, 144, 24, 3, 2, 1, 1),     # second stem conv width
 ]
 
 

@@ -73,6 +73,7 @@ def run_hip():
     m = OTPose(cfg)
     m.load_state_dict(sd)
     m = m.cuda().train()
+    m.train_dropout = False
     taps = {}
     outs = TR.forward_train(m, x.cuda(), margin.cuda(), taps)
     for t in taps.values():

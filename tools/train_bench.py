@@ -1,0 +1,66 @@
+#!/usr/bin/env python
+"""Training-step timing of the HIP autograd path (cfg3 of SURVEY.md section 8d, in fp32): forward (BatchNorm batch
+statistics), the two ST_OHKW terms, backward through every HIP kernel, global-norm clip and AdamW.  Development tool
+(run on the GPU box): `python tools/train_bench.py --batch 16 --steps 3`."""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from otpose_amd import OTPose, cfg2                    # noqa: E402
+from otpose_amd import synthetic as S                  # noqa: E402
+from otpose_amd import train as TR                     # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--no-dropout", action="store_true")
+    a = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    cfg = cfg2()
+    model = OTPose(cfg)
+    S.fill_synthetic_(model)
+    model = model.to(dev).train()
+    model.train_dropout = not a.no_dropout
+    x, margin = S.synthetic_clip(a.batch, cfg.MODEL.IMAGE_SIZE)
+    x, margin = x.to(dev), margin.to(dev)
+    J = cfg.MODEL.NUM_JOINTS
+    w, h = cfg.MODEL.HEATMAP_SIZE
+    g = torch.rand(a.batch, J, h, w, device=dev) * 0.2
+    g[:, ::2, 3, 4] = 1.0
+    wt = (torch.rand(a.batch, J, 1, device=dev) > 0.15).float()
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4, weight_decay=0.01)
+
+    def sync():
+        torch.cuda.synchronize()
+        return time.perf_counter()
+
+    for it in range(a.steps + 1):
+        torch.cuda.reset_peak_memory_stats()
+        t0 = sync()
+        outs = model(x, margin=margin)
+        t1 = sync()
+        loss = TR.criterion(outs, g, wt)
+        t2 = sync()
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        t3 = sync()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()
+        t4 = sync()
+        print("step %d%s: forward %.1f ms  loss %.1f ms  backward %.1f ms  clip+AdamW %.1f ms  total %.1f ms  "
+              "(%.1f frames/s)  loss %.5f  peak mem %.1f GB" %
+              (it, " (warm-up)" if it == 0 else "", (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3,
+               (t4 - t0) * 1e3, a.batch * 5 / (t4 - t0), float(loss), torch.cuda.max_memory_allocated() / 2**30),
+              flush=True)
+
+
+if __name__ == "__main__":
+    main()
