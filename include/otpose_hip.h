@@ -205,6 +205,20 @@ int otp_axpby(const void* x, void* y, float alpha, float beta, size_t n, void* s
 int otp_heatmap_decode(const void* heatmaps, void* preds, void* maxvals, const void* center, const void* scale,
                        int N, int J, int H, int W, int refine, void* stream);
 
+/* PCK accuracy of the training / validation loops (utils/evaluate.py:384-415 accuracy, :352-381 calc_dists / dist_acc;
+ * called per iteration at script/Common.py:147-150) from the otp_heatmap_decode(refine = 0) coordinates (N,J,2) of the
+ * predicted and target heat-maps of size H x W: acc (J+1) float32 = [mean over joints with a valid sample, per-joint
+ * fraction of valid samples with distance < thr (-1: no valid sample)], cnt (1) int32 = joints with a valid sample. */
+int otp_pck_accuracy(const void* pred_coords, const void* target_coords, void* acc, void* cnt, int N, int J, int H, int W,
+                     float thr, void* stream);
+
+/* ---- input assembly (the step before the path: dataset/PoseTrackDataset.py:397-406 transform per frame =
+ * utils/transform.py:7-15 ToTensor + Normalize, script/Common.py:117 torch.cat over the frames) ---------------------
+ * frames_u8 (B, F, H, W, 3) uint8 RGB, HWC like the cv2.warpAffine output -> out (B, 3F, H, W) float32,
+ * out[b, 3f + c] = (u8 / 255 - mean_c) / std_c in float32, bit-identical to torchvision's two steps.  H*W % 4 == 0. */
+int otp_frames_u8_to_clip(const void* frames_u8, void* out, int B, int F, int H, int W, float mean_r, float mean_g,
+                          float mean_b, float std_r, float std_g, float std_b, void* stream);
+
 /* ---- heatmap losses (model/loss.py) ------------------------------------------------------------- */
 /* ST_OHKW_MSELoss.forward (loss.py:25-92): s,t,g (B,J,HW), w (B,J); flags (J) int32 in/out: when
  * flags_given == 0 the kernel computes flags[j] = (max_b,p g[b,j,p] == 1) itself; result[0..2] =

@@ -475,3 +475,40 @@ def get_final_preds(hm, center=None, scale=None):
             preds[a, :, 0] = center[a][0] + (coords[a, :, 0] - 0.5 * w) * k
             preds[a, :, 1] = center[a][1] + (coords[a, :, 1] - 0.5 * h) * k
     return preds, maxvals
+
+
+def accuracy(output, target, thr=0.5):
+    """utils/evaluate.py:384-415 (hm_type='gaussian') with calc_dists (:352-365) and dist_acc (:368-381): PCK on the
+    argmax coordinates of predicted and target heat-maps.  Returns (acc (J+1) float64, avg_acc, cnt, pred)."""
+    import numpy as np
+    pred, _ = get_max_preds(output)
+    tgt, _ = get_max_preds(target)
+    n, j, h, w = np.asarray(output).shape
+    norm = np.ones((n, 2)) * np.array([h, w]) / 10                     # :396 - (x, y) divided by (h, w)/10, as written
+    valid = (tgt[:, :, 0] > 1) & (tgt[:, :, 1] > 1)                     # :358
+    d = np.linalg.norm(pred.astype(np.float32) / norm[:, None, :] - tgt.astype(np.float32) / norm[:, None, :], axis=2)
+    dists = np.where(valid, d, -1.0).T                                  # (J, N), -1 = ignored
+    acc = np.zeros(j + 1)
+    avg, cnt = 0.0, 0
+    for k in range(j):
+        use = dists[k] != -1
+        acc[k + 1] = (dists[k][use] < thr).sum() * 1.0 / use.sum() if use.sum() > 0 else -1      # :368-381
+        if acc[k + 1] >= 0:
+            avg += acc[k + 1]
+            cnt += 1
+    avg = avg / cnt if cnt != 0 else 0
+    if cnt != 0:
+        acc[0] = avg
+    return acc, avg, cnt, pred
+
+
+def frames_to_clip(frames_u8, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
+    """The reference's per-frame transform and clip assembly: torchvision ToTensor (uint8 HWC -> float CHW / 255) then
+    Normalize ((t - mean) / std) (utils/transform.py:7-15, applied at dataset/PoseTrackDataset.py:397-406), frames
+    concatenated on the channel axis (script/Common.py:117).  frames_u8 (B, F, H, W, 3) uint8 -> (B, 3F, H, W) float32."""
+    t = frames_u8.permute(0, 1, 4, 2, 3).to(torch.float32).div(255)
+    m = torch.tensor(mean, dtype=torch.float32).view(1, 1, 3, 1, 1)
+    s = torch.tensor(std, dtype=torch.float32).view(1, 1, 3, 1, 1)
+    t = (t - m) / s
+    b, f, c, h, w = t.shape
+    return t.reshape(b, f * c, h, w)

@@ -197,6 +197,81 @@ __global__ __launch_bounds__(256) void upsample_add_bwd_kernel(const float* __re
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// PCK accuracy of the training / validation loop (utils/evaluate.py:352-415: calc_dists, dist_acc, accuracy), from the
+// argmax coordinates of the predicted and the target heat-maps: per joint the fraction of samples whose normalised
+// distance is below thr, samples whose target argmax has x <= 1 or y <= 1 ignored; acc[0] = mean over the joints that
+// have a valid sample.  The reference divides (x, y) by (H/10, W/10) in that order (evaluate.py:396, 357-358) - kept.
+// One workgroup; a thread per joint walks the batch; float64 like the numpy reference.
+__global__ __launch_bounds__(256) void pck_accuracy_kernel(const float* __restrict__ pred, const float* __restrict__ tgt,
+                                                            float* __restrict__ acc, int* __restrict__ cnt, int N, int J,
+                                                            int H, int W, float thr) {
+    __shared__ double s_acc[256];
+    __shared__ int s_ok[256];
+    const double nx = (double)H / 10.0, ny = (double)W / 10.0;
+    double avg = 0.0;
+    int c = 0;
+    for (int j0 = 0; j0 < J; j0 += 256) {
+        const int j = j0 + threadIdx.x;
+        double a = -1.0;
+        if (j < J) {
+            int valid = 0, hit = 0;
+            for (int n = 0; n < N; ++n) {
+                const float tx = tgt[((size_t)n * J + j) * 2], ty = tgt[((size_t)n * J + j) * 2 + 1];
+                if (tx > 1.f && ty > 1.f) {
+                    const double dx = (double)pred[((size_t)n * J + j) * 2] / nx - (double)tx / nx;
+                    const double dy = (double)pred[((size_t)n * J + j) * 2 + 1] / ny - (double)ty / ny;
+                    ++valid;
+                    if (sqrt(dx * dx + dy * dy) < (double)thr) ++hit;
+                }
+            }
+            if (valid > 0) a = (double)hit / (double)valid;
+            acc[j + 1] = (float)a;
+        }
+        s_acc[threadIdx.x] = a >= 0.0 ? a : 0.0;
+        s_ok[threadIdx.x] = a >= 0.0 ? 1 : 0;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (int t = 0; t < 256 && j0 + t < J; ++t) { avg += s_acc[t]; c += s_ok[t]; }   // joint order, like the reference loop
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        acc[0] = c ? (float)(avg / c) : 0.f;
+        *cnt = c;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// input assembly (the step before the path: dataset/PoseTrackDataset.py:397-406 + utils/transform.py:7-15 ToTensor /
+// Normalize per frame, script/Common.py:117 channel concat): uint8 HWC frames (B, F, H, W, 3) ->
+// float32 (B, 3F, H, W) with v = (u8 / 255 - mean_c) / std_c, the exact float32 operation order of torchvision.
+// A thread converts 4 pixels: three aligned dword loads, one float4 store per colour plane.
+__global__ __launch_bounds__(256) void frames_u8_kernel(const uint32_t* __restrict__ in, float* __restrict__ out, int HW4,
+                                                         size_t total4, float m0, float m1, float m2, float s0, float s1,
+                                                         float s2) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t img = i / HW4;                                      // (b, f) image
+        const int q = (int)(i - img * HW4);                              // group of 4 pixels
+        const uint32_t w0 = in[i * 3], w1 = in[i * 3 + 1], w2 = in[i * 3 + 2];
+        // bytes: r0 g0 b0 r1 | g1 b1 r2 g2 | b2 r3 g3 b3
+        const float r[4] = {(float)(w0 & 255), (float)(w0 >> 24), (float)((w1 >> 16) & 255), (float)((w2 >> 8) & 255)};
+        const float g[4] = {(float)((w0 >> 8) & 255), (float)(w1 & 255), (float)(w1 >> 24), (float)((w2 >> 16) & 255)};
+        const float b[4] = {(float)((w0 >> 16) & 255), (float)((w1 >> 8) & 255), (float)(w2 & 255), (float)(w2 >> 24)};
+        otp_f32x4 vr, vg, vb;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            vr[e] = (r[e] / 255.f - m0) / s0;
+            vg[e] = (g[e] / 255.f - m1) / s1;
+            vb[e] = (b[e] / 255.f - m2) / s2;
+        }
+        float* o = out + img * 3 * (size_t)HW4 * 4 + (size_t)q * 4;
+        *reinterpret_cast<otp_f32x4*>(o) = vr;
+        *reinterpret_cast<otp_f32x4*>(o + (size_t)HW4 * 4) = vg;
+        *reinterpret_cast<otp_f32x4*>(o + (size_t)HW4 * 8) = vb;
+    }
+}
+
 }  // namespace
 
 extern "C" int otp_glue_total(const void* rough, void* total, void* squeezed, void* inter, void* flow_in,
@@ -273,6 +348,27 @@ extern "C" int otp_heatmap_decode(const void* heatmaps, void* preds, void* maxva
     hipLaunchKernelGGL(heatmap_decode_kernel, dim3(otp_ceil_div(NJ, 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        static_cast<const float*>(heatmaps), static_cast<float*>(preds), static_cast<float*>(maxvals),
                        static_cast<const float*>(center), static_cast<const float*>(scale), NJ, J, H, W, refine);
+    return otp_launch_status();
+}
+
+extern "C" int otp_pck_accuracy(const void* pred_coords, const void* target_coords, void* acc, void* cnt, int N, int J,
+                                int H, int W, float thr, void* stream) {
+    if (!pred_coords || !target_coords || !acc || !cnt || N <= 0 || J <= 0 || H <= 0 || W <= 0) return OTP_ERR_BAD_ARG;
+    hipLaunchKernelGGL(pck_accuracy_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const float*>(pred_coords), static_cast<const float*>(target_coords),
+                       static_cast<float*>(acc), static_cast<int*>(cnt), N, J, H, W, thr);
+    return otp_launch_status();
+}
+
+extern "C" int otp_frames_u8_to_clip(const void* frames_u8, void* out, int B, int F, int H, int W, float mean_r,
+                                     float mean_g, float mean_b, float std_r, float std_g, float std_b, void* stream) {
+    if (!frames_u8 || !out || B <= 0 || F <= 0 || H <= 0 || W <= 0) return OTP_ERR_BAD_ARG;
+    if (((size_t)H * W) % 4 != 0 || std_r == 0.f || std_g == 0.f || std_b == 0.f) return OTP_ERR_UNSUPPORTED;
+    const int HW4 = H * W / 4;
+    const size_t total4 = (size_t)B * F * HW4, blocks = (total4 + 255) / 256;
+    hipLaunchKernelGGL(frames_u8_kernel, dim3(blocks > 16384 ? 16384 : (unsigned)blocks), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), static_cast<const uint32_t*>(frames_u8), static_cast<float*>(out),
+                       HW4, total4, mean_r, mean_g, mean_b, std_r, std_g, std_b);
     return otp_launch_status();
 }
 

@@ -57,6 +57,10 @@ class InferenceEngine:
         return (x.shape[0] == self.B and x.device == self.dev and tuple(x.shape[2:]) == (self.H_img, self.W_img)
                 and self._param_version() == self.param_version)
 
+    def matches_shape(self, b, c, h, w, dev) -> bool:
+        return (b == self.B and dev == self.dev and (h, w) == (self.H_img, self.W_img) and c == 15
+                and self._param_version() == self.param_version)
+
     def _param_version(self):
         return sum(p._version for p in self.model.parameters())
 
@@ -373,7 +377,11 @@ class InferenceEngine:
     def run(self, x, margin):
         if not x.is_cuda:
             raise RuntimeError("OTPose.forward expects CUDA (HIP) tensors; there is no CPU path")
-        self.inp.copy_(x)
+        if x.dtype == torch.uint8:
+            # (B, 5, H, W, 3) uint8 frames: normalise + concatenate straight into the stem conv's input buffer
+            ops.frames_to_clip(x, out=self.inp)
+        else:
+            self.inp.copy_(x)
         self.margin.copy_(margin.to(torch.float32))
         if self.use_graph and self.graph is None:
             self._launch_all()                      # warm-up (sets kernel attributes) before capture

@@ -172,6 +172,19 @@ class OTPose(nn.Module):
             self._engine = InferenceEngine(self, x.shape[0], x.device)
         return self._engine.run(x, margin)
 
+    def forward_frames(self, frames_u8, margin):
+        """Eval forward from raw uint8 RGB crops (B, 5, H, W, 3) in the order cur, prev, next, pprev, nnext: the
+        ToTensor + Normalize + concat of the reference data pipeline (dataset/PoseTrackDataset.py:397-406,
+        script/Common.py:117) run as one HIP kernel writing the stem's input buffer."""
+        if self.training:
+            from . import ops
+            return self.forward(ops.frames_to_clip(frames_u8), margin=margin)
+        from .engine import InferenceEngine
+        b, f, h, w, _ = frames_u8.shape
+        if self._engine is None or not self._engine.matches_shape(b, 3 * f, h, w, frames_u8.device):
+            self._engine = InferenceEngine(self, b, frames_u8.device)
+        return self._engine.run(frames_u8, margin)
+
     def invalidate_engine(self):
         """Drop packed weights (call after changing parameters, e.g. load_state_dict)."""
         self._engine = None

@@ -316,6 +316,46 @@ def _decode(hm, center, scale, refine):
     return preds, maxvals
 
 
+def accuracy(output, target, hm_type="gaussian", thr=0.5):
+    """Device form of reference utils/evaluate.py:384-415 (called per iteration at script/Common.py:147-150 on heat-maps
+    copied to the host): PCK of the argmax of ``output`` against the argmax of ``target``.  Returns
+    ``(acc (J+1), avg_acc, cnt, pred)`` like the reference, as device tensors (no synchronisation)."""
+    if hm_type != "gaussian":
+        raise NotImplementedError("only hm_type='gaussian' (the reference's only caller)")
+    pred, _ = get_max_preds(output)
+    tgt, _ = get_max_preds(target)
+    n, j, h, w = output.shape
+    acc = torch.empty(j + 1, dtype=torch.float32, device=output.device)
+    cnt = torch.empty(1, dtype=torch.int32, device=output.device)
+    hip.check(hip.lib().otp_pck_accuracy(hip.ptr(pred), hip.ptr(tgt), hip.ptr(acc), hip.ptr(cnt), n, j, h, w, float(thr),
+                                         hip.stream_of(output)), "otp_pck_accuracy")
+    return acc, acc[0], cnt[0], pred
+
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)        # utils/transform.py:7-8
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def frames_to_clip(frames_u8, mean=IMAGENET_MEAN, std=IMAGENET_STD, out=None):
+    """uint8 RGB frames (B, F, H, W, 3) (the five warped crops of dataset/PoseTrackDataset.py:390-399) -> the model input
+    (B, 3F, H, W) float32: ToTensor + Normalize per frame (utils/transform.py:11-15) and the channel concat of
+    script/Common.py:117 in one kernel, bit-identical to the torchvision float32 arithmetic.  Moves 4x fewer bytes over
+    PCIe than shipping normalised floats."""
+    _require_gpu(frames_u8)
+    if frames_u8.dtype != torch.uint8 or frames_u8.dim() != 5 or frames_u8.shape[-1] != 3:
+        raise TypeError("frames_u8 must be a (B, F, H, W, 3) uint8 tensor")
+    frames_u8 = frames_u8.contiguous()
+    b, f, h, w, _ = frames_u8.shape
+    if out is None:
+        out = torch.empty((b, 3 * f, h, w), dtype=torch.float32, device=frames_u8.device)
+    elif out.shape != (b, 3 * f, h, w) or out.dtype != torch.float32 or not out.is_contiguous():
+        raise ValueError("out must be a contiguous float32 (B, 3F, H, W) tensor")
+    hip.check(hip.lib().otp_frames_u8_to_clip(hip.ptr(frames_u8), hip.ptr(out), b, f, h, w, *[float(v) for v in mean],
+                                              *[float(v) for v in std], hip.stream_of(frames_u8)),
+              "otp_frames_u8_to_clip")
+    return out
+
+
 def st_ohkw_loss(s, t, g, w, topk=8, flags=None, with_grad=False):
     """ST_OHKW_MSELoss forward (+ analytic gradients) on the GPU; returns dict like the reference
     (model/loss.py:89-91) plus ``flags`` and, when requested, ``grad_s`` / ``grad_t``."""

@@ -188,6 +188,36 @@ def gen_decode():
     save("decode", hm=hm, max_preds=p0, maxvals=m0, final_preds=p1)
 
 
+def gen_accuracy():
+    """accuracy() of the reference (utils/evaluate.py:384-415) on seeded heat-map pairs.  The module's unrelated imports
+    (motmetrics, shapely, utils.setup -> yacs) are absent here and replaced by empty modules; accuracy / calc_dists /
+    dist_acc touch none of them."""
+    import_reference()
+    for name in ("motmetrics", "shapely", "shapely.geometry", "utils.setup"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["shapely"].geometry = sys.modules["shapely.geometry"]
+    sys.modules["utils.setup"].convert_videos = None
+    import utils.evaluate as E
+    n, j, h, w = 6, 17, 24, 18
+    tgt = (seeded((n, j, h, w), 51) * 0.1).numpy().copy()
+    out = (seeded((n, j, h, w), 52) * 0.1).numpy().copy()
+    rng = np.random.RandomState(5)
+    for b in range(n):
+        for k in range(j):
+            ty, tx = rng.randint(0, h), rng.randint(0, w)
+            tgt[b, k, ty, tx] = 1.0
+            dy, dx = rng.randint(-2, 3), rng.randint(-2, 3)          # predictions 0..2.8 px away: both sides of thr
+            out[b, k, min(max(ty + dy, 0), h - 1), min(max(tx + dx, 0), w - 1)] = 2.0
+    tgt[:, 3] = -1.0                                  # joint without any valid target (argmax masked to 0) -> acc -1
+    tgt[0, 5] = 0.0
+    tgt[0, 5, 1, 7] = 1.0                             # y = 1 fails the strict > 1 test: sample ignored
+    acc, avg, cnt, pred = E.accuracy(out.copy(), tgt.copy())
+    acc7, avg7, cnt7, _ = E.accuracy(out.copy(), tgt.copy(), thr=0.7)
+    save("accuracy", out=out, tgt=tgt, acc=acc, avg=np.array([avg, avg7]), cnt=np.array([cnt, cnt7]), pred=pred,
+         acc7=acc7)
+    print("  acc", np.round(acc, 3), "avg", avg, "cnt", cnt)
+
+
 def _e2e(cfg, batch, name, keep_rough=True):
     with torch.no_grad():
         m = ref_otpose(cfg)
@@ -254,7 +284,7 @@ def calibrate():
 
 
 GENS = {"keys": gen_state_dict_keys, "blocks": gen_blocks, "hrnet_tiny": gen_hrnet_tiny,
-        "losses": gen_losses, "decode": gen_decode, "e2e_tiny": gen_e2e_tiny, "e2e_cfg1": gen_e2e_cfg1, "e2e_cfg2": gen_e2e_cfg2}
+        "losses": gen_losses, "decode": gen_decode, "accuracy": gen_accuracy, "e2e_tiny": gen_e2e_tiny, "e2e_cfg1": gen_e2e_cfg1, "e2e_cfg2": gen_e2e_cfg2}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

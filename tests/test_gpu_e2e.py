@@ -67,3 +67,20 @@ def test_graph_replay_and_eager_agree_and_batch_rows_are_independent():
     with torch.no_grad():
         solo = m2(x[1:2].cuda(), margin=margin[1:2].cuda())
     assert float((solo[0].cpu() - outs[0][1:2]).abs().max()) <= 1e-5
+
+
+def test_forward_frames_u8_equals_forward_of_normalised_clip():
+    """OTPose.forward_frames(uint8 crops) == OTPose.forward(ToTensor + Normalize + concat of the same crops)."""
+    from oracle import otpose_oracle as O
+    cfg = tiny_cfg(8, (64, 96))
+    model = OTPose(cfg)
+    S.fill_synthetic_(model)
+    model = model.cuda().eval()
+    gen = torch.Generator().manual_seed(3)
+    frames = torch.randint(0, 256, (2, 5, 96, 64, 3), generator=gen, dtype=torch.uint8)
+    margin = torch.tensor([[1.0, 1.0, 2.0, 2.0], [0.0, 1.0, 0.0, 2.0]])
+    with torch.no_grad():
+        a = [t.clone() for t in model.forward_frames(frames.cuda(), margin.cuda())]
+        b = model(O.frames_to_clip(frames).cuda(), margin=margin.cuda())
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
