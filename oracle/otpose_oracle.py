@@ -294,6 +294,17 @@ def mdcn_forward(x, offset, mask, weight, bias, stride=1, pad=0, dil=1, groups=1
     return out
 
 
+def dcn_v1_forward(x, offset, weight, stride=1, pad=0, dil=1, groups=1, dg=1):
+    """DCN v1 forward (deform_conv_cuda.cpp:148-249 + deformable_im2col_gpu_kernel, .cu:128-183): the sampling window
+    test (.cu:166) and the corner rules of deformable_im2col_bilinear (.cu:22-51) are those of the modulated kernel
+    (.cu:549, 403-432), so v1 is the modulated op with mask == 1 and no bias.  Differentiable like mdcn_forward."""
+    kh, kw = weight.shape[2:]
+    ho = (x.shape[2] + 2 * pad - (dil * (kh - 1) + 1)) // stride + 1
+    wo = (x.shape[3] + 2 * pad - (dil * (kw - 1) + 1)) // stride + 1
+    mask = x.new_ones((x.shape[0], dg * kh * kw, ho, wo))
+    return mdcn_forward(x, offset, mask, weight, None, stride, pad, dil, groups, dg)
+
+
 def mdcn_backward(x, offset, mask, weight, grad_out, stride=1, pad=0, dil=1, groups=1, dg=1, with_bias=True):
     """Analytic gradients (deform_conv_cuda.cpp:596-660; kernels .cu:574-705, helpers :434-503).
     Returns (grad_x, grad_offset, grad_mask, grad_weight, grad_bias)."""

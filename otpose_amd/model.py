@@ -8,6 +8,7 @@ no PyTorch-op or CPU fallback: without a GPU or without the built library the ca
 from __future__ import annotations
 
 import logging
+import math
 import os
 
 import torch
@@ -47,6 +48,29 @@ class ModulatedDeformConv(nn.Module):
     def forward(self, x, offset, mask):
         return ops.modulated_deform_conv(x, offset, mask, self.weight, self.bias, self.stride,
                                          self.padding, self.dilation, self.groups, self.deformable_groups)
+
+
+class DeformConv(nn.Module):
+    """DCN v1 module (reference thirdparty/deform_conv/modules/deform_conv.py:10-60): no mask, no bias."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 deformable_groups=1, bias=False):
+        super().__init__()
+        assert not bias
+        assert in_channels % groups == 0 and out_channels % groups == 0
+        k = (kernel_size, kernel_size) if isinstance(kernel_size, int) else tuple(kernel_size)
+        self.in_channels, self.out_channels, self.kernel_size = in_channels, out_channels, k
+        self.stride, self.padding, self.dilation = stride, padding, dilation
+        self.groups, self.deformable_groups = groups, deformable_groups
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels // groups, *k))
+        stdv = 1.0 / math.sqrt(in_channels * k[0] * k[1])
+        with torch.no_grad():
+            self.weight.uniform_(-stdv, stdv)
+
+    def forward(self, x, offset):
+        from . import ops
+        return ops.deform_conv(x, offset, self.weight, self.stride, self.padding, self.dilation, self.groups,
+                               self.deformable_groups)
 
 
 class DeformableCONV(nn.Module):

@@ -142,6 +142,104 @@ class ModulatedDeformConvFunction(Function):
 modulated_deform_conv = ModulatedDeformConvFunction.apply
 
 
+# ---- DCN v1 (no modulation mask, no bias): the other three entry points of the reference's pybind module ----------
+# The v1 kernels sample exactly like the modulated ones (same (-1, H) x (-1, W) window and corner tests:
+# deform_conv_cuda_kernel.cu:22-51,166 vs :403-432,549), so they run on the same HIP kernels with an all-ones mask.
+_ONES = {}
+
+
+def _ones_mask(like, n, ch, h, w):
+    key = (like.device, n, ch, h, w)
+    t = _ONES.get(key)
+    if t is None:
+        _ONES.clear()                      # one shape at a time: the mask is scratch, not state
+        t = _ONES[key] = torch.ones((n, ch, h, w), dtype=torch.float32, device=like.device)
+    return t
+
+
+def _v1_check(dW, dH, padW, padH, dilationW, dilationH):
+    if dW != dH or padW != padH or dilationW != dilationH:
+        raise RuntimeError("deform_conv: anisotropic stride/pad/dilation is not supported")
+
+
+def deform_conv_forward_cuda(input, weight, offset, output, columns, ones, kW, kH, dW, dH, padW, padH, dilationW,
+                             dilationH, group, deformable_group, im2col_step):
+    """Reference pybind signature deform_conv_cuda.cpp:148-153 (returns 1).  ``columns`` / ``ones`` / ``im2col_step``
+    are accepted and ignored: there is no im2col scratch and every image is one launch."""
+    _v1_check(dW, dH, padW, padH, dilationW, dilationH)
+    n = input.shape[0]
+    mask = _ones_mask(input, n, deformable_group * kH * kW, output.shape[2], output.shape[3])
+    modulated_deform_conv_cuda_forward(input, weight, None, None, offset, mask, output, None, kH, kW, dH, dW, padH, padW,
+                                       dilationH, dilationW, group, deformable_group, False)
+    return 1
+
+
+def _v1_backward(input, offset, grad_output, weight, kW, kH, dH, padH, dilationH, group, deformable_group):
+    n = input.shape[0]
+    mask = _ones_mask(input, n, deformable_group * kH * kW, grad_output.shape[2], grad_output.shape[3])
+    gi, go, gm = torch.empty_like(input), torch.empty_like(offset), torch.empty_like(mask)
+    gw = torch.zeros_like(weight)
+    modulated_deform_conv_cuda_backward(input, weight, None, None, offset, mask, None, gi, gw, None, go, gm, grad_output,
+                                        kH, kW, dH, dH, padH, padH, dilationH, dilationH, group, deformable_group, False)
+    return gi, go, gw
+
+
+def deform_conv_backward_input_cuda(input, offset, gradOutput, gradInput, gradOffset, weight, columns, kW, kH, dW, dH,
+                                    padW, padH, dilationW, dilationH, group, deformable_group, im2col_step):
+    """Reference pybind signature deform_conv_cuda.cpp:251-257: overwrites gradInput / gradOffset (returns 1)."""
+    _v1_check(dW, dH, padW, padH, dilationW, dilationH)
+    gi, go, _ = _v1_backward(input, offset, gradOutput, weight, kW, kH, dH, padH, dilationH, group, deformable_group)
+    gradInput.copy_(gi)
+    gradOffset.copy_(go)
+    return 1
+
+
+def deform_conv_backward_parameters_cuda(input, offset, gradOutput, gradWeight, columns, ones, kW, kH, dW, dH, padW, padH,
+                                         dilationW, dilationH, group, deformable_group, scale, im2col_step):
+    """Reference pybind signature deform_conv_cuda.cpp:364-370: gradWeight += scale * dL/dW (returns 1)."""
+    _v1_check(dW, dH, padW, padH, dilationW, dilationH)
+    # dL/dW does not depend on W; the input / offset gradients computed alongside are discarded
+    _, _, gw = _v1_backward(input, offset, gradOutput, torch.zeros_like(gradWeight), kW, kH, dH, padH, dilationH, group,
+                            deformable_group)
+    gradWeight.add_(gw, alpha=float(scale))
+    return 1
+
+
+class DeformConvFunction(Function):
+    """autograd wrapper of DCN v1 (reference thirdparty/deform_conv/functions/deform_conv.py:10-107)."""
+
+    @staticmethod
+    def forward(ctx, input, offset, weight, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1, im2col_step=80):
+        if input is not None and input.dim() != 4:
+            raise ValueError("Expected 4D tensor as input, got {}D tensor instead.".format(input.dim()))
+        if not input.is_cuda:
+            raise NotImplementedError
+        ctx.stride, ctx.padding, ctx.dilation = stride, padding, dilation
+        ctx.groups, ctx.deformable_groups = groups, deformable_groups
+        ctx.save_for_backward(input, offset, weight)
+        kh, kw = weight.shape[2:4]
+        ho, wo = _out_hw(input.shape[2], input.shape[3], kh, kw, stride, padding, dilation)
+        if ho <= 0 or wo <= 0:
+            raise ValueError("convolution input is too small (output would be {}x{})".format(ho, wo))
+        output = input.new_empty((input.shape[0], weight.shape[0], ho, wo))
+        deform_conv_forward_cuda(input.contiguous(), weight.contiguous(), offset, output, None, None, kw, kh, stride, stride,
+                                 padding, padding, dilation, dilation, groups, deformable_groups, im2col_step)
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        if not grad_output.is_cuda:
+            raise NotImplementedError
+        input, offset, weight = ctx.saved_tensors
+        kh, kw = weight.shape[2:4]
+        gi, go, gw = _v1_backward(input.contiguous(), offset, grad_output, weight.contiguous(), kw, kh, ctx.stride,
+                                  ctx.padding, ctx.dilation, ctx.groups, ctx.deformable_groups)
+        return gi, go, gw, None, None, None, None, None, None
+
+
+deform_conv = DeformConvFunction.apply
+
+
 # ------------------------------------------------------------------------------------------------
 # thin functional wrappers over the remaining C entry points (used by the engine and the tests)
 # ------------------------------------------------------------------------------------------------

@@ -143,3 +143,37 @@ def test_full_size_properties():
     assert float((o2 - 2.5 * o1).abs().max()) <= 1e-4 * float(o1.abs().max())
     ref = O.mdcn_forward(x[5:6].cpu(), off[5:6].cpu(), m[5:6].cpu(), w.cpu(), None, 1, 6, 6, 1, 17)
     _close(o1[5:6], ref, 5e-5)
+
+
+@pytest.mark.parametrize("case", [CASES[0], CASES[3], CASES[4]])
+def test_dcn_v1_matches_oracle(case):
+    """DCN v1 (deform_conv_forward_cuda / backward_input / backward_parameters, deform_conv_cuda.cpp:148-472): forward
+    and all three gradients vs the oracle's v1 restatement under autograd; the in-place pybind-style entry points
+    including the ``scale`` accumulation of backward_parameters."""
+    x, off, _, w, _ = _inputs(case)
+    N, C, H, W, Co, k, stride, pad, dil, groups, dg = case
+    xr, offr, wr = (t.clone().requires_grad_() for t in (x, off, w))
+    ref = O.dcn_v1_forward(xr, offr, wr, stride, pad, dil, groups, dg)
+    go = seeded(ref.shape, 9)
+    ref.backward(go)
+    xs, offs, ws = (t.cuda().requires_grad_() for t in (x, off, w))
+    out = ops.deform_conv(xs, offs, ws, stride, pad, dil, groups, dg)
+    _close(out, ref.detach())
+    out.backward(go.cuda())
+    _close(xs.grad, xr.grad, 1e-4)
+    _close(offs.grad, offr.grad, 1e-4)
+    _close(ws.grad, wr.grad, 1e-4)
+    # pybind-style calls
+    o2 = torch.empty_like(out)
+    assert ops.deform_conv_forward_cuda(xs.detach(), ws.detach(), offs.detach(), o2, None, None, k, k, stride, stride,
+                                        pad, pad, dil, dil, groups, dg, 1) == 1
+    assert torch.equal(o2, out.detach())
+    gi, goff = torch.zeros_like(xs), torch.zeros_like(offs)
+    ops.deform_conv_backward_input_cuda(xs.detach(), offs.detach(), go.cuda(), gi, goff, ws.detach(), None, k, k, stride,
+                                        stride, pad, pad, dil, dil, groups, dg, 1)
+    _close(gi, xr.grad, 1e-4)
+    _close(goff, offr.grad, 1e-4)
+    gw = torch.ones_like(ws)
+    ops.deform_conv_backward_parameters_cuda(xs.detach(), offs.detach(), go.cuda(), gw, None, None, k, k, stride, stride,
+                                             pad, pad, dil, dil, groups, dg, 0.5, 1)
+    _close(gw, 1.0 + 0.5 * wr.grad, 1e-4)
