@@ -188,12 +188,15 @@ __global__ __launch_bounds__(256, 2) void conv_win_kernel(
         const int f = P.res_up > 1 ? P.res_up : 1;
         // scale / shift of this wave's 16*MB output channels: lane l holds channel l (one global round trip per tile;
         // the store loops fetch them with a lane shuffle)
-        float sc_l = 1.f, sh_l = 0.f;
-        {
-            const int co = T.m_wg + m_wave + lane;
-            if (lane < 16 * MB && co < P.Cout) {
-                if (scale) sc_l = scale[co];
-                if (shift) sh_l = shift[co];
+        constexpr int NSC = (16 * MB + 63) / 64;
+        float sc_l[NSC], sh_l[NSC];
+#pragma unroll
+        for (int i = 0; i < NSC; ++i) {
+            const int co = T.m_wg + m_wave + lane + 64 * i;
+            sc_l[i] = 1.f; sh_l[i] = 0.f;
+            if (lane + 64 * i < 16 * MB && co < P.Cout) {
+                if (scale) sc_l[i] = scale[co];
+                if (shift) sh_l[i] = shift[co];
             }
         }
 #pragma unroll
@@ -209,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void conv_win_kernel(
                 // Buffer descriptors over this image's out / res slices: channels past Cout fall off the end and are
                 // dropped by the range check; pixels past Ho*Wo are masked to an out-of-range offset.
                 const int row = lane >> 2, c40 = lane & 3;
-                const float sc = __shfl(sc_l, mb * 16 + row, 64), sh = __shfl(sh_l, mb * 16 + row, 64);
+                const float sc = __shfl(sc_l[mb >> 2], (mb & 3) * 16 + row, 64), sh = __shfl(sh_l[mb >> 2], (mb & 3) * 16 + row, 64);
                 const int co = co_base + row;
                 const unsigned obytes = co < P.Cout ? (unsigned)P.HoWo * 4u : 0u;
                 const float* ep_row = ep + row * RS + 4 * c40;
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void conv_win_kernel(
                 for (int i = lane; i < 16 * 16 * PB; i += 64) {
                     const int row = i / (16 * PB), col = i - row * (16 * PB);
                     const int co = co_base + row, q = pix_wave + col;
-                    const float sc = __shfl(sc_l, mb * 16 + row, 64), sh = __shfl(sh_l, mb * 16 + row, 64);
+                    const float sc = __shfl(sc_l[mb >> 2], (mb & 3) * 16 + row, 64), sh = __shfl(sh_l[mb >> 2], (mb & 3) * 16 + row, 64);
                     if (co < P.Cout && q < P.HoWo) {
                         const float v0 = fmaf(ep[row * RS + col], sc, sh);
                         int qhi = q;
@@ -636,7 +639,8 @@ bool fill_plan(WinPlan& P, const Tile& t, int KS, size_t& lds_bytes) {
     P.tiles_per_img = (P.HoWo + P.Ptile - 1) / P.Ptile;
     P.nP = P.N * P.tiles_per_img;
     P.nM = (P.Cout16 + P.Mtile - 1) / P.Mtile;
-    if (P.Cout16 % P.Mtile) return false;                  // weight rows are staged whole: no ragged last M tile
+    // a ragged last M tile is fine: its surplus weight columns alias the next row of the slab (finite values) or fall off
+    // the tensor (range check -> 0), and rows >= Cout are never stored; only the whole-workgroup waste is priced
     P.M4 = P.Mtile / 4;
     P.MS = pad_stride(P.Mtile, 16);
     P.G = ((P.pad + 3) & ~3) < 16 ? 16 : ((P.pad + 3) & ~3);
@@ -750,6 +754,10 @@ int dispatch_win(int MB, int PB, const float* in, const float* wp, const float* 
     OTP_CASE(2, 7) OTP_CASE(2, 9)
     OTP_CASE(3, 7)
 #undef OTP_CASE
+    // tall tiles for the 1x1 GEMMs of the temporal encoders (one pass over the pixels instead of one per 48 channels)
+    if constexpr (KS == 1) {
+        if (P.lin && MB == 9 && PB == 3) return launch_win<9, 3, 1, true>(in, wp, scale, shift, res, out, P, lds, st);
+    }
     return OTP_ERR_UNSUPPORTED;
 }
 
@@ -824,32 +832,37 @@ bool plan_window(const otp_conv_desc& d, const void* in, const void* in2, const 
     const int mblk = P.Cout16 / 16, G = (P.HoWo + 15) / 16;
     best = Tile{0, 0, 0, 0, 0};
     double best_cost = 1e300;
-    static const int wms[] = {1, 2, 4}, pbs[] = {7, 9};
-    for (int MB = 1; MB <= 3; ++MB)
-        for (int PB : pbs)
-            for (int WM : wms)
-                for (int WP = 1; WM * WP <= 4; ++WP) {
-                    if (MB * PB > 21) continue;                  // registers: acc + prefetch + addressing <= 256
-                    if (g_force[0]) {
-                        if (MB != g_force[0] || PB != g_force[1] || WM != g_force[2] || WP != g_force[3]) continue;
-                    } else {
-                        if (WM > 1 && MB * (WM - 1) >= mblk) continue;            // whole waves of padding
-                        if (WP > 1 && PB * (WP - 1) >= G) continue;
-                    }
-                    const int cin4 = (d.Cin + 3) & ~3;
-                    int last_ck = 0;
-                    for (int ck : {cin4 <= 40 ? cin4 : 32, 32, 24, 16, 12, 8, 4}) {
-                        if (ck > cin4) ck = cin4;
-                        if (ck == last_ck) continue;
-                        last_ck = ck;
-                        const Tile t{MB, PB, WM, WP, ck};
-                        WinPlan C = P;
-                        size_t l = 0;
-                        if (!fill_plan(C, t, d.kh, l)) continue;
-                        const double cost = tile_cost(C, t, d.kh, l);
-                        if (cost < best_cost) { best_cost = cost; best = t; }
-                    }
+    static const int wms[] = {1, 2, 4};
+    // accumulator shapes (MB x PB 16x16 blocks per wave): the 7- / 9-block wide ones for everything, the tall one for
+    // 1x1 GEMMs whose input would otherwise be re-staged once per 48 output channels (temporal-encoder projections / MLP)
+    static const int shapes[][2] = {{1, 7}, {1, 9}, {2, 7}, {2, 9}, {3, 7}, {9, 3}};
+    for (const auto& sh : shapes)
+        for (int WM : wms)
+            for (int WP = 1; WM * WP <= 4; ++WP) {
+                const int MB = sh[0], PB = sh[1];
+                const bool tall = MB > 3;
+                if (tall && !(d.kh == 1 && P.lin)) continue;
+                if (g_force[0]) {
+                    if (MB != g_force[0] || PB != g_force[1] || WM != g_force[2] || WP != g_force[3]) continue;
+                } else {
+                    if (WM > 1 && MB * (WM - 1) >= mblk) continue;            // whole waves of padding
+                    if (WP > 1 && PB * (WP - 1) >= G) continue;
+                    if (tall ? (WM != 1 || WP != 4 || mblk < MB) : (P.Cout16 % (16 * MB * WM)) != 0) continue;
                 }
+                const int cin4 = (d.Cin + 3) & ~3;
+                int last_ck = 0;
+                for (int ck : {cin4 <= 40 ? cin4 : 32, 32, 24, 16, 12, 8, 4}) {
+                    if (ck > cin4) ck = cin4;
+                    if (ck == last_ck) continue;
+                    last_ck = ck;
+                    const Tile t{MB, PB, WM, WP, ck};
+                    WinPlan C = P;
+                    size_t l = 0;
+                    if (!fill_plan(C, t, d.kh, l)) continue;
+                    const double cost = tile_cost(C, t, d.kh, l);
+                    if (cost < best_cost) { best_cost = cost; best = t; }
+                }
+            }
     if (!best.MB) return false;
     fill_plan(P, best, d.kh, lds);
     return true;

@@ -1,5 +1,7 @@
 """Every other C entry point vs plain PyTorch CPU / the oracle on seeded inputs (float32)."""
+import ctypes
 import math
+
 
 import pytest
 import torch
@@ -53,7 +55,29 @@ def test_conv2d_matches_torch(case):
     _close(out, F.gelu(F.conv2d(x, wt, sh, stride, pad, dil)))
 
 
-@pytest.mark.parametrize("tile", [(1, 7, 1, 1), (2, 8, 2, 2), (3, 9, 1, 4), (4, 7, 4, 1), (4, 9, 1, 3), (3, 8, 2, 1)])
+@pytest.mark.parametrize("cout", [100, 250, 144])
+@pytest.mark.parametrize("tile", [(9, 3, 1, 4)])
+def test_conv1x1_tall_tiles(tile, cout):
+    """The tall accumulator tiles of the 1x1 GEMMs (forced through the tuning hook), including a ragged last M tile
+    (Cout16 not a multiple of the tile height) and the fused epilogue."""
+    L = hip.lib()
+    x = seeded((3, 136, 1, 460), 1)
+    wt = seeded((cout, 136, 1, 1), 2, 0.05)
+    sc, sh = 1 + 0.1 * seeded((cout,), 3), seeded((cout,), 4)
+    ref = F.conv2d(x, wt) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    res = seeded(ref.shape, 5)
+    try:
+        assert L.otp_conv2d_set_tile(*tile) == 0
+        out = ops.conv2d(x.cuda(), wt.cuda(), sc.cuda(), sh.cuda(), 1, 0, 1, act=ops.ACT_GELU, res=res.cuda())
+        plan = (ctypes.c_int * 8)()
+        L.otp_conv2d_last_plan(plan)
+        assert tuple(plan[:4]) == tile                      # the window kernel ran with the forced tile
+        _close(out, F.gelu(ref + res))
+    finally:
+        L.otp_conv2d_set_tile(0, 0, 0, 0)
+
+
+@pytest.mark.parametrize("tile", [(1, 7, 1, 1), (2, 7, 2, 2), (3, 7, 1, 4), (2, 9, 4, 1), (1, 9, 1, 3), (2, 9, 2, 1)])
 def test_conv2d_every_tile_shape(tile):
     """Results do not depend on the workgroup tiling (forced through the tuning hook)."""
     L = hip.lib()

@@ -108,10 +108,8 @@ def main():
         if a.sweep:
             L = hip.lib()
             res = []
-            for MB in (1, 2, 3, 4):
-                for PB in (7, 8, 9):
-                    if MB * PB > 28:
-                        continue
+            for MB, PB in ((1, 7), (1, 9), (2, 7), (2, 9), (3, 7), (9, 3)):
+                if True:
                     for WM in (1, 2, 4):
                         for WP in (1, 2, 3, 4):
                             if WM * WP > 4:
