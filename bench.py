@@ -120,6 +120,24 @@ def kernel_rooflines(dev, batch):
     return conv, dcn_r
 
 
+def golden_parity(model, cfg, dev):
+    """Max-abs difference of the 7 forward outputs against the committed reference-generated golden of this very
+    configuration (tests/golden/e2e_cfg2_b1.npz: one 384x288 W48 clip run through the reference model in the build
+    container, same seeded weights / inputs).  None when the fixture did not travel."""
+    import numpy as np
+    path = os.path.join(ROOT, "tests", "golden", "e2e_cfg2_b1.npz")
+    if not os.path.isfile(path):
+        return None
+    z = np.load(path)
+    x, margin = S.synthetic_clip(1, cfg.MODEL.IMAGE_SIZE)
+    with torch.no_grad():
+        outs = [o.clone() for o in model(x.to(dev), margin=margin.to(dev))]
+    names = ("output", "rough", "intersection", "prev_b", "context", "squeezed", "total_b")
+    deltas = {n: float((o.cpu() - torch.from_numpy(z[n])).abs().max()) for n, o in zip(names, outs) if n in z.files}
+    return {"max_abs_delta": max(deltas.values()), "max_abs_delta_output_heatmaps": deltas.get("output"),
+            "tolerance": 1e-3, "vs": "tests/golden/e2e_cfg2_b1.npz (reference model, 1 clip of this config)"}
+
+
 def cpu_baseline():
     """The oracle (CPU restatement of the reference graph) timed on the host cores: ONE clip of the same
     workload (5 frames, 384x288, W48), median of 3 after a warm-up (a bounded sample, ~10-20 s)."""
@@ -223,6 +241,8 @@ def main():
         log("kernel rooflines done")
         line["roofline"] = conv
         line["roofline_dcn"] = dcn
+        line["parity"] = golden_parity(model, cfg, dev)     # the "heatmap max-abs delta vs ref" half of the metric
+        log("golden parity done")
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

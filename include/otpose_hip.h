@@ -212,6 +212,17 @@ int otp_heatmap_decode(const void* heatmaps, void* preds, void* maxvals, const v
 int otp_pck_accuracy(const void* pred_coords, const void* target_coords, void* acc, void* cnt, int N, int J, int H, int W,
                      float thr, void* stream);
 
+/* ---- optimizer step of the training loop (script/Common.py:136-143: clip_grad_norm_ then optimizer.step(); AdamW built by
+ * thirdparty/utils/train_utils.py:129-133) over flat, 16-byte aligned fp32 buffers ------------------------------------
+ * otp_grad_sumsq: *acc_f64 += sum(grad^2) (zero it first; call once per flat gradient segment).
+ * otp_adamw_step: torch.optim.AdamW update of one hyper-parameter group, step >= 1 = the 1-based step count; the
+ * gradient is first scaled by min(1, max_norm / (sqrt(*gradnorm_sq_f64) + 1e-6)) read on the device
+ * (gradnorm_sq_f64 == NULL or max_norm <= 0: no clipping). */
+int otp_grad_sumsq(const void* grad, size_t n, void* acc_f64, void* stream);
+int otp_adamw_step(void* param, const void* grad, void* exp_avg, void* exp_avg_sq, size_t n, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, int step, const void* gradnorm_sq_f64, float max_norm,
+                   void* stream);
+
 /* ---- input assembly (the step before the path: dataset/PoseTrackDataset.py:397-406 transform per frame =
  * utils/transform.py:7-15 ToTensor + Normalize, script/Common.py:117 torch.cat over the frames) ---------------------
  * frames_u8 (B, F, H, W, 3) uint8 RGB, HWC like the cv2.warpAffine output -> out (B, 3F, H, W) float32,

@@ -44,6 +44,8 @@ SIGNATURES = {
     "otp_conv2d_plan": (c_int, [ctypes.POINTER(ConvDesc), ctypes.POINTER(c_int)]),
     "otp_conv2d_pack_weight_dgrad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "otp_dilate": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "otp_grad_sumsq": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
+    "otp_adamw_step": (c_int, [c_void_p] * 4 + [c_size_t] + [c_float] * 5 + [c_int, c_void_p, c_float, c_void_p]),
     "otp_pck_accuracy": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_float, c_void_p]),
     "otp_frames_u8_to_clip": (c_int, [c_void_p] * 2 + [c_int] * 4 + [c_float] * 6 + [c_void_p]),
     "otp_conv2d_wgrad_workspace": (c_size_t, [c_int] * 2),

@@ -1,0 +1,119 @@
+"""Optimizer step of the reference training loop on flat HBM buffers: ``torch.nn.utils.clip_grad_norm_`` followed by
+``torch.optim.AdamW.step()`` (script/Common.py:138-143; groups built by thirdparty/utils/train_utils.py:62-133) as two
+HIP passes - a sum of squares over the flat gradients and one fused clip + AdamW update per hyper-parameter group - with no
+host synchronisation (the clip coefficient is read from device memory).
+
+``FusedAdamW`` takes the same parameter groups as ``torch.optim.AdamW`` (so ``make_optimizer``'s three groups carry over
+unchanged) and re-homes parameters and gradients into one flat fp32 buffer per group: ``p.data`` and ``p.grad`` become views,
+autograd keeps accumulating into them, and ``flat_grads()`` hands the few large buffers to the RCCL all-reduce
+(:mod:`otpose_amd.parallel`) - large messages are what the point-to-point xGMI links want.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import hip
+
+
+def _bump_versions(tensors):
+    """The kernels write parameters through raw pointers; tell autograd / the inference engine's staleness check."""
+    try:
+        torch._C._increment_version(tensors)
+    except TypeError:                                   # older signature: one tensor at a time
+        for t in tensors:
+            torch._C._increment_version(t)
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=0.0):
+        if lr < 0 or eps < 0 or weight_decay < 0 or not (0 <= betas[0] < 1 and 0 <= betas[1] < 1):
+            raise ValueError("invalid AdamW hyper-parameters")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.max_grad_norm = float(max_grad_norm)
+        self._flat = []                                  # per group: dict(p, g, m, v, params, step)
+        for group in self.param_groups:
+            ps = [p for p in group["params"] if p.requires_grad]
+            if not ps:
+                self._flat.append(None)
+                continue
+            dev = ps[0].device
+            if dev.type != "cuda" or any(p.device != dev or p.dtype != torch.float32 for p in ps):
+                raise RuntimeError("FusedAdamW needs float32 parameters on one CUDA (HIP) device; there is no CPU path")
+            total = sum(p.numel() for p in ps)
+            fp = torch.empty(total, dtype=torch.float32, device=dev)
+            fg, fm, fv = torch.zeros_like(fp), torch.zeros_like(fp), torch.zeros_like(fp)
+            off = 0
+            for p in ps:
+                n = p.numel()
+                fp[off:off + n].copy_(p.data.reshape(-1))
+                p.data = fp[off:off + n].view_as(p)
+                if p.grad is not None:
+                    fg[off:off + n].copy_(p.grad.reshape(-1))
+                p.grad = fg[off:off + n].view_as(p)
+                self.state[p] = {"step": 0, "exp_avg": fm[off:off + n].view_as(p), "exp_avg_sq": fv[off:off + n].view_as(p)}
+                off += n
+            self._flat.append({"p": fp, "g": fg, "m": fm, "v": fv, "params": ps, "step": 0})
+        devs = {f["p"].device for f in self._flat if f}
+        self._normsq = {d: torch.zeros(1, dtype=torch.float64, device=d) for d in devs}
+
+    def flat_grads(self):
+        """The flat gradient buffers (one per group) - the units to all-reduce."""
+        return [f["g"] for f in self._flat if f]
+
+    def zero_grad(self, set_to_none: bool = False):
+        # gradients live in the flat buffers: dropping them (set_to_none) would detach the views
+        for f in self._flat:
+            if f:
+                f["g"].zero_()
+
+    @torch.no_grad()
+    def grad_norm(self):
+        """Global L2 norm of all gradients as a device scalar (what clip_grad_norm_ returns), no host sync."""
+        L = hip.lib()
+        for acc in self._normsq.values():
+            acc.zero_()
+        for f in self._flat:
+            if f:
+                hip.check(L.otp_grad_sumsq(hip.ptr(f["g"]), f["g"].numel(), hip.ptr(self._normsq[f["g"].device]),
+                                           hip.stream_of(f["g"])), "otp_grad_sumsq")
+        accs = list(self._normsq.values())
+        return accs[0].sqrt() if len(accs) == 1 else torch.stack([a.cpu() for a in accs]).sum().sqrt()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        L = hip.lib()
+        clip = self.max_grad_norm > 0.0
+        if clip:
+            self.grad_norm()
+        for group, f in zip(self.param_groups, self._flat):
+            if not f:
+                continue
+            f["step"] += 1
+            b1, b2 = group["betas"]
+            acc = self._normsq[f["g"].device]
+            hip.check(L.otp_adamw_step(hip.ptr(f["p"]), hip.ptr(f["g"]), hip.ptr(f["m"]), hip.ptr(f["v"]), f["p"].numel(),
+                                       float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                       float(group["weight_decay"]), f["step"], hip.ptr(acc) if clip else None,
+                                       self.max_grad_norm, hip.stream_of(f["p"])), "otp_adamw_step")
+            for p in f["params"]:
+                self.state[p]["step"] = f["step"]
+            _bump_versions(f["params"])
+        return loss
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        # the base class re-creates the state tensors: copy them back into the flat moment buffers and re-point the views
+        for f in self._flat:
+            if not f:
+                continue
+            off = 0
+            for p in f["params"]:
+                n = p.numel()
+                st = self.state[p]
+                for key, flat in (("exp_avg", f["m"]), ("exp_avg_sq", f["v"])):
+                    flat[off:off + n].copy_(st[key].reshape(-1))
+                    st[key] = flat[off:off + n].view_as(p)
+                f["step"] = int(st.get("step", f["step"]))
+                st["step"] = f["step"]
+                off += n

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--no-dropout", action="store_true")
+    ap.add_argument("--torch-optim", action="store_true", help="torch.optim.AdamW + clip_grad_norm_ instead of FusedAdamW")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     cfg = cfg2()
@@ -36,7 +37,12 @@ def main():
     g = torch.rand(a.batch, J, h, w, device=dev) * 0.2
     g[:, ::2, 3, 4] = 1.0
     wt = (torch.rand(a.batch, J, 1, device=dev) > 0.15).float()
-    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4, weight_decay=0.01)
+    params = [p for p in model.parameters() if p.requires_grad]
+    if a.torch_optim:
+        opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01)
+    else:
+        from otpose_amd.optim import FusedAdamW
+        opt = FusedAdamW(params, lr=1e-4, weight_decay=0.01, max_grad_norm=1.0)
 
     def sync():
         torch.cuda.synchronize()
@@ -49,10 +55,11 @@ def main():
         t1 = sync()
         loss = TR.criterion(outs, g, wt)
         t2 = sync()
-        opt.zero_grad(set_to_none=True)
+        opt.zero_grad()
         loss.backward()
         t3 = sync()
-        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        if a.torch_optim:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
         opt.step()
         t4 = sync()
         print("step %d%s: forward %.1f ms  loss %.1f ms  backward %.1f ms  clip+AdamW %.1f ms  total %.1f ms  "
