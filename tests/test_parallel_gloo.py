@@ -113,3 +113,41 @@ def test_single_process_is_a_no_op():
     bk.reduce()
     assert all(torch.equal(a, p.grad) for a, p in zip(before, m.parameters()))
     assert P.world_size() == 1 and P.rank() == 0
+
+
+class _FlatStub:
+    """Stands in for FusedAdamW (which needs HIP tensors): anything with flat_grads()."""
+
+    def __init__(self, bufs):
+        self.bufs = bufs
+
+    def flat_grads(self):
+        return self.bufs
+
+
+def _flat_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    P.init_from_env("gloo")
+    opt = _FlatStub([torch.full((1000,), float(rank + 1)), torch.arange(7.) * (rank + 1)])
+    P.allreduce_flat_grads(opt)
+    if rank == 0:
+        q.put([b.clone() for b in opt.bufs])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_flat_gradient_allreduce():
+    """allreduce_flat_grads: one all-reduce per flat group buffer, mean over ranks, in place."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_flat_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    a, b = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert torch.equal(a, torch.full((1000,), 1.5)) and torch.equal(b, torch.arange(7.) * 1.5)
