@@ -88,6 +88,17 @@ int otp_conv2d_pack_weight(const void* weight, void* wpacked, int Cout, int Cin,
 int otp_conv2d(const void* in, const void* in2, const void* wpacked, const void* scale, const void* shift,
                const void* res, void* out, const otp_conv_desc* desc, void* stream);
 
+/* 3x3 / stride 1 / pad 1 convolutions (the HRNet BasicBlock / Bottleneck convs, model/HRNet.py:500-571) in Winograd
+ * F(2x2, 3x3) form: 2.25x fewer multiplies on the same f32 matrix cores, fp32 throughout, same fused epilogue
+ * (scale / shift, residual, activation, channel-sliced views) as otp_conv2d.  upacked = otp_conv2d_wino_weight_bytes(Cout, Cin)
+ * bytes filled by otp_conv2d_wino_pack_weight from the (Cout, Cin, 3, 3) weights.  otp_conv2d_wino_supported tells whether
+ * a descriptor qualifies (3x3, stride 1, pad 1, dilation 1, H*W % 4 == 0, no res_up / frame_split / second input). */
+size_t otp_conv2d_wino_weight_bytes(int Cout, int Cin);
+int otp_conv2d_wino_pack_weight(const void* weight, void* upacked, int Cout, int Cin, void* stream);
+int otp_conv2d_wino_supported(const otp_conv_desc* desc);
+int otp_conv2d_wino(const void* in, const void* upacked, const void* scale, const void* shift, const void* res, void* out,
+                    const otp_conv_desc* desc, void* stream);
+
 /* ---- training-step building blocks for the convolutional layers (script/Common.py:91,136-144 run the reference under
  * model.train(): BatchNorm2d uses batch statistics, every conv needs both gradients) -----------------------------
  * Gradient w.r.t. the input of a stride-1 conv = otp_conv2d of grad_out with the weights packed by

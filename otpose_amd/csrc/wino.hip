@@ -1,0 +1,379 @@
+// 3x3 stride-1 convolution in Winograd F(2x2, 3x3) form on the gfx950 f32 matrix cores.
+//
+// The HRNet branch convs (reference model/HRNet.py:500-530 BasicBlock, :533-571 Bottleneck conv2; 73 % of the MACs of
+// the OTPose forward) are 3x3 / stride 1 / pad 1.  Y = A^T [ (G g G^T) . (B^T d B) ] A turns each 2x2 output tile into
+// 16 independent products instead of 36, i.e. 16 GEMMs  M_xy[co][tile] = sum_ci U_xy[co][ci] * V_xy[ci][tile]  - 2.25x
+// fewer multiplies, all in fp32 (v_mfma_f32_16x16x4_f32); the transforms only add and subtract (G carries the 1/2 s into
+// the pre-packed weights), so the result differs from the direct form by fp32 rounding of a few extra additions.
+//
+// Workgroup = 4 waves = (NT = 48 consecutive output tiles of one image, flattened row-major over the tile grid) x
+// (48 output channels).  Per chunk of 8 input channels:
+//   1. the input WINDOW (the rows the 48 tiles touch, contiguous in the NCHW plane) and the 16 x 8 x 48 slab of packed
+//      weights U travel global -> registers -> LDS (buffer loads: rows above / below the image and channels past Cin read
+//      as zero through the descriptor's range check; the loads of chunk c+1 are in flight under the work on chunk c);
+//   2. every thread transforms (tile, channel) patches 4x4 -> 4x4 (32 adds; the left / right image edge is masked here)
+//      and writes V[xy][ci][tile];
+//   3. wave w owns the four coordinates xy = (w, 0..3): 4 x 3 x 3 accumulator tiles, fragments at compile-time LDS offsets.
+// Epilogue: a wave reduces its row of M to P_w[j] = sum_y A^T[j][y] M[w][y] in registers, the four waves meet in LDS, and
+// all threads finish Y[i][j] = sum_x A^T[i][x] P_x[j], apply scale / shift (+ residual) (+ ReLU / GELU) and store float2
+// pairs (a tile's two columns) - coalesced along the tile row.
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float wino_gelu(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ uint32_t wdiv(uint32_t i, uint32_t magic) { return magic ? __umulhi(i, magic) : i; }
+uint32_t wmagic(uint32_t d) { return d <= 1 ? 0u : (uint32_t)((1ull << 32) / d) + 1u; }
+
+constexpr int WCK = 8;            // input channels per chunk (two MFMA k-steps)
+constexpr int WMB = 3;            // 16-row output-channel blocks per workgroup
+constexpr int WMS = 16 * WMB;     // 48: LDS row of the weight slab (== 16 mod 32: the 4 k-rows of a fragment hit distinct banks)
+constexpr int WG_ = 4;            // guard floats in front of every channel window (column -1 of the first row)
+constexpr int WMAXJ = 8;          // float4 window items per thread
+constexpr int WUJ = 16 * WCK * (WMS / 4) / 256;   // 6 float4 weight items per thread
+
+struct WinoPlan {
+    int N, Cin, H, W, HW, Cout, Cout16;
+    int in_ctot, in_coff, out_ctot, out_coff, res_ctot, res_coff, act;
+    int TX, tpi, bpi, nM;          // tile columns, tiles per image, tile blocks per image, 48-channel tiles
+    int L4, WS, JR;                // window float4 per channel, LDS channel stride, 64-float4 pieces per window
+    int w_even;                    // W % 2 == 0: a tile's two columns are an aligned float2
+    uint32_t magicTX, magicBpi;
+};
+
+// (Cout, Cin, 3, 3) -> U[16][Cin][Cout16] = G g G^T, G = [[1,0,0],[1/2,1/2,1/2],[1/2,-1/2,1/2],[0,0,1]]
+__global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin, int Cout16) {
+    const int total = Cin * Cout16;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int ci = i / Cout16, co = i - ci * Cout16;
+        float g[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) g[a][b] = co < Cout ? w[((size_t)co * Cin + ci) * 9 + a * 3 + b] : 0.f;
+        float t[4][3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            t[0][b] = g[0][b];
+            t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+            t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+            t[3][b] = g[2][b];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const float u0 = t[a][0], u1 = 0.5f * (t[a][0] + t[a][1] + t[a][2]), u2 = 0.5f * (t[a][0] - t[a][1] + t[a][2]),
+                        u3 = t[a][2];
+            u[((size_t)(a * 4 + 0) * Cin + ci) * Cout16 + co] = u0;
+            u[((size_t)(a * 4 + 1) * Cin + ci) * Cout16 + co] = u1;
+            u[((size_t)(a * 4 + 2) * Cin + ci) * Cout16 + co] = u2;
+            u[((size_t)(a * 4 + 3) * Cin + ci) * Cout16 + co] = u3;
+        }
+    }
+}
+
+template <int TB>
+__global__ __launch_bounds__(256, 2) void conv_wino_kernel(const float* __restrict__ in, const float* __restrict__ up,
+                                                             const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, const float* res, float* out,
+                                                             const WinoPlan P) {
+    constexpr int NT = 16 * TB;
+    constexpr int VS = (NT % 32 == 16) ? NT : NT + 16;            // == 16 (mod 32)
+    constexpr int SLOTS = (WCK * NT + 255) / 256;                 // (tile, channel) patches per thread and chunk
+    constexpr int PST = NT + 2;                                   // epilogue row pitch
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* raw = smem;                                            // [WCK][WS]
+    float* V = smem + WCK * P.WS;                                 // [16][WCK][VS]
+    float* U = V + 16 * WCK * VS;                                 // [16][WCK][WMS]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, kl = lane >> 4;
+
+    // ---- block -> (image, first tile, output-channel tile) -----------------------------------------------------------
+    const int bp = blockIdx.x, m0 = blockIdx.y * WMS;
+    const int n = (int)wdiv((uint32_t)bp, P.magicBpi);
+    const int t0 = (bp - n * P.bpi) * NT;
+    const int nt = min(NT, P.tpi - t0);
+    const int ty0 = (int)wdiv((uint32_t)t0, P.magicTX);
+    const int f0 = (2 * ty0 - 1) * P.W;                           // first flattened input position the block touches (< 0 at the top)
+    const int f0a = f0 & ~3;
+    const float* img = in + ((size_t)n * P.in_ctot + P.in_coff) * P.HW;
+
+    // ---- staging ---------------------------------------------------------------------------------------------------------
+    f32x4 pfi[WMAXJ], pfu[WUJ];
+    int uoff[WUJ], udst[WUJ], uc[WUJ];
+#pragma unroll
+    for (int j = 0; j < WUJ; ++j) {
+        const int i = tid + 256 * j;                              // [16 coords][WCK][12 float4]
+        const int row = i / (WMS / 4), q = i - row * (WMS / 4);
+        const int coord = row / WCK, c = row - coord * WCK;
+        uoff[j] = ((coord * P.Cin + c) * P.Cout16 + m0 + 4 * q) * 4;
+        udst[j] = (coord * WCK + c) * WMS + 4 * q;
+        uc[j] = c;
+    }
+    const otp_rsrc ru = make_rsrc32(up, (unsigned)(16 * P.Cin) * (unsigned)P.Cout16 * 4u);
+    const int vbase = (f0a + 4 * lane) * 4;
+    auto load_chunk = [&](int c0) __attribute__((always_inline)) {
+        int jc = 0, jr = 0;
+#pragma unroll
+        for (int j = 0; j < WMAXJ; ++j) {
+            if (j < 2 * P.JR) {
+                const int c = wave * 2 + jc, ch = c0 + c;         // wave w stages channels 2w, 2w+1 of the chunk
+                const bool live = ch < P.Cin;
+                const otp_rsrc r = make_rsrc32(img + (size_t)(live ? ch : 0) * P.HW, live ? (unsigned)P.HW * 4u : 0u);
+                pfi[j] = bload4(r, vbase + jr * 1024);
+                if (++jr == P.JR) { jr = 0; ++jc; }
+            }
+        }
+        const int cbytes = c0 * P.Cout16 * 4;
+#pragma unroll
+        for (int j = 0; j < WUJ; ++j) {
+            pfu[j] = bload4(ru, c0 + uc[j] < P.Cin ? uoff[j] + cbytes : -1);
+        }
+        asm volatile("" ::: "memory");
+    };
+    auto store_chunk = [&]() __attribute__((always_inline)) {
+        int jc = 0, jr = 0;
+#pragma unroll
+        for (int j = 0; j < WMAXJ; ++j) {
+            if (j < 2 * P.JR) {
+                const int c = wave * 2 + jc, r4 = lane + 64 * jr;
+                if (r4 < P.L4) *reinterpret_cast<f32x4*>(raw + c * P.WS + WG_ + 4 * r4) = pfi[j];
+                if (++jr == P.JR) { jr = 0; ++jc; }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < WUJ; ++j) *reinterpret_cast<f32x4*>(U + udst[j]) = pfu[j];
+    };
+
+    // ---- per-thread patch geometry (the same for every chunk) -----------------------------------------------------------
+    int toff[SLOTS], vdst[SLOTS];
+    unsigned cmask[SLOTS];                                        // bits 0..3: patch column jj inside the image; bit 4: patch live
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const int i = tid + 256 * s;
+        const int c = i / NT, j = i - c * NT;
+        const bool live = i < WCK * NT;
+        const int t = t0 + (j < nt ? j : 0);
+        const int ty = (int)wdiv((uint32_t)t, P.magicTX), tx = t - ty * P.TX;
+        const int x0 = 2 * tx - 1;
+        toff[s] = (live ? c : 0) * P.WS + WG_ + (f0 - f0a) + 2 * (ty - ty0) * P.W + x0;
+        vdst[s] = live ? c * VS + j : -1;
+        unsigned m = 0;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) m |= (x0 + jj >= 0 && x0 + jj < P.W) ? 1u << jj : 0u;
+        cmask[s] = (live && j < nt) ? (m | 16u) : 0u;
+    }
+
+    f32x4 acc[4][WMB][TB];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int mb = 0; mb < WMB; ++mb)
+#pragma unroll
+            for (int tb = 0; tb < TB; ++tb) acc[a][mb][tb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const float* Uw = U + (wave * 4) * WCK * WMS + kl * WMS + i16;
+    const float* Vw = V + (wave * 4) * WCK * VS + kl * VS + i16;
+
+    load_chunk(0);
+    store_chunk();
+    __syncthreads();
+    for (int c0 = 0; c0 < P.Cin; c0 += WCK) {
+        const bool more = c0 + WCK < P.Cin;
+        if (more) load_chunk(c0 + WCK);                           // in flight under the transform and the MFMAs
+        // ---- input transform: V = B^T d B, B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]] -------------------------
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            if (vdst[s] >= 0) {
+                float d[4][4];
+                const float* src = raw + toff[s];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const float v = src[i * P.W + jj];
+                        d[i][jj] = (cmask[s] >> jj) & 1u ? v : 0.f;
+                    }
+                float t[4][4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    t[0][jj] = d[0][jj] - d[2][jj];
+                    t[1][jj] = d[1][jj] + d[2][jj];
+                    t[2][jj] = d[2][jj] - d[1][jj];
+                    t[3][jj] = d[1][jj] - d[3][jj];
+                }
+                const bool on = cmask[s] & 16u;
+                float* dst = V + vdst[s];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float v0 = t[i][0] - t[i][2], v1 = t[i][1] + t[i][2], v2 = t[i][2] - t[i][1], v3 = t[i][1] - t[i][3];
+                    dst[(i * 4 + 0) * WCK * VS] = on ? v0 : 0.f;
+                    dst[(i * 4 + 1) * WCK * VS] = on ? v1 : 0.f;
+                    dst[(i * 4 + 2) * WCK * VS] = on ? v2 : 0.f;
+                    dst[(i * 4 + 3) * WCK * VS] = on ? v3 : 0.f;
+                }
+            }
+        }
+        __syncthreads();                                          // V complete (U was complete at the previous barrier)
+        // ---- 4 coordinates x 2 k-steps x (WMB x TB) MFMAs ------------------------------------------------------------------
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+            for (int k = 0; k < WCK / 4; ++k) {
+                float a[WMB], b[TB];
+#pragma unroll
+                for (int mb = 0; mb < WMB; ++mb) a[mb] = Uw[(nu * WCK + 4 * k) * WMS + mb * 16];
+#pragma unroll
+                for (int tb = 0; tb < TB; ++tb) b[tb] = Vw[(nu * WCK + 4 * k) * VS + tb * 16];
+#pragma unroll
+                for (int mb = 0; mb < WMB; ++mb)
+#pragma unroll
+                    for (int tb = 0; tb < TB; ++tb)
+                        acc[nu][mb][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb], b[tb], acc[nu][mb][tb], 0, 0, 0);
+            }
+        __syncthreads();                                          // raw / V / U free
+        if (more) {
+            store_chunk();
+            __syncthreads();
+        }
+    }
+
+    // ---- output transform + epilogue, one 16-channel block at a time -----------------------------------------------------
+    float* Pb = V;                                                // [4 waves][2][16][PST] (aliases V / U: both are dead)
+    const int HoWo = P.HW;
+#pragma unroll 1
+    for (int mb = 0; mb < WMB; ++mb) {
+#pragma unroll
+        for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // (select the 16-channel block with a runtime index: keep the accumulators in registers by unrolling over mb below)
+                float m0v = 0.f, m1v = 0.f, m2v = 0.f, m3v = 0.f;
+#pragma unroll
+                for (int q = 0; q < WMB; ++q)
+                    if (q == mb) { m0v = acc[0][q][tb][r]; m1v = acc[1][q][tb][r]; m2v = acc[2][q][tb][r]; m3v = acc[3][q][tb][r]; }
+                Pb[((wave * 2 + 0) * 16 + kl * 4 + r) * PST + tb * 16 + i16] = m0v + m1v + m2v;
+                Pb[((wave * 2 + 1) * 16 + kl * 4 + r) * PST + tb * 16 + i16] = m1v - m2v - m3v;
+            }
+        __syncthreads();
+        for (int idx = tid; idx < 16 * 2 * NT; idx += 256) {
+            const int rest = idx / NT, j = idx - rest * NT;       // lanes = consecutive tiles: coalesced float2 stores
+            const int i = rest & 1, row = rest >> 1;
+            const int co = m0 + mb * 16 + row;
+            const int t = t0 + j;
+            const int ty = (int)wdiv((uint32_t)t, P.magicTX), tx = t - ty * P.TX;
+            const int y = 2 * ty + i, x = 2 * tx;
+            if (j < nt && co < P.Cout && y < P.H) {
+                const float* pr = Pb + row * PST + j;
+                float y0, y1;
+                if (i == 0) {
+                    y0 = pr[(0 * 2 + 0) * 16 * PST] + pr[(1 * 2 + 0) * 16 * PST] + pr[(2 * 2 + 0) * 16 * PST];
+                    y1 = pr[(0 * 2 + 1) * 16 * PST] + pr[(1 * 2 + 1) * 16 * PST] + pr[(2 * 2 + 1) * 16 * PST];
+                } else {
+                    y0 = pr[(1 * 2 + 0) * 16 * PST] - pr[(2 * 2 + 0) * 16 * PST] - pr[(3 * 2 + 0) * 16 * PST];
+                    y1 = pr[(1 * 2 + 1) * 16 * PST] - pr[(2 * 2 + 1) * 16 * PST] - pr[(3 * 2 + 1) * 16 * PST];
+                }
+                const float sc = scale ? scale[co] : 1.f, sh = shift ? shift[co] : 0.f;
+                y0 = fmaf(y0, sc, sh);
+                y1 = fmaf(y1, sc, sh);
+                const size_t ob = ((size_t)n * P.out_ctot + P.out_coff + co) * HoWo + (size_t)y * P.W + x;
+                const size_t rb = ((size_t)n * P.res_ctot + P.res_coff + co) * HoWo + (size_t)y * P.W + x;
+                const bool two = x + 1 < P.W;
+                if (res) {
+                    if (two && P.w_even) {
+                        const f32x2 rv = *reinterpret_cast<const f32x2*>(res + rb);
+                        y0 += rv.x; y1 += rv.y;
+                    } else {
+                        y0 += res[rb];
+                        if (two) y1 += res[rb + 1];
+                    }
+                }
+                if (P.act == OTP_ACT_RELU) { y0 = fmaxf(y0, 0.f); y1 = fmaxf(y1, 0.f); }
+                else if (P.act == OTP_ACT_GELU) { y0 = wino_gelu(y0); y1 = wino_gelu(y1); }
+                if (two && P.w_even) {
+                    *reinterpret_cast<f32x2*>(out + ob) = (f32x2){y0, y1};
+                } else {
+                    out[ob] = y0;
+                    if (two) out[ob + 1] = y1;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+bool wino_plan(const otp_conv_desc& d, WinoPlan& P, size_t& lds, int NT) {
+    if (d.kh != 3 || d.kw != 3 || d.stride != 1 || d.pad != 1 || d.dil != 1 || d.res_up > 1 || d.frame_split > 0) return false;
+    if (d.Ho != d.H || d.Wo != d.W || ((d.H * d.W) & 3)) return false;
+    P.N = d.N; P.Cin = d.Cin; P.H = d.H; P.W = d.W; P.HW = d.H * d.W; P.Cout = d.Cout; P.Cout16 = (d.Cout + 15) & ~15;
+    P.in_ctot = d.in_ctot; P.in_coff = d.in_coff; P.out_ctot = d.out_ctot; P.out_coff = d.out_coff;
+    P.res_ctot = d.res_ctot; P.res_coff = d.res_coff; P.act = d.act;
+    P.TX = (d.W + 1) / 2;
+    const int TY = (d.H + 1) / 2;
+    P.tpi = P.TX * TY;
+    P.bpi = (P.tpi + NT - 1) / NT;
+    P.nM = (P.Cout16 + WMS - 1) / WMS;
+    int span = (NT + P.TX - 2) / P.TX + 1;                        // tile rows NT consecutive tiles can touch
+    if (span > TY) span = TY;
+    const int rows_in = 2 * span + 2;
+    P.L4 = (rows_in * d.W + 3 + 3) / 4 + 1;
+    P.JR = (P.L4 + 63) / 64;
+    if (2 * P.JR > WMAXJ) return false;
+    P.WS = WG_ + 4 * P.L4 + 4;
+    if ((P.WS & 31) == 0) P.WS += 4;
+    P.w_even = (d.W & 1) == 0 ? 1 : 0;
+    P.magicTX = wmagic(P.TX);
+    P.magicBpi = wmagic(P.bpi);
+    const int VS = (NT % 32 == 16) ? NT : NT + 16;
+    lds = ((size_t)WCK * P.WS + (size_t)16 * WCK * VS + (size_t)16 * WCK * WMS) * sizeof(float);
+    const size_t ep = (size_t)4 * 2 * 16 * (NT + 2) * sizeof(float);
+    if (ep > ((size_t)16 * WCK * VS + (size_t)16 * WCK * WMS) * sizeof(float)) return false;
+    if ((long)16 * d.Cin * P.Cout16 * 4 >= (1l << 31) || (long)P.HW * 4 >= (1l << 30)) return false;
+    return lds <= 80 * 1024;
+}
+
+}  // namespace
+
+extern "C" size_t otp_conv2d_wino_weight_bytes(int Cout, int Cin) {
+    if (Cout <= 0 || Cin <= 0) return 0;
+    return (size_t)16 * Cin * ((Cout + 15) & ~15) * sizeof(float);
+}
+
+extern "C" int otp_conv2d_wino_pack_weight(const void* weight, void* upacked, int Cout, int Cin, void* stream) {
+    if (!weight || !upacked || Cout <= 0 || Cin <= 0) return OTP_ERR_BAD_ARG;
+    const int Cout16 = (Cout + 15) & ~15, total = Cin * Cout16;
+    hipLaunchKernelGGL(wino_pack_kernel, dim3(otp_ceil_div(total, 256) > 1024 ? 1024 : otp_ceil_div(total, 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), static_cast<const float*>(weight), static_cast<float*>(upacked), Cout,
+                       Cin, Cout16);
+    return otp_launch_status();
+}
+
+extern "C" int otp_conv2d_wino_supported(const otp_conv_desc* desc) {
+    if (!desc) return 0;
+    WinoPlan P{};
+    size_t lds = 0;
+    return wino_plan(*desc, P, lds, 48) ? 1 : 0;
+}
+
+extern "C" int otp_conv2d_wino(const void* in, const void* upacked, const void* scale, const void* shift, const void* res,
+                               void* out, const otp_conv_desc* desc, void* stream) {
+    if (!in || !upacked || !out || !desc) return OTP_ERR_BAD_ARG;
+    const otp_conv_desc& d = *desc;
+    if (d.N <= 0 || d.Cin <= 0 || d.Cout <= 0 || d.H <= 0 || d.W <= 0) return OTP_ERR_BAD_ARG;
+    if (d.in_ctot < d.in_coff + d.Cin || d.out_ctot < d.out_coff + d.Cout || (res && d.res_ctot < d.res_coff + d.Cout))
+        return OTP_ERR_BAD_ARG;
+    if ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(upacked)) & 15) return OTP_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(out) & 7) || (res && (reinterpret_cast<uintptr_t>(res) & 7))) return OTP_ERR_UNSUPPORTED;
+    WinoPlan P{};
+    size_t lds = 0;
+    if (!wino_plan(d, P, lds, 48)) return OTP_ERR_UNSUPPORTED;
+    auto kern = conv_wino_kernel<3>;
+    OTP_ALLOW_BIG_LDS(kern, lds);
+    hipLaunchKernelGGL(kern, dim3(P.N * P.bpi, P.nM), dim3(256), lds, static_cast<hipStream_t>(stream),
+                       static_cast<const float*>(in), static_cast<const float*>(upacked), static_cast<const float*>(scale),
+                       static_cast<const float*>(shift), static_cast<const float*>(res), static_cast<float*>(out), P);
+    return otp_launch_status();
+}

@@ -47,6 +47,7 @@ class InferenceEngine:
         if use_graph is None:
             use_graph = os.environ.get("OTPOSE_HIP_GRAPH", "1") != "0"
         self.use_graph = use_graph
+        self.use_winograd = os.environ.get("OTPOSE_WINOGRAD", "1") != "0"     # 3x3 stride-1 convs via csrc/wino.hip
         self.graph = None
         self.param_version = self._param_version()
         with torch.no_grad():
@@ -76,6 +77,13 @@ class InferenceEngine:
         self._keep.append(t)
         return t
 
+    @staticmethod
+    def winograd_pays(cin, cout):
+        """Shapes on which the Winograd kernel measured faster than the direct one (tools/conv_bench.py --wino): whole
+        8-channel chunks and output-channel counts that fill its 48-row tiles (64 -> 64 would compute 96 rows)."""
+        cout16 = (cout + 15) // 16 * 16
+        return cin >= 32 and cin % 8 == 0 and cout16 >= 48 and ((cout16 + 47) // 48) * 48 <= 1.15 * cout16
+
     # ---- op emitters ----------------------------------------------------------------------------
     def conv(self, inp: View, weight, out: View, stride=1, pad=0, dil=1, bn=None, bias=None, act=ACT_NONE,
              res: View = None, in2: View = None, res_up=1, frame_split=0, cin=None, scale=None, shift=None):
@@ -83,9 +91,7 @@ class InferenceEngine:
         w = self.dev_param(weight)
         if w.dim() == 3:
             w = w.unsqueeze(-1)
-        cout, _, kh, kw = w.shape
-        wp = ops.pack_conv_weight(w)
-        self._keep.append(wp)
+        cout, cin_w, kh, kw = w.shape
         if bn is not None:
             g, b = self.dev_param(bn.weight), self.dev_param(bn.bias)
             mu, var = self.dev_param(bn.running_mean), self.dev_param(bn.running_var)
@@ -107,6 +113,19 @@ class InferenceEngine:
         d = ops.conv_desc(inp, out, cout, kh, kw, stride, pad, dil, act, in2, res, res_up, frame_split, cin)
         self._keep.append(d)
         L = self.lib
+        if self.use_winograd and in2 is None and self.winograd_pays(cin_w, cout) and ops.wino_supported(d):
+            # 3x3 / stride 1 / pad 1 with enough channels: Winograd F(2x2,3x3) kernel (csrc/wino.hip), same epilogue
+            up = ops.pack_wino_weight(w)
+            self._keep.append(up)
+            wargs = (hip.ptr(inp.t), hip.ptr(up), hip.ptr(sc), hip.ptr(sh), hip.ptr(res.t if res is not None else None),
+                     hip.ptr(out.t), d)
+
+            def run_wino():
+                hip.check(L.otp_conv2d_wino(*wargs, self._stream), "otp_conv2d_wino")
+            self.ops.append(run_wino)
+            return out
+        wp = ops.pack_conv_weight(w)
+        self._keep.append(wp)
         args = (hip.ptr(inp.t), hip.ptr(in2.t if in2 is not None else None), hip.ptr(wp), hip.ptr(sc), hip.ptr(sh),
                 hip.ptr(res.t if res is not None else None), hip.ptr(out.t), d)
 

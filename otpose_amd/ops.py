@@ -311,6 +311,42 @@ def conv2d_launch(inp: View, wpacked, scale, shift, out: View, desc, in2: View =
     hip.check(st, "otp_conv2d")
 
 
+def pack_wino_weight(weight):
+    """(Cout, Cin, 3, 3) -> U[16][Cin][Cout16] = G g G^T device tensor for :func:`conv2d_wino_launch`."""
+    _require_gpu(weight)
+    _check_f32(weight)
+    w = weight.detach().contiguous()
+    cout, cin, kh, kw = w.shape
+    assert (kh, kw) == (3, 3)
+    L = hip.lib()
+    u = torch.empty(L.otp_conv2d_wino_weight_bytes(cout, cin) // 4, dtype=torch.float32, device=w.device)
+    hip.check(L.otp_conv2d_wino_pack_weight(hip.ptr(w), hip.ptr(u), cout, cin, hip.stream_of(w)), "otp_conv2d_wino_pack_weight")
+    return u
+
+
+def wino_supported(desc) -> bool:
+    return bool(hip.lib().otp_conv2d_wino_supported(desc))
+
+
+def conv2d_wino_launch(inp: View, upacked, scale, shift, out: View, desc, res: View = None, stream=None):
+    st = hip.lib().otp_conv2d_wino(hip.ptr(inp.t), hip.ptr(upacked), hip.ptr(scale), hip.ptr(shift),
+                                   hip.ptr(res.t if res is not None else None), hip.ptr(out.t), desc,
+                                   stream if stream is not None else hip.stream_of(out.t))
+    hip.check(st, "otp_conv2d_wino")
+
+
+def conv2d_wino(x, weight, scale=None, shift=None, act=ACT_NONE, res=None):
+    """3x3 / stride 1 / pad 1 convolution through the Winograd F(2x2, 3x3) kernel, fresh output."""
+    _require_gpu(x, weight)
+    cout = weight.shape[0]
+    out = torch.empty((x.shape[0], cout, x.shape[2], x.shape[3]), dtype=torch.float32, device=x.device)
+    iv, ov = View(x.contiguous()), View(out)
+    rv = View(res.contiguous()) if res is not None else None
+    d = conv_desc(iv, ov, cout, 3, 3, 1, 1, 1, act, None, rv, 1)
+    conv2d_wino_launch(iv, pack_wino_weight(weight), scale, shift, ov, d, rv)
+    return out
+
+
 def conv2d(x, weight, scale=None, shift=None, stride=1, pad=0, dil=1, act=ACT_NONE, res=None, in2=None, res_up=1):
     """Convenience form: out = act(scale * conv(x (+ in2), weight) + shift (+ res)), fresh output."""
     _require_gpu(x, weight)

@@ -210,3 +210,35 @@ def test_loss_matches_golden_and_oracle(golden):
     r2 = ops.st_ohkw_loss(g["s"].cuda(), g["t"].cuda(), g["g"].cuda(), g["w"].cuda(), flags=forced.cuda())
     ref2 = O.st_ohkw_mse_loss(g["s"], g["t"], g["g"], g["w"], global_flags=forced)
     _close(r2["final_loss"].reshape(()), ref2["final_loss"].reshape(()), 1e-5)
+
+
+@pytest.mark.parametrize("case", [  # N, Cin, H, W, Cout
+    (2, 48, 24, 18, 48),       # even sizes, one M tile, several tile blocks per image
+    (2, 20, 12, 9, 100),       # odd width (last tile column half empty), ragged Cin chunk and ragged last M tile
+    (1, 8, 6, 6, 16),          # one partly filled tile block
+    (3, 96, 10, 14, 96),       # odd tile-row count inside blocks, two M tiles
+    (1, 13, 96, 72, 17),       # the full heat-map size: blocks spanning three tile rows
+])
+def test_conv2d_winograd_matches_conv2d(case):
+    """Winograd F(2x2,3x3) kernel vs F.conv2d (3x3, stride 1, pad 1) with the fused epilogue and channel-sliced views."""
+    n, cin, h, w, cout = case
+    x = seeded((n, cin, h, w), 1)
+    wt = seeded((cout, cin, 3, 3), 2, 1.0 / math.sqrt(9 * cin))
+    sc, sh = 1 + 0.1 * seeded((cout,), 3), seeded((cout,), 4)
+    ref = F.conv2d(x, wt, None, 1, 1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    res = seeded(ref.shape, 5)
+    _close(ops.conv2d_wino(x.cuda(), wt.cuda()), F.conv2d(x, wt, None, 1, 1))
+    _close(ops.conv2d_wino(x.cuda(), wt.cuda(), sc.cuda(), sh.cuda(), act=ops.ACT_RELU, res=res.cuda()), F.relu(ref + res))
+    # channel-sliced input / output / residual views
+    big_in = torch.zeros(n, cin + 5, h, w)
+    big_in[:, 3:3 + cin] = x
+    big_out = torch.full((n, cout + 4, h, w), 7.0)
+    big_res = torch.zeros(n, cout + 2, h, w)
+    big_res[:, 2:] = res
+    bi, bo, br = big_in.cuda(), big_out.cuda(), big_res.cuda()
+    iv, ov, rv = ops.View(bi, 3, cin), ops.View(bo, 1, cout), ops.View(br, 2, cout)
+    d = ops.conv_desc(iv, ov, cout, 3, 3, 1, 1, 1, ops.ACT_NONE, None, rv, 1)
+    assert ops.wino_supported(d)
+    ops.conv2d_wino_launch(iv, ops.pack_wino_weight(wt.cuda()), sc.cuda(), sh.cuda(), ov, d, rv)
+    _close(bo[:, 1:1 + cout], ref + res)
+    assert float((bo[:, 0] - 7).abs().max()) == 0 and float((bo[:, 1 + cout:] - 7).abs().max()) == 0

@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--tile", default="", help="force MB,PB,WM,WP")
     ap.add_argument("--prio", type=int, default=-1, help="static wave priority on (1) / off (0)")
     ap.add_argument("--shape", action="append", default=[], help="extra shape N,Cin,Cout,k,s,d,H,W (repeatable)")
+    ap.add_argument("--wino", action="store_true", help="time the Winograd F(2x2,3x3) kernel on the 3x3 stride-1 shapes")
     ap.add_argument("--sweep", action="store_true", help="try every (MB,PB,WM,WP) tile through the tuning hook")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -100,6 +101,17 @@ def main():
         iv, ov = ops.View(x), ops.View(out)
         wp = ops.pack_conv_weight(wt)
         desc = ops.conv_desc(iv, ov, cout, k, k, s, pad, d, act=ops.ACT_RELU)
+        if a.wino:
+            if not (k == 3 and s == 1 and d == 1 and ops.wino_supported(desc)):
+                continue
+            up = ops.pack_wino_weight(wt)
+            ms = time_ms(lambda: ops.conv2d_wino_launch(iv, up, sc, sh, ov, desc), a.iters)
+            flop = 2.0 * cin * cout * k * k * ho * wo * n
+            print("%-58s %9.4f %9.2f %7.3f %9.3f" % (name + " [winograd]", ms, flop / (ms * 1e-3) / 1e12,
+                                                    flop / (ms * 1e-3) / PEAK, ms * calls))
+            tot_ms += ms * calls
+            tot_flop += flop * calls
+            continue
         ms = time_ms(lambda: ops.conv2d_launch(iv, wp, sc, sh, ov, desc), a.iters)
         import ctypes
         plan = (ctypes.c_int * 8)()
