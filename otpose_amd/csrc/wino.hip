@@ -32,8 +32,7 @@ constexpr int WCK = 8;            // input channels per chunk (two MFMA k-steps)
 constexpr int WMB = 3;            // 16-row output-channel blocks per workgroup
 constexpr int WMS = 16 * WMB;     // 48: LDS row of the weight slab (== 16 mod 32: the 4 k-rows of a fragment hit distinct banks)
 constexpr int WG_ = 4;            // guard floats in front of every channel window (column -1 of the first row)
-constexpr int WMAXJ = 8;          // float4 window items per thread
-constexpr int WUJ = 16 * WCK * (WMS / 4) / 256;   // 6 float4 weight items per thread
+constexpr int WMAXJ = 6;          // float4 window items per thread
 
 struct WinoPlan {
     int N, Cin, H, W, HW, Cout, Cout16;
@@ -86,7 +85,6 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const float* __restri
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* raw = smem;                                            // [WCK][WS]
     float* V = smem + WCK * P.WS;                                 // [16][WCK][VS]
-    float* U = V + 16 * WCK * VS;                                 // [16][WCK][WMS]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i16 = lane & 15, kl = lane >> 4;
@@ -102,18 +100,25 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const float* __restri
     const float* img = in + ((size_t)n * P.in_ctot + P.in_coff) * P.HW;
 
     // ---- staging ---------------------------------------------------------------------------------------------------------
-    f32x4 pfi[WMAXJ], pfu[WUJ];
-    int uoff[WUJ], udst[WUJ], uc[WUJ];
-#pragma unroll
-    for (int j = 0; j < WUJ; ++j) {
-        const int i = tid + 256 * j;                              // [16 coords][WCK][12 float4]
-        const int row = i / (WMS / 4), q = i - row * (WMS / 4);
-        const int coord = row / WCK, c = row - coord * WCK;
-        uoff[j] = ((coord * P.Cin + c) * P.Cout16 + m0 + 4 * q) * 4;
-        udst[j] = (coord * WCK + c) * WMS + 4 * q;
-        uc[j] = c;
-    }
+    f32x4 pfi[WMAXJ];
+    // Weight fragments: wave w multiplies only its own four coordinates, so its A operands never pass through LDS - lane
+    // (i16, kl) loads U[4w + nu][c0 + 4k + kl][m0 + 16 mb + i16] straight into the register the MFMA reads (24 dwords per
+    // chunk, L2-resident; rows past Cin alias finite values that meet zero inputs, or fall off the tensor -> 0).
+    float areg[4][WCK / 4][WMB];
     const otp_rsrc ru = make_rsrc32(up, (unsigned)(16 * P.Cin) * (unsigned)P.Cout16 * 4u);
+    const int ubase = (((wave * 4) * P.Cin + kl) * P.Cout16 + m0 + i16) * 4;
+    auto load_weights = [&](int c0) __attribute__((always_inline)) {
+        const int v = ubase + c0 * P.Cout16 * 4;
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+            for (int k = 0; k < WCK / 4; ++k) {
+                const int so = (nu * P.Cin + 4 * k) * P.Cout16 * 4;
+#pragma unroll
+                for (int mb = 0; mb < WMB; ++mb)
+                    areg[nu][k][mb] = bload(ru, v + mb * 64, so);
+            }
+    };
     const int vbase = (f0a + 4 * lane) * 4;
     auto load_chunk = [&](int c0) __attribute__((always_inline)) {
         int jc = 0, jr = 0;
@@ -127,14 +132,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const float* __restri
                 if (++jr == P.JR) { jr = 0; ++jc; }
             }
         }
-        const int cbytes = c0 * P.Cout16 * 4;
-#pragma unroll
-        for (int j = 0; j < WUJ; ++j) {
-            pfu[j] = bload4(ru, c0 + uc[j] < P.Cin ? uoff[j] + cbytes : -1);
-        }
         asm volatile("" ::: "memory");
     };
-    auto store_chunk = [&]() __attribute__((always_inline)) {
+    auto store_window = [&]() __attribute__((always_inline)) {
         int jc = 0, jr = 0;
 #pragma unroll
         for (int j = 0; j < WMAXJ; ++j) {
@@ -144,13 +144,14 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const float* __restri
                 if (++jr == P.JR) { jr = 0; ++jc; }
             }
         }
-#pragma unroll
-        for (int j = 0; j < WUJ; ++j) *reinterpret_cast<f32x4*>(U + udst[j]) = pfu[j];
     };
-
     // ---- per-thread patch geometry (the same for every chunk) -----------------------------------------------------------
+    // A thread transforms SLOTS patches per chunk side by side (packed f32 math: one v_pk_* per pair of patches).  Edge
+    // columns and dead patches are multiplied by 0 (the guard floats a masked read can touch are zeroed below, everything
+    // else in the window is image data or range-check zeros, so 0 * x is exact).
+    static_assert(SLOTS == 2, "the packed transform pairs two patches per thread");
     int toff[SLOTS], vdst[SLOTS];
-    unsigned cmask[SLOTS];                                        // bits 0..3: patch column jj inside the image; bit 4: patch live
+    f32x2 cm[4];                                                  // cm[jj] = (slot 0, slot 1) keep factors of patch column jj
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
         const int i = tid + 256 * s;
@@ -161,11 +162,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const float* __restri
         const int x0 = 2 * tx - 1;
         toff[s] = (live ? c : 0) * P.WS + WG_ + (f0 - f0a) + 2 * (ty - ty0) * P.W + x0;
         vdst[s] = live ? c * VS + j : -1;
-        unsigned m = 0;
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) m |= (x0 + jj >= 0 && x0 + jj < P.W) ? 1u << jj : 0u;
-        cmask[s] = (live && j < nt) ? (m | 16u) : 0u;
+        for (int jj = 0; jj < 4; ++jj) cm[jj][s] = (live && j < nt && x0 + jj >= 0 && x0 + jj < P.W) ? 1.f : 0.f;
     }
+    for (int c = tid; c < WCK * WG_; c += 256) raw[(c / WG_) * P.WS + (c % WG_)] = 0.f;       // guard floats
 
     f32x4 acc[4][WMB][TB];
 #pragma unroll
@@ -175,48 +175,45 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const float* __restri
 #pragma unroll
             for (int tb = 0; tb < TB; ++tb) acc[a][mb][tb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const float* Uw = U + (wave * 4) * WCK * WMS + kl * WMS + i16;
     const float* Vw = V + (wave * 4) * WCK * VS + kl * VS + i16;
 
     load_chunk(0);
-    store_chunk();
+    load_weights(0);
+    store_window();
     __syncthreads();
     for (int c0 = 0; c0 < P.Cin; c0 += WCK) {
         const bool more = c0 + WCK < P.Cin;
-        if (more) load_chunk(c0 + WCK);                           // in flight under the transform and the MFMAs
         // ---- input transform: V = B^T d B, B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]] -------------------------
+        {
+            const float* s0 = raw + toff[0];
+            const float* s1 = raw + toff[1];
+            f32x2 t[4][4];
 #pragma unroll
-        for (int s = 0; s < SLOTS; ++s) {
-            if (vdst[s] >= 0) {
-                float d[4][4];
-                const float* src = raw + toff[s];
+            for (int jj = 0; jj < 4; ++jj) {                       // one patch column at a time: 4 loads -> 4 results
+                const f32x2 d0 = (f32x2){s0[jj], s1[jj]} * cm[jj];
+                const f32x2 d1 = (f32x2){s0[P.W + jj], s1[P.W + jj]} * cm[jj];
+                const f32x2 d2 = (f32x2){s0[2 * P.W + jj], s1[2 * P.W + jj]} * cm[jj];
+                const f32x2 d3 = (f32x2){s0[3 * P.W + jj], s1[3 * P.W + jj]} * cm[jj];
+                t[0][jj] = d0 - d2;
+                t[1][jj] = d1 + d2;
+                t[2][jj] = d2 - d1;
+                t[3][jj] = d1 - d3;
+            }
+            float* q0 = V + vdst[0];
+            float* q1 = V + (vdst[1] >= 0 ? vdst[1] : 0);
+            const bool w1 = vdst[1] >= 0;
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) {
-                        const float v = src[i * P.W + jj];
-                        d[i][jj] = (cmask[s] >> jj) & 1u ? v : 0.f;
-                    }
-                float t[4][4];
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    t[0][jj] = d[0][jj] - d[2][jj];
-                    t[1][jj] = d[1][jj] + d[2][jj];
-                    t[2][jj] = d[2][jj] - d[1][jj];
-                    t[3][jj] = d[1][jj] - d[3][jj];
-                }
-                const bool on = cmask[s] & 16u;
-                float* dst = V + vdst[s];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float v0 = t[i][0] - t[i][2], v1 = t[i][1] + t[i][2], v2 = t[i][2] - t[i][1], v3 = t[i][1] - t[i][3];
-                    dst[(i * 4 + 0) * WCK * VS] = on ? v0 : 0.f;
-                    dst[(i * 4 + 1) * WCK * VS] = on ? v1 : 0.f;
-                    dst[(i * 4 + 2) * WCK * VS] = on ? v2 : 0.f;
-                    dst[(i * 4 + 3) * WCK * VS] = on ? v3 : 0.f;
+            for (int i = 0; i < 4; ++i) {
+                const f32x2 v0 = t[i][0] - t[i][2], v1 = t[i][1] + t[i][2], v2 = t[i][2] - t[i][1], v3 = t[i][1] - t[i][3];
+                q0[(i * 4 + 0) * WCK * VS] = v0[0]; q0[(i * 4 + 1) * WCK * VS] = v1[0];
+                q0[(i * 4 + 2) * WCK * VS] = v2[0]; q0[(i * 4 + 3) * WCK * VS] = v3[0];
+                if (w1) {
+                    q1[(i * 4 + 0) * WCK * VS] = v0[1]; q1[(i * 4 + 1) * WCK * VS] = v1[1];
+                    q1[(i * 4 + 2) * WCK * VS] = v2[1]; q1[(i * 4 + 3) * WCK * VS] = v3[1];
                 }
             }
         }
+        if (more) load_chunk(c0 + WCK);                           // window of the next chunk: in flight under the MFMAs
         __syncthreads();                                          // V complete (U was complete at the previous barrier)
         // ---- 4 coordinates x 2 k-steps x (WMB x TB) MFMAs ------------------------------------------------------------------
 #pragma unroll
@@ -225,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const float* __restri
             for (int k = 0; k < WCK / 4; ++k) {
                 float a[WMB], b[TB];
 #pragma unroll
-                for (int mb = 0; mb < WMB; ++mb) a[mb] = Uw[(nu * WCK + 4 * k) * WMS + mb * 16];
+                for (int mb = 0; mb < WMB; ++mb) a[mb] = areg[nu][k][mb];
 #pragma unroll
                 for (int tb = 0; tb < TB; ++tb) b[tb] = Vw[(nu * WCK + 4 * k) * VS + tb * 16];
 #pragma unroll
@@ -234,24 +231,35 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const float* __restri
                     for (int tb = 0; tb < TB; ++tb)
                         acc[nu][mb][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb], b[tb], acc[nu][mb][tb], 0, 0, 0);
             }
-        __syncthreads();                                          // raw / V / U free
         if (more) {
-            store_chunk();
-            __syncthreads();
+            load_weights(c0 + WCK);                               // the fragments of this chunk are spent; in flight under the next transform
+            store_window();                                       // raw is free since the barrier above
         }
+        __syncthreads();                                          // V free, raw of the next chunk complete
     }
 
     // ---- output transform + epilogue, one 16-channel block at a time -----------------------------------------------------
-    float* Pb = V;                                                // [4 waves][2][16][PST] (aliases V / U: both are dead)
+    // thread = (channel row = tid / 16, 16 consecutive tiles = tid % 16 + 16 * tb): stores of a wave are 128-byte runs
+    float* Pb = smem;                                             // [4 waves][2][16][PST] (aliases the window and V: both are dead)
     const int HoWo = P.HW;
+    const int erow = tid >> 4, el = tid & 15;
+    int eoff[TB];                                                 // pixel offset of the tile's top-left output, -1: no such tile
+    bool etwo[TB], ebot[TB];
+#pragma unroll
+    for (int tb = 0; tb < TB; ++tb) {
+        const int j = tb * 16 + el, t = t0 + j;
+        const int ty = (int)wdiv((uint32_t)t, P.magicTX), tx = t - ty * P.TX;
+        eoff[tb] = j < nt ? 2 * ty * P.W + 2 * tx : -1;
+        etwo[tb] = 2 * tx + 1 < P.W;
+        ebot[tb] = 2 * ty + 1 < P.H;
+    }
 #pragma unroll 1
     for (int mb = 0; mb < WMB; ++mb) {
 #pragma unroll
         for (int tb = 0; tb < TB; ++tb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                // (select the 16-channel block with a runtime index: keep the accumulators in registers by unrolling over mb below)
-                float m0v = 0.f, m1v = 0.f, m2v = 0.f, m3v = 0.f;
+                float m0v = 0.f, m1v = 0.f, m2v = 0.f, m3v = 0.f;  // runtime mb, static register indices
 #pragma unroll
                 for (int q = 0; q < WMB; ++q)
                     if (q == mb) { m0v = acc[0][q][tb][r]; m1v = acc[1][q][tb][r]; m2v = acc[2][q][tb][r]; m3v = acc[3][q][tb][r]; }
@@ -259,45 +267,43 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const float* __restri
                 Pb[((wave * 2 + 1) * 16 + kl * 4 + r) * PST + tb * 16 + i16] = m1v - m2v - m3v;
             }
         __syncthreads();
-        for (int idx = tid; idx < 16 * 2 * NT; idx += 256) {
-            const int rest = idx / NT, j = idx - rest * NT;       // lanes = consecutive tiles: coalesced float2 stores
-            const int i = rest & 1, row = rest >> 1;
-            const int co = m0 + mb * 16 + row;
-            const int t = t0 + j;
-            const int ty = (int)wdiv((uint32_t)t, P.magicTX), tx = t - ty * P.TX;
-            const int y = 2 * ty + i, x = 2 * tx;
-            if (j < nt && co < P.Cout && y < P.H) {
-                const float* pr = Pb + row * PST + j;
-                float y0, y1;
-                if (i == 0) {
-                    y0 = pr[(0 * 2 + 0) * 16 * PST] + pr[(1 * 2 + 0) * 16 * PST] + pr[(2 * 2 + 0) * 16 * PST];
-                    y1 = pr[(0 * 2 + 1) * 16 * PST] + pr[(1 * 2 + 1) * 16 * PST] + pr[(2 * 2 + 1) * 16 * PST];
-                } else {
-                    y0 = pr[(1 * 2 + 0) * 16 * PST] - pr[(2 * 2 + 0) * 16 * PST] - pr[(3 * 2 + 0) * 16 * PST];
-                    y1 = pr[(1 * 2 + 1) * 16 * PST] - pr[(2 * 2 + 1) * 16 * PST] - pr[(3 * 2 + 1) * 16 * PST];
-                }
-                const float sc = scale ? scale[co] : 1.f, sh = shift ? shift[co] : 0.f;
-                y0 = fmaf(y0, sc, sh);
-                y1 = fmaf(y1, sc, sh);
-                const size_t ob = ((size_t)n * P.out_ctot + P.out_coff + co) * HoWo + (size_t)y * P.W + x;
-                const size_t rb = ((size_t)n * P.res_ctot + P.res_coff + co) * HoWo + (size_t)y * P.W + x;
-                const bool two = x + 1 < P.W;
-                if (res) {
-                    if (two && P.w_even) {
-                        const f32x2 rv = *reinterpret_cast<const f32x2*>(res + rb);
-                        y0 += rv.x; y1 += rv.y;
-                    } else {
-                        y0 += res[rb];
-                        if (two) y1 += res[rb + 1];
+        const int co = m0 + mb * 16 + erow;
+        if (co < P.Cout) {
+            const float sc = scale ? scale[co] : 1.f, sh = shift ? shift[co] : 0.f;
+            float* orow = out + ((size_t)n * P.out_ctot + P.out_coff + co) * HoWo;
+            const float* rrow = res ? res + ((size_t)n * P.res_ctot + P.res_coff + co) * HoWo : nullptr;
+#pragma unroll
+            for (int tb = 0; tb < TB; ++tb) {
+                if (eoff[tb] < 0) continue;
+                const float* pr = Pb + erow * PST + tb * 16 + el;
+                const float p00 = pr[0 * 16 * PST], p01 = pr[1 * 16 * PST], p10 = pr[2 * 16 * PST], p11 = pr[3 * 16 * PST],
+                            p20 = pr[4 * 16 * PST], p21 = pr[5 * 16 * PST], p30 = pr[6 * 16 * PST], p31 = pr[7 * 16 * PST];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    if (i == 1 && !ebot[tb]) continue;
+                    float y0 = i == 0 ? p00 + p10 + p20 : p10 - p20 - p30;
+                    float y1 = i == 0 ? p01 + p11 + p21 : p11 - p21 - p31;
+                    y0 = fmaf(y0, sc, sh);
+                    y1 = fmaf(y1, sc, sh);
+                    const int o = eoff[tb] + i * P.W;
+                    const bool two = etwo[tb];
+                    if (rrow) {
+                        if (two && P.w_even) {
+                            const f32x2 rv = *reinterpret_cast<const f32x2*>(rrow + o);
+                            y0 += rv.x; y1 += rv.y;
+                        } else {
+                            y0 += rrow[o];
+                            if (two) y1 += rrow[o + 1];
+                        }
                     }
-                }
-                if (P.act == OTP_ACT_RELU) { y0 = fmaxf(y0, 0.f); y1 = fmaxf(y1, 0.f); }
-                else if (P.act == OTP_ACT_GELU) { y0 = wino_gelu(y0); y1 = wino_gelu(y1); }
-                if (two && P.w_even) {
-                    *reinterpret_cast<f32x2*>(out + ob) = (f32x2){y0, y1};
-                } else {
-                    out[ob] = y0;
-                    if (two) out[ob + 1] = y1;
+                    if (P.act == OTP_ACT_RELU) { y0 = fmaxf(y0, 0.f); y1 = fmaxf(y1, 0.f); }
+                    else if (P.act == OTP_ACT_GELU) { y0 = wino_gelu(y0); y1 = wino_gelu(y1); }
+                    if (two && P.w_even) {
+                        *reinterpret_cast<f32x2*>(orow + o) = (f32x2){y0, y1};
+                    } else {
+                        orow[o] = y0;
+                        if (two) orow[o + 1] = y1;
+                    }
                 }
             }
         }
@@ -328,9 +334,9 @@ bool wino_plan(const otp_conv_desc& d, WinoPlan& P, size_t& lds, int NT) {
     P.magicTX = wmagic(P.TX);
     P.magicBpi = wmagic(P.bpi);
     const int VS = (NT % 32 == 16) ? NT : NT + 16;
-    lds = ((size_t)WCK * P.WS + (size_t)16 * WCK * VS + (size_t)16 * WCK * WMS) * sizeof(float);
-    const size_t ep = (size_t)4 * 2 * 16 * (NT + 2) * sizeof(float);
-    if (ep > ((size_t)16 * WCK * VS + (size_t)16 * WCK * WMS) * sizeof(float)) return false;
+    lds = ((size_t)WCK * P.WS + (size_t)16 * WCK * VS) * sizeof(float);
+    const size_t ep = (size_t)4 * 2 * 16 * (NT + 2) * sizeof(float);      // epilogue tiles alias the window + V
+    if (ep > lds) lds = ep;
     if ((long)16 * d.Cin * P.Cout16 * 4 >= (1l << 31) || (long)P.HW * 4 >= (1l << 30)) return false;
     return lds <= 80 * 1024;
 }
