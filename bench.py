@@ -88,17 +88,32 @@ def kernel_rooflines(dev, batch):
     iv, ov = ops.View(x), ops.View(out)
     wp = ops.pack_conv_weight(w)
     d = ops.conv_desc(iv, ov, 48, 3, 3, 1, 1, 1, act=ops.ACT_RELU)
-    t_conv = event_time_ms(lambda: ops.conv2d_launch(iv, wp, sc, sh, ov, d), 20, st)
-    import ctypes
-    plan = (ctypes.c_int * 8)()
-    hip.lib().otp_conv2d_last_plan(plan)
     conv_flop = 2.0 * 48 * 48 * 9 * 96 * 72 * n
-    conv = {"kernel": "conv_win_kernel<%d,%d,3,true> 48->48 3x3 @96x72 x%d frames (grid %d x %d threads)"
-                      % (plan[0], plan[1], n, plan[5], 64 * plan[2] * plan[3]),
+    from otpose_amd.engine import InferenceEngine
+    use_wino = (os.environ.get("OTPOSE_WINOGRAD", "1") != "0" and InferenceEngine.winograd_pays(48, 48)
+                and ops.wino_supported(d))
+    if use_wino:
+        # the kernel the engine runs for this layer: Winograd F(2x2,3x3) (csrc/wino.hip).  `achieved` stays ALGORITHMIC
+        # (direct-convolution) FLOPs per second; the kernel itself executes 16/36 of them on the MFMA pipe.
+        up = ops.pack_wino_weight(w)
+        t_conv = event_time_ms(lambda: ops.conv2d_wino_launch(iv, up, sc, sh, ov, d), 20, st)
+        tiles = n * 48 * 36
+        kname = ("conv_wino_kernel<3> 48->48 3x3 @96x72 x%d frames (grid %d x 256 threads)" % (n, n * 36))
+        executed = 2.0 * 48 * 48 * 16 * tiles
+    else:
+        t_conv = event_time_ms(lambda: ops.conv2d_launch(iv, wp, sc, sh, ov, d), 20, st)
+        import ctypes
+        plan = (ctypes.c_int * 8)()
+        hip.lib().otp_conv2d_last_plan(plan)
+        kname = ("conv_win_kernel<%d,%d,3,true> 48->48 3x3 @96x72 x%d frames (grid %d x %d threads)"
+                 % (plan[0], plan[1], n, plan[5], 64 * plan[2] * plan[3]))
+        executed = conv_flop
+    conv = {"kernel": kname,
             "bound": "mfma", "achieved": conv_flop / (t_conv * 1e-3) / 1e12, "peak": PEAK_F32_MATRIX / 1e12,
             "unit": "TFLOP/s", "frac": conv_flop / (t_conv * 1e-3) / PEAK_F32_MATRIX,
-            "traffic": measured_traffic("conv_48_48_3x3_96x72_x80"), "ms_per_launch": t_conv,
-            "algorithmic_flop_per_launch": conv_flop}
+            "traffic": measured_traffic("conv_wino_48_48_3x3_96x72_x80" if use_wino else "conv_48_48_3x3_96x72_x80"),
+            "ms_per_launch": t_conv, "algorithmic_flop_per_launch": conv_flop,
+            "executed_mfma_flop_per_launch": executed, "mfma_pipe_frac": executed / (t_conv * 1e-3) / PEAK_F32_MATRIX}
     # one DCN call (one dilation) over the batch
     xd = torch.randn(batch, 17, 96, 72, generator=g).to(dev)
     off = (torch.randn(batch, 306, 96, 72, generator=g) * 3).to(dev)

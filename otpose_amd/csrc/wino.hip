@@ -73,7 +73,7 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict_
     }
 }
 
-template <int TB>
+template <int TB, bool WEVEN>
 __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const float* __restrict__ in, const float* __restrict__ up,
                                                              const float* __restrict__ scale,
                                                              const float* __restrict__ shift, const float* res, float* out,
@@ -90,7 +90,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const float* __restri
     const int i16 = lane & 15, kl = lane >> 4;
 
     // ---- block -> (image, first tile, output-channel tile) -----------------------------------------------------------
-    const int bp = blockIdx.x, m0 = blockIdx.y * WMS;
+    // the nM output-channel tiles of one tile block are 8 block ids apart (= the same XCD under round-robin dispatch) and
+    // run back to back, so the window is fetched into that L2 once
+    const int per = 8 * P.nM;
+    const int grp = (int)blockIdx.x / per, rem = (int)blockIdx.x - grp * per;
+    const int bp = grp * 8 + (rem & 7), m0 = (rem >> 3) * WMS;
+    if (bp >= P.N * P.bpi) return;                                // uniform per workgroup (padding of the last group of 8)
     const int n = (int)wdiv((uint32_t)bp, P.magicBpi);
     const int t0 = (bp - n * P.bpi) * NT;
     const int nt = min(NT, P.tpi - t0);
@@ -188,16 +193,49 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const float* __restri
             const float* s0 = raw + toff[0];
             const float* s1 = raw + toff[1];
             f32x2 t[4][4];
+            if (WEVEN) {
+                // even W: patch columns 1, 2 of every row are an 8-byte aligned pair -> 3 LDS reads per row instead of 4, and
+                // the paired read is conflict-free (the single reads step 2 floats per lane: 2-way)
+                {                                                  // columns 1 and 2 together
+                    f32x2 e[4][2];
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {                       // one patch column at a time: 4 loads -> 4 results
-                const f32x2 d0 = (f32x2){s0[jj], s1[jj]} * cm[jj];
-                const f32x2 d1 = (f32x2){s0[P.W + jj], s1[P.W + jj]} * cm[jj];
-                const f32x2 d2 = (f32x2){s0[2 * P.W + jj], s1[2 * P.W + jj]} * cm[jj];
-                const f32x2 d3 = (f32x2){s0[3 * P.W + jj], s1[3 * P.W + jj]} * cm[jj];
-                t[0][jj] = d0 - d2;
-                t[1][jj] = d1 + d2;
-                t[2][jj] = d2 - d1;
-                t[3][jj] = d1 - d3;
+                    for (int i = 0; i < 4; ++i) {
+                        const f32x2 m0 = *reinterpret_cast<const f32x2*>(s0 + i * P.W + 1);
+                        const f32x2 m1 = *reinterpret_cast<const f32x2*>(s1 + i * P.W + 1);
+                        e[i][0] = (f32x2){m0[0], m1[0]} * cm[1];
+                        e[i][1] = (f32x2){m0[1], m1[1]} * cm[2];
+                    }
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        t[0][1 + h] = e[0][h] - e[2][h];
+                        t[1][1 + h] = e[1][h] + e[2][h];
+                        t[2][1 + h] = e[2][h] - e[1][h];
+                        t[3][1 + h] = e[1][h] - e[3][h];
+                    }
+                }
+#pragma unroll
+                for (int jj = 0; jj < 4; jj += 3) {               // columns 0 and 3
+                    const f32x2 d0 = (f32x2){s0[jj], s1[jj]} * cm[jj];
+                    const f32x2 d1 = (f32x2){s0[P.W + jj], s1[P.W + jj]} * cm[jj];
+                    const f32x2 d2 = (f32x2){s0[2 * P.W + jj], s1[2 * P.W + jj]} * cm[jj];
+                    const f32x2 d3 = (f32x2){s0[3 * P.W + jj], s1[3 * P.W + jj]} * cm[jj];
+                    t[0][jj] = d0 - d2;
+                    t[1][jj] = d1 + d2;
+                    t[2][jj] = d2 - d1;
+                    t[3][jj] = d1 - d3;
+                }
+            } else {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {                   // one patch column at a time: 4 loads -> 4 results
+                    const f32x2 d0 = (f32x2){s0[jj], s1[jj]} * cm[jj];
+                    const f32x2 d1 = (f32x2){s0[P.W + jj], s1[P.W + jj]} * cm[jj];
+                    const f32x2 d2 = (f32x2){s0[2 * P.W + jj], s1[2 * P.W + jj]} * cm[jj];
+                    const f32x2 d3 = (f32x2){s0[3 * P.W + jj], s1[3 * P.W + jj]} * cm[jj];
+                    t[0][jj] = d0 - d2;
+                    t[1][jj] = d1 + d2;
+                    t[2][jj] = d2 - d1;
+                    t[3][jj] = d1 - d3;
+                }
             }
             float* q0 = V + vdst[0];
             float* q1 = V + (vdst[1] >= 0 ? vdst[1] : 0);
@@ -288,7 +326,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const float* __restri
                     const int o = eoff[tb] + i * P.W;
                     const bool two = etwo[tb];
                     if (rrow) {
-                        if (two && P.w_even) {
+                        if (two && WEVEN) {
                             const f32x2 rv = *reinterpret_cast<const f32x2*>(rrow + o);
                             y0 += rv.x; y1 += rv.y;
                         } else {
@@ -298,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const float* __restri
                     }
                     if (P.act == OTP_ACT_RELU) { y0 = fmaxf(y0, 0.f); y1 = fmaxf(y1, 0.f); }
                     else if (P.act == OTP_ACT_GELU) { y0 = wino_gelu(y0); y1 = wino_gelu(y1); }
-                    if (two && P.w_even) {
+                    if (two && WEVEN) {
                         *reinterpret_cast<f32x2*>(orow + o) = (f32x2){y0, y1};
                     } else {
                         orow[o] = y0;
@@ -376,10 +414,20 @@ extern "C" int otp_conv2d_wino(const void* in, const void* upacked, const void* 
     WinoPlan P{};
     size_t lds = 0;
     if (!wino_plan(d, P, lds, 48)) return OTP_ERR_UNSUPPORTED;
-    auto kern = conv_wino_kernel<3>;
-    OTP_ALLOW_BIG_LDS(kern, lds);
-    hipLaunchKernelGGL(kern, dim3(P.N * P.bpi, P.nM), dim3(256), lds, static_cast<hipStream_t>(stream),
-                       static_cast<const float*>(in), static_cast<const float*>(upacked), static_cast<const float*>(scale),
-                       static_cast<const float*>(shift), static_cast<const float*>(res), static_cast<float*>(out), P);
+    const dim3 grid(((P.N * P.bpi + 7) / 8) * 8 * P.nM);
+    auto st = static_cast<hipStream_t>(stream);
+    if (P.w_even) {
+        auto kern = conv_wino_kernel<3, true>;
+        OTP_ALLOW_BIG_LDS(kern, lds);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, static_cast<const float*>(in), static_cast<const float*>(upacked),
+                           static_cast<const float*>(scale), static_cast<const float*>(shift),
+                           static_cast<const float*>(res), static_cast<float*>(out), P);
+    } else {
+        auto kern = conv_wino_kernel<3, false>;
+        OTP_ALLOW_BIG_LDS(kern, lds);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, static_cast<const float*>(in), static_cast<const float*>(upacked),
+                           static_cast<const float*>(scale), static_cast<const float*>(shift),
+                           static_cast<const float*>(res), static_cast<float*>(out), P);
+    }
     return otp_launch_status();
 }
