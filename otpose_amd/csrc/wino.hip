@@ -18,6 +18,7 @@
 // all threads finish Y[i][j] = sum_x A^T[i][x] P_x[j], apply scale / shift (+ residual) (+ ReLU / GELU) and store float2
 // pairs (a tile's two columns) - coalesced along the tile row.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -28,11 +29,9 @@ __device__ __forceinline__ float wino_gelu(float x) { return 0.5f * x * (1.f + e
 __device__ __forceinline__ uint32_t wdiv(uint32_t i, uint32_t magic) { return magic ? __umulhi(i, magic) : i; }
 uint32_t wmagic(uint32_t d) { return d <= 1 ? 0u : (uint32_t)((1ull << 32) / d) + 1u; }
 
-constexpr int WCK = 8;            // input channels per chunk (two MFMA k-steps)
 constexpr int WMB = 3;            // 16-row output-channel blocks per workgroup
 constexpr int WMS = 16 * WMB;     // 48: LDS row of the weight slab (== 16 mod 32: the 4 k-rows of a fragment hit distinct banks)
 constexpr int WG_ = 4;            // guard floats in front of every channel window (column -1 of the first row)
-constexpr int WMAXJ = 6;          // float4 window items per thread
 
 struct WinoPlan {
     int N, Cin, H, W, HW, Cout, Cout16;
@@ -73,7 +72,10 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict_
     }
 }
 
-template <int TB, bool WEVEN>
+// TB x WCK: 3 x 8 (48 tiles, 8-channel chunks) is the general shape; 2 x 16 (32 tiles, 16-channel chunks: the same 144
+// accumulator + 24/48 fragment registers, two patches per thread and chunk either way) fills the tile blocks of the small
+// maps better (12x9: 30 tiles per image, 24x18: 108).
+template <int TB, int WCK, bool WEVEN>
 __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const float* __restrict__ in, const float* __restrict__ up,
                                                              const float* __restrict__ scale,
                                                              const float* __restrict__ shift, const float* res, float* out,
@@ -105,7 +107,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const float* __restri
     const float* img = in + ((size_t)n * P.in_ctot + P.in_coff) * P.HW;
 
     // ---- staging ---------------------------------------------------------------------------------------------------------
-    f32x4 pfi[WMAXJ];
+    constexpr int NJI = WCK == 8 ? 6 : 8;
+    f32x4 pfi[NJI];
     // Weight fragments: wave w multiplies only its own four coordinates, so its A operands never pass through LDS - lane
     // (i16, kl) loads U[4w + nu][c0 + 4k + kl][m0 + 16 mb + i16] straight into the register the MFMA reads (24 dwords per
     // chunk, L2-resident; rows past Cin alias finite values that meet zero inputs, or fall off the tensor -> 0).
@@ -128,9 +131,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const float* __restri
     auto load_chunk = [&](int c0) __attribute__((always_inline)) {
         int jc = 0, jr = 0;
 #pragma unroll
-        for (int j = 0; j < WMAXJ; ++j) {
-            if (j < 2 * P.JR) {
-                const int c = wave * 2 + jc, ch = c0 + c;         // wave w stages channels 2w, 2w+1 of the chunk
+        for (int j = 0; j < NJI; ++j) {
+            if (j < (WCK / 4) * P.JR) {
+                const int c = wave * (WCK / 4) + jc, ch = c0 + c;  // wave w stages WCK / 4 channels of the chunk
                 const bool live = ch < P.Cin;
                 const otp_rsrc r = make_rsrc32(img + (size_t)(live ? ch : 0) * P.HW, live ? (unsigned)P.HW * 4u : 0u);
                 pfi[j] = bload4(r, vbase + jr * 1024);
@@ -142,9 +145,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const float* __restri
     auto store_window = [&]() __attribute__((always_inline)) {
         int jc = 0, jr = 0;
 #pragma unroll
-        for (int j = 0; j < WMAXJ; ++j) {
-            if (j < 2 * P.JR) {
-                const int c = wave * 2 + jc, r4 = lane + 64 * jr;
+        for (int j = 0; j < NJI; ++j) {
+            if (j < (WCK / 4) * P.JR) {
+                const int c = wave * (WCK / 4) + jc, r4 = lane + 64 * jr;
                 if (r4 < P.L4) *reinterpret_cast<f32x4*>(raw + c * P.WS + WG_ + 4 * r4) = pfi[j];
                 if (++jr == P.JR) { jr = 0; ++jc; }
             }
@@ -349,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const float* __restri
     }
 }
 
-bool wino_plan(const otp_conv_desc& d, WinoPlan& P, size_t& lds, int NT) {
+bool wino_plan(const otp_conv_desc& d, WinoPlan& P, size_t& lds, int NT, int WCK) {
     if (d.kh != 3 || d.kw != 3 || d.stride != 1 || d.pad != 1 || d.dil != 1 || d.res_up > 1 || d.frame_split > 0) return false;
     if (d.Ho != d.H || d.Wo != d.W || ((d.H * d.W) & 3)) return false;
     P.N = d.N; P.Cin = d.Cin; P.H = d.H; P.W = d.W; P.HW = d.H * d.W; P.Cout = d.Cout; P.Cout16 = (d.Cout + 15) & ~15;
@@ -365,7 +368,7 @@ bool wino_plan(const otp_conv_desc& d, WinoPlan& P, size_t& lds, int NT) {
     const int rows_in = 2 * span + 2;
     P.L4 = (rows_in * d.W + 3 + 3) / 4 + 1;
     P.JR = (P.L4 + 63) / 64;
-    if (2 * P.JR > WMAXJ) return false;
+    if ((WCK / 4) * P.JR > (WCK == 8 ? 6 : 8)) return false;
     P.WS = WG_ + 4 * P.L4 + 4;
     if ((P.WS & 31) == 0) P.WS += 4;
     P.w_even = (d.W & 1) == 0 ? 1 : 0;
@@ -377,6 +380,40 @@ bool wino_plan(const otp_conv_desc& d, WinoPlan& P, size_t& lds, int NT) {
     if (ep > lds) lds = ep;
     if ((long)16 * d.Cin * P.Cout16 * 4 >= (1l << 31) || (long)P.HW * 4 >= (1l << 30)) return false;
     return lds <= 80 * 1024;
+}
+
+// variant 0 = 48 tiles x 8-channel chunks, 1 = 32 tiles x 16-channel chunks.  Measured (tools/conv_bench.py --wino with
+// OTP_WINO_VARIANT=0/1): the second is faster wherever its tile blocks are at least as full (48->48 @96x72 0.219 -> 0.200 ms,
+// 192->192 @24x18 0.201 -> 0.175, 384->384 @12x9 0.282 -> 0.203, 256->48 @96x72 0.941 -> 0.779); 96->96 @48x36, whose 432
+// tiles per image split into 9 full 48-tile blocks but 13.5 32-tile ones, prefers the first (0.164 vs 0.178).
+int wino_choose(const otp_conv_desc& d, WinoPlan& P, size_t& lds) {
+    WinoPlan A{}, B{};
+    size_t la = 0, lb = 0;
+    const bool oka = wino_plan(d, A, la, 48, 8), okb = wino_plan(d, B, lb, 32, 16);
+    if (!oka && !okb) return -1;
+    const double fa = oka ? (double)A.tpi / (A.bpi * 48.0) : 0.0, fb = okb ? (double)B.tpi / (B.bpi * 32.0) : 0.0;
+    const char* force = getenv("OTP_WINO_VARIANT");
+    if (force && force[0] == '1' && okb) { P = B; lds = lb; return 1; }
+    if (force && force[0] == '0' && oka) { P = A; lds = la; return 0; }
+    if (okb && (!oka || fb >= fa)) { P = B; lds = lb; return 1; }
+    P = A; lds = la;
+    return 0;
+}
+
+template <int TB, int WCK>
+int wino_launch(const float* in, const float* up, const float* scale, const float* shift, const float* res, float* out,
+                const WinoPlan& P, size_t lds, hipStream_t st) {
+    const dim3 grid(((P.N * P.bpi + 7) / 8) * 8 * P.nM);
+    if (P.w_even) {
+        auto kern = conv_wino_kernel<TB, WCK, true>;
+        OTP_ALLOW_BIG_LDS(kern, lds);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, in, up, scale, shift, res, out, P);
+    } else {
+        auto kern = conv_wino_kernel<TB, WCK, false>;
+        OTP_ALLOW_BIG_LDS(kern, lds);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, in, up, scale, shift, res, out, P);
+    }
+    return otp_launch_status();
 }
 
 }  // namespace
@@ -399,7 +436,7 @@ extern "C" int otp_conv2d_wino_supported(const otp_conv_desc* desc) {
     if (!desc) return 0;
     WinoPlan P{};
     size_t lds = 0;
-    return wino_plan(*desc, P, lds, 48) ? 1 : 0;
+    return wino_choose(*desc, P, lds) >= 0 ? 1 : 0;
 }
 
 extern "C" int otp_conv2d_wino(const void* in, const void* upacked, const void* scale, const void* shift, const void* res,
@@ -413,21 +450,10 @@ extern "C" int otp_conv2d_wino(const void* in, const void* upacked, const void* 
     if ((reinterpret_cast<uintptr_t>(out) & 7) || (res && (reinterpret_cast<uintptr_t>(res) & 7))) return OTP_ERR_UNSUPPORTED;
     WinoPlan P{};
     size_t lds = 0;
-    if (!wino_plan(d, P, lds, 48)) return OTP_ERR_UNSUPPORTED;
-    const dim3 grid(((P.N * P.bpi + 7) / 8) * 8 * P.nM);
+    const int variant = wino_choose(d, P, lds);
+    if (variant < 0) return OTP_ERR_UNSUPPORTED;
     auto st = static_cast<hipStream_t>(stream);
-    if (P.w_even) {
-        auto kern = conv_wino_kernel<3, true>;
-        OTP_ALLOW_BIG_LDS(kern, lds);
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, static_cast<const float*>(in), static_cast<const float*>(upacked),
-                           static_cast<const float*>(scale), static_cast<const float*>(shift),
-                           static_cast<const float*>(res), static_cast<float*>(out), P);
-    } else {
-        auto kern = conv_wino_kernel<3, false>;
-        OTP_ALLOW_BIG_LDS(kern, lds);
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, static_cast<const float*>(in), static_cast<const float*>(upacked),
-                           static_cast<const float*>(scale), static_cast<const float*>(shift),
-                           static_cast<const float*>(res), static_cast<float*>(out), P);
-    }
-    return otp_launch_status();
+    auto f = [](const void* p) { return static_cast<const float*>(p); };
+    return variant == 1 ? wino_launch<2, 16>(f(in), f(upacked), f(scale), f(shift), f(res), static_cast<float*>(out), P, lds, st)
+                        : wino_launch<3, 8>(f(in), f(upacked), f(scale), f(shift), f(res), static_cast<float*>(out), P, lds, st);
 }
