@@ -8,11 +8,14 @@ PyTorch supplies memory, streams and the autograd tape only; CPU tensors raise l
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch.autograd import Function
 
 from . import hip
-from .ops import ACT_NONE, View, _check_f32, _require_gpu, conv2d_launch, conv_desc, pack_conv_weight
+from .ops import (ACT_NONE, View, _check_f32, _require_gpu, conv2d_launch, conv2d_wino_launch, conv_desc,
+                  pack_conv_weight, pack_wino_weight, wino_supported)
 
 
 def _out_hw(h, w, k, stride, pad, dil):
@@ -25,8 +28,19 @@ def conv2d_forward(x, weight, bias, stride, pad, dil):
     out = torch.empty((x.shape[0], cout, ho, wo), dtype=torch.float32, device=x.device)
     iv, ov = View(x), View(out)
     d = conv_desc(iv, ov, cout, kh, kw, stride, pad, dil, ACT_NONE)
-    conv2d_launch(iv, pack_conv_weight(weight), None, bias, ov, d)
+    if _winograd(cin, cout, d):
+        conv2d_wino_launch(iv, pack_wino_weight(weight), None, bias, ov, d)
+    else:
+        conv2d_launch(iv, pack_conv_weight(weight), None, bias, ov, d)
     return out
+
+
+def _winograd(cin, cout, d):
+    """3x3 / stride 1 / pad 1 layers with enough channels run on the Winograd kernel, forward and input gradient alike
+    (same rule as the inference engine)."""
+    from .engine import InferenceEngine
+    return (os.environ.get("OTPOSE_WINOGRAD", "1") != "0" and d.kh == 3 and d.stride == 1 and d.pad == 1 and d.dil == 1
+            and InferenceEngine.winograd_pays(cin, cout) and wino_supported(d))
 
 
 def conv2d_grad_input(grad_out, weight, in_shape, stride, pad, dil):
@@ -42,13 +56,18 @@ def conv2d_grad_input(grad_out, weight, in_shape, stride, pad, dil):
         hip.check(L.otp_dilate(hip.ptr(g), hip.ptr(gd), n * cout, g.shape[2], g.shape[3], stride, hd, wd,
                                hip.stream_of(g)), "otp_dilate")
         g = gd
+    gx = torch.empty(in_shape, dtype=torch.float32, device=g.device)
+    iv, ov = View(g), View(gx)
+    d = conv_desc(iv, ov, cin, kh, kw, 1, dil * (kh - 1) - pad, dil, ACT_NONE)
+    if stride == 1 and _winograd(cout, cin, d):
+        # the transposed convolution as a Winograd conv: weights flipped and channel-transposed, then G g G^T
+        wt = weight.flip(2, 3).transpose(0, 1).contiguous()
+        conv2d_wino_launch(iv, pack_wino_weight(wt), None, None, ov, d)
+        return gx
     cin16 = (cin + 15) // 16 * 16
     wp = torch.empty(kh * kw * cout * cin16, dtype=torch.float32, device=g.device)
     hip.check(L.otp_conv2d_pack_weight_dgrad(hip.ptr(weight.contiguous()), hip.ptr(wp), cout, cin, kh, kw,
                                              hip.stream_of(g)), "otp_conv2d_pack_weight_dgrad")
-    gx = torch.empty(in_shape, dtype=torch.float32, device=g.device)
-    iv, ov = View(g), View(gx)
-    d = conv_desc(iv, ov, cin, kh, kw, 1, dil * (kh - 1) - pad, dil, ACT_NONE)
     conv2d_launch(iv, wp, None, None, ov, d)
     return gx
 
