@@ -48,6 +48,12 @@ class InferenceEngine:
             use_graph = os.environ.get("OTPOSE_HIP_GRAPH", "1") != "0"
         self.use_graph = use_graph
         self.use_winograd = os.environ.get("OTPOSE_WINOGRAD", "1") != "0"     # 3x3 stride-1 convs via csrc/wino.hip
+        # independent sub-graphs (the HRNet branches of a stage, the rows of its fuse layer, the two temporal encoders) are
+        # emitted on side HIP streams: inside the captured graph they become parallel branches, so the small-map launches
+        # (640-960 workgroups on 512 resident slots) fill each other's tails
+        self.multi_stream = os.environ.get("OTPOSE_STREAMS", "1") != "0"
+        self._sid = 0
+        self._side = [torch.cuda.Stream(device) for _ in range(3)] if self.multi_stream else []
         self.graph = None
         self.param_version = self._param_version()
         with torch.no_grad():
@@ -85,6 +91,37 @@ class InferenceEngine:
         return cin >= 32 and cin % 8 == 0 and cout16 >= 48 and ((cout16 + 47) // 48) * 48 <= 1.15 * cout16
 
     # ---- op emitters ----------------------------------------------------------------------------
+    def _emit(self, fn):
+        self.ops.append((fn, self._sid))
+
+    def fork(self, sids):
+        """Side streams ``sids`` (1-based) start after everything emitted so far on the main stream."""
+        if not self.multi_stream:
+            return
+        sids = [s for s in sids if 0 < s <= len(self._side)]
+
+        def run():
+            main = torch.cuda.current_stream(self.dev)
+            for s_ in sids:
+                self._side[s_ - 1].wait_stream(main)
+        self.ops.append((run, -1))
+
+    def join(self, sids):
+        """The main stream waits for everything emitted on side streams ``sids``."""
+        if not self.multi_stream:
+            return
+        sids = [s for s in sids if 0 < s <= len(self._side)]
+
+        def run():
+            main = torch.cuda.current_stream(self.dev)
+            for s_ in sids:
+                main.wait_stream(self._side[s_ - 1])
+        self.ops.append((run, -1))
+
+    def on_stream(self, sid):
+        """Ops emitted from now on go to side stream ``sid`` (0 = main; ids past the pool fall back to main)."""
+        self._sid = sid if (self.multi_stream and 0 <= sid <= len(self._side)) else 0
+
     def conv(self, inp: View, weight, out: View, stride=1, pad=0, dil=1, bn=None, bias=None, act=ACT_NONE,
              res: View = None, in2: View = None, res_up=1, frame_split=0, cin=None, scale=None, shift=None):
         """Emit act(scale*conv(inp (+in2)) + shift (+res)) with BN / bias folded into scale / shift."""
@@ -122,7 +159,7 @@ class InferenceEngine:
 
             def run_wino():
                 hip.check(L.otp_conv2d_wino(*wargs, self._stream), "otp_conv2d_wino")
-            self.ops.append(run_wino)
+            self._emit(run_wino)
             return out
         wp = ops.pack_conv_weight(w)
         self._keep.append(wp)
@@ -131,7 +168,7 @@ class InferenceEngine:
 
         def run():
             hip.check(L.otp_conv2d(*args, self._stream), "otp_conv2d")
-        self.ops.append(run)
+        self._emit(run)
         return out
 
     def conv_bn(self, inp: View, conv_mod, bn_mod, act=ACT_NONE, res=None, out=None, res_up=1, **kw):
@@ -150,7 +187,7 @@ class InferenceEngine:
     def call(self, fn, name, *args):
         def run():
             hip.check(fn(*args, self._stream), name)
-        self.ops.append(run)
+        self._emit(run)
 
     # ---- HRNet (reference model/HRNet.py:116-152) -------------------------------------------------
     def basic_block(self, blk, x: View) -> View:
@@ -171,13 +208,19 @@ class InferenceEngine:
     def hr_module(self, mod, xs: List[View]) -> List[View]:
         n = mod.num_branches
         xs = list(xs)
+        self.fork(range(1, n))
         for i in range(n):
+            self.on_stream(i)                                     # branch i is independent of the others until the fuse
             for blk in mod.branches[i]:
                 xs[i] = self.basic_block(blk, xs[i])
+        self.on_stream(0)
+        self.join(range(1, n))
         if n == 1:
             return xs
         outs = []
+        self.fork(range(1, len(mod.fuse_layers)))
         for i in range(len(mod.fuse_layers)):
+            self.on_stream(i)                                     # fuse row i reads every branch, writes only y_i
             # y_i = sum_j f_ij(x_j), then ReLU (HRNet.py:487-494).  The identity term rides on the first
             # emitted conv as its residual; later terms accumulate in place; the last one applies the ReLU.
             terms = [j for j in range(n) if j != i]
@@ -208,6 +251,8 @@ class InferenceEngine:
                     tgt = y if y is not None else View(self.new(*xs[i].t.shape))
                     y = self.conv_bn(t, fl[-1][0], fl[-1][1], act, res=res, out=tgt)
             outs.append(y)
+        self.on_stream(0)
+        self.join(range(1, len(mod.fuse_layers)))
         return outs
 
     def hrnet(self, net, x_in: View) -> View:
@@ -356,13 +401,19 @@ class InferenceEngine:
                   B, J, T)
         levels = m.scale_arch[-1] + 1
         s1, s2 = self.new(B, levels * D, T), self.new(B, levels * D, T)
+        # the two temporal encoders and the def_fuse RSB chain (which only needs `total`) are independent: three streams
+        self.fork((1, 2))
         self.conv_transformer(m.temporal_encoder1, x1, s1)
+        self.on_stream(1)
         self.conv_transformer(m.temporal_encoder2, x2, s2)
+        self.on_stream(2)
+        def_h = self.rsb_chain(m.def_fuse, View(total))
+        self.on_stream(0)
+        self.join((1, 2))
         # final 1x1 layers write straight into the channel-concatenated tensor (OTPose.py:372-378)
         cat3 = self.new(B, 3 * J, h, w)
         for i, (fl, s) in enumerate(((m.final_layer1, s1), (m.final_layer2, s2))):
             self.conv(View(s.view(B, levels * D, h, w)), fl.weight, View(cat3, i * J, J), 1, fl.padding[0], 1, bias=fl.bias)
-        def_h = self.rsb_chain(m.def_fuse, View(total))
         # def_heatmaps feeds the DCN as a dense (B, J, h, w) tensor and the concat as a channel slice: copy once
         self.copy_into(def_h, View(cat3, 2 * J, J))
         trans = self.rsb_chain(m.offset_mask_combine_conv, View(cat3))
@@ -389,9 +440,12 @@ class InferenceEngine:
 
     # ---------------------------------------------------------------------------------------------
     def _launch_all(self):
-        self._stream = hip.stream_of(self.inp)
-        for op in self.ops:
+        main = hip.stream_of(self.inp)
+        handles = [main] + [s_.cuda_stream for s_ in self._side]
+        for op, sid in self.ops:
+            self._stream = handles[sid] if sid > 0 else main
             op()
+        self._stream = main
 
     def run(self, x, margin):
         if not x.is_cuda:
