@@ -98,7 +98,11 @@ def kernel_rooflines(dev, batch):
         up = ops.pack_wino_weight(w)
         t_conv = event_time_ms(lambda: ops.conv2d_wino_launch(iv, up, sc, sh, ov, d), 20, st)
         tiles = n * 48 * 36
-        kname = ("conv_wino_kernel<3> 48->48 3x3 @96x72 x%d frames (grid %d x 256 threads)" % (n, n * 36))
+        import ctypes
+        wplan = (ctypes.c_int * 4)()
+        hip.lib().otp_conv2d_wino_last_plan(wplan)
+        kname = ("conv_wino_kernel<%d,%d,true> 48->48 3x3 @96x72 x%d frames (grid %d x 256 threads)"
+                 % (wplan[0], wplan[1], n, wplan[2]))
         executed = 2.0 * 48 * 48 * 16 * tiles
     else:
         t_conv = event_time_ms(lambda: ops.conv2d_launch(iv, wp, sc, sh, ov, d), 20, st)

@@ -96,6 +96,8 @@ int otp_conv2d(const void* in, const void* in2, const void* wpacked, const void*
 size_t otp_conv2d_wino_weight_bytes(int Cout, int Cin);
 int otp_conv2d_wino_pack_weight(const void* weight, void* upacked, int Cout, int Cin, void* stream);
 int otp_conv2d_wino_supported(const otp_conv_desc* desc);
+/* tuning hook: {16-tile blocks per workgroup, channels per chunk, grid (workgroups), LDS bytes} of the last otp_conv2d_wino */
+int otp_conv2d_wino_last_plan(int* out4);
 int otp_conv2d_wino(const void* in, const void* upacked, const void* scale, const void* shift, const void* res, void* out,
                     const otp_conv_desc* desc, void* stream);
 

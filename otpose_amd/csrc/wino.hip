@@ -416,7 +416,15 @@ int wino_launch(const float* in, const float* up, const float* scale, const floa
     return otp_launch_status();
 }
 
+int g_wino_last[4] = {0, 0, 0, 0};      // tuning hook: {tile blocks per workgroup, chunk channels, grid, lds bytes} of the last launch
+
 }  // namespace
+
+extern "C" int otp_conv2d_wino_last_plan(int* out4) {
+    if (!out4) return OTP_ERR_BAD_ARG;
+    for (int i = 0; i < 4; ++i) out4[i] = g_wino_last[i];
+    return OTP_OK;
+}
 
 extern "C" size_t otp_conv2d_wino_weight_bytes(int Cout, int Cin) {
     if (Cout <= 0 || Cin <= 0) return 0;
@@ -453,6 +461,8 @@ extern "C" int otp_conv2d_wino(const void* in, const void* upacked, const void* 
     const int variant = wino_choose(d, P, lds);
     if (variant < 0) return OTP_ERR_UNSUPPORTED;
     auto st = static_cast<hipStream_t>(stream);
+    g_wino_last[0] = variant == 1 ? 2 : 3; g_wino_last[1] = variant == 1 ? 16 : 8;
+    g_wino_last[2] = ((P.N * P.bpi + 7) / 8) * 8 * P.nM; g_wino_last[3] = (int)lds;
     auto f = [](const void* p) { return static_cast<const float*>(p); };
     return variant == 1 ? wino_launch<2, 16>(f(in), f(upacked), f(scale), f(shift), f(res), static_cast<float*>(out), P, lds, st)
                         : wino_launch<3, 8>(f(in), f(upacked), f(scale), f(shift), f(res), static_cast<float*>(out), P, lds, st);
