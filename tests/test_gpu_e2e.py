@@ -84,3 +84,29 @@ def test_forward_frames_u8_equals_forward_of_normalised_clip():
         b = model(O.frames_to_clip(frames).cuda(), margin=margin.cuda())
     for u, v in zip(a, b):
         assert torch.equal(u, v)
+
+
+def test_parallel_stream_graph_equals_single_stream(monkeypatch):
+    """The engine's parallel graph branches (HRNet branches / fuse rows / temporal encoders on side streams) and the
+    Winograd routing change scheduling and kernels only: single-stream replay is bit-identical, the direct-kernel engine
+    agrees to fp32 rounding."""
+    cfg = tiny_cfg(8, (64, 96))
+    x, margin = S.synthetic_clip(2, cfg.MODEL.IMAGE_SIZE)
+    outs = {}
+    for key, env in (("default", {}), ("single", {"OTPOSE_STREAMS": "0"}), ("direct", {"OTPOSE_WINOGRAD": "0"})):
+        for k in ("OTPOSE_STREAMS", "OTPOSE_WINOGRAD"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m = OTPose(cfg)
+        S.fill_synthetic_(m)
+        m = m.cuda().eval()
+        with torch.no_grad():
+            outs[key] = [o.clone() for o in m(x.cuda(), margin=margin.cuda())]
+            again = [o.clone() for o in m(x.cuda(), margin=margin.cuda())]          # graph replay
+        for a, b in zip(outs[key], again):
+            assert torch.equal(a, b)
+    for a, b in zip(outs["default"], outs["single"]):
+        assert torch.equal(a, b)
+    for a, b in zip(outs["default"], outs["direct"]):
+        assert float((a - b).abs().max()) <= 1e-4 * max(1.0, float(b.abs().max()))
