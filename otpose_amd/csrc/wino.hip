@@ -39,7 +39,8 @@ struct WinoPlan {
     int TX, tpi, bpi, nM;          // tile columns, tiles per image, tile blocks per image, 48-channel tiles
     int L4, WS, JR;                // window float4 per channel, LDS channel stride, 64-float4 pieces per window
     int w_even;                    // W % 2 == 0: a tile's two columns are an aligned float2
-    uint32_t magicTX, magicBpi;
+    int TXB;                       // 2-D tile blocks: blocks per tile row
+    uint32_t magicTX, magicBpi, magicTXB;
 };
 
 // (Cout, Cin, 3, 3) -> U[16][Cin][Cout16] = G g G^T, G = [[1,0,0],[1/2,1/2,1/2],[1/2,-1/2,1/2],[0,0,1]]
@@ -75,7 +76,10 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict_
 // TB x WCK: 3 x 8 (48 tiles, 8-channel chunks) is the general shape; 2 x 16 (32 tiles, 16-channel chunks: the same 144
 // accumulator + 24/48 fragment registers, two patches per thread and chunk either way) fills the tile blocks of the small
 // maps better (12x9: 30 tiles per image, 24x18: 108).
-template <int TB, int WCK, bool WEVEN>
+// BC > 0: the NT tiles of a workgroup form a (NT / BC) x BC rectangle of the tile grid instead of a row-major run, and the
+// staged window is that rectangle's (2 BR + 2) x (2 BC + 2) pixel patch with true zeros outside the image (needs W % 4 == 0):
+// on wide maps (96x72: 36 tiles per row) a run of 32 tiles drags 6 full image rows through LDS, 3.4x the input it uses.
+template <int TB, int WCK, bool WEVEN, int BC>
 __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const float* __restrict__ in, const float* __restrict__ up,
                                                              const float* __restrict__ scale,
                                                              const float* __restrict__ shift, const float* res, float* out,
@@ -84,6 +88,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const float* __restri
     constexpr int VS = (NT % 32 == 16) ? NT : NT + 16;            // == 16 (mod 32)
     constexpr int SLOTS = (WCK * NT + 255) / 256;                 // (tile, channel) patches per thread and chunk
     constexpr int PST = NT + 2;                                   // epilogue row pitch
+    constexpr bool TWOD = BC > 0;
+    constexpr int BCc = TWOD ? BC : 1, BR = NT / BCc;             // tile rectangle
+    constexpr int NR = 2 * BR + 2, GW = (2 * BCc + 2 + 3 + 3) / 4, WC = 4 * GW;   // window rows, float4 per row, row pitch
+    constexpr int NI2 = (WCK * NR * GW + 255) / 256;             // float4 window items per thread (2-D)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* raw = smem;                                            // [WCK][WS]
     float* V = smem + WCK * P.WS;                                 // [16][WCK][VS]
@@ -99,16 +107,45 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const float* __restri
     const int bp = grp * 8 + (rem & 7), m0 = (rem >> 3) * WMS;
     if (bp >= P.N * P.bpi) return;                                // uniform per workgroup (padding of the last group of 8)
     const int n = (int)wdiv((uint32_t)bp, P.magicBpi);
-    const int t0 = (bp - n * P.bpi) * NT;
-    const int nt = min(NT, P.tpi - t0);
-    const int ty0 = (int)wdiv((uint32_t)t0, P.magicTX);
+    const int bi = bp - n * P.bpi;
+    // row-major run: tiles t0 .. t0 + nt - 1;  rectangle: tile rows ty0 .. ty0 + BR - 1, tile columns tx0 .. tx0 + BC - 1
+    const int t0 = TWOD ? 0 : bi * NT;
+    const int nt = TWOD ? NT : min(NT, P.tpi - t0);
+    const int by = TWOD ? (int)wdiv((uint32_t)bi, P.magicTXB) : 0;
+    const int ty0 = TWOD ? by * BR : (int)wdiv((uint32_t)t0, P.magicTX);
+    const int tx0 = TWOD ? (bi - by * P.TXB) * BCc : 0;
     const int f0 = (2 * ty0 - 1) * P.W;                           // first flattened input position the block touches (< 0 at the top)
     const int f0a = f0 & ~3;
+    const int x0c = 2 * tx0 - 1, xa = x0c & ~3;                   // 2-D: first window column and its 16-byte aligned start
+    // tile j of the block -> (tile row, tile column, exists)
+    auto tile_of = [&](int j, int& ty, int& tx) __attribute__((always_inline)) {
+        if (TWOD) {
+            const int jr = j / BCc, jc = j - jr * BCc;
+            ty = ty0 + jr; tx = tx0 + jc;
+            return ty * 2 < P.H && tx * 2 < P.W;
+        }
+        const int t = t0 + (j < nt ? j : 0);
+        ty = (int)wdiv((uint32_t)t, P.magicTX); tx = t - ty * P.TX;
+        return j < nt;
+    };
     const float* img = in + ((size_t)n * P.in_ctot + P.in_coff) * P.HW;
 
     // ---- staging ---------------------------------------------------------------------------------------------------------
-    constexpr int NJI = WCK == 8 ? 6 : 8;
+    constexpr int NJI = TWOD ? NI2 : (WCK == 8 ? 6 : 8);
     f32x4 pfi[NJI];
+    int goff[TWOD ? NI2 : 1], ldst[TWOD ? NI2 : 1];               // 2-D: byte offset inside the chunk's channels / LDS word
+    if (TWOD) {
+#pragma unroll
+        for (int j = 0; j < NI2; ++j) {
+            const int i = tid + 256 * j;
+            const int c = i / (NR * GW), rem = i - c * (NR * GW);
+            const int r = rem / GW, g = rem - r * GW;
+            const int y = 2 * ty0 - 1 + r, xg = xa + 4 * g;
+            const bool live = i < WCK * NR * GW;
+            goff[j] = (live && y >= 0 && y < P.H && xg >= 0 && xg < P.W) ? ((c * P.H + y) * P.W + xg) * 4 : -1;
+            ldst[j] = live ? (c * NR + r) * WC + 4 * g : -1;
+        }
+    }
     // Weight fragments: wave w multiplies only its own four coordinates, so its A operands never pass through LDS - lane
     // (i16, kl) loads U[4w + nu][c0 + 4k + kl][m0 + 16 mb + i16] straight into the register the MFMA reads (24 dwords per
     // chunk, L2-resident; rows past Cin alias finite values that meet zero inputs, or fall off the tensor -> 0).
@@ -128,28 +165,41 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const float* __restri
             }
     };
     const int vbase = (f0a + 4 * lane) * 4;
+    const otp_rsrc rimg = make_rsrc32(img, (unsigned)P.Cin * (unsigned)P.HW * 4u);   // 2-D: channels past Cin fall off the end -> 0
     auto load_chunk = [&](int c0) __attribute__((always_inline)) {
-        int jc = 0, jr = 0;
+        if (TWOD) {
+            const int cb = c0 * P.HW * 4;
 #pragma unroll
-        for (int j = 0; j < NJI; ++j) {
-            if (j < (WCK / 4) * P.JR) {
-                const int c = wave * (WCK / 4) + jc, ch = c0 + c;  // wave w stages WCK / 4 channels of the chunk
-                const bool live = ch < P.Cin;
-                const otp_rsrc r = make_rsrc32(img + (size_t)(live ? ch : 0) * P.HW, live ? (unsigned)P.HW * 4u : 0u);
-                pfi[j] = bload4(r, vbase + jr * 1024);
-                if (++jr == P.JR) { jr = 0; ++jc; }
+            for (int j = 0; j < NI2; ++j) pfi[j] = bload4(rimg, goff[j] >= 0 ? goff[j] + cb : -1);
+        } else {
+            int jc = 0, jr = 0;
+#pragma unroll
+            for (int j = 0; j < NJI; ++j) {
+                if (j < (WCK / 4) * P.JR) {
+                    const int c = wave * (WCK / 4) + jc, ch = c0 + c;  // wave w stages WCK / 4 channels of the chunk
+                    const bool live = ch < P.Cin;
+                    const otp_rsrc r = make_rsrc32(img + (size_t)(live ? ch : 0) * P.HW, live ? (unsigned)P.HW * 4u : 0u);
+                    pfi[j] = bload4(r, vbase + jr * 1024);
+                    if (++jr == P.JR) { jr = 0; ++jc; }
+                }
             }
         }
         asm volatile("" ::: "memory");
     };
     auto store_window = [&]() __attribute__((always_inline)) {
-        int jc = 0, jr = 0;
+        if (TWOD) {
 #pragma unroll
-        for (int j = 0; j < NJI; ++j) {
-            if (j < (WCK / 4) * P.JR) {
-                const int c = wave * (WCK / 4) + jc, r4 = lane + 64 * jr;
-                if (r4 < P.L4) *reinterpret_cast<f32x4*>(raw + c * P.WS + WG_ + 4 * r4) = pfi[j];
-                if (++jr == P.JR) { jr = 0; ++jc; }
+            for (int j = 0; j < NI2; ++j)
+                if (ldst[j] >= 0) *reinterpret_cast<f32x4*>(raw + ldst[j]) = pfi[j];
+        } else {
+            int jc = 0, jr = 0;
+#pragma unroll
+            for (int j = 0; j < NJI; ++j) {
+                if (j < (WCK / 4) * P.JR) {
+                    const int c = wave * (WCK / 4) + jc, r4 = lane + 64 * jr;
+                    if (r4 < P.L4) *reinterpret_cast<f32x4*>(raw + c * P.WS + WG_ + 4 * r4) = pfi[j];
+                    if (++jr == P.JR) { jr = 0; ++jc; }
+                }
             }
         }
     };
@@ -165,15 +215,23 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const float* __restri
         const int i = tid + 256 * s;
         const int c = i / NT, j = i - c * NT;
         const bool live = i < WCK * NT;
-        const int t = t0 + (j < nt ? j : 0);
-        const int ty = (int)wdiv((uint32_t)t, P.magicTX), tx = t - ty * P.TX;
+        int ty, tx;
+        const bool ok = tile_of(j, ty, tx);
         const int x0 = 2 * tx - 1;
-        toff[s] = (live ? c : 0) * P.WS + WG_ + (f0 - f0a) + 2 * (ty - ty0) * P.W + x0;
+        if (TWOD) {
+            // window rows / columns outside the image hold zeros (range-checked loads), so no column masks: a tile that does
+            // not exist reads zeros only and contributes V = 0
+            const int jr = j / BCc, jc = j - jr * BCc;
+            toff[s] = ((live ? c : 0) * NR + 2 * jr) * WC + 2 * jc + (x0c - xa);
+        } else {
+            toff[s] = (live ? c : 0) * P.WS + WG_ + (f0 - f0a) + 2 * (ty - ty0) * P.W + x0;
+        }
         vdst[s] = live ? c * VS + j : -1;
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) cm[jj][s] = (live && j < nt && x0 + jj >= 0 && x0 + jj < P.W) ? 1.f : 0.f;
+        for (int jj = 0; jj < 4; ++jj) cm[jj][s] = (live && ok && x0 + jj >= 0 && x0 + jj < P.W) ? 1.f : 0.f;
     }
-    for (int c = tid; c < WCK * WG_; c += 256) raw[(c / WG_) * P.WS + (c % WG_)] = 0.f;       // guard floats
+    if (!TWOD)
+        for (int c = tid; c < WCK * WG_; c += 256) raw[(c / WG_) * P.WS + (c % WG_)] = 0.f;   // guard floats
 
     f32x4 acc[4][WMB][TB];
 #pragma unroll
@@ -193,6 +251,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const float* __restri
         const bool more = c0 + WCK < P.Cin;
         // ---- input transform: V = B^T d B, B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]] -------------------------
         {
+            const int RS_ = TWOD ? WC : P.W;                       // row pitch of the staged window
             const float* s0 = raw + toff[0];
             const float* s1 = raw + toff[1];
             f32x2 t[4][4];
@@ -203,10 +262,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const float* __restri
                     f32x2 e[4][2];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const f32x2 m0 = *reinterpret_cast<const f32x2*>(s0 + i * P.W + 1);
-                        const f32x2 m1 = *reinterpret_cast<const f32x2*>(s1 + i * P.W + 1);
-                        e[i][0] = (f32x2){m0[0], m1[0]} * cm[1];
-                        e[i][1] = (f32x2){m0[1], m1[1]} * cm[2];
+                        const f32x2 m0 = *reinterpret_cast<const f32x2*>(s0 + i * RS_ + 1);
+                        const f32x2 m1 = *reinterpret_cast<const f32x2*>(s1 + i * RS_ + 1);
+                        e[i][0] = (f32x2){m0[0], m1[0]} * (TWOD ? (f32x2){1.f, 1.f} : cm[1]);
+                        e[i][1] = (f32x2){m0[1], m1[1]} * (TWOD ? (f32x2){1.f, 1.f} : cm[2]);
                     }
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
@@ -218,10 +277,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const float* __restri
                 }
 #pragma unroll
                 for (int jj = 0; jj < 4; jj += 3) {               // columns 0 and 3
-                    const f32x2 d0 = (f32x2){s0[jj], s1[jj]} * cm[jj];
-                    const f32x2 d1 = (f32x2){s0[P.W + jj], s1[P.W + jj]} * cm[jj];
-                    const f32x2 d2 = (f32x2){s0[2 * P.W + jj], s1[2 * P.W + jj]} * cm[jj];
-                    const f32x2 d3 = (f32x2){s0[3 * P.W + jj], s1[3 * P.W + jj]} * cm[jj];
+                    const f32x2 d0 = (f32x2){s0[jj], s1[jj]} * (TWOD ? (f32x2){1.f, 1.f} : cm[jj]);
+                    const f32x2 d1 = (f32x2){s0[RS_ + jj], s1[RS_ + jj]} * (TWOD ? (f32x2){1.f, 1.f} : cm[jj]);
+                    const f32x2 d2 = (f32x2){s0[2 * RS_ + jj], s1[2 * RS_ + jj]} * (TWOD ? (f32x2){1.f, 1.f} : cm[jj]);
+                    const f32x2 d3 = (f32x2){s0[3 * RS_ + jj], s1[3 * RS_ + jj]} * (TWOD ? (f32x2){1.f, 1.f} : cm[jj]);
                     t[0][jj] = d0 - d2;
                     t[1][jj] = d1 + d2;
                     t[2][jj] = d2 - d1;
@@ -230,10 +289,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const float* __restri
             } else {
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {                   // one patch column at a time: 4 loads -> 4 results
-                    const f32x2 d0 = (f32x2){s0[jj], s1[jj]} * cm[jj];
-                    const f32x2 d1 = (f32x2){s0[P.W + jj], s1[P.W + jj]} * cm[jj];
-                    const f32x2 d2 = (f32x2){s0[2 * P.W + jj], s1[2 * P.W + jj]} * cm[jj];
-                    const f32x2 d3 = (f32x2){s0[3 * P.W + jj], s1[3 * P.W + jj]} * cm[jj];
+                    const f32x2 d0 = (f32x2){s0[jj], s1[jj]} * (TWOD ? (f32x2){1.f, 1.f} : cm[jj]);
+                    const f32x2 d1 = (f32x2){s0[RS_ + jj], s1[RS_ + jj]} * (TWOD ? (f32x2){1.f, 1.f} : cm[jj]);
+                    const f32x2 d2 = (f32x2){s0[2 * RS_ + jj], s1[2 * RS_ + jj]} * (TWOD ? (f32x2){1.f, 1.f} : cm[jj]);
+                    const f32x2 d3 = (f32x2){s0[3 * RS_ + jj], s1[3 * RS_ + jj]} * (TWOD ? (f32x2){1.f, 1.f} : cm[jj]);
                     t[0][jj] = d0 - d2;
                     t[1][jj] = d1 + d2;
                     t[2][jj] = d2 - d1;
@@ -288,9 +347,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const float* __restri
     bool etwo[TB], ebot[TB];
 #pragma unroll
     for (int tb = 0; tb < TB; ++tb) {
-        const int j = tb * 16 + el, t = t0 + j;
-        const int ty = (int)wdiv((uint32_t)t, P.magicTX), tx = t - ty * P.TX;
-        eoff[tb] = j < nt ? 2 * ty * P.W + 2 * tx : -1;
+        const int j = tb * 16 + el;
+        int ty, tx;
+        const bool ok = tile_of(j, ty, tx);
+        eoff[tb] = ok ? 2 * ty * P.W + 2 * tx : -1;
         etwo[tb] = 2 * tx + 1 < P.W;
         ebot[tb] = 2 * ty + 1 < P.H;
     }
@@ -368,7 +428,6 @@ bool wino_plan(const otp_conv_desc& d, WinoPlan& P, size_t& lds, int NT, int WCK
     const int rows_in = 2 * span + 2;
     P.L4 = (rows_in * d.W + 3 + 3) / 4 + 1;
     P.JR = (P.L4 + 63) / 64;
-    if ((WCK / 4) * P.JR > (WCK == 8 ? 6 : 8)) return false;
     P.WS = WG_ + 4 * P.L4 + 4;
     if ((P.WS & 31) == 0) P.WS += 4;
     P.w_even = (d.W & 1) == 0 ? 1 : 0;
@@ -379,6 +438,28 @@ bool wino_plan(const otp_conv_desc& d, WinoPlan& P, size_t& lds, int NT, int WCK
     const size_t ep = (size_t)4 * 2 * 16 * (NT + 2) * sizeof(float);      // epilogue tiles alias the window + V
     if (ep > lds) lds = ep;
     if ((long)16 * d.Cin * P.Cout16 * 4 >= (1l << 31) || (long)P.HW * 4 >= (1l << 30)) return false;
+    if ((WCK / 4) * P.JR > (WCK == 8 ? 6 : 8)) return false;      // window too long for the staging registers
+    return lds <= 80 * 1024;
+}
+
+// 2-D tile blocks (BR x BC tiles per workgroup): only the block geometry and the LDS window differ from wino_plan
+bool wino_plan2d(const otp_conv_desc& d, WinoPlan& P, size_t& lds, int NT, int WCK, int BC) {
+    size_t dummy = 0;
+    (void)wino_plan(d, P, dummy, NT, WCK);                         // fills the shape-independent fields (may itself not fit)
+    if (d.kh != 3 || d.kw != 3 || d.stride != 1 || d.pad != 1 || d.dil != 1 || d.res_up > 1 || d.frame_split > 0) return false;
+    if (d.Ho != d.H || d.Wo != d.W || (d.W & 3)) return false;
+    const int BR = NT / BC, TY = (d.H + 1) / 2;
+    P.TXB = (P.TX + BC - 1) / BC;
+    P.bpi = P.TXB * ((TY + BR - 1) / BR);
+    const int NR = 2 * BR + 2, GW = (2 * BC + 2 + 3 + 3) / 4;
+    P.WS = NR * 4 * GW;
+    P.magicTXB = wmagic(P.TXB);
+    P.magicBpi = wmagic(P.bpi);
+    const int VS = (NT % 32 == 16) ? NT : NT + 16;
+    lds = ((size_t)WCK * P.WS + (size_t)16 * WCK * VS) * sizeof(float);
+    const size_t ep = (size_t)4 * 2 * 16 * (NT + 2) * sizeof(float);
+    if (ep > lds) lds = ep;
+    if ((long)d.Cin * P.HW * 4 >= (1l << 31)) return false;
     return lds <= 80 * 1024;
 }
 
@@ -400,16 +481,16 @@ int wino_choose(const otp_conv_desc& d, WinoPlan& P, size_t& lds) {
     return 0;
 }
 
-template <int TB, int WCK>
+template <int TB, int WCK, int BC>
 int wino_launch(const float* in, const float* up, const float* scale, const float* shift, const float* res, float* out,
                 const WinoPlan& P, size_t lds, hipStream_t st) {
     const dim3 grid(((P.N * P.bpi + 7) / 8) * 8 * P.nM);
     if (P.w_even) {
-        auto kern = conv_wino_kernel<TB, WCK, true>;
+        auto kern = conv_wino_kernel<TB, WCK, true, BC>;
         OTP_ALLOW_BIG_LDS(kern, lds);
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, in, up, scale, shift, res, out, P);
     } else {
-        auto kern = conv_wino_kernel<TB, WCK, false>;
+        auto kern = conv_wino_kernel<TB, WCK, false, BC>;
         OTP_ALLOW_BIG_LDS(kern, lds);
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, in, up, scale, shift, res, out, P);
     }
@@ -464,6 +545,19 @@ extern "C" int otp_conv2d_wino(const void* in, const void* upacked, const void* 
     g_wino_last[0] = variant == 1 ? 2 : 3; g_wino_last[1] = variant == 1 ? 16 : 8;
     g_wino_last[2] = ((P.N * P.bpi + 7) / 8) * 8 * P.nM; g_wino_last[3] = (int)lds;
     auto f = [](const void* p) { return static_cast<const float*>(p); };
-    return variant == 1 ? wino_launch<2, 16>(f(in), f(upacked), f(scale), f(shift), f(res), static_cast<float*>(out), P, lds, st)
-                        : wino_launch<3, 8>(f(in), f(upacked), f(scale), f(shift), f(res), static_cast<float*>(out), P, lds, st);
+    {
+        // wide maps whose tile grid splits into full 4 x 12 rectangles (96x72: 48 x 36 tiles): 2-D tile blocks, 8-channel chunks.
+        // Measured against the row-major shapes: 48->48 0.196 -> 0.180 ms, 256->48 0.766 -> 0.692, 64->64 0.460 -> 0.413;
+        // 96->96 @48x36 (18 tile columns) 0.164 -> 0.192, so narrower maps keep the row-major run.
+        WinoPlan Q{};
+        size_t l2 = 0;
+        const char* e2 = getenv("OTP_WINO_2D");
+        const bool allow2d = !e2 || e2[0] != '0';
+        if (allow2d && d.W >= 64 && ((d.W + 1) / 2) % 12 == 0 && ((d.H + 1) / 2) % 4 == 0 && wino_plan2d(d, Q, l2, 48, 8, 12)) {
+            g_wino_last[0] = 3; g_wino_last[1] = 8; g_wino_last[2] = ((Q.N * Q.bpi + 7) / 8) * 8 * Q.nM; g_wino_last[3] = (int)l2;
+            return wino_launch<3, 8, 12>(f(in), f(upacked), f(scale), f(shift), f(res), static_cast<float*>(out), Q, l2, st);
+        }
+    }
+    return variant == 1 ? wino_launch<2, 16, 0>(f(in), f(upacked), f(scale), f(shift), f(res), static_cast<float*>(out), P, lds, st)
+                        : wino_launch<3, 8, 0>(f(in), f(upacked), f(scale), f(shift), f(res), static_cast<float*>(out), P, lds, st);
 }
