@@ -553,6 +553,13 @@ extern "C" int otp_conv2d_wino(const void* in, const void* upacked, const void* 
         size_t l2 = 0;
         const char* e2 = getenv("OTP_WINO_2D");
         const bool allow2d = !e2 || e2[0] != '0';
+        if (allow2d && !(d.W >= 64 && ((d.W + 1) / 2) % 12 == 0 && ((d.H + 1) / 2) % 4 == 0) && ((d.W + 1) / 2) % 6 == 0 &&
+            ((d.H + 1) / 2) % 8 == 0 && wino_plan2d(d, Q, l2, 48, 8, 6)) {
+            // 8 x 6 rectangles (48x36 maps: 24 x 18 tiles): same window volume as the row-major run but no edge masks and
+            // 22 fewer registers (no spills): 96->96 0.164 -> 0.150 ms
+            g_wino_last[0] = 3; g_wino_last[1] = 8; g_wino_last[2] = ((Q.N * Q.bpi + 7) / 8) * 8 * Q.nM; g_wino_last[3] = (int)l2;
+            return wino_launch<3, 8, 6>(f(in), f(upacked), f(scale), f(shift), f(res), static_cast<float*>(out), Q, l2, st);
+        }
         if (allow2d && d.W >= 64 && ((d.W + 1) / 2) % 12 == 0 && ((d.H + 1) / 2) % 4 == 0 && wino_plan2d(d, Q, l2, 48, 8, 12)) {
             g_wino_last[0] = 3; g_wino_last[1] = 8; g_wino_last[2] = ((Q.N * Q.bpi + 7) / 8) * 8 * Q.nM; g_wino_last[3] = (int)l2;
             return wino_launch<3, 8, 12>(f(in), f(upacked), f(scale), f(shift), f(res), static_cast<float*>(out), Q, l2, st);
