@@ -391,6 +391,11 @@ class InferenceEngine:
         self.call(L.otp_glue_total, "otp_glue_total", hip.ptr(rough), hip.ptr(total), hip.ptr(squeezed), hip.ptr(inter),
                   hip.ptr(flow_in), hip.ptr(pe_f), B, J, T)
         ctx = self.new(B, J, T)
+        # def_fuse only needs `total`: it runs on a side stream next to the flow encoder and the temporal encoders
+        self.fork((2,))
+        self.on_stream(2)
+        def_h = self.rsb_chain(m.def_fuse, View(total))
+        self.on_stream(0)
         self.conv_transformer(m.flow_encoder, flow_in, ctx)
         D = 8 * J
         x1, x2, prev_b = self.new(B, D, T), self.new(B, D, T), self.new(B, J, h, w)
@@ -401,13 +406,11 @@ class InferenceEngine:
                   B, J, T)
         levels = m.scale_arch[-1] + 1
         s1, s2 = self.new(B, levels * D, T), self.new(B, levels * D, T)
-        # the two temporal encoders and the def_fuse RSB chain (which only needs `total`) are independent: three streams
-        self.fork((1, 2))
+        # the two temporal encoders are independent: two streams
+        self.fork((1,))
         self.conv_transformer(m.temporal_encoder1, x1, s1)
         self.on_stream(1)
         self.conv_transformer(m.temporal_encoder2, x2, s2)
-        self.on_stream(2)
-        def_h = self.rsb_chain(m.def_fuse, View(total))
         self.on_stream(0)
         self.join((1, 2))
         # final 1x1 layers write straight into the channel-concatenated tensor (OTPose.py:372-378)
