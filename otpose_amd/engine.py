@@ -88,6 +88,8 @@ class InferenceEngine:
         """Shapes on which the Winograd kernel measured faster than the direct one (tools/conv_bench.py --wino): whole
         8-channel chunks and output-channel counts that fill its 48-row tiles (64 -> 64 would compute 96 rows)."""
         cout16 = (cout + 15) // 16 * 16
+        if cin == 64 and cout16 == 64:
+            return True                                   # layer1 Bottleneck conv2: 0.463 -> 0.408 ms despite the ragged 2nd tile
         return cin >= 32 and cin % 8 == 0 and cout16 >= 48 and ((cout16 + 47) // 48) * 48 <= 1.15 * cout16
 
     # ---- op emitters ----------------------------------------------------------------------------
