@@ -217,7 +217,10 @@ def test_loss_matches_golden_and_oracle(golden):
     (2, 20, 12, 9, 100),       # odd width (last tile column half empty), ragged Cin chunk and ragged last M tile
     (1, 8, 6, 6, 16),          # one partly filled tile block
     (3, 96, 10, 14, 96),       # odd tile-row count inside blocks, two M tiles
-    (1, 13, 96, 72, 17),       # the full heat-map size: blocks spanning three tile rows
+    (1, 13, 96, 72, 17),       # the full heat-map size: 4 x 12 tile rectangles (2-D blocks), ragged Cin / Cout
+    (2, 40, 16, 12, 48),       # 8 x 6 tile rectangles (the 48x36 branch shape family)
+    (1, 16, 8, 96, 32),        # 4 x 12 rectangles on a wide, short map; Cout below one 48-row tile
+    (2, 24, 6, 8, 20),         # 3 x 4 tiles: smaller than any rectangle -> row-major 32-tile run
 ])
 def test_conv2d_winograd_matches_conv2d(case):
     """Winograd F(2x2,3x3) kernel vs F.conv2d (3x3, stride 1, pad 1) with the fused epilogue and channel-sliced views."""
