@@ -65,6 +65,7 @@ struct WgradPlan {
     int sparse;               // dilated kernels: stage only the KS rows a tap row touches per output row (r = ti*RT + yl)
     int tiles_x, tiles_per_img, ntiles;
     int vec, GX, GD;          // 16-byte staging path; float4 groups per staged input row / per dY row
+    int pipe, NPD, NPX;       // software-pipelined staging (full-width tiles): float4 items per thread for dY / x
     unsigned magicRT, magicNRX, magicWT, magicLWP, magicGX, magicGD;   // ceil(2^32 / d): exact quotients of the small (< 2^16) staging indices
 };
 
@@ -143,6 +144,105 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restr
         dys[c * P.PS + P.RT * P.WT + q] = 0.f;
     }
 
+    if (P.pipe) {
+        // ---- software-pipelined tile loop (16-byte staging, full-width tiles): the loads of tile t+1 are in flight in
+        // registers while tile t is multiplied; a thread's items are the same for every tile up to the tile's row offset,
+        // so each is one packed (channel, row, group) word decoded at issue and at store time --------------------------------
+        constexpr int MPD = 6, MPX = 12;
+        otp_f32x4 pd[MPD], px[MPX];
+        int kd[MPD], kx[MPX];                                          // (c << 16) | (row << 8) | group, -1: no item
+        const int totd = WG_CO * P.RT * P.GD, totx = WG_CI * P.NRX * P.GX;
+#pragma unroll
+        for (int u = 0; u < MPD; ++u) {
+            const int i = tid + 256 * u;
+            const int cr = magic_div(i, P.magicGD, P.GD), g = i - cr * P.GD;
+            const int c = magic_div(cr, P.magicRT, P.RT), yl = cr - c * P.RT;
+            kd[u] = (u < P.NPD && i < totd) ? (c << 16) | (yl << 8) | g : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < MPX; ++u) {
+            const int i = tid + 256 * u;
+            const int cr = magic_div(i, P.magicGX, P.GX), g = i - cr * P.GX;
+            const int c = magic_div(cr, P.magicNRX, P.NRX), r = cr - c * P.NRX;
+            kx[u] = (u < P.NPX && i < totx) ? (c << 16) | (r << 8) | g : -1;
+        }
+        const int xg0 = (0 - P.pad) & ~3;                              // x0 == 0: aligned first image column of group 0
+        const int colb = xg0 + P.pad;                                  // staged column of element 0 of group 0 (-3 .. 0)
+        auto issue_dy = [&](int tile) __attribute__((always_inline)) {
+            const int n = tile / P.tiles_per_img;
+            const int y0 = (tile - n * P.tiles_per_img) * P.RT;
+            const int rows = min(P.RT, P.Ho - y0);
+            const otp_rsrc rdy = make_rsrc32(dy + ((size_t)n * P.dy_ctot + P.dy_coff) * P.Ho * P.Wo,
+                                             (unsigned)P.Cout * (unsigned)(P.Ho * P.Wo) * 4u);
+#pragma unroll
+            for (int u = 0; u < MPD; ++u) {
+                const int c = kd[u] >> 16, yl = (kd[u] >> 8) & 255, g = kd[u] & 255;
+                const bool ok = kd[u] >= 0 && co0 + c < P.Cout && yl < rows;
+                pd[u] = bload4(rdy, ok ? (((co0 + c) * P.Ho + y0 + yl) * P.Wo + 4 * g) * 4 : -1);
+            }
+        };
+        auto issue = [&](int tile) __attribute__((always_inline)) {
+            const int n = tile / P.tiles_per_img;
+            const int y0 = (tile - n * P.tiles_per_img) * P.RT;
+            const int r0 = y0 - P.pad;
+            const otp_rsrc rx = make_rsrc32(x + ((size_t)n * P.x_ctot + P.x_coff) * P.H * P.W,
+                                            (unsigned)P.Cin * (unsigned)(P.H * P.W) * 4u);
+#pragma unroll
+            for (int u = 0; u < MPX; ++u) {
+                const int c = kx[u] >> 16, r = (kx[u] >> 8) & 255, g = kx[u] & 255;
+                const int yy = r0 + r, xg = xg0 + 4 * g;
+                const bool ok = kx[u] >= 0 && ci0 + c < P.Cin && yy >= 0 && yy < P.H && xg >= 0 && xg < P.W;
+                px[u] = bload4(rx, ok ? (((ci0 + c) * P.H + yy) * P.W + xg) * 4 : -1);
+            }
+            asm volatile("" ::: "memory");
+        };
+        auto store = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int u = 0; u < MPD; ++u)
+                if (kd[u] >= 0) {
+                    float* d = dys + (kd[u] >> 16) * P.PS + ((kd[u] >> 8) & 255) * P.WT + 4 * (kd[u] & 255);
+                    *reinterpret_cast<float2*>(d) = make_float2(pd[u][0], pd[u][1]);
+                    *reinterpret_cast<float2*>(d + 2) = make_float2(pd[u][2], pd[u][3]);
+                }
+#pragma unroll
+            for (int u = 0; u < MPX; ++u)
+                if (kx[u] >= 0) {
+                    const int col = colb + 4 * (kx[u] & 255);
+                    float* d = xs + (kx[u] >> 16) * P.CSX + ((kx[u] >> 8) & 255) * P.LWP + col;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (col + e >= 0 && col + e < P.LWP) d[e] = px[u][e];
+                }
+        };
+        int tile = blockIdx.x;
+        if (tile < P.ntiles) issue(tile);
+        for (; tile < P.ntiles; tile += gridDim.x) {
+            const int y0 = (tile - (tile / P.tiles_per_img) * P.tiles_per_img) * P.RT;
+            const int rows = min(P.RT, P.Ho - y0);
+            // keep the packed item words opaque per iteration: otherwise their decoded addresses are hoisted out of the tile loop
+            // into ~50 more registers (spills)
+#pragma unroll
+            for (int u = 0; u < MPD; ++u) asm volatile("" : "+v"(kd[u]));
+#pragma unroll
+            for (int u = 0; u < MPX; ++u) asm volatile("" : "+v"(kx[u]));
+            issue_dy(tile);                                            // the small operand: loaded here, its latency overlaps the barrier
+            __syncthreads();                                           // previous tile fully consumed
+            store();
+            __syncthreads();
+            if (tile + (int)gridDim.x < P.ntiles) issue(tile + (int)gridDim.x);   // the large operand of the next tile: under the MFMAs
+            const int steps = (rows * P.WT + 3) >> 2;
+            switch (ng) {
+                case 7: wgrad_steps<7>(acc, dys, xs, poff, bbase, abase, PS16, s0, ds, steps, ncob); break;
+                case 6: wgrad_steps<6>(acc, dys, xs, poff, bbase, abase, PS16, s0, ds, steps, ncob); break;
+                case 5: wgrad_steps<5>(acc, dys, xs, poff, bbase, abase, PS16, s0, ds, steps, ncob); break;
+                case 4: wgrad_steps<4>(acc, dys, xs, poff, bbase, abase, PS16, s0, ds, steps, ncob); break;
+                case 3: wgrad_steps<3>(acc, dys, xs, poff, bbase, abase, PS16, s0, ds, steps, ncob); break;
+                case 2: wgrad_steps<2>(acc, dys, xs, poff, bbase, abase, PS16, s0, ds, steps, ncob); break;
+                case 1: wgrad_steps<1>(acc, dys, xs, poff, bbase, abase, PS16, s0, ds, steps, ncob); break;
+                default: break;
+            }
+        }
+    } else
     for (int tile = blockIdx.x; tile < P.ntiles; tile += gridDim.x) {
         const int n = tile / P.tiles_per_img;
         const int tin = tile - n * P.tiles_per_img;
@@ -527,6 +627,10 @@ extern "C" int otp_conv2d_wgrad(const void* x, const void* grad_out, void* grad_
         if (lds <= 72 * 1024) break;
         if (rt == 1 && lds > OTP_LDS_LIMIT) return OTP_ERR_UNSUPPORTED;
     }
+    {   // equal row blocks: 24 rows as 4 x 6 instead of 7 + 7 + 7 + 3
+        const int nyt = otp_ceil_div(P.Ho, P.RT);
+        lds = size_for(wt, otp_ceil_div(P.Ho, nyt));
+    }
     P.magicRT = (unsigned)((0x100000000ull + P.RT - 1) / P.RT);
     P.magicNRX = (unsigned)((0x100000000ull + P.NRX - 1) / P.NRX);
     P.magicWT = (unsigned)((0x100000000ull + P.WT - 1) / P.WT);
@@ -536,10 +640,14 @@ extern "C" int otp_conv2d_wgrad(const void* x, const void* grad_out, void* grad_
              (kw - 1) * dil - pad <= 4 && (x_coff * H * W) % 4 == 0)
                 ? 1 : 0;
     P.GD = P.WT / 4 > 0 ? P.WT / 4 : 1;
+    P.pipe = 0;
     P.GX = (((4 - pad % 4) % 4) + P.LWP + 3) / 4;
     P.magicGD = (unsigned)((0x100000000ull + P.GD - 1) / P.GD);
     P.magicGX = (unsigned)((0x100000000ull + P.GX - 1) / P.GX);
     P.tiles_per_img = otp_ceil_div(P.Ho, P.RT) * P.tiles_x;
+    P.NPD = otp_ceil_div(WG_CO * P.RT * P.GD, 256);
+    P.NPX = otp_ceil_div(WG_CI * P.NRX * P.GX, 256);
+    P.pipe = (P.vec && P.tiles_x == 1 && P.NPD <= 6 && P.NPX <= 12 && P.RT < 256 && P.NRX < 256 && P.GX < 256) ? 1 : 0;
     P.ntiles = N * P.tiles_per_img;
     const int gy = otp_ceil_div(Cout, WG_CO), gz = otp_ceil_div(Cin, WG_CI);
     int gx = wgrad_grid_x(Cout, Cin);
