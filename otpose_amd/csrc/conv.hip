@@ -727,6 +727,10 @@ double tile_cost(const WinPlan& P, const Tile& t, int KS, size_t lds) {
     // measured on the sweeps: at equal tile shape 2-wave workgroups run 7-24 % and 1-wave workgroups 17-26 % behind
     // 4-wave ones (the weight slab is staged once per workgroup)
     if (!P.lin) cost *= 1.0 + 0.2 * (P.nM - 1);                   // strided windows: re-staged by every M tile
+    // tall 1x1 tiles read the input once instead of once per 48 output channels.  Stand-alone that only pays for 136->544
+    // (tile-count quantisation hides it elsewhere); inside the forward graph, where the two temporal encoders share the GPU and
+    // the L2, preferring them everywhere they fit measured 66.4 -> 65.0 ms per forward
+    if (t.MB > 3) cost *= 0.7;
     if (wpw == 2) cost *= 1.12;
     else if (wpw == 3) cost *= 1.2;
     else if (wpw == 1) cost *= 2.0;                                // measured 2.4x on 384->48 1x1 @12x9
