@@ -157,6 +157,47 @@ def golden_parity(model, cfg, dev):
             "tolerance": 1e-3, "vs": "tests/golden/e2e_cfg2_b1.npz (reference model, 1 clip of this config)"}
 
 
+def train_step_probe(cfg, dev, batch, steps=3):
+    """cfg3 of SURVEY.md section 8d in fp32: forward under model.train() (BatchNorm batch statistics, dropout / drop-path),
+    the two ST_OHKW terms, backward through the HIP kernels, fused clip + AdamW.  Reported next to the headline metric;
+    not part of `value`."""
+    from otpose_amd import train as TR
+    from otpose_amd.optim import FusedAdamW
+    model = OTPose(cfg)
+    S.fill_synthetic_(model)
+    model = model.to(dev).train()
+    x, margin = S.synthetic_clip(batch, cfg.MODEL.IMAGE_SIZE)
+    x, margin = x.to(dev), margin.to(dev)
+    J = cfg.MODEL.NUM_JOINTS
+    w, h = cfg.MODEL.HEATMAP_SIZE
+    gen = torch.Generator().manual_seed(11)
+    g = (torch.rand(batch, J, h, w, generator=gen) * 0.2).to(dev)
+    g[:, ::2, 3, 4] = 1.0
+    wt = (torch.rand(batch, J, 1, generator=gen) > 0.15).float().to(dev)
+    opt = FusedAdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4, weight_decay=0.01, max_grad_norm=1.0)
+    times = []
+    loss = None
+    for it in range(steps + 1):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        outs = model(x, margin=margin)
+        loss = TR.criterion(outs, g, wt)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        torch.cuda.synchronize(dev)
+        if it:
+            times.append(time.perf_counter() - t0)
+    t = sorted(times)[len(times) // 2]
+    res = {"ms_per_step": 1e3 * t, "frames_per_s": 5 * batch / t, "batch": batch, "dtype": "f32",
+           "what": "forward (train mode) + 2x ST_OHKW loss + backward + clip + AdamW, median of %d after 1 warm-up" % steps,
+           "loss_finite": bool(torch.isfinite(loss.detach()).all()),
+           "peak_mem_GB": torch.cuda.max_memory_allocated(dev) / 2 ** 30}
+    del model, opt, outs, loss
+    torch.cuda.empty_cache()
+    return res
+
+
 def cpu_baseline():
     """The oracle (CPU restatement of the reference graph) timed on the host cores on a bounded sample of the same
     workload: a 1-clip warm-up sizes the sample so that the three timed forwards take ~12 s together (1-8 clips of
@@ -198,6 +239,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="clips per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-step", action="store_true", help="skip the training-step probe (extra field of the line)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -267,6 +309,9 @@ def main():
         line["roofline_dcn"] = dcn
         line["parity"] = golden_parity(model, cfg, dev)     # the "heatmap max-abs delta vs ref" half of the metric
         log("golden parity done")
+        if world == 1 and not a.no_train_step:
+            line["train_step"] = train_step_probe(cfg, dev, a.batch)
+            log("training-step probe done: %.1f ms" % line["train_step"]["ms_per_step"])
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
