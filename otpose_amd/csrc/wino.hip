@@ -354,16 +354,13 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const float* __restri
         etwo[tb] = 2 * tx + 1 < P.W;
         ebot[tb] = 2 * ty + 1 < P.H;
     }
-#pragma unroll 1
-    for (int mb = 0; mb < WMB; ++mb) {
+#pragma unroll
+    for (int mb = 0; mb < WMB; ++mb) {                                // fully unrolled: static accumulator indices, no selects
 #pragma unroll
         for (int tb = 0; tb < TB; ++tb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float m0v = 0.f, m1v = 0.f, m2v = 0.f, m3v = 0.f;  // runtime mb, static register indices
-#pragma unroll
-                for (int q = 0; q < WMB; ++q)
-                    if (q == mb) { m0v = acc[0][q][tb][r]; m1v = acc[1][q][tb][r]; m2v = acc[2][q][tb][r]; m3v = acc[3][q][tb][r]; }
+                const float m0v = acc[0][mb][tb][r], m1v = acc[1][mb][tb][r], m2v = acc[2][mb][tb][r], m3v = acc[3][mb][tb][r];
                 Pb[((wave * 2 + 0) * 16 + kl * 4 + r) * PST + tb * 16 + i16] = m0v + m1v + m2v;
                 Pb[((wave * 2 + 1) * 16 + kl * 4 + r) * PST + tb * 16 + i16] = m1v - m2v - m3v;
             }
