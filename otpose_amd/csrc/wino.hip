@@ -19,6 +19,7 @@
 // pairs (a tile's two columns) - coalesced along the tile row.
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -234,12 +235,6 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const float* __restri
         for (int c = tid; c < WCK * WG_; c += 256) raw[(c / WG_) * P.WS + (c % WG_)] = 0.f;   // guard floats
 
     f32x4 acc[4][WMB][TB];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int mb = 0; mb < WMB; ++mb)
-#pragma unroll
-            for (int tb = 0; tb < TB; ++tb) acc[a][mb][tb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const float* Vw = V + (wave * 4) * WCK * VS + kl * VS + i16;
 
@@ -316,21 +311,29 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const float* __restri
         if (more) load_chunk(c0 + WCK);                           // window of the next chunk: in flight under the MFMAs
         __syncthreads();                                          // V complete (U was complete at the previous barrier)
         // ---- 4 coordinates x 2 k-steps x (WMB x TB) MFMAs ------------------------------------------------------------------
+        // (the very first MFMA of every accumulator takes a literal zero as C: no 144-register clear per workgroup)
+        auto mfma_phase = [&](auto first_tag) __attribute__((always_inline)) {
+            constexpr bool FIRST = decltype(first_tag)::value;
 #pragma unroll
-        for (int nu = 0; nu < 4; ++nu)
+            for (int nu = 0; nu < 4; ++nu)
 #pragma unroll
-            for (int k = 0; k < WCK / 4; ++k) {
-                float a[WMB], b[TB];
+                for (int k = 0; k < WCK / 4; ++k) {
+                    float a[WMB], b[TB];
 #pragma unroll
-                for (int mb = 0; mb < WMB; ++mb) a[mb] = areg[nu][k][mb];
+                    for (int mb = 0; mb < WMB; ++mb) a[mb] = areg[nu][k][mb];
 #pragma unroll
-                for (int tb = 0; tb < TB; ++tb) b[tb] = Vw[(nu * WCK + 4 * k) * VS + tb * 16];
+                    for (int tb = 0; tb < TB; ++tb) b[tb] = Vw[(nu * WCK + 4 * k) * VS + tb * 16];
 #pragma unroll
-                for (int mb = 0; mb < WMB; ++mb)
+                    for (int mb = 0; mb < WMB; ++mb)
 #pragma unroll
-                    for (int tb = 0; tb < TB; ++tb)
-                        acc[nu][mb][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb], b[tb], acc[nu][mb][tb], 0, 0, 0);
-            }
+                        for (int tb = 0; tb < TB; ++tb) {
+                            const f32x4 cin = (FIRST && k == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[nu][mb][tb];
+                            acc[nu][mb][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb], b[tb], cin, 0, 0, 0);
+                        }
+                }
+        };
+        if (c0 == 0) mfma_phase(std::true_type{});
+        else mfma_phase(std::false_type{});
         if (more) {
             load_weights(c0 + WCK);                               // the fragments of this chunk are spent; in flight under the next transform
             store_window();                                       // raw is free since the barrier above
