@@ -34,22 +34,29 @@ def main():
 
 
 def isolated(src, dst, kernel_substr, grid, last):
-    """The `last` final dispatches of one (kernel, grid): bench.py's stand-alone roofline launches, which follow the timed
-    region (inside the captured graph the same kernel overlaps with launches of other streams, which stretches its
-    in-graph duration)."""
+    """bench.py's stand-alone roofline launches of one (kernel, grid): the run of `last` consecutive dispatches of that kernel
+    with the shortest span (back-to-back launches; inside the captured graph the same kernel overlaps with launches of other
+    streams, which stretches its in-graph duration, and the training probe launches it with other epilogues)."""
     rows = []
     with open(src) as f:
         for r in csv.DictReader(f):
             g = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
             if kernel_substr in r["Kernel_Name"] and g == grid:
-                rows.append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+                rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
     rows.sort()
-    d = [x[1] for x in rows[-last:]]
+    if len(rows) < last:
+        return
+    best = min(range(len(rows) - last + 1), key=lambda i: rows[i + last - 1][1] - rows[i][0])
+    run = rows[best:best + last]
+    d = [(e - s_) / 1e3 for s_, e in run]
+    gaps = [(run[i + 1][0] - run[i][1]) / 1e3 for i in range(last - 1)]
     with open(dst, "a") as o:
-        o.write("#\n# stand-alone launches of %s (grid %d threads): the last %d dispatches of the trace = bench.py's roofline\n"
-                "# measurement (20 timed + 1 warm-up); in-graph dispatches of the same kernel overlap with other streams\n"
-                % (kernel_substr, grid, last))
-        o.write("# durations_us: %s\n# average of the 20 timed: %.1f us\n" % (" ".join("%.0f" % x for x in d), sum(d[-20:]) / 20))
+        o.write("#\n# stand-alone launches of %s (grid %d threads): the tightest run of %d consecutive dispatches = bench.py's\n"
+                "# roofline measurement (1 warm-up + 20 timed, back to back on one stream)\n" % (kernel_substr, grid, last))
+        o.write("# durations_us: %s\n# average duration of the 20 timed: %.1f us; average gap to the next dispatch (end-of-kernel\n"
+                "# cache write-back + dispatch): %.1f us; duration + gap = %.1f us = what HIP events around back-to-back launches see\n"
+                % (" ".join("%.0f" % x for x in d), sum(d[1:]) / (last - 1), sum(gaps) / len(gaps),
+                   sum(d[1:]) / (last - 1) + sum(gaps) / len(gaps)))
 
 
 if __name__ == "__main__":
