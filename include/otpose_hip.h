@@ -257,6 +257,13 @@ int otp_loss_st_ohkw_grads(const void* s, const void* t, const void* g, const vo
 int otp_loss_st_ohkw(const void* s, const void* t, const void* g, const void* w, void* flags,
                      void* result, void* grad_s, void* grad_t, void* workspace, size_t workspace_bytes,
                      int B, int J, int HW, int topk, int flags_given, void* stream);
+/* JointsMSE_OHKMMSELoss.forward (loss.py:115-148; ohkm != 0: result = {ohkm_loss, mse_loss / effective_num_joints,
+ * final_loss}) and JointMSELoss.forward (loss.py:158-182; ohkm == 0: result = {0, loss, loss}).  o, g (B,J,HW);
+ * w (B,J) or NULL for use_target_weight = False; effective_num_joints <= 0 means J (the reference's None);
+ * grad_o (optional) receives d final_loss / d o (d loss / d o for the plain form).  Workspace: otp_loss_workspace. */
+int otp_loss_joints_mse(const void* o, const void* g, const void* w, void* result, void* grad_o, void* workspace,
+                        size_t workspace_bytes, int B, int J, int HW, int topk, int ohkm, int effective_num_joints,
+                        void* stream);
 
 #ifdef __cplusplus
 }

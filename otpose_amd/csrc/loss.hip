@@ -116,6 +116,81 @@ __global__ void loss_grad_kernel(const float* __restrict__ s, const float* __res
     if (gg) gg[i] = -wt * cg * dg;              // the 2nd criterion call's target depends on the model (Common.py:128-130)
 }
 
+// ---- JointsMSE_OHKMMSELoss (loss.py:95-148) and JointMSELoss (loss.py:151-182): one prediction, one target ----
+// grid (B*J): ss[bj] = sum (o*w - g*w)^2
+__global__ __launch_bounds__(256) void joints_stats_kernel(const float* __restrict__ o, const float* __restrict__ g,
+                                                            const float* __restrict__ w, float* __restrict__ ss, int HW) {
+    __shared__ float red[4];
+    const int bj = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float wt = w ? w[bj] : 1.f;
+    const size_t base = (size_t)bj * HW;
+    float acc = 0.f;
+    for (int p = tid; p < HW; p += 256) {
+        const float d = o[base + p] * wt - g[base + p] * wt;
+        acc += d * d;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (tid == 0) ss[bj] = red[0] + red[1] + red[2] + red[3];
+}
+
+// one workgroup; ohkm != 0: result = {ohkm, mse/eff, ohkm + mse}; else result = {0, mse/eff, mse/eff}
+__global__ __launch_bounds__(256) void joints_finish_kernel(const float* __restrict__ ss, float* __restrict__ result,
+                                                             float* __restrict__ coef, int B, int J, int HW, int topk,
+                                                             int ohkm, float eff) {
+    extern __shared__ float sm[];
+    float* l = sm;                                    // [B*J]
+    int* sel = reinterpret_cast<int*>(sm + B * J);    // [B*J]
+    float* acc = sm + 2 * B * J;                      // [2]
+    const int tid = threadIdx.x;
+    if (tid < 2) acc[tid] = 0.f;
+    const float inv_hw = 1.f / (float)HW;
+    for (int i = tid; i < B * J; i += blockDim.x) { l[i] = 0.5f * ss[i] * inv_hw; sel[i] = 0; }
+    __syncthreads();
+    for (int j = tid; j < J; j += blockDim.x) {
+        float m = 0.f;
+        for (int b = 0; b < B; ++b) m += ss[b * J + j];
+        atomicAdd(&acc[1], m / ((float)B * (float)HW));
+    }
+    if (ohkm)
+        for (int b = tid; b < B; b += blockDim.x) {
+            float sum = 0.f;
+            for (int k = 0; k < topk; ++k) {
+                int best = -1;
+                float bv = -INFINITY;
+                for (int j = 0; j < J; ++j)
+                    if (!sel[b * J + j] && l[b * J + j] > bv) { bv = l[b * J + j]; best = j; }
+                if (best < 0) break;
+                sel[b * J + best] = 1;
+                sum += bv;
+            }
+            atomicAdd(&acc[0], sum / (float)topk);
+        }
+    __syncthreads();
+    if (tid == 0) {
+        if (ohkm) {
+            const float v = acc[0] / (float)B;
+            result[0] = v; result[1] = acc[1] / eff; result[2] = v + acc[1];
+        } else {
+            result[0] = 0.f; result[1] = acc[1] / eff; result[2] = acc[1] / eff;
+        }
+    }
+    if (coef)
+        for (int i = tid; i < B * J; i += blockDim.x)
+            coef[i] = ohkm ? (sel[i] ? 1.f / ((float)topk * B * HW) : 0.f) + 2.f / ((float)B * HW)
+                           : 2.f / ((float)B * HW * eff);
+}
+
+__global__ void joints_grad_kernel(const float* __restrict__ o, const float* __restrict__ g, const float* __restrict__ w,
+                                   const float* __restrict__ coef, float* __restrict__ go, int HW) {
+    const int bj = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= HW) return;
+    const size_t i = (size_t)bj * HW + p;
+    const float wt = w ? w[bj] : 1.f;
+    go[i] = wt * coef[bj] * (o[i] * wt - g[i] * wt);
+}
+
 }  // namespace
 
 extern "C" size_t otp_loss_workspace(int B, int J) {
@@ -150,4 +225,26 @@ extern "C" int otp_loss_st_ohkw(const void* s, const void* t, const void* g, con
                                 int HW, int topk, int flags_given, void* stream) {
     return otp_loss_st_ohkw_grads(s, t, g, w, flags, result, grad_s, grad_t, nullptr, workspace, workspace_bytes, B, J, HW,
                                   topk, flags_given, stream);
+}
+
+extern "C" int otp_loss_joints_mse(const void* o, const void* g, const void* w, void* result, void* grad_o, void* workspace,
+                                   size_t workspace_bytes, int B, int J, int HW, int topk, int ohkm,
+                                   int effective_num_joints, void* stream) {
+    if (!o || !g || !result || !workspace || B <= 0 || J <= 0 || HW <= 0) return OTP_ERR_BAD_ARG;
+    if (ohkm && (topk <= 0 || topk > J)) return OTP_ERR_BAD_ARG;
+    if (workspace_bytes < otp_loss_workspace(B, J)) return OTP_ERR_WORKSPACE;
+    const size_t lds = ((size_t)B * J * 2 + 2) * sizeof(float);
+    if (lds > 64 * 1024) return OTP_ERR_UNSUPPORTED;
+    auto st = static_cast<hipStream_t>(stream);
+    auto f = [](const void* p) { return static_cast<const float*>(p); };
+    float* ss = static_cast<float*>(workspace);
+    float* coef = ss + (size_t)B * J;
+    const float eff = (float)(effective_num_joints > 0 ? effective_num_joints : J);
+    hipLaunchKernelGGL(joints_stats_kernel, dim3(B * J), dim3(256), 0, st, f(o), f(g), f(w), ss, HW);
+    hipLaunchKernelGGL(joints_finish_kernel, dim3(1), dim3(256), lds, st, ss, static_cast<float*>(result),
+                       grad_o ? coef : nullptr, B, J, HW, topk, ohkm, eff);
+    if (grad_o)
+        hipLaunchKernelGGL(joints_grad_kernel, dim3(otp_ceil_div(HW, 256), B * J), dim3(256), 0, st, f(o), f(g), f(w), coef,
+                           static_cast<float*>(grad_o), HW);
+    return otp_launch_status();
 }

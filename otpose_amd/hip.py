@@ -87,6 +87,7 @@ SIGNATURES = {
     "otp_loss_workspace": (c_size_t, [c_int, c_int]),
     "otp_loss_st_ohkw_grads": (c_int, [c_void_p] * 9 + [c_void_p, c_size_t] + [c_int] * 5 + [c_void_p]),
     "otp_loss_st_ohkw": (c_int, [c_void_p] * 8 + [c_void_p, c_size_t] + [c_int] * 5 + [c_void_p]),
+    "otp_loss_joints_mse": (c_int, [c_void_p] * 5 + [c_void_p, c_size_t] + [c_int] * 6 + [c_void_p]),
 }
 
 

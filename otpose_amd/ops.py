@@ -513,3 +513,36 @@ def st_ohkw_loss(s, t, g, w, topk=8, flags=None, with_grad=False):
     if with_grad:
         out["grad_s"], out["grad_t"] = gs, gt
     return out
+
+
+def _joints_mse(o, g, w, topk, ohkm, effective_num_joints, with_grad):
+    _require_gpu(o, g)
+    b, j = o.shape[:2]
+    hw = o[0, 0].numel()
+    o, g = o.contiguous(), g.contiguous()
+    wv = None if w is None else w.reshape(b, j).contiguous().float()
+    L = hip.lib()
+    nbytes = L.otp_loss_workspace(b, j)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=o.device)
+    res = torch.empty(3, dtype=torch.float32, device=o.device)
+    go = torch.empty_like(o) if with_grad else None
+    hip.check(L.otp_loss_joints_mse(hip.ptr(o), hip.ptr(g), hip.ptr(wv), hip.ptr(res), hip.ptr(go), hip.ptr(ws), nbytes,
+                                    b, j, hw, topk, int(ohkm), int(effective_num_joints or 0), hip.stream_of(o)),
+              "otp_loss_joints_mse")
+    return res, go
+
+
+def joints_ohkm_mse_loss(output, target, target_weight=None, effective_num_joints=None, topk=8, with_grad=False):
+    """JointsMSE_OHKMMSELoss.forward (model/loss.py:115-148) on the GPU; ``target_weight=None`` is the reference's
+    ``use_target_weight=False``.  Returns the reference's dict (+ ``grad_output`` of ``final_loss`` when requested)."""
+    res, go = _joints_mse(output, target, target_weight, topk, True, effective_num_joints, with_grad)
+    out = {"ohkm_loss": res[0], "mse_loss": res[1], "final_loss": res[2]}
+    if with_grad:
+        out["grad_output"] = go
+    return out
+
+
+def joint_mse_loss(output, target, target_weight=None, effective_num_joints=None, with_grad=False):
+    """JointMSELoss.forward (model/loss.py:158-182) on the GPU: a scalar (and its gradient when requested)."""
+    res, go = _joints_mse(output, target, target_weight, 1, False, effective_num_joints, with_grad)
+    return (res[2], go) if with_grad else res[2]

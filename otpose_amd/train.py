@@ -81,6 +81,78 @@ def st_ohkw_loss(s, t, g, w, flags=None):
     return StOhkwLossFunction.apply(s, t, g, w, flags)
 
 
+class JointsMseLossFunction(Function):
+    """``JointsMSE_OHKMMSELoss`` (model/loss.py:95-148, ``ohkm=True``: returns the three scalars of its dict, gradient
+    flows from ``final_loss``) and ``JointMSELoss`` (model/loss.py:151-182, ``ohkm=False``) with the analytic gradient
+    from the same launch."""
+
+    @staticmethod
+    def forward(ctx, o, g, w, ohkm, topk, eff):
+        res, go = ops._joints_mse(o, g, w, topk, ohkm, eff, True)
+        ctx.save_for_backward(go)
+        ctx.mark_non_differentiable(res)
+        return res[2].clone(), res
+
+    @staticmethod
+    def backward(ctx, gl, _gres):
+        (go,) = ctx.saved_tensors
+        return go * gl, None, None, None, None, None
+
+
+class ST_OHKW_MSELoss(torch.nn.Module):
+    """model/loss.py:25-92 — same constructor and call signature; returns the reference's dict."""
+
+    def __init__(self, use_target_weight=True, topk=8):
+        super().__init__()
+        if not use_target_weight:
+            raise NotImplementedError("the reference's use_target_weight=False branch fills only the unused teacher lists and "
+                                      "fails at torch.cat of the empty student list (loss.py:73-80)")
+        self.use_target_weight, self.topk = use_target_weight, topk
+
+    def forward(self, output_s, output_t, target, target_weight, flags=None):
+        final = st_ohkw_loss(output_s, output_t, target, target_weight, flags)
+        with torch.no_grad():
+            d = ops.st_ohkw_loss(output_s, output_t, target, target_weight, self.topk, flags)
+        return {"ohkm_loss_s": d["ohkm_loss_s"], "mse_loss_s": d["mse_loss_s"], "final_loss": final}
+
+
+class JointsMSE_OHKMMSELoss(torch.nn.Module):
+    """model/loss.py:95-148."""
+
+    def __init__(self, use_target_weight, topk=8):
+        super().__init__()
+        self.use_target_weight, self.topk = use_target_weight, topk
+
+    def forward(self, output, target, target_weight, effective_num_joints=None):
+        w = target_weight if self.use_target_weight else None
+        final, res = JointsMseLossFunction.apply(output, target, w, True, self.topk, effective_num_joints)
+        return {"ohkm_loss": res[0], "mse_loss": res[1], "final_loss": final}
+
+
+class JointMSELoss(torch.nn.Module):
+    """model/loss.py:151-182 (``margin`` is accepted and unused, as in the reference)."""
+
+    def __init__(self, use_target_weight):
+        super().__init__()
+        self.use_target_weight = use_target_weight
+
+    def forward(self, output, target, target_weight, effective_num_joints=None, margin=None):
+        w = target_weight if self.use_target_weight else None
+        final, _ = JointsMseLossFunction.apply(output, target, w, False, 1, effective_num_joints)
+        return final
+
+
+def build_loss(cfg, **kwargs):
+    """model/loss.py:185-189: LOSS.NAME -> criterion; an unknown name returns None there, here it raises."""
+    name = cfg["LOSS"]["NAME"] if isinstance(cfg, dict) else cfg.LOSS.NAME
+    utw = cfg["LOSS"]["USE_TARGET_WEIGHT"] if isinstance(cfg, dict) else cfg.LOSS.USE_TARGET_WEIGHT
+    if name == "ST_OHKW_MSELoss":
+        return ST_OHKW_MSELoss(utw)
+    if name == "MSELOSS_OHKM":
+        return JointsMSE_OHKMMSELoss(utw)
+    raise ValueError(f"unknown LOSS.NAME {name!r}")
+
+
 class TrainGraph:
     """Functional walk over the module's own parameters / buffers (same names as the reference state dict)."""
 

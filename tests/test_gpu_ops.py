@@ -212,6 +212,49 @@ def test_loss_matches_golden_and_oracle(golden):
     _close(r2["final_loss"].reshape(()), ref2["final_loss"].reshape(()), 1e-5)
 
 
+def test_joints_losses_match_golden_and_oracle(golden):
+    """JointsMSE_OHKMMSELoss / JointMSELoss (model/loss.py:95-182): values vs reference-generated goldens, gradients and
+    the use_target_weight=False / effective_num_joints forms vs the oracle."""
+    from otpose_amd import train as TR
+    g = golden("losses")
+    s, gt, w = g["s"], g["g"], g["w"]
+    r = ops.joints_ohkm_mse_loss(s.cuda(), gt.cuda(), w.cuda(), with_grad=True)
+    for k in ("ohkm_loss", "mse_loss", "final_loss"):
+        _close(r[k].reshape(()), g["ohkm_" + k].reshape(()), 1e-5)
+    sd = s.double().requires_grad_(True)
+    ref = O.joints_ohkm_mse_loss(sd, gt.double(), w.double())
+    ref["final_loss"].backward()
+    _close(r["grad_output"], sd.grad.float(), 1e-6)
+    v, gv = ops.joint_mse_loss(s.cuda(), gt.cuda(), w.cuda(), with_grad=True)
+    _close(v.reshape(()), g["jmse"].reshape(()), 1e-5)
+    sd = s.double().requires_grad_(True)
+    O.joint_mse_loss(sd, gt.double(), w.double()).backward()
+    _close(gv, sd.grad.float(), 1e-6)
+    # no target weight, effective_num_joints = 13 (mse_loss / plain loss scale only)
+    ones = torch.ones_like(w)
+    r2 = ops.joints_ohkm_mse_loss(s.cuda(), gt.cuda(), None, effective_num_joints=13, topk=5)
+    ref2 = O.joints_ohkm_mse_loss(s, gt, ones, topk=5)
+    _close(r2["ohkm_loss"].reshape(()), ref2["ohkm_loss"].reshape(()), 1e-5)
+    _close(r2["mse_loss"].reshape(()), (ref2["mse_loss"] * 17 / 13).reshape(()), 1e-5)
+    _close(r2["final_loss"].reshape(()), ref2["final_loss"].reshape(()), 1e-5)
+    v2 = ops.joint_mse_loss(s.cuda(), gt.cuda(), None, effective_num_joints=13)
+    _close(v2.reshape(()), (O.joint_mse_loss(s, gt, ones) * 17 / 13).reshape(()), 1e-5)
+    # the nn.Module mirrors + build_loss (loss.py:185-189), autograd through the fused gradient
+    crit = TR.build_loss({"LOSS": {"NAME": "MSELOSS_OHKM", "USE_TARGET_WEIGHT": True}})
+    assert isinstance(crit, TR.JointsMSE_OHKMMSELoss)
+    assert isinstance(TR.build_loss({"LOSS": {"NAME": "ST_OHKW_MSELoss", "USE_TARGET_WEIGHT": True}}), TR.ST_OHKW_MSELoss)
+    sc = s.cuda().requires_grad_(True)
+    d = crit(sc, gt.cuda(), w.cuda())
+    (3.0 * d["final_loss"]).backward()
+    _close(sc.grad, 3.0 * r["grad_output"].cpu(), 1e-6)
+    sc = s.cuda().requires_grad_(True)
+    TR.JointMSELoss(True)(sc, gt.cuda(), w.cuda(), margin=None).backward()
+    _close(sc.grad, gv.cpu(), 1e-6)
+    st = TR.ST_OHKW_MSELoss(True)(s.cuda(), g["t"].cuda(), gt.cuda(), w.cuda())
+    for k in ("ohkm_loss_s", "mse_loss_s", "final_loss"):
+        _close(st[k].reshape(()), g["st_" + k].reshape(()), 1e-5)
+
+
 @pytest.mark.parametrize("case", [  # N, Cin, H, W, Cout
     (2, 48, 24, 18, 48),       # even sizes, one M tile, several tile blocks per image
     (2, 20, 12, 9, 100),       # odd width (last tile column half empty), ragged Cin chunk and ragged last M tile
