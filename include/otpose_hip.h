@@ -166,6 +166,30 @@ int otp_chan_attn(const void* q, const void* k, const void* v, void* out, void* 
  * channel offset out_coff (f = 1 copies) (ConvVideoTransformer.py:108,179; OTPose.py:362-369) */
 int otp_upsample_linear(const void* x, void* out, int B, int C, int T, int f, int out_ctot, int out_coff, void* stream);
 
+/* TransformerBlock MLP in one launch (model/blocks.py:248-254 applied at :277-279, eval mode):
+ *   out = res + scale * (W2 . gelu(W1 . x + b1)) + shift,   x / res / out (B, C, T), W1 (HID, C), W2 (C, HID),
+ * scale = AffineDropPath scale (C), shift = b2 * scale (C); the hidden (B, HID, T) activation never reaches HBM.
+ * `packed` = otp_mlp_fused_pack's image of (W1, b1, W2) (otp_mlp_fused_weight_bytes bytes, 16-byte aligned).
+ * otp_mlp_fused_supported: 1 when a kernel is instantiated for (C, HID) and T qualifies (C = 136, HID = 544, T even);
+ * otherwise the caller issues the two otp_conv2d launches.  `res` may alias `out`. */
+int otp_mlp_fused_supported(int C, int HID, int T);
+size_t otp_mlp_fused_weight_bytes(int C, int HID);
+int otp_mlp_fused_pack(const void* w1, const void* b1, const void* w2, void* packed, int C, int HID, void* stream);
+int otp_mlp_fused(const void* x, const void* packed, const void* scale, const void* shift, const void* res, void* out,
+                  int B, int C, int HID, int T, void* stream);
+
+/* The C -> C pointwise projections of MaskedMHCA (query / key / value / proj: model/blocks.py:383-386, applied at :417-419
+ * and :450) on (B, C, T) tensors, nprob (1..3) independent problems of one shape per launch:
+ *   out[p] = scale[p] * (W[p] . x[p]) + shift[p] (+ res[p]);   res may be NULL, or hold NULL entries.
+ * `packed[p]` = otp_dense_cc_pack's image of (W (C, C), scale (C) or NULL = 1, shift (C) or NULL = 0), 16-byte aligned,
+ * otp_dense_cc_weight_bytes(C) bytes.  otp_dense_cc_supported: 1 when a kernel is instantiated (C = 136, T even);
+ * otherwise the caller uses otp_conv2d.  x / res / out are arrays of nprob device pointers (host memory). */
+int otp_dense_cc_supported(int C, int T);
+size_t otp_dense_cc_weight_bytes(int C);
+int otp_dense_cc_pack(const void* w, const void* scale, const void* shift, void* packed, int C, void* stream);
+int otp_dense_cc(const void* const* x, const void* const* packed, const void* const* res, void* const* out, int nprob,
+                 int B, int C, int T, void* stream);
+
 /* out = act(res + nearest_upsample_f(low)) on channel slices (HRNet fuse layers with f >= 4, model/HRNet.py:426-439,
  * 488-494; `res` may alias `out`); low (N, low_ctot, Hl, Wl), res / out (N, *_ctot, Hl*f, Wl*f); relu != 0 applies ReLU */
 int otp_upsample_add(const void* low, const void* res, void* out, int N, int C, int Hl, int Wl, int f, int relu,

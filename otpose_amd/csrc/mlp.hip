@@ -1,0 +1,216 @@
+// The TransformerBlock MLP of the temporal encoders (reference model/blocks.py:248-254, applied at :277-279) as ONE launch:
+//     out = res + scale * (W2 . gelu(W1 . x + b1)) + shift          x, res, out (B, C, T); W1 (HID, C); W2 (C, HID)
+// (eval mode: both Dropouts and the drop-path are identities; `scale` is AffineDropPath's per-channel scale, `shift` =
+// b2 * scale).  The 4C-wide hidden activation never leaves the register file: a wave owns 32 tokens, keeps their C input
+// channels as MFMA B-operand fragments (C/4 k-steps x 2 column tiles), and walks the hidden dimension 16 channels at a
+// time - phase 1 produces a 16 x 32 hidden tile with v_mfma_f32_16x16x4_f32, bias + erf-GELU are applied to the
+// accumulator registers, and phase 2 feeds those same registers back as the B operand of the second GEMM.  No cross-lane
+// movement is needed for that: accumulator register i of lane (g = lane / 16, n = lane % 16) is hidden channel 4g + i of
+// column n, and a B operand wants "k-slot g, column n" - so the i-th k-step of phase 2 simply contracts over the hidden
+// channels {4g + i}, and the packed W2 fragments are laid out in that order.  Columns are permuted too (column n of tile j
+// is token 2n + j) so every global access is an 8-byte load / store of two neighbouring tokens.
+// Weights are pre-packed per 16-channel hidden block in LDS fragment order and streamed L2 -> registers -> LDS, double
+// buffered, one barrier per block, shared by the waves of the workgroup.
+// Roofline: MFMA-bound.  2*2*C*HID flop/token (C = 136: 295.9 kflop) against 8 bytes/token/channel of HBM traffic (x, res
+// in, out: 1.6 kB/token).
+#include <math.h>
+
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// erf-GELU on a pair of accumulator values, branch-free and in packed-f32 form (v_pk_fma_f32): erf(t) = t P(t^2) / Q(t^2)
+// on |t| <= 4 (the classic single-precision rational fit; erf is 1 - 1.5e-8 beyond), max abs error 4.2e-7 on erf and
+// 7e-7 on gelu(x) over the whole real line - checked against fp64 in tests/test_gpu_ops.py.  The libm erff the other
+// epilogues call has two data-dependent paths, and both would run for every accumulator register of a wave here.
+__device__ __forceinline__ f32x2 mlp_gelu2(f32x2 x) {
+    f32x2 t = x * 0.70710678118654752440f;
+    t.x = __builtin_amdgcn_fmed3f(t.x, -4.f, 4.f);
+    t.y = __builtin_amdgcn_fmed3f(t.y, -4.f, 4.f);
+    const f32x2 t2 = t * t;
+    f32x2 p = t2 * -2.72614225801306e-10f + 2.77068142495902e-08f;
+    p = p * t2 + -2.10102402082508e-06f;
+    p = p * t2 + -5.69250639462346e-05f;
+    p = p * t2 + -7.34990630326855e-04f;
+    p = p * t2 + -2.95459980854025e-03f;
+    p = p * t2 + -1.60960333262415e-02f;
+    p = p * t;
+    f32x2 q = t2 * -1.45660718464996e-05f + -2.13374055278905e-04f;
+    q = q * t2 + -1.68282697438203e-03f;
+    q = q * t2 + -7.37332916720468e-03f;
+    q = q * t2 + -1.42647390514189e-02f;
+    f32x2 r;
+    r.x = __builtin_amdgcn_rcpf(q.x);
+    r.y = __builtin_amdgcn_rcpf(q.y);
+    const f32x2 e = p * r, hx = x * 0.5f;
+    return hx * e + hx;
+}
+
+// floats per hidden block, padded to whole 16-byte-per-thread passes of a 256-thread workgroup
+constexpr int mlp_block_floats(int C) { return (((C / 4 + 3) / 4 + (C + 15) / 16) * 256 + 16 + 1023) / 1024 * 1024; }
+
+// packed[h][...]: phase-1 A fragments [kgroup][lane][4 k-steps], phase-2 A fragments [mtile][lane][4 steps], b1[16]
+__global__ void mlp_pack_kernel(const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
+                                float* __restrict__ packed, int C, int HID) {
+    const int KS = C / 4, KG = (KS + 3) / 4, MT = (C + 15) / 16, BLK = mlp_block_floats(C);
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (HID / 16) * BLK) return;
+    const int h = idx / BLK, r = idx % BLK;
+    float v = 0.f;
+    if (r < KG * 256) {
+        const int sg = r / 256, l = (r % 256) / 4, q = r % 4, s = 4 * sg + q;
+        if (s < KS) v = w1[(size_t)(16 * h + (l & 15)) * C + 4 * s + (l >> 4)];
+    } else if (r < (KG + MT) * 256) {
+        const int r2 = r - KG * 256, mt = r2 / 256, l = (r2 % 256) / 4, i = r2 % 4;
+        const int row = 16 * mt + (l & 15);
+        if (row < C) v = w2[(size_t)row * HID + 16 * h + 4 * (l >> 4) + i];
+    } else if (r < (KG + MT) * 256 + 16) {
+        v = b1[16 * h + r - (KG + MT) * 256];
+    }
+    packed[idx] = v;
+}
+
+template <int C, int HID, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void mlp_fused_kernel(
+    const float* __restrict__ x, const float* __restrict__ packed, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ out, int T, int tiles_per_b) {
+    constexpr int KS = C / 4, KG = (KS + 3) / 4, HT = HID / 16, MT = (C + 15) / 16;
+    constexpr int BLK = mlp_block_floats(C), BLK4 = BLK / 4, NTHR = WAVES * 64, NST = (BLK4 + NTHR - 1) / NTHR;
+    extern __shared__ float lds[];                    // 2 x BLK floats
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kq = lane >> 4, n = lane & 15;
+    const int b = blockIdx.x / tiles_per_b, tile = blockIdx.x - b * tiles_per_b;
+    const int tok = tile * (WAVES * 32) + wave * 32 + 2 * n;
+    const bool valid = tok < T;                       // T is even: a token pair is inside or outside together
+    const size_t base = (size_t)b * C * T;
+
+    // weights of hidden block 0 -> LDS buffer 0
+    const f32x4* pk = reinterpret_cast<const f32x4*>(packed);
+    f32x4* l4 = reinterpret_cast<f32x4*>(lds);
+#pragma unroll
+    for (int i = 0; i < NST; ++i)
+        if (BLK4 % NTHR == 0 || tid + i * NTHR < BLK4) l4[tid + i * NTHR] = pk[tid + i * NTHR];
+
+    // the wave's input columns as B fragments: X[s] = x[4s + kq][tok, tok + 1]
+    f32x2 X[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s)       // columns past T read the last pair instead (their results are never stored)
+        X[s] = *reinterpret_cast<const f32x2*>(x + base + (size_t)(4 * s + kq) * T + (valid ? tok : T - 2));
+    f32x4 Y[MT][2];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) { Y[mt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; Y[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    __syncthreads();
+
+    for (int h = 0; h < HT; ++h) {
+        // next block's weights on their way while this one is consumed
+        f32x4 stage[NST];
+        if (h + 1 < HT) {
+            const f32x4* src = pk + (size_t)(h + 1) * BLK4;
+#pragma unroll
+            for (int i = 0; i < NST; ++i)
+                if (BLK4 % NTHR == 0 || tid + i * NTHR < BLK4) stage[i] = src[tid + i * NTHR];
+        }
+        const float* P1 = lds + (h & 1) * BLK;
+        const float* P2 = P1 + KG * 256;
+        const float* PB = P2 + MT * 256;
+        // phase 1: hidden tile (16 channels x 32 tokens) = W1[16h .. 16h+15][:] . X
+        // (the accumulators start from b1: register i of lane group kq is hidden channel 16h + 4 kq + i)
+        f32x4 H0 = *reinterpret_cast<const f32x4*>(PB + 4 * kq), H1 = H0;
+#pragma unroll
+        for (int sg = 0; sg < KG; ++sg) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(P1 + (sg * 64 + lane) * 4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int s = 4 * sg + q;
+                if (s < KS) {
+                    H0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], X[s].x, H0, 0, 0, 0);
+                    H1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], X[s].y, H1, 0, 0, 0);
+                }
+            }
+        }
+        {
+            const f32x2 g0 = mlp_gelu2(f32x2{H0[0], H0[1]}), g1 = mlp_gelu2(f32x2{H0[2], H0[3]});
+            const f32x2 g2 = mlp_gelu2(f32x2{H1[0], H1[1]}), g3 = mlp_gelu2(f32x2{H1[2], H1[3]});
+            H0 = f32x4{g0.x, g0.y, g1.x, g1.y};
+            H1 = f32x4{g2.x, g2.y, g3.x, g3.y};
+        }
+        // phase 2: Y += W2[:, 16h .. 16h+15] . hidden tile, contraction step i over the hidden channels {4g + i}
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(P2 + (mt * 64 + lane) * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                Y[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], H0[i], Y[mt][0], 0, 0, 0);
+                Y[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], H1[i], Y[mt][1], 0, 0, 0);
+            }
+        }
+        if (h + 1 < HT) {
+            f32x4* dst = reinterpret_cast<f32x4*>(lds + ((h + 1) & 1) * BLK);
+#pragma unroll
+            for (int i = 0; i < NST; ++i)
+                if (BLK4 % NTHR == 0 || tid + i * NTHR < BLK4) dst[tid + i * NTHR] = stage[i];
+        }
+        __syncthreads();
+    }
+
+    if (!valid) return;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = 16 * mt + 4 * kq + i;
+            if (c < C) {
+                const size_t o = base + (size_t)c * T + tok;
+                const float sc = scale[c], sh = shift[c];
+                const f32x2 r = *reinterpret_cast<const f32x2*>(res + o);
+                f32x2 v;
+                v.x = r.x + Y[mt][0][i] * sc + sh;
+                v.y = r.y + Y[mt][1][i] * sc + sh;
+                *reinterpret_cast<f32x2*>(out + o) = v;
+            }
+        }
+    }
+}
+
+constexpr int MLP_WAVES = 4;
+
+}  // namespace
+
+extern "C" int otp_mlp_fused_supported(int C, int HID, int T) {
+    return (C == 136 && HID == 544 && T > 0 && T % 2 == 0) ? 1 : 0;
+}
+
+extern "C" size_t otp_mlp_fused_weight_bytes(int C, int HID) {
+    if (C <= 0 || C % 4 || HID <= 0 || HID % 16) return 0;
+    return (size_t)(HID / 16) * mlp_block_floats(C) * sizeof(float);
+}
+
+extern "C" int otp_mlp_fused_pack(const void* w1, const void* b1, const void* w2, void* packed, int C, int HID,
+                                  void* stream) {
+    if (!w1 || !b1 || !w2 || !packed) return OTP_ERR_BAD_ARG;
+    const size_t bytes = otp_mlp_fused_weight_bytes(C, HID);
+    if (!bytes) return OTP_ERR_UNSUPPORTED;
+    const int total = (int)(bytes / sizeof(float));
+    hipLaunchKernelGGL(mlp_pack_kernel, dim3(otp_ceil_div(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const float*>(w1), static_cast<const float*>(b1), static_cast<const float*>(w2),
+                       static_cast<float*>(packed), C, HID);
+    return otp_launch_status();
+}
+
+extern "C" int otp_mlp_fused(const void* x, const void* packed, const void* scale, const void* shift, const void* res,
+                             void* out, int B, int C, int HID, int T, void* stream) {
+    if (!x || !packed || !scale || !shift || !res || !out || B <= 0) return OTP_ERR_BAD_ARG;
+    if (!otp_mlp_fused_supported(C, HID, T)) return OTP_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(res) | reinterpret_cast<uintptr_t>(out)) & 7 ||
+        reinterpret_cast<uintptr_t>(packed) & 15)
+        return OTP_ERR_BAD_ARG;
+    const int tiles = otp_ceil_div(T, MLP_WAVES * 32);
+    auto f = [](const void* p) { return static_cast<const float*>(p); };
+    const size_t lds = 2 * (size_t)mlp_block_floats(136) * sizeof(float);
+    auto kern = mlp_fused_kernel<136, 544, MLP_WAVES>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(B * tiles)), dim3(MLP_WAVES * 64), lds, static_cast<hipStream_t>(stream),
+                       f(x), f(packed), f(scale), f(shift), f(res), static_cast<float*>(out), T, tiles);
+    return otp_launch_status();
+}

@@ -48,6 +48,8 @@ class InferenceEngine:
             use_graph = os.environ.get("OTPOSE_HIP_GRAPH", "1") != "0"
         self.use_graph = use_graph
         self.use_winograd = os.environ.get("OTPOSE_WINOGRAD", "1") != "0"     # 3x3 stride-1 convs via csrc/wino.hip
+        self.use_fused_mlp = os.environ.get("OTPOSE_FUSED_MLP", "1") != "0"   # transformer MLP via csrc/mlp.hip
+        self.use_dense_cc = os.environ.get("OTPOSE_DENSE_CC", "1") != "0"     # q / k / v / proj via csrc/dense.hip
         # independent sub-graphs (the HRNet branches of a stage, the rows of its fuse layer, the two temporal encoders) are
         # emitted on side HIP streams: inside the captured graph they become parallel branches, so the small-map launches
         # (640-960 workgroups on 512 resident slots) fill each other's tails
@@ -186,6 +188,12 @@ class InferenceEngine:
         return self.conv(inp, conv_mod.weight, out, s, p, dl, bn=bn_mod, bias=conv_mod.bias, act=act, res=res,
                          res_up=res_up, **kw)
 
+    def dense(self, xs, packs, ress, outs, B, C, T):
+        """Emit one otp_dense_cc launch over len(xs) problems."""
+        ax, ap, ar, ao = ops.dense_cc_args(xs, packs, ress, outs)
+        self._keep += [ax, ap, ar, ao, *packs]
+        self.call(self.lib.otp_dense_cc, "otp_dense_cc", ax, ap, ar, ao, len(xs), B, C, T)
+
     def call(self, fn, name, *args):
         def run():
             hip.check(fn(*args, self._stream), name)
@@ -307,9 +315,15 @@ class InferenceEngine:
                   hip.ptr(p(a.value_norm.weight)), hip.ptr(p(a.value_norm.bias)),
                   hip.ptr(qn), hip.ptr(kn), hip.ptr(vn), B, C, T, stride, a.query_norm.eps)
         q, k, v = self.new(B, C, To), self.new(B, C, To), self.new(B, C, To)
-        self.conv(self.v3(qn), a.query.weight, self.v3(q), bias=a.query.bias)
-        self.conv(self.v3(kn), a.key.weight, self.v3(k), bias=a.key.bias)
-        self.conv(self.v3(vn), a.value.weight, self.v3(v), bias=a.value.bias)
+        dense = self.use_dense_cc and ops.dense_cc_supported(C, To)
+        if dense:
+            # the three projections as one launch of the register-resident-input kernel (csrc/dense.hip)
+            packs = [ops.pack_dense_cc(m.weight.to(self.dev), None, m.bias.to(self.dev)) for m in (a.query, a.key, a.value)]
+            self.dense((qn, kn, vn), packs, None, (q, k, v), B, C, To)
+        else:
+            self.conv(self.v3(qn), a.query.weight, self.v3(q), bias=a.query.bias)
+            self.conv(self.v3(kn), a.key.weight, self.v3(k), bias=a.key.bias)
+            self.conv(self.v3(vn), a.value.weight, self.v3(v), bias=a.value.bias)
         att = self.new(B, C, To)
         nbytes = L.otp_chan_attn_workspace(B, C, To, a.n_head)
         ws = self.new(max(nbytes // 4, 1))
@@ -318,15 +332,31 @@ class InferenceEngine:
         # y = pool_skip(x) + scale_attn * (proj(att) + b)   (eval: dropout / drop-path are identities)
         sa = blk.drop_path_attn.scale.detach().reshape(-1)
         y = self.new(B, C, To)
-        self.conv(self.v3(att), a.proj.weight, self.v3(y), scale=sa, shift=a.proj.bias.detach() * sa.to(a.proj.bias.device),
-                  res=self.v3(skip if stride > 1 else x))
+        if dense:
+            sad = sa.to(self.dev, torch.float32)
+            pk = ops.pack_dense_cc(a.proj.weight.to(self.dev), sad, a.proj.bias.detach().to(self.dev) * sad)
+            self.dense((att,), [pk], (skip if stride > 1 else x,), (y,), B, C, To)
+        else:
+            self.conv(self.v3(att), a.proj.weight, self.v3(y), scale=sa,
+                      shift=a.proj.bias.detach() * sa.to(a.proj.bias.device), res=self.v3(skip if stride > 1 else x))
         ln2 = self.new(B, C, To)
         self.call(L.otp_ln_channel, "otp_ln_channel", hip.ptr(y), hip.ptr(p(blk.ln2.weight)), hip.ptr(p(blk.ln2.bias)),
                   hip.ptr(ln2), None, B, C, To, blk.ln2.eps)
-        hdn = self.new(B, 4 * C, To)
-        self.conv(self.v3(ln2), blk.mlp[0].weight, self.v3(hdn), bias=blk.mlp[0].bias, act=ACT_GELU)
         sm = blk.drop_path_mlp.scale.detach().reshape(-1)
         out = self.new(B, C, To)
+        hid = blk.mlp[0].out_channels
+        if self.use_fused_mlp and ops.mlp_fused_supported(C, hid, To):
+            # Conv1d -> GELU -> Conv1d + residual as one launch, hidden activation kept on chip (csrc/mlp.hip)
+            dev = lambda t: t.detach().to(self.dev, torch.float32)     # noqa: E731
+            packed = ops.pack_mlp_weights(dev(blk.mlp[0].weight), dev(blk.mlp[0].bias), dev(blk.mlp[3].weight))
+            scd = dev(sm).contiguous()
+            shd = (dev(blk.mlp[3].bias) * scd).contiguous()
+            self._keep += [packed, scd, shd]
+            self.call(L.otp_mlp_fused, "otp_mlp_fused", hip.ptr(ln2), hip.ptr(packed), hip.ptr(scd), hip.ptr(shd),
+                      hip.ptr(y), hip.ptr(out), B, C, hid, To)
+            return out
+        hdn = self.new(B, 4 * C, To)
+        self.conv(self.v3(ln2), blk.mlp[0].weight, self.v3(hdn), bias=blk.mlp[0].bias, act=ACT_GELU)
         self.conv(self.v3(hdn), blk.mlp[3].weight, self.v3(out), scale=sm,
                   shift=blk.mlp[3].bias.detach() * sm.to(blk.mlp[3].bias.device), res=self.v3(y))
         return out

@@ -65,6 +65,14 @@ SIGNATURES = {
     "otp_ln_channel": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_float, c_void_p]),
     "otp_dwconv_ln3": (c_int, [c_void_p] * 13 + [c_int] * 4 + [c_float, c_void_p]),
     "otp_chan_attn_workspace": (c_size_t, [c_int] * 4),
+    "otp_dense_cc_supported": (c_int, [c_int] * 2),
+    "otp_dense_cc_weight_bytes": (c_size_t, [c_int]),
+    "otp_dense_cc_pack": (c_int, [c_void_p] * 4 + [c_int, c_void_p]),
+    "otp_dense_cc": (c_int, [ctypes.POINTER(c_void_p)] * 4 + [c_int] * 4 + [c_void_p]),
+    "otp_mlp_fused_supported": (c_int, [c_int] * 3),
+    "otp_mlp_fused_weight_bytes": (c_size_t, [c_int] * 2),
+    "otp_mlp_fused_pack": (c_int, [c_void_p] * 4 + [c_int] * 2 + [c_void_p]),
+    "otp_mlp_fused": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_void_p]),
     "otp_chan_attn": (c_int, [c_void_p] * 4 + [c_void_p, c_size_t] + [c_int] * 4 + [c_float, c_void_p]),
     "otp_chan_attn_splits": (c_int, [c_int, c_int]),
     "otp_chan_attn_scores": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p]),

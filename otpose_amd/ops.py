@@ -9,6 +9,8 @@ callers that bind the native module directly.
 """
 from __future__ import annotations
 
+import ctypes
+
 import torch
 from torch.autograd import Function
 
@@ -322,6 +324,79 @@ def pack_wino_weight(weight):
     u = torch.empty(L.otp_conv2d_wino_weight_bytes(cout, cin) // 4, dtype=torch.float32, device=w.device)
     hip.check(L.otp_conv2d_wino_pack_weight(hip.ptr(w), hip.ptr(u), cout, cin, hip.stream_of(w)), "otp_conv2d_wino_pack_weight")
     return u
+
+
+def dense_cc_supported(c, t) -> bool:
+    return bool(hip.lib().otp_dense_cc_supported(int(c), int(t)))
+
+
+def pack_dense_cc(weight, scale=None, shift=None):
+    """(C, C[, 1]) pointwise weight (+ per-output-channel scale / shift) -> the per-16-row fragment image of
+    :func:`dense_cc` (MaskedMHCA query / key / value / proj, model/blocks.py:383-386)."""
+    _require_gpu(weight)
+    c = weight.shape[0]
+    L = hip.lib()
+    nbytes = L.otp_dense_cc_weight_bytes(c)
+    if not nbytes or weight.shape[1] != c:
+        raise RuntimeError(f"otp_dense_cc: unsupported weight shape {tuple(weight.shape)}")
+    f = lambda t: None if t is None else t.detach().to(weight.device, torch.float32).contiguous()   # noqa: E731
+    w, sc, sh = f(weight), f(scale), f(shift)
+    packed = torch.empty(nbytes // 4, dtype=torch.float32, device=weight.device)
+    hip.check(L.otp_dense_cc_pack(hip.ptr(w), hip.ptr(sc), hip.ptr(sh), hip.ptr(packed), c, hip.stream_of(w)),
+              "otp_dense_cc_pack")
+    return packed
+
+
+def dense_cc_args(xs, packs, ress, outs):
+    """ctypes pointer arrays for :func:`dense_cc_launch` (kept by the caller while launches may still be issued)."""
+    n = len(xs)
+    arr = lambda ts: (ctypes.c_void_p * n)(*[hip.ptr(t) for t in ts])     # noqa: E731
+    return arr(xs), arr(packs), arr(ress if ress is not None else [None] * n), arr(outs)
+
+
+def dense_cc(xs, packs, ress=None, outs=None, stream=None):
+    """out[p] = scale[p] * (W[p] . x[p]) + shift[p] (+ res[p]) for up to three (B, C, T) problems in one launch."""
+    _require_gpu(*xs)
+    b, c, t = xs[0].shape
+    outs = [torch.empty_like(x) for x in xs] if outs is None else outs
+    ax, ap, ar, ao = dense_cc_args(xs, packs, ress, outs)
+    hip.check(hip.lib().otp_dense_cc(ax, ap, ar, ao, len(xs), b, c, t, stream if stream is not None else hip.stream_of(xs[0])),
+              "otp_dense_cc")
+    return outs
+
+
+def mlp_fused_supported(c, hid, t) -> bool:
+    return bool(hip.lib().otp_mlp_fused_supported(int(c), int(hid), int(t)))
+
+
+def pack_mlp_weights(w1, b1, w2):
+    """Conv1d(C,4C,1) / Conv1d(4C,C,1) weights of a TransformerBlock MLP (model/blocks.py:248-254) -> the per-hidden-block
+    fragment image :func:`mlp_fused` streams through LDS."""
+    _require_gpu(w1, b1, w2)
+    hid, c = w1.shape[:2]
+    L = hip.lib()
+    nbytes = L.otp_mlp_fused_weight_bytes(c, hid)
+    if not nbytes:
+        raise RuntimeError(f"otp_mlp_fused: unsupported widths C={c}, HID={hid}")
+    packed = torch.empty(nbytes // 4, dtype=torch.float32, device=w1.device)
+    w1c, w2c, b1c = (t.detach().contiguous().float() for t in (w1, w2, b1))
+    hip.check(L.otp_mlp_fused_pack(hip.ptr(w1c), hip.ptr(b1c), hip.ptr(w2c), hip.ptr(packed), c, hid, hip.stream_of(w1c)),
+              "otp_mlp_fused_pack")
+    return packed
+
+
+def mlp_fused(x, packed, scale, shift, res, out=None, hid=None, stream=None):
+    """out = res + scale * (W2 . gelu(W1 . x + b1)) + shift on (B, C, T) tensors, one launch (eval-mode MLP half of
+    TransformerBlock.forward, model/blocks.py:277-279)."""
+    _require_gpu(x, packed, res)
+    _check_f32(x)
+    b, c, t = x.shape
+    hid = 4 * c if hid is None else hid
+    out = torch.empty_like(x) if out is None else out
+    hip.check(hip.lib().otp_mlp_fused(hip.ptr(x), hip.ptr(packed), hip.ptr(scale), hip.ptr(shift), hip.ptr(res),
+                                      hip.ptr(out), b, c, hid, t, stream if stream is not None else hip.stream_of(x)),
+              "otp_mlp_fused")
+    return out
 
 
 def wino_supported(desc) -> bool:

@@ -212,6 +212,46 @@ def test_loss_matches_golden_and_oracle(golden):
     _close(r2["final_loss"].reshape(()), ref2["final_loss"].reshape(()), 1e-5)
 
 
+@pytest.mark.parametrize("T", [32, 250, 1152])
+def test_mlp_fused_matches_fp64(T):
+    """csrc/mlp.hip vs the MLP half of TransformerBlock.forward (model/blocks.py:248-254, 277-279) in fp64; T = 250 leaves
+    a ragged last workgroup and half-empty waves."""
+    B, C, HID = 2, 136, 544
+    x, res = seeded((B, C, T), 11), seeded((B, C, T), 12)
+    w1, w2 = seeded((HID, C, 1), 13) / C ** 0.5, seeded((C, HID, 1), 14) / HID ** 0.5
+    b1, b2, sc = seeded((HID,), 15) * 0.5, seeded((C,), 16), seeded((C,), 17)
+    hidden = F.gelu(F.conv1d(x.double(), w1.double(), b1.double()))
+    ref = res.double() + sc.double()[None, :, None] * F.conv1d(hidden, w2.double(), b2.double())
+    assert ops.mlp_fused_supported(C, HID, T) and not ops.mlp_fused_supported(C, HID, T + 1)
+    packed = ops.pack_mlp_weights(w1.cuda(), b1.cuda(), w2.cuda())
+    out = ops.mlp_fused(x.cuda(), packed, sc.cuda(), (b2 * sc).cuda(), res.cuda())
+    _close(out, ref.float(), 2e-6)
+    # in place on the residual (the engine may alias them)
+    r2 = res.cuda().clone()
+    ops.mlp_fused(x.cuda(), packed, sc.cuda(), (b2 * sc).cuda(), r2, out=r2)
+    assert torch.equal(r2, out)
+
+
+@pytest.mark.parametrize("T", [32, 250, 1152])
+def test_dense_cc_matches_fp64(T):
+    """csrc/dense.hip vs the pointwise projections of MaskedMHCA (model/blocks.py:383-386) in fp64: three problems in one
+    launch (bias only, like query / key / value) and one with scale, shift and residual (like proj + drop-path scale)."""
+    B, C = 2, 136
+    xs = [seeded((B, C, T), 21 + i) for i in range(3)]
+    ws = [seeded((C, C, 1), 31 + i) / C ** 0.5 for i in range(3)]
+    bs = [seeded((C,), 41 + i) for i in range(3)]
+    assert ops.dense_cc_supported(C, T) and not ops.dense_cc_supported(C, T + 1) and not ops.dense_cc_supported(17, T)
+    packs = [ops.pack_dense_cc(w.cuda(), None, b.cuda()) for w, b in zip(ws, bs)]
+    outs = ops.dense_cc([x.cuda() for x in xs], packs)
+    for x, w, b, o in zip(xs, ws, bs, outs):
+        _close(o, F.conv1d(x.double(), w.double(), b.double()).float(), 2e-6)
+    sc, res = seeded((C,), 51), seeded((B, C, T), 52)
+    pk = ops.pack_dense_cc(ws[0].cuda(), sc.cuda(), (bs[0] * sc).cuda())
+    (o,) = ops.dense_cc([xs[1].cuda()], [pk], [res.cuda()])
+    ref = res.double() + sc.double()[None, :, None] * F.conv1d(xs[1].double(), ws[0].double(), bs[0].double())
+    _close(o, ref.float(), 2e-6)
+
+
 def test_joints_losses_match_golden_and_oracle(golden):
     """JointsMSE_OHKMMSELoss / JointMSELoss (model/loss.py:95-182): values vs reference-generated goldens, gradients and
     the use_target_weight=False / effective_num_joints forms vs the oracle."""
