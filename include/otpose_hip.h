@@ -190,6 +190,18 @@ int otp_dense_cc_pack(const void* w, const void* scale, const void* shift, void*
 int otp_dense_cc(const void* const* x, const void* const* packed, const void* const* res, void* const* out, int nprob,
                  int B, int C, int T, void* stream);
 
+/* Attention front end of MaskedMHCA.forward for stride 1 (model/blocks.py:406-419): q, k, v = W_p . LN_p(dwconv3_p(x)) + b_p,
+ * i.e. otp_dwconv_ln3 followed by the three projections, in one launch without the (B, C, T) intermediates.  x, q, k, v
+ * (B, C, T); `table` = otp_qkv_front_pack_table's image of the three depthwise weights (C, 3) and LayerNorm gamma / beta (C)
+ * (otp_qkv_front_table_bytes bytes); packed_q/k/v = otp_dense_cc_pack(W_p, NULL, b_p).  Supported when
+ * otp_dense_cc_supported(C, T). */
+size_t otp_qkv_front_table_bytes(int C);
+int otp_qkv_front_pack_table(const void* dwq, const void* dwk, const void* dwv, const void* gq, const void* bq,
+                             const void* gk, const void* bk, const void* gv, const void* bv, void* table, int C,
+                             void* stream);
+int otp_qkv_front(const void* x, const void* table, const void* packed_q, const void* packed_k, const void* packed_v,
+                  void* q, void* k, void* v, int B, int C, int T, float eps, void* stream);
+
 /* out = act(res + nearest_upsample_f(low)) on channel slices (HRNet fuse layers with f >= 4, model/HRNet.py:426-439,
  * 488-494; `res` may alias `out`); low (N, low_ctot, Hl, Wl), res / out (N, *_ctot, Hl*f, Wl*f); relu != 0 applies ReLU */
 int otp_upsample_add(const void* low, const void* res, void* out, int N, int C, int Hl, int Wl, int f, int relu,

@@ -50,6 +50,7 @@ class InferenceEngine:
         self.use_winograd = os.environ.get("OTPOSE_WINOGRAD", "1") != "0"     # 3x3 stride-1 convs via csrc/wino.hip
         self.use_fused_mlp = os.environ.get("OTPOSE_FUSED_MLP", "1") != "0"   # transformer MLP via csrc/mlp.hip
         self.use_dense_cc = os.environ.get("OTPOSE_DENSE_CC", "1") != "0"     # q / k / v / proj via csrc/dense.hip
+        self.use_qkv_front = os.environ.get("OTPOSE_QKV_FRONT", "1") != "0"   # + dwconv / LayerNorm fused in front of them
         # independent sub-graphs (the HRNet branches of a stage, the rows of its fuse layer, the two temporal encoders) are
         # emitted on side HIP streams: inside the captured graph they become parallel branches, so the small-map launches
         # (640-960 workgroups on 512 resident slots) fill each other's tails
@@ -307,23 +308,33 @@ class InferenceEngine:
         p = self.dev_param
         self.call(L.otp_ln_channel, "otp_ln_channel", hip.ptr(x), hip.ptr(p(blk.ln1.weight)), hip.ptr(p(blk.ln1.bias)),
                   hip.ptr(ln1), hip.ptr(skip), B, C, T, blk.ln1.eps)
-        qn, kn, vn = self.new(B, C, To), self.new(B, C, To), self.new(B, C, To)
-        self.call(L.otp_dwconv_ln3, "otp_dwconv_ln3", hip.ptr(ln1), hip.ptr(p(a.query_conv.weight)),
-                  hip.ptr(p(a.key_conv.weight)), hip.ptr(p(a.value_conv.weight)),
-                  hip.ptr(p(a.query_norm.weight)), hip.ptr(p(a.query_norm.bias)),
-                  hip.ptr(p(a.key_norm.weight)), hip.ptr(p(a.key_norm.bias)),
-                  hip.ptr(p(a.value_norm.weight)), hip.ptr(p(a.value_norm.bias)),
-                  hip.ptr(qn), hip.ptr(kn), hip.ptr(vn), B, C, T, stride, a.query_norm.eps)
         q, k, v = self.new(B, C, To), self.new(B, C, To), self.new(B, C, To)
         dense = self.use_dense_cc and ops.dense_cc_supported(C, To)
         if dense:
-            # the three projections as one launch of the register-resident-input kernel (csrc/dense.hip)
             packs = [ops.pack_dense_cc(m.weight.to(self.dev), None, m.bias.to(self.dev)) for m in (a.query, a.key, a.value)]
-            self.dense((qn, kn, vn), packs, None, (q, k, v), B, C, To)
+        if dense and stride == 1 and self.use_qkv_front:
+            # depthwise convs + LayerNorms + the three projections in one launch (csrc/dense.hip, qkv_front_kernel)
+            table = ops.pack_qkv_table(*[p(t) for t in (a.query_conv.weight, a.key_conv.weight, a.value_conv.weight,
+                                                         a.query_norm.weight, a.query_norm.bias, a.key_norm.weight,
+                                                         a.key_norm.bias, a.value_norm.weight, a.value_norm.bias)])
+            self._keep += [table, *packs]
+            self.call(L.otp_qkv_front, "otp_qkv_front", hip.ptr(ln1), hip.ptr(table), *[hip.ptr(t) for t in packs],
+                      hip.ptr(q), hip.ptr(k), hip.ptr(v), B, C, T, a.query_norm.eps)
         else:
-            self.conv(self.v3(qn), a.query.weight, self.v3(q), bias=a.query.bias)
-            self.conv(self.v3(kn), a.key.weight, self.v3(k), bias=a.key.bias)
-            self.conv(self.v3(vn), a.value.weight, self.v3(v), bias=a.value.bias)
+            qn, kn, vn = self.new(B, C, To), self.new(B, C, To), self.new(B, C, To)
+            self.call(L.otp_dwconv_ln3, "otp_dwconv_ln3", hip.ptr(ln1), hip.ptr(p(a.query_conv.weight)),
+                      hip.ptr(p(a.key_conv.weight)), hip.ptr(p(a.value_conv.weight)),
+                      hip.ptr(p(a.query_norm.weight)), hip.ptr(p(a.query_norm.bias)),
+                      hip.ptr(p(a.key_norm.weight)), hip.ptr(p(a.key_norm.bias)),
+                      hip.ptr(p(a.value_norm.weight)), hip.ptr(p(a.value_norm.bias)),
+                      hip.ptr(qn), hip.ptr(kn), hip.ptr(vn), B, C, T, stride, a.query_norm.eps)
+            if dense:
+                # the three projections as one launch of the register-resident-input kernel (csrc/dense.hip)
+                self.dense((qn, kn, vn), packs, None, (q, k, v), B, C, To)
+            else:
+                self.conv(self.v3(qn), a.query.weight, self.v3(q), bias=a.query.bias)
+                self.conv(self.v3(kn), a.key.weight, self.v3(k), bias=a.key.bias)
+                self.conv(self.v3(vn), a.value.weight, self.v3(v), bias=a.value.bias)
         att = self.new(B, C, To)
         nbytes = L.otp_chan_attn_workspace(B, C, To, a.n_head)
         ws = self.new(max(nbytes // 4, 1))

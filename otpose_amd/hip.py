@@ -69,6 +69,9 @@ SIGNATURES = {
     "otp_dense_cc_weight_bytes": (c_size_t, [c_int]),
     "otp_dense_cc_pack": (c_int, [c_void_p] * 4 + [c_int, c_void_p]),
     "otp_dense_cc": (c_int, [ctypes.POINTER(c_void_p)] * 4 + [c_int] * 4 + [c_void_p]),
+    "otp_qkv_front_table_bytes": (c_size_t, [c_int]),
+    "otp_qkv_front_pack_table": (c_int, [c_void_p] * 10 + [c_int, c_void_p]),
+    "otp_qkv_front": (c_int, [c_void_p] * 8 + [c_int] * 3 + [c_float, c_void_p]),
     "otp_mlp_fused_supported": (c_int, [c_int] * 3),
     "otp_mlp_fused_weight_bytes": (c_size_t, [c_int] * 2),
     "otp_mlp_fused_pack": (c_int, [c_void_p] * 4 + [c_int] * 2 + [c_void_p]),

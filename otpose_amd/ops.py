@@ -365,6 +365,29 @@ def dense_cc(xs, packs, ress=None, outs=None, stream=None):
     return outs
 
 
+def pack_qkv_table(dwq, dwk, dwv, gq, bq, gk, bk, gv, bv):
+    """Depthwise (C, 1, 3) weights and LayerNorm (C) gamma / beta of MaskedMHCA's query / key / value paths
+    (model/blocks.py:359-381) -> the per-channel table of :func:`qkv_front`."""
+    ts = [t.detach().float().contiguous() for t in (dwq, dwk, dwv, gq, bq, gk, bk, gv, bv)]
+    _require_gpu(*ts)
+    c = ts[3].numel()
+    L = hip.lib()
+    table = torch.empty(L.otp_qkv_front_table_bytes(c) // 4, dtype=torch.float32, device=ts[0].device)
+    hip.check(L.otp_qkv_front_pack_table(*[hip.ptr(t) for t in ts], hip.ptr(table), c, hip.stream_of(ts[0])),
+              "otp_qkv_front_pack_table")
+    return table
+
+
+def qkv_front(x, table, packs, eps=1e-5, outs=None, stream=None):
+    """q, k, v = W_p . LN_p(dwconv3_p(x)) + b_p (stride 1) in one launch; ``packs`` = three :func:`pack_dense_cc` images."""
+    _require_gpu(x, table)
+    b, c, t = x.shape
+    outs = [torch.empty_like(x) for _ in range(3)] if outs is None else outs
+    hip.check(hip.lib().otp_qkv_front(hip.ptr(x), hip.ptr(table), *[hip.ptr(p) for p in packs], *[hip.ptr(o) for o in outs],
+                                      b, c, t, eps, stream if stream is not None else hip.stream_of(x)), "otp_qkv_front")
+    return outs
+
+
 def mlp_fused_supported(c, hid, t) -> bool:
     return bool(hip.lib().otp_mlp_fused_supported(int(c), int(hid), int(t)))
 

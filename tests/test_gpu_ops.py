@@ -252,6 +252,35 @@ def test_dense_cc_matches_fp64(T):
     _close(o, ref.float(), 2e-6)
 
 
+@pytest.mark.parametrize("T", [32, 250, 1152])
+def test_qkv_front_matches_fp64(T):
+    """csrc/dense.hip qkv_front vs MaskedMHCA's depthwise conv -> channel LayerNorm -> pointwise projection chain
+    (model/blocks.py:406-419, LayerNorm of :95-110) in fp64, and vs the two-launch path it replaces."""
+    B, C, eps = 2, 136, 1e-5
+    x = seeded((B, C, T), 61)
+    dws = [seeded((C, 1, 3), 62 + i) * 0.6 for i in range(3)]
+    gs = [1.0 + 0.3 * seeded((C,), 65 + i) for i in range(3)]
+    bs = [0.2 * seeded((C,), 68 + i) for i in range(3)]
+    ws = [seeded((C, C, 1), 71 + i) / C ** 0.5 for i in range(3)]
+    cb = [seeded((C,), 74 + i) for i in range(3)]
+    table = ops.pack_qkv_table(dws[0].cuda(), dws[1].cuda(), dws[2].cuda(), gs[0].cuda(), bs[0].cuda(), gs[1].cuda(),
+                               bs[1].cuda(), gs[2].cuda(), bs[2].cuda())
+    packs = [ops.pack_dense_cc(w.cuda(), None, b.cuda()) for w, b in zip(ws, cb)]
+    outs = ops.qkv_front(x.cuda(), table, packs, eps)
+    for i in range(3):
+        d = F.conv1d(x.double(), dws[i].double(), None, 1, 1, 1, C)
+        mu = d.mean(1, keepdim=True)
+        r = d - mu
+        ln = r / torch.sqrt((r * r).mean(1, keepdim=True) + eps) * gs[i].double()[None, :, None] + bs[i].double()[None, :, None]
+        ref = F.conv1d(ln, ws[i].double(), cb[i].double())
+        _close(outs[i], ref.float(), 3e-6)
+    qn, kn, vn = ops.dwconv_ln3(x.cuda(), [t.cuda().contiguous() for t in dws], [t.cuda() for t in gs],
+                                [t.cuda() for t in bs], 1, eps)
+    two = ops.dense_cc([qn, kn, vn], packs)
+    for a, b in zip(outs, two):
+        _close(a, b.cpu(), 3e-6)
+
+
 def test_joints_losses_match_golden_and_oracle(golden):
     """JointsMSE_OHKMMSELoss / JointMSELoss (model/loss.py:95-182): values vs reference-generated goldens, gradients and
     the use_target_weight=False / effective_num_joints forms vs the oracle."""

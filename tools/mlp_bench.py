@@ -86,3 +86,28 @@ def dense_main():
 
 if __name__ == "__main__":
     dense_main()
+
+
+def qkv_main():
+    B, C = 16, 136
+    g = torch.Generator().manual_seed(2)
+    r = lambda *s: torch.randn(*s, generator=g).cuda()       # noqa: E731
+    for T in (6912,):
+        x = r(B, C, T)
+        dws, gs, bs = [r(C, 1, 3) for _ in range(3)], [r(C) for _ in range(3)], [r(C) for _ in range(3)]
+        ws, cb = [r(C, C, 1) / C ** 0.5 for _ in range(3)], [r(C) for _ in range(3)]
+        table = ops.pack_qkv_table(*dws, gs[0], bs[0], gs[1], bs[1], gs[2], bs[2])
+        packs = [ops.pack_dense_cc(w, None, b) for w, b in zip(ws, cb)]
+        outs = [torch.empty_like(x) for _ in range(3)]
+        tf = timeit(lambda: ops.qkv_front(x, table, packs, 1e-5, outs))
+        mids = [torch.empty_like(x) for _ in range(3)]
+
+        def two():
+            m = ops.dwconv_ln3(x, dws, gs, bs, 1, 1e-5)
+            ops.dense_cc(m, packs, None, mids)
+        t2 = timeit(two)
+        print(f"T={T}: qkv_front {tf:.1f} us   dwconv_ln3 + dense_cc x3 {t2:.1f} us   max|diff| {float((outs[0] - mids[0]).abs().max())}")
+
+
+if __name__ == "__main__":
+    qkv_main()
