@@ -177,6 +177,10 @@ size_t otp_mlp_fused_weight_bytes(int C, int HID);
 int otp_mlp_fused_pack(const void* w1, const void* b1, const void* w2, void* packed, int C, int HID, void* stream);
 int otp_mlp_fused(const void* x, const void* packed, const void* scale, const void* shift, const void* res, void* out,
                   int B, int C, int HID, int T, void* stream);
+/* the same with TransformerBlock.ln2 in front (model/blocks.py:277: out = y + drop_path_mlp(mlp(ln2(y)))):
+ *   out = y + scale * (W2 . gelu(W1 . LN(y) + b1)) + shift, LN over channels with gamma / beta (C), eps inside the root. */
+int otp_ln_mlp_fused(const void* y, const void* ln_gamma, const void* ln_beta, float ln_eps, const void* packed,
+                     const void* scale, const void* shift, void* out, int B, int C, int HID, int T, void* stream);
 
 /* The C -> C pointwise projections of MaskedMHCA (query / key / value / proj: model/blocks.py:383-386, applied at :417-419
  * and :450) on (B, C, T) tensors, nprob (1..3) independent problems of one shape per launch:

@@ -49,6 +49,12 @@ __device__ __forceinline__ f32x2 mlp_gelu2(f32x2 x) {
     return hx * e + hx;
 }
 
+__device__ __forceinline__ float kslot_sum(float v) {      // sum over the four k-slot lane groups (lanes n, n+16, n+32, n+48)
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
 // floats per hidden block, padded to whole 16-byte-per-thread passes of a 256-thread workgroup
 constexpr int mlp_block_floats(int C) { return (((C / 4 + 3) / 4 + (C + 15) / 16) * 256 + 16 + 1023) / 1024 * 1024; }
 
@@ -73,10 +79,14 @@ __global__ void mlp_pack_kernel(const float* __restrict__ w1, const float* __res
     packed[idx] = v;
 }
 
-template <int C, int HID, int WAVES>
+// LN: x is the block's un-normalised input and the kernel applies the channel LayerNorm in front of the MLP itself
+// (TransformerBlock.ln2, model/blocks.py:95-110: biased variance, eps inside the root) - a token's channels are the wave's
+// k-steps x the four k-slot lane groups, so its statistics are an in-lane sum and two cross-lane adds.
+template <int C, int HID, int WAVES, bool LN>
 __global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void mlp_fused_kernel(
     const float* __restrict__ x, const float* __restrict__ packed, const float* __restrict__ scale,
-    const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ out, int T, int tiles_per_b) {
+    const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ out, int T, int tiles_per_b,
+    const float* __restrict__ ln_gamma, const float* __restrict__ ln_beta, float ln_eps) {
     constexpr int KS = C / 4, KG = (KS + 3) / 4, HT = HID / 16, MT = (C + 15) / 16;
     constexpr int BLK = mlp_block_floats(C), BLK4 = BLK / 4, NTHR = WAVES * 64, NST = (BLK4 + NTHR - 1) / NTHR;
     extern __shared__ float lds[];                    // 2 x BLK floats
@@ -98,6 +108,28 @@ __global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void mlp_fused_kernel(
 #pragma unroll
     for (int s = 0; s < KS; ++s)       // columns past T read the last pair instead (their results are never stored)
         X[s] = *reinterpret_cast<const f32x2*>(x + base + (size_t)(4 * s + kq) * T + (valid ? tok : T - 2));
+    if (LN) {
+        constexpr float inv_c = 1.f / (float)C;
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) { s0 += X[s].x; s1 += X[s].y; }
+        const float m0 = kslot_sum(s0) * inv_c, m1 = kslot_sum(s1) * inv_c;
+        float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            X[s].x -= m0;
+            X[s].y -= m1;
+            v0 += X[s].x * X[s].x;
+            v1 += X[s].y * X[s].y;
+        }
+        const float r0 = 1.f / sqrtf(kslot_sum(v0) * inv_c + ln_eps), r1 = 1.f / sqrtf(kslot_sum(v1) * inv_c + ln_eps);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const float g = ln_gamma[4 * s + kq], be = ln_beta[4 * s + kq];
+            X[s].x = X[s].x * r0 * g + be;
+            X[s].y = X[s].y * r1 * g + be;
+        }
+    }
     f32x4 Y[MT][2];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) { Y[mt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; Y[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -199,8 +231,9 @@ extern "C" int otp_mlp_fused_pack(const void* w1, const void* b1, const void* w2
     return otp_launch_status();
 }
 
-extern "C" int otp_mlp_fused(const void* x, const void* packed, const void* scale, const void* shift, const void* res,
-                             void* out, int B, int C, int HID, int T, void* stream) {
+namespace {
+int mlp_launch(const void* x, const void* packed, const void* scale, const void* shift, const void* res, void* out,
+               const void* ln_gamma, const void* ln_beta, float ln_eps, int B, int C, int HID, int T, void* stream) {
     if (!x || !packed || !scale || !shift || !res || !out || B <= 0) return OTP_ERR_BAD_ARG;
     if (!otp_mlp_fused_supported(C, HID, T)) return OTP_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(res) | reinterpret_cast<uintptr_t>(out)) & 7 ||
@@ -209,8 +242,22 @@ extern "C" int otp_mlp_fused(const void* x, const void* packed, const void* scal
     const int tiles = otp_ceil_div(T, MLP_WAVES * 32);
     auto f = [](const void* p) { return static_cast<const float*>(p); };
     const size_t lds = 2 * (size_t)mlp_block_floats(136) * sizeof(float);
-    auto kern = mlp_fused_kernel<136, 544, MLP_WAVES>;
+    auto kern = ln_gamma ? mlp_fused_kernel<136, 544, MLP_WAVES, true> : mlp_fused_kernel<136, 544, MLP_WAVES, false>;
     hipLaunchKernelGGL(kern, dim3((unsigned)(B * tiles)), dim3(MLP_WAVES * 64), lds, static_cast<hipStream_t>(stream),
-                       f(x), f(packed), f(scale), f(shift), f(res), static_cast<float*>(out), T, tiles);
+                       f(x), f(packed), f(scale), f(shift), f(res), static_cast<float*>(out), T, tiles, f(ln_gamma),
+                       f(ln_beta), ln_eps);
     return otp_launch_status();
+}
+}  // namespace
+
+extern "C" int otp_mlp_fused(const void* x, const void* packed, const void* scale, const void* shift, const void* res,
+                             void* out, int B, int C, int HID, int T, void* stream) {
+    return mlp_launch(x, packed, scale, shift, res, out, nullptr, nullptr, 0.f, B, C, HID, T, stream);
+}
+
+extern "C" int otp_ln_mlp_fused(const void* y, const void* ln_gamma, const void* ln_beta, float ln_eps, const void* packed,
+                                const void* scale, const void* shift, void* out, int B, int C, int HID, int T,
+                                void* stream) {
+    if (!ln_gamma || !ln_beta) return OTP_ERR_BAD_ARG;
+    return mlp_launch(y, packed, scale, shift, y, out, ln_gamma, ln_beta, ln_eps, B, C, HID, T, stream);
 }

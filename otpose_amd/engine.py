@@ -350,22 +350,22 @@ class InferenceEngine:
         else:
             self.conv(self.v3(att), a.proj.weight, self.v3(y), scale=sa,
                       shift=a.proj.bias.detach() * sa.to(a.proj.bias.device), res=self.v3(skip if stride > 1 else x))
-        ln2 = self.new(B, C, To)
-        self.call(L.otp_ln_channel, "otp_ln_channel", hip.ptr(y), hip.ptr(p(blk.ln2.weight)), hip.ptr(p(blk.ln2.bias)),
-                  hip.ptr(ln2), None, B, C, To, blk.ln2.eps)
         sm = blk.drop_path_mlp.scale.detach().reshape(-1)
         out = self.new(B, C, To)
         hid = blk.mlp[0].out_channels
         if self.use_fused_mlp and ops.mlp_fused_supported(C, hid, To):
-            # Conv1d -> GELU -> Conv1d + residual as one launch, hidden activation kept on chip (csrc/mlp.hip)
+            # ln2 -> Conv1d -> GELU -> Conv1d + residual as one launch, hidden activation kept on chip (csrc/mlp.hip)
             dev = lambda t: t.detach().to(self.dev, torch.float32)     # noqa: E731
             packed = ops.pack_mlp_weights(dev(blk.mlp[0].weight), dev(blk.mlp[0].bias), dev(blk.mlp[3].weight))
             scd = dev(sm).contiguous()
             shd = (dev(blk.mlp[3].bias) * scd).contiguous()
             self._keep += [packed, scd, shd]
-            self.call(L.otp_mlp_fused, "otp_mlp_fused", hip.ptr(ln2), hip.ptr(packed), hip.ptr(scd), hip.ptr(shd),
-                      hip.ptr(y), hip.ptr(out), B, C, hid, To)
+            self.call(L.otp_ln_mlp_fused, "otp_ln_mlp_fused", hip.ptr(y), hip.ptr(p(blk.ln2.weight)), hip.ptr(p(blk.ln2.bias)),
+                      blk.ln2.eps, hip.ptr(packed), hip.ptr(scd), hip.ptr(shd), hip.ptr(out), B, C, hid, To)
             return out
+        ln2 = self.new(B, C, To)
+        self.call(L.otp_ln_channel, "otp_ln_channel", hip.ptr(y), hip.ptr(p(blk.ln2.weight)), hip.ptr(p(blk.ln2.bias)),
+                  hip.ptr(ln2), None, B, C, To, blk.ln2.eps)
         hdn = self.new(B, 4 * C, To)
         self.conv(self.v3(ln2), blk.mlp[0].weight, self.v3(hdn), bias=blk.mlp[0].bias, act=ACT_GELU)
         self.conv(self.v3(hdn), blk.mlp[3].weight, self.v3(out), scale=sm,

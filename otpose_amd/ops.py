@@ -326,6 +326,20 @@ def pack_wino_weight(weight):
     return u
 
 
+def ln_mlp_fused(y, gamma, beta, eps, packed, scale, shift, out=None, hid=None, stream=None):
+    """out = y + scale * (W2 . gelu(W1 . LN(y) + b1)) + shift: ln2 + MLP + residual of TransformerBlock.forward
+    (model/blocks.py:277-279) in one launch."""
+    _require_gpu(y, packed)
+    _check_f32(y)
+    b, c, t = y.shape
+    hid = 4 * c if hid is None else hid
+    out = torch.empty_like(y) if out is None else out
+    hip.check(hip.lib().otp_ln_mlp_fused(hip.ptr(y), hip.ptr(gamma), hip.ptr(beta), eps, hip.ptr(packed), hip.ptr(scale),
+                                         hip.ptr(shift), hip.ptr(out), b, c, hid, t,
+                                         stream if stream is not None else hip.stream_of(y)), "otp_ln_mlp_fused")
+    return out
+
+
 def dense_cc_supported(c, t) -> bool:
     return bool(hip.lib().otp_dense_cc_supported(int(c), int(t)))
 

@@ -226,6 +226,15 @@ def test_mlp_fused_matches_fp64(T):
     packed = ops.pack_mlp_weights(w1.cuda(), b1.cuda(), w2.cuda())
     out = ops.mlp_fused(x.cuda(), packed, sc.cuda(), (b2 * sc).cuda(), res.cuda())
     _close(out, ref.float(), 2e-6)
+    # ln2 in front (otp_ln_mlp_fused): the residual is the un-normalised input
+    g, be = 1.0 + 0.3 * seeded((C,), 18), 0.2 * seeded((C,), 19)
+    mu = res.double().mean(1, keepdim=True)
+    rc = res.double() - mu
+    ln = rc / torch.sqrt((rc * rc).mean(1, keepdim=True) + 1e-5) * g.double()[None, :, None] + be.double()[None, :, None]
+    ref_ln = res.double() + sc.double()[None, :, None] * F.conv1d(F.gelu(F.conv1d(ln, w1.double(), b1.double())), w2.double(),
+                                                                  b2.double())
+    out_ln = ops.ln_mlp_fused(res.cuda(), g.cuda(), be.cuda(), 1e-5, packed, sc.cuda(), (b2 * sc).cuda())
+    _close(out_ln, ref_ln.float(), 3e-6)
     # in place on the residual (the engine may alias them)
     r2 = res.cuda().clone()
     ops.mlp_fused(x.cuda(), packed, sc.cuda(), (b2 * sc).cuda(), r2, out=r2)
