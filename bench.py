@@ -136,7 +136,22 @@ def kernel_rooflines(dev, batch):
              "achieved": dcn_bytes / (t_dcn * 1e-3) / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
              "frac": dcn_bytes / (t_dcn * 1e-3) / PEAK_HBM, "traffic": measured_traffic("mdcn_fwd_17x96x72_x16"),
              "ms_per_launch": t_dcn, "algorithmic_bytes_per_launch": dcn_bytes}
-    return conv, dcn_r
+    # one TransformerBlock ln2 + MLP launch of a temporal encoder (C = 136, hidden 544, T = 96*72) over the batch
+    C, HID, T = 136, 544, 96 * 72
+    xm = torch.randn(batch, C, T, generator=g).to(dev)
+    w1, w2 = (torch.randn(HID, C, 1, generator=g) / C ** 0.5).to(dev), (torch.randn(C, HID, 1, generator=g) / HID ** 0.5).to(dev)
+    b1, one, zero = torch.zeros(HID, device=dev), torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    om = torch.empty_like(xm)
+    mlp_r = None
+    if ops.mlp_fused_supported(C, HID, T):
+        packed = ops.pack_mlp_weights(w1, b1, w2)
+        t_mlp = event_time_ms(lambda: ops.ln_mlp_fused(xm, one, zero, 1e-5, packed, one, zero, out=om), 20, st)
+        mlp_flop = 4.0 * C * HID * batch * T
+        mlp_r = {"kernel": "mlp_fused_kernel<136,544,4,true> ln2 + 136->544->gelu->136 + residual, T=6912 x%d clips" % batch,
+                 "bound": "mfma", "achieved": mlp_flop / (t_mlp * 1e-3) / 1e12, "peak": PEAK_F32_MATRIX / 1e12,
+                 "unit": "TFLOP/s", "frac": mlp_flop / (t_mlp * 1e-3) / PEAK_F32_MATRIX, "traffic": None,
+                 "ms_per_launch": t_mlp, "algorithmic_flop_per_launch": mlp_flop}
+    return conv, dcn_r, mlp_r
 
 
 def golden_parity(model, cfg, dev):
@@ -303,10 +318,12 @@ def main():
                                  "frac": FLOP_PER_CLIP * a.batch * fwd_per_s / PEAK_F32_MATRIX, "traffic": None},
         }
         log("timed region done: %.2f ms/step" % (1e3 * dt / a.steps))
-        conv, dcn = kernel_rooflines(dev, a.batch)
+        conv, dcn, mlp = kernel_rooflines(dev, a.batch)
         log("kernel rooflines done")
         line["roofline"] = conv
         line["roofline_dcn"] = dcn
+        if mlp is not None:
+            line["roofline_mlp"] = mlp
         line["parity"] = golden_parity(model, cfg, dev)     # the "heatmap max-abs delta vs ref" half of the metric
         log("golden parity done")
         if world == 1 and not a.no_train_step:

@@ -88,13 +88,14 @@ def test_forward_frames_u8_equals_forward_of_normalised_clip():
 
 def test_parallel_stream_graph_equals_single_stream(monkeypatch):
     """The engine's parallel graph branches (HRNet branches / fuse rows / temporal encoders on side streams) and the
-    Winograd routing change scheduling and kernels only: single-stream replay is bit-identical, the direct-kernel engine
-    agrees to fp32 rounding."""
+    Winograd / fused-encoder routing change scheduling and kernels only: single-stream replay is bit-identical, the
+    direct-kernel and generic-kernel engines agree to fp32 rounding."""
     cfg = tiny_cfg(8, (64, 96))
     x, margin = S.synthetic_clip(2, cfg.MODEL.IMAGE_SIZE)
     outs = {}
-    for key, env in (("default", {}), ("single", {"OTPOSE_STREAMS": "0"}), ("direct", {"OTPOSE_WINOGRAD": "0"})):
-        for k in ("OTPOSE_STREAMS", "OTPOSE_WINOGRAD"):
+    for key, env in (("default", {}), ("single", {"OTPOSE_STREAMS": "0"}), ("direct", {"OTPOSE_WINOGRAD": "0"}),
+                     ("generic", {"OTPOSE_FUSED_MLP": "0", "OTPOSE_DENSE_CC": "0"}), ("unfused", {"OTPOSE_QKV_FRONT": "0"})):
+        for k in ("OTPOSE_STREAMS", "OTPOSE_WINOGRAD", "OTPOSE_FUSED_MLP", "OTPOSE_DENSE_CC", "OTPOSE_QKV_FRONT"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -108,5 +109,8 @@ def test_parallel_stream_graph_equals_single_stream(monkeypatch):
             assert torch.equal(a, b)
     for a, b in zip(outs["default"], outs["single"]):
         assert torch.equal(a, b)
-    for a, b in zip(outs["default"], outs["direct"]):
-        assert float((a - b).abs().max()) <= 1e-4 * max(1.0, float(b.abs().max()))
+    for other in ("direct", "generic", "unfused"):
+        # generic: the temporal encoders' dense layers on conv_win_kernel instead of csrc/mlp.hip / csrc/dense.hip;
+        # unfused: dwconv_ln3 + otp_dense_cc instead of qkv_front
+        for a, b in zip(outs["default"], outs[other]):
+            assert float((a - b).abs().max()) <= 1e-4 * max(1.0, float(b.abs().max())), other
