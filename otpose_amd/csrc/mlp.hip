@@ -55,8 +55,8 @@ __device__ __forceinline__ float kslot_sum(float v) {      // sum over the four 
     return v;
 }
 
-// floats per hidden block, padded to whole 16-byte-per-thread passes of a 256-thread workgroup
-constexpr int mlp_block_floats(int C) { return (((C / 4 + 3) / 4 + (C + 15) / 16) * 256 + 16 + 1023) / 1024 * 1024; }
+// floats per hidden block (a multiple of 4: the block is copied as 16-byte pieces)
+constexpr int mlp_block_floats(int C) { return ((C / 4 + 3) / 4 + (C + 15) / 16) * 256 + 16; }
 
 // packed[h][...]: phase-1 A fragments [kgroup][lane][4 k-steps], phase-2 A fragments [mtile][lane][4 steps], b1[16]
 __global__ void mlp_pack_kernel(const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
@@ -83,7 +83,7 @@ __global__ void mlp_pack_kernel(const float* __restrict__ w1, const float* __res
 // (TransformerBlock.ln2, model/blocks.py:95-110: biased variance, eps inside the root) - a token's channels are the wave's
 // k-steps x the four k-slot lane groups, so its statistics are an in-lane sum and two cross-lane adds.
 template <int C, int HID, int WAVES, bool LN>
-__global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void mlp_fused_kernel(
+__global__ __launch_bounds__(WAVES * 64, 2) void mlp_fused_kernel(
     const float* __restrict__ x, const float* __restrict__ packed, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ out, int T, int tiles_per_b,
     const float* __restrict__ ln_gamma, const float* __restrict__ ln_beta, float ln_eps) {
@@ -206,7 +206,10 @@ __global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void mlp_fused_kernel(
     }
 }
 
-constexpr int MLP_WAVES = 4;
+#ifndef OTP_MLP_WAVES
+#define OTP_MLP_WAVES 4
+#endif
+constexpr int MLP_WAVES = OTP_MLP_WAVES;
 
 }  // namespace
 
