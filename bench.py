@@ -149,7 +149,8 @@ def kernel_rooflines(dev, batch):
         mlp_flop = 4.0 * C * HID * batch * T
         mlp_r = {"kernel": "mlp_fused_kernel<136,544,4,true> ln2 + 136->544->gelu->136 + residual, T=6912 x%d clips" % batch,
                  "bound": "mfma", "achieved": mlp_flop / (t_mlp * 1e-3) / 1e12, "peak": PEAK_F32_MATRIX / 1e12,
-                 "unit": "TFLOP/s", "frac": mlp_flop / (t_mlp * 1e-3) / PEAK_F32_MATRIX, "traffic": None,
+                 "unit": "TFLOP/s", "frac": mlp_flop / (t_mlp * 1e-3) / PEAK_F32_MATRIX,
+                 "traffic": measured_traffic("ln_mlp_fused_136_544_T6912_x16"),
                  "ms_per_launch": t_mlp, "algorithmic_flop_per_launch": mlp_flop}
     return conv, dcn_r, mlp_r
 

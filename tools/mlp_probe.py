@@ -15,6 +15,7 @@ w1, w2 = (torch.randn(HID, C, 1, generator=g) / C ** 0.5).cuda(), (torch.randn(C
 b1, b2, sc = torch.randn(HID, generator=g).cuda(), torch.randn(C, generator=g).cuda(), torch.randn(C, generator=g).cuda()
 packed = ops.pack_mlp_weights(w1, b1, w2)
 out = torch.empty_like(x)
+one, zero = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
 for _ in range(4):
-    ops.mlp_fused(x, packed, sc, (b2 * sc).contiguous(), res, out=out)
+    ops.ln_mlp_fused(x, one, zero, 1e-5, packed, sc, (b2 * sc).contiguous(), out=out)
 torch.cuda.synchronize()

@@ -31,7 +31,8 @@ def main():
         prev = {}
     for key, sub, kern, fetch_corr in (("conv_48_48_3x3_96x72_x80", "conv", "conv_win_kernel", 2.0),
                                        ("conv_wino_48_48_3x3_96x72_x80", "wino", "conv_wino_kernel", 1.0),   # 16 B window + 4 B weight streams: raw = lower bound
-                                       ("mdcn_fwd_17x96x72_x16", "dcn", "mdcn_fwd_kernel", 1.0)):
+                                       ("mdcn_fwd_17x96x72_x16", "dcn", "mdcn_fwd_kernel", 1.0),
+                                       ("ln_mlp_fused_136_544_T6912_x16", "mlp", "mlp_fused_kernel", 1.0)):   # 8 B streams: raw
         f = mean_counter(os.path.join(base, "traffic_%s_fetch" % sub, "p_counter_collection.csv"), kern, "FETCH_SIZE")
         w = mean_counter(os.path.join(base, "traffic_%s_write" % sub, "p_counter_collection.csv"), kern, "WRITE_SIZE")
         if f is None or w is None:
