@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Time the fused TransformerBlock MLP (csrc/mlp.hip) against the two otp_conv2d launches it replaces, cfg2 shapes
+"""Time the temporal-encoder kernels (csrc/mlp.hip, csrc/dense.hip) against the launches they replace, cfg2 shapes
 (run on the GPU box)."""
 import os
 import sys
@@ -56,8 +56,6 @@ def main():
         print(f"T={T}: fused {t_f:.1f} us ({fl / t_f / 1e6:.1f} TFLOP/s)  two launches {t_2:.1f} us  max|diff| {err}")
 
 
-if __name__ == "__main__":
-    main()
 
 
 def dense_main():
@@ -84,8 +82,6 @@ def dense_main():
               f"max|diff| {err}")
 
 
-if __name__ == "__main__":
-    dense_main()
 
 
 def qkv_main():
@@ -110,4 +106,6 @@ def qkv_main():
 
 
 if __name__ == "__main__":
+    main()
+    dense_main()
     qkv_main()
