@@ -8,6 +8,8 @@
 //     residual add and ReLU that follow it in every HRNet / RSB block, and its backward
 //   * per-channel sums (bias gradients)
 // Everything is fp32 NCHW like the forward path; statistics are combined in fp64.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -580,6 +582,123 @@ extern "C" int otp_dilate(const void* in, void* out, int planes, int Hi, int Wi,
     return otp_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------------
+// 1x1 / stride-1 wgrad (the pointwise layers of the temporal encoders, the HRNet bottleneck and fuse 1x1s):
+//     dW[co][ci] += sum_{n, p} dY[n, co, p] * X[n, ci, p]
+// The generic kernel above walks 48 x 48 blocks of dW, so a 136 x 136 layer reads both operands three times and feeds
+// every MFMA from 4-byte LDS reads.  Here a workgroup owns up to 144 x 144 of dW (9 x 9 MFMA tiles: wave w takes column
+// tiles w, w + 4, w + 8 of all nine row tiles) over one chunk of pixels of one image, and both operands go straight from
+// L2 into MFMA operand registers: lane (m, kq) loads the four pixels p0 + 4 kq .. + 3 of row m with one 16-byte buffer
+// load (k-step q of the group contracts over the pixels {p0 + 4 kq + q}, the same permutation on both operands), rows past
+// the tensor and pixels past the chunk fall off the buffer descriptor and read zeros.  The next group's loads are in flight
+// while this one is multiplied.  Partial sums leave in fragment order; w1x1_reduce_kernel folds the chunks.
+struct W1Plan {
+    int N, Cin, Cout, HW, x_ctot, x_coff, dy_ctot, dy_coff;
+    int chunk, cpi, S;          // pixels per chunk (multiple of 16), chunks per image, S = N * cpi
+    int MT, NT;                 // 16-row / 16-column tiles of dW in total
+};
+
+__global__ __launch_bounds__(256, 2) void wgrad1x1_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            float* __restrict__ part, const W1Plan P) {
+    const int lane = threadIdx.x & 63, m = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int s = blockIdx.x, n = s / P.cpi, p_begin = (s - n * P.cpi) * P.chunk;
+    const int p_end = min(P.HW, p_begin + P.chunk);
+    const int mt0 = blockIdx.y * 9, nt0 = blockIdx.z * 9;
+    const int nmt = min(9, P.MT - mt0);
+    int ntile[3], nnt = 0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        ntile[j] = nt0 + wave + 4 * j;
+        if (wave + 4 * j < 9 && ntile[j] < P.NT) nnt = j + 1;
+    }
+    // rows past Cout / Cin start past the descriptor's range -> zeros
+    const otp_rsrc rdy = make_rsrc(dy + ((size_t)n * P.dy_ctot + P.dy_coff) * P.HW, (size_t)P.Cout * P.HW * sizeof(float));
+    const otp_rsrc rx = make_rsrc(x + ((size_t)n * P.x_ctot + P.x_coff) * P.HW, (size_t)P.Cin * P.HW * sizeof(float));
+    const int arow = ((mt0 * 16 + m) * P.HW + 4 * kq) * 4;            // byte offset of (row, pixel 4 kq) for row tile 0
+    int brow[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) brow[j] = ((ntile[j] * 16 + m) * P.HW + 4 * kq) * 4;
+    const int tstep = 16 * P.HW * 4;                                   // next row tile
+
+    f32x4 acc[9][3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 A[9], B[3], An[9], Bn[3];
+    auto load = [&](f32x4 (&a)[9], f32x4 (&b)[3], int p0) __attribute__((always_inline)) {
+        const bool ok = p0 + 4 * kq < p_end;                           // HW % 4 == 0: a pixel quad is inside or outside
+        const int po = p0 * 4;                                         // offset -1 = past every descriptor -> zeros
+#pragma unroll
+        for (int i = 0; i < 9; ++i) a[i] = bload4(rdy, (ok && i < nmt) ? arow + po + i * tstep : -1);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) b[j] = bload4(rx, (ok && j < nnt) ? brow[j] + po : -1);
+    };
+    load(A, B, p_begin);
+    for (int p0 = p_begin; p0 < p_end; p0 += 16) {
+        if (p0 + 16 < p_end) load(An, Bn, p0 + 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int i = 0; i < 9; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    if (i < nmt && j < nnt)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[i][q], B[j][q], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) A[i] = An[i];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) B[j] = Bn[j];
+    }
+    // part[s][row tile][column tile][lane][4]
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (i < nmt && j < nnt)
+                *reinterpret_cast<f32x4*>(part + ((((size_t)s * P.MT + mt0 + i) * P.NT + ntile[j]) * 64 + lane) * 4) = acc[i][j];
+}
+
+// grid (tiles, 4 quarters of a tile); 256 threads = 16 float4 lanes x 16 chunk groups
+__global__ __launch_bounds__(256) void w1x1_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int S, int MT,
+                                                           int NT, int Cout, int Cin) {
+    __shared__ f32x4 red[16][16];
+    const int tile = blockIdx.x, mt = tile / NT, nt = tile - mt * NT;
+    const int l4 = threadIdx.x & 15, sg = threadIdx.x >> 4, lane = blockIdx.y * 16 + l4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    const size_t stride = (size_t)MT * NT * 256;
+    const float* src = part + ((size_t)tile * 64 + lane) * 4;
+    for (int s = sg; s < S; s += 16) v += *reinterpret_cast<const f32x4*>(src + (size_t)s * stride);
+    red[sg][l4] = v;
+    __syncthreads();
+    if (sg == 0) {
+#pragma unroll
+        for (int k = 1; k < 16; ++k) v += red[k][l4];
+        const int ci = nt * 16 + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = mt * 16 + (lane >> 4) * 4 + r;
+            if (co < Cout && ci < Cin) dw[(size_t)co * Cin + ci] += v[r];
+        }
+    }
+}
+
+static bool w1x1_plan(W1Plan& P, int N, int Cin, int Cout, int HW) {
+    P.N = N; P.Cin = Cin; P.Cout = Cout; P.HW = HW;
+    P.MT = otp_ceil_div(Cout, 16); P.NT = otp_ceil_div(Cin, 16);
+    const int blocks = otp_ceil_div(P.MT, 9) * otp_ceil_div(P.NT, 9);
+    int want = 512 / blocks;                                 // chunks in total: two workgroups per CU
+    if (want < 1) want = 1;
+    int cpi = otp_ceil_div(want, N);
+    int chunk = otp_ceil_div(otp_ceil_div(HW, cpi), 16) * 16;
+    if (chunk < 64) chunk = 64;
+    cpi = otp_ceil_div(HW, chunk);
+    P.chunk = chunk; P.cpi = cpi; P.S = N * cpi;
+    return true;
+}
+constexpr size_t W1_MAX_PART_BYTES = 96u << 20;
+
 static int wgrad_grid_x(int Cout, int Cin) {
     const int gy = otp_ceil_div(Cout, WG_CO), gz = otp_ceil_div(Cin, WG_CI);
     int gx = 512 / (gy * gz);
@@ -588,7 +707,8 @@ static int wgrad_grid_x(int Cout, int Cin) {
 
 extern "C" size_t otp_conv2d_wgrad_workspace(int Cin, int Cout) {
     if (Cin <= 0 || Cout <= 0) return 0;
-    return (size_t)wgrad_grid_x(Cout, Cin) * otp_ceil_div(Cout, WG_CO) * otp_ceil_div(Cin, WG_CI) * WG_SLOTS * sizeof(float);
+    const size_t generic = (size_t)wgrad_grid_x(Cout, Cin) * otp_ceil_div(Cout, WG_CO) * otp_ceil_div(Cin, WG_CI) * WG_SLOTS * sizeof(float);
+    return generic > W1_MAX_PART_BYTES ? generic : W1_MAX_PART_BYTES;      // the 1x1 path keeps one 1 KB tile per chunk
 }
 
 extern "C" int otp_conv2d_wgrad(const void* x, const void* grad_out, void* grad_weight, int N, int Cin, int H, int W,
@@ -599,6 +719,29 @@ extern "C" int otp_conv2d_wgrad(const void* x, const void* grad_out, void* grad_
         return OTP_ERR_BAD_ARG;
     if (kh != kw || (kh != 1 && kh != 3)) return OTP_ERR_UNSUPPORTED;
     if (x_ctot < x_coff + Cin || dy_ctot < dy_coff + Cout) return OTP_ERR_BAD_ARG;
+    if (kh == 1 && stride == 1 && pad == 0 && (H * W) % 4 == 0 && workspace && Cin >= 16 && Cout >= 16 &&
+        (long)x_ctot * H * W < (1l << 28) && (long)dy_ctot * H * W < (1l << 28) &&
+        !((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(grad_out)) & 15)) {
+        static const bool off = [] { const char* e = getenv("OTP_WGRAD_1X1"); return e && e[0] == '0'; }();
+        W1Plan Q{};
+        w1x1_plan(Q, N, Cin, Cout, H * W);
+        Q.x_ctot = x_ctot; Q.x_coff = x_coff; Q.dy_ctot = dy_ctot; Q.dy_coff = dy_coff;
+        const size_t need = (size_t)Q.S * Q.MT * Q.NT * 256 * sizeof(float);
+        // measured against the generic kernel (tools/wgrad_bench.py): it wins from 3 x 12 tiles of dW upwards (136 -> 136
+        // 0.166 -> 0.106 ms, 136 <-> 544 0.64 -> 0.35, 256 -> 64 1.07 -> 0.86, 384 -> 48 0.053 -> 0.028) and loses on the
+        // thin ones (96 -> 48 0.066 -> 0.104, 408 -> 17 0.16 -> 0.21)
+        const bool pays = (Q.MT < Q.NT ? Q.MT : Q.NT) >= 3 && Q.MT * Q.NT >= 36;
+        if (!off && pays && need <= workspace_bytes && ((x_coff * H * W) % 4 == 0) && ((dy_coff * H * W) % 4 == 0)) {
+            auto st = static_cast<hipStream_t>(stream);
+            hipLaunchKernelGGL(wgrad1x1_kernel, dim3(Q.S, otp_ceil_div(Q.MT, 9), otp_ceil_div(Q.NT, 9)), dim3(256), 0, st,
+                               static_cast<const float*>(x), static_cast<const float*>(grad_out),
+                               static_cast<float*>(workspace), Q);
+            hipLaunchKernelGGL(w1x1_reduce_kernel, dim3(Q.MT * Q.NT, 4), dim3(256), 0, st,
+                               static_cast<const float*>(workspace), static_cast<float*>(grad_weight), Q.S, Q.MT, Q.NT, Cout,
+                               Cin);
+            return otp_launch_status();
+        }
+    }
     WgradPlan P{};
     P.N = N; P.Cin = Cin; P.H = H; P.W = W; P.Cout = Cout; P.KS = kh; P.stride = stride; P.pad = pad; P.dil = dil;
     P.Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) / stride + 1;

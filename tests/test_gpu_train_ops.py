@@ -33,6 +33,10 @@ CASES = [  # N, Cin, H, W, Cout, k, stride, pad, dil
     (2, 32, 16, 24, 34, 3, 1, 15, 15),    # dilation 15 on a small map (sparse row staging)
     (1, 3, 24, 288, 20, 3, 2, 1, 1),      # full-width 384x288 stem rows: strided rows split into column tiles
     (1, 20, 12, 144, 24, 3, 2, 1, 1),     # second stem conv width
+    (2, 136, 1, 1240, 544, 1, 1, 0, 1),   # MLP up-projection: four 144-row blocks of dW, ragged last pixel chunk
+    (2, 544, 1, 500, 136, 1, 1, 0, 1),    # MLP down-projection: four 144-column blocks
+    (3, 96, 12, 9, 48, 1, 1, 0, 1),       # fuse-layer 1x1 on a small map (one chunk per image)
+    (2, 40, 7, 5, 24, 1, 1, 0, 1),        # H * W % 4 != 0: stays on the generic wgrad kernel
 ]
 
 
