@@ -28,11 +28,28 @@ def conv2d_forward(x, weight, bias, stride, pad, dil):
     out = torch.empty((x.shape[0], cout, ho, wo), dtype=torch.float32, device=x.device)
     iv, ov = View(x), View(out)
     d = conv_desc(iv, ov, cout, kh, kw, stride, pad, dil, ACT_NONE)
-    if _winograd(cin, cout, d):
+    if _dense_cc(cin, cout, kh, stride, pad, x.shape[2] * x.shape[3]):
+        _dense_cc_launch(x, weight.reshape(cout, cin), bias, out)
+    elif _winograd(cin, cout, d):
         conv2d_wino_launch(iv, pack_wino_weight(weight), None, bias, ov, d)
     else:
         conv2d_launch(iv, pack_conv_weight(weight), None, bias, ov, d)
     return out
+
+
+def _dense_cc(cin, cout, k, stride, pad, hw):
+    """Pointwise C -> C layers of the temporal encoders (query / key / value / proj): the register-resident-input kernel of
+    csrc/dense.hip, forward and input gradient alike (same rule as the inference engine)."""
+    from . import ops
+    return (os.environ.get("OTPOSE_DENSE_CC", "1") != "0" and k == 1 and stride == 1 and pad == 0 and cin == cout
+            and ops.dense_cc_supported(cin, hw))
+
+
+def _dense_cc_launch(x4, w2, bias, out4):
+    from . import ops
+    n, c = x4.shape[:2]
+    pk = ops.pack_dense_cc(w2, None, bias)
+    ops.dense_cc([x4.view(n, c, -1)], [pk], None, [out4.view(n, c, -1)])
 
 
 def _winograd(cin, cout, d):
@@ -57,6 +74,9 @@ def conv2d_grad_input(grad_out, weight, in_shape, stride, pad, dil):
                                hip.stream_of(g)), "otp_dilate")
         g = gd
     gx = torch.empty(in_shape, dtype=torch.float32, device=g.device)
+    if _dense_cc(cin, cout, kh, stride, pad, h * w):
+        _dense_cc_launch(g, weight.reshape(cout, cin).t(), None, gx)         # dx = W^T . dy
+        return gx
     iv, ov = View(g), View(gx)
     d = conv_desc(iv, ov, cin, kh, kw, 1, dil * (kh - 1) - pad, dil, ACT_NONE)
     if stride == 1 and _winograd(cout, cin, d):
