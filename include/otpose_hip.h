@@ -227,6 +227,13 @@ int otp_softmax_backward(const void* slabs, const void* P, void* dS, void* dST, 
  * grad_beta = otp_channel_sum(grad_y) */
 int otp_ln_channel_backward(const void* x, const void* grad_y, const void* gamma, void* grad_x, void* dy_xhat, int B, int C,
                             int T, float eps, void* stream);
+/* the same with the parameter gradients from the same pass (C <= 136): grad_gamma = sum_{b,t} dy * xhat, grad_beta =
+ * sum_{b,t} dy, reduced per workgroup in the kernel and folded by a second tiny launch (fixed order, fp64); no dy * xhat
+ * tensor.  Workspace: otp_ln_channel_backward_workspace bytes (0 = shape not supported, use the form above). */
+size_t otp_ln_channel_backward_workspace(int B, int C, int T);
+int otp_ln_channel_backward_params(const void* x, const void* grad_y, const void* gamma, void* grad_x, void* grad_gamma,
+                                   void* grad_beta, void* workspace, size_t workspace_bytes, int B, int C, int T, float eps,
+                                   void* stream);
 /* depthwise Conv1d(C, C, 3, stride, padding 1, groups C, bias False): w (C,3); grad_w is ACCUMULATED into */
 int otp_dwconv3_forward(const void* x, const void* w, void* y, int B, int C, int T, int stride, void* stream);
 int otp_dwconv3_backward(const void* x, const void* w, const void* grad_y, void* grad_x, void* grad_w, int B, int C, int T,

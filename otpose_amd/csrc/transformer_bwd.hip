@@ -45,7 +45,10 @@ __global__ __launch_bounds__(256) void ln_channel_bwd_kernel(const float* __rest
 // of x and dy in registers (cw = ceil(C / 4)), the three per-token reductions (mean, variance, the two dy moments) cross the
 // waves through LDS.  One HBM read of x and dy, one write of dx and dy * xhat (the one-thread-per-token form above re-reads
 // its 136-channel columns four times out of L2: 145 us -> the traffic bound at (B, 136, 6912) is ~75 us).
-template <int CW>
+// SUMS: instead of writing dy * xhat for a later channel_sum, the workgroup reduces sum_t dy * xhat and sum_t dy of its 64
+// tokens per channel (wavefront shuffles) and stores them as partials[2][C][workgroups]; ln_param_reduce_kernel folds them
+// into dgamma / dbeta - saves the dy * xhat round trip and two more passes over dy per LayerNorm.
+template <int CW, bool SUMS>
 __global__ __launch_bounds__(256) void ln_channel_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                     const float* __restrict__ gamma, float* __restrict__ dx,
                                                                     float* __restrict__ dyxh, int C, int T, float eps) {
@@ -101,14 +104,47 @@ __global__ __launch_bounds__(256) void ln_channel_bwd_split_kernel(const float* 
     __syncthreads();
     m1 = (red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane]) * inv_c;
     m2 = (red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane]) * inv_c;
+    if (SUMS) {
+        const int nwg = gridDim.x * gridDim.y, wg = blockIdx.y * gridDim.x + blockIdx.x;
+#pragma unroll
+        for (int i = 0; i < CW; ++i) {
+            const int c = cbeg + i;
+            if (i < cw && c < C) {                       // (wave-uniform condition)
+                const float pg = wave_sum(live ? dv[i] * xv[i] : 0.f), pb = wave_sum(live ? dv[i] : 0.f);
+                if (lane == 0) {
+                    dyxh[(size_t)c * nwg + wg] = pg;      // here `dyxh` is the partial-sum workspace [2][C][nwg]
+                    dyxh[((size_t)C + c) * nwg + wg] = pb;
+                }
+            }
+        }
+    }
     if (!live) return;
 #pragma unroll
     for (int i = 0; i < CW; ++i) {
         const int c = cbeg + i;
         if (i < cw && c < C) {
             dx[base + (size_t)c * T] = r * (dv[i] * gamma[c] - m1 - xv[i] * m2);
-            dyxh[base + (size_t)c * T] = dv[i] * xv[i];
+            if (!SUMS) dyxh[base + (size_t)c * T] = dv[i] * xv[i];
         }
+    }
+}
+
+// grid (2 * C): out[k] = sum over the nwg partials of row k (fp64 accumulation, fixed order)
+__global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta, int C, int nwg) {
+    __shared__ double red[256];
+    const float* src = part + (size_t)blockIdx.x * nwg;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nwg; i += 256) s += (double)src[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if ((int)blockIdx.x < C) dgamma[blockIdx.x] = (float)red[0];
+        else dbeta[blockIdx.x - C] = (float)red[0];
     }
 }
 
@@ -288,7 +324,7 @@ extern "C" int otp_ln_channel_backward(const void* x, const void* grad_y, const 
                                        int B, int C, int T, float eps, void* stream) {
     if (!x || !grad_y || !gamma || !grad_x || !dy_xhat || B <= 0 || C <= 0 || T <= 0) return OTP_ERR_BAD_ARG;
     if (C <= 4 * 34)
-        hipLaunchKernelGGL(ln_channel_bwd_split_kernel<34>, dim3(otp_ceil_div(T, 64), B), dim3(256), 0,
+        hipLaunchKernelGGL((ln_channel_bwd_split_kernel<34, false>), dim3(otp_ceil_div(T, 64), B), dim3(256), 0,
                            static_cast<hipStream_t>(stream), static_cast<const float*>(x), static_cast<const float*>(grad_y),
                            static_cast<const float*>(gamma), static_cast<float*>(grad_x), static_cast<float*>(dy_xhat), C, T,
                            eps);
@@ -373,5 +409,27 @@ extern "C" int otp_softmax_backward(const void* slabs, const void* P, void* dS, 
     hipLaunchKernelGGL(softmax_bwd_kernel, dim3(BH, HSP), dim3(64), 0, static_cast<hipStream_t>(stream),
                        static_cast<const float*>(slabs), static_cast<const float*>(P), static_cast<float*>(dS),
                        static_cast<float*>(dST), static_cast<float*>(PT), hs, HSP, NS);
+    return otp_launch_status();
+}
+
+extern "C" size_t otp_ln_channel_backward_workspace(int B, int C, int T) {
+    if (B <= 0 || C <= 0 || T <= 0 || C > 4 * 34) return 0;
+    return (size_t)2 * C * B * otp_ceil_div(T, 64) * sizeof(float);
+}
+
+extern "C" int otp_ln_channel_backward_params(const void* x, const void* grad_y, const void* gamma, void* grad_x,
+                                              void* grad_gamma, void* grad_beta, void* workspace, size_t workspace_bytes,
+                                              int B, int C, int T, float eps, void* stream) {
+    if (!x || !grad_y || !gamma || !grad_x || !grad_gamma || !grad_beta || !workspace || B <= 0 || C <= 0 || T <= 0)
+        return OTP_ERR_BAD_ARG;
+    if (C > 4 * 34) return OTP_ERR_UNSUPPORTED;
+    if (workspace_bytes < otp_ln_channel_backward_workspace(B, C, T)) return OTP_ERR_WORKSPACE;
+    auto st = static_cast<hipStream_t>(stream);
+    const int gx = otp_ceil_div(T, 64);
+    hipLaunchKernelGGL((ln_channel_bwd_split_kernel<34, true>), dim3(gx, B), dim3(256), 0, st, static_cast<const float*>(x),
+                       static_cast<const float*>(grad_y), static_cast<const float*>(gamma), static_cast<float*>(grad_x),
+                       static_cast<float*>(workspace), C, T, eps);
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(2 * C), dim3(256), 0, st, static_cast<const float*>(workspace),
+                       static_cast<float*>(grad_gamma), static_cast<float*>(grad_beta), C, gx * B);
     return otp_launch_status();
 }

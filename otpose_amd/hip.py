@@ -84,6 +84,8 @@ SIGNATURES = {
     "otp_transpose_scale": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "otp_softmax_backward": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_void_p]),
     "otp_ln_channel_backward": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_float, c_void_p]),
+    "otp_ln_channel_backward_workspace": (c_size_t, [c_int] * 3),
+    "otp_ln_channel_backward_params": (c_int, [c_void_p] * 6 + [c_void_p, c_size_t] + [c_int] * 3 + [c_float, c_void_p]),
     "otp_dwconv3_forward": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),
     "otp_dwconv3_backward": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
     "otp_gelu_forward": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),

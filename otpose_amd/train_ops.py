@@ -235,6 +235,17 @@ class LayerNormFunction(Function):
         x, g = ctx.saved_tensors
         gy = gy.contiguous()
         b, c, t = x.shape
+        L = hip.lib()
+        nbytes = L.otp_ln_channel_backward_workspace(b, c, t)
+        if nbytes:
+            # dx, dgamma and dbeta from one pass over x and dy
+            gx = torch.empty_like(x)
+            ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+            gg, gb = torch.empty(c, dtype=torch.float32, device=x.device), torch.empty(c, dtype=torch.float32, device=x.device)
+            hip.check(L.otp_ln_channel_backward_params(hip.ptr(x), hip.ptr(gy), hip.ptr(g), hip.ptr(gx), hip.ptr(gg), hip.ptr(gb),
+                                                       hip.ptr(ws), nbytes, b, c, t, ctx.eps, hip.stream_of(x)),
+                      "otp_ln_channel_backward_params")
+            return gx, gg.reshape(ctx.pshape), gb.reshape(ctx.pshape), None
         gx, dyxh = torch.empty_like(x), torch.empty_like(x)
         hip.check(hip.lib().otp_ln_channel_backward(hip.ptr(x), hip.ptr(gy), hip.ptr(g), hip.ptr(gx), hip.ptr(dyxh), b, c, t,
                                                     ctx.eps, hip.stream_of(x)), "otp_ln_channel_backward")
