@@ -174,6 +174,33 @@ def test_mhca_pipeline_matches_golden(golden, c, nh, stride, t):
     _close(y, g[tag + "_y"], 5e-5)
 
 
+def test_fused_transformer_block_matches_golden(golden):
+    """A whole TransformerBlock (model/blocks.py:264-280, eval mode) assembled from the launches the engine uses for the
+    temporal encoders - ln_channel, qkv_front, chan_attn, dense_cc (proj + drop-path scale + residual), ln_mlp_fused -
+    against the vectors the reference's TransformerBlock produced (tests/golden/blocks.npz, tblock_136_s1)."""
+    c, nh = 136, 2
+    g = golden("blocks")
+    blk = M.TransformerBlock(c, nh, (1, 1), proj_pdrop=0.1, path_pdrop=0.1)
+    S.fill_synthetic_(blk, 12)
+    a = blk.attn
+    x = g["tblock_136_s1_x"].cuda()
+    d = lambda p: p.detach().cuda().float().contiguous()          # noqa: E731
+    ln1 = ops.ln_channel(x, d(blk.ln1.weight).reshape(-1), d(blk.ln1.bias).reshape(-1), blk.ln1.eps)
+    table = ops.pack_qkv_table(d(a.query_conv.weight), d(a.key_conv.weight), d(a.value_conv.weight),
+                               d(a.query_norm.weight), d(a.query_norm.bias), d(a.key_norm.weight), d(a.key_norm.bias),
+                               d(a.value_norm.weight), d(a.value_norm.bias))
+    packs = [ops.pack_dense_cc(d(m.weight), None, d(m.bias)) for m in (a.query, a.key, a.value)]
+    q, k, v = ops.qkv_front(ln1, table, packs, a.query_norm.eps)
+    att = ops.chan_attn(q, k, v, nh, a.scale)
+    sa = d(blk.drop_path_attn.scale).reshape(-1)
+    (y,) = ops.dense_cc([att], [ops.pack_dense_cc(d(a.proj.weight), sa, d(a.proj.bias) * sa)], [x])
+    sm = d(blk.drop_path_mlp.scale).reshape(-1)
+    packed = ops.pack_mlp_weights(d(blk.mlp[0].weight), d(blk.mlp[0].bias), d(blk.mlp[3].weight))
+    out = ops.ln_mlp_fused(y, d(blk.ln2.weight).reshape(-1), d(blk.ln2.bias).reshape(-1), blk.ln2.eps, packed, sm,
+                           d(blk.mlp[3].bias) * sm)
+    _close(out, g["tblock_136_s1_y"], 5e-5)
+
+
 def test_chan_attn_full_size_vs_oracle_slice():
     """cfg2 size (B=2 of 16, C=136, T=6912): compare with the CPU oracle arithmetic."""
     b, c, t, nh = 2, 136, 6912, 2
