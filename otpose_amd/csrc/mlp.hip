@@ -14,6 +14,7 @@
 // Roofline: MFMA-bound.  2*2*C*HID flop/token (C = 136: 295.9 kflop) against 8 bytes/token/channel of HBM traffic (x, res
 // in, out: 1.6 kB/token).
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -79,60 +80,65 @@ __global__ void mlp_pack_kernel(const float* __restrict__ w1, const float* __res
     packed[idx] = v;
 }
 
-// LN: x is the block's un-normalised input and the kernel applies the channel LayerNorm in front of the MLP itself
-// (TransformerBlock.ln2, model/blocks.py:95-110: biased variance, eps inside the root) - a token's channels are the wave's
-// k-steps x the four k-slot lane groups, so its statistics are an in-lane sum and two cross-lane adds.
-template <int C, int HID, int WAVES, bool LN>
-__global__ __launch_bounds__(WAVES * 64, 2) void mlp_fused_kernel(
-    const float* __restrict__ x, const float* __restrict__ packed, const float* __restrict__ scale,
-    const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ out, int T, int tiles_per_b,
-    const float* __restrict__ ln_gamma, const float* __restrict__ ln_beta, float ln_eps) {
+// One pass of a wave over NT (1 or 2) column tiles of 16 tokens starting at token tok0, all HID / 16 hidden blocks; every wave
+// of the workgroup calls it together (the weight blocks go through LDS behind one barrier per block).
+// NT == 2: column n of tile j is token tok0 + 2n + j (8-byte accesses); NT == 1: token tok0 + n.
+template <int C, int HID, int NTHR, bool LN, int NT>
+__device__ __forceinline__ void mlp_pass(const float* __restrict__ x, const float* __restrict__ packed,
+                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                         const float* __restrict__ res, float* __restrict__ out, int T, size_t base, int tok0,
+                                         float* lds, const float* __restrict__ ln_gamma, const float* __restrict__ ln_beta,
+                                         float ln_eps) {
     constexpr int KS = C / 4, KG = (KS + 3) / 4, HT = HID / 16, MT = (C + 15) / 16;
-    constexpr int BLK = mlp_block_floats(C), BLK4 = BLK / 4, NTHR = WAVES * 64, NST = (BLK4 + NTHR - 1) / NTHR;
-    extern __shared__ float lds[];                    // 2 x BLK floats
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kq = lane >> 4, n = lane & 15;
-    const int b = blockIdx.x / tiles_per_b, tile = blockIdx.x - b * tiles_per_b;
-    const int tok = tile * (WAVES * 32) + wave * 32 + 2 * n;
-    const bool valid = tok < T;                       // T is even: a token pair is inside or outside together
-    const size_t base = (size_t)b * C * T;
+    constexpr int BLK = mlp_block_floats(C), BLK4 = BLK / 4, NST = (BLK4 + NTHR - 1) / NTHR;
+    const int tid = threadIdx.x, lane = tid & 63, kq = lane >> 4, n = lane & 15;
+    const int tok = tok0 + NT * n;
+    const bool valid = tok < T;                       // NT == 2: T is even, a token pair is inside or outside together
 
-    // weights of hidden block 0 -> LDS buffer 0
+    // weights of hidden block 0 -> LDS buffer 0 (every wave is past the previous pass: the barrier that ended its loop)
     const f32x4* pk = reinterpret_cast<const f32x4*>(packed);
     f32x4* l4 = reinterpret_cast<f32x4*>(lds);
 #pragma unroll
     for (int i = 0; i < NST; ++i)
         if (BLK4 % NTHR == 0 || tid + i * NTHR < BLK4) l4[tid + i * NTHR] = pk[tid + i * NTHR];
 
-    // the wave's input columns as B fragments: X[s] = x[4s + kq][tok, tok + 1]
-    f32x2 X[KS];
+    // the wave's input columns as B fragments: X[s][j] = x[4s + kq][token of column n of tile j]
+    float X[KS][NT];
 #pragma unroll
-    for (int s = 0; s < KS; ++s)       // columns past T read the last pair instead (their results are never stored)
-        X[s] = *reinterpret_cast<const f32x2*>(x + base + (size_t)(4 * s + kq) * T + (valid ? tok : T - 2));
-    if (LN) {
-        constexpr float inv_c = 1.f / (float)C;
-        float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) { s0 += X[s].x; s1 += X[s].y; }
-        const float m0 = kslot_sum(s0) * inv_c, m1 = kslot_sum(s1) * inv_c;
-        float v0 = 0.f, v1 = 0.f;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            X[s].x -= m0;
-            X[s].y -= m1;
-            v0 += X[s].x * X[s].x;
-            v1 += X[s].y * X[s].y;
-        }
-        const float r0 = 1.f / sqrtf(kslot_sum(v0) * inv_c + ln_eps), r1 = 1.f / sqrtf(kslot_sum(v1) * inv_c + ln_eps);
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const float g = ln_gamma[4 * s + kq], be = ln_beta[4 * s + kq];
-            X[s].x = X[s].x * r0 * g + be;
-            X[s].y = X[s].y * r1 * g + be;
+    for (int s = 0; s < KS; ++s) {     // columns past T read the last ones instead (their results are never stored)
+        const float* src = x + base + (size_t)(4 * s + kq) * T + (valid ? tok : T - NT);
+        if (NT == 2) {
+            const f32x2 v = *reinterpret_cast<const f32x2*>(src);
+            X[s][0] = v.x;
+            X[s][NT - 1] = v.y;
+        } else {
+            X[s][0] = *src;
         }
     }
-    f32x4 Y[MT][2];
+    if (LN) {
+        constexpr float inv_c = 1.f / (float)C;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) { Y[mt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; Y[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int j = 0; j < NT; ++j) {
+            float s0 = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) s0 += X[s][j];
+            const float m0 = kslot_sum(s0) * inv_c;
+            float v0 = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                X[s][j] -= m0;
+                v0 += X[s][j] * X[s][j];
+            }
+            const float r0 = 1.f / sqrtf(kslot_sum(v0) * inv_c + ln_eps);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) X[s][j] = X[s][j] * r0 * ln_gamma[4 * s + kq] + ln_beta[4 * s + kq];
+        }
+    }
+    f32x4 Y[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) Y[mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
 
     for (int h = 0; h < HT; ++h) {
@@ -147,9 +153,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void mlp_fused_kernel(
         const float* P1 = lds + (h & 1) * BLK;
         const float* P2 = P1 + KG * 256;
         const float* PB = P2 + MT * 256;
-        // phase 1: hidden tile (16 channels x 32 tokens) = W1[16h .. 16h+15][:] . X
+        // phase 1: hidden tile (16 channels x 16 NT tokens) = W1[16h .. 16h+15][:] . X
         // (the accumulators start from b1: register i of lane group kq is hidden channel 16h + 4 kq + i)
-        f32x4 H0 = *reinterpret_cast<const f32x4*>(PB + 4 * kq), H1 = H0;
+        f32x4 H[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) H[j] = *reinterpret_cast<const f32x4*>(PB + 4 * kq);
 #pragma unroll
         for (int sg = 0; sg < KG; ++sg) {
             const f32x4 a = *reinterpret_cast<const f32x4*>(P1 + (sg * 64 + lane) * 4);
@@ -157,26 +165,24 @@ __global__ __launch_bounds__(WAVES * 64, 2) void mlp_fused_kernel(
             for (int q = 0; q < 4; ++q) {
                 const int s = 4 * sg + q;
                 if (s < KS) {
-                    H0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], X[s].x, H0, 0, 0, 0);
-                    H1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], X[s].y, H1, 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) H[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], X[s][j], H[j], 0, 0, 0);
                 }
             }
         }
-        {
-            const f32x2 g0 = mlp_gelu2(f32x2{H0[0], H0[1]}), g1 = mlp_gelu2(f32x2{H0[2], H0[3]});
-            const f32x2 g2 = mlp_gelu2(f32x2{H1[0], H1[1]}), g3 = mlp_gelu2(f32x2{H1[2], H1[3]});
-            H0 = f32x4{g0.x, g0.y, g1.x, g1.y};
-            H1 = f32x4{g2.x, g2.y, g3.x, g3.y};
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const f32x2 g0 = mlp_gelu2(f32x2{H[j][0], H[j][1]}), g1 = mlp_gelu2(f32x2{H[j][2], H[j][3]});
+            H[j] = f32x4{g0.x, g0.y, g1.x, g1.y};
         }
         // phase 2: Y += W2[:, 16h .. 16h+15] . hidden tile, contraction step i over the hidden channels {4g + i}
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const f32x4 a = *reinterpret_cast<const f32x4*>(P2 + (mt * 64 + lane) * 4);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                Y[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], H0[i], Y[mt][0], 0, 0, 0);
-                Y[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], H1[i], Y[mt][1], 0, 0, 0);
-            }
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) Y[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], H[j][i], Y[mt][j], 0, 0, 0);
         }
         if (h + 1 < HT) {
             f32x4* dst = reinterpret_cast<f32x4*>(lds + ((h + 1) & 1) * BLK);
@@ -196,13 +202,58 @@ __global__ __launch_bounds__(WAVES * 64, 2) void mlp_fused_kernel(
             if (c < C) {
                 const size_t o = base + (size_t)c * T + tok;
                 const float sc = scale[c], sh = shift[c];
-                const f32x2 r = *reinterpret_cast<const f32x2*>(res + o);
-                f32x2 v;
-                v.x = r.x + Y[mt][0][i] * sc + sh;
-                v.y = r.y + Y[mt][1][i] * sc + sh;
-                *reinterpret_cast<f32x2*>(out + o) = v;
+                if (NT == 2) {
+                    const f32x2 r = *reinterpret_cast<const f32x2*>(res + o);
+                    f32x2 v;
+                    v.x = r.x + Y[mt][0][i] * sc + sh;
+                    v.y = r.y + Y[mt][NT - 1][i] * sc + sh;
+                    *reinterpret_cast<f32x2*>(out + o) = v;
+                } else {
+                    out[o] = res[o] + Y[mt][0][i] * sc + sh;
+                }
             }
         }
+    }
+}
+
+// LN: x is the block's un-normalised input and the kernel applies the channel LayerNorm in front of the MLP itself
+// (TransformerBlock.ln2, model/blocks.py:95-110: biased variance, eps inside the root) - a token's channels are the wave's
+// k-steps x the four k-slot lane groups, so its statistics are an in-lane sum and two cross-lane adds.
+template <int C, int HID, int WAVES, bool LN>
+__global__ __launch_bounds__(WAVES * 64, 2) void mlp_fused_kernel(
+    const float* __restrict__ x, const float* __restrict__ packed, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ out, int T, int tiles_per_b,
+    const float* __restrict__ ln_gamma, const float* __restrict__ ln_beta, float ln_eps) {
+    extern __shared__ float lds[];                    // 2 x BLK floats
+    const int wave = threadIdx.x >> 6;
+    const int b = blockIdx.x / tiles_per_b, tile = blockIdx.x - b * tiles_per_b;
+    mlp_pass<C, HID, WAVES * 64, LN, 2>(x, packed, scale, shift, res, out, T, (size_t)b * C * T,
+                                        tile * (WAVES * 32) + wave * 32, lds, ln_gamma, ln_beta, ln_eps);
+}
+
+// Balanced form for token counts that are multiples of 27 column tiles per workgroup (T = 6912 = 16 x 27 x 16): 6912 x B / 16
+// column tiles over the 1024 SIMDs of the chip are 6.75 per SIMD, so equal workgroups of 4 x 2 tiles need two rounds of
+// four tiles per SIMD (8) where 7 would do.  Here one 8-wave workgroup per CU owns 27 tiles and walks them in two passes:
+// every wave takes two tiles in the first, then the waves of a SIMD (w, w + 4) take 2 + 1, 2 + 1, 2 + 1 and 1 + 1.
+template <int C, int HID, bool LN>
+__global__ __launch_bounds__(512, 2) void mlp_fused_balanced_kernel(
+    const float* __restrict__ x, const float* __restrict__ packed, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ out, int T, int wgs_per_b,
+    const float* __restrict__ ln_gamma, const float* __restrict__ ln_beta, float ln_eps) {
+    extern __shared__ float lds[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x / wgs_per_b, part = blockIdx.x - b * wgs_per_b;
+    const size_t base = (size_t)b * C * T;
+    const int t0 = part * (27 * 16);
+    mlp_pass<C, HID, 512, LN, 2>(x, packed, scale, shift, res, out, T, base, t0 + wave * 32, lds, ln_gamma, ln_beta, ln_eps);
+    if (wave < 3) {
+        mlp_pass<C, HID, 512, LN, 2>(x, packed, scale, shift, res, out, T, base, t0 + (16 + 2 * wave) * 16, lds, ln_gamma,
+                                     ln_beta, ln_eps);
+    } else {
+        // waves 4, 5, 6 -> tiles 22, 23, 24; wave 3 -> 25; wave 7 -> 26
+        const int tile = wave == 3 ? 25 : (wave == 7 ? 26 : 18 + wave);
+        mlp_pass<C, HID, 512, LN, 1>(x, packed, scale, shift, res, out, T, base, t0 + tile * 16, lds, ln_gamma, ln_beta,
+                                     ln_eps);
     }
 }
 
@@ -245,6 +296,16 @@ int mlp_launch(const void* x, const void* packed, const void* scale, const void*
     const int tiles = otp_ceil_div(T, MLP_WAVES * 32);
     auto f = [](const void* p) { return static_cast<const float*>(p); };
     const size_t lds = 2 * (size_t)mlp_block_floats(136) * sizeof(float);
+    const char* bal = getenv("OTP_MLP_BALANCED");               // "0": never, "2": whenever the shape allows (tests)
+    const bool bal_off = bal && bal[0] == '0', bal_force = bal && bal[0] == '2';
+    if (!bal_off && T % (27 * 16) == 0 && (bal_force || (long)B * (T / (27 * 16)) >= 192)) {
+        // one 8-wave workgroup per CU and two passes: 7 column tiles per SIMD instead of 8
+        auto bk = ln_gamma ? mlp_fused_balanced_kernel<136, 544, true> : mlp_fused_balanced_kernel<136, 544, false>;
+        const int per_b = T / (27 * 16);
+        hipLaunchKernelGGL(bk, dim3((unsigned)(B * per_b)), dim3(512), lds, static_cast<hipStream_t>(stream), f(x), f(packed),
+                           f(scale), f(shift), f(res), static_cast<float*>(out), T, per_b, f(ln_gamma), f(ln_beta), ln_eps);
+        return otp_launch_status();
+    }
     auto kern = ln_gamma ? mlp_fused_kernel<136, 544, MLP_WAVES, true> : mlp_fused_kernel<136, 544, MLP_WAVES, false>;
     hipLaunchKernelGGL(kern, dim3((unsigned)(B * tiles)), dim3(MLP_WAVES * 64), lds, static_cast<hipStream_t>(stream),
                        f(x), f(packed), f(scale), f(shift), f(res), static_cast<float*>(out), T, tiles, f(ln_gamma),

@@ -239,11 +239,14 @@ def test_loss_matches_golden_and_oracle(golden):
     _close(r2["final_loss"].reshape(()), ref2["final_loss"].reshape(()), 1e-5)
 
 
-@pytest.mark.parametrize("T", [32, 250, 1152])
-def test_mlp_fused_matches_fp64(T):
+@pytest.mark.parametrize("T", [32, 250, 1152, 864])
+def test_mlp_fused_matches_fp64(T, monkeypatch):
     """csrc/mlp.hip vs the MLP half of TransformerBlock.forward (model/blocks.py:248-254, 277-279) in fp64; T = 250 leaves
     a ragged last workgroup and half-empty waves."""
     B, C, HID = 2, 136, 544
+    if T % 432 == 0:
+        # the balanced two-pass form (one 8-wave workgroup per 27 column tiles; picked by itself from B * T / 432 >= 192)
+        monkeypatch.setenv("OTP_MLP_BALANCED", "2")
     x, res = seeded((B, C, T), 11), seeded((B, C, T), 12)
     w1, w2 = seeded((HID, C, 1), 13) / C ** 0.5, seeded((C, HID, 1), 14) / HID ** 0.5
     b1, b2, sc = seeded((HID,), 15) * 0.5, seeded((C,), 16), seeded((C,), 17)
