@@ -147,7 +147,10 @@ def kernel_rooflines(dev, batch):
         packed = ops.pack_mlp_weights(w1, b1, w2)
         t_mlp = event_time_ms(lambda: ops.ln_mlp_fused(xm, one, zero, 1e-5, packed, one, zero, out=om), 20, st)
         mlp_flop = 4.0 * C * HID * batch * T
-        mlp_r = {"kernel": "mlp_fused_kernel<136,544,4,true> ln2 + 136->544->gelu->136 + residual, T=6912 x%d clips" % batch,
+        balanced = T % 432 == 0 and batch * (T // 432) >= 192 and os.environ.get("OTP_MLP_BALANCED", "1") != "0"
+        mlp_r = {"kernel": ("%s ln2 + 136->544->gelu->136 + residual, T=6912 x%d clips"
+                            % ("mlp_fused_balanced_kernel<136,544,true>" if balanced else "mlp_fused_kernel<136,544,4,true>",
+                               batch)),
                  "bound": "mfma", "achieved": mlp_flop / (t_mlp * 1e-3) / 1e12, "peak": PEAK_F32_MATRIX / 1e12,
                  "unit": "TFLOP/s", "frac": mlp_flop / (t_mlp * 1e-3) / PEAK_F32_MATRIX,
                  "traffic": measured_traffic("ln_mlp_fused_136_544_T6912_x16"),
