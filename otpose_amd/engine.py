@@ -209,11 +209,17 @@ class InferenceEngine:
         return self.conv_bn(y, blk.conv2, blk.bn2, ACT_RELU, res=res)
 
     def bottleneck(self, blk, x: View) -> View:
-        y = self.conv_bn(x, blk.conv1, blk.bn1, ACT_RELU)
-        y = self.conv_bn(y, blk.conv2, blk.bn2, ACT_RELU)
         res = x
         if blk.downsample is not None:
+            # the 1x1 shortcut only needs x: a side stream next to conv1 / conv2
+            self.fork((1,))
+            self.on_stream(1)
             res = self.conv_bn(x, blk.downsample[0], blk.downsample[1])
+            self.on_stream(0)
+        y = self.conv_bn(x, blk.conv1, blk.bn1, ACT_RELU)
+        y = self.conv_bn(y, blk.conv2, blk.bn2, ACT_RELU)
+        if blk.downsample is not None:
+            self.join((1,))
         return self.conv_bn(y, blk.conv3, blk.bn3, ACT_RELU, res=res)
 
     def hr_module(self, mod, xs: List[View]) -> List[View]:
@@ -275,16 +281,22 @@ class InferenceEngine:
         for s in (2, 3, 4):
             trans = getattr(net, f"transition{s - 1}")
             xs = []
+            live = [i for i, tr in enumerate(trans) if tr is not None]
+            self.fork(range(1, len(live)))                         # the transition convs only share their inputs
             for i, tr in enumerate(trans):
                 if tr is None:
                     xs.append(ys[i])
-                elif isinstance(tr[0], torch.nn.Conv2d):          # same-resolution width change
+                    continue
+                self.on_stream(live.index(i))
+                if isinstance(tr[0], torch.nn.Conv2d):            # same-resolution width change
                     xs.append(self.conv_bn(ys[i], tr[0], tr[1], ACT_RELU))
                 else:                                              # new branch from the last tensor
                     z = ys[-1]
                     for step in tr:
                         z = self.conv_bn(z, step[0], step[1], ACT_RELU)
                     xs.append(z)
+            self.on_stream(0)
+            self.join(range(1, len(live)))
             ys = xs
             for mod in getattr(net, f"stage{s}"):
                 ys = self.hr_module(mod, ys)
