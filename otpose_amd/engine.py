@@ -411,14 +411,30 @@ class InferenceEngine:
         cbr(blk.conv_bn_relu1, x, View(t), ACT_RELU)
         s = [View(t, i * bc, bc) for i in range(4)]
         tmp = lambda: View(self.new(n, bc, h, w))                       # noqa: E731
+        # the staircase of RSB.py:80-92 is a DAG of depth 7, not a chain of 10: on the main stream the three convs off the
+        # critical path (2_2, 3_2, 3_3) run on a side stream (these launches are tiny and latency-bound)
+        par = self.multi_stream and self._sid == 0
+        side = (lambda: (self.fork((1,)), self.on_stream(1))) if par else (lambda: None)      # noqa: E731
+        main = (lambda: self.on_stream(0)) if par else (lambda: None)                          # noqa: E731
         o11 = cbr(blk.conv_bn_relu2_1_1, s[0], View(cat, 0, bc), ACT_RELU)
         o21 = cbr(blk.conv_bn_relu2_2_1, s[1], tmp(), ACT_RELU, in2=o11)
+        side()
         o22 = cbr(blk.conv_bn_relu2_2_2, o21, View(cat, bc, bc), ACT_RELU)
+        main()
         o31 = cbr(blk.conv_bn_relu2_3_1, s[2], tmp(), ACT_RELU, in2=o21)
+        side()
         o32 = cbr(blk.conv_bn_relu2_3_2, o31, tmp(), ACT_RELU, in2=o22)
-        o33 = cbr(blk.conv_bn_relu2_3_3, o32, View(cat, 2 * bc, bc), ACT_RELU)
+        main()
         o41 = cbr(blk.conv_bn_relu2_4_1, s[3], tmp(), ACT_RELU, in2=o31)
+        if par:
+            self.join((1,))
         o42 = cbr(blk.conv_bn_relu2_4_2, o41, tmp(), ACT_RELU, in2=o32)
+        if par:
+            self.on_stream(1)
+        o33 = cbr(blk.conv_bn_relu2_3_3, o32, View(cat, 2 * bc, bc), ACT_RELU)
+        if par:
+            self.on_stream(0)
+            self.join((1,))
         o43 = cbr(blk.conv_bn_relu2_4_3, o42, tmp(), ACT_RELU, in2=o33)
         cbr(blk.conv_bn_relu2_4_4, o43, View(cat, 3 * bc, bc), ACT_RELU)
         res = x
