@@ -49,6 +49,7 @@ class InferenceEngine:
         self.use_graph = use_graph
         self.use_winograd = os.environ.get("OTPOSE_WINOGRAD", "1") != "0"     # 3x3 stride-1 convs via csrc/wino.hip
         self.use_fused_mlp = os.environ.get("OTPOSE_FUSED_MLP", "1") != "0"   # transformer MLP via csrc/mlp.hip
+        self.fuse_shortcut = os.environ.get("OTPOSE_FUSE_SHORTCUT", "1") != "0"  # layer1 shortcut folded into conv3
         self.use_dense_cc = os.environ.get("OTPOSE_DENSE_CC", "1") != "0"     # q / k / v / proj via csrc/dense.hip
         self.use_qkv_front = os.environ.get("OTPOSE_QKV_FRONT", "1") != "0"   # + dwconv / LayerNorm fused in front of them
         # independent sub-graphs (the HRNet branches of a stage, the rows of its fuse layer, the two temporal encoders) are
@@ -274,8 +275,38 @@ class InferenceEngine:
 
     def hrnet(self, net, x_in: View) -> View:
         x = self.conv_bn(x_in, net.conv1, net.bn1, ACT_RELU, frame_split=self.B, cin=3)
-        x = self.conv_bn(x, net.conv2, net.bn2, ACT_RELU)
-        for blk in net.layer1:
+        blocks = list(net.layer1)
+        b0 = blocks[0]
+        if (self.fuse_shortcut and b0.downsample is not None and b0.conv3.kernel_size == (1, 1)
+                and b0.downsample[0].kernel_size == (1, 1) and b0.downsample[0].stride == (1, 1)):
+            # first Bottleneck (HRNet.py:551-571 with the 1x1 shortcut of :240-247): relu(bn3(conv3(y)) + bn_d(conv_d(x))) is
+            # one 1x1 conv over the channel concatenation [x, y] with both BatchNorm scales folded into the weights - the
+            # 256-channel shortcut tensor (566 MB at cfg2) is neither written nor read back.  x (stem conv2) and y
+            # (Bottleneck conv2) are written straight into the two channel slices of one buffer.
+            n, _, h, w = x.t.shape
+            c2 = net.conv2
+            ho = (h + 2 * c2.padding[0] - c2.kernel_size[0]) // c2.stride[0] + 1
+            wo = (w + 2 * c2.padding[0] - c2.kernel_size[0]) // c2.stride[0] + 1
+            cx, cy = c2.out_channels, b0.conv2.out_channels
+            cat = self.new(n, cx + cy, ho, wo)
+            xin = self.conv_bn(x, c2, net.bn2, ACT_RELU, out=View(cat, 0, cx))
+            y = self.conv_bn(xin, b0.conv1, b0.bn1, ACT_RELU)
+            self.conv_bn(y, b0.conv2, b0.bn2, ACT_RELU, out=View(cat, cx, cy))
+
+            def fold(conv, bn):
+                g, b = self.dev_param(bn.weight), self.dev_param(bn.bias)
+                mu, var = self.dev_param(bn.running_mean), self.dev_param(bn.running_var)
+                sc = g / torch.sqrt(var + bn.eps)
+                return self.dev_param(conv.weight) * sc[:, None, None, None], b - mu * sc
+            wd, shd = fold(b0.downsample[0], b0.downsample[1])
+            w3, sh3 = fold(b0.conv3, b0.bn3)
+            cout = b0.conv3.out_channels
+            x = self.conv(View(cat), torch.cat([wd, w3], 1), View(self.new(n, cout, ho, wo)),
+                          scale=torch.ones(cout, device=self.dev), shift=shd + sh3, act=ACT_RELU)
+            blocks = blocks[1:]
+        else:
+            x = self.conv_bn(x, net.conv2, net.bn2, ACT_RELU)
+        for blk in blocks:
             x = self.bottleneck(blk, x)
         ys = [x]
         for s in (2, 3, 4):

@@ -94,8 +94,10 @@ def test_parallel_stream_graph_equals_single_stream(monkeypatch):
     x, margin = S.synthetic_clip(2, cfg.MODEL.IMAGE_SIZE)
     outs = {}
     for key, env in (("default", {}), ("single", {"OTPOSE_STREAMS": "0"}), ("direct", {"OTPOSE_WINOGRAD": "0"}),
-                     ("generic", {"OTPOSE_FUSED_MLP": "0", "OTPOSE_DENSE_CC": "0"}), ("unfused", {"OTPOSE_QKV_FRONT": "0"})):
-        for k in ("OTPOSE_STREAMS", "OTPOSE_WINOGRAD", "OTPOSE_FUSED_MLP", "OTPOSE_DENSE_CC", "OTPOSE_QKV_FRONT"):
+                     ("generic", {"OTPOSE_FUSED_MLP": "0", "OTPOSE_DENSE_CC": "0"}),
+                     ("unfused", {"OTPOSE_QKV_FRONT": "0", "OTPOSE_FUSE_SHORTCUT": "0"})):
+        for k in ("OTPOSE_STREAMS", "OTPOSE_WINOGRAD", "OTPOSE_FUSED_MLP", "OTPOSE_DENSE_CC", "OTPOSE_QKV_FRONT",
+                  "OTPOSE_FUSE_SHORTCUT"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -111,6 +113,6 @@ def test_parallel_stream_graph_equals_single_stream(monkeypatch):
         assert torch.equal(a, b)
     for other in ("direct", "generic", "unfused"):
         # generic: the temporal encoders' dense layers on conv_win_kernel instead of csrc/mlp.hip / csrc/dense.hip;
-        # unfused: dwconv_ln3 + otp_dense_cc instead of qkv_front
+        # unfused: dwconv_ln3 + otp_dense_cc instead of qkv_front, layer1 shortcut as its own conv + residual
         for a, b in zip(outs["default"], outs[other]):
             assert float((a - b).abs().max()) <= 1e-4 * max(1.0, float(b.abs().max())), other
