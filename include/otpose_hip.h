@@ -210,6 +210,11 @@ int otp_qkv_front(const void* x, const void* table, const void* packed_q, const 
  * 488-494; `res` may alias `out`); low (N, low_ctot, Hl, Wl), res / out (N, *_ctot, Hl*f, Wl*f); relu != 0 applies ReLU */
 int otp_upsample_add(const void* low, const void* res, void* out, int N, int C, int Hl, int Wl, int f, int relu,
                      int low_ctot, int low_coff, int res_ctot, int res_coff, int out_ctot, int out_coff, void* stream);
+/* a whole fuse row's upsampled terms in one pass: out = act(res + up_f0(low0) + up_f1(low1) (+ up_f2(low2))), summed in that
+ * order (bit-identical to chaining otp_upsample_add); lows are dense (N, C, Hh / f_k, Wh / f_k), f_k powers of two >= 2,
+ * Wh % 4 == 0; `lows` / `factors` are host arrays of nlow (1..3) entries */
+int otp_upsample_add_multi(const void* const* lows, const int* factors, int nlow, const void* res, void* out, int N, int C,
+                           int Hh, int Wh, int relu, int res_ctot, int res_coff, int out_ctot, int out_coff, void* stream);
 
 /* ---- ConvTransformer backward pieces (training step; model/blocks.py:95-110,234-254,359-381,400-453) -------------
  * Channel attention backward is assembled on the host side from these (otpose_amd/train_ops.py): with O^T = the

@@ -154,6 +154,43 @@ __global__ __launch_bounds__(256) void upsample_add_kernel(const float* __restri
     }
 }
 
+// out = act(res + up_f0(low0) + up_f1(low1) (+ up_f2(low2))), added in that order: a whole fuse row's upsampled terms in one
+// pass over the high-resolution tensor instead of one read-modify-write pass per term (dense lows, f_k >= 2, W % 4 == 0)
+struct UpMulti {
+    const float* low[3];
+    int f[3];
+    int n;
+};
+__global__ __launch_bounds__(256) void upsample_add_multi_kernel(UpMulti U, const float* res, float* out, int C, int Hh, int Wh,
+                                                                  int relu, int res_ctot, int res_coff, int out_ctot,
+                                                                  int out_coff, size_t total4) {
+    const int Wh4 = Wh >> 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        const int x4 = (int)(i % Wh4);
+        size_t r = i / Wh4;
+        const int y = (int)(r % Hh);
+        r /= Hh;
+        const int c = (int)(r % C), n = (int)(r / C);
+        const size_t hi = ((size_t)y * Wh + 4 * x4);
+        otp_f32x4 o = *reinterpret_cast<const otp_f32x4*>(res + ((size_t)n * res_ctot + res_coff + c) * Hh * Wh + hi);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (k < U.n) {
+                const int f = U.f[k], Wl = Wh / f, Hl = Hh / f;
+                const float* lrow = U.low[k] + (((size_t)n * C + c) * Hl + y / f) * Wl;
+                if (f >= 4) {
+                    o = o + lrow[(4 * x4) / f];
+                } else {
+                    const float l0 = lrow[2 * x4], l1 = lrow[2 * x4 + 1];
+                    o = o + (otp_f32x4){l0, l0, l1, l1};
+                }
+            }
+        }
+        if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        *reinterpret_cast<otp_f32x4*>(out + ((size_t)n * out_ctot + out_coff + c) * Hh * Wh + hi) = o;
+    }
+}
+
 // the same, one element per thread (rows that are not whole float4)
 __global__ __launch_bounds__(256) void upsample_add_scalar_kernel(const float* __restrict__ low, const float* res, float* out,
                                                                    int C, int Hl, int Wl, int f, int relu, int low_ctot,
@@ -326,6 +363,29 @@ extern "C" int otp_upsample_add(const void* low, const void* res, void* out, int
                        static_cast<hipStream_t>(stream), static_cast<const float*>(low), static_cast<const float*>(res),
                        static_cast<float*>(out), C, Hl, Wl, f, relu, low_ctot, low_coff, res_ctot, res_coff, out_ctot,
                        out_coff, total4);
+    return otp_launch_status();
+}
+
+extern "C" int otp_upsample_add_multi(const void* const* lows, const int* factors, int nlow, const void* res, void* out, int N,
+                                      int C, int Hh, int Wh, int relu, int res_ctot, int res_coff, int out_ctot, int out_coff,
+                                      void* stream) {
+    if (!lows || !factors || !res || !out || nlow < 1 || nlow > 3 || N <= 0 || C <= 0 || Hh <= 0 || Wh <= 0) return OTP_ERR_BAD_ARG;
+    if (Wh % 4 || res_ctot < res_coff + C || out_ctot < out_coff + C) return OTP_ERR_UNSUPPORTED;
+    UpMulti U{};
+    U.n = nlow;
+    for (int k = 0; k < nlow; ++k) {
+        const int f = factors[k];
+        if (!lows[k]) return OTP_ERR_BAD_ARG;
+        if (f < 2 || (f & (f - 1)) || Hh % f || Wh % f) return OTP_ERR_UNSUPPORTED;
+        U.low[k] = static_cast<const float*>(lows[k]);
+        U.f[k] = f;
+    }
+    if ((reinterpret_cast<uintptr_t>(res) | reinterpret_cast<uintptr_t>(out)) & 15 || ((size_t)Hh * Wh) % 4) return OTP_ERR_UNSUPPORTED;
+    const size_t total4 = (size_t)N * C * Hh * (Wh / 4);
+    const size_t blocks = (total4 + 255) / 256;
+    hipLaunchKernelGGL(upsample_add_multi_kernel, dim3(blocks > 8192 ? 8192 : (unsigned)blocks), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), U, static_cast<const float*>(res), static_cast<float*>(out), C, Hh, Wh,
+                       relu, res_ctot, res_coff, out_ctot, out_coff, total4);
     return otp_launch_status();
 }
 

@@ -14,6 +14,7 @@ order [cur | prev | next | pprev | nnext] x B (OTPose.py:317) without materialis
 """
 from __future__ import annotations
 
+import ctypes
 import os
 import warnings
 from typing import Callable, List
@@ -50,6 +51,7 @@ class InferenceEngine:
         self.use_winograd = os.environ.get("OTPOSE_WINOGRAD", "1") != "0"     # 3x3 stride-1 convs via csrc/wino.hip
         self.use_fused_mlp = os.environ.get("OTPOSE_FUSED_MLP", "1") != "0"   # transformer MLP via csrc/mlp.hip
         self.fuse_shortcut = os.environ.get("OTPOSE_FUSE_SHORTCUT", "1") != "0"  # layer1 shortcut folded into conv3
+        self.fuse_upsample = os.environ.get("OTPOSE_FUSE_UPSAMPLE", "1") != "0"  # a fuse row's upsampled terms in one pass
         self.use_dense_cc = os.environ.get("OTPOSE_DENSE_CC", "1") != "0"     # q / k / v / proj via csrc/dense.hip
         self.use_qkv_front = os.environ.get("OTPOSE_QKV_FRONT", "1") != "0"   # + dwconv / LayerNorm fused in front of them
         # independent sub-graphs (the HRNet branches of a stage, the rows of its fuse layer, the two temporal encoders) are
@@ -243,8 +245,16 @@ class InferenceEngine:
             # emitted conv as its residual; later terms accumulate in place; the last one applies the ReLU.
             terms = [j for j in range(n) if j != i]
             y = None
+            # two or three upsampled terms (the j > i tail of the row): their convs run at low resolution and ONE streaming pass
+            # adds them all to the high-resolution tensor (same summation order as chaining them)
+            ups = [j for j in terms if j > i]
+            hi_w = xs[i].t.shape[3]
+            if self.fuse_upsample and len(ups) >= 2 and hi_w % 4 == 0:
+                terms = [j for j in terms if j < i]
+            else:
+                ups = []
             for idx, j in enumerate(terms):
-                last = idx == len(terms) - 1
+                last = idx == len(terms) - 1 and not ups
                 act = ACT_RELU if last else ACT_NONE
                 res = xs[i] if y is None else y
                 fl = mod.fuse_layers[i][j]
@@ -268,6 +278,17 @@ class InferenceEngine:
                         t = self.conv_bn(t, fl[k][0], fl[k][1], ACT_RELU)
                     tgt = y if y is not None else View(self.new(*xs[i].t.shape))
                     y = self.conv_bn(t, fl[-1][0], fl[-1][1], act, res=res, out=tgt)
+            if ups:
+                res = xs[i] if y is None else y
+                tgt = y if y is not None else View(self.new(*xs[i].t.shape))
+                lows = [self.conv_bn(xs[j], mod.fuse_layers[i][j][0], mod.fuse_layers[i][j][1], ACT_NONE) for j in ups]
+                n_, c_, hh, wh = tgt.t.shape[0], xs[i].C, xs[i].t.shape[2], xs[i].t.shape[3]
+                lp = (ctypes.c_void_p * len(ups))(*[hip.ptr(v.t) for v in lows])
+                fp = (ctypes.c_int * len(ups))(*[2 ** (j - i) for j in ups])
+                self._keep += [lp, fp]
+                self.call(self.lib.otp_upsample_add_multi, "otp_upsample_add_multi", lp, fp, len(ups), hip.ptr(res.t),
+                          hip.ptr(tgt.t), n_, c_, hh, wh, 1, res.ctot, res.coff, tgt.ctot, tgt.coff)
+                y = tgt
             outs.append(y)
         self.on_stream(0)
         self.join(range(1, len(mod.fuse_layers)))

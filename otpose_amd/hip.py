@@ -95,6 +95,7 @@ SIGNATURES = {
     "otp_upsample_linear_backward": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "otp_upsample_linear": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "otp_upsample_add": (c_int, [c_void_p] * 3 + [c_int] * 12 + [c_void_p]),
+    "otp_upsample_add_multi": (c_int, [ctypes.POINTER(c_void_p), ctypes.POINTER(c_int), c_int, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
     "otp_upsample_add_backward": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
     "otp_axpby": (c_int, [c_void_p, c_void_p, c_float, c_float, c_size_t, c_void_p]),
     "otp_heatmap_decode": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),

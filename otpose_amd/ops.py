@@ -487,6 +487,20 @@ def upsample_add(low, res, f, relu=False, out=None):
     return out
 
 
+def upsample_add_multi(lows, res, relu=False, out=None):
+    """out = act(res + sum_k nearest_upsample(lows[k])) in one pass (an HRNet fuse row's upsampled terms, summed in list
+    order); each ``lows[k]`` is (N, C, H / f_k, W / f_k) with f_k a power of two >= 2."""
+    _require_gpu(res, *lows)
+    n, c, hh, wh = res.shape
+    out = torch.empty_like(res) if out is None else out
+    lows = [t.contiguous() for t in lows]
+    lp = (ctypes.c_void_p * len(lows))(*[hip.ptr(t) for t in lows])
+    fp = (ctypes.c_int * len(lows))(*[hh // t.shape[2] for t in lows])
+    hip.check(hip.lib().otp_upsample_add_multi(lp, fp, len(lows), hip.ptr(res), hip.ptr(out), n, c, hh, wh, int(relu),
+                                               c, 0, c, 0, hip.stream_of(res)), "otp_upsample_add_multi")
+    return out
+
+
 def ln_channel(x, gamma, beta, eps=1e-5, pool=False):
     _require_gpu(x)
     b, c, t = x.shape

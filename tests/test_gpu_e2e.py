@@ -95,9 +95,9 @@ def test_parallel_stream_graph_equals_single_stream(monkeypatch):
     outs = {}
     for key, env in (("default", {}), ("single", {"OTPOSE_STREAMS": "0"}), ("direct", {"OTPOSE_WINOGRAD": "0"}),
                      ("generic", {"OTPOSE_FUSED_MLP": "0", "OTPOSE_DENSE_CC": "0"}),
-                     ("unfused", {"OTPOSE_QKV_FRONT": "0", "OTPOSE_FUSE_SHORTCUT": "0"})):
+                     ("unfused", {"OTPOSE_QKV_FRONT": "0", "OTPOSE_FUSE_SHORTCUT": "0", "OTPOSE_FUSE_UPSAMPLE": "0"})):
         for k in ("OTPOSE_STREAMS", "OTPOSE_WINOGRAD", "OTPOSE_FUSED_MLP", "OTPOSE_DENSE_CC", "OTPOSE_QKV_FRONT",
-                  "OTPOSE_FUSE_SHORTCUT"):
+                  "OTPOSE_FUSE_SHORTCUT", "OTPOSE_FUSE_UPSAMPLE"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)

@@ -320,6 +320,23 @@ def test_qkv_front_matches_fp64(T):
         _close(a, b.cpu(), 3e-6)
 
 
+@pytest.mark.parametrize("nlow", [2, 3])
+def test_upsample_add_multi_equals_the_chain(nlow):
+    """One pass over the high-resolution tensor == chaining otp_upsample_add term by term (same order: bit-identical), and
+    both equal F.interpolate(nearest) sums (HRNet fuse rows, model/HRNet.py:426-439, 488-494)."""
+    n, c, h, w = 2, 5, 16, 24
+    res = seeded((n, c, h, w), 81)
+    lows = [seeded((n, c, h // f, w // f), 82 + i) for i, f in enumerate((2, 4, 8)[:nlow])]
+    ref = res.clone()
+    chain = res.cuda()
+    for i, low in enumerate(lows):
+        ref = ref + F.interpolate(low, scale_factor=h // low.shape[2], mode="nearest")
+        chain = ops.upsample_add(low.cuda(), chain, h // low.shape[2], relu=(i == nlow - 1))
+    out = ops.upsample_add_multi([t.cuda() for t in lows], res.cuda(), relu=True)
+    assert torch.equal(out, chain)
+    _close(out, F.relu(ref), 1e-6)
+
+
 def test_joints_losses_match_golden_and_oracle(golden):
     """JointsMSE_OHKMMSELoss / JointMSELoss (model/loss.py:95-182): values vs reference-generated goldens, gradients and
     the use_target_weight=False / effective_num_joints forms vs the oracle."""
