@@ -4,6 +4,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/otpose_hip.h"
 
 #define OTP_LDS_LIMIT (160 * 1024)
@@ -12,15 +14,23 @@ static inline int otp_launch_status() {
     return hipGetLastError() == hipSuccess ? OTP_OK : OTP_ERR_LAUNCH;
 }
 
-// Raise the dynamic-LDS limit of a kernel once per process and per kernel instantiation (the static lives
-// in the enclosing template instantiation); never called again, so launches stay graph-capturable.
+// Raise the dynamic-LDS limit of a kernel once per DEVICE and per kernel instantiation (the flags live in the
+// enclosing template instantiation): hipFuncSetAttribute applies to the device that is current at the call, so a
+// process driving several GPUs must set it on each.  Set-once, so launches stay graph-capturable; the flag is an
+// atomic bit per device (two threads racing both set the attribute, which is idempotent).
+#define OTP_MAX_DEVICES 64
 #define OTP_ALLOW_BIG_LDS(kern, bytes)                                                                      \
     do {                                                                                                    \
-        static bool otp_done_ = false;                                                                      \
-        if (!otp_done_ && (bytes) > 64 * 1024) {                                                            \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                  \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, OTP_LDS_LIMIT);           \
-            otp_done_ = true;                                                                               \
+        if ((bytes) > 64 * 1024) {                                                                          \
+            static std::atomic<uint64_t> otp_done_{0};                                                      \
+            int otp_dev_ = 0;                                                                               \
+            (void)hipGetDevice(&otp_dev_);                                                                  \
+            const uint64_t otp_bit_ = 1ull << (otp_dev_ & (OTP_MAX_DEVICES - 1));                           \
+            if (!(otp_done_.load(std::memory_order_acquire) & otp_bit_)) {                                  \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                              \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, OTP_LDS_LIMIT);       \
+                otp_done_.fetch_or(otp_bit_, std::memory_order_release);                                    \
+            }                                                                                               \
         }                                                                                                   \
     } while (0)
 

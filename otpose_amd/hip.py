@@ -8,11 +8,13 @@ from __future__ import annotations
 
 import ctypes
 import os
+import threading
 from ctypes import c_float, c_int, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OTPOSE_HIP_LIB") or os.path.join(_HERE, "csrc", "libotpose_hip.so")   # env: dev builds
 _lib = None
+_tls = threading.local()          # device of the tensor the latest stream_of() was asked about (per thread)
 
 OTP_OK = 0
 _ERRORS = {
@@ -114,12 +116,37 @@ def lib():
             raise RuntimeError(
                 f"HIP library {LIB_PATH} is missing - run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or `make -C otpose_amd/csrc`). otpose_amd has no CPU or PyTorch-op fallback.")
-        _lib = ctypes.CDLL(LIB_PATH)
+        cdll = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
-            fn = getattr(_lib, name)
+            fn = getattr(cdll, name)
             fn.restype = res
             fn.argtypes = args
+        _lib = _DeviceGuarded(cdll)
     return _lib
+
+
+class _DeviceGuarded:
+    """The loaded library with every entry point wrapped so that a launch runs with the device of its tensors current:
+    the kernels are enqueued on the stream ``stream_of(t)`` returned, and a HIP launch (and ``hipFuncSetAttribute``)
+    applies to the *current* device.  PyTorch's current device is per thread and DataParallel-style callers already set
+    it, so the guard only acts when a caller hands tensors of another device (single-process multi-device use)."""
+
+    def __init__(self, cdll):
+        self._cdll = cdll
+        for name in SIGNATURES:
+            setattr(self, name, self._wrap(getattr(cdll, name)))
+
+    @staticmethod
+    def _wrap(fn):
+        import torch
+
+        def call(*args):
+            dev = getattr(_tls, "dev", None)
+            if dev is not None and dev != torch.cuda.current_device():
+                with torch.cuda.device(dev):
+                    return fn(*args)
+            return fn(*args)
+        return call
 
 
 def check(status: int, what: str):
@@ -135,4 +162,5 @@ def ptr(t):
 def stream_of(t):
     """The HIP stream PyTorch is currently enqueuing on for ``t``'s device."""
     import torch
+    _tls.dev = t.device.index
     return c_void_p(torch.cuda.current_stream(t.device).cuda_stream)

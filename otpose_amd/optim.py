@@ -56,8 +56,30 @@ class FusedAdamW(torch.optim.Optimizer):
         devs = {f["p"].device for f in self._flat if f}
         self._normsq = {d: torch.zeros(1, dtype=torch.float64, device=d) for d in devs}
 
+    def _rehome_grads(self):
+        """``p.grad`` must stay a view of the flat gradient buffer.  ``model.zero_grad()`` (set_to_none=True by default)
+        or any ``p.grad = ...`` detaches it, after which autograd accumulates outside the buffer and step() /
+        allreduce_flat_grads() would see zeros: copy such a gradient back and re-point the view.  A parameter whose
+        gradient is None keeps a zero slot (its weight decay / moment update then match torch.optim.AdamW only if the
+        caller really meant "zero gradient"; use this optimizer's own zero_grad() to keep the views)."""
+        for f in self._flat:
+            if not f:
+                continue
+            off = 0
+            for p in f["params"]:
+                n = p.numel()
+                slot = f["g"][off:off + n]
+                if p.grad is None:
+                    slot.zero_()
+                    p.grad = slot.view_as(p)
+                elif p.grad.data_ptr() != slot.data_ptr():
+                    slot.copy_(p.grad.reshape(-1))
+                    p.grad = slot.view_as(p)
+                off += n
+
     def flat_grads(self):
         """The flat gradient buffers (one per group) - the units to all-reduce."""
+        self._rehome_grads()
         return [f["g"] for f in self._flat if f]
 
     def zero_grad(self, set_to_none: bool = False):
@@ -70,6 +92,7 @@ class FusedAdamW(torch.optim.Optimizer):
     def grad_norm(self):
         """Global L2 norm of all gradients as a device scalar (what clip_grad_norm_ returns), no host sync."""
         L = hip.lib()
+        self._rehome_grads()
         for acc in self._normsq.values():
             acc.zero_()
         for f in self._flat:
@@ -83,6 +106,7 @@ class FusedAdamW(torch.optim.Optimizer):
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         L = hip.lib()
+        self._rehome_grads()
         clip = self.max_grad_norm > 0.0
         if clip:
             self.grad_norm()

@@ -162,6 +162,7 @@ class GradBuckets:
         self._where = {id(p): (i, j) for i, bk in enumerate(self.buckets) for j, p in enumerate(bk)}
         self._pending: List[int] = [len(bk) for bk in self.buckets]
         self._work: List[Optional[object]] = [None] * len(self.buckets)
+        self._next = 0                      # hook mode: the next bucket allowed to launch (strict index order)
         self._handles = []
         if hooks and self.world > 1:
             for p in self.params:
@@ -187,9 +188,15 @@ class GradBuckets:
 
     def _on_grad(self, p: torch.nn.Parameter) -> None:
         i, _ = self._where[id(p)]
+        if self._pending[i] <= 0:
+            raise RuntimeError("GradBuckets: a second backward reached a bucket before finish(); gradient accumulation "
+                               "needs hooks=False (call reduce() after the last backward)")
         self._pending[i] -= 1
-        if self._pending[i] == 0:
-            self._pack_and_launch(i)
+        # collectives must be issued in the same order on every rank: bucket i goes out only after 0..i-1, whatever
+        # order the gradients land in on this rank (a parameter without a gradient here must not reorder the launches)
+        while self._next < len(self.buckets) and self._pending[self._next] == 0:
+            self._pack_and_launch(self._next)
+            self._next += 1
 
     # ---- public -------------------------------------------------------------------------------
     def reduce(self) -> None:
@@ -207,7 +214,7 @@ class GradBuckets:
             return
         for i, bk in enumerate(self.buckets):
             if self._work[i] is None:          # hook mode: a parameter of this bucket got no gradient
-                self._pack_and_launch(i)
+                self._pack_and_launch(i)       # (flushed here in index order, like the launches above)
             self._work[i].wait()
             flat = self.flat[i]
             flat.div_(self.world)
@@ -218,8 +225,47 @@ class GradBuckets:
                     p.grad.copy_(flat[o:o + p.numel()].view_as(p))
             self._work[i] = None
             self._pending[i] = len(bk)
+        self._next = 0
 
     def remove_hooks(self) -> None:
         for h in self._handles:
             h.remove()
         self._handles = []
+
+
+def joint_flags(target: torch.Tensor) -> torch.Tensor:
+    """Per-joint "the ground truth of this joint has an exact-1 peak somewhere in the batch" flags (model/loss.py:47:
+    ``torch.max(heatmap_gt) == 1``) of this rank's (B, J, h, w) targets, as int32 (J,)."""
+    return (target.amax(dim=(0, 2, 3)) == 1).to(torch.int32)
+
+
+def train_step_dp(model, optimizer, x, margin, target, target_weight, forward=None, criterion=None):
+    """One data-parallel training step on this rank's clips - the reference's ``nn.DataParallel`` iteration
+    (train.py:78-79, script/Common.py:118-144) as one process per GPU:
+
+    forward (training mode) -> ``criterion(outputs, target, target_weight, flags)`` with the per-joint flags of
+    model/loss.py:47 MAX-reduced over ranks, so every rank takes the branch the gathered global batch would take ->
+    backward -> gradient all-reduce (mean) over RCCL (the optimizer's flat buffers when it has them, bucketed otherwise)
+    -> ``optimizer.step()`` (global-norm clip on the already-reduced gradients, identical on every rank).
+
+    ``forward(model, x, margin)`` and ``criterion(outputs, target, target_weight, flags)`` default to the HIP training
+    graph (:mod:`otpose_amd.train`); the CPU tests pass their own.  Returns the rank-mean loss (detached)."""
+    if forward is None or criterion is None:
+        from . import train as _train
+        forward = forward or _train.forward_train
+        criterion = criterion or _train.criterion
+    optimizer.zero_grad()
+    outputs = forward(model, x, margin)
+    flags = allreduce_joint_flags(joint_flags(target))
+    loss = criterion(outputs, target, target_weight, flags)
+    loss.backward()
+    if hasattr(optimizer, "flat_grads"):
+        allreduce_flat_grads(optimizer)
+    elif world_size() > 1:
+        bk = getattr(optimizer, "_otp_buckets", None)
+        if bk is None:
+            bk = GradBuckets([p for g in optimizer.param_groups for p in g["params"]])
+            optimizer._otp_buckets = bk
+        bk.reduce()
+    optimizer.step()
+    return allreduce_mean_(loss.detach().clone())

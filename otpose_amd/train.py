@@ -53,7 +53,7 @@ class StOhkwLossFunction(Function):
     from one fused launch; ``flags`` (J) optionally carries the globally MAX-reduced "GT has an exact-1 peak" flags."""
 
     @staticmethod
-    def forward(ctx, s, t, g, w, flags):
+    def forward(ctx, s, t, g, w, flags, topk=8):
         b, j = s.shape[:2]
         hw = s[0, 0].numel()
         s, t, g = s.contiguous(), t.contiguous(), g.contiguous()
@@ -66,19 +66,20 @@ class StOhkwLossFunction(Function):
         fl = flags.to(torch.int32).contiguous() if given else torch.empty(j, dtype=torch.int32, device=s.device)
         gs, gt, gg = torch.empty_like(s), torch.empty_like(t), torch.empty_like(g)
         hip.check(L.otp_loss_st_ohkw_grads(hip.ptr(s), hip.ptr(t), hip.ptr(g), hip.ptr(wv), hip.ptr(fl), hip.ptr(res),
-                                           hip.ptr(gs), hip.ptr(gt), hip.ptr(gg), hip.ptr(ws), nbytes, b, j, hw, 8,
+                                           hip.ptr(gs), hip.ptr(gt), hip.ptr(gg), hip.ptr(ws), nbytes, b, j, hw, int(topk),
                                            int(given), hip.stream_of(s)), "otp_loss_st_ohkw_grads")
         ctx.save_for_backward(gs, gt, gg)
-        return res[2].clone()
+        ctx.mark_non_differentiable(res)
+        return res[2].clone(), res                 # res = [ohkm_loss_s, (sum_j mse_j) / J, final_loss]
 
     @staticmethod
-    def backward(ctx, gl):
+    def backward(ctx, gl, _gres):
         gs, gt, gg = ctx.saved_tensors
-        return gs * gl, gt * gl, gg * gl, None, None
+        return gs * gl, gt * gl, gg * gl, None, None, None
 
 
 def st_ohkw_loss(s, t, g, w, flags=None):
-    return StOhkwLossFunction.apply(s, t, g, w, flags)
+    return StOhkwLossFunction.apply(s, t, g, w, flags)[0]
 
 
 class JointsMseLossFunction(Function):
@@ -109,11 +110,13 @@ class ST_OHKW_MSELoss(torch.nn.Module):
                                       "fails at torch.cat of the empty student list (loss.py:73-80)")
         self.use_target_weight, self.topk = use_target_weight, topk
 
-    def forward(self, output_s, output_t, target, target_weight, flags=None):
-        final = st_ohkw_loss(output_s, output_t, target, target_weight, flags)
-        with torch.no_grad():
-            d = ops.st_ohkw_loss(output_s, output_t, target, target_weight, self.topk, flags)
-        return {"ohkm_loss_s": d["ohkm_loss_s"], "mse_loss_s": d["mse_loss_s"], "final_loss": final}
+    def forward(self, output_s, output_t, target, target_weight, effective_num_joints: int = None, *, flags=None):
+        """Reference signature (model/loss.py:25); ``flags`` (keyword only) carries the globally MAX-reduced per-joint
+        ``max(gt) == 1`` flags of a data-parallel run.  One launch yields the three scalars and the gradients."""
+        final, res = StOhkwLossFunction.apply(output_s, output_t, target, target_weight, flags, self.topk)
+        j = output_t.shape[1]
+        mse = res[1] if effective_num_joints in (None, j) else res[1] * (j / float(effective_num_joints))
+        return {"ohkm_loss_s": res[0], "mse_loss_s": mse, "final_loss": final}
 
 
 class JointsMSE_OHKMMSELoss(torch.nn.Module):

@@ -2,6 +2,7 @@
 hook-overlapped), the per-joint flag MAX-reduce and loss-mean composition."""
 import os
 import socket
+import tempfile
 
 import pytest
 import torch
@@ -25,7 +26,24 @@ def _make_model(seed=0):
                                torch.nn.Flatten(), torch.nn.Linear(4 * 6 * 5, 7))
 
 
-def _worker(rank, world, port, hooks, q):
+def _spawn(target, world, *args):
+    """Run ``target(rank, world, port, out_path, *args)`` on ``world`` spawned ranks; rank 0 ``torch.save``s its result to
+    ``out_path`` (plain file hand-off: a tensor put on a multiprocessing queue travels through a shared-memory handle
+    that dies with the sender, which made this test flaky when rank 0 exited before the parent had read it)."""
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "rank0.pt")
+        procs = [ctx.Process(target=target, args=(r, world, port, out) + args) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(180)
+            assert p.exitcode == 0, f"rank exited with {p.exitcode}"
+        return torch.load(out)
+
+
+def _worker(rank, world, port, out_path, hooks):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     torch.set_num_threads(1)
@@ -62,23 +80,14 @@ def _worker(rank, world, port, hooks, q):
         buckets.reduce()
     grads2 = [p.grad.clone() for p in model.parameters()]
     if rank == 0:
-        q.put({"grads": grads, "grads2": grads2, "loss": lm, "flags": flags, "gathered": gathered})
+        torch.save({"grads": grads, "grads2": grads2, "loss": lm, "flags": flags, "gathered": gathered}, out_path)
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("hooks", [False, True])
 def test_two_rank_gradient_allreduce_matches_global_batch(hooks):
-    ctx = mp.get_context("spawn")
-    q = ctx.SimpleQueue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, hooks, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    out = q.get()
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
+    out = _spawn(_worker, 2, hooks)
     g = torch.Generator().manual_seed(5)
     x = torch.randn(6, 3, 6, 5, generator=g)
     y = torch.randn(6, 7, generator=g)
@@ -125,7 +134,7 @@ class _FlatStub:
         return self.bufs
 
 
-def _flat_worker(rank, world, port, q):
+def _flat_worker(rank, world, port, out_path):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     torch.set_num_threads(1)
@@ -133,21 +142,142 @@ def _flat_worker(rank, world, port, q):
     opt = _FlatStub([torch.full((1000,), float(rank + 1)), torch.arange(7.) * (rank + 1)])
     P.allreduce_flat_grads(opt)
     if rank == 0:
-        q.put([b.clone() for b in opt.bufs])
+        torch.save([b.clone() for b in opt.bufs], out_path)
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_two_rank_flat_gradient_allreduce():
     """allreduce_flat_grads: one all-reduce per flat group buffer, mean over ranks, in place."""
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_flat_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    a, b = q.get(timeout=120)
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+    a, b = _spawn(_flat_worker, 2)
     assert torch.equal(a, torch.full((1000,), 1.5)) and torch.equal(b, torch.arange(7.) * 1.5)
+
+
+# ---- hook mode: launch order must not depend on which gradients exist on a rank -----------------------------------
+class _TwoHeads(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(3)
+        self.a = torch.nn.Linear(5, 64)
+        self.b = torch.nn.Linear(5, 64)
+        self.c = torch.nn.Linear(64, 3)
+
+    def forward(self, x, use_b):
+        h = self.a(x) + (self.b(x) if use_b else 0)
+        return self.c(h)
+
+
+def _uneven_worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    P.init_from_env("gloo")
+    m = _TwoHeads()
+    bk = P.GradBuckets(m.parameters(), bucket_bytes=512, hooks=True)
+    assert len(bk.buckets) >= 3
+    x = torch.full((4, 5), float(rank + 1))
+    # head b gets a gradient on rank 1 only: rank 0's bucket for it is flushed in finish(), after the others were
+    # launched in index order on both ranks
+    m(x, use_b=(rank == 1)).sum().backward()
+    bk.finish()
+    res = [p.grad.clone() for p in m.parameters()]
+    # a second backward before finish() must be refused in hook mode
+    m.zero_grad()
+    m(x, True).sum().backward()
+    try:
+        m(x, True).sum().backward()
+        refused = False
+    except RuntimeError:
+        refused = True
+    if rank == 0:
+        torch.save({"grads": res, "refused": refused}, out_path)
+    # leave without another collective: the second step's buckets are half launched by design
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_hook_mode_with_a_gradient_missing_on_one_rank():
+    out = _spawn(_uneven_worker, 2)
+    assert out["refused"]
+    m = _TwoHeads()
+    x1, x2 = torch.full((4, 5), 1.0), torch.full((4, 5), 2.0)
+    (m(x1, False).sum() + m(x2, True).sum()).backward()
+    for got, p in zip(out["grads"], m.parameters()):
+        assert torch.allclose(got, p.grad / 2, atol=1e-5), float((got - p.grad / 2).abs().max())
+
+
+# ---- train_step_dp: MAX-reduced joint flags make the sharded loss the global-batch loss -------------------------------
+def _loss_case():
+    g = torch.Generator().manual_seed(11)
+    B, J, h, w = 4, 17, 6, 5
+    s = torch.randn(B, J, h, w, generator=g) * 0.3
+    t = torch.randn(B, J, h, w, generator=g) * 0.3
+    tgt = torch.rand(B, J, h, w, generator=g) * 0.9
+    # exact-1 peaks: joints 0-5 only in the first half, joints 6-9 only in the second half, 10-12 in both, 13-16 nowhere
+    for j in range(0, 6):
+        tgt[0, j, 2, 2] = 1.0
+    for j in range(6, 10):
+        tgt[3, j, 1, 4] = 1.0
+    for j in range(10, 13):
+        tgt[1, j, 0, 0] = 1.0
+        tgt[2, j, 5, 4] = 1.0
+    wgt = (torch.rand(B, J, 1, generator=g) > 0.15).float()
+    return s, t, tgt, wgt
+
+
+class _Heads(torch.nn.Module):
+    """Stand-in model: student / teacher maps are learnable tensors indexed by the clip ids in ``x``."""
+
+    def __init__(self, s, t):
+        super().__init__()
+        self.s = torch.nn.Parameter(s.clone())
+        self.t = torch.nn.Parameter(t.clone())
+
+
+def _dp_worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    P.init_from_env("gloo")
+    from oracle import otpose_oracle as O
+    s, t, tgt, wgt = _loss_case()
+    b, e = P.shard_range(s.shape[0], rank, world)
+    model = _Heads(s, t)
+    opt = torch.optim.SGD(model.parameters(), lr=0.5)
+    ids = torch.arange(b, e)
+
+    def forward(m, x, margin):
+        return m.s[x], m.t[x]
+
+    def criterion(outs, target, target_weight, flags):
+        return O.st_ohkw_mse_loss(outs[0], outs[1], target, target_weight, 8, global_flags=flags)["final_loss"]
+
+    local_flags = P.joint_flags(tgt[b:e]).tolist()
+    loss = P.train_step_dp(model, opt, ids, None, tgt[b:e], wgt[b:e], forward=forward, criterion=criterion)
+    if rank == 0:
+        torch.save({"loss": loss, "s": model.s.detach().clone(), "t": model.t.detach().clone(),
+                    "local_flags": local_flags}, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_train_step_dp_matches_the_global_batch_loss():
+    """Two half batches with MAX-reduced flags == ST_OHKW on the whole batch (model/loss.py:47,
+    script/Common.py:124-130), for the loss value and for the parameter update."""
+    from oracle import otpose_oracle as O
+    out = _spawn(_dp_worker, 2)
+    s, t, tgt, wgt = _loss_case()
+    # the local flags of rank 0 differ from the global ones, so the reduce is what makes the branch right
+    glob = P.joint_flags(tgt).tolist()
+    assert out["local_flags"] != glob and glob == [1] * 13 + [0] * 4
+    model = _Heads(s, t)
+    ref = O.st_ohkw_mse_loss(model.s, model.t, tgt, wgt, 8)
+    # the OHKM mean and every per-joint mean are means over samples: with equal shards the mean over ranks of the
+    # local losses is the global loss
+    assert abs(float(out["loss"]) - float(ref["final_loss"].detach())) < 1e-6
+    ref["final_loss"].backward()
+    with torch.no_grad():
+        # rank r's gradient is non-zero on its own rows only and carries a 1/(B/world) mean; the all-reduce mean
+        # divides by world, so the update equals the global-batch update
+        assert torch.allclose(out["s"], model.s - 0.5 * model.s.grad, atol=1e-6)
+        assert torch.allclose(out["t"], model.t - 0.5 * model.t.grad, atol=1e-6)

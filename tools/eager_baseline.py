@@ -38,6 +38,9 @@ times.sort()
 med = times[len(times) // 2]
 print("eager PyTorch-ROCm forward, batch %d: median %.1f ms -> %.1f frames/s (min %.1f ms)" %
       (B, med, 5 * B / med * 1e3, times[0]))
+result = {"batch": B, "forward_ms": med, "forward_min_ms": times[0], "frames_per_s": 5 * B / med * 1e3,
+          "what": "oracle/otpose_oracle.py graph on stock PyTorch-ROCm ops (MIOpen / rocBLAS, DCN as gather ops), fp32, "
+                  "HIP events, median of %d" % len(times), "device": torch.cuda.get_device_name(0)}
 
 if TRAIN:
     # training step of the same eager graph (BatchNorm batch statistics, two ST_OHKW terms, backward, clip, AdamW)
@@ -72,3 +75,12 @@ if TRAIN:
               "total %.1f ms (%.1f frames/s)  peak mem %.1f GB" %
               (it, B, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t3 - t0) * 1e3, 5 * B / (t3 - t0),
                torch.cuda.max_memory_allocated() / 2**30), flush=True)
+        result["train_step_%d" % it] = {"forward_loss_ms": (t1 - t0) * 1e3, "backward_ms": (t2 - t1) * 1e3,
+                                         "optimizer_ms": (t3 - t2) * 1e3, "total_ms": (t3 - t0) * 1e3,
+                                         "peak_mem_GB": torch.cuda.max_memory_allocated() / 2**30}
+
+for a in sys.argv:
+    if a.startswith("--json="):
+        import json
+        with open(a[7:], "w") as f:
+            json.dump(result, f, indent=1)
