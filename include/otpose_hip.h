@@ -317,6 +317,55 @@ int otp_loss_joints_mse(const void* o, const void* g, const void* w, void* resul
                         size_t workspace_bytes, int B, int J, int HW, int topk, int ohkm, int effective_num_joints,
                         void* stream);
 
+
+/* ---- bf16 training path of the backbone (BASELINE configs[2]; reference step script/Common.py:118-144 over
+ * model/HRNet.py:116-152).  Activations are NHWC bfloat16 with the channel stride rounded up to 8 (padding channels
+ * zero); contractions run on the bf16 matrix cores with fp32 accumulation; statistics, parameter gradients and the
+ * master weights are fp32.  `desc` describes the convolution as seen by the kernel (Cin -> Cout, true channel counts). */
+typedef struct otp_nhwc_conv_desc {
+    int N, H, W, Cin, Cout, kh, kw, stride, pad, dil;
+    int out_mode;                /* 0: NHWC bf16 (+ per-tile channel statistics), 1: NCHW fp32 (+ bias), no statistics */
+} otp_nhwc_conv_desc;
+/* bytes of the packed bf16 weights / rows of the per-tile statistics buffer ([rows][2][CoutS] floats: sum, sum of squares
+ * of the bf16-rounded outputs) / {MB, NB, CK, chunks, m-tiles, grid, LDS bytes, k-steps} of the launch (host only) */
+size_t otp_nhwc_conv_weight_bytes(const otp_nhwc_conv_desc* desc);
+int otp_nhwc_conv_stats_rows(const otp_nhwc_conv_desc* desc);
+int otp_nhwc_conv_plan(const otp_nhwc_conv_desc* desc, int* out8);
+/* fp32 (Cout, Cin, kh, kw) weights -> packed bf16.  dgrad != 0: `weight` is the (desc->Cin, desc->Cout, kh, kw) tensor of
+ * the FORWARD conv and the packed operator is its input gradient (channels transposed, taps flipped; the caller sets
+ * desc->pad = dil*(k-1) - pad and feeds a zero-inserted gradient for stride > 1, otp_nhwc_dilate). */
+int otp_nhwc_conv_pack(const void* weight, void* wpacked, const otp_nhwc_conv_desc* desc, int dgrad, void* stream);
+/* out = conv(x) (+ bias, fp32 (Cout), may be NULL); stats may be NULL */
+int otp_nhwc_conv_bf16(const void* x, const void* wpacked, const void* bias, void* out, void* stats,
+                       const otp_nhwc_conv_desc* desc, void* stream);
+/* grad_weight (Cout, Cin, kh, kw) fp32 is OVERWRITTEN with sum over batch and pixels of grad_out x shifted input;
+ * x (N, H, W, CinS) and grad_out (N, Ho, Wo, CoutS) bf16; 1x1 and 3x3 kernels */
+size_t otp_nhwc_wgrad_workspace(const otp_nhwc_conv_desc* desc);
+int otp_nhwc_wgrad_bf16(const void* x, const void* grad_out, void* grad_weight, void* workspace, size_t workspace_bytes,
+                        const otp_nhwc_conv_desc* desc, void* stream);
+/* BatchNorm2d with batch statistics (nn.BatchNorm2d in training mode, model/HRNet.py:500-571): the conv's per-tile sums
+ * -> mean / rstd / scale = gamma*rstd / shift = beta - mean*scale (C-padded arrays of CS floats) and the running
+ * statistics update; y = act(x*scale + shift (+ res)); backward in two passes (sums of g and g*xhat, then gx / gres). */
+int otp_nhwc_bn_finalize(const void* partials, int rows, int C, int CS, float count, const void* gamma, const void* beta,
+                         void* mean, void* rstd, void* scale, void* shift, void* running_mean, void* running_var, float eps,
+                         float momentum, void* stream);
+int otp_nhwc_bn_apply(const void* x, const void* scale, const void* shift, const void* res, void* y, size_t pixels, int CS,
+                      int relu, void* stream);
+size_t otp_nhwc_bn_backward_workspace(size_t pixels, int CS);
+int otp_nhwc_bn_backward(const void* gy, const void* y, const void* x, const void* mean, const void* rstd, const void* gamma,
+                         void* gx, void* gres, void* dgamma, void* dbeta, void* workspace, size_t workspace_bytes,
+                         size_t pixels, int C, int CS, int relu, void* stream);
+/* out = act(res + nearest_upsample_f(low)) on NHWC bf16 (HRNet fuse rows, model/HRNet.py:426-439,488-494) and its backward */
+int otp_nhwc_upsample_add(const void* low, const void* res, void* out, int N, int H, int W, int CS, int f, int relu,
+                          void* stream);
+int otp_nhwc_upsample_add_backward(const void* gy, const void* out, void* gres, void* glow, int N, int Hl, int Wl, int CS,
+                                   int f, int relu, void* stream);
+/* layout / precision hand-over between the fp32 NCHW tensors of the module boundary and the NHWC bf16 interior;
+ * frame_split = B > 0 reads the (B, 5*C, H, W) clip as (5B, C, H, W) like otp_conv2d does (model/OTPose.py:317) */
+int otp_nchw_f32_to_nhwc_bf16(const void* in, void* out, int N, int C, int H, int W, int frame_split, void* stream);
+int otp_nhwc_bf16_to_nchw_f32(const void* in, void* out, int N, int C, int H, int W, void* stream);
+int otp_nhwc_dilate(const void* in, void* out, int N, int Hi, int Wi, int s, int H, int W, int CS, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

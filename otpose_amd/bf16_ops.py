@@ -1,0 +1,273 @@
+"""bf16 training operators of the backbone over the C-ABI (``csrc/nhwc.hip``; BASELINE configs[2], reference step
+script/Common.py:118-144 over model/HRNet.py:116-152).
+
+Activations are NHWC bfloat16 tensors ``(N, H, W, CS)`` with ``CS`` = channels rounded up to 8 (padding channels are
+zero); parameters, their gradients, BatchNorm statistics and running buffers are fp32 (the fp32 *master* weights are cast
+to bf16 while they are packed for the matrix cores, every step).  Every ``torch.autograd.Function`` here launches HIP
+kernels in both directions; PyTorch supplies memory, streams and the tape.  CPU tensors raise.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+from torch.autograd import Function
+
+from . import hip
+from .ops import _require_gpu
+
+BF16 = torch.bfloat16
+
+
+def cs(c: int) -> int:
+    """Channel stride of an NHWC bf16 activation with ``c`` channels."""
+    return (c + 7) // 8 * 8
+
+
+def _desc(n, h, w, cin, cout, kh, kw, stride, pad, dil, out_mode=0):
+    return hip.NhwcConvDesc(n, h, w, cin, cout, kh, kw, stride, pad, dil, out_mode)
+
+
+def _new(shape, dtype, like):
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+def to_nhwc(x: torch.Tensor, frame_split: int = 0) -> torch.Tensor:
+    """(N, C, H, W) fp32 -> (N, H, W, CS) bf16.  ``frame_split = B``: ``x`` is the (B, 5*C', H, W) clip tensor read as
+    (5B, C', H, W) in the reference's frame order (model/OTPose.py:317) without materialising the re-layout."""
+    _require_gpu(x)
+    x = x.contiguous()
+    if x.dtype != torch.float32:
+        raise TypeError("to_nhwc expects float32")
+    if frame_split:
+        b, c5, h, w = x.shape
+        n, c = 5 * b, c5 // 5
+    else:
+        n, c, h, w = x.shape
+    out = _new((n, h, w, cs(c)), BF16, x)
+    hip.check(hip.lib().otp_nchw_f32_to_nhwc_bf16(hip.ptr(x), hip.ptr(out), n, c, h, w, int(frame_split), hip.stream_of(x)),
+              "otp_nchw_f32_to_nhwc_bf16")
+    return out
+
+
+def to_nchw(x: torch.Tensor, c: int) -> torch.Tensor:
+    """(N, H, W, CS) bf16 -> (N, c, H, W) fp32."""
+    _require_gpu(x)
+    n, h, w, _ = x.shape
+    out = _new((n, c, h, w), torch.float32, x)
+    hip.check(hip.lib().otp_nhwc_bf16_to_nchw_f32(hip.ptr(x.contiguous()), hip.ptr(out), n, c, h, w, hip.stream_of(x)),
+              "otp_nhwc_bf16_to_nchw_f32")
+    return out
+
+
+def _pack(weight, d, dgrad):
+    L = hip.lib()
+    nbytes = L.otp_nhwc_conv_weight_bytes(ctypes.byref(d))
+    if nbytes == 0:
+        raise RuntimeError("otp_nhwc_conv: unsupported convolution shape")
+    wp = torch.empty(nbytes // 2, dtype=BF16, device=weight.device)
+    hip.check(L.otp_nhwc_conv_pack(hip.ptr(weight), hip.ptr(wp), ctypes.byref(d), int(dgrad), hip.stream_of(weight)),
+              "otp_nhwc_conv_pack")
+    return wp
+
+
+def conv_forward(x, weight, bias=None, stride=1, pad=0, dil=1, out_mode=0, want_stats=True):
+    """x (N, H, W, CinS) bf16, weight (Cout, Cin, kh, kw) fp32.  Returns (out, stats, rows): ``out`` NHWC bf16 (out_mode 0)
+    or NCHW fp32 (out_mode 1); ``stats`` = per-tile [rows][2][CoutS] fp32 sums / sums of squares (out_mode 0 only)."""
+    cout, cin, kh, kw = weight.shape
+    n, h, w, cins = x.shape
+    assert cins == cs(cin) and x.dtype == BF16 and x.is_contiguous()
+    d = _desc(n, h, w, cin, cout, kh, kw, stride, pad, dil, out_mode)
+    wp = _pack(weight.contiguous(), d, 0)
+    ho = (h + 2 * pad - dil * (kh - 1) - 1) // stride + 1
+    wo = (w + 2 * pad - dil * (kw - 1) - 1) // stride + 1
+    L = hip.lib()
+    stats, rows = None, 0
+    if out_mode == 0:
+        out = _new((n, ho, wo, cs(cout)), BF16, x)
+        if want_stats:
+            rows = L.otp_nhwc_conv_stats_rows(ctypes.byref(d))
+            stats = _new((rows, 2, cs(cout)), torch.float32, x)
+    else:
+        out = _new((n, cout, ho, wo), torch.float32, x)
+    hip.check(L.otp_nhwc_conv_bf16(hip.ptr(x), hip.ptr(wp), hip.ptr(bias), hip.ptr(out), hip.ptr(stats), ctypes.byref(d),
+                                   hip.stream_of(x)), "otp_nhwc_conv_bf16")
+    return out, stats, rows
+
+
+def conv_dgrad(gy, weight, in_hw, stride, pad, dil):
+    """dL/dx of ``conv_forward``: gy (N, Ho, Wo, CoutS) bf16 -> (N, H, W, CinS) bf16."""
+    cout, cin, kh, kw = weight.shape
+    n = gy.shape[0]
+    h, w = in_hw
+    L = hip.lib()
+    g = gy
+    if stride > 1:
+        hd, wd = h + 2 * pad - dil * (kh - 1), w + 2 * pad - dil * (kw - 1)
+        gd = _new((n, hd, wd, gy.shape[3]), BF16, gy)
+        hip.check(L.otp_nhwc_dilate(hip.ptr(gy), hip.ptr(gd), n, gy.shape[1], gy.shape[2], stride, hd, wd, gy.shape[3],
+                                    hip.stream_of(gy)), "otp_nhwc_dilate")
+        g = gd
+    d = _desc(n, g.shape[1], g.shape[2], cout, cin, kh, kw, 1, dil * (kh - 1) - pad, dil, 0)
+    wp = _pack(weight.contiguous(), d, 1)
+    gx = _new((n, h, w, cs(cin)), BF16, gy)
+    hip.check(L.otp_nhwc_conv_bf16(hip.ptr(g), hip.ptr(wp), None, hip.ptr(gx), None, ctypes.byref(d), hip.stream_of(gy)),
+              "otp_nhwc_conv_bf16(dgrad)")
+    return gx
+
+
+_WS = {}
+
+
+def _workspace(device, nbytes):
+    """Grow-only scratch per device (stream-ordered reuse: every user launches on the current stream)."""
+    buf = _WS.get(device)
+    if buf is None or buf.numel() * 4 < nbytes:
+        buf = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+        _WS[device] = buf
+    return buf
+
+
+def conv_wgrad(x, gy, weight_shape, stride, pad, dil):
+    cout, cin, kh, kw = weight_shape
+    n, h, w, _ = x.shape
+    d = _desc(n, h, w, cin, cout, kh, kw, stride, pad, dil, 0)
+    L = hip.lib()
+    nbytes = L.otp_nhwc_wgrad_workspace(ctypes.byref(d))
+    if nbytes == 0:
+        raise RuntimeError("otp_nhwc_wgrad: unsupported convolution shape")
+    ws = _workspace(x.device, nbytes)
+    gw = _new(weight_shape, torch.float32, x)
+    hip.check(L.otp_nhwc_wgrad_bf16(hip.ptr(x), hip.ptr(gy), hip.ptr(gw), hip.ptr(ws), nbytes, ctypes.byref(d),
+                                    hip.stream_of(x)), "otp_nhwc_wgrad_bf16")
+    return gw
+
+
+def bn_finalize(stats, rows, c, count, gamma, beta, running_mean, running_var, momentum, eps):
+    """Per-tile sums -> (mean, rstd, scale, shift) as CS-padded fp32 vectors; updates the running statistics in place."""
+    csz = stats.shape[2]
+    vec = _new((4, csz), torch.float32, stats)
+    hip.check(hip.lib().otp_nhwc_bn_finalize(hip.ptr(stats), rows, c, csz, float(count), hip.ptr(gamma), hip.ptr(beta),
+                                             hip.ptr(vec[0]), hip.ptr(vec[1]), hip.ptr(vec[2]), hip.ptr(vec[3]),
+                                             hip.ptr(running_mean), hip.ptr(running_var), eps, momentum,
+                                             hip.stream_of(stats)), "otp_nhwc_bn_finalize")
+    return vec
+
+
+def bn_apply(x, scale, shift, res, relu):
+    y = torch.empty_like(x)
+    pixels = x.numel() // x.shape[-1]
+    hip.check(hip.lib().otp_nhwc_bn_apply(hip.ptr(x), hip.ptr(scale), hip.ptr(shift), hip.ptr(res), hip.ptr(y), pixels,
+                                          x.shape[-1], int(relu), hip.stream_of(x)), "otp_nhwc_bn_apply")
+    return y
+
+
+def bn_backward(gy, y, x, mean, rstd, gamma, c, relu, want_res):
+    L = hip.lib()
+    csz = x.shape[-1]
+    pixels = x.numel() // csz
+    nbytes = L.otp_nhwc_bn_backward_workspace(pixels, csz)
+    ws = _new(((nbytes + 3) // 4,), torch.float32, x)
+    gx = torch.empty_like(x)
+    gres = torch.empty_like(x) if want_res else None
+    dg, db = _new((c,), torch.float32, x), _new((c,), torch.float32, x)
+    hip.check(L.otp_nhwc_bn_backward(hip.ptr(gy), hip.ptr(y), hip.ptr(x), hip.ptr(mean), hip.ptr(rstd), hip.ptr(gamma),
+                                     hip.ptr(gx), hip.ptr(gres), hip.ptr(dg), hip.ptr(db), hip.ptr(ws), nbytes, pixels, c, csz,
+                                     int(relu), hip.stream_of(x)), "otp_nhwc_bn_backward")
+    return gx, gres, dg, db
+
+
+class ConvBnFunction(Function):
+    """``relu?(batch_norm(conv2d(x, weight, None, stride, pad)) (+ res))`` - one HRNet conv + BatchNorm2d (training mode:
+    batch statistics, running buffers updated) + residual + ReLU (model/HRNet.py:500-571, 192-231, 416-473)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, res, running_mean, running_var, stride, pad, relu, momentum, eps):
+        _require_gpu(x, weight, gamma, beta)
+        x = x.contiguous()
+        cout = weight.shape[0]
+        c, stats, rows = conv_forward(x, weight, None, stride, pad, 1)
+        count = c.numel() // c.shape[-1]
+        vec = bn_finalize(stats, rows, cout, count, gamma, beta, running_mean, running_var, momentum, eps)
+        r = res.contiguous() if res is not None else None
+        y = bn_apply(c, vec[2], vec[3], r, relu)
+        ctx.save_for_backward(x, weight, gamma, c, y if relu else None, vec)
+        ctx.cfg = (stride, pad, relu, res is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, gamma, c, y, vec = ctx.saved_tensors
+        stride, pad, relu, has_res = ctx.cfg
+        gy = gy.contiguous()
+        gc, gres, dg, db = bn_backward(gy, y, c, vec[0], vec[1], gamma, weight.shape[0], relu, has_res)
+        gx = conv_dgrad(gc, weight, x.shape[1:3], stride, pad, 1) if ctx.needs_input_grad[0] else None
+        gw = conv_wgrad(x, gc, weight.shape, stride, pad, 1) if ctx.needs_input_grad[1] else None
+        return gx, gw, dg, db, gres, None, None, None, None, None, None, None
+
+
+def conv_bn(x, weight, gamma, beta, res=None, running_mean=None, running_var=None, stride=1, pad=0, relu=True,
+            momentum=0.1, eps=1e-5):
+    return ConvBnFunction.apply(x, weight, gamma, beta, res, running_mean, running_var, stride, pad, relu, momentum, eps)
+
+
+class ConvOutFunction(Function):
+    """``F.conv2d(x, weight, bias, stride, pad, dil)`` from NHWC bf16 to the fp32 NCHW tensors of the module boundary (the
+    HRNet ``final_layer``, model/HRNet.py:88-94,150)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, dil):
+        _require_gpu(x, weight)
+        x = x.contiguous()
+        out, _, _ = conv_forward(x, weight, bias, stride, pad, dil, out_mode=1)
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (stride, pad, dil, bias is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        from .train_ops import channel_sum
+        x, weight = ctx.saved_tensors
+        stride, pad, dil, has_bias = ctx.cfg
+        gy = gy.contiguous()
+        g = to_nhwc(gy)
+        gx = conv_dgrad(g, weight, x.shape[1:3], stride, pad, dil) if ctx.needs_input_grad[0] else None
+        gw = conv_wgrad(x, g, weight.shape, stride, pad, dil) if ctx.needs_input_grad[1] else None
+        gb = channel_sum(gy) if has_bias and ctx.needs_input_grad[2] else None
+        return gx, gw, gb, None, None, None
+
+
+def conv_out(x, weight, bias=None, stride=1, pad=0, dil=1):
+    return ConvOutFunction.apply(x, weight, bias, stride, pad, dil)
+
+
+class UpsampleAddFunction(Function):
+    """``relu?(res + nearest_upsample_f(low))`` on NHWC bf16 (HRNet fuse rows, model/HRNet.py:426-439,488-494)."""
+
+    @staticmethod
+    def forward(ctx, low, res, f, relu):
+        _require_gpu(low, res)
+        low, res = low.contiguous(), res.contiguous()
+        n, h, w, c = res.shape
+        out = torch.empty_like(res)
+        hip.check(hip.lib().otp_nhwc_upsample_add(hip.ptr(low), hip.ptr(res), hip.ptr(out), n, h, w, c, f, int(relu),
+                                                  hip.stream_of(low)), "otp_nhwc_upsample_add")
+        ctx.save_for_backward(out if relu else None)
+        ctx.cfg = (f, relu, low.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        (out,) = ctx.saved_tensors
+        f, relu, (n, hl, wl, c) = ctx.cfg
+        gy = gy.contiguous()
+        gres = torch.empty_like(gy)
+        glow = _new((n, hl, wl, c), BF16, gy)
+        hip.check(hip.lib().otp_nhwc_upsample_add_backward(hip.ptr(gy), hip.ptr(out), hip.ptr(gres), hip.ptr(glow), n, hl, wl,
+                                                           c, f, int(relu), hip.stream_of(gy)),
+                  "otp_nhwc_upsample_add_backward")
+        return glow, gres, None, None
+
+
+def upsample_add(low, res, f, relu):
+    return UpsampleAddFunction.apply(low, res, f, relu)

@@ -1,0 +1,914 @@
+// bf16 training path of the HRNet backbone (BASELINE configs[2]: "bf16 training step"; the reference step is
+// script/Common.py:118-144 over model/HRNet.py:116-152): activations live in HBM as NHWC bfloat16 (channel stride
+// rounded up to 8, padding channels zero), every contraction runs on v_mfma_f32_16x16x32_bf16 with fp32 accumulation,
+// BatchNorm statistics / gradients and the weight gradients are fp32, master weights stay fp32 (cast while packing).
+//
+// Why NHWC here when the fp32 path is NCHW: a bf16 MFMA operand is 8 consecutive k-values per lane; with channels
+// innermost both the activations (k = input channel) and the packed weights deliver a fragment as ONE 16-byte LDS
+// read, taps shift whole pixels (16-byte aligned), and nothing is transposed on the way in or out.
+//
+//   nhwc_conv_kernel<MB,NB>   implicit GEMM  out[px][co] = sum_{tap,ci} W[co][tap][ci] * x[px+tap][ci]   (forward and,
+//                             with flipped / transposed weights, the input gradient); the epilogue also leaves the
+//                             per-tile sum / sum of squares of every output channel (BatchNorm batch statistics)
+//   nhwc_wgrad_kernel         dW[co][tap][ci] = sum_px gy[px][co] * x[px+tap][ci]: both operands are read from their
+//                             [pixel][channel] LDS images with ds_read_b64_tr_b16 (the hardware transpose read), so the
+//                             contraction index (pixels) lands in the fragment's k slots without a transposed copy
+//   bn_* / upsample_add_*     HBM-bound NHWC passes (16-byte accesses, fp32 arithmetic)
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float bf2f(bf16 v) { return (float)v; }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// plan: a pure function of the descriptor (host), shared by the packer and the launcher
+// ---------------------------------------------------------------------------------------------------------------------
+struct ConvPlan {
+    int N, H, W, Cin, CinS, Ho, Wo, Cout, CoutS, kh, kw, stride, pad, dil, out_mode;
+    int CK, CK8, CKp, nChunks, KGc, KS;      // channels per chunk, k-groups (8 channels of one tap) and k-steps per chunk
+    int MB, NB, BM, nM, P, tilesPerImg;
+    int RW, rowsMax;
+    int ldsW, ldsX, ldsTab, lds;
+    size_t wbytes;
+};
+
+int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+bool make_plan(const otp_nhwc_conv_desc* d, ConvPlan* p) {
+    if (!d || d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->kh <= 0 || d->kw <= 0 ||
+        d->stride <= 0 || d->dil <= 0 || d->pad < 0)
+        return false;
+    p->N = d->N, p->H = d->H, p->W = d->W, p->Cin = d->Cin, p->Cout = d->Cout;
+    p->kh = d->kh, p->kw = d->kw, p->stride = d->stride, p->pad = d->pad, p->dil = d->dil, p->out_mode = d->out_mode;
+    p->CinS = round_up(d->Cin, 8), p->CoutS = round_up(d->Cout, 8);
+    p->Ho = (d->H + 2 * d->pad - d->dil * (d->kh - 1) - 1) / d->stride + 1;
+    p->Wo = (d->W + 2 * d->pad - d->dil * (d->kw - 1) - 1) / d->stride + 1;
+    if (p->Ho <= 0 || p->Wo <= 0) return false;
+    // channels per chunk: 24 keeps the pixel stride of the LDS window an odd multiple of 16 bytes (conflict-free 16-byte
+    // reads) and the per-chunk weight slab small enough for 3-4 workgroups per CU
+    const int taps = d->kh * d->kw;
+    int ck = p->CinS <= 24 ? p->CinS : 24;
+    if (taps == 1) ck = p->CinS <= 64 ? p->CinS : (p->CinS % 40 == 0 ? 40 : (p->CinS % 24 == 0 ? 24 : 40));
+    p->CK = ck, p->CK8 = ck / 8;
+    p->CKp = (p->CK8 & 1) ? ck : ck + 8;
+    p->nChunks = (p->CinS + ck - 1) / ck;
+    p->KGc = taps * p->CK8;
+    p->KS = (p->KGc + 3) / 4;
+    const int c16 = round_up(d->Cout, 16);
+    int bm = c16 <= 96 ? c16 : 96;
+    if (c16 > 96 && c16 % 96 != 0 && c16 % 64 == 0) bm = 64;
+    p->BM = bm, p->MB = bm / 16, p->nM = (c16 + bm - 1) / bm;
+    const int npx = p->Ho * p->Wo;
+    p->NB = (npx >= 4096 && p->MB <= 3) ? 4 : 2;
+    p->P = 64 * p->NB;
+    p->tilesPerImg = (npx + p->P - 1) / p->P;
+    const int need = (p->Wo - 1) * d->stride + (d->kw - 1) * d->dil + 1;
+    p->RW = d->W + 2 * d->pad > need ? d->W + 2 * d->pad : need;
+    int rowsOut = (p->P - 1 + p->Wo - 1) / p->Wo + 1;
+    if (rowsOut > p->Ho) rowsOut = p->Ho;
+    p->rowsMax = (rowsOut - 1) * d->stride + (d->kh - 1) * d->dil + 1;
+    p->ldsW = p->KS * 4 * p->BM * 16;
+    p->ldsX = round_up(p->rowsMax * p->RW * p->CKp * 2, 16);
+    p->ldsTab = round_up(p->KS * 4 * 4, 16);
+    p->lds = p->ldsW + p->ldsX + p->ldsTab + 4 * 2 * p->BM * 4;
+    p->wbytes = (size_t)p->nChunks * p->nM * p->ldsW;
+    return p->lds <= OTP_LDS_LIMIT;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// weight packing: fp32 (O, I, kh, kw) master weights -> bf16 [chunk][m-tile][k-group (KS*4)][BM][8]
+// element (o, i, dy, dx) of the EFFECTIVE conv is w[base + o*so + i*si + dy*sdy + dx*sdx] (the input-gradient conv
+// reads the same tensor with o <-> i swapped and the taps flipped)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void nhwc_pack_kernel(const float* __restrict__ w, bf16* __restrict__ out, ConvPlan p, long so, long si, long sdy,
+                                 long sdx, long base, size_t total) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t r = i;
+        const int j = r % 8; r /= 8;
+        const int co = r % p.BM; r /= p.BM;
+        const int kg = r % (p.KS * 4); r /= (p.KS * 4);
+        const int mt = r % p.nM; r /= p.nM;
+        const int ch = (int)r;
+        float v = 0.f;
+        if (kg < p.KGc) {
+            const int tap = kg / p.CK8, cgi = kg % p.CK8;
+            const int ci = ch * p.CK + cgi * 8 + j, o = mt * p.BM + co;
+            if (ci < p.Cin && o < p.Cout) v = w[base + o * so + ci * si + (tap / p.kw) * sdy + (tap % p.kw) * sdx];
+        }
+        out[i] = (bf16)v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// implicit-GEMM convolution
+// ---------------------------------------------------------------------------------------------------------------------
+template <int MB, int NB>
+__global__ __launch_bounds__(256) void nhwc_conv_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wpk,
+                                                         const float* __restrict__ bias, bf16* __restrict__ out,
+                                                         float* __restrict__ out_f32, float* __restrict__ stats, ConvPlan p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16* sW = reinterpret_cast<bf16*>(smem);
+    bf16* sX = reinterpret_cast<bf16*>(smem + p.ldsW);
+    int* sTab = reinterpret_cast<int*>(smem + p.ldsW + p.ldsX);
+    float* sRed = reinterpret_cast<float*>(smem + p.ldsW + p.ldsX + p.ldsTab);      // [4 waves][2][BM]
+    constexpr int P = 64 * NB, BM = MB * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+    int bid = blockIdx.x;
+    const int mt = bid % p.nM;
+    bid /= p.nM;
+    const int tile = bid % p.tilesPerImg, n = bid / p.tilesPerImg;
+    const int npx = p.Ho * p.Wo;
+    const int p0 = tile * P, p1 = min(p0 + P, npx);
+    const int oy0 = p0 / p.Wo, oy1 = (p1 - 1) / p.Wo;
+    const int rowLo = oy0 * p.stride - p.pad;
+    const int nrows = (oy1 - oy0) * p.stride + (p.kh - 1) * p.dil + 1;
+
+    // k-group -> element offset inside the window (tap shift + channel group); identical for every chunk
+    for (int kg = tid; kg < p.KS * 4; kg += 256) {
+        int v = 0;
+        if (kg < p.KGc) {
+            const int tap = kg / p.CK8, cgi = kg - tap * p.CK8;
+            const int dy = tap / p.kw, dx = tap - dy * p.kw;
+            v = ((dy * p.dil) * p.RW + dx * p.dil) * p.CKp + cgi * 8;
+        }
+        sTab[kg] = v;
+    }
+    int boff[NB];
+    bool valid[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int pix = p0 + (wave * NB + nb) * 16 + l15;
+        valid[nb] = pix < p1;
+        const int pc = valid[nb] ? pix : p1 - 1;
+        const int oy = pc / p.Wo, ox = pc - oy * p.Wo;
+        boff[nb] = (((oy - oy0) * p.stride) * p.RW + ox * p.stride) * p.CKp;
+    }
+    f32x4 acc[MB][NB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[m][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int wunits = p.ldsW / 16;
+    const int rowUnits = p.RW * p.CK8;
+    const size_t imgBase = (size_t)n * p.H * p.W * p.CinS;
+    for (int ch = 0; ch < p.nChunks; ++ch) {
+        if (ch) __syncthreads();
+        // weights of this (chunk, m-tile): one contiguous slab
+        const u32x4* wsrc = reinterpret_cast<const u32x4*>(wpk) + (size_t)(ch * p.nM + mt) * wunits;
+        for (int i = tid; i < wunits; i += 256) reinterpret_cast<u32x4*>(sW)[i] = wsrc[i];
+        // input window: rows [rowLo, rowLo + nrows) x columns [-pad, RW - pad) x CK channels, zeros outside the image
+        const int c0 = ch * p.CK;
+        for (int r = 0; r < nrows; ++r) {
+            const int iy = rowLo + r;
+            const bool rowIn = iy >= 0 && iy < p.H;
+            const bf16* grow = x + imgBase + (size_t)iy * p.W * p.CinS;
+            bf16* lrow = sX + (size_t)r * p.RW * p.CKp;
+            for (int u = tid; u < rowUnits; u += 256) {
+                const int col = u / p.CK8, cgi = u - col * p.CK8;
+                const int ix = col - p.pad, c = c0 + cgi * 8;
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (rowIn && ix >= 0 && ix < p.W && c < p.CinS)
+                    v = *reinterpret_cast<const u32x4*>(grow + (size_t)ix * p.CinS + c);
+                *reinterpret_cast<u32x4*>(lrow + col * p.CKp + cgi * 8) = v;
+            }
+        }
+        __syncthreads();
+        for (int ks = 0; ks < p.KS; ++ks) {
+            const int koff = sTab[ks * 4 + lg];
+            bf16x8 a[MB];
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+                a[m] = *reinterpret_cast<const bf16x8*>(sW + ((size_t)((ks * 4 + lg) * BM + m * 16 + l15)) * 8);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const bf16x8 b = *reinterpret_cast<const bf16x8*>(sX + boff[nb] + koff);
+#pragma unroll
+                for (int m = 0; m < MB; ++m) acc[m][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], b, acc[m][nb], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: bias, rounding, store; per-tile channel sums of the ROUNDED values (what BatchNorm will normalise) ----
+    float s1[MB][4], s2[MB][4];
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s1[m][r] = s2[m][r] = 0.f;
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+        const int co = mt * BM + m * 16 + lg * 4;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bias) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (co + r < p.Cout) bv[r] = bias[co + r];
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int pix = p0 + (wave * NB + nb) * 16 + l15;
+            if (p.out_mode == 1) {                               // fp32 NCHW (hand-over to the fp32 NCHW kernels)
+                if (valid[nb]) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (co + r < p.Cout) out_f32[((size_t)n * p.Cout + co + r) * npx + pix] = acc[m][nb][r] + bv[r];
+                }
+                continue;
+            }
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                o[r] = (bf16)(acc[m][nb][r] + bv[r]);
+                const float f = valid[nb] ? bf2f(o[r]) : 0.f;
+                s1[m][r] += f;
+                s2[m][r] += f * f;
+            }
+            if (valid[nb] && co < p.CoutS)
+                *reinterpret_cast<bf16x4*>(out + ((size_t)n * npx + pix) * p.CoutS + co) = o;
+        }
+    }
+    if (stats && p.out_mode == 0) {
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    s1[m][r] += __shfl_xor(s1[m][r], o, 64);
+                    s2[m][r] += __shfl_xor(s2[m][r], o, 64);
+                }
+                if (l15 == 0) {
+                    sRed[(wave * 2 + 0) * BM + m * 16 + lg * 4 + r] = s1[m][r];
+                    sRed[(wave * 2 + 1) * BM + m * 16 + lg * 4 + r] = s2[m][r];
+                }
+            }
+        __syncthreads();
+        for (int i = tid; i < 2 * BM; i += 256) {
+            const int which = i / BM, c = i - which * BM, co = mt * BM + c;
+            if (co < p.CoutS) {
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) v += sRed[(w * 2 + which) * BM + c];
+                stats[((size_t)(n * p.tilesPerImg + tile) * 2 + which) * p.CoutS + co] = v;
+            }
+        }
+    }
+}
+
+template <int MB, int NB>
+int launch_conv(const ConvPlan& p, const void* x, const void* wpk, const void* bias, void* out, void* stats, hipStream_t st) {
+    auto kern = nhwc_conv_kernel<MB, NB>;
+    OTP_ALLOW_BIG_LDS(kern, p.lds);
+    const int grid = p.N * p.tilesPerImg * p.nM;
+    kern<<<grid, 256, p.lds, st>>>(static_cast<const bf16*>(x), static_cast<const bf16*>(wpk), static_cast<const float*>(bias),
+                                   static_cast<bf16*>(out), static_cast<float*>(out), static_cast<float*>(stats), p);
+    return otp_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// weight gradient
+// ---------------------------------------------------------------------------------------------------------------------
+// A workgroup owns (co block of up to 48) x (ci block of up to 48) x all taps and a contiguous range of pixel tiles of
+// 32 output pixels; wave w owns N-blocks {w, w+4, ...} of the (tap, ci16) list for all 3 co blocks.  gy tile [32 px][48 co]
+// and the x window live in LDS as [pixel][channel]; a fragment is two ds_read_b64_tr_b16 (4 pixels x 16 channels each).
+struct WgradPlan {
+    int N, H, W, CinS, Ho, Wo, CoutS, Cin, Cout, kh, kw, stride, pad, dil;
+    int nCo, nCi, splits, tilesPerImg, tilesTotal, tilesPerSplit;
+    int RW, rowsMax, XC, ldsG, ldsX, lds;
+    int nbTot;             // N-blocks per workgroup = taps * 3
+};
+
+__device__ __forceinline__ bf16x4 tr_read(const bf16* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+        (__attribute__((address_space(3))) bf16x4*)(const_cast<bf16*>(p)));
+}
+
+constexpr int WG_PX = 32;      // output pixels per k-step (one MFMA k extent)
+constexpr int WG_NBW = 7;      // N-blocks per wave (27 = 9 taps x 3 ci blocks over 4 waves)
+
+__global__ __launch_bounds__(256) void nhwc_wgrad_kernel(const bf16* __restrict__ x, const bf16* __restrict__ gy,
+                                                          float* __restrict__ part, WgradPlan p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16* sG = reinterpret_cast<bf16*>(smem);                 // [32 px][56] (48 channels + 8 pad: row stride 112 B)
+    bf16* sX = reinterpret_cast<bf16*>(smem + p.ldsG);        // [rows][RW][XC] (XC = 56)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+    int bid = blockIdx.x;
+    const int split = bid % p.splits;
+    bid /= p.splits;
+    const int cib = bid % p.nCi, cob = bid / p.nCi;
+    const int co0 = cob * 48, ci0 = cib * 48;
+    const int taps = p.kh * p.kw;
+    const int npx = p.Ho * p.Wo;
+
+    // this wave's N-blocks: nb = wave + 4*i  ->  (tap, ci16 block)
+    int xoff[WG_NBW];          // element offset inside the x window of (tap shift, ci block) for this lane's channel quad
+    bool has[WG_NBW];
+#pragma unroll
+    for (int i = 0; i < WG_NBW; ++i) {
+        const int nb = wave + 4 * i;
+        has[i] = nb < p.nbTot;
+        const int nbc = has[i] ? nb : 0;
+        const int tap = nbc / 3, cb = nbc - tap * 3;
+        const int dy = tap / p.kw, dx = tap - dy * p.kw;
+        xoff[i] = ((dy * p.dil) * p.RW + dx * p.dil) * p.XC + cb * 16;
+    }
+    f32x4 acc[3][WG_NBW];
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int i = 0; i < WG_NBW; ++i) acc[m][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // transpose-read addressing: within a 16-lane group, lane 4q+pp supplies row q (pixel), columns 4pp..4pp+3 (channels)
+    const int q = l15 >> 2, pp = l15 & 3;
+
+    const int t0 = split * p.tilesPerSplit, t1 = min(t0 + p.tilesPerSplit, p.tilesTotal);
+    for (int t = t0; t < t1; ++t) {
+        const int n = t / p.tilesPerImg, tile = t - n * p.tilesPerImg;
+        const int p0 = tile * WG_PX, p1 = min(p0 + WG_PX, npx);
+        const int oy0 = p0 / p.Wo, oy1 = (p1 - 1) / p.Wo;
+        const int rowLo = oy0 * p.stride - p.pad;
+        const int nrows = (oy1 - oy0) * p.stride + (p.kh - 1) * p.dil + 1;
+        __syncthreads();
+        // gy tile: 32 pixels x 48 channels (6 units of 16 B per pixel); pixels past the image and channels past CoutS are zero
+        for (int u = tid; u < WG_PX * 6; u += 256) {
+            const int px = u / 6, cg = u - px * 6;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (p0 + px < p1 && co0 + cg * 8 < p.CoutS)
+                v = *reinterpret_cast<const u32x4*>(gy + ((size_t)n * npx + p0 + px) * p.CoutS + co0 + cg * 8);
+            *reinterpret_cast<u32x4*>(sG + px * 56 + cg * 8) = v;
+        }
+        // x window: rows x RW columns x 48 channels of this ci block
+        const size_t imgBase = (size_t)n * p.H * p.W * p.CinS;
+        for (int r = 0; r < nrows; ++r) {
+            const int iy = rowLo + r;
+            const bool rowIn = iy >= 0 && iy < p.H;
+            const bf16* grow = x + imgBase + (size_t)iy * p.W * p.CinS;
+            bf16* lrow = sX + (size_t)r * p.RW * p.XC;
+            for (int u = tid; u < p.RW * 6; u += 256) {
+                const int col = u / 6, cg = u - col * 6;
+                const int ix = col - p.pad, c = ci0 + cg * 8;
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (rowIn && ix >= 0 && ix < p.W && c < p.CinS) v = *reinterpret_cast<const u32x4*>(grow + (size_t)ix * p.CinS + c);
+                *reinterpret_cast<u32x4*>(lrow + col * p.XC + cg * 8) = v;
+            }
+        }
+        __syncthreads();
+        // one k-step of 32 pixels: lane group lg covers pixels 8*lg .. 8*lg+7 (two transposed reads of 4 pixels)
+        bf16x8 a[3];
+        int xrow[2];           // window element offset of this lane's row (pixel) for the two 4-pixel halves
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int px = 8 * lg + 4 * h + q;
+            const int pc = min(p0 + px, p1 - 1);               // rows past the tile pair with zero gy rows
+            const int oy = pc / p.Wo, ox = pc - oy * p.Wo;
+            xrow[h] = (((oy - oy0) * p.stride) * p.RW + ox * p.stride) * p.XC + 4 * pp;
+        }
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            const bf16x4 lo = tr_read(sG + (8 * lg + q) * 56 + m * 16 + 4 * pp);
+            const bf16x4 hi = tr_read(sG + (8 * lg + 4 + q) * 56 + m * 16 + 4 * pp);
+            a[m] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+#pragma unroll
+        for (int i = 0; i < WG_NBW; ++i) {
+            const bf16x4 lo = tr_read(sX + xrow[0] + xoff[i]);
+            const bf16x4 hi = tr_read(sX + xrow[1] + xoff[i]);
+            const bf16x8 b = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+            for (int m = 0; m < 3; ++m) acc[m][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], b, acc[m][i], 0, 0, 0);
+        }
+    }
+    // partial sums: part[split][co][tap][ci]  (co, ci relative to the true Cout / Cin; skipped past them)
+#pragma unroll
+    for (int i = 0; i < WG_NBW; ++i) {
+        const int nb = wave + 4 * i;
+        if (nb >= p.nbTot) continue;
+        const int tap = nb / 3, cb = nb - tap * 3;
+        const int ci = ci0 + cb * 16 + l15;
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + m * 16 + lg * 4 + r;
+                if (co < p.Cout && ci < p.Cin)
+                    part[(((size_t)split * p.Cout + co) * p.Cin + ci) * taps + tap] = acc[m][i][r];
+            }
+    }
+}
+
+__global__ void nhwc_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw, int splits, size_t n) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += part[(size_t)k * n + i];
+    gw[i] = s;
+}
+
+bool make_wgrad_plan(const otp_nhwc_conv_desc* d, WgradPlan* p) {
+    ConvPlan c;
+    if (!make_plan(d, &c)) return false;
+    p->N = c.N, p->H = c.H, p->W = c.W, p->CinS = c.CinS, p->Ho = c.Ho, p->Wo = c.Wo, p->CoutS = c.CoutS;
+    p->Cin = c.Cin, p->Cout = c.Cout, p->kh = c.kh, p->kw = c.kw, p->stride = c.stride, p->pad = c.pad, p->dil = c.dil;
+    if (c.kh * c.kw * 3 > 4 * WG_NBW) return false;            // 1x1 and 3x3 kernels
+    p->nCo = (c.Cout + 47) / 48, p->nCi = (c.Cin + 47) / 48;
+    p->nbTot = c.kh * c.kw * 3;
+    const int npx = c.Ho * c.Wo;
+    p->tilesPerImg = (npx + WG_PX - 1) / WG_PX;
+    p->tilesTotal = c.N * p->tilesPerImg;
+    int splits = 2048 / (p->nCo * p->nCi);
+    if (splits < 1) splits = 1;
+    if (splits > p->tilesTotal) splits = p->tilesTotal;
+    if (splits > 512) splits = 512;
+    p->tilesPerSplit = (p->tilesTotal + splits - 1) / splits;
+    p->splits = (p->tilesTotal + p->tilesPerSplit - 1) / p->tilesPerSplit;
+    const int need = (c.Wo - 1) * c.stride + (c.kw - 1) * c.dil + 1;
+    p->RW = c.W + 2 * c.pad > need ? c.W + 2 * c.pad : need;
+    int rowsOut = (WG_PX - 1 + c.Wo - 1) / c.Wo + 1;
+    if (rowsOut > c.Ho) rowsOut = c.Ho;
+    p->rowsMax = (rowsOut - 1) * c.stride + (c.kh - 1) * c.dil + 1;
+    p->XC = 56;
+    p->ldsG = WG_PX * 56 * 2;
+    p->ldsX = round_up(p->rowsMax * p->RW * p->XC * 2, 16);
+    p->lds = p->ldsG + p->ldsX;
+    return p->lds <= OTP_LDS_LIMIT;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// BatchNorm (batch statistics) on NHWC bf16, fp32 arithmetic
+// ---------------------------------------------------------------------------------------------------------------------
+// partial sums [rows][2][C] -> mean / rstd, scale = gamma*rstd, shift = beta - mean*scale, running statistics update
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int rows, int C, int Ctrue, float count,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                                           float* __restrict__ scale_o, float* __restrict__ shift_o,
+                                                           float* __restrict__ run_mean, float* __restrict__ run_var, float eps,
+                                                           float momentum) {
+    __shared__ double red[2][16][16];
+    const int cl = threadIdx.x & 15, rq = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C)
+        for (int r = rq; r < rows; r += 16) {
+            s1 += (double)part[((size_t)r * 2) * C + c];
+            s2 += (double)part[((size_t)r * 2 + 1) * C + c];
+        }
+    red[0][rq][cl] = s1, red[1][rq][cl] = s2;
+    __syncthreads();
+    if (rq == 0 && c < C) {
+        for (int k = 1; k < 16; ++k) s1 += red[0][k][cl], s2 += red[1][k][cl];
+        const double m = s1 / count;
+        double var = s2 / count - m * m;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const bool live = c < Ctrue;
+        const float g = live ? gamma[c] : 0.f, b = live ? beta[c] : 0.f;
+        mean_o[c] = (float)m, rstd_o[c] = rstd;
+        scale_o[c] = g * rstd;
+        shift_o[c] = b - (float)m * g * rstd;
+        if (live && run_mean) {
+            run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)m;
+            const double unb = count > 1.f ? var * (double)count / ((double)count - 1.0) : var;
+            run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unb;
+        }
+    }
+}
+
+// y = act(x*scale[c] + shift[c] (+ res)); 8 channels per thread
+__global__ __launch_bounds__(256) void bn_apply_kernel(const bf16* __restrict__ x, const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, const bf16* __restrict__ res,
+                                                        bf16* __restrict__ y, size_t units, int C8, int relu) {
+    for (size_t u = blockIdx.x * (size_t)blockDim.x + threadIdx.x; u < units; u += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(u % C8) * 8;
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + u * 8);
+        bf16x8 r8;
+        if (res) r8 = *reinterpret_cast<const bf16x8*>(res + u * 8);
+        const f32x4 sa = *reinterpret_cast<const f32x4*>(scale + c), sb = *reinterpret_cast<const f32x4*>(scale + c + 4);
+        const f32x4 ha = *reinterpret_cast<const f32x4*>(shift + c), hb = *reinterpret_cast<const f32x4*>(shift + c + 4);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float f = bf2f(v[j]) * (j < 4 ? sa[j] : sb[j - 4]) + (j < 4 ? ha[j] : hb[j - 4]);
+            if (res) f += bf2f(r8[j]);
+            if (relu) f = fmaxf(f, 0.f);
+            o[j] = (bf16)f;
+        }
+        *reinterpret_cast<bf16x8*>(y + u * 8) = o;
+    }
+}
+
+// backward pass 1: per-workgroup partial sums of g and g*xhat over a pixel range, g = gy * (y > 0 when relu)
+// threads: (pixel lane pl, channel group cg); partial rows [wg][2][C]
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16* __restrict__ gy, const bf16* __restrict__ y,
+                                                             const bf16* __restrict__ x, const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd, float* __restrict__ part,
+                                                             size_t npix, int C8, int pixPerWg, int relu) {
+    extern __shared__ float sred[];                       // [ppw][C8*16]
+    const int ppw = 256 / C8;
+    const int pl = threadIdx.x / C8, cg = threadIdx.x - pl * C8;
+    const int C = C8 * 8;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+    if (pl < ppw) {
+        float mu[8], rs[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mu[j] = mean[cg * 8 + j], rs[j] = rstd[cg * 8 + j];
+        const size_t pbeg = (size_t)blockIdx.x * pixPerWg;
+        const size_t pend = pbeg + pixPerWg < npix ? pbeg + pixPerWg : npix;
+        for (size_t px = pbeg + pl; px < pend; px += ppw) {
+            const size_t o = px * C + cg * 8;
+            const bf16x8 g8 = *reinterpret_cast<const bf16x8*>(gy + o);
+            const bf16x8 x8 = *reinterpret_cast<const bf16x8*>(x + o);
+            bf16x8 y8;
+            if (relu) y8 = *reinterpret_cast<const bf16x8*>(y + o);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float g = bf2f(g8[j]);
+                if (relu && !(bf2f(y8[j]) > 0.f)) g = 0.f;
+                s1[j] += g;
+                s2[j] += g * (bf2f(x8[j]) - mu[j]) * rs[j];
+            }
+        }
+    }
+    if (pl < ppw) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            sred[(pl * C8 + cg) * 16 + j] = s1[j];
+            sred[(pl * C8 + cg) * 16 + 8 + j] = s2[j];
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C8 * 16; i += 256) {
+        float v = 0.f;
+        for (int k = 0; k < ppw; ++k) v += sred[k * C8 * 16 + i];
+        const int cgi = i / 16, j = i & 15;
+        part[((size_t)blockIdx.x * 2 + (j >> 3)) * C + cgi * 8 + (j & 7)] = v;
+    }
+}
+
+// partials -> dgamma, dbeta, and the three per-channel coefficients of pass 2
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int rows, int C, int Ctrue,
+                                                               float count, const float* __restrict__ gamma,
+                                                               const float* __restrict__ rstd, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta, float* __restrict__ coef) {
+    __shared__ double red[2][16][16];
+    const int cl = threadIdx.x & 15, rq = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C)
+        for (int r = rq; r < rows; r += 16) {
+            s1 += (double)part[((size_t)r * 2) * C + c];
+            s2 += (double)part[((size_t)r * 2 + 1) * C + c];
+        }
+    red[0][rq][cl] = s1, red[1][rq][cl] = s2;
+    __syncthreads();
+    if (rq == 0 && c < C) {
+        for (int k = 1; k < 16; ++k) s1 += red[0][k][cl], s2 += red[1][k][cl];
+        const bool live = c < Ctrue;
+        if (live) dbeta[c] = (float)s1, dgamma[c] = (float)s2;
+        const float k1 = live ? gamma[c] * rstd[c] : 0.f;
+        coef[c] = k1;                                     // gx = k1 * (g - mg - xhat * mgx)
+        coef[C + c] = (float)(s1 / count);
+        coef[2 * C + c] = (float)(s2 / count);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16* __restrict__ gy, const bf16* __restrict__ y,
+                                                            const bf16* __restrict__ x, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, const float* __restrict__ coef,
+                                                            bf16* __restrict__ gx, bf16* __restrict__ gres, size_t units, int C8,
+                                                            int relu) {
+    const int C = C8 * 8;
+    for (size_t u = blockIdx.x * (size_t)blockDim.x + threadIdx.x; u < units; u += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(u % C8) * 8;
+        const bf16x8 g8 = *reinterpret_cast<const bf16x8*>(gy + u * 8);
+        const bf16x8 x8 = *reinterpret_cast<const bf16x8*>(x + u * 8);
+        bf16x8 y8;
+        if (relu) y8 = *reinterpret_cast<const bf16x8*>(y + u * 8);
+        bf16x8 o, gr;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float g = bf2f(g8[j]);
+            if (relu && !(bf2f(y8[j]) > 0.f)) g = 0.f;
+            const float xh = (bf2f(x8[j]) - mean[c + j]) * rstd[c + j];
+            o[j] = (bf16)(coef[c + j] * (g - coef[C + c + j] - xh * coef[2 * C + c + j]));
+            gr[j] = (bf16)g;
+        }
+        *reinterpret_cast<bf16x8*>(gx + u * 8) = o;
+        if (gres) *reinterpret_cast<bf16x8*>(gres + u * 8) = gr;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// nearest-upsample-accumulate (HRNet fuse rows, model/HRNet.py:426-439, 488-494) and layout converters
+// ---------------------------------------------------------------------------------------------------------------------
+// out[n, y, x, c] = act(res[n, y, x, c] + low[n, y/f, x/f, c])
+__global__ __launch_bounds__(256) void upsample_add_nhwc_kernel(const bf16* __restrict__ low, const bf16* __restrict__ res,
+                                                                 bf16* __restrict__ out, int N, int H, int W, int C8, int f,
+                                                                 int relu) {
+    const size_t units = (size_t)N * H * W * C8;
+    const int Hl = H / f, Wl = W / f;
+    for (size_t u = blockIdx.x * (size_t)blockDim.x + threadIdx.x; u < units; u += (size_t)gridDim.x * blockDim.x) {
+        size_t r = u;
+        const int cg = r % C8; r /= C8;
+        const int xx = r % W; r /= W;
+        const int yy = r % H;
+        const int n = (int)(r / H);
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(res + u * 8);
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(low + ((((size_t)n * Hl + yy / f) * Wl + xx / f) * C8 + cg) * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = bf2f(a[j]) + bf2f(b[j]);
+            if (relu) v = fmaxf(v, 0.f);
+            o[j] = (bf16)v;
+        }
+        *reinterpret_cast<bf16x8*>(out + u * 8) = o;
+    }
+}
+
+// gres = gy * mask, glow[n, yl, xl, c] = sum over the f x f block of gy * mask   (mask = out > 0 when relu)
+__global__ __launch_bounds__(256) void upsample_add_nhwc_bwd_kernel(const bf16* __restrict__ gy, const bf16* __restrict__ out,
+                                                                     bf16* __restrict__ gres, bf16* __restrict__ glow, int N,
+                                                                     int Hl, int Wl, int C8, int f, int relu) {
+    const size_t units = (size_t)N * Hl * Wl * C8;
+    const int H = Hl * f, W = Wl * f;
+    for (size_t u = blockIdx.x * (size_t)blockDim.x + threadIdx.x; u < units; u += (size_t)gridDim.x * blockDim.x) {
+        size_t r = u;
+        const int cg = r % C8; r /= C8;
+        const int xl = r % Wl; r /= Wl;
+        const int yl = r % Hl;
+        const int n = (int)(r / Hl);
+        float s[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] = 0.f;
+        for (int dy = 0; dy < f; ++dy)
+            for (int dx = 0; dx < f; ++dx) {
+                const size_t o = ((((size_t)n * H + yl * f + dy) * W + xl * f + dx) * C8 + cg) * 8;
+                const bf16x8 g8 = *reinterpret_cast<const bf16x8*>(gy + o);
+                bf16x8 y8, gr;
+                if (relu) y8 = *reinterpret_cast<const bf16x8*>(out + o);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float g = bf2f(g8[j]);
+                    if (relu && !(bf2f(y8[j]) > 0.f)) g = 0.f;
+                    s[j] += g;
+                    gr[j] = (bf16)g;
+                }
+                *reinterpret_cast<bf16x8*>(gres + o) = gr;
+            }
+        bf16x8 o8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o8[j] = (bf16)s[j];
+        *reinterpret_cast<bf16x8*>(glow + u * 8) = o8;
+    }
+}
+
+// (N, C, H, W) fp32 -> (N, H, W, CS) bf16, padding channels zero.  frame_split = B > 0 reads the (B, 5*C, H, W) clip tensor
+// as (5B, C, H, W) with image n = f*B + b from channels [f*C, (f+1)*C) of sample b (model/OTPose.py:317).
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in, bf16* __restrict__ out, int N, int C,
+                                                            int HW, int CS, int frame_split) {
+    const size_t total = (size_t)N * HW;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i / HW), px = (int)(i - (size_t)n * HW);
+        const float* src;
+        if (frame_split > 0) {
+            const int fr = n / frame_split, b = n - fr * frame_split;
+            src = in + (((size_t)b * (N / frame_split) + fr) * C) * HW + px;
+        } else {
+            src = in + (size_t)n * C * HW + px;
+        }
+        for (int c0 = 0; c0 < CS; c0 += 8) {
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (bf16)(c0 + j < C ? src[(size_t)(c0 + j) * HW] : 0.f);
+            *reinterpret_cast<bf16x8*>(out + i * CS + c0) = o;
+        }
+    }
+}
+
+// (N, H, W, CS) bf16 -> (N, C, H, W) fp32
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const bf16* __restrict__ in, float* __restrict__ out, int N, int C,
+                                                            int HW, int CS) {
+    const size_t total = (size_t)N * C * HW;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int px = (int)(i % HW);
+        const size_t r = i / HW;
+        const int c = (int)(r % C), n = (int)(r / C);
+        out[i] = bf2f(in[((size_t)n * HW + px) * CS + c]);
+    }
+}
+
+// (N, C, H, W) fp32 gradient -> (N, H, W, CS) bf16 (same as nchw_to_nhwc without frame_split) is reused for grads.
+
+// zero-insertion for the input gradient of a strided conv: out (N, H, W, C) = 0 except out[:, y*s, x*s] = in[:, y, x]
+__global__ __launch_bounds__(256) void dilate_nhwc_kernel(const bf16* __restrict__ in, bf16* __restrict__ out, int N, int Hi,
+                                                           int Wi, int s, int H, int W, int C8) {
+    const size_t units = (size_t)N * H * W * C8;
+    for (size_t u = blockIdx.x * (size_t)blockDim.x + threadIdx.x; u < units; u += (size_t)gridDim.x * blockDim.x) {
+        size_t r = u;
+        const int cg = r % C8; r /= C8;
+        const int xx = r % W; r /= W;
+        const int yy = r % H;
+        const int n = (int)(r / H);
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (yy % s == 0 && xx % s == 0 && yy / s < Hi && xx / s < Wi)
+            v = *reinterpret_cast<const u32x4*>(in + ((((size_t)n * Hi + yy / s) * Wi + xx / s) * C8 + cg) * 8);
+        *reinterpret_cast<u32x4*>(out + u * 8) = v;
+    }
+}
+
+int grid_for(size_t units) {
+    size_t g = (units + 255) / 256;
+    if (g > 256 * 16) g = 256 * 16;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+// =====================================================================================================================
+// C ABI
+// =====================================================================================================================
+extern "C" size_t otp_nhwc_conv_weight_bytes(const otp_nhwc_conv_desc* d) {
+    ConvPlan p;
+    return make_plan(d, &p) ? p.wbytes : 0;
+}
+
+extern "C" int otp_nhwc_conv_stats_rows(const otp_nhwc_conv_desc* d) {
+    ConvPlan p;
+    return make_plan(d, &p) ? p.N * p.tilesPerImg : 0;
+}
+
+extern "C" int otp_nhwc_conv_plan(const otp_nhwc_conv_desc* d, int* out8) {
+    ConvPlan p;
+    if (!out8) return OTP_ERR_BAD_ARG;
+    if (!make_plan(d, &p)) return OTP_ERR_UNSUPPORTED;
+    out8[0] = p.MB, out8[1] = p.NB, out8[2] = p.CK, out8[3] = p.nChunks, out8[4] = p.nM, out8[5] = p.N * p.tilesPerImg * p.nM;
+    out8[6] = p.lds, out8[7] = p.KS;
+    return OTP_OK;
+}
+
+extern "C" int otp_nhwc_conv_pack(const void* weight, void* wpacked, const otp_nhwc_conv_desc* d, int dgrad, void* stream) {
+    ConvPlan p;
+    if (!weight || !wpacked) return OTP_ERR_BAD_ARG;
+    if (!make_plan(d, &p)) return OTP_ERR_UNSUPPORTED;
+    const long taps = (long)p.kh * p.kw;
+    long so, si, sdy, sdx, base;
+    if (!dgrad) {
+        so = p.Cin * taps, si = taps, sdy = p.kw, sdx = 1, base = 0;
+    } else {      // original weight is (O = d->Cin, I = d->Cout, kh, kw); this conv maps O -> I with flipped taps
+        so = taps, si = (long)p.Cout * taps, sdy = -p.kw, sdx = -1, base = taps - 1;
+    }
+    const size_t total = p.wbytes / 2;
+    nhwc_pack_kernel<<<grid_for(total), 256, 0, static_cast<hipStream_t>(stream)>>>(
+        static_cast<const float*>(weight), static_cast<bf16*>(wpacked), p, so, si, sdy, sdx, base, total);
+    return otp_launch_status();
+}
+
+extern "C" int otp_nhwc_conv_bf16(const void* x, const void* wpacked, const void* bias, void* out, void* stats,
+                                  const otp_nhwc_conv_desc* d, void* stream) {
+    ConvPlan p;
+    if (!x || !wpacked || !out) return OTP_ERR_BAD_ARG;
+    if (!make_plan(d, &p)) return OTP_ERR_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define OTP_NHWC_CASE(mb, nb) \
+    if (p.MB == mb && p.NB == nb) return launch_conv<mb, nb>(p, x, wpacked, bias, out, stats, st)
+    OTP_NHWC_CASE(1, 2); OTP_NHWC_CASE(2, 2); OTP_NHWC_CASE(3, 2); OTP_NHWC_CASE(4, 2); OTP_NHWC_CASE(5, 2); OTP_NHWC_CASE(6, 2);
+    OTP_NHWC_CASE(1, 4); OTP_NHWC_CASE(2, 4); OTP_NHWC_CASE(3, 4);
+#undef OTP_NHWC_CASE
+    return OTP_ERR_UNSUPPORTED;
+}
+
+extern "C" size_t otp_nhwc_wgrad_workspace(const otp_nhwc_conv_desc* d) {
+    WgradPlan p;
+    if (!make_wgrad_plan(d, &p)) return 0;
+    return (size_t)p.splits * p.Cout * p.Cin * p.kh * p.kw * sizeof(float);
+}
+
+extern "C" int otp_nhwc_wgrad_bf16(const void* x, const void* gy, void* grad_weight, void* workspace, size_t workspace_bytes,
+                                   const otp_nhwc_conv_desc* d, void* stream) {
+    WgradPlan p;
+    if (!x || !gy || !grad_weight || !workspace) return OTP_ERR_BAD_ARG;
+    if (!make_wgrad_plan(d, &p)) return OTP_ERR_UNSUPPORTED;
+    const size_t n = (size_t)p.Cout * p.Cin * p.kh * p.kw;
+    if (workspace_bytes < (size_t)p.splits * n * sizeof(float)) return OTP_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    OTP_ALLOW_BIG_LDS(nhwc_wgrad_kernel, p.lds);
+    nhwc_wgrad_kernel<<<p.nCo * p.nCi * p.splits, 256, p.lds, st>>>(static_cast<const bf16*>(x), static_cast<const bf16*>(gy),
+                                                                     static_cast<float*>(workspace), p);
+    if (otp_launch_status() != OTP_OK) return OTP_ERR_LAUNCH;
+    nhwc_wgrad_reduce_kernel<<<(int)((n + 255) / 256), 256, 0, st>>>(static_cast<const float*>(workspace),
+                                                                      static_cast<float*>(grad_weight), p.splits, n);
+    return otp_launch_status();
+}
+
+extern "C" int otp_nhwc_bn_finalize(const void* partials, int rows, int C, int CS, float count, const void* gamma,
+                                    const void* beta, void* mean, void* rstd, void* scale, void* shift, void* running_mean,
+                                    void* running_var, float eps, float momentum, void* stream) {
+    if (!partials || !gamma || !beta || !mean || !rstd || !scale || !shift || rows <= 0 || C <= 0 || CS < C)
+        return OTP_ERR_BAD_ARG;
+    bn_finalize_kernel<<<(CS + 15) / 16, 256, 0, static_cast<hipStream_t>(stream)>>>(
+        static_cast<const float*>(partials), rows, CS, C, count, static_cast<const float*>(gamma), static_cast<const float*>(beta),
+        static_cast<float*>(mean), static_cast<float*>(rstd), static_cast<float*>(scale), static_cast<float*>(shift),
+        static_cast<float*>(running_mean), static_cast<float*>(running_var), eps, momentum);
+    return otp_launch_status();
+}
+
+extern "C" int otp_nhwc_bn_apply(const void* x, const void* scale, const void* shift, const void* res, void* y, size_t pixels,
+                                 int CS, int relu, void* stream) {
+    if (!x || !scale || !shift || !y || CS <= 0 || CS % 8) return OTP_ERR_BAD_ARG;
+    const size_t units = pixels * (CS / 8);
+    bn_apply_kernel<<<grid_for(units), 256, 0, static_cast<hipStream_t>(stream)>>>(
+        static_cast<const bf16*>(x), static_cast<const float*>(scale), static_cast<const float*>(shift),
+        static_cast<const bf16*>(res), static_cast<bf16*>(y), units, CS / 8, relu);
+    return otp_launch_status();
+}
+
+static int bn_bwd_rows(size_t pixels, int* pixPerWg) {
+    int rows = (int)((pixels + 1023) / 1024);
+    if (rows > 2048) rows = 2048;
+    if (rows < 1) rows = 1;
+    *pixPerWg = (int)((pixels + rows - 1) / rows);
+    return (int)((pixels + *pixPerWg - 1) / *pixPerWg);
+}
+
+extern "C" size_t otp_nhwc_bn_backward_workspace(size_t pixels, int CS) {
+    int ppw;
+    const int rows = bn_bwd_rows(pixels, &ppw);
+    return ((size_t)rows * 2 * CS + 3 * (size_t)CS) * sizeof(float);
+}
+
+// gx (and gres = gy * relu-mask when not NULL) from gy; dgamma / dbeta (C floats) overwritten.  y may be NULL when relu == 0.
+extern "C" int otp_nhwc_bn_backward(const void* gy, const void* y, const void* x, const void* mean, const void* rstd,
+                                    const void* gamma, void* gx, void* gres, void* dgamma, void* dbeta, void* workspace,
+                                    size_t workspace_bytes, size_t pixels, int C, int CS, int relu, void* stream) {
+    if (!gy || !x || !mean || !rstd || !gamma || !gx || !dgamma || !dbeta || !workspace || (relu && !y) || CS % 8 || CS > 2048)
+        return OTP_ERR_BAD_ARG;
+    if (workspace_bytes < otp_nhwc_bn_backward_workspace(pixels, CS)) return OTP_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int ppw;
+    const int rows = bn_bwd_rows(pixels, &ppw);
+    float* part = static_cast<float*>(workspace);
+    float* coef = part + (size_t)rows * 2 * CS;
+    const int C8 = CS / 8;
+    if (C8 > 256) return OTP_ERR_UNSUPPORTED;
+    const size_t lds = (size_t)(256 / C8) * C8 * 16 * sizeof(float);
+    bn_bwd_reduce_kernel<<<rows, 256, lds, st>>>(static_cast<const bf16*>(gy), static_cast<const bf16*>(y),
+                                                 static_cast<const bf16*>(x), static_cast<const float*>(mean),
+                                                 static_cast<const float*>(rstd), part, pixels, C8, ppw, relu);
+    bn_bwd_finalize_kernel<<<(CS + 15) / 16, 256, 0, st>>>(part, rows, CS, C, (float)pixels, static_cast<const float*>(gamma),
+                                                           static_cast<const float*>(rstd), static_cast<float*>(dgamma),
+                                                           static_cast<float*>(dbeta), coef);
+    const size_t units = pixels * C8;
+    bn_bwd_apply_kernel<<<grid_for(units), 256, 0, st>>>(static_cast<const bf16*>(gy), static_cast<const bf16*>(y),
+                                                         static_cast<const bf16*>(x), static_cast<const float*>(mean),
+                                                         static_cast<const float*>(rstd), coef, static_cast<bf16*>(gx),
+                                                         static_cast<bf16*>(gres), units, C8, relu);
+    return otp_launch_status();
+}
+
+extern "C" int otp_nhwc_upsample_add(const void* low, const void* res, void* out, int N, int H, int W, int CS, int f, int relu,
+                                     void* stream) {
+    if (!low || !res || !out || f <= 0 || H % f || W % f || CS % 8) return OTP_ERR_BAD_ARG;
+    upsample_add_nhwc_kernel<<<grid_for((size_t)N * H * W * (CS / 8)), 256, 0, static_cast<hipStream_t>(stream)>>>(
+        static_cast<const bf16*>(low), static_cast<const bf16*>(res), static_cast<bf16*>(out), N, H, W, CS / 8, f, relu);
+    return otp_launch_status();
+}
+
+extern "C" int otp_nhwc_upsample_add_backward(const void* gy, const void* out, void* gres, void* glow, int N, int Hl, int Wl,
+                                              int CS, int f, int relu, void* stream) {
+    if (!gy || !gres || !glow || (relu && !out) || f <= 0 || CS % 8) return OTP_ERR_BAD_ARG;
+    upsample_add_nhwc_bwd_kernel<<<grid_for((size_t)N * Hl * Wl * (CS / 8)), 256, 0, static_cast<hipStream_t>(stream)>>>(
+        static_cast<const bf16*>(gy), static_cast<const bf16*>(out), static_cast<bf16*>(gres), static_cast<bf16*>(glow), N, Hl, Wl,
+        CS / 8, f, relu);
+    return otp_launch_status();
+}
+
+extern "C" int otp_nchw_f32_to_nhwc_bf16(const void* in, void* out, int N, int C, int H, int W, int frame_split, void* stream) {
+    if (!in || !out || N <= 0 || C <= 0 || (frame_split > 0 && N % frame_split)) return OTP_ERR_BAD_ARG;
+    const int CS = (C + 7) / 8 * 8;
+    nchw_to_nhwc_kernel<<<grid_for((size_t)N * H * W), 256, 0, static_cast<hipStream_t>(stream)>>>(
+        static_cast<const float*>(in), static_cast<bf16*>(out), N, C, H * W, CS, frame_split);
+    return otp_launch_status();
+}
+
+extern "C" int otp_nhwc_bf16_to_nchw_f32(const void* in, void* out, int N, int C, int H, int W, void* stream) {
+    if (!in || !out || N <= 0 || C <= 0) return OTP_ERR_BAD_ARG;
+    const int CS = (C + 7) / 8 * 8;
+    nhwc_to_nchw_kernel<<<grid_for((size_t)N * C * H * W), 256, 0, static_cast<hipStream_t>(stream)>>>(
+        static_cast<const bf16*>(in), static_cast<float*>(out), N, C, H * W, CS);
+    return otp_launch_status();
+}
+
+extern "C" int otp_nhwc_dilate(const void* in, void* out, int N, int Hi, int Wi, int s, int H, int W, int CS, void* stream) {
+    if (!in || !out || s <= 0 || CS % 8) return OTP_ERR_BAD_ARG;
+    dilate_nhwc_kernel<<<grid_for((size_t)N * H * W * (CS / 8)), 256, 0, static_cast<hipStream_t>(stream)>>>(
+        static_cast<const bf16*>(in), static_cast<bf16*>(out), N, Hi, Wi, s, H, W, CS / 8);
+    return otp_launch_status();
+}

@@ -33,6 +33,13 @@ class ConvDesc(ctypes.Structure):
         "res_ctot", "res_coff", "res_up", "act", "Ho", "Wo", "frame_split")]
 
 
+class NhwcConvDesc(ctypes.Structure):
+    """Mirror of ``otp_nhwc_conv_desc`` (include/otpose_hip.h)."""
+    _fields_ = [(n, c_int) for n in ("N", "H", "W", "Cin", "Cout", "kh", "kw", "stride", "pad", "dil", "out_mode")]
+
+
+_ND = ctypes.POINTER(NhwcConvDesc)
+
 # name -> (restype, argtypes); kept in one table so tests can check every symbol is exported
 SIGNATURES = {
     "otp_version": (c_int, []),
@@ -104,6 +111,22 @@ SIGNATURES = {
     "otp_loss_workspace": (c_size_t, [c_int, c_int]),
     "otp_loss_st_ohkw_grads": (c_int, [c_void_p] * 9 + [c_void_p, c_size_t] + [c_int] * 5 + [c_void_p]),
     "otp_loss_st_ohkw": (c_int, [c_void_p] * 8 + [c_void_p, c_size_t] + [c_int] * 5 + [c_void_p]),
+    "otp_nhwc_conv_weight_bytes": (c_size_t, [_ND]),
+    "otp_nhwc_conv_stats_rows": (c_int, [_ND]),
+    "otp_nhwc_conv_plan": (c_int, [_ND, ctypes.POINTER(c_int)]),
+    "otp_nhwc_conv_pack": (c_int, [c_void_p, c_void_p, _ND, c_int, c_void_p]),
+    "otp_nhwc_conv_bf16": (c_int, [c_void_p] * 5 + [_ND, c_void_p]),
+    "otp_nhwc_wgrad_workspace": (c_size_t, [_ND]),
+    "otp_nhwc_wgrad_bf16": (c_int, [c_void_p] * 4 + [c_size_t, _ND, c_void_p]),
+    "otp_nhwc_bn_finalize": (c_int, [c_void_p, c_int, c_int, c_int, c_float] + [c_void_p] * 8 + [c_float, c_float, c_void_p]),
+    "otp_nhwc_bn_apply": (c_int, [c_void_p] * 5 + [c_size_t, c_int, c_int, c_void_p]),
+    "otp_nhwc_bn_backward_workspace": (c_size_t, [c_size_t, c_int]),
+    "otp_nhwc_bn_backward": (c_int, [c_void_p] * 11 + [c_size_t, c_size_t, c_int, c_int, c_int, c_void_p]),
+    "otp_nhwc_upsample_add": (c_int, [c_void_p] * 3 + [c_int] * 6 + [c_void_p]),
+    "otp_nhwc_upsample_add_backward": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_void_p]),
+    "otp_nchw_f32_to_nhwc_bf16": (c_int, [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
+    "otp_nhwc_bf16_to_nchw_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
+    "otp_nhwc_dilate": (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     "otp_loss_joints_mse": (c_int, [c_void_p] * 5 + [c_void_p, c_size_t] + [c_int] * 6 + [c_void_p]),
 }
 

@@ -1,0 +1,176 @@
+"""bf16 NHWC training operators (csrc/nhwc.hip) against plain PyTorch fp32 references of the same ops on the SAME
+bf16-rounded operands: the conv products are exact in fp32, so forward outputs differ from the reference only by the
+final rounding to bf16 (2^-9 relative) and fp32 summation order; weight gradients are fp32 end to end.
+Reference ops: nn.Conv2d / nn.BatchNorm2d(training) / nearest upsample + add as composed in model/HRNet.py:416-571."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+def _dev():
+    return torch.device("cuda", 0)
+
+
+def _nhwc(t):
+    """(N, C, H, W) float (values already bf16-representable) -> (N, H, W, CS) bf16 on the GPU, zero padded."""
+    from otpose_amd.bf16_ops import cs
+    n, c, h, w = t.shape
+    out = torch.zeros(n, h, w, cs(c), dtype=BF)
+    out[..., :c] = t.permute(0, 2, 3, 1).to(BF)
+    return out.to(_dev())
+
+
+def _nchw(t, c):
+    return t[..., :c].float().permute(0, 3, 1, 2).cpu()
+
+
+def _rb(t):
+    return t.to(BF).float()
+
+
+CONV_CASES = [
+    # cin, cout, k, stride, pad, dil, n, h, w
+    (48, 48, 3, 1, 1, 1, 3, 24, 18),
+    (3, 64, 3, 2, 1, 1, 2, 32, 24),
+    (64, 256, 1, 1, 0, 1, 2, 16, 12),
+    (96, 48, 1, 1, 0, 1, 2, 12, 9),
+    (48, 96, 3, 2, 1, 1, 2, 24, 18),
+    (384, 384, 3, 1, 1, 1, 2, 12, 9),
+    (192, 192, 3, 1, 1, 1, 2, 24, 18),
+    (48, 17, 1, 1, 0, 1, 2, 24, 18),
+    (32, 306, 3, 1, 6, 6, 1, 24, 18),
+    (40, 24, 3, 1, 1, 1, 1, 7, 5),
+    (64, 64, 3, 1, 1, 1, 1, 96, 72),
+    (48, 48, 3, 1, 1, 1, 1, 96, 72),
+    (256, 64, 1, 1, 0, 1, 1, 96, 72),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_forward_stats_dgrad_wgrad(case):
+    from otpose_amd import bf16_ops as B
+    cin, cout, k, stride, pad, dil, n, h, w = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = _rb(torch.randn(n, cin, h, w, generator=g))
+    wt = _rb(torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5)
+    ref = F.conv2d(x.double(), wt.double(), None, stride, pad, dil).float()
+    xd, wd = _nhwc(x), wt.to(_dev())
+    out, stats, rows = B.conv_forward(xd, wd, None, stride, pad, dil)
+    torch.cuda.synchronize()
+    got = _nchw(out, cout)
+    tol = 2.0 ** -8 * ref.abs().max()
+    assert float((got - ref).abs().max()) <= tol, float((got - ref).abs().max())
+    # padding channels are zero, statistics are those of the rounded outputs
+    assert float(out[..., cout:].float().abs().max() if out.shape[-1] > cout else 0.0) == 0.0
+    s = stats.sum(0).cpu()
+    o = out.float().cpu().reshape(-1, out.shape[-1])
+    assert torch.allclose(s[0], o.sum(0), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(s[1], (o * o).sum(0), rtol=1e-4, atol=1e-2)
+    assert rows == stats.shape[0]
+    # fp32 NCHW output mode with bias
+    bias = torch.randn(cout, generator=g)
+    o32, _, _ = B.conv_forward(xd, wd, bias.to(_dev()), stride, pad, dil, out_mode=1)
+    ref32 = ref + bias.view(1, -1, 1, 1)
+    assert float((o32.cpu() - ref32).abs().max()) <= 1e-4 * max(1.0, float(ref32.abs().max()))
+    # gradients
+    gy = _rb(torch.randn(ref.shape, generator=g))
+    xr, wr = x.double().requires_grad_(), wt.double().requires_grad_()
+    F.conv2d(xr, wr, None, stride, pad, dil).backward(gy.double())
+    gyd = _nhwc(gy)
+    gx = _nchw(B.conv_dgrad(gyd, wd, (h, w), stride, pad, dil), cin)
+    gxr = xr.grad.float()
+    assert float((gx - gxr).abs().max()) <= 2.0 ** -8 * gxr.abs().max(), float((gx - gxr).abs().max())
+    gw = B.conv_wgrad(xd, gyd, tuple(wt.shape), stride, pad, dil).cpu()
+    gwr = wr.grad.float()
+    assert float((gw - gwr).abs().max()) <= 2e-5 * max(1.0, float(gwr.abs().max())), float((gw - gwr).abs().max())
+
+
+@pytest.mark.parametrize("c,relu,with_res", [(48, True, True), (96, True, False), (17, False, False), (256, False, True)])
+def test_conv_bn_function_matches_torch_autograd(c, relu, with_res):
+    """ConvBnFunction forward / backward vs conv2d + batch_norm(training) + residual + relu on fp64 autograd."""
+    from otpose_amd import bf16_ops as B
+    g = torch.Generator().manual_seed(c)
+    n, cin, h, w = 3, 48, 12, 9
+    x = _rb(torch.randn(n, cin, h, w, generator=g))
+    wt = _rb(torch.randn(c, cin, 3, 3, generator=g) / (cin * 9) ** 0.5)
+    gamma = torch.rand(c, generator=g) + 0.5
+    beta = torch.randn(c, generator=g) * 0.2
+    res = _rb(torch.randn(n, c, h, w, generator=g)) if with_res else None
+    gy = _rb(torch.randn(n, c, h, w, generator=g))
+    rm, rv = torch.zeros(c), torch.ones(c)
+    # reference in fp64, with the conv output rounded to bf16 where the kernel rounds it (BatchNorm normalises the stored tensor)
+    xr, wr = x.double().requires_grad_(), wt.double().requires_grad_()
+    gr, br = gamma.double().requires_grad_(), beta.double().requires_grad_()
+    rr = res.double().requires_grad_() if with_res else None
+    conv = F.conv2d(xr, wr, None, 1, 1)
+    conv_q = conv + (conv.detach().to(BF).double() - conv.detach())          # straight-through rounding
+    rmr, rvr = rm.double().clone(), rv.double().clone()
+    y = F.batch_norm(conv_q, rmr, rvr, gr, br, True, 0.1, 1e-5)
+    if with_res:
+        y = y + rr
+    if relu:
+        y = torch.relu(y)
+    y.backward(gy.double())
+    dev = _dev()
+    xd = _nhwc(x).requires_grad_()
+    wd = wt.to(dev).requires_grad_()
+    gd, bd = gamma.to(dev).requires_grad_(), beta.to(dev).requires_grad_()
+    rd = _nhwc(res).requires_grad_() if with_res else None
+    rmd, rvd = rm.to(dev), rv.to(dev)
+    out = B.conv_bn(xd, wd, gd, bd, rd, rmd, rvd, 1, 1, relu)
+    out.backward(_nhwc(gy))
+    torch.cuda.synchronize()
+    scale = float(y.detach().abs().max())
+    assert float((_nchw(out.detach(), c) - y.detach().float()).abs().max()) <= 2.0 ** -7 * scale
+    assert torch.allclose(rmd.cpu(), rmr.float(), atol=1e-4) and torch.allclose(rvd.cpu(), rvr.float(), rtol=1e-3, atol=1e-4)
+
+    def close(a, b, rel):
+        return float((a - b).abs().max()) <= rel * max(float(b.abs().max()), 1e-6)
+
+    # input / residual gradients pass through bf16 tensors (gc is rounded before the dgrad conv)
+    assert close(_nchw(xd.grad, cin), xr.grad.float(), 3e-2)
+    if with_res:
+        assert close(_nchw(rd.grad, c), rr.grad.float(), 1e-2)
+    assert close(wd.grad.cpu(), wr.grad.float(), 3e-2)
+    assert close(gd.grad.cpu(), gr.grad.float(), 2e-2)
+    assert close(bd.grad.cpu(), br.grad.float(), 2e-2)
+
+
+@pytest.mark.parametrize("f,relu", [(2, True), (4, False), (8, True)])
+def test_upsample_add_forward_backward(f, relu):
+    from otpose_amd import bf16_ops as B
+    g = torch.Generator().manual_seed(f)
+    n, c, hl, wl = 2, 48, 3, 2
+    low = _rb(torch.randn(n, c, hl, wl, generator=g))
+    res = _rb(torch.randn(n, c, hl * f, wl * f, generator=g))
+    gy = _rb(torch.randn(n, c, hl * f, wl * f, generator=g))
+    lr, rr = low.double().requires_grad_(), res.double().requires_grad_()
+    y = rr + F.interpolate(lr, scale_factor=f, mode="nearest")
+    if relu:
+        y = torch.relu(y)
+    y.backward(gy.double())
+    ld, rd = _nhwc(low).requires_grad_(), _nhwc(res).requires_grad_()
+    out = B.upsample_add(ld, rd, f, relu)
+    out.backward(_nhwc(gy))
+    torch.cuda.synchronize()
+    assert float((_nchw(out.detach(), c) - y.detach().float()).abs().max()) <= 2.0 ** -8 * float(y.detach().abs().max())
+    assert float((_nchw(rd.grad, c) - rr.grad.float()).abs().max()) == 0.0
+    assert float((_nchw(ld.grad, c) - lr.grad.float()).abs().max()) <= 2.0 ** -8 * float(lr.grad.abs().max())
+
+
+def test_layout_converters_round_trip_and_frame_split():
+    from otpose_amd import bf16_ops as B
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 15, 8, 6, generator=g)
+    d = B.to_nhwc(x.to(_dev()), frame_split=2)                      # (10, 8, 6, 8): frames on the batch axis, C 3 -> 8
+    ref = torch.cat(x.split(3, dim=1), 0)                           # model/OTPose.py:317
+    assert d.shape == (10, 8, 6, 8)
+    assert torch.equal(_nchw(d, 3), _rb(ref)) and float(d[..., 3:].float().abs().max()) == 0.0
+    y = torch.randn(3, 17, 5, 4, generator=g)
+    n = B.to_nhwc(y.to(_dev()))
+    assert n.shape == (3, 5, 4, 24)
+    assert torch.equal(B.to_nchw(n, 17).cpu(), _rb(y))
