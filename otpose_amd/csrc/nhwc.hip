@@ -14,6 +14,8 @@
 //                             [pixel][channel] LDS images with ds_read_b64_tr_b16 (the hardware transpose read), so the
 //                             contraction index (pixels) lands in the fragment's k slots without a transposed copy
 //   bn_* / upsample_add_*     HBM-bound NHWC passes (16-byte accesses, fp32 arithmetic)
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -26,6 +28,25 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float bf2f(bf16 v) { return (float)v; }
+
+// 16-byte range-checked buffer load: staging loops mask a unit by pointing it past the descriptor (the hardware returns
+// zeros) instead of branching around the load - hipcc waits for every outstanding load at each such branch, which turns a
+// batch of independent loads into a chain of L2 round trips.
+constexpr int OOB = -16;
+
+#ifdef OTP_NHWC_TIMING
+// development build only (tools/nhwc_timing.py): per-workgroup phase stamps of nhwc_conv_kernel, never in libotpose_hip.so
+__device__ unsigned long long otp_nhwc_stamps[8192 * 8];
+#define OTP_STAMP(slot)                                                                              \
+    do {                                                                                             \
+        if (threadIdx.x == 0 && blockIdx.x < 8192) otp_nhwc_stamps[blockIdx.x * 8 + (slot)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define OTP_STAMP(slot)
+#endif
+__device__ __forceinline__ u32x4 bload16(otp_rsrc r, int voff_bytes) {
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff_bytes, 0, 0));
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // plan: a pure function of the descriptor (host), shared by the packer and the launcher
@@ -66,7 +87,9 @@ bool make_plan(const otp_nhwc_conv_desc* d, ConvPlan* p) {
     if (c16 > 96 && c16 % 96 != 0 && c16 % 64 == 0) bm = 64;
     p->BM = bm, p->MB = bm / 16, p->nM = (c16 + bm - 1) / bm;
     const int npx = p->Ho * p->Wo;
-    p->NB = (npx >= 4096 && p->MB <= 3) ? 4 : 2;
+    // 256-pixel tiles (4 N-blocks per wave: 10 LDS fragment reads per 24 MFMAs at MB = 6 instead of 8 per 12) when that
+    // still leaves >= 4 workgroups per CU to balance; 128-pixel tiles otherwise
+    p->NB = ((long)d->N * ((npx + 255) / 256) * p->nM >= 1024) ? 4 : 2;
     p->P = 64 * p->NB;
     p->tilesPerImg = (npx + p->P - 1) / p->P;
     const int need = (p->Wo - 1) * d->stride + (d->kw - 1) * d->dil + 1;
@@ -76,6 +99,8 @@ bool make_plan(const otp_nhwc_conv_desc* d, ConvPlan* p) {
     p->rowsMax = (rowsOut - 1) * d->stride + (d->kh - 1) * d->dil + 1;
     p->ldsW = p->KS * 4 * p->BM * 16;
     p->ldsX = round_up(p->rowsMax * p->RW * p->CKp * 2, 16);
+    const int outTile = p->P * (p->BM + 8) * 2;                 // the epilogue's [pixel][channel] image reuses the operand space
+    if (p->ldsW + p->ldsX < outTile) p->ldsX = outTile - p->ldsW;
     p->ldsTab = round_up(p->KS * 4 * 4, 16);
     p->lds = p->ldsW + p->ldsX + p->ldsTab + 4 * 2 * p->BM * 4;
     p->wbytes = (size_t)p->nChunks * p->nM * p->ldsW;
@@ -109,7 +134,112 @@ __global__ void nhwc_pack_kernel(const float* __restrict__ w, bf16* __restrict__
 // ---------------------------------------------------------------------------------------------------------------------
 // implicit-GEMM convolution
 // ---------------------------------------------------------------------------------------------------------------------
+// bias, rounding, store; per-tile channel sums of the ROUNDED values (what BatchNorm will normalise).  Contains one
+// workgroup barrier when statistics are requested.
+// sum over the 16 lanes of a DPP row (one MFMA pixel column group) with four VALU adds; every lane ends with the total.
+// (__shfl_xor with offsets 4 and 8 lowers to ds_bpermute on gfx950: 96 LDS round trips in the old epilogue)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_mov<0xB1>(v);        // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);        // quad_perm [2,3,0,1]
+    v += dpp_mov<0x124>(v);       // row_ror:4
+    v += dpp_mov<0x128>(v);       // row_ror:8
+    return v;
+}
+
+// bias, rounding, store; per-tile channel sums of the ROUNDED values (what BatchNorm will normalise).
+// NHWC output: the tile is transposed through LDS (smem is free once every wave has left the MFMA loop) so that it leaves as
+// 16-byte stores of whole pixel rows - the accumulator layout (4 channels x 1 pixel per lane) would otherwise issue MB*NB
+// 8-byte stores per lane in 32-byte runs, which is store-issue bound (10-16k cycles per workgroup, measured with
+// tools/nhwc_timing.py).  Contains workgroup barriers; every thread of the workgroup must call it.
 template <int MB, int NB>
+__device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[MB][NB], const bool (&valid)[NB], const ConvPlan& p,
+                                              const float* __restrict__ bias, bf16* __restrict__ out,
+                                              float* __restrict__ out_f32, float* __restrict__ stats, unsigned char* smem,
+                                              float* sRed, int n, int tile, int mt, int p0, int npx) {
+    constexpr int BM = MB * 16, P = 64 * NB, BMS = BM + 8;      // LDS row stride: 16-byte aligned, odd multiple of 16 bytes
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+    if (p.out_mode == 1) {                                       // fp32 NCHW (hand-over to the fp32 NCHW kernels)
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            const int co = mt * BM + m * 16 + lg * 4;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const int pix = p0 + (wave * NB + nb) * 16 + l15;
+                if (valid[nb]) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (co + r < p.Cout)
+                            out_f32[((size_t)n * p.Cout + co + r) * npx + pix] = acc[m][nb][r] + (bias ? bias[co + r] : 0.f);
+                }
+            }
+        }
+        return;
+    }
+    bf16* sOut = reinterpret_cast<bf16*>(smem);
+    __syncthreads();                                             // every wave is done with the operand images
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+        const int co = mt * BM + m * 16 + lg * 4;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bias) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (co + r < p.Cout) bv[r] = bias[co + r];
+        }
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                o[r] = (bf16)(acc[m][nb][r] + bv[r]);
+                const float f = valid[nb] ? bf2f(o[r]) : 0.f;
+                s1[r] += f;
+                s2[r] += f * f;
+            }
+            *reinterpret_cast<bf16x4*>(sOut + ((wave * NB + nb) * 16 + l15) * BMS + m * 16 + lg * 4) = o;
+        }
+        if (stats) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float a = row16_sum(s1[r]), b = row16_sum(s2[r]);
+                if (l15 == 0) {
+                    sRed[(wave * 2 + 0) * BM + m * 16 + lg * 4 + r] = a;
+                    sRed[(wave * 2 + 1) * BM + m * 16 + lg * 4 + r] = b;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // rows of the tile -> global: (pixel, 8-channel group) units, consecutive threads = consecutive bytes of a pixel row
+    int cvalid = p.CoutS - mt * BM;
+    if (cvalid > BM) cvalid = BM;
+    const int cu8 = cvalid / 8, units = P * cu8;
+    const int pmax = min(P, npx - p0);
+    for (int u = tid; u < units; u += 256) {
+        const int px = u / cu8, cg = u - px * cu8;
+        if (px < pmax)
+            *reinterpret_cast<u32x4*>(out + ((size_t)n * npx + p0 + px) * p.CoutS + mt * BM + cg * 8) =
+                *reinterpret_cast<const u32x4*>(sOut + px * BMS + cg * 8);
+    }
+    if (stats) {
+        for (int i = tid; i < 2 * BM; i += 256) {
+            const int which = i / BM, c = i - which * BM, co = mt * BM + c;
+            if (co < p.CoutS) {
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) v += sRed[(w * 2 + which) * BM + c];
+                stats[((size_t)(n * p.tilesPerImg + tile) * 2 + which) * p.CoutS + co] = v;
+            }
+        }
+    }
+}
+
+template <int MB, int NB, bool K7>
 __global__ __launch_bounds__(256) void nhwc_conv_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wpk,
                                                          const float* __restrict__ bias, bf16* __restrict__ out,
                                                          float* __restrict__ out_f32, float* __restrict__ stats, ConvPlan p) {
@@ -130,6 +260,7 @@ __global__ __launch_bounds__(256) void nhwc_conv_kernel(const bf16* __restrict__
     const int rowLo = oy0 * p.stride - p.pad;
     const int nrows = (oy1 - oy0) * p.stride + (p.kh - 1) * p.dil + 1;
 
+    OTP_STAMP(0);
     // k-group -> element offset inside the window (tap shift + channel group); identical for every chunk
     for (int kg = tid; kg < p.KS * 4; kg += 256) {
         int v = 0;
@@ -158,113 +289,105 @@ __global__ __launch_bounds__(256) void nhwc_conv_kernel(const bf16* __restrict__
 
     const int wunits = p.ldsW / 16;
     const int rowUnits = p.RW * p.CK8;
-    const size_t imgBase = (size_t)n * p.H * p.W * p.CinS;
+    const otp_rsrc xres = make_rsrc(x, (size_t)p.N * p.H * p.W * p.CinS * 2), wres = make_rsrc(wpk, p.wbytes);
+    OTP_STAMP(1);
     for (int ch = 0; ch < p.nChunks; ++ch) {
         if (ch) __syncthreads();
-        // weights of this (chunk, m-tile): one contiguous slab
-        const u32x4* wsrc = reinterpret_cast<const u32x4*>(wpk) + (size_t)(ch * p.nM + mt) * wunits;
-        for (int i = tid; i < wunits; i += 256) reinterpret_cast<u32x4*>(sW)[i] = wsrc[i];
-        // input window: rows [rowLo, rowLo + nrows) x columns [-pad, RW - pad) x CK channels, zeros outside the image
+        // One L2 round trip per chunk: the first 8 weight units AND the first 8 window rows of this thread are all in
+        // flight before the first LDS store (weights: one contiguous slab per (chunk, m-tile); window: rows
+        // [rowLo, rowLo + nrows) x columns [-pad, RW - pad) x CK channels, zeros outside the image; a thread owns one
+        // (column, channel group) and walks the rows, so the column arithmetic is done once per chunk).
+        const int wbase = (ch * p.nM + mt) * wunits * 16;
         const int c0 = ch * p.CK;
-        for (int r = 0; r < nrows; ++r) {
-            const int iy = rowLo + r;
-            const bool rowIn = iy >= 0 && iy < p.H;
-            const bf16* grow = x + imgBase + (size_t)iy * p.W * p.CinS;
-            bf16* lrow = sX + (size_t)r * p.RW * p.CKp;
-            for (int u = tid; u < rowUnits; u += 256) {
-                const int col = u / p.CK8, cgi = u - col * p.CK8;
-                const int ix = col - p.pad, c = c0 + cgi * 8;
-                u32x4 v = {0u, 0u, 0u, 0u};
-                if (rowIn && ix >= 0 && ix < p.W && c < p.CinS)
-                    v = *reinterpret_cast<const u32x4*>(grow + (size_t)ix * p.CinS + c);
-                *reinterpret_cast<u32x4*>(lrow + col * p.CKp + cgi * 8) = v;
+        u32x4 wv[8], xv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = j * 256 + tid;
+            wv[j] = bload16(wres, i < wunits ? wbase + i * 16 : OOB);
+        }
+        const int col0 = tid / p.CK8, cg0 = tid - col0 * p.CK8;
+        const int ix0 = col0 - p.pad;
+        const bool colOK0 = tid < rowUnits && ix0 >= 0 && ix0 < p.W && c0 + cg0 * 8 < p.CinS;
+        const int gcol0 = (ix0 * p.CinS + c0 + cg0 * 8) * 2, ldst0 = col0 * p.CKp + cg0 * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int iy = rowLo + j;
+            const bool ok = colOK0 && j < nrows && iy >= 0 && iy < p.H;
+            xv[j] = bload16(xres, ok ? (n * p.H + iy) * (p.W * p.CinS * 2) + gcol0 : OOB);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = j * 256 + tid;
+            if (i < wunits) reinterpret_cast<u32x4*>(sW)[i] = wv[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (tid < rowUnits && j < nrows) *reinterpret_cast<u32x4*>(sX + j * (p.RW * p.CKp) + ldst0) = xv[j];
+        // the rest (more than 2048 weight units, rows past 8, rows wider than 256 units)
+        for (int base = 256 * 8; base < wunits; base += 256 * 8) {
+            u32x4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = base + j * 256 + tid;
+                v[j] = bload16(wres, i < wunits ? wbase + i * 16 : OOB);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = base + j * 256 + tid;
+                if (i < wunits) reinterpret_cast<u32x4*>(sW)[i] = v[j];
+            }
+        }
+        for (int sub = 0; sub * 256 < rowUnits; ++sub) {
+            const int cu = sub * 256 + tid;
+            const int col = cu / p.CK8, cgi = cu - col * p.CK8;
+            const int ix = col - p.pad, c = c0 + cgi * 8;
+            const bool colOK = cu < rowUnits && ix >= 0 && ix < p.W && c < p.CinS;
+            const int gcol = (ix * p.CinS + c) * 2, ldst = col * p.CKp + cgi * 8;
+            for (int r0 = sub ? 0 : 8; r0 < nrows; r0 += 8) {
+                u32x4 v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int iy = rowLo + r0 + j;
+                    const bool ok = colOK && r0 + j < nrows && iy >= 0 && iy < p.H;
+                    v[j] = bload16(xres, ok ? (n * p.H + iy) * (p.W * p.CinS * 2) + gcol : OOB);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (cu < rowUnits && r0 + j < nrows)
+                        *reinterpret_cast<u32x4*>(sX + (r0 + j) * (p.RW * p.CKp) + ldst) = v[j];
             }
         }
         __syncthreads();
-        for (int ks = 0; ks < p.KS; ++ks) {
+        if (ch == 0) OTP_STAMP(2);
+        auto kstep = [&](int ks) {
             const int koff = sTab[ks * 4 + lg];
             bf16x8 a[MB];
 #pragma unroll
-            for (int m = 0; m < MB; ++m)
-                a[m] = *reinterpret_cast<const bf16x8*>(sW + ((size_t)((ks * 4 + lg) * BM + m * 16 + l15)) * 8);
+            for (int m = 0; m < MB; ++m) a[m] = *reinterpret_cast<const bf16x8*>(sW + ((ks * 4 + lg) * BM + m * 16 + l15) * 8);
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 const bf16x8 b = *reinterpret_cast<const bf16x8*>(sX + boff[nb] + koff);
 #pragma unroll
                 for (int m = 0; m < MB; ++m) acc[m][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], b, acc[m][nb], 0, 0, 0);
             }
+        };
+        if constexpr (K7) {               // 3x3 taps x 24 channels: fully unrolled so the LDS reads of step k+1 issue under step k
+#pragma unroll
+            for (int ks = 0; ks < 7; ++ks) kstep(ks);
+        } else {
+            for (int ks = 0; ks < p.KS; ++ks) kstep(ks);
         }
+        if (ch == 0) OTP_STAMP(3);
     }
 
-    // ---- epilogue: bias, rounding, store; per-tile channel sums of the ROUNDED values (what BatchNorm will normalise) ----
-    float s1[MB][4], s2[MB][4];
-#pragma unroll
-    for (int m = 0; m < MB; ++m)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) s1[m][r] = s2[m][r] = 0.f;
-#pragma unroll
-    for (int m = 0; m < MB; ++m) {
-        const int co = mt * BM + m * 16 + lg * 4;
-        float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (bias) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (co + r < p.Cout) bv[r] = bias[co + r];
-        }
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            const int pix = p0 + (wave * NB + nb) * 16 + l15;
-            if (p.out_mode == 1) {                               // fp32 NCHW (hand-over to the fp32 NCHW kernels)
-                if (valid[nb]) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (co + r < p.Cout) out_f32[((size_t)n * p.Cout + co + r) * npx + pix] = acc[m][nb][r] + bv[r];
-                }
-                continue;
-            }
-            bf16x4 o;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                o[r] = (bf16)(acc[m][nb][r] + bv[r]);
-                const float f = valid[nb] ? bf2f(o[r]) : 0.f;
-                s1[m][r] += f;
-                s2[m][r] += f * f;
-            }
-            if (valid[nb] && co < p.CoutS)
-                *reinterpret_cast<bf16x4*>(out + ((size_t)n * npx + pix) * p.CoutS + co) = o;
-        }
-    }
-    if (stats && p.out_mode == 0) {
-#pragma unroll
-        for (int m = 0; m < MB; ++m)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    s1[m][r] += __shfl_xor(s1[m][r], o, 64);
-                    s2[m][r] += __shfl_xor(s2[m][r], o, 64);
-                }
-                if (l15 == 0) {
-                    sRed[(wave * 2 + 0) * BM + m * 16 + lg * 4 + r] = s1[m][r];
-                    sRed[(wave * 2 + 1) * BM + m * 16 + lg * 4 + r] = s2[m][r];
-                }
-            }
-        __syncthreads();
-        for (int i = tid; i < 2 * BM; i += 256) {
-            const int which = i / BM, c = i - which * BM, co = mt * BM + c;
-            if (co < p.CoutS) {
-                float v = 0.f;
-#pragma unroll
-                for (int w = 0; w < 4; ++w) v += sRed[(w * 2 + which) * BM + c];
-                stats[((size_t)(n * p.tilesPerImg + tile) * 2 + which) * p.CoutS + co] = v;
-            }
-        }
-    }
+    OTP_STAMP(4);
+    conv_epilogue<MB, NB>(acc, valid, p, bias, out, out_f32, stats, smem, sRed, n, tile, mt, p0, npx);
+    OTP_STAMP(5);
 }
 
-template <int MB, int NB>
-int launch_conv(const ConvPlan& p, const void* x, const void* wpk, const void* bias, void* out, void* stats, hipStream_t st) {
-    auto kern = nhwc_conv_kernel<MB, NB>;
+template <int MB, int NB, bool K7>
+int launch_conv_k(const ConvPlan& p, const void* x, const void* wpk, const void* bias, void* out, void* stats, hipStream_t st) {
+    auto kern = nhwc_conv_kernel<MB, NB, K7>;
     OTP_ALLOW_BIG_LDS(kern, p.lds);
     const int grid = p.N * p.tilesPerImg * p.nM;
     kern<<<grid, 256, p.lds, st>>>(static_cast<const bf16*>(x), static_cast<const bf16*>(wpk), static_cast<const float*>(bias),
@@ -272,15 +395,22 @@ int launch_conv(const ConvPlan& p, const void* x, const void* wpk, const void* b
     return otp_launch_status();
 }
 
+template <int MB, int NB>
+int launch_conv(const ConvPlan& p, const void* x, const void* wpk, const void* bias, void* out, void* stats, hipStream_t st) {
+    return p.KS == 7 ? launch_conv_k<MB, NB, true>(p, x, wpk, bias, out, stats, st)
+                     : launch_conv_k<MB, NB, false>(p, x, wpk, bias, out, stats, st);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // weight gradient
 // ---------------------------------------------------------------------------------------------------------------------
 // A workgroup owns (co block of up to 48) x (ci block of up to 48) x all taps and a contiguous range of pixel tiles of
-// 32 output pixels; wave w owns N-blocks {w, w+4, ...} of the (tap, ci16) list for all 3 co blocks.  gy tile [32 px][48 co]
-// and the x window live in LDS as [pixel][channel]; a fragment is two ds_read_b64_tr_b16 (4 pixels x 16 channels each).
+// TPX output pixels (TPX / 32 k-steps per staged tile); wave w owns N-blocks {w, w+4, ...} of the (tap, ci16) list for all
+// 3 co blocks.  The gy tile [TPX px][48 co] and the x window live in LDS as [pixel][channel]; a fragment is two
+// ds_read_b64_tr_b16 (4 pixels x 16 channels each).
 struct WgradPlan {
     int N, H, W, CinS, Ho, Wo, CoutS, Cin, Cout, kh, kw, stride, pad, dil;
-    int nCo, nCi, splits, tilesPerImg, tilesTotal, tilesPerSplit;
+    int nCo, nCi, splits, tilesPerImg, tilesTotal, tilesPerSplit, TPX;
     int RW, rowsMax, XC, ldsG, ldsX, lds;
     int nbTot;             // N-blocks per workgroup = taps * 3
 };
@@ -290,14 +420,13 @@ __device__ __forceinline__ bf16x4 tr_read(const bf16* p) {
         (__attribute__((address_space(3))) bf16x4*)(const_cast<bf16*>(p)));
 }
 
-constexpr int WG_PX = 32;      // output pixels per k-step (one MFMA k extent)
 constexpr int WG_NBW = 7;      // N-blocks per wave (27 = 9 taps x 3 ci blocks over 4 waves)
 
 __global__ __launch_bounds__(256) void nhwc_wgrad_kernel(const bf16* __restrict__ x, const bf16* __restrict__ gy,
                                                           float* __restrict__ part, WgradPlan p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    bf16* sG = reinterpret_cast<bf16*>(smem);                 // [32 px][56] (48 channels + 8 pad: row stride 112 B)
-    bf16* sX = reinterpret_cast<bf16*>(smem + p.ldsG);        // [rows][RW][XC] (XC = 56)
+    bf16* sG = reinterpret_cast<bf16*>(smem);                 // [TPX px][56] (48 channels + 8 pad: row stride 112 B)
+    bf16* sX = reinterpret_cast<bf16*>(smem + p.ldsG);        // [rows][RW][XC]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
     int bid = blockIdx.x;
     const int split = bid % p.splits;
@@ -306,15 +435,14 @@ __global__ __launch_bounds__(256) void nhwc_wgrad_kernel(const bf16* __restrict_
     const int co0 = cob * 48, ci0 = cib * 48;
     const int taps = p.kh * p.kw;
     const int npx = p.Ho * p.Wo;
+    const int TPX = p.TPX;
 
     // this wave's N-blocks: nb = wave + 4*i  ->  (tap, ci16 block)
-    int xoff[WG_NBW];          // element offset inside the x window of (tap shift, ci block) for this lane's channel quad
-    bool has[WG_NBW];
+    int xoff[WG_NBW];          // element offset inside the x window of (tap shift, ci block)
 #pragma unroll
     for (int i = 0; i < WG_NBW; ++i) {
         const int nb = wave + 4 * i;
-        has[i] = nb < p.nbTot;
-        const int nbc = has[i] ? nb : 0;
+        const int nbc = nb < p.nbTot ? nb : 0;
         const int tap = nbc / 3, cb = nbc - tap * 3;
         const int dy = tap / p.kw, dx = tap - dy * p.kw;
         xoff[i] = ((dy * p.dil) * p.RW + dx * p.dil) * p.XC + cb * 16;
@@ -327,65 +455,90 @@ __global__ __launch_bounds__(256) void nhwc_wgrad_kernel(const bf16* __restrict_
 
     // transpose-read addressing: within a 16-lane group, lane 4q+pp supplies row q (pixel), columns 4pp..4pp+3 (channels)
     const int q = l15 >> 2, pp = l15 & 3;
+    const int xcu = p.XC / 8;
+    const int gunits = TPX * 6;
+    const otp_rsrc xres = make_rsrc(x, (size_t)p.N * p.H * p.W * p.CinS * 2);
+    const otp_rsrc gres = make_rsrc(gy, (size_t)p.N * npx * p.CoutS * 2);
 
     const int t0 = split * p.tilesPerSplit, t1 = min(t0 + p.tilesPerSplit, p.tilesTotal);
     for (int t = t0; t < t1; ++t) {
         const int n = t / p.tilesPerImg, tile = t - n * p.tilesPerImg;
-        const int p0 = tile * WG_PX, p1 = min(p0 + WG_PX, npx);
+        const int p0 = tile * TPX, p1 = min(p0 + TPX, npx);
         const int oy0 = p0 / p.Wo, oy1 = (p1 - 1) / p.Wo;
         const int rowLo = oy0 * p.stride - p.pad;
         const int nrows = (oy1 - oy0) * p.stride + (p.kh - 1) * p.dil + 1;
         __syncthreads();
-        // gy tile: 32 pixels x 48 channels (6 units of 16 B per pixel); pixels past the image and channels past CoutS are zero
-        for (int u = tid; u < WG_PX * 6; u += 256) {
-            const int px = u / 6, cg = u - px * 6;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (p0 + px < p1 && co0 + cg * 8 < p.CoutS)
-                v = *reinterpret_cast<const u32x4*>(gy + ((size_t)n * npx + p0 + px) * p.CoutS + co0 + cg * 8);
-            *reinterpret_cast<u32x4*>(sG + px * 56 + cg * 8) = v;
+        // gy tile: TPX pixels x 48 channels (6 units of 16 B per pixel); pixels past the image and channels past CoutS are
+        // zero.  Loads are batched ahead of the LDS stores (see nhwc_conv_kernel).
+        for (int base = 0; base < gunits; base += 256 * 4) {
+            u32x4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int u = base + j * 256 + tid;
+                const int px = u / 6, cg = u - px * 6;
+                const bool ok = u < gunits && p0 + px < p1 && co0 + cg * 8 < p.CoutS;
+                v[j] = bload16(gres, ok ? ((n * npx + p0 + px) * p.CoutS + co0 + cg * 8) * 2 : OOB);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int u = base + j * 256 + tid;
+                const int px = u / 6, cg = u - px * 6;
+                if (u < gunits) *reinterpret_cast<u32x4*>(sG + px * 56 + cg * 8) = v[j];
+            }
         }
-        // x window: rows x RW columns x 48 channels of this ci block
-        const size_t imgBase = (size_t)n * p.H * p.W * p.CinS;
-        for (int r = 0; r < nrows; ++r) {
-            const int iy = rowLo + r;
-            const bool rowIn = iy >= 0 && iy < p.H;
-            const bf16* grow = x + imgBase + (size_t)iy * p.W * p.CinS;
-            bf16* lrow = sX + (size_t)r * p.RW * p.XC;
-            for (int u = tid; u < p.RW * 6; u += 256) {
-                const int col = u / 6, cg = u - col * 6;
-                const int ix = col - p.pad, c = ci0 + cg * 8;
-                u32x4 v = {0u, 0u, 0u, 0u};
-                if (rowIn && ix >= 0 && ix < p.W && c < p.CinS) v = *reinterpret_cast<const u32x4*>(grow + (size_t)ix * p.CinS + c);
-                *reinterpret_cast<u32x4*>(lrow + col * p.XC + cg * 8) = v;
+        // x window: rows x RW columns x the ci block's channels (+ zero padding channels); thread = (column, channel group),
+        // 8 rows in flight (see nhwc_conv_kernel)
+        const int rowUnits = p.RW * xcu;
+        for (int sub = 0; sub * 256 < rowUnits; ++sub) {
+            const int cu = sub * 256 + tid;
+            const int col = cu / xcu, cg = cu - col * xcu;
+            const int ix = col - p.pad, c = ci0 + cg * 8;
+            const bool colOK = cu < rowUnits && cg < 6 && ix >= 0 && ix < p.W && c < p.CinS;
+            const int gcol = (ix * p.CinS + c) * 2, ldst = col * p.XC + cg * 8;
+            for (int r0 = 0; r0 < nrows; r0 += 8) {
+                u32x4 v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int iy = rowLo + r0 + j;
+                    const bool ok = colOK && r0 + j < nrows && iy >= 0 && iy < p.H;
+                    v[j] = bload16(xres, ok ? (n * p.H + iy) * (p.W * p.CinS * 2) + gcol : OOB);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (cu < rowUnits && r0 + j < nrows)
+                        *reinterpret_cast<u32x4*>(sX + (r0 + j) * (p.RW * p.XC) + ldst) = v[j];
             }
         }
         __syncthreads();
-        // one k-step of 32 pixels: lane group lg covers pixels 8*lg .. 8*lg+7 (two transposed reads of 4 pixels)
-        bf16x8 a[3];
-        int xrow[2];           // window element offset of this lane's row (pixel) for the two 4-pixel halves
+        // k-steps of 32 pixels: lane group lg covers pixels 8*lg .. 8*lg+7 of the step (two transposed reads of 4 pixels)
+        for (int k0 = 0; k0 < TPX; k0 += 32) {
+            if (p0 + k0 >= p1) break;                            // uniform: the rest of the tile is past the image
+            bf16x8 a[3];
+            int xrow[2];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int px = 8 * lg + 4 * h + q;
-            const int pc = min(p0 + px, p1 - 1);               // rows past the tile pair with zero gy rows
-            const int oy = pc / p.Wo, ox = pc - oy * p.Wo;
-            xrow[h] = (((oy - oy0) * p.stride) * p.RW + ox * p.stride) * p.XC + 4 * pp;
-        }
+            for (int h = 0; h < 2; ++h) {
+                const int px = k0 + 8 * lg + 4 * h + q;
+                const int pc = min(p0 + px, p1 - 1);             // rows past the tile pair with zero gy rows
+                const int oy = pc / p.Wo, ox = pc - oy * p.Wo;
+                xrow[h] = (((oy - oy0) * p.stride) * p.RW + ox * p.stride) * p.XC + 4 * pp;
+            }
 #pragma unroll
-        for (int m = 0; m < 3; ++m) {
-            const bf16x4 lo = tr_read(sG + (8 * lg + q) * 56 + m * 16 + 4 * pp);
-            const bf16x4 hi = tr_read(sG + (8 * lg + 4 + q) * 56 + m * 16 + 4 * pp);
-            a[m] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        }
+            for (int m = 0; m < 3; ++m) {
+                const bf16x4 lo = tr_read(sG + (k0 + 8 * lg + q) * 56 + m * 16 + 4 * pp);
+                const bf16x4 hi = tr_read(sG + (k0 + 8 * lg + 4 + q) * 56 + m * 16 + 4 * pp);
+                a[m] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
 #pragma unroll
-        for (int i = 0; i < WG_NBW; ++i) {
-            const bf16x4 lo = tr_read(sX + xrow[0] + xoff[i]);
-            const bf16x4 hi = tr_read(sX + xrow[1] + xoff[i]);
-            const bf16x8 b = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            for (int i = 0; i < WG_NBW; ++i) {
+                const bf16x4 lo = tr_read(sX + xrow[0] + xoff[i]);
+                const bf16x4 hi = tr_read(sX + xrow[1] + xoff[i]);
+                const bf16x8 b = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
-            for (int m = 0; m < 3; ++m) acc[m][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], b, acc[m][i], 0, 0, 0);
+                for (int m = 0; m < 3; ++m) acc[m][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], b, acc[m][i], 0, 0, 0);
+            }
         }
     }
-    // partial sums: part[split][co][tap][ci]  (co, ci relative to the true Cout / Cin; skipped past them)
+    // partial sums: part[split][co][ci][tap]  (co, ci relative to the true Cout / Cin; skipped past them)
 #pragma unroll
     for (int i = 0; i < WG_NBW; ++i) {
         const int nb = wave + 4 * i;
@@ -403,12 +556,27 @@ __global__ __launch_bounds__(256) void nhwc_wgrad_kernel(const bf16* __restrict_
     }
 }
 
-__global__ void nhwc_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw, int splits, size_t n) {
-    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i >= n) return;
+// gw[i] = sum over splits of part[k][i]: 64 elements x 4 split lanes per workgroup, 8 loads in flight per thread
+__global__ __launch_bounds__(256) void nhwc_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw, int splits,
+                                                                 size_t n) {
+    __shared__ float red[4][64];
+    const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const size_t i = blockIdx.x * (size_t)64 + e;
     float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += part[(size_t)k * n + i];
-    gw[i] = s;
+    if (i < n) {
+        int k = sl;
+        for (; k + 28 < splits; k += 32) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = part[(size_t)(k + 4 * j) * n + i];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[j];
+        }
+        for (; k < splits; k += 4) s += part[(size_t)k * n + i];
+    }
+    red[sl][e] = s;
+    __syncthreads();
+    if (sl == 0 && i < n) gw[i] = red[0][e] + red[1][e] + red[2][e] + red[3][e];
 }
 
 bool make_wgrad_plan(const otp_nhwc_conv_desc* d, WgradPlan* p) {
@@ -420,24 +588,35 @@ bool make_wgrad_plan(const otp_nhwc_conv_desc* d, WgradPlan* p) {
     p->nCo = (c.Cout + 47) / 48, p->nCi = (c.Cin + 47) / 48;
     p->nbTot = c.kh * c.kw * 3;
     const int npx = c.Ho * c.Wo;
-    p->tilesPerImg = (npx + WG_PX - 1) / WG_PX;
+    const int need = (c.Wo - 1) * c.stride + (c.kw - 1) * c.dil + 1;
+    p->RW = c.W + 2 * c.pad > need ? c.W + 2 * c.pad : need;
+    // window pixel stride: the ci block's channels (at most 48) + 8 zero channels; narrow inputs (the 3-channel stem) keep a
+    // narrow window.  N-blocks past the real channels read neighbouring pixels (finite, discarded): 128 bytes of slack.
+    p->XC = 8 * (c.CinS / 8 < 6 ? c.CinS / 8 : 6) + 8;
+    // pixels per staged tile: the largest of 128 / 64 / 32 whose LDS image leaves room for two workgroups per CU, else
+    // the largest that fits at all (full-width input rows make the window of wide strided layers large)
+    bool found = false;
+    for (int pass = 0; pass < 2 && !found; ++pass)
+        for (int tpx = 128; tpx >= 32 && !found; tpx >>= 1) {
+            int rowsOut = (tpx - 1 + c.Wo - 1) / c.Wo + 1;
+            if (rowsOut > c.Ho) rowsOut = c.Ho;
+            const int rows = (rowsOut - 1) * c.stride + (c.kh - 1) * c.dil + 1;
+            const int ldsG = tpx * 56 * 2, ldsX = round_up(rows * p->RW * p->XC * 2, 16) + 128;
+            if (ldsG + ldsX <= (pass == 0 ? 80 * 1024 : OTP_LDS_LIMIT)) {
+                p->TPX = tpx, p->rowsMax = rows, p->ldsG = ldsG, p->ldsX = ldsX, p->lds = ldsG + ldsX;
+                found = true;
+            }
+        }
+    if (!found) return false;
+    p->tilesPerImg = (npx + p->TPX - 1) / p->TPX;
     p->tilesTotal = c.N * p->tilesPerImg;
-    int splits = 2048 / (p->nCo * p->nCi);
+    int splits = 768 / (p->nCo * p->nCi);
     if (splits < 1) splits = 1;
     if (splits > p->tilesTotal) splits = p->tilesTotal;
     if (splits > 512) splits = 512;
     p->tilesPerSplit = (p->tilesTotal + splits - 1) / splits;
     p->splits = (p->tilesTotal + p->tilesPerSplit - 1) / p->tilesPerSplit;
-    const int need = (c.Wo - 1) * c.stride + (c.kw - 1) * c.dil + 1;
-    p->RW = c.W + 2 * c.pad > need ? c.W + 2 * c.pad : need;
-    int rowsOut = (WG_PX - 1 + c.Wo - 1) / c.Wo + 1;
-    if (rowsOut > c.Ho) rowsOut = c.Ho;
-    p->rowsMax = (rowsOut - 1) * c.stride + (c.kh - 1) * c.dil + 1;
-    p->XC = 56;
-    p->ldsG = WG_PX * 56 * 2;
-    p->ldsX = round_up(p->rowsMax * p->RW * p->XC * 2, 16);
-    p->lds = p->ldsG + p->ldsX;
-    return p->lds <= OTP_LDS_LIMIT;
+    return true;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -450,18 +629,31 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                            float* __restrict__ scale_o, float* __restrict__ shift_o,
                                                            float* __restrict__ run_mean, float* __restrict__ run_var, float eps,
                                                            float momentum) {
-    __shared__ double red[2][16][16];
-    const int cl = threadIdx.x & 15, rq = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
+    // 8 channels x 32 row lanes per workgroup: the partial rows (up to N * tiles of the conv) are the long axis
+    __shared__ double red[2][32][8];
+    const int cl = threadIdx.x & 7, rq = threadIdx.x >> 3, c = blockIdx.x * 8 + cl;
     double s1 = 0.0, s2 = 0.0;
-    if (c < C)
-        for (int r = rq; r < rows; r += 16) {
+    if (c < C) {
+        int r = rq;
+        for (; r + 96 < rows; r += 128) {
+            float a[4], b[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a[j] = part[((size_t)(r + 32 * j) * 2) * C + c];
+                b[j] = part[((size_t)(r + 32 * j) * 2 + 1) * C + c];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s1 += (double)a[j], s2 += (double)b[j];
+        }
+        for (; r < rows; r += 32) {
             s1 += (double)part[((size_t)r * 2) * C + c];
             s2 += (double)part[((size_t)r * 2 + 1) * C + c];
         }
+    }
     red[0][rq][cl] = s1, red[1][rq][cl] = s2;
     __syncthreads();
     if (rq == 0 && c < C) {
-        for (int k = 1; k < 16; ++k) s1 += red[0][k][cl], s2 += red[1][k][cl];
+        for (int k = 1; k < 32; ++k) s1 += red[0][k][cl], s2 += red[1][k][cl];
         const double m = s1 / count;
         double var = s2 / count - m * m;
         if (var < 0.0) var = 0.0;
@@ -557,18 +749,31 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
                                                                float count, const float* __restrict__ gamma,
                                                                const float* __restrict__ rstd, float* __restrict__ dgamma,
                                                                float* __restrict__ dbeta, float* __restrict__ coef) {
-    __shared__ double red[2][16][16];
-    const int cl = threadIdx.x & 15, rq = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
+    // 8 channels x 32 row lanes per workgroup: the partial rows (up to N * tiles of the conv) are the long axis
+    __shared__ double red[2][32][8];
+    const int cl = threadIdx.x & 7, rq = threadIdx.x >> 3, c = blockIdx.x * 8 + cl;
     double s1 = 0.0, s2 = 0.0;
-    if (c < C)
-        for (int r = rq; r < rows; r += 16) {
+    if (c < C) {
+        int r = rq;
+        for (; r + 96 < rows; r += 128) {
+            float a[4], b[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a[j] = part[((size_t)(r + 32 * j) * 2) * C + c];
+                b[j] = part[((size_t)(r + 32 * j) * 2 + 1) * C + c];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s1 += (double)a[j], s2 += (double)b[j];
+        }
+        for (; r < rows; r += 32) {
             s1 += (double)part[((size_t)r * 2) * C + c];
             s2 += (double)part[((size_t)r * 2 + 1) * C + c];
         }
+    }
     red[0][rq][cl] = s1, red[1][rq][cl] = s2;
     __syncthreads();
     if (rq == 0 && c < C) {
-        for (int k = 1; k < 16; ++k) s1 += red[0][k][cl], s2 += red[1][k][cl];
+        for (int k = 1; k < 32; ++k) s1 += red[0][k][cl], s2 += red[1][k][cl];
         const bool live = c < Ctrue;
         if (live) dbeta[c] = (float)s1, dgamma[c] = (float)s2;
         const float k1 = live ? gamma[c] * rstd[c] : 0.f;
@@ -780,7 +985,7 @@ extern "C" int otp_nhwc_conv_bf16(const void* x, const void* wpacked, const void
 #define OTP_NHWC_CASE(mb, nb) \
     if (p.MB == mb && p.NB == nb) return launch_conv<mb, nb>(p, x, wpacked, bias, out, stats, st)
     OTP_NHWC_CASE(1, 2); OTP_NHWC_CASE(2, 2); OTP_NHWC_CASE(3, 2); OTP_NHWC_CASE(4, 2); OTP_NHWC_CASE(5, 2); OTP_NHWC_CASE(6, 2);
-    OTP_NHWC_CASE(1, 4); OTP_NHWC_CASE(2, 4); OTP_NHWC_CASE(3, 4);
+    OTP_NHWC_CASE(1, 4); OTP_NHWC_CASE(2, 4); OTP_NHWC_CASE(3, 4); OTP_NHWC_CASE(4, 4); OTP_NHWC_CASE(5, 4); OTP_NHWC_CASE(6, 4);
 #undef OTP_NHWC_CASE
     return OTP_ERR_UNSUPPORTED;
 }
@@ -803,7 +1008,7 @@ extern "C" int otp_nhwc_wgrad_bf16(const void* x, const void* gy, void* grad_wei
     nhwc_wgrad_kernel<<<p.nCo * p.nCi * p.splits, 256, p.lds, st>>>(static_cast<const bf16*>(x), static_cast<const bf16*>(gy),
                                                                      static_cast<float*>(workspace), p);
     if (otp_launch_status() != OTP_OK) return OTP_ERR_LAUNCH;
-    nhwc_wgrad_reduce_kernel<<<(int)((n + 255) / 256), 256, 0, st>>>(static_cast<const float*>(workspace),
+    nhwc_wgrad_reduce_kernel<<<(int)((n + 63) / 64), 256, 0, st>>>(static_cast<const float*>(workspace),
                                                                       static_cast<float*>(grad_weight), p.splits, n);
     return otp_launch_status();
 }
@@ -813,7 +1018,7 @@ extern "C" int otp_nhwc_bn_finalize(const void* partials, int rows, int C, int C
                                     void* running_var, float eps, float momentum, void* stream) {
     if (!partials || !gamma || !beta || !mean || !rstd || !scale || !shift || rows <= 0 || C <= 0 || CS < C)
         return OTP_ERR_BAD_ARG;
-    bn_finalize_kernel<<<(CS + 15) / 16, 256, 0, static_cast<hipStream_t>(stream)>>>(
+    bn_finalize_kernel<<<(CS + 7) / 8, 256, 0, static_cast<hipStream_t>(stream)>>>(
         static_cast<const float*>(partials), rows, CS, C, count, static_cast<const float*>(gamma), static_cast<const float*>(beta),
         static_cast<float*>(mean), static_cast<float*>(rstd), static_cast<float*>(scale), static_cast<float*>(shift),
         static_cast<float*>(running_mean), static_cast<float*>(running_var), eps, momentum);
@@ -831,8 +1036,10 @@ extern "C" int otp_nhwc_bn_apply(const void* x, const void* scale, const void* s
 }
 
 static int bn_bwd_rows(size_t pixels, int* pixPerWg) {
-    int rows = (int)((pixels + 1023) / 1024);
-    if (rows > 2048) rows = 2048;
+    // a workgroup strides its pixel range with 256 / (C/8) pixel lanes: 64-pixel ranges still give every lane several
+    // pixels at 384 channels, and the small maps (12x9 x 80 frames = 8640 pixels) still fill the chip
+    int rows = (int)((pixels + 63) / 64);
+    if (rows > 1024) rows = 1024;
     if (rows < 1) rows = 1;
     *pixPerWg = (int)((pixels + rows - 1) / rows);
     return (int)((pixels + *pixPerWg - 1) / *pixPerWg);
@@ -862,7 +1069,7 @@ extern "C" int otp_nhwc_bn_backward(const void* gy, const void* y, const void* x
     bn_bwd_reduce_kernel<<<rows, 256, lds, st>>>(static_cast<const bf16*>(gy), static_cast<const bf16*>(y),
                                                  static_cast<const bf16*>(x), static_cast<const float*>(mean),
                                                  static_cast<const float*>(rstd), part, pixels, C8, ppw, relu);
-    bn_bwd_finalize_kernel<<<(CS + 15) / 16, 256, 0, st>>>(part, rows, CS, C, (float)pixels, static_cast<const float*>(gamma),
+    bn_bwd_finalize_kernel<<<(CS + 7) / 8, 256, 0, st>>>(part, rows, CS, C, (float)pixels, static_cast<const float*>(gamma),
                                                            static_cast<const float*>(rstd), static_cast<float*>(dgamma),
                                                            static_cast<float*>(dbeta), coef);
     const size_t units = pixels * C8;
@@ -912,3 +1119,9 @@ extern "C" int otp_nhwc_dilate(const void* in, void* out, int N, int Hi, int Wi,
         static_cast<const bf16*>(in), static_cast<bf16*>(out), N, Hi, Wi, s, H, W, CS / 8);
     return otp_launch_status();
 }
+
+#ifdef OTP_NHWC_TIMING
+extern "C" int otp_nhwc_read_stamps(void* host_out, size_t bytes) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(otp_nhwc_stamps), bytes) == hipSuccess ? OTP_OK : OTP_ERR_LAUNCH;
+}
+#endif

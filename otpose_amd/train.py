@@ -18,6 +18,7 @@ import math
 import torch
 from torch.autograd import Function
 
+from . import bf16_ops as B16
 from . import hip, ops
 from . import train_ops as T
 
@@ -226,7 +227,7 @@ class TrainGraph:
                 q = f"{p}.fuse_layers.{i}.{j}"
                 if j > i:
                     low = self.conv_bn(q + ".0", q + ".1", xs[j], 1, 0, False)
-                    y = UpsampleAddFunction.apply(low, y, 2 ** (j - i), last)
+                    y = self.upsample_add(low, y, 2 ** (j - i), last)
                 else:
                     t = xs[j]
                     for k in range(i - j - 1):
@@ -235,6 +236,16 @@ class TrainGraph:
                     y = self.conv_bn(f"{q}.{k}.0", f"{q}.{k}.1", t, 2, 1, relu=last, res=y)
             outs.append(y)
         return outs
+
+    def upsample_add(self, low, y, f, relu):
+        return UpsampleAddFunction.apply(low, y, f, relu)
+
+    def hrnet_input(self, x):
+        """(B, 15, H, W) clip -> the backbone's (5B, 3, H, W) batch (model/OTPose.py:317)."""
+        return torch.cat(x.split(3, dim=1), 0).contiguous()
+
+    def hrnet_output(self, p, y):
+        return self.conv(p, y)
 
     def hrnet(self, p, x):
         m = self.cfg["MODEL"]
@@ -265,7 +276,7 @@ class TrainGraph:
             for mi in range(nm):
                 n_out = 1 if (s == 4 and mi == nm - 1) else nb
                 ys = self.hr_module(f"{p}.stage{s}.{mi}", ys, n_out)
-        return self.conv(p + ".final_layer", ys[0])
+        return self.hrnet_output(p + ".final_layer", ys[0])
 
     # ---- ConvTransformer (model/blocks.py:264-280, 400-453; ConvVideoTransformer.py:123-184) ------------------------
     def layer_norm(self, p, x):
@@ -358,9 +369,8 @@ class TrainGraph:
         J = m["NUM_JOINTS"]
         pe_w, pe_h = m["HEATMAP_SIZE"]
         dils = list(m["DEFORMABLE_CONV"]["DILATION"])
-        x = torch.cat(x.split(3, dim=1), 0).contiguous()
-        B = x.shape[0] // 5
-        rough = self.hrnet("rough_pose_estimation_net", x)
+        B = x.shape[0]
+        rough = self.hrnet("rough_pose_estimation_net", self.hrnet_input(x))
         cur, prev, nxt, pprev, nnext = rough.split(B, dim=0)
         total_b = cur + prev + nxt + pprev + nnext
         squeezed = total_b.sum(1, keepdim=True).expand(-1, J, -1, -1).contiguous()
@@ -399,10 +409,41 @@ class TrainGraph:
         return out, rough, inter, prev_b, ctx, squeezed, total_b
 
 
+class TrainGraphBF16(TrainGraph):
+    """The same walk with the HRNet backbone (86 % of the FLOPs, model/HRNet.py:116-152) on the bf16 path of
+    :mod:`otpose_amd.bf16_ops`: NHWC bfloat16 activations, bf16 matrix-core convolutions with fp32 accumulation, fp32
+    BatchNorm statistics, fp32 master weights and weight gradients (BASELINE configs[2]).  The frames enter through one
+    layout / precision conversion that also performs the ``cat(split(3, 1), 0)`` of model/OTPose.py:317, and the final
+    1x1 layer hands fp32 NCHW heat-maps to the rest of the graph."""
+
+    def conv_bn(self, conv, bn, x, stride=1, pad=0, relu=False, res=None):
+        if x.dtype != B16.BF16:
+            return super().conv_bn(conv, bn, x, stride, pad, relu, res)
+        nbt = self.Bf.get(bn + ".num_batches_tracked")
+        if nbt is not None:
+            nbt += 1
+        return B16.conv_bn(x, self.P[conv + ".weight"], self.P[bn + ".weight"], self.P[bn + ".bias"], res,
+                           self.Bf[bn + ".running_mean"], self.Bf[bn + ".running_var"], stride, pad, relu, 0.1, 1e-5)
+
+    def upsample_add(self, low, y, f, relu):
+        if low.dtype != B16.BF16:
+            return super().upsample_add(low, y, f, relu)
+        return B16.upsample_add(low, y, f, relu)
+
+    def hrnet_input(self, x):
+        return B16.to_nhwc(x, frame_split=x.shape[0])
+
+    def hrnet_output(self, p, y):
+        return B16.conv_out(y, self.P[p + ".weight"], self.P.get(p + ".bias"))
+
+
 def forward_train(model, x, margin, taps=None):
     if not x.is_cuda:
         raise RuntimeError("OTPose training forward expects CUDA (HIP) tensors; there is no CPU path")
-    graph = TrainGraph(model)
+    dtype = getattr(model, "train_dtype", "f32")
+    if dtype not in ("f32", "bf16"):
+        raise ValueError(f"OTPose.train_dtype must be 'f32' or 'bf16', got {dtype!r}")
+    graph = (TrainGraphBF16 if dtype == "bf16" else TrainGraph)(model)
     graph.taps = taps
     return graph.forward(x, margin)
 

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--no-dropout", action="store_true")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="activation dtype of the backbone")
     ap.add_argument("--torch-optim", action="store_true", help="torch.optim.AdamW + clip_grad_norm_ instead of FusedAdamW")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -30,6 +31,7 @@ def main():
     S.fill_synthetic_(model)
     model = model.to(dev).train()
     model.train_dropout = not a.no_dropout
+    model.train_dtype = a.dtype
     x, margin = S.synthetic_clip(a.batch, cfg.MODEL.IMAGE_SIZE)
     x, margin = x.to(dev), margin.to(dev)
     J = cfg.MODEL.NUM_JOINTS
@@ -47,6 +49,7 @@ def main():
     def sync():
         torch.cuda.synchronize()
         return time.perf_counter()
+
 
     for it in range(a.steps + 1):
         torch.cuda.reset_peak_memory_stats()
