@@ -366,6 +366,16 @@ int otp_nchw_f32_to_nhwc_bf16(const void* in, void* out, int N, int C, int H, in
 int otp_nhwc_bf16_to_nchw_f32(const void* in, void* out, int N, int C, int H, int W, void* stream);
 int otp_nhwc_dilate(const void* in, void* out, int N, int Hi, int Wi, int s, int H, int W, int CS, void* stream);
 
+
+/* ---- TransformerBlock residual update in training (model/blocks.py:277-279 with AffineDropPath, :283-316):
+ * out = x + mask[b] * scale[c] * a on (B, C, T) fp32 tensors; `mask` (B floats: Bernoulli(keep) / keep) may be NULL.
+ * Backward: grad_a = mask[b]*scale[c]*grad_out, grad_scale[c] = sum_{b,t} mask[b]*a*grad_out (grad_x is grad_out). */
+int otp_scale_residual(const void* x, const void* a, const void* scale, const void* mask, void* out, int B, int C, int T,
+                       void* stream);
+size_t otp_scale_residual_backward_workspace(int B, int C, int T);
+int otp_scale_residual_backward(const void* grad_out, const void* a, const void* scale, const void* mask, void* grad_a,
+                                void* grad_scale, void* workspace, size_t workspace_bytes, int B, int C, int T, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

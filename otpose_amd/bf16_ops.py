@@ -16,6 +16,11 @@ from torch.autograd import Function
 from . import hip
 from .ops import _require_gpu
 
+
+def grad_slot(param):
+    from .train_ops import grad_slot as _gs
+    return _gs(param)
+
 BF16 = torch.bfloat16
 
 
@@ -128,7 +133,7 @@ def _workspace(device, nbytes):
     return buf
 
 
-def conv_wgrad(x, gy, weight_shape, stride, pad, dil):
+def conv_wgrad(x, gy, weight_shape, stride, pad, dil, out=None):
     cout, cin, kh, kw = weight_shape
     n, h, w, _ = x.shape
     d = _desc(n, h, w, cin, cout, kh, kw, stride, pad, dil, 0)
@@ -137,7 +142,7 @@ def conv_wgrad(x, gy, weight_shape, stride, pad, dil):
     if nbytes == 0:
         raise RuntimeError("otp_nhwc_wgrad: unsupported convolution shape")
     ws = _workspace(x.device, nbytes)
-    gw = _new(weight_shape, torch.float32, x)
+    gw = out if out is not None else _new(weight_shape, torch.float32, x)
     hip.check(L.otp_nhwc_wgrad_bf16(hip.ptr(x), hip.ptr(gy), hip.ptr(gw), hip.ptr(ws), nbytes, ctypes.byref(d),
                                     hip.stream_of(x)), "otp_nhwc_wgrad_bf16")
     return gw
@@ -162,7 +167,7 @@ def bn_apply(x, scale, shift, res, relu):
     return y
 
 
-def bn_backward(gy, y, x, mean, rstd, gamma, c, relu, want_res):
+def bn_backward(gy, y, x, mean, rstd, gamma, c, relu, want_res, out_gamma=None, out_beta=None):
     L = hip.lib()
     csz = x.shape[-1]
     pixels = x.numel() // csz
@@ -170,7 +175,8 @@ def bn_backward(gy, y, x, mean, rstd, gamma, c, relu, want_res):
     ws = _new(((nbytes + 3) // 4,), torch.float32, x)
     gx = torch.empty_like(x)
     gres = torch.empty_like(x) if want_res else None
-    dg, db = _new((c,), torch.float32, x), _new((c,), torch.float32, x)
+    dg = out_gamma if out_gamma is not None else _new((c,), torch.float32, x)
+    db = out_beta if out_beta is not None else _new((c,), torch.float32, x)
     hip.check(L.otp_nhwc_bn_backward(hip.ptr(gy), hip.ptr(y), hip.ptr(x), hip.ptr(mean), hip.ptr(rstd), hip.ptr(gamma),
                                      hip.ptr(gx), hip.ptr(gres), hip.ptr(dg), hip.ptr(db), hip.ptr(ws), nbytes, pixels, c, csz,
                                      int(relu), hip.stream_of(x)), "otp_nhwc_bn_backward")
@@ -193,6 +199,7 @@ class ConvBnFunction(Function):
         y = bn_apply(c, vec[2], vec[3], r, relu)
         ctx.save_for_backward(x, weight, gamma, c, y if relu else None, vec)
         ctx.cfg = (stride, pad, relu, res is not None)
+        ctx.params = (weight, gamma, beta)             # gradient slots are looked up at backward time
         return y
 
     @staticmethod
@@ -200,9 +207,11 @@ class ConvBnFunction(Function):
         x, weight, gamma, c, y, vec = ctx.saved_tensors
         stride, pad, relu, has_res = ctx.cfg
         gy = gy.contiguous()
-        gc, gres, dg, db = bn_backward(gy, y, c, vec[0], vec[1], gamma, weight.shape[0], relu, has_res)
+        pw, pg, pb = ctx.params
+        gc, gres, dg, db = bn_backward(gy, y, c, vec[0], vec[1], gamma, weight.shape[0], relu, has_res, grad_slot(pg),
+                                       grad_slot(pb))
         gx = conv_dgrad(gc, weight, x.shape[1:3], stride, pad, 1) if ctx.needs_input_grad[0] else None
-        gw = conv_wgrad(x, gc, weight.shape, stride, pad, 1) if ctx.needs_input_grad[1] else None
+        gw = conv_wgrad(x, gc, weight.shape, stride, pad, 1, grad_slot(pw)) if ctx.needs_input_grad[1] else None
         return gx, gw, dg, db, gres, None, None, None, None, None, None, None
 
 
@@ -222,6 +231,7 @@ class ConvOutFunction(Function):
         out, _, _ = conv_forward(x, weight, bias, stride, pad, dil, out_mode=1)
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, pad, dil, bias is not None)
+        ctx.params = (weight, bias)
         return out
 
     @staticmethod
@@ -232,8 +242,8 @@ class ConvOutFunction(Function):
         gy = gy.contiguous()
         g = to_nhwc(gy)
         gx = conv_dgrad(g, weight, x.shape[1:3], stride, pad, dil) if ctx.needs_input_grad[0] else None
-        gw = conv_wgrad(x, g, weight.shape, stride, pad, dil) if ctx.needs_input_grad[1] else None
-        gb = channel_sum(gy) if has_bias and ctx.needs_input_grad[2] else None
+        gw = conv_wgrad(x, g, weight.shape, stride, pad, dil, grad_slot(ctx.params[0])) if ctx.needs_input_grad[1] else None
+        gb = channel_sum(gy, grad_slot(ctx.params[1])) if has_bias and ctx.needs_input_grad[2] else None
         return gx, gw, gb, None, None, None
 
 

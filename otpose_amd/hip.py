@@ -127,6 +127,9 @@ SIGNATURES = {
     "otp_nchw_f32_to_nhwc_bf16": (c_int, [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
     "otp_nhwc_bf16_to_nchw_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
     "otp_nhwc_dilate": (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
+    "otp_scale_residual": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_void_p]),
+    "otp_scale_residual_backward_workspace": (c_size_t, [c_int] * 3),
+    "otp_scale_residual_backward": (c_int, [c_void_p] * 7 + [c_size_t] + [c_int] * 3 + [c_void_p]),
     "otp_loss_joints_mse": (c_int, [c_void_p] * 5 + [c_void_p, c_size_t] + [c_int] * 6 + [c_void_p]),
 }
 

@@ -50,6 +50,9 @@ class FusedAdamW(torch.optim.Optimizer):
                 if p.grad is not None:
                     fg[off:off + n].copy_(p.grad.reshape(-1))
                 p.grad = fg[off:off + n].view_as(p)
+                # destination of this parameter's gradient inside the flat buffer: the backward kernels of otpose_amd write
+                # there directly (grad_slot() below), so autograd neither allocates nor accumulates per-parameter tensors
+                p._otp_grad_slot = p.grad
                 self.state[p] = {"step": 0, "exp_avg": fm[off:off + n].view_as(p), "exp_avg_sq": fv[off:off + n].view_as(p)}
                 off += n
             self._flat.append({"p": fp, "g": fg, "m": fm, "v": fv, "params": ps, "step": 0})
@@ -83,10 +86,15 @@ class FusedAdamW(torch.optim.Optimizer):
         return [f["g"] for f in self._flat if f]
 
     def zero_grad(self, set_to_none: bool = False):
-        # gradients live in the flat buffers: dropping them (set_to_none) would detach the views
+        """One memset per group.  ``p.grad`` is dropped so that the next backward hands each parameter its gradient
+        exactly once: the otpose_amd backward kernels write straight into the parameter's slot of the flat buffer and return
+        that view (autograd adopts it - no allocation, no ``grad += new`` launch per parameter, ~2000 tiny kernels per step
+        at W48); gradients that arrive as ordinary tensors are copied into their slot by step() / flat_grads()."""
         for f in self._flat:
             if f:
                 f["g"].zero_()
+                for p in f["params"]:
+                    p.grad = None
 
     @torch.no_grad()
     def grad_norm(self):

@@ -168,8 +168,15 @@ class TrainGraph:
         self.taps = None                      # dict -> forward() records named intermediates (tools/grad_noise.py)
         self.stochastic = bool(getattr(model, "train_dropout", True))
         self.mods = dict(model.named_modules())
+        self._nbt = []
 
     # ---- conv / BN helpers ------------------------------------------------------------------------------------
+    def count_batch(self, bn):
+        """``num_batches_tracked += 1`` of every BatchNorm2d, applied in one batched launch at the end of forward()."""
+        nbt = self.Bf.get(bn + ".num_batches_tracked")
+        if nbt is not None:
+            self._nbt.append(nbt)
+
     def has(self, name):
         return name in self.P
 
@@ -177,9 +184,7 @@ class TrainGraph:
         return T.conv2d(x, self.P[p + ".weight"], self.P.get(p + ".bias"), stride, pad, dil)
 
     def bn(self, p, x, res=None, relu=False):
-        nbt = self.Bf.get(p + ".num_batches_tracked")
-        if nbt is not None:
-            nbt += 1
+        self.count_batch(p)
         return T.batch_norm_relu(x, self.P[p + ".weight"], self.P[p + ".bias"], res, self.Bf[p + ".running_mean"],
                                  self.Bf[p + ".running_var"], 0.1, 1e-5, relu)
 
@@ -188,7 +193,12 @@ class TrainGraph:
 
     def conv1d(self, p, x):
         """nn.Conv1d(k=1) on (B, C, T)."""
-        return T.conv2d(x.unsqueeze(2), self.P[p + ".weight"].unsqueeze(-1), self.P.get(p + ".bias"), 1, 0, 1).squeeze(2)
+        w = self.P[p + ".weight"]
+        w4 = w.unsqueeze(-1)
+        slot = getattr(w, "_otp_grad_slot", None)
+        if slot is not None:                      # the (Cout, Cin, 1, 1) view writes its gradient into the parameter's slot
+            w4._otp_grad_slot, w4._otp_grad_owner = slot.unsqueeze(-1), w
+        return T.conv2d(x.unsqueeze(2), w4, self.P.get(p + ".bias"), 1, 0, 1).squeeze(2)
 
     # ---- HRNet (model/HRNet.py:116-152, 478-496, 514-571) -------------------------------------------------------
     def basic_block(self, p, x):
@@ -300,23 +310,22 @@ class TrainGraph:
             return torch.nn.functional.dropout(x, rate, True)
         return x
 
-    def drop_path(self, x, rate):
-        """blocks.py:303-316: one Bernoulli(keep) draw per sample, survivors scaled by 1/keep."""
+    def drop_path_mask(self, x, rate):
+        """blocks.py:303-316: one Bernoulli(keep) draw per sample, survivors scaled by 1/keep -> (B,) factors, or None."""
         if not (self.stochastic and rate > 0.0):
-            return x
+            return None
         keep = 1.0 - rate
-        mask = (keep + torch.rand((x.shape[0],) + (1,) * (x.dim() - 1), dtype=x.dtype, device=x.device)).floor_()
-        return x.div(keep) * mask
+        return (keep + torch.rand((x.shape[0],), dtype=x.dtype, device=x.device)).floor_().div_(keep)
 
     def tblock(self, p, x, n_head, stride):
         a = self.mhca(p + ".attn", self.layer_norm(p + ".ln1", x), n_head, stride)
         skip = x if stride == 1 else T.maxpool3s2(x)
         blk = self.mods[p]
-        y = skip + self.drop_path(self.P[p + ".drop_path_attn.scale"] * a, blk.path_pdrop)
+        y = T.scale_residual(skip, a, self.P[p + ".drop_path_attn.scale"], self.drop_path_mask(a, blk.path_pdrop))
         h = self.conv1d(p + ".mlp.0", self.layer_norm(p + ".ln2", y))
         h = self.conv1d(p + ".mlp.3", self.dropout(T.gelu(h), blk.proj_pdrop))
         h = self.dropout(h, blk.proj_pdrop)
-        return y + self.drop_path(self.P[p + ".drop_path_mlp.scale"] * h, blk.path_pdrop)
+        return T.scale_residual(y, h, self.P[p + ".drop_path_mlp.scale"], self.drop_path_mask(h, blk.path_pdrop))
 
     def conv_transformer(self, p, x4, n_head, arch):
         b, c, h, w = x4.shape
@@ -406,6 +415,9 @@ class TrainGraph:
             out = (1.0 / len(dils)) * wrp if out is None else out + (1.0 / len(dils)) * wrp
             if self.taps is not None:
                 self.taps.update({f"off{i}": off, f"msk{i}": msk, f"wrp{i}": wrp})
+        if self._nbt:
+            torch._foreach_add_(self._nbt, 1)
+            self._nbt = []
         return out, rough, inter, prev_b, ctx, squeezed, total_b
 
 
@@ -419,9 +431,7 @@ class TrainGraphBF16(TrainGraph):
     def conv_bn(self, conv, bn, x, stride=1, pad=0, relu=False, res=None):
         if x.dtype != B16.BF16:
             return super().conv_bn(conv, bn, x, stride, pad, relu, res)
-        nbt = self.Bf.get(bn + ".num_batches_tracked")
-        if nbt is not None:
-            nbt += 1
+        self.count_batch(bn)
         return B16.conv_bn(x, self.P[conv + ".weight"], self.P[bn + ".weight"], self.P[bn + ".bias"], res,
                            self.Bf[bn + ".running_mean"], self.Bf[bn + ".running_var"], stride, pad, relu, 0.1, 1e-5)
 

@@ -18,6 +18,19 @@ from .ops import (ACT_NONE, View, _check_f32, _require_gpu, conv2d_launch, conv2
                   pack_conv_weight, pack_wino_weight, wino_supported)
 
 
+def grad_slot(param):
+    """Where the gradient of ``param`` should be written: its slot inside the optimizer's flat gradient buffer
+    (:class:`otpose_amd.optim.FusedAdamW`, zero-filled by ``zero_grad``) when this is the first gradient of the step,
+    else None (the caller allocates; autograd accumulates as usual)."""
+    slot = getattr(param, "_otp_grad_slot", None)
+    owner = getattr(param, "_otp_grad_owner", param)        # a reshaped view of a parameter names its owner (TrainGraph.conv1d)
+    if slot is None or owner.grad is not None or slot.shape != param.shape:
+        return None
+    # a fresh tensor object over the same memory: autograd adopts an incoming gradient without cloning it only when nobody
+    # else holds a reference to that tensor object
+    return slot.view(slot.shape)
+
+
 def _out_hw(h, w, k, stride, pad, dil):
     return (h + 2 * pad - (dil * (k - 1) + 1)) // stride + 1, (w + 2 * pad - (dil * (k - 1) + 1)) // stride + 1
 
@@ -105,9 +118,10 @@ def _workspace(device, nbytes):
     return buf
 
 
-def conv2d_grad_weight(x, grad_out, weight_shape, stride, pad, dil):
+def conv2d_grad_weight(x, grad_out, weight_shape, stride, pad, dil, out=None):
+    """``out``: a zero-filled (Cout, Cin, kh, kw) destination (the kernel accumulates), e.g. a :func:`grad_slot`."""
     cout, cin, kh, kw = weight_shape
-    gw = torch.zeros(weight_shape, dtype=torch.float32, device=x.device)
+    gw = out if out is not None else torch.zeros(weight_shape, dtype=torch.float32, device=x.device)
     x, g = x.contiguous(), grad_out.contiguous()
     L = hip.lib()
     nbytes = L.otp_conv2d_wgrad_workspace(cin, cout)
@@ -118,13 +132,14 @@ def conv2d_grad_weight(x, grad_out, weight_shape, stride, pad, dil):
     return gw
 
 
-def channel_sum(t):
+def channel_sum(t, out=None):
     """Per-channel sum over (N, H, W) of a contiguous (N, C, H, W) tensor (bias gradients)."""
     n, c, h, w = t.shape
     L = hip.lib()
     nbytes = L.otp_bn_workspace(n, c, h * w) + 4 * c
     ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=t.device)
-    out = torch.empty(c, dtype=torch.float32, device=t.device)
+    if out is None:
+        out = torch.empty(c, dtype=torch.float32, device=t.device)
     hip.check(L.otp_channel_sum(hip.ptr(t), hip.ptr(out), hip.ptr(ws), nbytes, n, c, h * w, c, 0, hip.stream_of(t)),
               "otp_channel_sum")
     return out
@@ -140,16 +155,19 @@ class Conv2dFunction(Function):
         x, weight = x.contiguous(), weight.contiguous()
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, pad, dil, bias is not None)
+        ctx.params = (weight, bias)                    # gradient slots are looked up at backward time
         return conv2d_forward(x, weight, bias, stride, pad, dil)
 
     @staticmethod
     def backward(ctx, grad_out):
         x, weight = ctx.saved_tensors
         stride, pad, dil, has_bias = ctx.cfg
+        pw, pb = ctx.params
         grad_out = grad_out.contiguous()
         gx = conv2d_grad_input(grad_out, weight, x.shape, stride, pad, dil) if ctx.needs_input_grad[0] else None
-        gw = conv2d_grad_weight(x, grad_out, weight.shape, stride, pad, dil) if ctx.needs_input_grad[1] else None
-        gb = channel_sum(grad_out) if has_bias and ctx.needs_input_grad[2] else None
+        gw = (conv2d_grad_weight(x, grad_out, weight.shape, stride, pad, dil, grad_slot(pw))
+              if ctx.needs_input_grad[1] else None)
+        gb = channel_sum(grad_out, grad_slot(pb)) if has_bias and ctx.needs_input_grad[2] else None
         return gx, gw, gb, None, None, None
 
 
@@ -180,6 +198,7 @@ class BatchNormReluFunction(Function):
                   "otp_bn_train_forward")
         ctx.save_for_backward(x, gamma, mean, rstd, y if relu else None)
         ctx.has_res = res is not None
+        ctx.params = (gamma, beta)
         return y
 
     @staticmethod
@@ -192,8 +211,9 @@ class BatchNormReluFunction(Function):
         ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=x.device)
         gx = torch.empty_like(x)
         gres = torch.empty_like(x) if ctx.has_res else None
-        gg = torch.empty(c, dtype=torch.float32, device=x.device)
-        gb = torch.empty(c, dtype=torch.float32, device=x.device)
+        sg, sb = grad_slot(ctx.params[0]), grad_slot(ctx.params[1])
+        gg = sg if sg is not None else torch.empty(c, dtype=torch.float32, device=x.device)
+        gb = sb if sb is not None else torch.empty(c, dtype=torch.float32, device=x.device)
         hip.check(L.otp_bn_train_backward(hip.ptr(grad_y), hip.ptr(x), hip.ptr(y), hip.ptr(mean), hip.ptr(rstd),
                                           hip.ptr(gamma), hip.ptr(gx), hip.ptr(gres), hip.ptr(gg), hip.ptr(gb),
                                           hip.ptr(ws), nbytes, n, c, h * w, c, 0, c, 0, c, 0, hip.stream_of(x)),
@@ -228,6 +248,7 @@ class LayerNormFunction(Function):
                                            hip.stream_of(x)), "otp_ln_channel")
         ctx.save_for_backward(x, g)
         ctx.eps, ctx.pshape = eps, gamma.shape
+        ctx.params = (gamma, beta)
         return y
 
     @staticmethod
@@ -241,7 +262,9 @@ class LayerNormFunction(Function):
             # dx, dgamma and dbeta from one pass over x and dy
             gx = torch.empty_like(x)
             ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
-            gg, gb = torch.empty(c, dtype=torch.float32, device=x.device), torch.empty(c, dtype=torch.float32, device=x.device)
+            sg, sb = grad_slot(ctx.params[0]), grad_slot(ctx.params[1])
+            gg = sg if sg is not None else torch.empty(c, dtype=torch.float32, device=x.device)
+            gb = sb if sb is not None else torch.empty(c, dtype=torch.float32, device=x.device)
             hip.check(L.otp_ln_channel_backward_params(hip.ptr(x), hip.ptr(gy), hip.ptr(g), hip.ptr(gx), hip.ptr(gg), hip.ptr(gb),
                                                        hip.ptr(ws), nbytes, b, c, t, ctx.eps, hip.stream_of(x)),
                       "otp_ln_channel_backward_params")
@@ -270,13 +293,15 @@ class DwConv3Function(Function):
                   "otp_dwconv3_forward")
         ctx.save_for_backward(x, w)
         ctx.stride = stride
+        ctx.params = (w,)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
         b, c, t = x.shape
-        gx, gw = torch.empty_like(x), torch.zeros_like(w)
+        sw = grad_slot(ctx.params[0])                      # zero-filled by the optimizer's zero_grad; the kernel accumulates
+        gx, gw = torch.empty_like(x), (sw if sw is not None else torch.zeros_like(w))
         hip.check(hip.lib().otp_dwconv3_backward(hip.ptr(x), hip.ptr(w), hip.ptr(gy.contiguous()), hip.ptr(gx), hip.ptr(gw),
                                                  b, c, t, ctx.stride, hip.stream_of(x)), "otp_dwconv3_backward")
         return gx, gw, None
@@ -418,3 +443,42 @@ class ChanAttnFunction(Function):
 
 def chan_attn(q, k, v, n_head, scale):
     return ChanAttnFunction.apply(q, k, v, n_head, scale)
+
+
+class ScaleResidualFunction(Function):
+    """``x + drop_path(scale * a)`` of a TransformerBlock (model/blocks.py:277-279, AffineDropPath :283-316): ``scale`` is the
+    (1, C, 1) AffineDropPath parameter, ``mask`` (B,) the per-sample Bernoulli(keep) / keep factors (None: no drop-path)."""
+
+    @staticmethod
+    def forward(ctx, x, a, scale, mask):
+        _require_gpu(x, a, scale)
+        _check_f32(x, a)
+        x, a = x.contiguous(), a.contiguous()
+        b, c, t = x.shape
+        sc = scale.reshape(-1).contiguous()
+        out = torch.empty_like(x)
+        hip.check(hip.lib().otp_scale_residual(hip.ptr(x), hip.ptr(a), hip.ptr(sc), hip.ptr(mask), hip.ptr(out), b, c, t,
+                                               hip.stream_of(x)), "otp_scale_residual")
+        ctx.save_for_backward(a, sc, mask)
+        ctx.pshape = scale.shape
+        ctx.params = (scale,)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, sc, mask = ctx.saved_tensors
+        g = g.contiguous()
+        b, c, t = a.shape
+        L = hip.lib()
+        nbytes = L.otp_scale_residual_backward_workspace(b, c, t)
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=a.device)
+        ga = torch.empty_like(a)
+        ss = grad_slot(ctx.params[0])
+        gs = ss if ss is not None else torch.empty(c, dtype=torch.float32, device=a.device)
+        hip.check(L.otp_scale_residual_backward(hip.ptr(g), hip.ptr(a), hip.ptr(sc), hip.ptr(mask), hip.ptr(ga), hip.ptr(gs),
+                                                hip.ptr(ws), nbytes, b, c, t, hip.stream_of(a)), "otp_scale_residual_backward")
+        return g, ga, gs.reshape(ctx.pshape), None
+
+
+def scale_residual(x, a, scale, mask=None):
+    return ScaleResidualFunction.apply(x, a, scale, mask)

@@ -39,7 +39,7 @@ def test_fused_adamw_matches_torch(max_norm):
         for a, b in zip(ref.parameters(), dut.parameters()):
             g = torch.randn(a.shape, generator=gen) * (0.1 if a.dim() > 1 else 1e-3)
             a.grad = g.clone()
-            b.grad.copy_(g)                                  # the flat-buffer view stays in place
+            b.grad = g.cuda()                                # an ordinary tensor: step() copies it into the flat slot
         if max_norm > 0:
             total = torch.nn.utils.clip_grad_norm_(ref.parameters(), max_norm)
             assert abs(float(o_dut.grad_norm()) - float(total)) <= 1e-5 * float(total)

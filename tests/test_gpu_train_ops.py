@@ -199,3 +199,25 @@ def test_chan_attn_backward(c, nh, t):
         att = F.softmax((qq * scale) @ kk.transpose(-2, -1), dim=-1)
         return (att @ vv).transpose(2, 3).contiguous().view(b, c, -1)
     _check_op(ref, lambda q, k, v: T.chan_attn(q, k, v, nh, scale), [q, k, v], 2e-4)
+
+
+@pytest.mark.parametrize("b,c,t,masked", [(3, 136, 432, True), (2, 17, 55, False), (4, 136, 6912, True)])
+def test_scale_residual_matches_autograd(b, c, t, masked):
+    """x + drop_path(scale * a) (blocks.py:277-279, 283-316) as one fused op vs the same expression in torch."""
+    from otpose_amd import train_ops as T
+    x, a = seeded((b, c, t), 1), seeded((b, c, t), 2)
+    scale = seeded((1, c, 1), 3) * 0.5
+    g = seeded((b, c, t), 4)
+    mask = torch.tensor([0.0, 1 / 0.9, 1 / 0.9, 0.0][:b]) if masked else None
+    xr, ar, sr = x.clone().requires_grad_(), a.clone().requires_grad_(), scale.clone().requires_grad_()
+    y = sr * ar
+    if masked:
+        y = y * mask.view(b, 1, 1)
+    (xr + y).backward(g)
+    xd, ad, sd = x.cuda().requires_grad_(), a.cuda().requires_grad_(), scale.cuda().requires_grad_()
+    out = T.scale_residual(xd, ad, sd, mask.cuda() if masked else None)
+    out.backward(g.cuda())
+    _close(out, (xr + y).detach())
+    _close(xd.grad, xr.grad)
+    _close(ad.grad, ar.grad)
+    _close(sd.grad, sr.grad, 1e-4)
