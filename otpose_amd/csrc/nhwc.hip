@@ -404,7 +404,8 @@ int launch_conv(const ConvPlan& p, const void* x, const void* wpk, const void* b
 // ---------------------------------------------------------------------------------------------------------------------
 // weight gradient
 // ---------------------------------------------------------------------------------------------------------------------
-// A workgroup owns (co block of up to 48) x (ci block of up to 48) x all taps and a contiguous range of pixel tiles of
+// A workgroup owns (co block of up to 48) x (ci block of 16*cbw channels: 48 for 3x3 kernels, up to 192 for 1x1) x all taps
+// and a contiguous range of pixel tiles of
 // TPX output pixels (TPX / 32 k-steps per staged tile); wave w owns N-blocks {w, w+4, ...} of the (tap, ci16) list for all
 // 3 co blocks.  The gy tile [TPX px][48 co] and the x window live in LDS as [pixel][channel]; a fragment is two
 // ds_read_b64_tr_b16 (4 pixels x 16 channels each).
@@ -412,7 +413,7 @@ struct WgradPlan {
     int N, H, W, CinS, Ho, Wo, CoutS, Cin, Cout, kh, kw, stride, pad, dil;
     int nCo, nCi, splits, tilesPerImg, tilesTotal, tilesPerSplit, TPX;
     int RW, rowsMax, XC, ldsG, ldsX, lds;
-    int nbTot;             // N-blocks per workgroup = taps * 3
+    int nbTot, cbw;        // N-blocks per workgroup = taps * cbw; cbw = 16-channel blocks of ci per workgroup (3 for 3x3 taps)
 };
 
 __device__ __forceinline__ bf16x4 tr_read(const bf16* p) {
@@ -422,6 +423,13 @@ __device__ __forceinline__ bf16x4 tr_read(const bf16* p) {
 
 constexpr int WG_NBW = 7;      // N-blocks per wave (27 = 9 taps x 3 ci blocks over 4 waves)
 
+constexpr int WG_GU = 3;       // gy units of 16 B per thread per tile (TPX * 6 / 256 at TPX = 128)
+constexpr int WG_XU = 10;      // x window units per thread per tile that the prefetch path holds in registers
+
+// PF = true: the loads of tile t+1 (gy tile + x window, at most WG_GU + WG_XU 16-byte units per thread) are issued right
+// after tile t has been written to LDS and complete under its MFMAs; the unit -> (row, column, channel group)
+// decomposition is computed once per thread.  PF = false: the general form (windows too large for the registers).
+template <bool PF>
 __global__ __launch_bounds__(256) void nhwc_wgrad_kernel(const bf16* __restrict__ x, const bf16* __restrict__ gy,
                                                           float* __restrict__ part, WgradPlan p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -431,9 +439,9 @@ __global__ __launch_bounds__(256) void nhwc_wgrad_kernel(const bf16* __restrict_
     int bid = blockIdx.x;
     const int split = bid % p.splits;
     bid /= p.splits;
+    const int blk = bid;
     const int cib = bid % p.nCi, cob = bid / p.nCi;
-    const int co0 = cob * 48, ci0 = cib * 48;
-    const int taps = p.kh * p.kw;
+    const int co0 = cob * 48, ci0 = cib * 16 * p.cbw;
     const int npx = p.Ho * p.Wo;
     const int TPX = p.TPX;
 
@@ -443,7 +451,7 @@ __global__ __launch_bounds__(256) void nhwc_wgrad_kernel(const bf16* __restrict_
     for (int i = 0; i < WG_NBW; ++i) {
         const int nb = wave + 4 * i;
         const int nbc = nb < p.nbTot ? nb : 0;
-        const int tap = nbc / 3, cb = nbc - tap * 3;
+        const int tap = nbc / p.cbw, cb = nbc - tap * p.cbw;
         const int dy = tap / p.kw, dx = tap - dy * p.kw;
         xoff[i] = ((dy * p.dil) * p.RW + dx * p.dil) * p.XC + cb * 16;
     }
@@ -455,72 +463,127 @@ __global__ __launch_bounds__(256) void nhwc_wgrad_kernel(const bf16* __restrict_
 
     // transpose-read addressing: within a 16-lane group, lane 4q+pp supplies row q (pixel), columns 4pp..4pp+3 (channels)
     const int q = l15 >> 2, pp = l15 & 3;
-    const int xcu = p.XC / 8;
+    const int xcu = p.XC / 8 - 1;                             // channel groups that carry data (the last 8 are zero padding)
     const int gunits = TPX * 6;
+    const int rowUnits = p.RW * xcu;
     const otp_rsrc xres = make_rsrc(x, (size_t)p.N * p.H * p.W * p.CinS * 2);
     const otp_rsrc gres = make_rsrc(gy, (size_t)p.N * npx * p.CoutS * 2);
 
-    const int t0 = split * p.tilesPerSplit, t1 = min(t0 + p.tilesPerSplit, p.tilesTotal);
-    for (int t = t0; t < t1; ++t) {
-        const int n = t / p.tilesPerImg, tile = t - n * p.tilesPerImg;
-        const int p0 = tile * TPX, p1 = min(p0 + TPX, npx);
-        const int oy0 = p0 / p.Wo, oy1 = (p1 - 1) / p.Wo;
-        const int rowLo = oy0 * p.stride - p.pad;
-        const int nrows = (oy1 - oy0) * p.stride + (p.kh - 1) * p.dil + 1;
-        __syncthreads();
-        // gy tile: TPX pixels x 48 channels (6 units of 16 B per pixel); pixels past the image and channels past CoutS are
-        // zero.  Loads are batched ahead of the LDS stores (see nhwc_conv_kernel).
-        for (int base = 0; base < gunits; base += 256 * 4) {
-            u32x4 v[4];
+    // the padding channel group of every window pixel is zero for the whole kernel
+    for (int i = tid; i < p.rowsMax * p.RW; i += 256)
+        *reinterpret_cast<u32x4*>(sX + (size_t)i * p.XC + xcu * 8) = u32x4{0u, 0u, 0u, 0u};
+
+    struct Geom {
+        int n, p0, p1, oy0, rowLo, nrows;
+    };
+    auto geom = [&](int t) {
+        Geom g;
+        g.n = t / p.tilesPerImg;
+        const int tile = t - g.n * p.tilesPerImg;
+        g.p0 = tile * TPX;
+        g.p1 = min(g.p0 + TPX, npx);
+        g.oy0 = g.p0 / p.Wo;
+        const int oy1 = (g.p1 - 1) / p.Wo;
+        g.rowLo = g.oy0 * p.stride - p.pad;
+        g.nrows = (oy1 - g.oy0) * p.stride + (p.kh - 1) * p.dil + 1;
+        return g;
+    };
+
+    // per-thread unit decomposition (tile independent)
+    int gpx[WG_GU], gcg[WG_GU];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int u = base + j * 256 + tid;
-                const int px = u / 6, cg = u - px * 6;
-                const bool ok = u < gunits && p0 + px < p1 && co0 + cg * 8 < p.CoutS;
-                v[j] = bload16(gres, ok ? ((n * npx + p0 + px) * p.CoutS + co0 + cg * 8) * 2 : OOB);
-            }
+    for (int j = 0; j < WG_GU; ++j) {
+        const int u = j * 256 + tid;
+        gpx[j] = u / 6;
+        gcg[j] = u - gpx[j] * 6;
+    }
+    int xu[PF ? WG_XU : 1];                                   // packed (row << 20 | column << 4 | channel group)
+    if constexpr (PF) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int u = base + j * 256 + tid;
-                const int px = u / 6, cg = u - px * 6;
-                if (u < gunits) *reinterpret_cast<u32x4*>(sG + px * 56 + cg * 8) = v[j];
+        for (int j = 0; j < WG_XU; ++j) {
+            const int u = j * 256 + tid;
+            const int r = u / rowUnits, ur = u - r * rowUnits;
+            const int col = ur / xcu, cg = ur - col * xcu;
+            xu[j] = (r << 20) | (col << 4) | cg;
+        }
+    }
+    u32x4 gv[WG_GU], xv[PF ? WG_XU : 1];
+    auto load_g = [&](const Geom& g) {
+#pragma unroll
+        for (int j = 0; j < WG_GU; ++j) {
+            const bool ok = j * 256 + tid < gunits && g.p0 + gpx[j] < g.p1 && co0 + gcg[j] * 8 < p.CoutS;
+            gv[j] = bload16(gres, ok ? ((g.n * npx + g.p0 + gpx[j]) * p.CoutS + co0 + gcg[j] * 8) * 2 : OOB);
+        }
+    };
+    auto load_x = [&](const Geom& g) {
+        if constexpr (PF) {
+#pragma unroll
+            for (int j = 0; j < WG_XU; ++j) {
+                const int r = xu[j] >> 20, col = (xu[j] >> 4) & 0xffff, cg = xu[j] & 15;
+                const int iy = g.rowLo + r, ix = col - p.pad, c = ci0 + cg * 8;
+                const bool ok = r < g.nrows && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && c < p.CinS;
+                xv[j] = bload16(xres, ok ? (((g.n * p.H + iy) * p.W + ix) * p.CinS + c) * 2 : OOB);
             }
         }
-        // x window: rows x RW columns x the ci block's channels (+ zero padding channels); thread = (column, channel group),
-        // 8 rows in flight (see nhwc_conv_kernel)
-        const int rowUnits = p.RW * xcu;
-        for (int sub = 0; sub * 256 < rowUnits; ++sub) {
-            const int cu = sub * 256 + tid;
-            const int col = cu / xcu, cg = cu - col * xcu;
-            const int ix = col - p.pad, c = ci0 + cg * 8;
-            const bool colOK = cu < rowUnits && cg < 6 && ix >= 0 && ix < p.W && c < p.CinS;
-            const int gcol = (ix * p.CinS + c) * 2, ldst = col * p.XC + cg * 8;
-            for (int r0 = 0; r0 < nrows; r0 += 8) {
+    };
+
+    OTP_STAMP(0);
+    const int t0 = split * p.tilesPerSplit, t1 = min(t0 + p.tilesPerSplit, p.tilesTotal);
+    Geom g = geom(t0);
+    load_g(g);
+    load_x(g);
+    for (int t = t0; t < t1; ++t) {
+        __syncthreads();                                        // the previous tile's fragments have been read
+        if (t == t0) OTP_STAMP(1);
+#pragma unroll
+        for (int j = 0; j < WG_GU; ++j)
+            if (j * 256 + tid < gunits) *reinterpret_cast<u32x4*>(sG + gpx[j] * 56 + gcg[j] * 8) = gv[j];
+        if constexpr (PF) {
+#pragma unroll
+            for (int j = 0; j < WG_XU; ++j) {
+                const int r = xu[j] >> 20, col = (xu[j] >> 4) & 0xffff, cg = xu[j] & 15;
+                if (r < g.nrows) *reinterpret_cast<u32x4*>(sX + (r * p.RW + col) * p.XC + cg * 8) = xv[j];
+            }
+        } else {
+            // general form: flat (row, column, channel group) units, 8 loads in flight per thread
+            const int xunits = g.nrows * rowUnits;
+            for (int base = 0; base < xunits; base += 256 * 8) {
                 u32x4 v[8];
+                int dst[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const int iy = rowLo + r0 + j;
-                    const bool ok = colOK && r0 + j < nrows && iy >= 0 && iy < p.H;
-                    v[j] = bload16(xres, ok ? (n * p.H + iy) * (p.W * p.CinS * 2) + gcol : OOB);
+                    const int u = base + j * 256 + tid;
+                    const int r = u / rowUnits, ur = u - r * rowUnits;
+                    const int col = ur / xcu, cg = ur - col * xcu;
+                    const int iy = g.rowLo + r, ix = col - p.pad, c = ci0 + cg * 8;
+                    dst[j] = u < xunits ? (r * p.RW + col) * p.XC + cg * 8 : -1;
+                    const bool ok = u < xunits && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && c < p.CinS;
+                    v[j] = bload16(xres, ok ? (((g.n * p.H + iy) * p.W + ix) * p.CinS + c) * 2 : OOB);
                 }
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    if (cu < rowUnits && r0 + j < nrows)
-                        *reinterpret_cast<u32x4*>(sX + (r0 + j) * (p.RW * p.XC) + ldst) = v[j];
+                    if (dst[j] >= 0) *reinterpret_cast<u32x4*>(sX + dst[j]) = v[j];
             }
         }
         __syncthreads();
+        if (t == t0) OTP_STAMP(2);
+        const Geom gc = g;
+        if (t + 1 < t1) {                                       // next tile's loads fly under this tile's MFMAs
+            g = geom(t + 1);
+            load_g(g);
+            load_x(g);
+        }
         // k-steps of 32 pixels: lane group lg covers pixels 8*lg .. 8*lg+7 of the step (two transposed reads of 4 pixels)
         for (int k0 = 0; k0 < TPX; k0 += 32) {
-            if (p0 + k0 >= p1) break;                            // uniform: the rest of the tile is past the image
+            if (gc.p0 + k0 >= gc.p1) break;                      // uniform: the rest of the tile is past the image
             bf16x8 a[3];
             int xrow[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int px = k0 + 8 * lg + 4 * h + q;
-                const int pc = min(p0 + px, p1 - 1);             // rows past the tile pair with zero gy rows
+                const int pc = min(gc.p0 + px, gc.p1 - 1);       // rows past the tile pair with zero gy rows
                 const int oy = pc / p.Wo, ox = pc - oy * p.Wo;
-                xrow[h] = (((oy - oy0) * p.stride) * p.RW + ox * p.stride) * p.XC + 4 * pp;
+                xrow[h] = (((oy - gc.oy0) * p.stride) * p.RW + ox * p.stride) * p.XC + 4 * pp;
             }
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
@@ -537,42 +600,46 @@ __global__ __launch_bounds__(256) void nhwc_wgrad_kernel(const bf16* __restrict_
                 for (int m = 0; m < 3; ++m) acc[m][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], b, acc[m][i], 0, 0, 0);
             }
         }
+        if (t == t0) OTP_STAMP(3);
     }
-    // partial sums: part[split][co][ci][tap]  (co, ci relative to the true Cout / Cin; skipped past them)
+    OTP_STAMP(4);
+    // partial sums in FRAGMENT order, one 16-byte store per lane and accumulator tile (1 KB per wave instruction):
+    // part[split][block][wave][i][m][lane][4]; nhwc_wgrad_reduce_kernel maps them to (Cout, Cin, kh, kw)
+    f32x4* dst = reinterpret_cast<f32x4*>(part) + ((size_t)(split * p.nCo * p.nCi + blk) * 4 + wave) * (WG_NBW * 3 * 64);
 #pragma unroll
-    for (int i = 0; i < WG_NBW; ++i) {
-        const int nb = wave + 4 * i;
-        if (nb >= p.nbTot) continue;
-        const int tap = nb / 3, cb = nb - tap * 3;
-        const int ci = ci0 + cb * 16 + l15;
+    for (int i = 0; i < WG_NBW; ++i)
 #pragma unroll
-        for (int m = 0; m < 3; ++m)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int co = co0 + m * 16 + lg * 4 + r;
-                if (co < p.Cout && ci < p.Cin)
-                    part[(((size_t)split * p.Cout + co) * p.Cin + ci) * taps + tap] = acc[m][i][r];
-            }
-    }
+        for (int m = 0; m < 3; ++m) dst[(i * 3 + m) * 64 + lane] = acc[m][i];
+    OTP_STAMP(5);
 }
 
-// gw[i] = sum over splits of part[k][i]: 64 elements x 4 split lanes per workgroup, 8 loads in flight per thread
-__global__ __launch_bounds__(256) void nhwc_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw, int splits,
+// gw[co][ci][tap] = sum over splits of the fragment-ordered partials: 64 weights x 4 split lanes per workgroup
+__global__ __launch_bounds__(256) void nhwc_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw, WgradPlan p,
                                                                  size_t n) {
     __shared__ float red[4][64];
     const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const size_t i = blockIdx.x * (size_t)64 + e;
     float s = 0.f;
     if (i < n) {
+        const int taps = p.kh * p.kw;
+        const int tap = (int)(i % taps);
+        const int ci = (int)((i / taps) % p.Cin), co = (int)(i / ((size_t)taps * p.Cin));
+        const int cw = 16 * p.cbw;
+        const int cob = co / 48, cib = ci / cw, cor = co - cob * 48, cir = ci - cib * cw;
+        const int nb = tap * p.cbw + cir / 16, wave = nb & 3, ii = nb >> 2;
+        const int m = cor >> 4, lg = (cor & 15) >> 2, r = cor & 3, lane = lg * 16 + (cir & 15);
+        const size_t blockStride = (size_t)4 * WG_NBW * 3 * 256;                       // floats per (split, block)
+        const size_t off = ((size_t)(cob * p.nCi + cib) * 4 + wave) * (WG_NBW * 3 * 256) + ((size_t)(ii * 3 + m) * 64 + lane) * 4 + r;
+        const size_t splitStride = blockStride * p.nCo * p.nCi;
         int k = sl;
-        for (; k + 28 < splits; k += 32) {
+        for (; k + 28 < p.splits; k += 32) {
             float v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = part[(size_t)(k + 4 * j) * n + i];
+            for (int j = 0; j < 8; ++j) v[j] = part[(size_t)(k + 4 * j) * splitStride + off];
 #pragma unroll
             for (int j = 0; j < 8; ++j) s += v[j];
         }
-        for (; k < splits; k += 4) s += part[(size_t)k * n + i];
+        for (; k < p.splits; k += 4) s += part[(size_t)k * splitStride + off];
     }
     red[sl][e] = s;
     __syncthreads();
@@ -584,21 +651,39 @@ bool make_wgrad_plan(const otp_nhwc_conv_desc* d, WgradPlan* p) {
     if (!make_plan(d, &c)) return false;
     p->N = c.N, p->H = c.H, p->W = c.W, p->CinS = c.CinS, p->Ho = c.Ho, p->Wo = c.Wo, p->CoutS = c.CoutS;
     p->Cin = c.Cin, p->Cout = c.Cout, p->kh = c.kh, p->kw = c.kw, p->stride = c.stride, p->pad = c.pad, p->dil = c.dil;
-    if (c.kh * c.kw * 3 > 4 * WG_NBW) return false;            // 1x1 and 3x3 kernels
-    p->nCo = (c.Cout + 47) / 48, p->nCi = (c.Cin + 47) / 48;
-    p->nbTot = c.kh * c.kw * 3;
+    const int taps = c.kh * c.kw;
+    if (taps * 1 > 4 * WG_NBW) return false;                   // up to 28 (tap, 16-channel) blocks per workgroup
+    // ci blocks of 16 channels per workgroup: fill the 28 N-block slots (3 for 3x3 kernels, up to 12 = 192 channels for 1x1)
+    int cbw = (4 * WG_NBW) / taps;
+    if (cbw > 12) cbw = 12;
+    if (cbw > (c.CinS + 15) / 16) cbw = (c.CinS + 15) / 16;
+    p->cbw = cbw;
+    p->nCo = (c.Cout + 47) / 48, p->nCi = (c.Cin + 16 * cbw - 1) / (16 * cbw);
+    p->nbTot = taps * cbw;
+    // a pointwise conv sees the image as rows of 128 / 64 / 32 pixels (when that divides it): a tile's window is then the
+    // tile itself instead of the full-width image rows it touches
+    if (taps == 1 && c.stride == 1 && c.pad == 0) {
+        const int npx1 = c.H * c.W;
+        for (int w1 = 128; w1 >= 32; w1 >>= 1)
+            if (npx1 % w1 == 0) {
+                p->W = p->Wo = c.W = c.Wo = w1;
+                p->H = p->Ho = c.H = c.Ho = npx1 / w1;
+                break;
+            }
+    }
     const int npx = c.Ho * c.Wo;
     const int need = (c.Wo - 1) * c.stride + (c.kw - 1) * c.dil + 1;
     p->RW = c.W + 2 * c.pad > need ? c.W + 2 * c.pad : need;
-    // window pixel stride: the ci block's channels (at most 48) + 8 zero channels; narrow inputs (the 3-channel stem) keep a
-    // narrow window.  N-blocks past the real channels read neighbouring pixels (finite, discarded): 128 bytes of slack.
-    p->XC = 8 * (c.CinS / 8 < 6 ? c.CinS / 8 : 6) + 8;
+    // window pixel stride: the ci block's channels + 8 zero channels (odd multiple of 16 bytes).  N-blocks past the real
+    // channels read neighbouring pixels (finite, discarded): 128 bytes of slack.
+    p->XC = 8 * (c.CinS / 8 < 2 * cbw ? c.CinS / 8 : 2 * cbw) + 8;
     // pixels per staged tile: the largest of 128 / 64 / 32 whose LDS image leaves room for two workgroups per CU, else
     // the largest that fits at all (full-width input rows make the window of wide strided layers large)
     bool found = false;
     for (int pass = 0; pass < 2 && !found; ++pass)
         for (int tpx = 128; tpx >= 32 && !found; tpx >>= 1) {
-            int rowsOut = (tpx - 1 + c.Wo - 1) / c.Wo + 1;
+            // output rows a tile can touch (tiles start at multiples of tpx: aligned tiles never straddle a row)
+            int rowsOut = c.Wo % tpx == 0 ? 1 : (tpx % c.Wo == 0 ? tpx / c.Wo : (tpx - 1 + c.Wo - 1) / c.Wo + 1);
             if (rowsOut > c.Ho) rowsOut = c.Ho;
             const int rows = (rowsOut - 1) * c.stride + (c.kh - 1) * c.dil + 1;
             const int ldsG = tpx * 56 * 2, ldsX = round_up(rows * p->RW * p->XC * 2, 16) + 128;
@@ -993,7 +1078,7 @@ extern "C" int otp_nhwc_conv_bf16(const void* x, const void* wpacked, const void
 extern "C" size_t otp_nhwc_wgrad_workspace(const otp_nhwc_conv_desc* d) {
     WgradPlan p;
     if (!make_wgrad_plan(d, &p)) return 0;
-    return (size_t)p.splits * p.Cout * p.Cin * p.kh * p.kw * sizeof(float);
+    return (size_t)p.splits * p.nCo * p.nCi * 4 * WG_NBW * 3 * 256 * sizeof(float);
 }
 
 extern "C" int otp_nhwc_wgrad_bf16(const void* x, const void* gy, void* grad_weight, void* workspace, size_t workspace_bytes,
@@ -1002,14 +1087,24 @@ extern "C" int otp_nhwc_wgrad_bf16(const void* x, const void* gy, void* grad_wei
     if (!x || !gy || !grad_weight || !workspace) return OTP_ERR_BAD_ARG;
     if (!make_wgrad_plan(d, &p)) return OTP_ERR_UNSUPPORTED;
     const size_t n = (size_t)p.Cout * p.Cin * p.kh * p.kw;
-    if (workspace_bytes < (size_t)p.splits * n * sizeof(float)) return OTP_ERR_WORKSPACE;
+    if (workspace_bytes < otp_nhwc_wgrad_workspace(d)) return OTP_ERR_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    OTP_ALLOW_BIG_LDS(nhwc_wgrad_kernel, p.lds);
-    nhwc_wgrad_kernel<<<p.nCo * p.nCi * p.splits, 256, p.lds, st>>>(static_cast<const bf16*>(x), static_cast<const bf16*>(gy),
-                                                                     static_cast<float*>(workspace), p);
+    // register prefetch of the next tile when the window fits WG_XU units per thread
+    const int xunits = p.rowsMax * p.RW * (p.XC / 8 - 1);
+    const bool pf = xunits <= WG_XU * 256 && p.TPX * 6 <= WG_GU * 256;
+    const int grid = p.nCo * p.nCi * p.splits;
+    if (pf) {
+        OTP_ALLOW_BIG_LDS(nhwc_wgrad_kernel<true>, p.lds);
+        nhwc_wgrad_kernel<true><<<grid, 256, p.lds, st>>>(static_cast<const bf16*>(x), static_cast<const bf16*>(gy),
+                                                           static_cast<float*>(workspace), p);
+    } else {
+        OTP_ALLOW_BIG_LDS(nhwc_wgrad_kernel<false>, p.lds);
+        nhwc_wgrad_kernel<false><<<grid, 256, p.lds, st>>>(static_cast<const bf16*>(x), static_cast<const bf16*>(gy),
+                                                            static_cast<float*>(workspace), p);
+    }
     if (otp_launch_status() != OTP_OK) return OTP_ERR_LAUNCH;
     nhwc_wgrad_reduce_kernel<<<(int)((n + 63) / 64), 256, 0, st>>>(static_cast<const float*>(workspace),
-                                                                      static_cast<float*>(grad_weight), p.splits, n);
+                                                                    static_cast<float*>(grad_weight), p, n);
     return otp_launch_status();
 }
 
