@@ -376,6 +376,15 @@ size_t otp_scale_residual_backward_workspace(int B, int C, int T);
 int otp_scale_residual_backward(const void* grad_out, const void* a, const void* scale, const void* mask, void* grad_a,
                                 void* grad_scale, void* workspace, size_t workspace_bytes, int B, int C, int T, void* stream);
 
+
+/* bf16 interior of the TransformerBlock MLP (model/blocks.py:248-254) on (B, 1, T, CS) NHWC views of the (B, C, T)
+ * sequences: bias gradients (per-channel sums over the pixels) and the exact-erf GELU with fp32 arithmetic. */
+size_t otp_nhwc_channel_sum_workspace(size_t pixels, int CS);
+int otp_nhwc_channel_sum(const void* g, void* out, void* workspace, size_t workspace_bytes, size_t pixels, int C, int CS,
+                         void* stream);
+int otp_gelu_bf16_forward(const void* x, void* y, size_t n, void* stream);
+int otp_gelu_bf16_backward(const void* x, const void* grad_y, void* grad_x, size_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

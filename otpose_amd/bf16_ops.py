@@ -281,3 +281,88 @@ class UpsampleAddFunction(Function):
 
 def upsample_add(low, res, f, relu):
     return UpsampleAddFunction.apply(low, res, f, relu)
+
+
+def channel_sum_nhwc(g, c, out=None):
+    """Per-channel sums over the pixels of an NHWC bf16 tensor -> (c,) fp32 (bias gradients)."""
+    L = hip.lib()
+    csz = g.shape[-1]
+    pixels = g.numel() // csz
+    nbytes = L.otp_nhwc_channel_sum_workspace(pixels, csz)
+    ws = _new(((nbytes + 3) // 4,), torch.float32, g)
+    if out is None:
+        out = _new((c,), torch.float32, g)
+    hip.check(L.otp_nhwc_channel_sum(hip.ptr(g), hip.ptr(out), hip.ptr(ws), nbytes, pixels, c, csz, hip.stream_of(g)),
+              "otp_nhwc_channel_sum")
+    return out
+
+
+class ConvBiasFunction(Function):
+    """``F.conv2d(x, weight, bias, stride, pad, dil)`` on NHWC bf16 in and out (no normalisation behind it): the MLP
+    up-projection of a TransformerBlock (model/blocks.py:248-254) on the (B, 1, T, C) view of a (B, C, T) sequence."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, dil):
+        _require_gpu(x, weight)
+        x = x.contiguous()
+        out, _, _ = conv_forward(x, weight, bias, stride, pad, dil, out_mode=0, want_stats=False)
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (stride, pad, dil, bias is not None)
+        ctx.params = (weight, bias)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        stride, pad, dil, has_bias = ctx.cfg
+        gy = gy.contiguous()
+        gx = conv_dgrad(gy, weight, x.shape[1:3], stride, pad, dil) if ctx.needs_input_grad[0] else None
+        gw = conv_wgrad(x, gy, weight.shape, stride, pad, dil, grad_slot(ctx.params[0])) if ctx.needs_input_grad[1] else None
+        gb = (channel_sum_nhwc(gy, weight.shape[0], grad_slot(ctx.params[1]))
+              if has_bias and ctx.needs_input_grad[2] else None)
+        return gx, gw, gb, None, None, None
+
+
+def conv_bias(x, weight, bias=None, stride=1, pad=0, dil=1):
+    return ConvBiasFunction.apply(x, weight, bias, stride, pad, dil)
+
+
+class GeluFunction(Function):
+    """Exact-erf GELU on bf16 (fp32 arithmetic)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _require_gpu(x)
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        hip.check(hip.lib().otp_gelu_bf16_forward(hip.ptr(x), hip.ptr(y), x.numel(), hip.stream_of(x)), "otp_gelu_bf16_forward")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        gx = torch.empty_like(x)
+        hip.check(hip.lib().otp_gelu_bf16_backward(hip.ptr(x), hip.ptr(gy.contiguous()), hip.ptr(gx), x.numel(),
+                                                   hip.stream_of(x)), "otp_gelu_bf16_backward")
+        return gx
+
+
+gelu = GeluFunction.apply
+
+
+class ToNhwcFunction(Function):
+    """(N, C, H, W) fp32 -> (N, H, W, CS) bf16 with the matching gradient conversion (the precision / layout hand-over
+    in front of a bf16 sub-graph)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.c = x.shape[1]
+        return to_nhwc(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return to_nchw(g.contiguous(), ctx.c)
+
+
+to_nhwc_grad = ToNhwcFunction.apply

@@ -92,9 +92,21 @@ bool make_plan(const otp_nhwc_conv_desc* d, ConvPlan* p) {
     p->NB = ((long)d->N * ((npx + 255) / 256) * p->nM >= 1024) ? 4 : 2;
     p->P = 64 * p->NB;
     p->tilesPerImg = (npx + p->P - 1) / p->P;
+    // a pointwise conv sees the image as rows of W' pixels, W' the largest divisor of H*W that is <= the tile size (and a
+    // multiple of 8): a tile's window is then (nearly) the tile itself instead of the full-width image rows it touches -
+    // (B, C, T) sequences enter as H = 1, W = T
+    if (taps == 1 && d->stride == 1 && d->pad == 0) {
+        int w1 = 0;
+        for (int cand = p->P; cand >= 32; cand -= 8)
+            if (npx % cand == 0) { w1 = cand; break; }
+        if (w1) {
+            p->W = p->Wo = w1;
+            p->H = p->Ho = npx / w1;
+        }
+    }
     const int need = (p->Wo - 1) * d->stride + (d->kw - 1) * d->dil + 1;
-    p->RW = d->W + 2 * d->pad > need ? d->W + 2 * d->pad : need;
-    int rowsOut = (p->P - 1 + p->Wo - 1) / p->Wo + 1;
+    p->RW = p->W + 2 * d->pad > need ? p->W + 2 * d->pad : need;
+    int rowsOut = p->Wo % p->P == 0 ? 1 : (p->P % p->Wo == 0 ? p->P / p->Wo : (p->P - 1 + p->Wo - 1) / p->Wo + 1);
     if (rowsOut > p->Ho) rowsOut = p->Ho;
     p->rowsMax = (rowsOut - 1) * d->stride + (d->kh - 1) * d->dil + 1;
     p->ldsW = p->KS * 4 * p->BM * 16;
@@ -497,14 +509,14 @@ __global__ __launch_bounds__(256) void nhwc_wgrad_kernel(const bf16* __restrict_
         gpx[j] = u / 6;
         gcg[j] = u - gpx[j] * 6;
     }
-    int xu[PF ? WG_XU : 1];                                   // packed (row << 20 | column << 4 | channel group)
+    int xu[PF ? WG_XU : 1];                                   // packed (row << 24 | column << 8 | channel group)
     if constexpr (PF) {
 #pragma unroll
         for (int j = 0; j < WG_XU; ++j) {
             const int u = j * 256 + tid;
             const int r = u / rowUnits, ur = u - r * rowUnits;
             const int col = ur / xcu, cg = ur - col * xcu;
-            xu[j] = (r << 20) | (col << 4) | cg;
+            xu[j] = (r << 24) | (col << 8) | cg;
         }
     }
     u32x4 gv[WG_GU], xv[PF ? WG_XU : 1];
@@ -519,7 +531,7 @@ __global__ __launch_bounds__(256) void nhwc_wgrad_kernel(const bf16* __restrict_
         if constexpr (PF) {
 #pragma unroll
             for (int j = 0; j < WG_XU; ++j) {
-                const int r = xu[j] >> 20, col = (xu[j] >> 4) & 0xffff, cg = xu[j] & 15;
+                const int r = xu[j] >> 24, col = (xu[j] >> 8) & 0xffff, cg = xu[j] & 255;
                 const int iy = g.rowLo + r, ix = col - p.pad, c = ci0 + cg * 8;
                 const bool ok = r < g.nrows && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && c < p.CinS;
                 xv[j] = bload16(xres, ok ? (((g.n * p.H + iy) * p.W + ix) * p.CinS + c) * 2 : OOB);
@@ -541,7 +553,7 @@ __global__ __launch_bounds__(256) void nhwc_wgrad_kernel(const bf16* __restrict_
         if constexpr (PF) {
 #pragma unroll
             for (int j = 0; j < WG_XU; ++j) {
-                const int r = xu[j] >> 20, col = (xu[j] >> 4) & 0xffff, cg = xu[j] & 15;
+                const int r = xu[j] >> 24, col = (xu[j] >> 8) & 0xffff, cg = xu[j] & 255;
                 if (r < g.nrows) *reinterpret_cast<u32x4*>(sX + (r * p.RW + col) * p.XC + cg * 8) = xv[j];
             }
         } else {
@@ -1013,6 +1025,79 @@ __global__ __launch_bounds__(256) void dilate_nhwc_kernel(const bf16* __restrict
     }
 }
 
+// per-channel sums over the pixels of an NHWC bf16 tensor (bias gradients): partial rows [wg][C] -> out[c]
+__global__ __launch_bounds__(256) void channel_sum_nhwc_kernel(const bf16* __restrict__ g, float* __restrict__ part, size_t npix,
+                                                                int C8, int pixPerWg) {
+    extern __shared__ float sred[];                       // [ppw][C8*8]
+    const int ppw = 256 / C8;
+    const int pl = threadIdx.x / C8, cg = threadIdx.x - pl * C8;
+    const int C = C8 * 8;
+    float s[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = 0.f;
+    if (pl < ppw) {
+        const size_t pbeg = (size_t)blockIdx.x * pixPerWg;
+        const size_t pend = pbeg + pixPerWg < npix ? pbeg + pixPerWg : npix;
+        for (size_t px = pbeg + pl; px < pend; px += ppw) {
+            const bf16x8 g8 = *reinterpret_cast<const bf16x8*>(g + px * C + cg * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] += bf2f(g8[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sred[(pl * C8 + cg) * 8 + j] = s[j];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += 256) {
+        float v = 0.f;
+        for (int k = 0; k < ppw; ++k) v += sred[k * C + i];
+        part[(size_t)blockIdx.x * C + i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void channel_sum_nhwc_finish_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                                       int rows, int C, int Ctrue) {
+    __shared__ double red[32][8];
+    const int cl = threadIdx.x & 7, rq = threadIdx.x >> 3, c = blockIdx.x * 8 + cl;
+    double s = 0.0;
+    if (c < C)
+        for (int r = rq; r < rows; r += 32) s += (double)part[(size_t)r * C + c];
+    red[rq][cl] = s;
+    __syncthreads();
+    if (rq == 0 && c < Ctrue) {
+        for (int k = 1; k < 32; ++k) s += red[k][cl];
+        out[c] = (float)s;
+    }
+}
+
+// exact-erf GELU on bf16 (nn.GELU of the TransformerBlock MLP, model/blocks.py:248-254), fp32 arithmetic
+__global__ __launch_bounds__(256) void gelu_bf16_fwd_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, size_t units) {
+    for (size_t u = blockIdx.x * (size_t)blockDim.x + threadIdx.x; u < units; u += (size_t)gridDim.x * blockDim.x) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + u * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float f = bf2f(v[j]);
+            o[j] = (bf16)(0.5f * f * (1.f + erff(f * 0.70710678118654752440f)));
+        }
+        *reinterpret_cast<bf16x8*>(y + u * 8) = o;
+    }
+}
+__global__ __launch_bounds__(256) void gelu_bf16_bwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
+                                                             bf16* __restrict__ dx, size_t units) {
+    for (size_t u = blockIdx.x * (size_t)blockDim.x + threadIdx.x; u < units; u += (size_t)gridDim.x * blockDim.x) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + u * 8), g = *reinterpret_cast<const bf16x8*>(dy + u * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float f = bf2f(v[j]);
+            const float cdf = 0.5f * (1.f + erff(f * 0.70710678118654752440f));
+            const float pdf = 0.39894228040143267794f * expf(-0.5f * f * f);
+            o[j] = (bf16)(bf2f(g[j]) * (cdf + f * pdf));
+        }
+        *reinterpret_cast<bf16x8*>(dx + u * 8) = o;
+    }
+}
+
 int grid_for(size_t units) {
     size_t g = (units + 255) / 256;
     if (g > 256 * 16) g = 256 * 16;
@@ -1220,3 +1305,39 @@ extern "C" int otp_nhwc_read_stamps(void* host_out, size_t bytes) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(otp_nhwc_stamps), bytes) == hipSuccess ? OTP_OK : OTP_ERR_LAUNCH;
 }
 #endif
+
+extern "C" size_t otp_nhwc_channel_sum_workspace(size_t pixels, int CS) {
+    int ppw;
+    const int rows = bn_bwd_rows(pixels, &ppw);
+    return (size_t)rows * CS * sizeof(float);
+}
+
+// out[c] (C floats) = sum over pixels of g[pixel][c], g NHWC bf16 with channel stride CS (bias gradients)
+extern "C" int otp_nhwc_channel_sum(const void* g, void* out, void* workspace, size_t workspace_bytes, size_t pixels, int C,
+                                    int CS, void* stream) {
+    if (!g || !out || !workspace || C <= 0 || CS < C || CS % 8 || CS > 2048) return OTP_ERR_BAD_ARG;
+    if (workspace_bytes < otp_nhwc_channel_sum_workspace(pixels, CS)) return OTP_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int ppw;
+    const int rows = bn_bwd_rows(pixels, &ppw);
+    const int C8 = CS / 8;
+    channel_sum_nhwc_kernel<<<rows, 256, (size_t)(256 / C8) * CS * sizeof(float), st>>>(
+        static_cast<const bf16*>(g), static_cast<float*>(workspace), pixels, C8, ppw);
+    channel_sum_nhwc_finish_kernel<<<(CS + 7) / 8, 256, 0, st>>>(static_cast<const float*>(workspace), static_cast<float*>(out),
+                                                                 rows, CS, C);
+    return otp_launch_status();
+}
+
+extern "C" int otp_gelu_bf16_forward(const void* x, void* y, size_t n, void* stream) {
+    if (!x || !y || n % 8) return OTP_ERR_BAD_ARG;
+    gelu_bf16_fwd_kernel<<<grid_for(n / 8), 256, 0, static_cast<hipStream_t>(stream)>>>(static_cast<const bf16*>(x),
+                                                                                          static_cast<bf16*>(y), n / 8);
+    return otp_launch_status();
+}
+
+extern "C" int otp_gelu_bf16_backward(const void* x, const void* grad_y, void* grad_x, size_t n, void* stream) {
+    if (!x || !grad_y || !grad_x || n % 8) return OTP_ERR_BAD_ARG;
+    gelu_bf16_bwd_kernel<<<grid_for(n / 8), 256, 0, static_cast<hipStream_t>(stream)>>>(
+        static_cast<const bf16*>(x), static_cast<const bf16*>(grad_y), static_cast<bf16*>(grad_x), n / 8);
+    return otp_launch_status();
+}

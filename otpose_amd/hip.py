@@ -130,6 +130,10 @@ SIGNATURES = {
     "otp_scale_residual": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_void_p]),
     "otp_scale_residual_backward_workspace": (c_size_t, [c_int] * 3),
     "otp_scale_residual_backward": (c_int, [c_void_p] * 7 + [c_size_t] + [c_int] * 3 + [c_void_p]),
+    "otp_nhwc_channel_sum_workspace": (c_size_t, [c_size_t, c_int]),
+    "otp_nhwc_channel_sum": (c_int, [c_void_p] * 3 + [c_size_t, c_size_t, c_int, c_int, c_void_p]),
+    "otp_gelu_bf16_forward": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "otp_gelu_bf16_backward": (c_int, [c_void_p] * 3 + [c_size_t, c_void_p]),
     "otp_loss_joints_mse": (c_int, [c_void_p] * 5 + [c_void_p, c_size_t] + [c_int] * 6 + [c_void_p]),
 }
 

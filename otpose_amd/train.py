@@ -322,10 +322,14 @@ class TrainGraph:
         skip = x if stride == 1 else T.maxpool3s2(x)
         blk = self.mods[p]
         y = T.scale_residual(skip, a, self.P[p + ".drop_path_attn.scale"], self.drop_path_mask(a, blk.path_pdrop))
-        h = self.conv1d(p + ".mlp.0", self.layer_norm(p + ".ln2", y))
-        h = self.conv1d(p + ".mlp.3", self.dropout(T.gelu(h), blk.proj_pdrop))
-        h = self.dropout(h, blk.proj_pdrop)
+        h = self.mlp(p + ".mlp", self.layer_norm(p + ".ln2", y), blk.proj_pdrop)
         return T.scale_residual(y, h, self.P[p + ".drop_path_mlp.scale"], self.drop_path_mask(h, blk.path_pdrop))
+
+    def mlp(self, p, yn, pdrop):
+        """Conv1d(C, 4C, 1) -> GELU -> Dropout -> Conv1d(4C, C, 1) -> Dropout (model/blocks.py:248-254)."""
+        h = self.conv1d(p + ".0", yn)
+        h = self.conv1d(p + ".3", self.dropout(T.gelu(h), pdrop))
+        return self.dropout(h, pdrop)
 
     def conv_transformer(self, p, x4, n_head, arch):
         b, c, h, w = x4.shape
@@ -442,6 +446,27 @@ class TrainGraphBF16(TrainGraph):
 
     def hrnet_input(self, x):
         return B16.to_nhwc(x, frame_split=x.shape[0])
+
+    def _w4(self, name):
+        """(Cout, Cin, 1) Conv1d weight as the (Cout, Cin, 1, 1) view the conv kernels take, gradient slot attached."""
+        w = self.P[name]
+        w4 = w.unsqueeze(-1)
+        slot = getattr(w, "_otp_grad_slot", None)
+        if slot is not None:
+            w4._otp_grad_slot, w4._otp_grad_owner = slot.unsqueeze(-1), w
+        return w4
+
+    def mlp(self, p, yn, pdrop):
+        """The MLP interior in bf16: the (B, C, T) fp32 LayerNorm output enters as a (B, 1, T, CS) NHWC bf16 view, the 4C-wide
+        hidden activation (the largest tensor of a block: 240 MB at cfg2 in fp32) exists only in bf16, both projections
+        and their gradients run on the bf16 matrix cores, and the down-projection hands back fp32 (B, C, T)."""
+        if yn.shape[1] % 8 or yn.shape[2] % 32:
+            return super().mlp(p, yn, pdrop)                  # the C = 17 flow encoder / odd lengths stay on the fp32 path
+        x = B16.to_nhwc_grad(yn.unsqueeze(2))
+        h = B16.conv_bias(x, self._w4(p + ".0.weight"), self.P.get(p + ".0.bias"))
+        h = self.dropout(B16.gelu(h), pdrop)
+        o = B16.conv_out(h, self._w4(p + ".3.weight"), self.P.get(p + ".3.bias"))
+        return self.dropout(o.squeeze(2), pdrop)
 
     def hrnet_output(self, p, y):
         return B16.conv_out(y, self.P[p + ".weight"], self.P.get(p + ".bias"))

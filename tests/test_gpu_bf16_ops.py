@@ -174,3 +174,37 @@ def test_layout_converters_round_trip_and_frame_split():
     n = B.to_nhwc(y.to(_dev()))
     assert n.shape == (3, 5, 4, 24)
     assert torch.equal(B.to_nchw(n, 17).cpu(), _rb(y))
+
+
+def test_mlp_interior_matches_fp32_reference():
+    """Conv1d(C, 4C, 1) -> GELU -> Conv1d(4C, C, 1) (model/blocks.py:248-254) through the bf16 NHWC kernels on a (B, C, T)
+    sequence vs fp64 autograd: output and every gradient."""
+    from otpose_amd import bf16_ops as B
+    g = torch.Generator().manual_seed(9)
+    b, c, t = 2, 136, 864
+    x = _rb(torch.randn(b, c, t, generator=g))
+    w1 = _rb(torch.randn(4 * c, c, 1, generator=g) / c ** 0.5)
+    b1 = torch.randn(4 * c, generator=g) * 0.1
+    w2 = _rb(torch.randn(c, 4 * c, 1, generator=g) / (4 * c) ** 0.5)
+    b2 = torch.randn(c, generator=g) * 0.1
+    gy = torch.randn(b, c, t, generator=g)
+    xr, w1r, b1r, w2r, b2r = (v.double().requires_grad_() for v in (x, w1, b1, w2, b2))
+    ref = F.conv1d(F.gelu(F.conv1d(xr, w1r, b1r)), w2r, b2r)
+    ref.backward(gy.double())
+    dev = _dev()
+    xd, w1d, b1d, w2d, b2d = (v.to(dev).requires_grad_() for v in (x, w1, b1, w2, b2))
+    h = B.gelu(B.conv_bias(B.to_nhwc_grad(xd.unsqueeze(2)), w1d.unsqueeze(-1), b1d))
+    out = B.conv_out(h, w2d.unsqueeze(-1), b2d).squeeze(2)
+    out.backward(gy.to(dev))
+    torch.cuda.synchronize()
+
+    def close(a, r, rel):
+        err = float((a.detach().cpu().double() - r).abs().max())
+        assert err <= rel * float(r.abs().max()), (err, float(r.abs().max()))
+
+    close(out, ref.detach(), 2e-2)          # two bf16 roundings of the hidden activation
+    close(xd.grad, xr.grad, 3e-2)
+    close(w1d.grad, w1r.grad, 3e-2)
+    close(w2d.grad, w2r.grad, 2e-2)
+    close(b1d.grad, b1r.grad, 2e-2)
+    close(b2d.grad, b2r.grad, 1e-4)
