@@ -62,35 +62,20 @@ struct ConvPlan {
 
 int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
-bool make_plan(const otp_nhwc_conv_desc* d, ConvPlan* p) {
-    if (!d || d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->kh <= 0 || d->kw <= 0 ||
-        d->stride <= 0 || d->dil <= 0 || d->pad < 0)
-        return false;
-    p->N = d->N, p->H = d->H, p->W = d->W, p->Cin = d->Cin, p->Cout = d->Cout;
-    p->kh = d->kh, p->kw = d->kw, p->stride = d->stride, p->pad = d->pad, p->dil = d->dil, p->out_mode = d->out_mode;
-    p->CinS = round_up(d->Cin, 8), p->CoutS = round_up(d->Cout, 8);
+// sizes everything for a given (channels per chunk, N-blocks per wave); false when the LDS image does not fit
+bool size_plan(const otp_nhwc_conv_desc* d, ConvPlan* p, int ck, int nb) {
+    const int taps = d->kh * d->kw;
+    p->H = d->H, p->W = d->W;
     p->Ho = (d->H + 2 * d->pad - d->dil * (d->kh - 1) - 1) / d->stride + 1;
     p->Wo = (d->W + 2 * d->pad - d->dil * (d->kw - 1) - 1) / d->stride + 1;
-    if (p->Ho <= 0 || p->Wo <= 0) return false;
-    // channels per chunk: 24 keeps the pixel stride of the LDS window an odd multiple of 16 bytes (conflict-free 16-byte
-    // reads) and the per-chunk weight slab small enough for 3-4 workgroups per CU
-    const int taps = d->kh * d->kw;
-    int ck = p->CinS <= 24 ? p->CinS : 24;
-    if (taps == 1) ck = p->CinS <= 64 ? p->CinS : (p->CinS % 40 == 0 ? 40 : (p->CinS % 24 == 0 ? 24 : 40));
     p->CK = ck, p->CK8 = ck / 8;
-    p->CKp = (p->CK8 & 1) ? ck : ck + 8;
+    p->CKp = (p->CK8 & 1) ? ck : ck + 8;        // pixel stride of the LDS window: an odd multiple of 16 bytes
     p->nChunks = (p->CinS + ck - 1) / ck;
     p->KGc = taps * p->CK8;
     p->KS = (p->KGc + 3) / 4;
-    const int c16 = round_up(d->Cout, 16);
-    int bm = c16 <= 96 ? c16 : 96;
-    if (c16 > 96 && c16 % 96 != 0 && c16 % 64 == 0) bm = 64;
-    p->BM = bm, p->MB = bm / 16, p->nM = (c16 + bm - 1) / bm;
     const int npx = p->Ho * p->Wo;
-    // 256-pixel tiles (4 N-blocks per wave: 10 LDS fragment reads per 24 MFMAs at MB = 6 instead of 8 per 12) when that
-    // still leaves >= 4 workgroups per CU to balance; 128-pixel tiles otherwise
-    p->NB = ((long)d->N * ((npx + 255) / 256) * p->nM >= 1024) ? 4 : 2;
-    p->P = 64 * p->NB;
+    p->NB = nb;
+    p->P = 64 * nb;
     p->tilesPerImg = (npx + p->P - 1) / p->P;
     // a pointwise conv sees the image as rows of W' pixels, W' the largest divisor of H*W that is <= the tile size (and a
     // multiple of 8): a tile's window is then (nearly) the tile itself instead of the full-width image rows it touches -
@@ -117,6 +102,49 @@ bool make_plan(const otp_nhwc_conv_desc* d, ConvPlan* p) {
     p->lds = p->ldsW + p->ldsX + p->ldsTab + 4 * 2 * p->BM * 4;
     p->wbytes = (size_t)p->nChunks * p->nM * p->ldsW;
     return p->lds <= OTP_LDS_LIMIT;
+}
+
+bool make_plan(const otp_nhwc_conv_desc* d, ConvPlan* p) {
+    if (!d || d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->kh <= 0 || d->kw <= 0 ||
+        d->stride <= 0 || d->dil <= 0 || d->pad < 0)
+        return false;
+    p->N = d->N, p->Cin = d->Cin, p->Cout = d->Cout;
+    p->kh = d->kh, p->kw = d->kw, p->stride = d->stride, p->pad = d->pad, p->dil = d->dil, p->out_mode = d->out_mode;
+    p->CinS = round_up(d->Cin, 8), p->CoutS = round_up(d->Cout, 8);
+    const int ho = (d->H + 2 * d->pad - d->dil * (d->kh - 1) - 1) / d->stride + 1;
+    const int wo = (d->W + 2 * d->pad - d->dil * (d->kw - 1) - 1) / d->stride + 1;
+    if (ho <= 0 || wo <= 0) return false;
+    // channels per chunk: 24 keeps the per-chunk weight slab small enough for 3-4 workgroups per CU
+    const int taps = d->kh * d->kw;
+    int ck = p->CinS <= 24 ? p->CinS : 24;
+    if (taps == 1) {
+        // pointwise: one chunk when the channels fit (136 = the temporal encoders' width), else equal chunks of 136 / 72 / 40
+        if (p->CinS <= 144) ck = p->CinS;
+        else if (p->CinS % 136 == 0) ck = 136;
+        else if (p->CinS % 72 == 0) ck = 72;
+        else ck = p->CinS % 40 == 0 ? 40 : (p->CinS % 24 == 0 ? 24 : 40);
+    }
+    const int c16 = round_up(d->Cout, 16);
+    int bm = c16 <= 96 ? c16 : 96;
+    if (c16 > 96 && c16 % 96 != 0 && c16 % 64 == 0) bm = 64;
+    if (taps == 1 && c16 > 96) {                                // pointwise: up to 9 M-blocks, least padding first
+        int best = 1 << 30;
+        for (int cand = 144; cand >= 96; cand -= 16) {
+            const int padded = (c16 + cand - 1) / cand * cand;
+            if (padded < best) best = padded, bm = cand;
+        }
+    }
+    p->BM = bm, p->MB = bm / 16, p->nM = (c16 + bm - 1) / bm;
+    const int npx = ho * wo;
+    // 256-pixel tiles (4 N-blocks per wave: 10 LDS fragment reads per 24 MFMAs at MB = 6 instead of 8 per 12) when that
+    // still leaves >= 4 workgroups per CU to balance; 128-pixel tiles otherwise
+    int nb = ((long)d->N * ((npx + 255) / 256) * p->nM >= 1024) ? 4 : 2;
+    if (p->MB > 6) nb = 2;                                      // 7-9 M-blocks: 72 accumulator registers at NB = 2
+    // candidates in order of preference; later ones shrink the LDS image (widely dilated taps on wide maps stage many rows)
+    if (size_plan(d, p, ck, nb) && (taps > 1 || nb == 2 || p->lds <= 72 * 1024)) return true;
+    if (nb == 4 && size_plan(d, p, ck, 2)) return true;
+    if (ck > 8 && size_plan(d, p, 8, 2)) return true;
+    return false;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -425,6 +453,7 @@ struct WgradPlan {
     int N, H, W, CinS, Ho, Wo, CoutS, Cin, Cout, kh, kw, stride, pad, dil;
     int nCo, nCi, splits, tilesPerImg, tilesTotal, tilesPerSplit, TPX;
     int RW, rowsMax, XC, ldsG, ldsX, lds;
+    int tapmode;           // 1: the LDS image of x is [tap][tile pixel][XC] (each tap's shifted copy of the tile) instead of a window of rows
     int nbTot, cbw;        // N-blocks per workgroup = taps * cbw; cbw = 16-channel blocks of ci per workgroup (3 for 3x3 taps)
 };
 
@@ -465,7 +494,7 @@ __global__ __launch_bounds__(256) void nhwc_wgrad_kernel(const bf16* __restrict_
         const int nbc = nb < p.nbTot ? nb : 0;
         const int tap = nbc / p.cbw, cb = nbc - tap * p.cbw;
         const int dy = tap / p.kw, dx = tap - dy * p.kw;
-        xoff[i] = ((dy * p.dil) * p.RW + dx * p.dil) * p.XC + cb * 16;
+        xoff[i] = (p.tapmode ? tap * p.TPX : (dy * p.dil) * p.RW + dx * p.dil) * p.XC + cb * 16;
     }
     f32x4 acc[3][WG_NBW];
 #pragma unroll
@@ -482,7 +511,7 @@ __global__ __launch_bounds__(256) void nhwc_wgrad_kernel(const bf16* __restrict_
     const otp_rsrc gres = make_rsrc(gy, (size_t)p.N * npx * p.CoutS * 2);
 
     // the padding channel group of every window pixel is zero for the whole kernel
-    for (int i = tid; i < p.rowsMax * p.RW; i += 256)
+    for (int i = tid; i < (p.tapmode ? p.kh * p.kw * p.TPX : p.rowsMax * p.RW); i += 256)
         *reinterpret_cast<u32x4*>(sX + (size_t)i * p.XC + xcu * 8) = u32x4{0u, 0u, 0u, 0u};
 
     struct Geom {
@@ -557,8 +586,33 @@ __global__ __launch_bounds__(256) void nhwc_wgrad_kernel(const bf16* __restrict_
                 if (r < g.nrows) *reinterpret_cast<u32x4*>(sX + (r * p.RW + col) * p.XC + cg * 8) = xv[j];
             }
         } else {
-            // general form: flat (row, column, channel group) units, 8 loads in flight per thread
-            const int xunits = g.nrows * rowUnits;
+            // general form: flat (row, column, channel group) units - or, in tap mode, (tap, tile pixel, channel group) units:
+            // each tap's shifted copy of the tile (widely dilated or strided taps would otherwise drag many full-width rows
+            // through LDS) - 8 loads in flight per thread
+            if (p.tapmode) {
+                const int tunits = p.kh * p.kw * TPX * xcu;
+                for (int base = 0; base < tunits; base += 256 * 8) {
+                    u32x4 v[8];
+                    int dst[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int u = base + j * 256 + tid;
+                        const int tp = u / xcu, cg = u - tp * xcu;
+                        const int tap = tp / TPX, px = tp - tap * TPX;
+                        const int dy = tap / p.kw, dx = tap - dy * p.kw;
+                        const int pc = min(g.p0 + px, g.p1 - 1);
+                        const int oy = pc / p.Wo, ox = pc - oy * p.Wo;
+                        const int iy = oy * p.stride - p.pad + dy * p.dil, ix = ox * p.stride - p.pad + dx * p.dil, c = ci0 + cg * 8;
+                        dst[j] = u < tunits ? tp * p.XC + cg * 8 : -1;
+                        const bool ok = u < tunits && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && c < p.CinS;
+                        v[j] = bload16(xres, ok ? (((g.n * p.H + iy) * p.W + ix) * p.CinS + c) * 2 : OOB);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (dst[j] >= 0) *reinterpret_cast<u32x4*>(sX + dst[j]) = v[j];
+                }
+            }
+            const int xunits = p.tapmode ? 0 : g.nrows * rowUnits;
             for (int base = 0; base < xunits; base += 256 * 8) {
                 u32x4 v[8];
                 int dst[8];
@@ -595,7 +649,7 @@ __global__ __launch_bounds__(256) void nhwc_wgrad_kernel(const bf16* __restrict_
                 const int px = k0 + 8 * lg + 4 * h + q;
                 const int pc = min(gc.p0 + px, gc.p1 - 1);       // rows past the tile pair with zero gy rows
                 const int oy = pc / p.Wo, ox = pc - oy * p.Wo;
-                xrow[h] = (((oy - gc.oy0) * p.stride) * p.RW + ox * p.stride) * p.XC + 4 * pp;
+                xrow[h] = (p.tapmode ? pc - gc.p0 : ((oy - gc.oy0) * p.stride) * p.RW + ox * p.stride) * p.XC + 4 * pp;
             }
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
@@ -625,37 +679,44 @@ __global__ __launch_bounds__(256) void nhwc_wgrad_kernel(const bf16* __restrict_
     OTP_STAMP(5);
 }
 
-// gw[co][ci][tap] = sum over splits of the fragment-ordered partials: 64 weights x 4 split lanes per workgroup
+// gw[co][ci][tap] = sum over splits of the fragment-ordered partials.  Threads walk the FRAGMENT order (coalesced reads of
+// the splits x fragments slab, 4 split lanes per fragment element, 8 loads in flight) and scatter the few results.
 __global__ __launch_bounds__(256) void nhwc_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw, WgradPlan p,
-                                                                 size_t n) {
+                                                                 size_t frag_total) {
     __shared__ float red[4][64];
     const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const size_t i = blockIdx.x * (size_t)64 + e;
+    const size_t f = blockIdx.x * (size_t)64 + e;
     float s = 0.f;
-    if (i < n) {
-        const int taps = p.kh * p.kw;
-        const int tap = (int)(i % taps);
-        const int ci = (int)((i / taps) % p.Cin), co = (int)(i / ((size_t)taps * p.Cin));
-        const int cw = 16 * p.cbw;
-        const int cob = co / 48, cib = ci / cw, cor = co - cob * 48, cir = ci - cib * cw;
-        const int nb = tap * p.cbw + cir / 16, wave = nb & 3, ii = nb >> 2;
-        const int m = cor >> 4, lg = (cor & 15) >> 2, r = cor & 3, lane = lg * 16 + (cir & 15);
-        const size_t blockStride = (size_t)4 * WG_NBW * 3 * 256;                       // floats per (split, block)
-        const size_t off = ((size_t)(cob * p.nCi + cib) * 4 + wave) * (WG_NBW * 3 * 256) + ((size_t)(ii * 3 + m) * 64 + lane) * 4 + r;
-        const size_t splitStride = blockStride * p.nCo * p.nCi;
+    if (f < frag_total) {
         int k = sl;
         for (; k + 28 < p.splits; k += 32) {
             float v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = part[(size_t)(k + 4 * j) * splitStride + off];
+            for (int j = 0; j < 8; ++j) v[j] = part[(size_t)(k + 4 * j) * frag_total + f];
 #pragma unroll
             for (int j = 0; j < 8; ++j) s += v[j];
         }
-        for (; k < p.splits; k += 4) s += part[(size_t)k * splitStride + off];
+        for (; k < p.splits; k += 4) s += part[(size_t)k * frag_total + f];
     }
     red[sl][e] = s;
     __syncthreads();
-    if (sl == 0 && i < n) gw[i] = red[0][e] + red[1][e] + red[2][e] + red[3][e];
+    if (sl == 0 && f < frag_total) {
+        // f = (((blk*4 + wave)*WG_NBW + i)*3 + m)*256 + lane*4 + r
+        const int r = (int)(f & 3), lane = (int)((f >> 2) & 63);
+        size_t q = f >> 8;
+        const int m = (int)(q % 3); q /= 3;
+        const int i = (int)(q % WG_NBW); q /= WG_NBW;
+        const int wave = (int)(q & 3);
+        const int blk = (int)(q >> 2);
+        const int cib = blk % p.nCi, cob = blk / p.nCi;
+        const int nb = wave + 4 * i;
+        if (nb < p.nbTot) {
+            const int tap = nb / p.cbw, cb = nb - tap * p.cbw;
+            const int co = cob * 48 + m * 16 + (lane >> 4) * 4 + r, ci = cib * 16 * p.cbw + cb * 16 + (lane & 15);
+            if (co < p.Cout && ci < p.Cin)
+                gw[((size_t)co * p.Cin + ci) * (p.kh * p.kw) + tap] = red[0][e] + red[1][e] + red[2][e] + red[3][e];
+        }
+    }
 }
 
 bool make_wgrad_plan(const otp_nhwc_conv_desc* d, WgradPlan* p) {
@@ -692,15 +753,21 @@ bool make_wgrad_plan(const otp_nhwc_conv_desc* d, WgradPlan* p) {
     // pixels per staged tile: the largest of 128 / 64 / 32 whose LDS image leaves room for two workgroups per CU, else
     // the largest that fits at all (full-width input rows make the window of wide strided layers large)
     bool found = false;
+    p->tapmode = 0;
     for (int pass = 0; pass < 2 && !found; ++pass)
         for (int tpx = 128; tpx >= 32 && !found; tpx >>= 1) {
             // output rows a tile can touch (tiles start at multiples of tpx: aligned tiles never straddle a row)
             int rowsOut = c.Wo % tpx == 0 ? 1 : (tpx % c.Wo == 0 ? tpx / c.Wo : (tpx - 1 + c.Wo - 1) / c.Wo + 1);
             if (rowsOut > c.Ho) rowsOut = c.Ho;
             const int rows = (rowsOut - 1) * c.stride + (c.kh - 1) * c.dil + 1;
-            const int ldsG = tpx * 56 * 2, ldsX = round_up(rows * p->RW * p->XC * 2, 16) + 128;
-            if (ldsG + ldsX <= (pass == 0 ? 80 * 1024 : OTP_LDS_LIMIT)) {
-                p->TPX = tpx, p->rowsMax = rows, p->ldsG = ldsG, p->ldsX = ldsX, p->lds = ldsG + ldsX;
+            const int ldsG = tpx * 56 * 2;
+            const int winX = round_up(rows * p->RW * p->XC * 2, 16) + 128, tapX = taps * tpx * p->XC * 2 + 128;
+            const int limit = pass == 0 ? 80 * 1024 : OTP_LDS_LIMIT;
+            // the window of rows unless each tap's copy of the tile is smaller (wide dilations, strided wide maps)
+            const bool tapm = taps > 1 && tapX < winX;
+            const int ldsX = tapm ? tapX : winX;
+            if (ldsG + ldsX <= limit) {
+                p->TPX = tpx, p->rowsMax = rows, p->ldsG = ldsG, p->ldsX = ldsX, p->lds = ldsG + ldsX, p->tapmode = tapm;
                 found = true;
             }
         }
@@ -994,16 +1061,26 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
     }
 }
 
-// (N, H, W, CS) bf16 -> (N, C, H, W) fp32
+// (N, H, W, CS) bf16 -> (N, C, H, W) fp32: a workgroup moves 64 pixels x all channels through LDS, so that the reads are
+// 16-byte units of whole pixel rows and the writes 256-byte runs of one channel plane
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const bf16* __restrict__ in, float* __restrict__ out, int N, int C,
                                                             int HW, int CS) {
-    const size_t total = (size_t)N * C * HW;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int px = (int)(i % HW);
-        const size_t r = i / HW;
-        const int c = (int)(r % C), n = (int)(r / C);
-        out[i] = bf2f(in[((size_t)n * HW + px) * CS + c]);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16* sT = reinterpret_cast<bf16*>(smem);                 // [64][CS + 8]
+    const int CP = CS + 8, C8 = CS / 8;
+    const int tilesPerImg = (HW + 63) / 64;
+    const int n = blockIdx.x / tilesPerImg, p0 = (blockIdx.x - n * tilesPerImg) * 64;
+    const int npx = min(64, HW - p0);
+    for (int u = threadIdx.x; u < 64 * C8; u += 256) {
+        const int px = u / C8, cg = u - px * C8;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (px < npx) v = *reinterpret_cast<const u32x4*>(in + ((size_t)n * HW + p0 + px) * CS + cg * 8);
+        *reinterpret_cast<u32x4*>(sT + px * CP + cg * 8) = v;
     }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < npx)
+        for (int c = wave; c < C; c += 4) out[((size_t)n * C + c) * HW + p0 + lane] = bf2f(sT[lane * CP + c]);
 }
 
 // (N, C, H, W) fp32 gradient -> (N, H, W, CS) bf16 (same as nchw_to_nhwc without frame_split) is reused for grads.
@@ -1155,6 +1232,7 @@ extern "C" int otp_nhwc_conv_bf16(const void* x, const void* wpacked, const void
 #define OTP_NHWC_CASE(mb, nb) \
     if (p.MB == mb && p.NB == nb) return launch_conv<mb, nb>(p, x, wpacked, bias, out, stats, st)
     OTP_NHWC_CASE(1, 2); OTP_NHWC_CASE(2, 2); OTP_NHWC_CASE(3, 2); OTP_NHWC_CASE(4, 2); OTP_NHWC_CASE(5, 2); OTP_NHWC_CASE(6, 2);
+    OTP_NHWC_CASE(7, 2); OTP_NHWC_CASE(8, 2); OTP_NHWC_CASE(9, 2);
     OTP_NHWC_CASE(1, 4); OTP_NHWC_CASE(2, 4); OTP_NHWC_CASE(3, 4); OTP_NHWC_CASE(4, 4); OTP_NHWC_CASE(5, 4); OTP_NHWC_CASE(6, 4);
 #undef OTP_NHWC_CASE
     return OTP_ERR_UNSUPPORTED;
@@ -1171,12 +1249,11 @@ extern "C" int otp_nhwc_wgrad_bf16(const void* x, const void* gy, void* grad_wei
     WgradPlan p;
     if (!x || !gy || !grad_weight || !workspace) return OTP_ERR_BAD_ARG;
     if (!make_wgrad_plan(d, &p)) return OTP_ERR_UNSUPPORTED;
-    const size_t n = (size_t)p.Cout * p.Cin * p.kh * p.kw;
     if (workspace_bytes < otp_nhwc_wgrad_workspace(d)) return OTP_ERR_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     // register prefetch of the next tile when the window fits WG_XU units per thread
     const int xunits = p.rowsMax * p.RW * (p.XC / 8 - 1);
-    const bool pf = xunits <= WG_XU * 256 && p.TPX * 6 <= WG_GU * 256;
+    const bool pf = !p.tapmode && xunits <= WG_XU * 256 && p.TPX * 6 <= WG_GU * 256;
     const int grid = p.nCo * p.nCi * p.splits;
     if (pf) {
         OTP_ALLOW_BIG_LDS(nhwc_wgrad_kernel<true>, p.lds);
@@ -1188,8 +1265,9 @@ extern "C" int otp_nhwc_wgrad_bf16(const void* x, const void* gy, void* grad_wei
                                                             static_cast<float*>(workspace), p);
     }
     if (otp_launch_status() != OTP_OK) return OTP_ERR_LAUNCH;
-    nhwc_wgrad_reduce_kernel<<<(int)((n + 63) / 64), 256, 0, st>>>(static_cast<const float*>(workspace),
-                                                                    static_cast<float*>(grad_weight), p, n);
+    const size_t frag_total = (size_t)p.nCo * p.nCi * 4 * WG_NBW * 3 * 256;
+    nhwc_wgrad_reduce_kernel<<<(int)((frag_total + 63) / 64), 256, 0, st>>>(static_cast<const float*>(workspace),
+                                                                             static_cast<float*>(grad_weight), p, frag_total);
     return otp_launch_status();
 }
 
@@ -1288,7 +1366,9 @@ extern "C" int otp_nchw_f32_to_nhwc_bf16(const void* in, void* out, int N, int C
 extern "C" int otp_nhwc_bf16_to_nchw_f32(const void* in, void* out, int N, int C, int H, int W, void* stream) {
     if (!in || !out || N <= 0 || C <= 0) return OTP_ERR_BAD_ARG;
     const int CS = (C + 7) / 8 * 8;
-    nhwc_to_nchw_kernel<<<grid_for((size_t)N * C * H * W), 256, 0, static_cast<hipStream_t>(stream)>>>(
+    if (CS > 2048) return OTP_ERR_UNSUPPORTED;
+    const int tiles = N * ((H * W + 63) / 64);
+    nhwc_to_nchw_kernel<<<tiles, 256, (size_t)64 * (CS + 8) * 2, static_cast<hipStream_t>(stream)>>>(
         static_cast<const bf16*>(in), static_cast<float*>(out), N, C, H * W, CS);
     return otp_launch_status();
 }

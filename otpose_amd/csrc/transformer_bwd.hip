@@ -63,13 +63,15 @@ __global__ __launch_bounds__(256) void ln_channel_bwd_split_kernel(const float* 
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < CW; ++i) {
+        // unconditional loads (channel index clamped, value masked afterwards): a branch around each load makes hipcc wait
+        // for every outstanding load at every branch, i.e. 2 * CW dependent HBM round trips instead of one batch
         const int c = cbeg + i;
-        xv[i] = dv[i] = 0.f;
-        if (i < cw && c < C) {
-            xv[i] = x[base + (size_t)c * T];
-            dv[i] = dy[base + (size_t)c * T];
-            s += xv[i];
-        }
+        const bool ok = i < cw && c < C;
+        const size_t o = base + (size_t)(ok ? c : C - 1) * T;
+        const float xl = x[o], dl = dy[o];
+        xv[i] = ok ? xl : 0.f;
+        dv[i] = ok ? dl : 0.f;
+        s += xv[i];
     }
     red[0][wave][lane] = s;
     __syncthreads();

@@ -376,6 +376,13 @@ class TrainGraph:
             i += 1
         return x
 
+    # ---- dilated offset / mask convs in front of the DCNs (model/OTPose.py:168-177, 381-383) ---------------------------
+    def offset_mask_input(self, trans):
+        return trans
+
+    def offset_mask_conv(self, trans, weight, d):
+        return T.conv2d(trans, weight, None, 1, d, d)
+
     # ---- whole forward (model/OTPose.py:307-394) ---------------------------------------------------------------
     def forward(self, x, margin):
         m = self.cfg["MODEL"]
@@ -411,9 +418,10 @@ class TrainGraph:
         out = None
         if self.taps is not None:
             self.taps.update(x1=x1, x2=x2, t1_0=t1[0], t2_0=t2[0], f1=f1, f2=f2, def_h=def_h, trans=trans)
+        trans_in = self.offset_mask_input(trans)
         for i, d in enumerate(dils):
-            off = T.conv2d(trans, self.P[f"offsets_list.{i}.0.weight"], None, 1, d, d)
-            msk = T.conv2d(trans, self.P[f"masks_list.{i}.0.weight"], None, 1, d, d)
+            off = self.offset_mask_conv(trans_in, self.P[f"offsets_list.{i}.0.weight"], d)
+            msk = self.offset_mask_conv(trans_in, self.P[f"masks_list.{i}.0.weight"], d)
             p = f"modulated_deform_conv_list.{i}.deform_conv"
             wrp = ops.modulated_deform_conv(def_h, off, msk, self.P[p + ".weight"], self.P[p + ".bias"], 1, d, d, 1, J)
             out = (1.0 / len(dils)) * wrp if out is None else out + (1.0 / len(dils)) * wrp
@@ -446,6 +454,14 @@ class TrainGraphBF16(TrainGraph):
 
     def hrnet_input(self, x):
         return B16.to_nhwc(x, frame_split=x.shape[0])
+
+    def offset_mask_input(self, trans):
+        """The 32-channel feature map feeds ten dilated 3x3 convs (32 -> 306 / 153): one conversion to NHWC bf16, every
+        conv on the bf16 matrix cores, offsets / masks handed to the DCN as fp32 NCHW."""
+        return B16.to_nhwc_grad(trans)
+
+    def offset_mask_conv(self, trans, weight, d):
+        return B16.conv_out(trans, weight, None, 1, d, d)
 
     def _w4(self, name):
         """(Cout, Cin, 1) Conv1d weight as the (Cout, Cin, 1, 1) view the conv kernels take, gradient slot attached."""

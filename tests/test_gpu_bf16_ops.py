@@ -47,6 +47,8 @@ CONV_CASES = [
     (64, 64, 3, 1, 1, 1, 1, 96, 72),
     (48, 48, 3, 1, 1, 1, 1, 96, 72),
     (256, 64, 1, 1, 0, 1, 1, 96, 72),
+    (32, 153, 3, 1, 15, 15, 1, 96, 72),      # widely dilated offset conv on the full map: tap-mode wgrad, 8-channel chunks
+    (64, 64, 3, 2, 1, 1, 1, 192, 144),       # second stem conv: strided wide map
 ]
 
 
