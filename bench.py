@@ -212,15 +212,23 @@ def golden_parity(model, cfg, dev):
             "tolerance": 1e-3, "vs": "tests/golden/e2e_cfg2_b1.npz (reference model, 1 clip of this config)"}
 
 
-def train_step_probe(cfg, dev, batch, steps=3):
-    """cfg3 of SURVEY.md section 8d in fp32: forward under model.train() (BatchNorm batch statistics, dropout / drop-path),
-    the two ST_OHKW terms, backward through the HIP kernels, fused clip + AdamW.  Reported next to the headline metric;
-    not part of `value`."""
-    from otpose_amd import train as TR
+PEAK_BF16_MATRIX = 2.5e15       # MI355X_MICROARCH.md: dense bf16 MFMA peak
+
+
+def train_step_probe(cfg, dev, batch, dtype="bf16", steps=3, dist=None):
+    """BASELINE configs[2] (1 GPU) / configs[3] (data parallel): one optimisation step as the reference runs it
+    (script/Common.py:118-144) - forward under model.train() (BatchNorm batch statistics, dropout / drop-path), the two
+    ST_OHKW terms with the per-joint flags MAX-reduced over ranks, backward through the HIP kernels, RCCL all-reduce of the
+    flat gradient buffers (world > 1), fused global-norm clip + AdamW on fp32 master weights.  dtype "bf16": backbone,
+    MLP interiors and offset / mask convs on bf16 activations + bf16 matrix cores (fp32 accumulation and statistics).
+    Every rank runs it; the time is the max over ranks.  Reported next to the headline metric, never part of `value`."""
+    from otpose_amd import parallel as PAR
     from otpose_amd.optim import FusedAdamW
+    world = dist.get_world_size() if dist is not None else 1
     model = OTPose(cfg)
-    S.fill_synthetic_(model)
+    S.fill_synthetic_(model)                      # identical seeded replicas
     model = model.to(dev).train()
+    model.train_dtype = dtype
     x, margin = S.synthetic_clip(batch, cfg.MODEL.IMAGE_SIZE)
     x, margin = x.to(dev), margin.to(dev)
     J = cfg.MODEL.NUM_JOINTS
@@ -232,23 +240,37 @@ def train_step_probe(cfg, dev, batch, steps=3):
     opt = FusedAdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4, weight_decay=0.01, max_grad_norm=1.0)
     times = []
     loss = None
+    torch.cuda.reset_peak_memory_stats(dev)
     for it in range(steps + 1):
+        if dist is not None:
+            dist.barrier()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
-        outs = model(x, margin=margin)
-        loss = TR.criterion(outs, g, wt)
-        opt.zero_grad()
-        loss.backward()
-        opt.step()
+        loss = PAR.train_step_dp(model, opt, x, margin, g, wt)
+        if dist is not None:
+            dist.barrier()
         torch.cuda.synchronize(dev)
         if it:
             times.append(time.perf_counter() - t0)
-    t = sorted(times)[len(times) // 2]
-    res = {"ms_per_step": 1e3 * t, "frames_per_s": 5 * batch / t, "batch": batch, "dtype": "f32",
-           "what": "forward (train mode) + 2x ST_OHKW loss + backward + clip + AdamW, median of %d after 1 warm-up" % steps,
+    t = torch.tensor([sorted(times)[len(times) // 2]], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    t = float(t.item())
+    flop = 3.0 * FLOP_PER_CLIP * batch * world               # forward + input gradients + weight gradients
+    res = {"ms_per_step": 1e3 * t, "frames_per_s": 5 * batch * world / t, "clips_per_gpu": batch, "n_gpus": world,
+           "dtype": dtype, "collective": ("RCCL all-reduce of the flat fp32 gradient buffers, world %d" % world) if world > 1
+           else "none (1 GPU)",
+           "what": "forward (train mode) + 2x ST_OHKW loss + backward + grad all-reduce + clip + AdamW, median of %d after "
+                   "1 warm-up, max over ranks" % steps,
            "loss_finite": bool(torch.isfinite(loss.detach()).all()),
-           "peak_mem_GB": torch.cuda.max_memory_allocated(dev) / 2 ** 30}
-    del model, opt, outs, loss
+           "peak_mem_GB": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
+           "roofline": {"bound": "mfma", "achieved": flop / t / 1e12 / world,
+                        "peak": (PEAK_BF16_MATRIX if dtype == "bf16" else PEAK_F32_MATRIX) / 1e12, "unit": "TFLOP/s per GPU",
+                        "frac": flop / t / world / (PEAK_BF16_MATRIX if dtype == "bf16" else PEAK_F32_MATRIX),
+                        "traffic": None,
+                        "note": "algorithmic 3 x 409 GFLOP per clip; at bf16 the step is bound by HBM / L2 traffic and launch "
+                                "latency of ~9000 kernels, not by the matrix pipe (see DESIGN.md section 5)"}}
+    del model, opt, loss
     torch.cuda.empty_cache()
     return res
 
@@ -295,7 +317,12 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="clips per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-step", action="store_true", help="skip the training-step probe (extra field of the line)")
+    ap.add_argument("--train-f32", action="store_true", help="also time the fp32 training step (1 GPU)")
     a = ap.parse_args()
+
+    # stdout carries exactly ONE JSON line: native libraries (RCCL prints a version banner through C stdio) get stderr
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -340,6 +367,14 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     finite = bool(torch.isfinite(outs[0]).all())
+    train = None
+    if not a.no_train_step:
+        del outs
+        model._engine = None                                    # free the inference engine's buffers before the training probe
+        torch.cuda.empty_cache()
+        train = train_step_probe(cfg, dev, a.batch, "bf16", dist=dist)      # every rank takes part (RCCL collectives)
+        if rank == 0:
+            log("training-step probe (bf16, %d GPU) done: %.1f ms" % (world, train["ms_per_step"]))
 
     if rank == 0:
         frames = 5 * a.batch * world * a.steps
@@ -368,12 +403,13 @@ def main():
         line["vs_eager_rocm"] = eager_ratio(1e3 * dt / a.steps / 1.0, a.batch)
         line["parity"] = golden_parity(model, cfg, dev)     # the "heatmap max-abs delta vs ref" half of the metric
         log("golden parity done")
-        if world == 1 and not a.no_train_step:
-            line["train_step"] = train_step_probe(cfg, dev, a.batch)
-            log("training-step probe done: %.1f ms" % line["train_step"]["ms_per_step"])
+        if train is not None:
+            line["train_step"] = train
+        if world == 1 and a.train_f32:
+            line["train_step_f32"] = train_step_probe(cfg, dev, a.batch, "f32")
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=json_out, flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

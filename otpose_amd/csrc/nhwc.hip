@@ -140,6 +140,8 @@ bool make_plan(const otp_nhwc_conv_desc* d, ConvPlan* p) {
     // still leaves >= 4 workgroups per CU to balance; 128-pixel tiles otherwise
     int nb = ((long)d->N * ((npx + 255) / 256) * p->nM >= 1024) ? 4 : 2;
     if (p->MB > 6) nb = 2;                                      // 7-9 M-blocks: 72 accumulator registers at NB = 2
+    static const int nb_env = getenv("OTP_NHWC_NB") ? atoi(getenv("OTP_NHWC_NB")) : 0;      // tuning override (2 or 4)
+    if (nb_env && p->MB <= 6) nb = nb_env;
     // candidates in order of preference; later ones shrink the LDS image (widely dilated taps on wide maps stage many rows)
     if (size_plan(d, p, ck, nb) && (taps > 1 || nb == 2 || p->lds <= 72 * 1024)) return true;
     if (nb == 4 && size_plan(d, p, ck, 2)) return true;
