@@ -30,7 +30,10 @@ extern "C" {
 #define OTP_ERR_LAUNCH (-3)      /* hipGetLastError() != hipSuccess after the launch */
 #define OTP_ERR_WORKSPACE (-4)   /* workspace_bytes too small */
 
-#define OTP_DTYPE_F32 0          /* the reference dispatches f64/f32/f16; f32 is what OTPose uses */
+#define OTP_DTYPE_F32 0          /* what OTPose uses: the fused kernels of mdcn.hip */
+#define OTP_DTYPE_F16 1          /* the reference dispatches f64 / f32 / f16 (AT_DISPATCH_FLOATING_TYPES_AND_HALF,      */
+#define OTP_DTYPE_BF16 2         /* deform_conv_cuda_kernel.cu:719,751,784); f16 / bf16 compute in fp32, f64 in fp64     */
+#define OTP_DTYPE_F64 3
 
 #define OTP_ACT_NONE 0
 #define OTP_ACT_RELU 1
@@ -50,6 +53,15 @@ int otp_mdcn_forward(const void* x, const void* offset, const void* mask, const 
                      int stride, int pad, int dil, int groups, int deformable_groups,
                      float alpha, float beta, int dtype, void* stream);
 
+/* The same operator with the reference's full argument list (deform_conv_cuda.cpp:474-480): independent stride / padding /
+ * dilation per axis; `dtype` selects the storage type of EVERY tensor; mask == NULL is DCN v1 (deform_conv_cuda.cpp:148-249:
+ * no modulation).  otp_mdcn_forward is the isotropic special case.  fp32 3x3 isotropic calls take the fused kernels, everything
+ * else the general form (csrc/mdcn_generic.hip). */
+int otp_mdcn_forward_ex(const void* x, const void* offset, const void* mask, const void* weight, const void* bias, void* out,
+                        int N, int C, int H, int W, int Cout, int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w,
+                        int dil_h, int dil_w, int groups, int deformable_groups, float alpha, float beta, int dtype,
+                        void* stream);
+
 /* grad_x / grad_offset / grad_mask are overwritten, grad_weight / grad_bias are ACCUMULATED into
  * (the reference accumulates them over the batch, cpp:638-650; the caller zeroes them, reference
  * functions/deform_conv.py:152-156).  grad_bias may be NULL.  workspace: otp_mdcn_backward_workspace bytes. */
@@ -60,6 +72,12 @@ int otp_mdcn_backward(const void* x, const void* offset, const void* mask, const
                       int N, int C, int H, int W, int Cout, int kh, int kw,
                       int stride, int pad, int dil, int groups, int deformable_groups,
                       int dtype, void* stream);
+/* full argument list of modulated_deform_conv_cuda_backward (deform_conv_cuda.cpp:551-558) and, with mask == grad_mask ==
+ * NULL, of deform_conv_backward_input_cuda + deform_conv_backward_parameters_cuda (cpp:251-472): any Cout, any kernel. */
+int otp_mdcn_backward_ex(const void* x, const void* offset, const void* mask, const void* weight, const void* grad_out,
+                         void* grad_x, void* grad_offset, void* grad_mask, void* grad_weight, void* grad_bias, void* workspace,
+                         size_t workspace_bytes, int N, int C, int H, int W, int Cout, int kh, int kw, int stride_h, int stride_w,
+                         int pad_h, int pad_w, int dil_h, int dil_w, int groups, int deformable_groups, int dtype, void* stream);
 
 /* ---- dense convolution (implicit GEMM on the f32 matrix cores) --------------------------------
  * out[n, out_coff+co, ho, wo] = act( scale[co] * conv(in (+ in2))[n,co,ho,wo] + shift[co] (+ res) )

@@ -238,18 +238,22 @@ def _mdcn_sample(x, offset, mask, kh, kw, stride, pad, dil, dg):
     (per-corner bounds of the bilinear kernel)."""
     N, C, H, W = x.shape
     K = kh * kw
-    Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) // stride + 1
-    Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) // stride + 1
+    # stride / pad / dil: one int, or (h, w) pairs as the reference's entry points take them (cpp:474-480: stride_h,
+    # stride_w, pad_h, pad_w, dilation_h, dilation_w; used as h_in = h_col * stride_h - pad_h + i * dilation_h, .cu:539-553)
+    pair = lambda v: (v, v) if isinstance(v, int) else tuple(v)                   # noqa: E731
+    (sh, sw), (ph, pw), (dh, dw) = pair(stride), pair(pad), pair(dil)
+    Ho = (H + 2 * ph - (dh * (kh - 1) + 1)) // sh + 1
+    Wo = (W + 2 * pw - (dw * (kw - 1) + 1)) // sw + 1
     cpg = C // dg
     dt = x.dtype
     off = offset.reshape(N, dg, K, 2, Ho, Wo)
     dev = x.device                       # device-agnostic: also run as the eager-GPU timing baseline (tools/)
     ki = torch.arange(K, device=dev) // kw
     kj = torch.arange(K, device=dev) % kw
-    hb = (torch.arange(Ho, device=dev) * stride - pad).to(dt)[None, None, None, :, None]
-    wb = (torch.arange(Wo, device=dev) * stride - pad).to(dt)[None, None, None, None, :]
-    hs = hb + (ki * dil).to(dt)[None, None, :, None, None] + off[:, :, :, 0]     # (N, dg, K, Ho, Wo)
-    ws = wb + (kj * dil).to(dt)[None, None, :, None, None] + off[:, :, :, 1]
+    hb = (torch.arange(Ho, device=dev) * sh - ph).to(dt)[None, None, None, :, None]
+    wb = (torch.arange(Wo, device=dev) * sw - pw).to(dt)[None, None, None, None, :]
+    hs = hb + (ki * dh).to(dt)[None, None, :, None, None] + off[:, :, :, 0]     # (N, dg, K, Ho, Wo)
+    ws = wb + (kj * dw).to(dt)[None, None, :, None, None] + off[:, :, :, 1]
     inside = (hs > -1) & (ws > -1) & (hs < H) & (ws < W)
     h0 = torch.floor(hs)
     w0 = torch.floor(ws)

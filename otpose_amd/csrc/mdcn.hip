@@ -481,15 +481,28 @@ int launch_fwd(const float* x, const float* off, const float* msk, const float* 
 
 }  // namespace
 
-extern "C" int otp_mdcn_forward(const void* x, const void* offset, const void* mask, const void* weight,
-                                const void* bias, void* out, int N, int C, int H, int W, int Cout, int kh,
-                                int kw, int stride, int pad, int dil, int groups, int deformable_groups,
-                                float alpha, float beta, int dtype, void* stream) {
-    if (!x || !offset || !mask || !weight || !out) return OTP_ERR_BAD_ARG;
-    if (dtype != OTP_DTYPE_F32) return OTP_ERR_UNSUPPORTED;
-    Geom g;
-    if (!make_geom(g, N, C, H, W, Cout, kh, kw, stride, pad, dil, groups, deformable_groups)) return OTP_ERR_BAD_ARG;
+// general form (any dtype / kernel / Cout / per-axis geometry, optional mask): mdcn_generic.hip
+int otp_mdcn_generic_forward(const void* x, const void* off, const void* msk, const void* w, const void* bias, void* out, int N,
+                             int C, int H, int W, int Co, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
+                             int groups, int dg, float alpha, float beta, int dtype, hipStream_t st);
+size_t otp_mdcn_generic_backward_workspace(int C, int Co, int kh, int kw, int groups);
+int otp_mdcn_generic_backward(const void* x, const void* off, const void* msk, const void* w, const void* gout, void* gx,
+                              void* goff, void* gmsk, void* gw, void* gb, void* ws, size_t ws_bytes, int N, int C, int H, int W,
+                              int Co, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int groups, int dg,
+                              int dtype, hipStream_t st);
+
+extern "C" int otp_mdcn_forward_ex(const void* x, const void* offset, const void* mask, const void* weight, const void* bias,
+                                   void* out, int N, int C, int H, int W, int Cout, int kh, int kw, int stride_h, int stride_w,
+                                   int pad_h, int pad_w, int dil_h, int dil_w, int groups, int deformable_groups, float alpha,
+                                   float beta, int dtype, void* stream) {
+    if (!x || !offset || !weight || !out) return OTP_ERR_BAD_ARG;
     auto st = static_cast<hipStream_t>(stream);
+    const bool iso = stride_h == stride_w && pad_h == pad_w && dil_h == dil_w;
+    if (dtype != OTP_DTYPE_F32 || !iso || !mask)
+        return otp_mdcn_generic_forward(x, offset, mask, weight, bias, out, N, C, H, W, Cout, kh, kw, stride_h, stride_w, pad_h,
+                                        pad_w, dil_h, dil_w, groups, deformable_groups, alpha, beta, dtype, st);
+    Geom g;
+    if (!make_geom(g, N, C, H, W, Cout, kh, kw, stride_h, pad_h, dil_h, groups, deformable_groups)) return OTP_ERR_BAD_ARG;
     auto xf = static_cast<const float*>(x);
     auto of = static_cast<const float*>(offset);
     auto mf = static_cast<const float*>(mask);
@@ -497,28 +510,51 @@ extern "C" int otp_mdcn_forward(const void* x, const void* offset, const void* m
     auto bf = static_cast<const float*>(bias);
     auto outf = static_cast<float*>(out);
     const bool k9 = (kh == 3 && kw == 3);
-    if (k9 && Cout == 17) return launch_fwd<17, 1, true>(xf, of, mf, wf, bf, outf, g, alpha, beta, st);
-    if (k9) return launch_fwd<16, 1, true>(xf, of, mf, wf, bf, outf, g, alpha, beta, st);
-    return launch_fwd<16, 1, false>(xf, of, mf, wf, bf, outf, g, alpha, beta, st);
+    int rc;
+    if (k9 && Cout == 17) rc = launch_fwd<17, 1, true>(xf, of, mf, wf, bf, outf, g, alpha, beta, st);
+    else if (k9) rc = launch_fwd<16, 1, true>(xf, of, mf, wf, bf, outf, g, alpha, beta, st);
+    else rc = launch_fwd<16, 1, false>(xf, of, mf, wf, bf, outf, g, alpha, beta, st);
+    if (rc == OTP_ERR_UNSUPPORTED)            // e.g. the transposed weights of a wide layer do not fit LDS: general form
+        rc = otp_mdcn_generic_forward(x, offset, mask, weight, bias, out, N, C, H, W, Cout, kh, kw, stride_h, stride_w, pad_h,
+                                      pad_w, dil_h, dil_w, groups, deformable_groups, alpha, beta, dtype, st);
+    return rc;
 }
 
-extern "C" size_t otp_mdcn_backward_workspace(int, int, int, int, int, int, int) { return 0; }
+extern "C" int otp_mdcn_forward(const void* x, const void* offset, const void* mask, const void* weight,
+                                const void* bias, void* out, int N, int C, int H, int W, int Cout, int kh,
+                                int kw, int stride, int pad, int dil, int groups, int deformable_groups,
+                                float alpha, float beta, int dtype, void* stream) {
+    return otp_mdcn_forward_ex(x, offset, mask, weight, bias, out, N, C, H, W, Cout, kh, kw, stride, stride, pad, pad, dil, dil,
+                               groups, deformable_groups, alpha, beta, dtype, stream);
+}
 
-extern "C" int otp_mdcn_backward(const void* x, const void* offset, const void* mask, const void* weight,
-                                 const void* grad_out, void* grad_x, void* grad_offset, void* grad_mask,
-                                 void* grad_weight, void* grad_bias, void* /*workspace*/, size_t /*workspace_bytes*/,
-                                 int N, int C, int H, int W, int Cout, int kh, int kw, int stride, int pad,
-                                 int dil, int groups, int deformable_groups, int dtype, void* stream) {
-    if (!x || !offset || !mask || !weight || !grad_out || !grad_x || !grad_offset || !grad_mask || !grad_weight)
-        return OTP_ERR_BAD_ARG;
-    if (dtype != OTP_DTYPE_F32) return OTP_ERR_UNSUPPORTED;
-    Geom g;
-    if (!make_geom(g, N, C, H, W, Cout, kh, kw, stride, pad, dil, groups, deformable_groups)) return OTP_ERR_BAD_ARG;
-    if (kh != 3 || kw != 3 || Cout > 17) return OTP_ERR_UNSUPPORTED;   // OTPose uses 3x3, 17 -> 17
-    constexpr int CO_T = 17, COP = 20, K = 9;
-    size_t lds = ((size_t)2 * g.plane + K * COP + 4 * CO_T) * sizeof(float);
-    if (lds > OTP_LDS_LIMIT) return OTP_ERR_UNSUPPORTED;
+extern "C" size_t otp_mdcn_backward_workspace(int N, int C, int H, int W, int Cout, int kh, int kw) {
+    (void)N, (void)H, (void)W;
+    return otp_mdcn_generic_backward_workspace(C, Cout, kh, kw, 1);      // groups = 1 is the largest case
+}
+
+extern "C" int otp_mdcn_backward_ex(const void* x, const void* offset, const void* mask, const void* weight,
+                                    const void* grad_out, void* grad_x, void* grad_offset, void* grad_mask, void* grad_weight,
+                                    void* grad_bias, void* workspace, size_t workspace_bytes, int N, int C, int H, int W,
+                                    int Cout, int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h,
+                                    int dil_w, int groups, int deformable_groups, int dtype, void* stream) {
+    if (!x || !offset || !weight || !grad_out || !grad_x || !grad_offset || !grad_weight) return OTP_ERR_BAD_ARG;
+    if (mask && !grad_mask) return OTP_ERR_BAD_ARG;
     auto st = static_cast<hipStream_t>(stream);
+    const bool iso = stride_h == stride_w && pad_h == pad_w && dil_h == dil_w;
+    Geom g;
+    bool fast = dtype == OTP_DTYPE_F32 && iso && mask && kh == 3 && kw == 3 && Cout <= 17 &&
+                make_geom(g, N, C, H, W, Cout, kh, kw, stride_h, pad_h, dil_h, groups, deformable_groups);
+    constexpr int CO_T = 17, COP = 20, K = 9;
+    size_t lds = 0;
+    if (fast) {
+        lds = ((size_t)2 * g.plane + K * COP + 4 * CO_T) * sizeof(float);
+        fast = lds <= OTP_LDS_LIMIT;
+    }
+    if (!fast)
+        return otp_mdcn_generic_backward(x, offset, mask, weight, grad_out, grad_x, grad_offset, grad_mask, grad_weight, grad_bias,
+                                         workspace, workspace_bytes, N, C, H, W, Cout, kh, kw, stride_h, stride_w, pad_h, pad_w,
+                                         dil_h, dil_w, groups, deformable_groups, dtype, st);
     // pixel chunks: enough workgroups to fill 256 CUs a few times over
     int wgs = N * deformable_groups;
     int S = 1;
@@ -537,4 +573,14 @@ extern "C" int otp_mdcn_backward(const void* x, const void* offset, const void* 
                        static_cast<float*>(grad_offset), static_cast<float*>(grad_mask),
                        static_cast<float*>(grad_weight), static_cast<float*>(grad_bias), g, chunk, atomic_gx);
     return otp_launch_status();
+}
+
+extern "C" int otp_mdcn_backward(const void* x, const void* offset, const void* mask, const void* weight,
+                                 const void* grad_out, void* grad_x, void* grad_offset, void* grad_mask,
+                                 void* grad_weight, void* grad_bias, void* workspace, size_t workspace_bytes,
+                                 int N, int C, int H, int W, int Cout, int kh, int kw, int stride, int pad,
+                                 int dil, int groups, int deformable_groups, int dtype, void* stream) {
+    return otp_mdcn_backward_ex(x, offset, mask, weight, grad_out, grad_x, grad_offset, grad_mask, grad_weight, grad_bias,
+                                workspace, workspace_bytes, N, C, H, W, Cout, kh, kw, stride, stride, pad, pad, dil, dil, groups,
+                                deformable_groups, dtype, stream);
 }

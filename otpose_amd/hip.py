@@ -44,6 +44,8 @@ _ND = ctypes.POINTER(NhwcConvDesc)
 SIGNATURES = {
     "otp_version": (c_int, []),
     "otp_mdcn_forward": (c_int, [c_void_p] * 6 + [c_int] * 12 + [c_float, c_float, c_int, c_void_p]),
+    "otp_mdcn_forward_ex": (c_int, [c_void_p] * 6 + [c_int] * 15 + [c_float, c_float, c_int, c_void_p]),
+    "otp_mdcn_backward_ex": (c_int, [c_void_p] * 10 + [c_void_p, c_size_t] + [c_int] * 15 + [c_int, c_void_p]),
     "otp_mdcn_backward_workspace": (c_size_t, [c_int] * 7),
     "otp_mdcn_backward": (c_int, [c_void_p] * 10 + [c_void_p, c_size_t] + [c_int] * 12 + [c_int, c_void_p]),
     "otp_conv2d_pack_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

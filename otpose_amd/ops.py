@@ -36,19 +36,35 @@ def _out_hw(h, w, kh, kw, stride, pad, dil):
             (w + 2 * pad - (dil * (kw - 1) + 1)) // stride + 1)
 
 
+_DTYPES = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2, torch.float64: 3}
+
+
+def _dcn_dtype(*tensors):
+    """Storage type code of a DCN call: every tensor must share one of the types the operator is instantiated for
+    (the reference dispatches double / float / half, deform_conv_cuda_kernel.cu:719,751,784; bf16 is an addition)."""
+    ts = [t for t in tensors if t is not None]
+    dt = ts[0].dtype
+    if dt not in _DTYPES:
+        raise RuntimeError(f"deformable convolution is not implemented for {dt}")
+    for t in ts:
+        if t.dtype != dt:
+            raise RuntimeError(f"deformable convolution: mixed dtypes {dt} / {t.dtype}")
+    return _DTYPES[dt]
+
+
 def modulated_deform_conv_cuda_forward(input, weight, bias, ones, offset, mask, output, columns,
                                        kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w,
                                        dilation_h, dilation_w, group, deformable_group, with_bias):
     """In-place forward with the reference pybind signature (deform_conv_cuda.cpp:474-480).
-    ``ones`` and ``columns`` are accepted and ignored: the fused kernel needs no im2col scratch."""
+    ``ones`` and ``columns`` are accepted and ignored: the fused kernel needs no im2col scratch.
+    ``mask = None`` runs DCN v1 (no modulation) on the same kernels."""
     _require_gpu(input, weight, offset, mask, output)
-    _check_f32(input, weight, offset, mask, output)
+    b = bias if with_bias else None
+    dtype = _dcn_dtype(input, weight, offset, mask, output, b)
     if not input.is_contiguous():
         raise RuntimeError("input tensor has to be contiguous")
     if not weight.is_contiguous():
         raise RuntimeError("weight tensor has to be contiguous")
-    if stride_h != stride_w or pad_h != pad_w or dilation_h != dilation_w:
-        raise RuntimeError("otp_mdcn_forward: anisotropic stride/pad/dilation is not supported")
     n, c, h, w = input.shape
     cout, cpg, kh_, kw_ = weight.shape
     if (kh_, kw_) != (kernel_h, kernel_w):
@@ -56,12 +72,11 @@ def modulated_deform_conv_cuda_forward(input, weight, bias, ones, offset, mask, 
     if c != cpg * group:
         raise RuntimeError(f"Input shape and kernel channels wont match: ({c} vs {cpg * group}).")
     offset = offset.contiguous()
-    mask = mask.contiguous()
-    b = bias if with_bias else None
-    st = hip.lib().otp_mdcn_forward(
+    mask = mask.contiguous() if mask is not None else None
+    st = hip.lib().otp_mdcn_forward_ex(
         hip.ptr(input), hip.ptr(offset), hip.ptr(mask), hip.ptr(weight), hip.ptr(b), hip.ptr(output),
-        n, c, h, w, cout, kernel_h, kernel_w, stride_h, pad_h, dilation_h, group, deformable_group,
-        1.0, 0.0, _DTYPE_F32, hip.stream_of(input))
+        n, c, h, w, cout, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, group,
+        deformable_group, 1.0, 0.0, dtype, hip.stream_of(input))
     hip.check(st, "otp_mdcn_forward")
 
 
@@ -71,29 +86,28 @@ def modulated_deform_conv_cuda_backward(input, weight, bias, ones, offset, mask,
                                         pad_w, dilation_h, dilation_w, group, deformable_group, with_bias):
     """In-place backward with the reference pybind signature (deform_conv_cuda.cpp:551-558).
     grad_input/grad_offset/grad_mask are overwritten; grad_weight/grad_bias are accumulated into
-    (the reference accumulates them over the batch with addmm_, cpp:638-650)."""
+    (the reference accumulates them over the batch with addmm_, cpp:638-650).  ``mask = grad_mask = None``: DCN v1."""
     _require_gpu(input, weight, offset, mask, grad_output)
-    _check_f32(input, weight, offset, mask, grad_output)
+    gb = grad_bias if with_bias else None
+    dtype = _dcn_dtype(input, weight, offset, mask, grad_output, grad_input, grad_weight, grad_offset, grad_mask, gb)
     if not input.is_contiguous():
         raise RuntimeError("input tensor has to be contiguous")
     if not weight.is_contiguous():
         raise RuntimeError("weight tensor has to be contiguous")
-    if stride_h != stride_w or pad_h != pad_w or dilation_h != dilation_w:
-        raise RuntimeError("otp_mdcn_backward: anisotropic stride/pad/dilation is not supported")
     n, c, h, w = input.shape
     cout = weight.shape[0]
     offset = offset.contiguous()
-    mask = mask.contiguous()
+    mask = mask.contiguous() if mask is not None else None
     grad_output = grad_output.contiguous()
     L = hip.lib()
     ws_bytes = L.otp_mdcn_backward_workspace(n, c, h, w, cout, kernel_h, kernel_w)
-    ws = torch.empty(max(int(ws_bytes), 4) // 4, dtype=torch.float32, device=input.device)
-    st = L.otp_mdcn_backward(
+    ws = torch.empty(max(int(ws_bytes), 8) // 8, dtype=torch.float64, device=input.device)
+    st = L.otp_mdcn_backward_ex(
         hip.ptr(input), hip.ptr(offset), hip.ptr(mask), hip.ptr(weight), hip.ptr(grad_output),
         hip.ptr(grad_input), hip.ptr(grad_offset), hip.ptr(grad_mask), hip.ptr(grad_weight),
-        hip.ptr(grad_bias if with_bias else None), hip.ptr(ws), ws_bytes,
-        n, c, h, w, cout, kernel_h, kernel_w, stride_h, pad_h, dilation_h, group, deformable_group,
-        _DTYPE_F32, hip.stream_of(input))
+        hip.ptr(gb), hip.ptr(ws), ws_bytes,
+        n, c, h, w, cout, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, group,
+        deformable_group, dtype, hip.stream_of(input))
     hip.check(st, "otp_mdcn_backward")
 
 
@@ -146,51 +160,31 @@ modulated_deform_conv = ModulatedDeformConvFunction.apply
 
 # ---- DCN v1 (no modulation mask, no bias): the other three entry points of the reference's pybind module ----------
 # The v1 kernels sample exactly like the modulated ones (same (-1, H) x (-1, W) window and corner tests:
-# deform_conv_cuda_kernel.cu:22-51,166 vs :403-432,549), so they run on the same HIP kernels with an all-ones mask.
-_ONES = {}
-
-
-def _ones_mask(like, n, ch, h, w):
-    key = (like.device, n, ch, h, w)
-    t = _ONES.get(key)
-    if t is None:
-        _ONES.clear()                      # one shape at a time: the mask is scratch, not state
-        t = _ONES[key] = torch.ones((n, ch, h, w), dtype=torch.float32, device=like.device)
-    return t
-
-
-def _v1_check(dW, dH, padW, padH, dilationW, dilationH):
-    if dW != dH or padW != padH or dilationW != dilationH:
-        raise RuntimeError("deform_conv: anisotropic stride/pad/dilation is not supported")
-
-
+# deform_conv_cuda_kernel.cu:22-51,166 vs :403-432,549), so they are the same HIP operator with mask == NULL: no mask
+# stream is read and no mask gradient is written.
 def deform_conv_forward_cuda(input, weight, offset, output, columns, ones, kW, kH, dW, dH, padW, padH, dilationW,
                              dilationH, group, deformable_group, im2col_step):
     """Reference pybind signature deform_conv_cuda.cpp:148-153 (returns 1).  ``columns`` / ``ones`` / ``im2col_step``
     are accepted and ignored: there is no im2col scratch and every image is one launch."""
-    _v1_check(dW, dH, padW, padH, dilationW, dilationH)
-    n = input.shape[0]
-    mask = _ones_mask(input, n, deformable_group * kH * kW, output.shape[2], output.shape[3])
-    modulated_deform_conv_cuda_forward(input, weight, None, None, offset, mask, output, None, kH, kW, dH, dW, padH, padW,
+    modulated_deform_conv_cuda_forward(input, weight, None, None, offset, None, output, None, kH, kW, dH, dW, padH, padW,
                                        dilationH, dilationW, group, deformable_group, False)
     return 1
 
 
-def _v1_backward(input, offset, grad_output, weight, kW, kH, dH, padH, dilationH, group, deformable_group):
-    n = input.shape[0]
-    mask = _ones_mask(input, n, deformable_group * kH * kW, grad_output.shape[2], grad_output.shape[3])
-    gi, go, gm = torch.empty_like(input), torch.empty_like(offset), torch.empty_like(mask)
+def _v1_backward(input, offset, grad_output, weight, kW, kH, dW, dH, padW, padH, dilationW, dilationH, group,
+                 deformable_group):
+    gi, go = torch.empty_like(input), torch.empty_like(offset)
     gw = torch.zeros_like(weight)
-    modulated_deform_conv_cuda_backward(input, weight, None, None, offset, mask, None, gi, gw, None, go, gm, grad_output,
-                                        kH, kW, dH, dH, padH, padH, dilationH, dilationH, group, deformable_group, False)
+    modulated_deform_conv_cuda_backward(input, weight, None, None, offset, None, None, gi, gw, None, go, None, grad_output,
+                                        kH, kW, dH, dW, padH, padW, dilationH, dilationW, group, deformable_group, False)
     return gi, go, gw
 
 
 def deform_conv_backward_input_cuda(input, offset, gradOutput, gradInput, gradOffset, weight, columns, kW, kH, dW, dH,
                                     padW, padH, dilationW, dilationH, group, deformable_group, im2col_step):
     """Reference pybind signature deform_conv_cuda.cpp:251-257: overwrites gradInput / gradOffset (returns 1)."""
-    _v1_check(dW, dH, padW, padH, dilationW, dilationH)
-    gi, go, _ = _v1_backward(input, offset, gradOutput, weight, kW, kH, dH, padH, dilationH, group, deformable_group)
+    gi, go, _ = _v1_backward(input, offset, gradOutput, weight, kW, kH, dW, dH, padW, padH, dilationW, dilationH, group,
+                             deformable_group)
     gradInput.copy_(gi)
     gradOffset.copy_(go)
     return 1
@@ -199,10 +193,9 @@ def deform_conv_backward_input_cuda(input, offset, gradOutput, gradInput, gradOf
 def deform_conv_backward_parameters_cuda(input, offset, gradOutput, gradWeight, columns, ones, kW, kH, dW, dH, padW, padH,
                                          dilationW, dilationH, group, deformable_group, scale, im2col_step):
     """Reference pybind signature deform_conv_cuda.cpp:364-370: gradWeight += scale * dL/dW (returns 1)."""
-    _v1_check(dW, dH, padW, padH, dilationW, dilationH)
     # dL/dW does not depend on W; the input / offset gradients computed alongside are discarded
-    _, _, gw = _v1_backward(input, offset, gradOutput, torch.zeros_like(gradWeight), kW, kH, dH, padH, dilationH, group,
-                            deformable_group)
+    _, _, gw = _v1_backward(input, offset, gradOutput, torch.zeros_like(gradWeight), kW, kH, dW, dH, padW, padH, dilationW,
+                            dilationH, group, deformable_group)
     gradWeight.add_(gw, alpha=float(scale))
     return 1
 
@@ -234,8 +227,8 @@ class DeformConvFunction(Function):
             raise NotImplementedError
         input, offset, weight = ctx.saved_tensors
         kh, kw = weight.shape[2:4]
-        gi, go, gw = _v1_backward(input.contiguous(), offset, grad_output, weight.contiguous(), kw, kh, ctx.stride,
-                                  ctx.padding, ctx.dilation, ctx.groups, ctx.deformable_groups)
+        gi, go, gw = _v1_backward(input.contiguous(), offset, grad_output, weight.contiguous(), kw, kh, ctx.stride, ctx.stride,
+                                  ctx.padding, ctx.padding, ctx.dilation, ctx.dilation, ctx.groups, ctx.deformable_groups)
         return gi, go, gw, None, None, None, None, None, None
 
 

@@ -177,3 +177,87 @@ def test_dcn_v1_matches_oracle(case):
     ops.deform_conv_backward_parameters_cuda(xs.detach(), offs.detach(), go.cuda(), gw, None, None, k, k, stride, stride,
                                              pad, pad, dil, dil, groups, dg, 0.5, 1)
     _close(gw, 1.0 + 0.5 * wr.grad, 1e-4)
+
+
+# ---- the general operator (csrc/mdcn_generic.hip): every case the reference's entry points accept -------------------
+GENERAL = [  # N, C, H, W, Co, kh, kw, (sh, sw), (ph, pw), (dh, dw), groups, dg
+    (1, 20, 10, 12, 40, 3, 3, (1, 1), (1, 1), (1, 1), 1, 4),        # backward with Cout 40 (three 16-channel passes)
+    (2, 8, 9, 7, 64, 3, 3, (1, 1), (2, 2), (2, 2), 2, 2),           # Cout 64, conv groups 2
+    (2, 6, 8, 9, 5, 1, 1, (1, 1), (0, 0), (1, 1), 1, 3),            # 1x1 kernel backward
+    (1, 4, 11, 10, 6, 5, 5, (1, 1), (2, 2), (1, 1), 1, 2),          # 5x5 kernel backward
+    (1, 6, 12, 10, 4, 3, 3, (2, 1), (1, 2), (1, 2), 1, 3),          # independent stride / padding / dilation per axis
+    (1, 4, 9, 9, 4, 3, 2, (1, 1), (1, 0), (1, 1), 1, 1),            # non-square kernel
+]
+
+
+def _general_inputs(case, dtype=torch.float64):
+    N, C, H, W, Co, kh, kw, (sh, sw), (ph, pw), (dh, dw), groups, dg = case
+    Ho = (H + 2 * ph - (dh * (kh - 1) + 1)) // sh + 1
+    Wo = (W + 2 * pw - (dw * (kw - 1) + 1)) // sw + 1
+    x = seeded((N, C, H, W), 1).to(dtype)
+    off = seeded((N, dg * 2 * kh * kw, Ho, Wo), 2, 2.0).to(dtype)
+    m = seeded((N, dg * kh * kw, Ho, Wo), 3).to(dtype)
+    w = seeded((Co, C // groups, kh, kw), 4, 0.3).to(dtype)
+    b = seeded((Co,), 5).to(dtype)
+    go = seeded((N, Co, Ho, Wo), 6).to(dtype)
+    return x, off, m, w, b, go
+
+
+def _run_general(case, tensors, with_mask=True):
+    """Forward + backward through the pybind-named entry points (full per-axis argument lists, cpp:474-480, 551-558)."""
+    N, C, H, W, Co, kh, kw, (sh, sw), (ph, pw), (dh, dw), groups, dg = case
+    x, off, m, w, b, go = (t.cuda() for t in tensors)
+    out = torch.empty_like(go)
+    mm = m if with_mask else None
+    ops.modulated_deform_conv_cuda_forward(x, w, b if with_mask else None, None, off, mm, out, None, kh, kw, sh, sw, ph, pw,
+                                           dh, dw, groups, dg, with_mask)
+    gx, goff, gm = torch.empty_like(x), torch.empty_like(off), (torch.empty_like(m) if with_mask else None)
+    gw, gb = torch.zeros_like(w), torch.zeros_like(b)
+    ops.modulated_deform_conv_cuda_backward(x, w, b if with_mask else None, None, off, mm, None, gx, gw,
+                                            gb if with_mask else None, goff, gm, go, kh, kw, sh, sw, ph, pw, dh, dw, groups, dg,
+                                            with_mask)
+    return out, gx, goff, gm, gw, gb
+
+
+def _reference_general(case, tensors, with_mask=True):
+    N, C, H, W, Co, kh, kw, s_, p_, d_, groups, dg = case
+    x, off, m, w, b, go = (t.double().clone() for t in tensors)
+    for t in (x, off, m, w, b):
+        t.requires_grad_()
+    mm = m if with_mask else torch.ones_like(m)
+    out = O.mdcn_forward(x, off, mm, w, b if with_mask else None, s_, p_, d_, groups, dg)
+    out.backward(go)
+    return out.detach(), x.grad, off.grad, m.grad if with_mask else None, w.grad, b.grad if with_mask else None
+
+
+@pytest.mark.parametrize("case", GENERAL)
+def test_general_operator_fp32_matches_oracle_autograd(case):
+    t = _general_inputs(case, torch.float32)
+    got = _run_general(case, t)
+    ref = _reference_general(case, t)
+    for g_, r_ in zip(got, ref):
+        _close(g_.double().cpu(), r_, 1e-4)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-10), (torch.float16, 2e-2), (torch.bfloat16, 8e-2)])
+def test_general_operator_dtypes(dtype, tol):
+    """The storage types of the reference's dispatch (f64 / f32 / f16, .cu:719,751,784) and bf16: same inputs rounded to the
+    storage type on both sides, fp64 oracle; the tolerance is the storage type's rounding of the OUTPUT tensors."""
+    case = GENERAL[0]
+    t = tuple(v.to(dtype) for v in _general_inputs(case, torch.float64))
+    got = _run_general(case, t)
+    ref = _reference_general(case, t)
+    for g_, r_ in zip(got, ref):
+        assert g_.dtype == dtype
+        _close(g_.double().cpu(), r_, tol)
+
+
+def test_dcn_v1_runs_without_a_mask_stream():
+    """mask = None: no modulation tensor is read or written (deform_conv_cuda.cpp:148-472), any kernel / Cout."""
+    case = GENERAL[3]
+    t = _general_inputs(case, torch.float32)
+    got = _run_general(case, t, with_mask=False)
+    ref = _reference_general(case, t, with_mask=False)
+    for g_, r_ in zip(got, ref):
+        if r_ is not None:
+            _close(g_.double().cpu(), r_, 1e-4)
