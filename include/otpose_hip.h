@@ -363,12 +363,14 @@ int otp_nhwc_wgrad_bf16(const void* x, const void* grad_out, void* grad_weight, 
                         const otp_nhwc_conv_desc* desc, void* stream);
 /* BatchNorm2d with batch statistics (nn.BatchNorm2d in training mode, model/HRNet.py:500-571): the conv's per-tile sums
  * -> mean / rstd / scale = gamma*rstd / shift = beta - mean*scale (C-padded arrays of CS floats) and the running
- * statistics update; y = act(x*scale + shift (+ res)); backward in two passes (sums of g and g*xhat, then gx / gres). */
+ * statistics update; y = act(x*scale + shift (+ res)); backward in two passes (sums of g and g*xhat, then gx / gres).
+ * relu_mask (may be NULL): one bit per element (one byte per 8-channel group, pixels * CS / 8 bytes) = y > 0, which is all
+ * the backward needs of y; otp_nhwc_bn_backward takes either y (relu = 1) or that mask (relu = 2) in its `y` argument. */
 int otp_nhwc_bn_finalize(const void* partials, int rows, int C, int CS, float count, const void* gamma, const void* beta,
                          void* mean, void* rstd, void* scale, void* shift, void* running_mean, void* running_var, float eps,
                          float momentum, void* stream);
-int otp_nhwc_bn_apply(const void* x, const void* scale, const void* shift, const void* res, void* y, size_t pixels, int CS,
-                      int relu, void* stream);
+int otp_nhwc_bn_apply(const void* x, const void* scale, const void* shift, const void* res, void* y, void* relu_mask,
+                      size_t pixels, int CS, int relu, void* stream);
 size_t otp_nhwc_bn_backward_workspace(size_t pixels, int CS);
 int otp_nhwc_bn_backward(const void* gy, const void* y, const void* x, const void* mean, const void* rstd, const void* gamma,
                          void* gx, void* gres, void* dgamma, void* dbeta, void* workspace, size_t workspace_bytes,

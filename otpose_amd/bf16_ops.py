@@ -159,12 +159,15 @@ def bn_finalize(stats, rows, c, count, gamma, beta, running_mean, running_var, m
     return vec
 
 
-def bn_apply(x, scale, shift, res, relu):
+def bn_apply(x, scale, shift, res, relu, want_mask=False):
+    """y = act(x*scale + shift (+ res)); with ``want_mask`` also the ReLU bit mask (1 bit per element) the backward reads
+    instead of y (1/16 of its bytes)."""
     y = torch.empty_like(x)
     pixels = x.numel() // x.shape[-1]
-    hip.check(hip.lib().otp_nhwc_bn_apply(hip.ptr(x), hip.ptr(scale), hip.ptr(shift), hip.ptr(res), hip.ptr(y), pixels,
-                                          x.shape[-1], int(relu), hip.stream_of(x)), "otp_nhwc_bn_apply")
-    return y
+    mask = torch.empty(x.numel() // 8, dtype=torch.uint8, device=x.device) if (want_mask and relu) else None
+    hip.check(hip.lib().otp_nhwc_bn_apply(hip.ptr(x), hip.ptr(scale), hip.ptr(shift), hip.ptr(res), hip.ptr(y), hip.ptr(mask),
+                                          pixels, x.shape[-1], int(relu), hip.stream_of(x)), "otp_nhwc_bn_apply")
+    return (y, mask) if want_mask else y
 
 
 def bn_backward(gy, y, x, mean, rstd, gamma, c, relu, want_res, out_gamma=None, out_beta=None):
@@ -179,7 +182,8 @@ def bn_backward(gy, y, x, mean, rstd, gamma, c, relu, want_res, out_gamma=None, 
     db = out_beta if out_beta is not None else _new((c,), torch.float32, x)
     hip.check(L.otp_nhwc_bn_backward(hip.ptr(gy), hip.ptr(y), hip.ptr(x), hip.ptr(mean), hip.ptr(rstd), hip.ptr(gamma),
                                      hip.ptr(gx), hip.ptr(gres), hip.ptr(dg), hip.ptr(db), hip.ptr(ws), nbytes, pixels, c, csz,
-                                     int(relu), hip.stream_of(x)), "otp_nhwc_bn_backward")
+                                     (2 if y.dtype == torch.uint8 else 1) if relu else 0, hip.stream_of(x)),
+              "otp_nhwc_bn_backward")
     return gx, gres, dg, db
 
 
@@ -196,8 +200,8 @@ class ConvBnFunction(Function):
         count = c.numel() // c.shape[-1]
         vec = bn_finalize(stats, rows, cout, count, gamma, beta, running_mean, running_var, momentum, eps)
         r = res.contiguous() if res is not None else None
-        y = bn_apply(c, vec[2], vec[3], r, relu)
-        ctx.save_for_backward(x, weight, gamma, c, y if relu else None, vec)
+        y, mask = bn_apply(c, vec[2], vec[3], r, relu, want_mask=True)
+        ctx.save_for_backward(x, weight, gamma, c, mask, vec)
         ctx.cfg = (stride, pad, relu, res is not None)
         ctx.params = (weight, gamma, beta)             # gradient slots are looked up at backward time
         return y

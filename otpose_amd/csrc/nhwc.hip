@@ -838,30 +838,38 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
 }
 
 // y = act(x*scale[c] + shift[c] (+ res)); 8 channels per thread
+template <bool HAS_RES>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16* __restrict__ x, const float* __restrict__ scale,
                                                         const float* __restrict__ shift, const bf16* __restrict__ res,
-                                                        bf16* __restrict__ y, size_t units, int C8, int relu) {
+                                                        bf16* __restrict__ y, unsigned char* __restrict__ mask, size_t units,
+                                                        int C8, int relu) {
     for (size_t u = blockIdx.x * (size_t)blockDim.x + threadIdx.x; u < units; u += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(u % C8) * 8;
         const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + u * 8);
         bf16x8 r8;
-        if (res) r8 = *reinterpret_cast<const bf16x8*>(res + u * 8);
+        if constexpr (HAS_RES) r8 = *reinterpret_cast<const bf16x8*>(res + u * 8);
         const f32x4 sa = *reinterpret_cast<const f32x4*>(scale + c), sb = *reinterpret_cast<const f32x4*>(scale + c + 4);
         const f32x4 ha = *reinterpret_cast<const f32x4*>(shift + c), hb = *reinterpret_cast<const f32x4*>(shift + c + 4);
         bf16x8 o;
+        unsigned bits = 0;                                     // ReLU mask of the 8 channels (1 bit each): what backward needs of y
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float f = bf2f(v[j]) * (j < 4 ? sa[j] : sb[j - 4]) + (j < 4 ? ha[j] : hb[j - 4]);
-            if (res) f += bf2f(r8[j]);
-            if (relu) f = fmaxf(f, 0.f);
+            if constexpr (HAS_RES) f += bf2f(r8[j]);
+            if (relu) {
+                bits |= (f > 0.f ? 1u : 0u) << j;
+                f = fmaxf(f, 0.f);
+            }
             o[j] = (bf16)f;
         }
         *reinterpret_cast<bf16x8*>(y + u * 8) = o;
+        if (mask) mask[u] = (unsigned char)bits;
     }
 }
 
 // backward pass 1: per-workgroup partial sums of g and g*xhat over a pixel range, g = gy * (y > 0 when relu)
 // threads: (pixel lane pl, channel group cg); partial rows [wg][2][C]
+template <int RELU>    // 0: no activation, 1: y tensor, 2: bit mask (compile time: a runtime branch around a load makes hipcc drain every outstanding load)
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16* __restrict__ gy, const bf16* __restrict__ y,
                                                              const bf16* __restrict__ x, const float* __restrict__ mean,
                                                              const float* __restrict__ rstd, float* __restrict__ part,
@@ -884,11 +892,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16* __restri
             const bf16x8 g8 = *reinterpret_cast<const bf16x8*>(gy + o);
             const bf16x8 x8 = *reinterpret_cast<const bf16x8*>(x + o);
             bf16x8 y8;
-            if (relu) y8 = *reinterpret_cast<const bf16x8*>(y + o);
+            unsigned bits = 0xffu;
+            if constexpr (RELU == 1) y8 = *reinterpret_cast<const bf16x8*>(y + o);
+            if constexpr (RELU == 2) bits = reinterpret_cast<const unsigned char*>(y)[px * C8 + cg];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 float g = bf2f(g8[j]);
-                if (relu && !(bf2f(y8[j]) > 0.f)) g = 0.f;
+                if constexpr (RELU == 1) { if (!(bf2f(y8[j]) > 0.f)) g = 0.f; }
+                if constexpr (RELU == 2) { if (!((bits >> j) & 1u)) g = 0.f; }
                 s1[j] += g;
                 s2[j] += g * (bf2f(x8[j]) - mu[j]) * rs[j];
             }
@@ -949,6 +960,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     }
 }
 
+template <int RELU>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16* __restrict__ gy, const bf16* __restrict__ y,
                                                             const bf16* __restrict__ x, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const float* __restrict__ coef,
@@ -960,12 +972,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16* __restric
         const bf16x8 g8 = *reinterpret_cast<const bf16x8*>(gy + u * 8);
         const bf16x8 x8 = *reinterpret_cast<const bf16x8*>(x + u * 8);
         bf16x8 y8;
-        if (relu) y8 = *reinterpret_cast<const bf16x8*>(y + u * 8);
+        unsigned bits = 0xffu;
+        if constexpr (RELU == 1) y8 = *reinterpret_cast<const bf16x8*>(y + u * 8);
+        if constexpr (RELU == 2) bits = reinterpret_cast<const unsigned char*>(y)[u];
         bf16x8 o, gr;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float g = bf2f(g8[j]);
-            if (relu && !(bf2f(y8[j]) > 0.f)) g = 0.f;
+            if constexpr (RELU == 1) { if (!(bf2f(y8[j]) > 0.f)) g = 0.f; }
+            if constexpr (RELU == 2) { if (!((bits >> j) & 1u)) g = 0.f; }
             const float xh = (bf2f(x8[j]) - mean[c + j]) * rstd[c + j];
             o[j] = (bf16)(coef[c + j] * (g - coef[C + c + j] - xh * coef[2 * C + c + j]));
             gr[j] = (bf16)g;
@@ -1285,13 +1300,18 @@ extern "C" int otp_nhwc_bn_finalize(const void* partials, int rows, int C, int C
     return otp_launch_status();
 }
 
-extern "C" int otp_nhwc_bn_apply(const void* x, const void* scale, const void* shift, const void* res, void* y, size_t pixels,
-                                 int CS, int relu, void* stream) {
+extern "C" int otp_nhwc_bn_apply(const void* x, const void* scale, const void* shift, const void* res, void* y, void* relu_mask,
+                                 size_t pixels, int CS, int relu, void* stream) {
     if (!x || !scale || !shift || !y || CS <= 0 || CS % 8) return OTP_ERR_BAD_ARG;
     const size_t units = pixels * (CS / 8);
-    bn_apply_kernel<<<grid_for(units), 256, 0, static_cast<hipStream_t>(stream)>>>(
-        static_cast<const bf16*>(x), static_cast<const float*>(scale), static_cast<const float*>(shift),
-        static_cast<const bf16*>(res), static_cast<bf16*>(y), units, CS / 8, relu);
+    if (res)
+        bn_apply_kernel<true><<<grid_for(units), 256, 0, static_cast<hipStream_t>(stream)>>>(
+            static_cast<const bf16*>(x), static_cast<const float*>(scale), static_cast<const float*>(shift),
+            static_cast<const bf16*>(res), static_cast<bf16*>(y), static_cast<unsigned char*>(relu_mask), units, CS / 8, relu);
+    else
+        bn_apply_kernel<false><<<grid_for(units), 256, 0, static_cast<hipStream_t>(stream)>>>(
+            static_cast<const bf16*>(x), static_cast<const float*>(scale), static_cast<const float*>(shift), nullptr,
+            static_cast<bf16*>(y), static_cast<unsigned char*>(relu_mask), units, CS / 8, relu);
     return otp_launch_status();
 }
 
@@ -1326,17 +1346,25 @@ extern "C" int otp_nhwc_bn_backward(const void* gy, const void* y, const void* x
     const int C8 = CS / 8;
     if (C8 > 256) return OTP_ERR_UNSUPPORTED;
     const size_t lds = (size_t)(256 / C8) * C8 * 16 * sizeof(float);
-    bn_bwd_reduce_kernel<<<rows, 256, lds, st>>>(static_cast<const bf16*>(gy), static_cast<const bf16*>(y),
-                                                 static_cast<const bf16*>(x), static_cast<const float*>(mean),
-                                                 static_cast<const float*>(rstd), part, pixels, C8, ppw, relu);
-    bn_bwd_finalize_kernel<<<(CS + 7) / 8, 256, 0, st>>>(part, rows, CS, C, (float)pixels, static_cast<const float*>(gamma),
-                                                           static_cast<const float*>(rstd), static_cast<float*>(dgamma),
-                                                           static_cast<float*>(dbeta), coef);
+#define OTP_BN_BWD(R)                                                                                               \
+    {                                                                                                                \
+        bn_bwd_reduce_kernel<R><<<rows, 256, lds, st>>>(static_cast<const bf16*>(gy), static_cast<const bf16*>(y),    \
+                                                        static_cast<const bf16*>(x), static_cast<const float*>(mean), \
+                                                        static_cast<const float*>(rstd), part, pixels, C8, ppw, relu); \
+        bn_bwd_finalize_kernel<<<(CS + 7) / 8, 256, 0, st>>>(part, rows, CS, C, (float)pixels,                         \
+                                                             static_cast<const float*>(gamma),                        \
+                                                             static_cast<const float*>(rstd), static_cast<float*>(dgamma), \
+                                                             static_cast<float*>(dbeta), coef);                       \
+        bn_bwd_apply_kernel<R><<<grid_for(units), 256, 0, st>>>(                                                      \
+            static_cast<const bf16*>(gy), static_cast<const bf16*>(y), static_cast<const bf16*>(x),                   \
+            static_cast<const float*>(mean), static_cast<const float*>(rstd), coef, static_cast<bf16*>(gx),           \
+            static_cast<bf16*>(gres), units, C8, relu);                                                               \
+    }
     const size_t units = pixels * C8;
-    bn_bwd_apply_kernel<<<grid_for(units), 256, 0, st>>>(static_cast<const bf16*>(gy), static_cast<const bf16*>(y),
-                                                         static_cast<const bf16*>(x), static_cast<const float*>(mean),
-                                                         static_cast<const float*>(rstd), coef, static_cast<bf16*>(gx),
-                                                         static_cast<bf16*>(gres), units, C8, relu);
+    if (relu == 0) OTP_BN_BWD(0)
+    else if (relu == 1) OTP_BN_BWD(1)
+    else OTP_BN_BWD(2)
+#undef OTP_BN_BWD
     return otp_launch_status();
 }
 

@@ -131,6 +131,105 @@ __global__ __launch_bounds__(256) void ln_channel_bwd_split_kernel(const float* 
     }
 }
 
+// Wide form of the kernel above for T % 4 == 0: a workgroup of 8 waves owns 256 consecutive tokens, a lane 4 of them
+// (16-byte accesses: every wave instruction moves 1 KB of one channel row instead of 256 B - the 64-token form spread its
+// traffic over 136 rows in 256-byte pieces and reached 1.6 TB/s), wave w keeps channels [w*CW, (w+1)*CW) of x and dy in
+// registers (CW = ceil(C / 8)).  Same arithmetic, same partial-sum layout [2][C][workgroups].
+typedef float lnf4 __attribute__((ext_vector_type(4)));
+template <int CW>
+__global__ __launch_bounds__(512) void ln_channel_bwd_wide_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                   const float* __restrict__ gamma, float* __restrict__ dx,
+                                                                   float* __restrict__ part, int C, int T, float eps) {
+    __shared__ lnf4 red[2][8][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t4 = blockIdx.x * 64 + lane, T4 = T >> 2;
+    const bool live = t4 < T4;
+    const size_t base = ((size_t)blockIdx.y * C * T4) + (live ? t4 : T4 - 1);      // in float4 units
+    const lnf4* x4 = reinterpret_cast<const lnf4*>(x);
+    const lnf4* d4 = reinterpret_cast<const lnf4*>(dy);
+    const float inv_c = 1.f / (float)C;
+    const int cw = (C + 7) / 8, cbeg = wave * cw;
+    lnf4 xv[CW], dv[CW];
+    lnf4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < CW; ++i) {
+        const int c = cbeg + i;
+        const bool ok = i < cw && c < C;
+        const size_t o = base + (size_t)(ok ? c : C - 1) * T4;
+        const lnf4 xl = x4[o], dl = d4[o];
+        xv[i] = ok ? xl : lnf4{0.f, 0.f, 0.f, 0.f};
+        dv[i] = ok ? dl : lnf4{0.f, 0.f, 0.f, 0.f};
+        s += xv[i];
+    }
+    auto all_waves = [&](int slot, lnf4 v) {
+        red[slot][wave][lane] = v;
+        __syncthreads();
+        lnf4 r = red[slot][0][lane];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) r += red[slot][w][lane];
+        __syncthreads();
+        return r;
+    };
+    const lnf4 mu = all_waves(0, s) * inv_c;
+    lnf4 q = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < CW; ++i) {
+        const bool ok = i < cw && cbeg + i < C;
+        if (ok) {
+            xv[i] -= mu;
+            q += xv[i] * xv[i];
+        }
+    }
+    const lnf4 var = all_waves(0, q) * inv_c;
+    lnf4 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = 1.f / sqrtf(var[j] + eps);
+    lnf4 m1 = {0.f, 0.f, 0.f, 0.f}, m2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < CW; ++i) {
+        const int c = cbeg + i;
+        if (i < cw && c < C) {
+            xv[i] *= r;                                          // xhat
+            const lnf4 g = dv[i] * gamma[c];
+            m1 += g;
+            m2 += g * xv[i];
+        }
+    }
+    red[0][wave][lane] = m1;
+    red[1][wave][lane] = m2;
+    __syncthreads();
+    m1 = red[0][0][lane];
+    m2 = red[1][0][lane];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) {
+        m1 += red[0][w][lane];
+        m2 += red[1][w][lane];
+    }
+    m1 *= inv_c;
+    m2 *= inv_c;
+    const int nwg = gridDim.x * gridDim.y, wg = blockIdx.y * gridDim.x + blockIdx.x;
+#pragma unroll
+    for (int i = 0; i < CW; ++i) {
+        const int c = cbeg + i;
+        if (i < cw && c < C) {                                   // (wave-uniform condition)
+            const lnf4 a = dv[i] * xv[i];
+            const float pg = wave_sum(live ? (a[0] + a[1]) + (a[2] + a[3]) : 0.f);
+            const float pb = wave_sum(live ? (dv[i][0] + dv[i][1]) + (dv[i][2] + dv[i][3]) : 0.f);
+            if (lane == 0) {
+                part[(size_t)c * nwg + wg] = pg;
+                part[((size_t)C + c) * nwg + wg] = pb;
+            }
+        }
+    }
+    if (!live) return;
+    lnf4* o4 = reinterpret_cast<lnf4*>(dx);
+#pragma unroll
+    for (int i = 0; i < CW; ++i) {
+        const int c = cbeg + i;
+        if (i < cw && c < C) o4[base + (size_t)c * T4] = r * (dv[i] * gamma[c] - m1 - xv[i] * m2);
+    }
+}
+
 // grid (2 * C): out[k] = sum over the nwg partials of row k (fp64 accumulation, fixed order)
 __global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
                                                                float* __restrict__ dbeta, int C, int nwg) {
@@ -427,7 +526,13 @@ extern "C" int otp_ln_channel_backward_params(const void* x, const void* grad_y,
     if (C > 4 * 34) return OTP_ERR_UNSUPPORTED;
     if (workspace_bytes < otp_ln_channel_backward_workspace(B, C, T)) return OTP_ERR_WORKSPACE;
     auto st = static_cast<hipStream_t>(stream);
-    const int gx = otp_ceil_div(T, 64);
+    int gx = otp_ceil_div(T, 64);
+    if ((T & 3) == 0 && T >= 1024) {                          // 256 tokens x all channels per workgroup, 16-byte accesses
+        gx = otp_ceil_div(T, 256);
+        hipLaunchKernelGGL((ln_channel_bwd_wide_kernel<17>), dim3(gx, B), dim3(512), 0, st, static_cast<const float*>(x),
+                           static_cast<const float*>(grad_y), static_cast<const float*>(gamma), static_cast<float*>(grad_x),
+                           static_cast<float*>(workspace), C, T, eps);
+    } else
     hipLaunchKernelGGL((ln_channel_bwd_split_kernel<34, true>), dim3(gx, B), dim3(256), 0, st, static_cast<const float*>(x),
                        static_cast<const float*>(grad_y), static_cast<const float*>(gamma), static_cast<float*>(grad_x),
                        static_cast<float*>(workspace), C, T, eps);

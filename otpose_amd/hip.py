@@ -121,7 +121,7 @@ SIGNATURES = {
     "otp_nhwc_wgrad_workspace": (c_size_t, [_ND]),
     "otp_nhwc_wgrad_bf16": (c_int, [c_void_p] * 4 + [c_size_t, _ND, c_void_p]),
     "otp_nhwc_bn_finalize": (c_int, [c_void_p, c_int, c_int, c_int, c_float] + [c_void_p] * 8 + [c_float, c_float, c_void_p]),
-    "otp_nhwc_bn_apply": (c_int, [c_void_p] * 5 + [c_size_t, c_int, c_int, c_void_p]),
+    "otp_nhwc_bn_apply": (c_int, [c_void_p] * 6 + [c_size_t, c_int, c_int, c_void_p]),
     "otp_nhwc_bn_backward_workspace": (c_size_t, [c_size_t, c_int]),
     "otp_nhwc_bn_backward": (c_int, [c_void_p] * 11 + [c_size_t, c_size_t, c_int, c_int, c_int, c_void_p]),
     "otp_nhwc_upsample_add": (c_int, [c_void_p] * 3 + [c_int] * 6 + [c_void_p]),

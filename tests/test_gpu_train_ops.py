@@ -156,7 +156,7 @@ def _check_op(ref_fn, hip_fn, inputs, tol=1e-4):
         _close(a, b, tol)
 
 
-@pytest.mark.parametrize("c,t", [(136, 300), (17, 77), (150, 70)])
+@pytest.mark.parametrize("c,t", [(136, 300), (17, 77), (150, 70), (136, 1728), (136, 1100), (40, 1024)])
 def test_layer_norm_backward(c, t):
     from otpose_amd import train_ops as T
     x, g, b = seeded((3, c, t), 1) * 2 + 0.3, 1 + 0.1 * seeded((1, c, 1), 2), seeded((1, c, 1), 3)
