@@ -14,6 +14,7 @@ pooling, up-sampling, DCN and loss kernel is in libotpose_hip.so.
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 from torch.autograd import Function
@@ -458,9 +459,13 @@ class TrainGraphBF16(TrainGraph):
     def offset_mask_input(self, trans):
         """The 32-channel feature map feeds ten dilated 3x3 convs (32 -> 306 / 153): one conversion to NHWC bf16, every
         conv on the bf16 matrix cores, offsets / masks handed to the DCN as fp32 NCHW."""
+        if os.environ.get("OTPOSE_BF16_OFFSETS", "1") == "0":
+            return trans
         return B16.to_nhwc_grad(trans)
 
     def offset_mask_conv(self, trans, weight, d):
+        if trans.dtype != B16.BF16:
+            return super().offset_mask_conv(trans, weight, d)
         return B16.conv_out(trans, weight, None, 1, d, d)
 
     def _w4(self, name):
@@ -476,7 +481,7 @@ class TrainGraphBF16(TrainGraph):
         """The MLP interior in bf16: the (B, C, T) fp32 LayerNorm output enters as a (B, 1, T, CS) NHWC bf16 view, the 4C-wide
         hidden activation (the largest tensor of a block: 240 MB at cfg2 in fp32) exists only in bf16, both projections
         and their gradients run on the bf16 matrix cores, and the down-projection hands back fp32 (B, C, T)."""
-        if yn.shape[1] % 8 or yn.shape[2] % 32:
+        if yn.shape[1] % 8 or yn.shape[2] % 32 or os.environ.get("OTPOSE_BF16_MLP", "1") == "0":
             return super().mlp(p, yn, pdrop)                  # the C = 17 flow encoder / odd lengths stay on the fp32 path
         x = B16.to_nhwc_grad(yn.unsqueeze(2))
         h = B16.conv_bias(x, self._w4(p + ".0.weight"), self.P.get(p + ".0.bias"))

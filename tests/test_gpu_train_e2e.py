@@ -195,3 +195,72 @@ def test_backbone_gradients_match_oracle(dtype):
     assert err <= tol["out"] and glob <= tol["glob"] and med <= tol["med"]
     assert live[0][0] <= tol["rel"] and min(s_[1] for s_ in live) >= tol["cos"]
     assert max(s_[0] for s_ in sig) <= tol["sig"]
+
+
+def test_bf16_step_on_a_cfg2_shaped_clip():
+    """BASELINE configs[2] at its real shape (HRNet-W48, one 5-frame 384x288 clip) vs the float64 oracle under torch
+    autograd (dropout / drop-path off), the float32 HIP step beside it as the rounding floor:
+      * whole step: loss and the backbone-side outputs (rough heat-maps, total_b);
+      * gradients: the backbone under a plain heat-map MSE - |g|, direction and relative L2 error.
+    Why not the whole-step gradient: on the seeded synthetic weights the flow encoder's channel LayerNorm (C = 17) sees
+    background tokens whose variance is ~eps, so d(loss)/d(total_b) is dominated by a few tokens amplified by
+    rstd ~ 1/sqrt(eps); the 2.7 % bf16 rounding noise of the backbone moves exactly those variances (measured: |g| 103 in
+    fp32 vs 2.2 with bf16 activations, for IDENTICAL gradients arriving at the encoder output) - a property of the
+    fixture, not of the kernels, so it cannot carry a tolerance."""
+    from otpose_amd import cfg2
+    cfg = cfg2()
+    model = OTPose(cfg)
+    S.fill_synthetic_(model)
+    sd_cpu = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    pre = "rough_pose_estimation_net"
+    names = [k for k, _ in model.named_parameters() if k.startswith(pre)]
+    x, margin = S.synthetic_clip(1, cfg.MODEL.IMAGE_SIZE)
+    torch.set_num_threads(16)
+    # ---- whole step, forward: loss + outputs ------------------------------------------------------------------------
+    sd_ref = {k: (v.double() if v.is_floating_point() else v) for k, v in sd_cpu.items()}
+    with torch.no_grad():
+        outs_ref = O.otpose_forward(sd_ref, cfg, x.double(), margin, training_bn=True)
+        B, J, h, w = outs_ref[0].shape
+        g, wt = _targets(B, J, h, w)
+        gd, wd = g.double(), wt.double()
+        loss_ref = float(O.st_ohkw_mse_loss(outs_ref[0], outs_ref[1][:B], gd, wd)["final_loss"]
+                         + O.st_ohkw_mse_loss(outs_ref[4], outs_ref[4], (gd + outs_ref[2]) / 2, wd)["final_loss"])
+    # ---- backbone gradient reference ---------------------------------------------------------------------------------
+    leaves = {k: sd_cpu[k].double().requires_grad_() for k in names}
+    sd_g = dict(sd_ref)
+    sd_g.update(leaves)
+    frames = torch.cat(x.split(3, dim=1), 0)
+    stages = [cfg["MODEL"]["EXTRA"][f"STAGE{s_}"] for s_ in (2, 3, 4)]
+    rough_ref = O.hrnet_forward(sd_g, pre, frames.double(), stages, training=True)
+    tgt = seeded(tuple(rough_ref.shape), 21).abs() * 0.3
+    (0.5 * ((rough_ref - tgt.double()) ** 2).mean()).backward()
+    gr = torch.cat([leaves[n].grad.flatten() for n in names])
+    res = {}
+    for dtype in ("f32", "bf16"):
+        m = OTPose(cfg)
+        m.load_state_dict(sd_cpu)
+        m = m.cuda().train()
+        m.train_dropout = False
+        m.train_dtype = dtype
+        with torch.no_grad():
+            outs = m(x.cuda(), margin=margin.cuda())
+            loss = float(TR.criterion(outs, g.cuda(), wt.cuda()))
+        rel = lambda a, r: float((a.detach().cpu().double() - r).abs().max() / r.abs().max())     # noqa: E731
+        e_rough, e_total = rel(outs[1], outs_ref[1]), rel(outs[6], outs_ref[6])
+        del outs
+        graph = (TR.TrainGraphBF16 if dtype == "bf16" else TR.TrainGraph)(m)
+        out = graph.hrnet(pre, graph.hrnet_input(x.cuda()))
+        (0.5 * ((out - tgt.cuda()) ** 2).mean()).backward()
+        P = dict(m.named_parameters())
+        gq = torch.cat([P[n].grad.cpu().double().flatten() for n in names])
+        res[dtype] = (abs(loss - loss_ref) / abs(loss_ref), e_rough, e_total, float(gq.norm() / gr.norm()),
+                      float(torch.dot(gq, gr) / (gq.norm() * gr.norm())), float((gq - gr).norm() / gr.norm()))
+        print("cfg2 clip %s: loss rel err %.3e, rough / total_b max err over range %.3e / %.3e; backbone gradient |g|/|g_ref| "
+              "%.4f, cosine %.6f, rel L2 %.3e" % ((dtype,) + res[dtype]))
+        del m, graph, out, P
+        torch.cuda.empty_cache()
+    f, b = res["f32"], res["bf16"]
+    assert f[0] <= 1e-4 and f[1] <= 1e-3 and abs(f[3] - 1) <= 1e-3 and f[4] >= 0.9999 and f[5] <= 5e-3
+    # bf16, measured on MI355X: loss 9.7e-3, rough / total_b 3.4e-2 / 2.3e-2 of their range, backbone gradient |g| ratio 1.0000,
+    # cosine 0.999999, relative L2 error 1.7e-3 (fp32: 2.8e-6, 3.7e-6 / 2.0e-6, 1.0000, 1.000000, 1.6e-5)
+    assert b[0] <= 3e-2 and b[1] <= 8e-2 and b[2] <= 8e-2 and abs(b[3] - 1) <= 1e-2 and b[4] >= 0.9999 and b[5] <= 1e-2
