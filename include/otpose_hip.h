@@ -165,6 +165,14 @@ int otp_glue_stack(const void* rough, const void* margin, const void* squeezed, 
                    const void* ctx, const void* pe1, const void* pe2, void* x1, void* x2, void* prev_b,
                    int B, int J, int HW, void* stream);
 
+/* the same for a window of F = 5 (reference) or 7 frames (BASELINE configs[4] extension: frames cur, prev_1, next_1, ...,
+ * margin (B, F-1), 12 stacked maps per joint; the map list is oracle/otpose_oracle.py:window_maps) */
+int otp_glue_total_n(const void* rough, void* total, void* squeezed, void* inter, void* flow_in, const void* pe,
+                     int B, int J, int HW, int F, void* stream);
+int otp_glue_stack_n(const void* rough, const void* margin, const void* squeezed, const void* inter,
+                     const void* ctx, const void* pe1, const void* pe2, void* x1, void* x2, void* prev_b,
+                     int B, int J, int HW, int F, void* stream);
+
 /* ---- ConvTransformer pieces (model/blocks.py) ---------------------------------------------------- */
 /* channel LayerNorm over C of (B,C,T) (blocks.py:95-110); optional second output
  * pool = MaxPool1d(3,2,1)(x) (blocks.py:234-238) when pool != NULL (then T must be the input length) */

@@ -350,32 +350,59 @@ def mdcn_backward(x, offset, mask, weight, grad_out, stride=1, pad=0, dil=1, gro
 # ------------------------------------------------------------------------------------------------
 # OTPose forward
 # ------------------------------------------------------------------------------------------------
+def window_maps(frames, mg, squeezed, inter, ctx):
+    """The stacked per-joint feature maps of the two temporal encoders (model/OTPose.py:339-359) for a window of
+    F = 2R + 1 frames ordered cur, prev_1, next_1, ..., prev_R, next_R with ``mg`` (B, 2R) = their frame distances.
+    R = 2 is the reference verbatim (8 maps per joint).  R = 3 is this build's BASELINE configs[4] extension (the reference
+    hard-codes 5 frames at :309, 320-321): every ring r adds ``sym_r = cur + (next_r + prev_r)`` (close, far, wide) and
+    the outer side sums ``cur + (prev_2 + prev_3)`` / ``cur + (next_2 + next_3)`` join the stack: 12 maps per joint."""
+    R = (len(frames) - 1) // 2
+    cur = frames[0]
+    div = lambda t, k: t / (mg[:, k] + 1)[:, None, None, None]               # noqa: E731  :339-342
+    prev = [div(frames[1 + 2 * r], 2 * r) for r in range(R)]
+    nxt = [div(frames[2 + 2 * r], 2 * r + 1) for r in range(R)]
+
+    def side(ts):                                                            # cur + ((t1 + t2) + t3 ...)   :345-346
+        acc = ts[0]
+        for t in ts[1:]:
+            acc = acc + t
+        return cur + acc
+
+    prev_b, next_b = side(prev), side(nxt)
+    sym = [cur + (nxt[r] + prev[r]) for r in range(R)]                       # close_b, far_b (:347-349), wide_b
+    b1 = [prev_b] + sym[::-1]                                                # prev_b, far_b, close_b          (:356)
+    b2 = [next_b] + sym                                                      # next_b, close_b, far_b          (:358)
+    if R == 3:
+        b1.append(side(prev[1:]))
+        b2.append(side(nxt[1:]))
+    elif R != 2:
+        raise ValueError("window of 5 or 7 frames expected")
+    x1 = torch.stack([inter, ctx] + b1 + [t * squeezed for t in b1], 2).flatten(1, 2)     # :351-356
+    x2 = torch.stack([inter, ctx] + b2 + [t * squeezed for t in b2], 2).flatten(1, 2)     # :358
+    return x1, x2, prev_b
+
+
 def otpose_forward(sd: SD, cfg, x, margin, training_bn=False, return_intermediates=False):
-    """model/OTPose.py:307-394, eval semantics.  ``x`` (B, 15, H, W), ``margin`` (B, 4).
+    """model/OTPose.py:307-394, eval semantics.  ``x`` (B, 15, H, W), ``margin`` (B, 4) (7-frame extension: (B, 21, H, W),
+    (B, 6), see :func:`window_maps`).
     Returns the reference's 7-tuple (output, rough, intersection, prev_b, context, squeezed, total_b)."""
     m = cfg["MODEL"]
     J = m["NUM_JOINTS"]
     pe_w, pe_h = m["HEATMAP_SIZE"]
     stages = [m["EXTRA"][f"STAGE{s}"] for s in (2, 3, 4)]
     dils = list(m["DEFORMABLE_CONV"]["DILATION"])
+    F_ = x.shape[1] // 3                                                     # frames of the window (reference: 5)
     x = torch.cat(x.split(3, dim=1), 0)                                      # :317
-    B = x.shape[0] // 5
+    B = x.shape[0] // F_
     rough = hrnet_forward(sd, "rough_pose_estimation_net", x, stages, training_bn)   # :319
-    cur, prev, nxt, pprev, nnext = rough.split(B, dim=0)                     # :320
-    total_b = cur + prev + nxt + pprev + nnext                               # :324
+    frames = rough.split(B, dim=0)                                           # :320  cur, prev1, next1, prev2, next2, ...
+    total_b = frames[0]
+    for f_ in frames[1:]:
+        total_b = total_b + f_                                               # :324 (left-to-right association)
     squeezed = total_b.sum(1, keepdim=True).expand(-1, J, -1, -1).contiguous()   # :325-328
     inter = total_b * squeezed                                               # :330
     ctx = conv_transformer(sd, "flow_encoder", total_b, 1, (0, 6, 0))[0].reshape(B, J, pe_h, pe_w)  # :331-335
-    mg = margin.to(x.dtype)
-    div = lambda t, k: t / (mg[:, k] + 1)[:, None, None, None]               # noqa: E731  :339-342
-    prev, nxt, pprev, nnext = div(prev, 0), div(nxt, 1), div(pprev, 2), div(nnext, 3)
-    prev_b = cur + (prev + pprev)                                            # :345-349
-    next_b = cur + (nxt + nnext)
-    close_b = cur + (nxt + prev)
-    far_b = cur + (nnext + pprev)
-    prev_i, next_i, close_i, far_i = (t * squeezed for t in (prev_b, next_b, close_b, far_b))   # :351-354
-    x1 = torch.stack((inter, ctx, prev_b, far_b, close_b, prev_i, far_i, close_i), 2).flatten(1, 2)   # :356
-    x2 = torch.stack((inter, ctx, next_b, close_b, far_b, next_i, close_i, far_i), 2).flatten(1, 2)   # :358
+    x1, x2, prev_b = window_maps(frames, margin.to(x.dtype), squeezed, inter, ctx)        # :339-359
     t1 = conv_transformer(sd, "temporal_encoder1", x1, 2, (0, 6, 2))          # :360
     t2 = conv_transformer(sd, "temporal_encoder2", x2, 2, (0, 6, 2))
     s1 = torch.stack(t1, 1).contiguous().view(B, -1, pe_h, pe_w)             # :362-369

@@ -45,8 +45,8 @@ def to_nhwc(x: torch.Tensor, frame_split: int = 0) -> torch.Tensor:
     if x.dtype != torch.float32:
         raise TypeError("to_nhwc expects float32")
     if frame_split:
-        b, c5, h, w = x.shape
-        n, c = 5 * b, c5 // 5
+        b, cf, h, w = x.shape                   # (B, 3 * frames, H, W): RGB frames stacked on the channel axis
+        n, c = (cf // 3) * b, 3
     else:
         n, c, h, w = x.shape
     out = _new((n, h, w, cs(c)), BF16, x)

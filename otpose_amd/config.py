@@ -86,8 +86,11 @@ def _stage(modules: int, channels: Iterable[int]) -> Dict[str, Any]:
 
 
 def make_cfg(width: int = 48, image_size: Tuple[int, int] = (288, 384),
-             dilations: Iterable[int] = (3, 6, 9, 12, 15)) -> CfgNode:
+             dilations: Iterable[int] = (3, 6, 9, 12, 15), frames: int = 5) -> CfgNode:
     """Built-in OTPose configuration.
+
+    ``frames`` = frames per clip window: 5 is the reference (hard-coded at model/OTPose.py:309,320-321); 7 is this build's
+    extension for BASELINE configs[4] (``MODEL.WINDOW_FRAMES``, 12 stacked maps per joint: oracle ``window_maps``).
 
     ``width`` is the HRNet branch-0 width (48 = the reference's W48 yaml, 32 = HRNet-W32 used by
     BASELINE.json configs[0]); ``image_size`` is (W, H) as in the reference yaml.
@@ -99,6 +102,7 @@ def make_cfg(width: int = 48, image_size: Tuple[int, int] = (288, 384),
         "MODEL": {
             "NAME": "OTPose",
             "NUM_JOINTS": 17,
+            "WINDOW_FRAMES": int(frames),
             "IMAGE_SIZE": [w, h],
             "HEATMAP_SIZE": [w // 4, h // 4],
             "PRETRAINED": "",
@@ -129,6 +133,11 @@ def cfg2() -> CfgNode:
     return make_cfg(48, (288, 384))
 
 
-def tiny_cfg(width: int = 8, image_size: Tuple[int, int] = (64, 96)) -> CfgNode:
+def tiny_cfg(width: int = 8, image_size: Tuple[int, int] = (64, 96), frames: int = 5) -> CfgNode:
     """A reduced-width, reduced-resolution model with the full OTPose topology (test sizes)."""
-    return make_cfg(width, image_size)
+    return make_cfg(width, image_size, frames=frames)
+
+
+def cfg5() -> CfgNode:
+    """BASELINE.json configs[4]: 7-frame window at 384x288 (extension; the reference has no such model)."""
+    return make_cfg(48, (288, 384), frames=7)

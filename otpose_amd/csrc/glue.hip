@@ -6,9 +6,10 @@
 namespace {
 
 // rough (5B, J, HW): frames [cur | prev | next | pprev | nnext] in blocks of B (OTPose.py:317-321)
+// F = frames of the window (5: reference; 7: the BASELINE configs[4] extension, oracle window_maps)
 __global__ void glue_total_kernel(const float* __restrict__ rough, float* __restrict__ total,
                                   float* __restrict__ squeezed, float* __restrict__ inter,
-                                  float* __restrict__ flow_in, const float* __restrict__ pe, int B, int J, int HW) {
+                                  float* __restrict__ flow_in, const float* __restrict__ pe, int B, int J, int HW, int F) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
     if (p >= HW) return;
     const size_t fs = (size_t)B * J * HW;                  // frame stride
@@ -17,7 +18,8 @@ __global__ void glue_total_kernel(const float* __restrict__ rough, float* __rest
     for (int j = 0; j < J; ++j) {
         const size_t i = base + (size_t)j * HW;
         // same association as the reference: (((cur + prev) + next) + pprev) + nnext  (OTPose.py:324)
-        float t = rough[i] + rough[fs + i] + rough[2 * fs + i] + rough[3 * fs + i] + rough[4 * fs + i];
+        float t = rough[i];
+        for (int f = 1; f < F; ++f) t += rough[(size_t)f * fs + i];
         total[i] = t;
         flow_in[i] = t + pe[(size_t)j * HW + p];
         sq += t;                                            // torch.sum over joints (OTPose.py:325)
@@ -29,34 +31,67 @@ __global__ void glue_total_kernel(const float* __restrict__ rough, float* __rest
     }
 }
 
-// x1/x2 channel = joint*8 + feature (OTPose.py:356-359); positional table added here (ConvVideoTransformer.py:144/155)
+// x1/x2 channel = joint*M + feature (OTPose.py:356-359); positional table added here (ConvVideoTransformer.py:144/155).
+// R = rings of the window (frames cur, prev_1, next_1, ..., prev_R, next_R); M = 8 (R = 2, reference) or 12 (R = 3).
+template <int R>
 __global__ void glue_stack_kernel(const float* __restrict__ rough, const float* __restrict__ margin,
                                   const float* __restrict__ squeezed, const float* __restrict__ inter,
                                   const float* __restrict__ ctx, const float* __restrict__ pe1,
                                   const float* __restrict__ pe2, float* __restrict__ x1, float* __restrict__ x2,
                                   float* __restrict__ prev_b_out, int B, int J, int HW) {
+    constexpr int NB = R == 2 ? 3 : 5, M = 2 + 2 * NB;       // "b" maps per encoder, stacked maps per joint
     const int p = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
     if (p >= HW) return;
     const size_t fs = (size_t)B * J * HW;
     const size_t base = (size_t)b * J * HW + p;
-    const float m0 = margin[b * 4] + 1.f, m1 = margin[b * 4 + 1] + 1.f, m2 = margin[b * 4 + 2] + 1.f,
-                m3 = margin[b * 4 + 3] + 1.f;
+    float mg[2 * R];
+#pragma unroll
+    for (int k = 0; k < 2 * R; ++k) mg[k] = margin[b * 2 * R + k] + 1.f;
     const float sq = squeezed[base];
     for (int j = 0; j < J; ++j) {
         const size_t i = base + (size_t)j * HW;
         const float cur = rough[i];
-        const float prev = rough[fs + i] / m0, next = rough[2 * fs + i] / m1;      // OTPose.py:339-342
-        const float pprev = rough[3 * fs + i] / m2, nnext = rough[4 * fs + i] / m3;
-        const float prev_b = cur + (prev + pprev), next_b = cur + (next + nnext);   // OTPose.py:345-349
-        const float close_b = cur + (next + prev), far_b = cur + (nnext + pprev);
+        float prev[R], next[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {                       // OTPose.py:339-342
+            prev[r] = rough[(size_t)(1 + 2 * r) * fs + i] / mg[2 * r];
+            next[r] = rough[(size_t)(2 + 2 * r) * fs + i] / mg[2 * r + 1];
+        }
+        float sp = prev[0], sn = next[0];
+#pragma unroll
+        for (int r = 1; r < R; ++r) { sp += prev[r]; sn += next[r]; }
+        const float prev_b = cur + sp, next_b = cur + sn;   // OTPose.py:345-346: cur + (prev + pprev)
+        float sym[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) sym[r] = cur + (next[r] + prev[r]);      // close_b, far_b (:347-349), wide_b
+        float b1[NB], b2[NB];
+        b1[0] = prev_b;
+        b2[0] = next_b;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            b1[1 + r] = sym[R - 1 - r];                     // prev_b, far_b, close_b          (:356)
+            b2[1 + r] = sym[r];                             // next_b, close_b, far_b          (:358)
+        }
+        if (R == 3) {
+            b1[NB - 1] = cur + (prev[1] + prev[2]);
+            b2[NB - 1] = cur + (next[1] + next[2]);
+        }
         const float in = inter[i], cx = ctx[i];
         prev_b_out[i] = prev_b;
-        const size_t o = ((size_t)b * J * 8 + (size_t)j * 8) * HW + p;
-        const size_t pj = (size_t)j * 8 * HW + p;
-        const float f1[8] = {in, cx, prev_b, far_b, close_b, prev_b * sq, far_b * sq, close_b * sq};
-        const float f2[8] = {in, cx, next_b, close_b, far_b, next_b * sq, close_b * sq, far_b * sq};
+        const size_t o = ((size_t)b * J * M + (size_t)j * M) * HW + p;
+        const size_t pj = (size_t)j * M * HW + p;
+        float f1[M], f2[M];
+        f1[0] = f2[0] = in;
+        f1[1] = f2[1] = cx;
 #pragma unroll
-        for (int f = 0; f < 8; ++f) {
+        for (int k = 0; k < NB; ++k) {
+            f1[2 + k] = b1[k];
+            f2[2 + k] = b2[k];
+            f1[2 + NB + k] = b1[k] * sq;                    // :351-354
+            f2[2 + NB + k] = b2[k] * sq;
+        }
+#pragma unroll
+        for (int f = 0; f < M; ++f) {
             x1[o + (size_t)f * HW] = f1[f] + pe1[pj + (size_t)f * HW];
             x2[o + (size_t)f * HW] = f2[f] + pe2[pj + (size_t)f * HW];
         }
@@ -311,25 +346,44 @@ __global__ __launch_bounds__(256) void frames_u8_kernel(const uint32_t* __restri
 
 }  // namespace
 
-extern "C" int otp_glue_total(const void* rough, void* total, void* squeezed, void* inter, void* flow_in,
-                              const void* pe, int B, int J, int HW, void* stream) {
-    if (!rough || !total || !squeezed || !inter || !flow_in || !pe || B <= 0 || J <= 0 || HW <= 0) return OTP_ERR_BAD_ARG;
+extern "C" int otp_glue_total_n(const void* rough, void* total, void* squeezed, void* inter, void* flow_in, const void* pe,
+                                int B, int J, int HW, int F, void* stream) {
+    if (!rough || !total || !squeezed || !inter || !flow_in || !pe) return OTP_ERR_BAD_ARG;
+    if (B <= 0 || J <= 0 || HW <= 0 || F < 1) return OTP_ERR_BAD_ARG;
     hipLaunchKernelGGL(glue_total_kernel, dim3(otp_ceil_div(HW, 256), B), dim3(256), 0, static_cast<hipStream_t>(stream),
                        static_cast<const float*>(rough), static_cast<float*>(total), static_cast<float*>(squeezed),
-                       static_cast<float*>(inter), static_cast<float*>(flow_in), static_cast<const float*>(pe), B, J, HW);
+                       static_cast<float*>(inter), static_cast<float*>(flow_in), static_cast<const float*>(pe), B, J, HW, F);
+    return otp_launch_status();
+}
+
+extern "C" int otp_glue_total(const void* rough, void* total, void* squeezed, void* inter, void* flow_in, const void* pe,
+                              int B, int J, int HW, void* stream) {
+    return otp_glue_total_n(rough, total, squeezed, inter, flow_in, pe, B, J, HW, 5, stream);
+}
+
+extern "C" int otp_glue_stack_n(const void* rough, const void* margin, const void* squeezed, const void* inter,
+                                const void* ctx, const void* pe1, const void* pe2, void* x1, void* x2, void* prev_b,
+                                int B, int J, int HW, int F, void* stream) {
+    if (!rough || !margin || !squeezed || !inter || !ctx || !pe1 || !pe2 || !x1 || !x2 || !prev_b) return OTP_ERR_BAD_ARG;
+    if (B <= 0 || J <= 0 || HW <= 0) return OTP_ERR_BAD_ARG;
+    if (F != 5 && F != 7) return OTP_ERR_UNSUPPORTED;
+    auto f = [](const void* p) { return static_cast<const float*>(p); };
+    const dim3 grid(otp_ceil_div(HW, 256), B);
+    if (F == 5)
+        hipLaunchKernelGGL(glue_stack_kernel<2>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), f(rough), f(margin),
+                           f(squeezed), f(inter), f(ctx), f(pe1), f(pe2), static_cast<float*>(x1), static_cast<float*>(x2),
+                           static_cast<float*>(prev_b), B, J, HW);
+    else
+        hipLaunchKernelGGL(glue_stack_kernel<3>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), f(rough), f(margin),
+                           f(squeezed), f(inter), f(ctx), f(pe1), f(pe2), static_cast<float*>(x1), static_cast<float*>(x2),
+                           static_cast<float*>(prev_b), B, J, HW);
     return otp_launch_status();
 }
 
 extern "C" int otp_glue_stack(const void* rough, const void* margin, const void* squeezed, const void* inter,
                               const void* ctx, const void* pe1, const void* pe2, void* x1, void* x2, void* prev_b,
                               int B, int J, int HW, void* stream) {
-    if (!rough || !margin || !squeezed || !inter || !ctx || !pe1 || !pe2 || !x1 || !x2 || !prev_b) return OTP_ERR_BAD_ARG;
-    if (B <= 0 || J <= 0 || HW <= 0) return OTP_ERR_BAD_ARG;
-    auto f = [](const void* p) { return static_cast<const float*>(p); };
-    hipLaunchKernelGGL(glue_stack_kernel, dim3(otp_ceil_div(HW, 256), B), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       f(rough), f(margin), f(squeezed), f(inter), f(ctx), f(pe1), f(pe2), static_cast<float*>(x1),
-                       static_cast<float*>(x2), static_cast<float*>(prev_b), B, J, HW);
-    return otp_launch_status();
+    return otp_glue_stack_n(rough, margin, squeezed, inter, ctx, pe1, pe2, x1, x2, prev_b, B, J, HW, 5, stream);
 }
 
 extern "C" int otp_axpby(const void* x, void* y, float alpha, float beta, size_t n, void* stream) {

@@ -306,23 +306,24 @@ __global__ __launch_bounds__(256) void attn_softmax_kernel(const float* __restri
 // Phase 3: O^T[t, i] = sum_j v[j, t] P[i, j], stored as out[bh][t][i] (i contiguous) - exactly the memory
 // image of `out.transpose(2,3).contiguous()` (blocks.py:447).  grid (B*nh, ceil(T / 256)); each wave owns
 // 64 time steps (4 row blocks) x all NB column blocks.  A = v^T from an LDS tile, B = P^T from LDS.
-constexpr int PV_TT = 256;            // time steps per workgroup
+// time steps per workgroup: 256, 128 once HSP > 96 (the v tile must fit in LDS)
+constexpr int pv_tt(int nb) { return nb > 6 ? 128 : 256; }
 template <int NB>
 __global__ __launch_bounds__(256) void attn_pv_kernel(const float* __restrict__ v, const float* __restrict__ P,
                                                        float* __restrict__ out, int hs, int T) {
-    constexpr int HSP = NB * 16;
+    constexpr int HSP = NB * 16, TT = pv_tt(NB), TB = TT / 64;   // TB 16-row time blocks per wave
     constexpr int PS = HSP + 2;       // P row pitch: (i*2 + k) distinct banks
-    constexpr int VS = PV_TT + 16;    // v row pitch == 16 (mod 32)
+    constexpr int VS = TT + 16;    // v row pitch == 16 (mod 32)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* pl = smem;                 // [HSP][PS]
     float* vl = smem + HSP * PS;      // [HSP][VS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int bh = blockIdx.x, t0 = blockIdx.y * PV_TT;
+    const int bh = blockIdx.x, t0 = blockIdx.y * TT;
     const float* vb = v + (size_t)bh * hs * T;
     const float* pb = P + (size_t)bh * HSP * HSP;
     // 16-byte vector loads, all issued before the first LDS write (one memory round trip for the whole tile)
     {
-        constexpr int NP4 = (HSP * HSP / 4 + 255) / 256, NV4 = (HSP * (PV_TT / 4) + 255) / 256;
+        constexpr int NP4 = (HSP * HSP / 4 + 255) / 256, NV4 = (HSP * (TT / 4) + 255) / 256;
         const bool vecv = (T & 3) == 0 && (reinterpret_cast<uintptr_t>(v) & 15) == 0;
         f32x4 rp[NP4], rv[NV4];
 #pragma unroll
@@ -333,9 +334,9 @@ __global__ __launch_bounds__(256) void attn_pv_kernel(const float* __restrict__ 
 #pragma unroll
         for (int j = 0; j < NV4; ++j) {
             const int idx = tid + j * 256;
-            const int row = idx / (PV_TT / 4), t = t0 + 4 * (idx - row * (PV_TT / 4));
+            const int row = idx / (TT / 4), t = t0 + 4 * (idx - row * (TT / 4));
             f32x4 a = {0.f, 0.f, 0.f, 0.f};
-            if (row < hs && idx < HSP * (PV_TT / 4)) {
+            if (row < hs && idx < HSP * (TT / 4)) {
                 const float* vp = vb + (size_t)row * T + t;
                 if (vecv && t + 3 < T) {
                     a = *reinterpret_cast<const f32x4*>(vp);
@@ -359,39 +360,39 @@ __global__ __launch_bounds__(256) void attn_pv_kernel(const float* __restrict__ 
 #pragma unroll
         for (int j = 0; j < NV4; ++j) {
             const int idx = tid + j * 256;
-            if (idx < HSP * (PV_TT / 4)) {
-                const int row = idx / (PV_TT / 4), tt = 4 * (idx - row * (PV_TT / 4));
+            if (idx < HSP * (TT / 4)) {
+                const int row = idx / (TT / 4), tt = 4 * (idx - row * (TT / 4));
                 *reinterpret_cast<f32x4*>(vl + row * VS + tt) = rv[j];
             }
         }
     }
     __syncthreads();
     const int r16 = lane & 15, kk = lane >> 4;
-    f32x4 acc[4][NB];
+    f32x4 acc[TB][NB];
 #pragma unroll
-    for (int tb = 0; tb < 4; ++tb)
+    for (int tb = 0; tb < TB; ++tb)
 #pragma unroll
         for (int ib = 0; ib < NB; ++ib) acc[tb][ib] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const float* va = vl + kk * VS + wave * 64 + r16;          // A[t][j]: lane (t = r16, k = kk)
+    const float* va = vl + kk * VS + wave * (TT / 4) + r16;          // A[t][j]: lane (t = r16, k = kk)
     const float* pa = pl + r16 * PS + kk;                      // B[j][i]: lane (k = kk, i = r16)
     for (int j0 = 0; j0 < HSP; j0 += 4) {
-        float a[4], b[NB];
+        float a[TB], b[NB];
 #pragma unroll
-        for (int tb = 0; tb < 4; ++tb) a[tb] = va[j0 * VS + tb * 16];
+        for (int tb = 0; tb < TB; ++tb) a[tb] = va[j0 * VS + tb * 16];
 #pragma unroll
         for (int ib = 0; ib < NB; ++ib) b[ib] = pa[ib * 16 * PS + j0];
 #pragma unroll
-        for (int tb = 0; tb < 4; ++tb)
+        for (int tb = 0; tb < TB; ++tb)
 #pragma unroll
             for (int ib = 0; ib < NB; ++ib)
                 acc[tb][ib] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tb], b[ib], acc[tb][ib], 0, 0, 0);
     }
     float* ob = out + (size_t)bh * T * hs;
 #pragma unroll
-    for (int tb = 0; tb < 4; ++tb)
+    for (int tb = 0; tb < TB; ++tb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int t = t0 + wave * 64 + tb * 16 + kk * 4 + r;
+            const int t = t0 + wave * (TT / 4) + tb * 16 + kk * 4 + r;
             if (t < T) {
 #pragma unroll
                 for (int ib = 0; ib < NB; ++ib) {
@@ -486,7 +487,7 @@ extern "C" int otp_chan_attn(const void* q, const void* k, const void* v, void* 
     if (!q || !k || !v || !out || !workspace || B <= 0 || C <= 0 || T <= 0 || n_head <= 0) return OTP_ERR_BAD_ARG;
     if (C % n_head) return OTP_ERR_BAD_ARG;
     const int hs = C / n_head, HSP = (hs + 15) & ~15, NB = HSP / 16;
-    if (NB != 5 && NB != 2 && NB != 1) return OTP_ERR_UNSUPPORTED;      // hs in (64,80], (16,32], <=16
+    if (NB > 7) return OTP_ERR_UNSUPPORTED;                              // hs <= 112
     if (workspace_bytes < otp_chan_attn_workspace(B, C, T, n_head)) return OTP_ERR_WORKSPACE;
     const int BH = B * n_head, NS = attn_splits(BH, T);
     const int chunk = otp_ceil_div(otp_ceil_div(T, NS), ATT_TC) * ATT_TC;
@@ -497,8 +498,9 @@ extern "C" int otp_chan_attn(const void* q, const void* k, const void* v, void* 
     auto kf = static_cast<const float*>(k);
     auto vf = static_cast<const float*>(v);
     auto of = static_cast<float*>(out);
-    const size_t pv_lds = ((size_t)HSP * (HSP + 2) + (size_t)HSP * (PV_TT + 16)) * sizeof(float);
-    dim3 g1(BH, NS), g3(BH, otp_ceil_div(T, PV_TT));
+    const int TT = pv_tt(NB);
+    const size_t pv_lds = ((size_t)HSP * (HSP + 2) + (size_t)HSP * (TT + 16)) * sizeof(float);
+    dim3 g1(BH, NS), g3(BH, otp_ceil_div(T, TT));
 #define OTP_ATT(NB_)                                                                                           \
     {                                                                                                          \
         hipLaunchKernelGGL(attn_scores_kernel<NB_>, g1, dim3(256), 0, st, qf, kf, slabs, hs, T, chunk);        \
@@ -507,7 +509,15 @@ extern "C" int otp_chan_attn(const void* q, const void* k, const void* v, void* 
         OTP_ALLOW_BIG_LDS(kern, pv_lds);                                                                       \
         hipLaunchKernelGGL(kern, g3, dim3(256), pv_lds, st, vf, P, of, hs, T);                                 \
     }
-    if (NB == 5) OTP_ATT(5) else if (NB == 2) OTP_ATT(2) else OTP_ATT(1)
+    switch (NB) {
+        case 1: OTP_ATT(1) break;
+        case 2: OTP_ATT(2) break;
+        case 3: OTP_ATT(3) break;
+        case 4: OTP_ATT(4) break;
+        case 5: OTP_ATT(5) break;
+        case 6: OTP_ATT(6) break;
+        default: OTP_ATT(7) break;
+    }
 #undef OTP_ATT
     return otp_launch_status();
 }
@@ -520,7 +530,7 @@ extern "C" int otp_chan_attn_splits(int BH, int T) { return (BH > 0 && T > 0) ? 
 extern "C" int otp_chan_attn_scores(const void* a, const void* b, void* slabs, int BH, int hs, int T, void* stream) {
     if (!a || !b || !slabs || BH <= 0 || hs <= 0 || T <= 0) return OTP_ERR_BAD_ARG;
     const int HSP = (hs + 15) & ~15, NB = HSP / 16;
-    if (NB != 5 && NB != 2 && NB != 1) return OTP_ERR_UNSUPPORTED;
+    if (NB > 7) return OTP_ERR_UNSUPPORTED;
     const int NS = attn_splits(BH, T);
     const int chunk = otp_ceil_div(otp_ceil_div(T, NS), ATT_TC) * ATT_TC;
     auto st = static_cast<hipStream_t>(stream);
@@ -528,9 +538,17 @@ extern "C" int otp_chan_attn_scores(const void* a, const void* b, void* slabs, i
     auto af = static_cast<const float*>(a);
     auto bf = static_cast<const float*>(b);
     auto sf = static_cast<float*>(slabs);
-    if (NB == 5) hipLaunchKernelGGL(attn_scores_kernel<5>, g1, dim3(256), 0, st, af, bf, sf, hs, T, chunk);
-    else if (NB == 2) hipLaunchKernelGGL(attn_scores_kernel<2>, g1, dim3(256), 0, st, af, bf, sf, hs, T, chunk);
-    else hipLaunchKernelGGL(attn_scores_kernel<1>, g1, dim3(256), 0, st, af, bf, sf, hs, T, chunk);
+#define OTP_SC(NB_) hipLaunchKernelGGL(attn_scores_kernel<NB_>, g1, dim3(256), 0, st, af, bf, sf, hs, T, chunk);
+    switch (NB) {
+        case 1: OTP_SC(1) break;
+        case 2: OTP_SC(2) break;
+        case 3: OTP_SC(3) break;
+        case 4: OTP_SC(4) break;
+        case 5: OTP_SC(5) break;
+        case 6: OTP_SC(6) break;
+        default: OTP_SC(7) break;
+    }
+#undef OTP_SC
     return otp_launch_status();
 }
 
@@ -538,10 +556,11 @@ extern "C" int otp_chan_attn_scores(const void* a, const void* b, void* slabs, i
 extern "C" int otp_chan_attn_apply(const void* v, const void* M, void* out, int BH, int hs, int T, void* stream) {
     if (!v || !M || !out || BH <= 0 || hs <= 0 || T <= 0) return OTP_ERR_BAD_ARG;
     const int HSP = (hs + 15) & ~15, NB = HSP / 16;
-    if (NB != 5 && NB != 2 && NB != 1) return OTP_ERR_UNSUPPORTED;
+    if (NB > 7) return OTP_ERR_UNSUPPORTED;
     auto st = static_cast<hipStream_t>(stream);
-    const size_t pv_lds = ((size_t)HSP * (HSP + 2) + (size_t)HSP * (PV_TT + 16)) * sizeof(float);
-    dim3 g3(BH, otp_ceil_div(T, PV_TT));
+    const int TT = pv_tt(NB);
+    const size_t pv_lds = ((size_t)HSP * (HSP + 2) + (size_t)HSP * (TT + 16)) * sizeof(float);
+    dim3 g3(BH, otp_ceil_div(T, TT));
     auto vf = static_cast<const float*>(v);
     auto mf = static_cast<const float*>(M);
     auto of = static_cast<float*>(out);
@@ -551,7 +570,15 @@ extern "C" int otp_chan_attn_apply(const void* v, const void* M, void* out, int 
         OTP_ALLOW_BIG_LDS(kern, pv_lds);                                        \
         hipLaunchKernelGGL(kern, g3, dim3(256), pv_lds, st, vf, mf, of, hs, T); \
     }
-    if (NB == 5) OTP_APPLY(5) else if (NB == 2) OTP_APPLY(2) else OTP_APPLY(1)
+    switch (NB) {
+        case 1: OTP_APPLY(1) break;
+        case 2: OTP_APPLY(2) break;
+        case 3: OTP_APPLY(3) break;
+        case 4: OTP_APPLY(4) break;
+        case 5: OTP_APPLY(5) break;
+        case 6: OTP_APPLY(6) break;
+        default: OTP_APPLY(7) break;
+    }
 #undef OTP_APPLY
     return otp_launch_status();
 }

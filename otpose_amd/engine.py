@@ -39,6 +39,7 @@ class InferenceEngine:
         self.model = model
         cfg = model.cfg
         self.J = model.num_joints
+        self.F = getattr(model, "window_frames", 5)             # frames per clip window
         self.W_img, self.H_img = cfg.MODEL.IMAGE_SIZE
         self.h, self.w = model.pe_h, model.pe_w
         self.ops: List[Callable] = []
@@ -71,7 +72,7 @@ class InferenceEngine:
                 and self._param_version() == self.param_version)
 
     def matches_shape(self, b, c, h, w, dev) -> bool:
-        return (b == self.B and dev == self.dev and (h, w) == (self.H_img, self.W_img) and c == 15
+        return (b == self.B and dev == self.dev and (h, w) == (self.H_img, self.W_img) and c == 3 * self.F
                 and self._param_version() == self.param_version)
 
     def _param_version(self):
@@ -364,7 +365,7 @@ class InferenceEngine:
             for mod in getattr(net, f"stage{s}"):
                 ys = self.hr_module(mod, ys)
         fl = net.final_layer
-        rough = View(self.new(5 * self.B, self.J, self.h, self.w))
+        rough = View(self.new(self.F * self.B, self.J, self.h, self.w))
         return self.conv(ys[0], fl.weight, rough, 1, fl.padding[0], 1, bias=fl.bias)
 
     # ---- ConvTransformer (reference model/ConvVideoTransformer.py:123-184, model/blocks.py:264-280,400-453) ----
@@ -515,15 +516,15 @@ class InferenceEngine:
     def _build(self):
         m, B, J, h, w = self.model, self.B, self.J, self.h, self.w
         L, T = self.lib, self.h * self.w
-        self.inp = self.new(B, 15, self.H_img, self.W_img)
-        self.margin = self.new(B, 4)
+        self.inp = self.new(B, 3 * self.F, self.H_img, self.W_img)
+        self.margin = self.new(B, self.F - 1)
         rough = self.hrnet(m.rough_pose_estimation_net, View(self.inp)).t
 
         total, squeezed, inter = self.new(B, J, h, w), self.new(B, J, h, w), self.new(B, J, h, w)
         flow_in = self.new(B, J, T)
         pe_f = self.dev_param(m.flow_encoder.pos_embd[0, :, :T])
-        self.call(L.otp_glue_total, "otp_glue_total", hip.ptr(rough), hip.ptr(total), hip.ptr(squeezed), hip.ptr(inter),
-                  hip.ptr(flow_in), hip.ptr(pe_f), B, J, T)
+        self.call(L.otp_glue_total_n, "otp_glue_total", hip.ptr(rough), hip.ptr(total), hip.ptr(squeezed), hip.ptr(inter),
+                  hip.ptr(flow_in), hip.ptr(pe_f), B, J, T, self.F)
         ctx = self.new(B, J, T)
         # def_fuse only needs `total`: it runs on a side stream next to the flow encoder and the temporal encoders
         self.fork((2,))
@@ -531,13 +532,13 @@ class InferenceEngine:
         def_h = self.rsb_chain(m.def_fuse, View(total))
         self.on_stream(0)
         self.conv_transformer(m.flow_encoder, flow_in, ctx)
-        D = 8 * J
+        D = m.num_frames * J                       # stacked maps per joint: 8 (5-frame window) or 12 (7 frames)
         x1, x2, prev_b = self.new(B, D, T), self.new(B, D, T), self.new(B, J, h, w)
         pe1 = self.dev_param(m.temporal_encoder1.pos_embd[0, :, :T])
         pe2 = self.dev_param(m.temporal_encoder2.pos_embd[0, :, :T])
-        self.call(L.otp_glue_stack, "otp_glue_stack", hip.ptr(rough), hip.ptr(self.margin), hip.ptr(squeezed),
+        self.call(L.otp_glue_stack_n, "otp_glue_stack", hip.ptr(rough), hip.ptr(self.margin), hip.ptr(squeezed),
                   hip.ptr(inter), hip.ptr(ctx), hip.ptr(pe1), hip.ptr(pe2), hip.ptr(x1), hip.ptr(x2), hip.ptr(prev_b),
-                  B, J, T)
+                  B, J, T, self.F)
         levels = m.scale_arch[-1] + 1
         s1, s2 = self.new(B, levels * D, T), self.new(B, levels * D, T)
         # the two temporal encoders are independent: two streams

@@ -73,6 +73,8 @@ SIGNATURES = {
     "otp_channel_sum": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t] + [c_int] * 5 + [c_void_p]),
     "otp_glue_total": (c_int, [c_void_p] * 6 + [c_int] * 3 + [c_void_p]),
     "otp_glue_stack": (c_int, [c_void_p] * 10 + [c_int] * 3 + [c_void_p]),
+    "otp_glue_total_n": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_void_p]),
+    "otp_glue_stack_n": (c_int, [c_void_p] * 10 + [c_int] * 4 + [c_void_p]),
     "otp_ln_channel": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_float, c_void_p]),
     "otp_dwconv_ln3": (c_int, [c_void_p] * 13 + [c_int] * 4 + [c_float, c_void_p]),
     "otp_chan_attn_workspace": (c_size_t, [c_int] * 4),

@@ -97,7 +97,11 @@ class OTPose(nn.Module):
         self.cfg = cfg
         m = cfg.MODEL
         extra = cfg["MODEL"]["EXTRA"]
-        self.num_frames = 8                       # feature maps stacked per joint (OTPose.py:188)
+        # frames per clip window: 5 in the reference (OTPose.py:309,320-321); 7 = the BASELINE configs[4] extension
+        self.window_frames = int(m.get("WINDOW_FRAMES", 5)) if hasattr(m, "get") else 5
+        if self.window_frames not in (5, 7):
+            raise ValueError("MODEL.WINDOW_FRAMES must be 5 (reference) or 7 (extension)")
+        self.num_frames = 8 if self.window_frames == 5 else 12    # feature maps stacked per joint (OTPose.py:188)
         self.pe_w, self.pe_h = m.HEATMAP_SIZE
         self.num_joints = m.NUM_JOINTS
         self.num_patches = self.pe_h * self.pe_w

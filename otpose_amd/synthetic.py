@@ -144,17 +144,19 @@ def fill_synthetic_(module: torch.nn.Module, seed: int = WEIGHT_SEED, gains=None
     return module
 
 
-def synthetic_clip(batch: int, image_size, seed: int = INPUT_SEED):
+def synthetic_clip(batch: int, image_size, seed: int = INPUT_SEED, frames: int = 5):
     """``x`` (B, 15, H, W) ~ N(0, 1) (five ImageNet-normalised frames: cur, prev, next, pprev,
     nnext - reference script/Common.py:112-117) and ``margin`` (B, 4) float frame distances:
     [1, 1, 2, 2] with every fourth row [0, 1, 0, 2] (clip borders, reference
-    dataset/PoseTrackDataset.py:263-293)."""
+    dataset/PoseTrackDataset.py:263-293).  ``frames = 7`` (the configs[4] extension): (B, 21, H, W) and (B, 6) =
+    [1, 1, 2, 2, 3, 3] / [0, 1, 0, 2, 0, 3]."""
     w, h = image_size
+    r = (frames - 1) // 2
     gen = torch.Generator(device="cpu")
     gen.manual_seed(seed)
-    x = torch.randn((batch, 15, h, w), generator=gen, dtype=torch.float32)
-    margin = torch.tensor([[1.0, 1.0, 2.0, 2.0]]).repeat(batch, 1)
-    margin[3::4] = torch.tensor([0.0, 1.0, 0.0, 2.0])
+    x = torch.randn((batch, 3 * frames, h, w), generator=gen, dtype=torch.float32)
+    margin = torch.tensor([[float(k // 2 + 1) for k in range(2 * r)]]).repeat(batch, 1)
+    margin[3::4] = torch.tensor([0.0 if k % 2 == 0 else float(k // 2 + 1) for k in range(2 * r)])
     return x, margin
 
 

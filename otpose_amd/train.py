@@ -392,21 +392,34 @@ class TrainGraph:
         dils = list(m["DEFORMABLE_CONV"]["DILATION"])
         B = x.shape[0]
         rough = self.hrnet("rough_pose_estimation_net", self.hrnet_input(x))
-        cur, prev, nxt, pprev, nnext = rough.split(B, dim=0)
-        total_b = cur + prev + nxt + pprev + nnext
+        frames = rough.split(B, dim=0)                         # cur, prev_1, next_1, prev_2, next_2 (, prev_3, next_3)
+        R = (len(frames) - 1) // 2
+        cur = frames[0]
+        total_b = cur
+        for f_ in frames[1:]:
+            total_b = total_b + f_
         squeezed = total_b.sum(1, keepdim=True).expand(-1, J, -1, -1).contiguous()
         inter = total_b * squeezed
         ctx = self.conv_transformer("flow_encoder", total_b, 1, (0, 6, 0))[0].reshape(B, J, pe_h, pe_w)
         mg = margin.to(x.dtype)
         div = lambda t, k: t / (mg[:, k] + 1)[:, None, None, None]           # noqa: E731
-        prev, nxt, pprev, nnext = div(prev, 0), div(nxt, 1), div(pprev, 2), div(nnext, 3)
-        prev_b = cur + (prev + pprev)
-        next_b = cur + (nxt + nnext)
-        close_b = cur + (nxt + prev)
-        far_b = cur + (nnext + pprev)
-        prev_i, next_i, close_i, far_i = (t * squeezed for t in (prev_b, next_b, close_b, far_b))
-        x1 = torch.stack((inter, ctx, prev_b, far_b, close_b, prev_i, far_i, close_i), 2).flatten(1, 2)
-        x2 = torch.stack((inter, ctx, next_b, close_b, far_b, next_i, close_i, far_i), 2).flatten(1, 2)
+        prev = [div(frames[1 + 2 * r], 2 * r) for r in range(R)]
+        nxt = [div(frames[2 + 2 * r], 2 * r + 1) for r in range(R)]
+
+        def side(ts):
+            acc = ts[0]
+            for t in ts[1:]:
+                acc = acc + t
+            return cur + acc
+
+        prev_b, next_b = side(prev), side(nxt)
+        sym = [cur + (nxt[r] + prev[r]) for r in range(R)]                   # close_b, far_b (, wide_b)
+        b1, b2 = [prev_b] + sym[::-1], [next_b] + sym
+        if R == 3:                                                           # 7-frame extension (oracle window_maps)
+            b1.append(side(prev[1:]))
+            b2.append(side(nxt[1:]))
+        x1 = torch.stack([inter, ctx] + b1 + [t * squeezed for t in b1], 2).flatten(1, 2)
+        x2 = torch.stack([inter, ctx] + b2 + [t * squeezed for t in b2], 2).flatten(1, 2)
         t1 = self.conv_transformer("temporal_encoder1", x1, 2, (0, 6, 2))
         t2 = self.conv_transformer("temporal_encoder2", x2, 2, (0, 6, 2))
         s1 = torch.stack(t1, 1).contiguous().view(B, -1, pe_h, pe_w)
