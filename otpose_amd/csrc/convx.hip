@@ -1,0 +1,487 @@
+// fp32 convolution on the gfx950 bf16 matrix cores: "split" (bf16x3) products, fp32 storage and accumulation.
+//
+// The HRNet convs (reference model/HRNet.py:500-571, 442-470) are fp32 NCHW tensors.  The f32 MFMA
+// (v_mfma_f32_16x16x4_f32, 157 TFLOP/s) bounds the whole OTPose forward at ~42 ms; the bf16 MFMA
+// (v_mfma_f32_16x16x32_bf16) is 16x faster per instruction.  Every fp32 operand is split into two bf16 pieces
+//     a = a_hi + a_lo + r,   a_hi = bf16_rne(a),  a_lo = bf16_rne(a - a_hi),   |r| <= 2^-18 |a|
+// and a product is accumulated in fp32 as  a_lo*b_hi + a_hi*b_lo + a_hi*b_hi  (three MFMAs; the dropped a_lo*b_lo and
+// remainder terms are <= 3 * 2^-18 |a b|, typically 2^-19: the same order as the fp32 rounding of a K = 432 accumulation).
+// Three bf16 MFMAs cost 3/16 of the f32 MFMA they replace, so the convolution turns HBM-bound.
+//
+// Implicit GEMM: M = 256 consecutive output pixels (flattened over the images of the batch: NCHW planes are contiguous, so
+// a lane's 4 accumulator rows are one aligned float4 of the output), N = 16 * NTW output channels, K = (tap, input channel)
+// in chunks of 16 channels.  Per chunk the input WINDOW (the image rows the 256 pixels touch, all columns, zero rows between
+// images / zero columns left and right) travels global fp32 NCHW -> registers -> split -> LDS as per-pixel records
+// [16 ch hi | 16 ch lo | 16 B pad] (80 B: an odd multiple of 16 B, so the 16 lanes of a fragment read hit 16 distinct bank
+// groups), the packed weights arrive in MFMA fragment order (lane-linear, conflict-free).  One k-step = 2 taps x 16 channels;
+// the loads of chunk c+1 are in flight under the MFMAs of chunk c.
+#include "common.h"
+#include <cstdlib>
+
+namespace {
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int XCK = 16;        // input channels per chunk
+constexpr int XPIX = 80;       // bytes of a window pixel record
+constexpr int XBM = 256;       // output pixels per workgroup
+constexpr int XKS = 5;         // k-steps per chunk of a 3x3 kernel (2 taps each, the tenth tap has zero weights)
+constexpr int XOOB = -16;      // buffer offset past any descriptor: the load returns zeros
+
+#ifdef OTP_CONVX_TIMING
+// development build only (tools/convx_timing.py): per-workgroup phase stamps, never in libotpose_hip.so
+__device__ unsigned long long otp_convx_stamps[8192 * 16];
+#define XSTAMP(slot)                                                                                  \
+    do {                                                                                              \
+        if (threadIdx.x == 0 && blockIdx.x < 8192) otp_convx_stamps[blockIdx.x * 16 + (slot)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define XSTAMP(slot)
+#endif
+
+__device__ __forceinline__ uint32_t xdiv(uint32_t i, uint32_t magic) { return magic ? __umulhi(i, magic) : i; }
+uint32_t xmagic(uint32_t d) { return d <= 1 ? 0u : (uint32_t)((1ull << 32) / d) + 1u; }   // exact while i * d < 2^32
+
+struct XPlan {
+    int N, Cin, H, W, HW, Cout, Ho, Wo, HoWo, total;
+    int in_ctot, in_coff, out_ctot, out_coff, res_ctot, res_coff, act;
+    int stride, pad, dil;
+    int NTW, nN, nTiles, nChunks, tpx;
+    int VR, WPp, rowsMax, QW, VW, NI;
+    int winBytes, wBytes;
+    uint32_t mHoWo, mWo, mVR, mQW, mRQ, mPad;
+};
+
+// split 8 floats into bf16 hi / lo vectors
+__device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo) {
+    uint32_t h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x2 a = {v[2 * i], v[2 * i + 1]};
+        const bf16x2 ah = __builtin_convertvector(a, bf16x2);
+        const uint32_t hb = __builtin_bit_cast(uint32_t, ah);
+        const f32x2 af = {__builtin_bit_cast(float, hb << 16), __builtin_bit_cast(float, hb & 0xffff0000u)};
+        const bf16x2 al = __builtin_convertvector(a - af, bf16x2);
+        h[i] = hb;
+        l[i] = __builtin_bit_cast(uint32_t, al);
+    }
+    hi = (u32x4){h[0], h[1], h[2], h[3]};
+    lo = (u32x4){l[0], l[1], l[2], l[3]};
+}
+
+// (Cout, Cin, 3, 3) fp32 (x scale[cout]) -> [cout block][chunk][k-step][n-tile][hi, lo][lane][8] bf16: the B fragments of
+// v_mfma_f32_16x16x32_bf16 (lane = (cout & 15) + 16 * kl; kl -> tap 2s + (kl >> 1), channels 8 (kl & 1) .. + 7 of the chunk)
+__global__ void convx_pack_kernel(const float* __restrict__ w, const float* __restrict__ scale, u32x4* __restrict__ out, int Cout,
+                                  int Cin, int NTW, int nN, int nChunks) {
+    const int total = nN * nChunks * XKS * NTW * 64;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int lane = idx & 63;
+        int r = idx >> 6;
+        const int t = r % NTW; r /= NTW;
+        const int s = r % XKS; r /= XKS;
+        const int chunk = r % nChunks, cb = r / nChunks;
+        const int cout = (cb * NTW + t) * 16 + (lane & 15), kl = lane >> 4;
+        const int tap = 2 * s + (kl >> 1), ci0 = chunk * XCK + 8 * (kl & 1);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int ci = ci0 + j;
+            v[j] = (tap < 9 && cout < Cout && ci < Cin) ? w[((size_t)cout * Cin + ci) * 9 + tap] * (scale ? scale[cout] : 1.f) : 0.f;
+        }
+        u32x4 hi, lo;
+        split8(v, hi, lo);
+        const size_t o = ((((size_t)(cb * nChunks + chunk) * XKS + s) * NTW + t) * 2) * 64 + lane;
+        out[o] = hi;
+        out[o + 64] = lo;
+    }
+}
+
+template <int VW, int NI, int NTW>
+__global__ __launch_bounds__(256, 2) void convx_kernel(const float* __restrict__ in, const u32x4* __restrict__ wpk,
+                                                        const float* __restrict__ shift, const float* res, float* out,
+                                                        const XPlan P) {
+    constexpr int MTW = 4;                                         // m-tiles (16 pixels) per wave
+    constexpr int WUNITS = XKS * NTW * 2 * 64;                     // 16-byte units of a chunk's weights
+    constexpr int NWL = (WUNITS + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* win = smem;
+    unsigned char* wl = smem + P.winBytes;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, kl = lane >> 4;
+
+    // workgroup -> (pixel tile, output-channel block).  Block ids are dealt round-robin to the 8 XCDs: XCD x walks the
+    // contiguous tile range [x * tpx, (x + 1) * tpx), the cout blocks of a tile back to back, so that the window rows shared
+    // by neighbouring tiles and the re-read window of the next cout block hit that XCD's L2.
+    const int xcd = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
+    const int tl = j / P.nN, cb = j - tl * P.nN;
+    const int tile = xcd * P.tpx + tl;
+    if (tile >= P.nTiles) return;
+    XSTAMP(0);
+#ifdef OTP_CONVX_TIMING
+    if (threadIdx.x == 0 && blockIdx.x < 8192) otp_convx_stamps[blockIdx.x * 16 + 9] = __builtin_amdgcn_s_memrealtime();
+#endif
+    const int P0 = tile * XBM;
+    const int n0 = P0 / P.HoWo, p0 = P0 - n0 * P.HoWo;
+    const int yo0 = p0 / P.Wo;
+    const int Vfirst = n0 * P.VR + yo0 * P.stride;                // first virtual row (image n: rows n*VR .. n*VR+pad-1 are zero rows)
+
+    // ---- window items: (channel group g, window row r, VW-pixel column group q) -> 8 channel loads + VW records ------------
+    int goff[NI], ldst[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int i = tid + 256 * j;
+        const int g = (int)xdiv((uint32_t)i, P.mRQ), r2 = i - g * (P.rowsMax * P.QW);
+        const int r = (int)xdiv((uint32_t)r2, P.mQW), q = r2 - r * P.QW;
+        const int V = Vfirst + r;
+        const int n = (int)xdiv((uint32_t)V, P.mVR), y = V - n * P.VR - P.pad;
+        const bool live = g < 2;
+        const bool valid = live && y >= 0 && n < P.N;
+        goff[j] = valid ? ((((n - n0) * P.in_ctot + 8 * g) * P.HW) + y * P.W + q * VW) * 4 : XOOB;
+        ldst[j] = live ? (r * P.WPp + P.pad + q * VW) * XPIX + g * 16 : -1;
+    }
+    const size_t in_base = ((size_t)n0 * P.in_ctot + P.in_coff) * P.HW;
+    const size_t in_left = ((size_t)P.N * P.in_ctot) * P.HW - in_base;
+    // (descriptor size capped below XOOB so that the masked offset is always out of range)
+    const otp_rsrc rin = make_rsrc32(in + in_base, in_left * 4 > 0x7fffffffull ? 0x7fffffffu : (unsigned)(in_left * 4));
+    const otp_rsrc rw = make_rsrc32(wpk, (unsigned)((size_t)P.nN * P.nChunks * WUNITS * 16));
+
+    float xv[NI][8][VW];
+    u32x4 wv[NWL];
+    auto load_chunk = [&](int c) __attribute__((always_inline)) {
+        const int cs = c * XCK * P.HW * 4;                         // scalar byte offset of the chunk's first channel
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int so = cs + e * P.HW * 4;
+                if constexpr (VW == 4) {
+                    const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, goff[j], so, 0));
+                    xv[j][e][0] = v[0]; xv[j][e][1] = v[1]; xv[j][e][2] = v[2]; xv[j][e][3] = v[3];
+                } else if constexpr (VW == 2) {
+                    const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rin, goff[j], so, 0));
+                    xv[j][e][0] = v[0]; xv[j][e][1] = v[1];
+                } else {
+                    xv[j][e][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, goff[j], so, 0));
+                }
+            }
+        const int wb = ((cb * P.nChunks + c) * WUNITS) * 16;
+#pragma unroll
+        for (int j = 0; j < NWL; ++j) {
+            const int i = tid + 256 * j;
+            wv[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, i < WUNITS ? wb + i * 16 : XOOB, 0, 0));
+        }
+    };
+    auto store_chunk = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            if (ldst[j] >= 0) {
+#pragma unroll
+                for (int k = 0; k < VW; ++k) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = xv[j][e][k];
+                    u32x4 hi, lo;
+                    split8(v, hi, lo);
+                    *reinterpret_cast<u32x4*>(win + ldst[j] + k * XPIX) = hi;
+                    *reinterpret_cast<u32x4*>(win + ldst[j] + k * XPIX + 32) = lo;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NWL; ++j) {
+            const int i = tid + 256 * j;
+            if (i < WUNITS) reinterpret_cast<u32x4*>(wl)[i] = wv[j];
+        }
+    };
+
+    load_chunk(0);
+    // zero the left / right padding columns of every window row and the slack records behind the last row once: the
+    // staging never writes them (hi and lo halves of a record; its last 16 bytes are never read)
+    {
+        const int npad = 2 * P.pad, nrec = P.rowsMax * npad + 2 * P.dil + 4;
+        for (int i = tid; i < nrec; i += 256) {
+            int rec;
+            if (i < P.rowsMax * npad) {
+                const int r = (int)xdiv((uint32_t)i, P.mPad), k = i - r * npad;
+                rec = r * P.WPp + (k < P.pad ? k : P.W + k);
+            } else {
+                rec = P.rowsMax * P.WPp + (i - P.rowsMax * npad);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<u32x4*>(win + rec * XPIX + 16 * q) = (u32x4){0u, 0u, 0u, 0u};
+        }
+    }
+
+    // ---- fragment addresses ---------------------------------------------------------------------------------------------------
+    int mbase[MTW];
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) {
+        int m = (wave * MTW + mt) * 16 + i16;
+        if (P0 + m >= P.total) m = P.total - 1 - P0;               // tail tile: a finite address, the result is dropped
+        const int p = p0 + m;
+        const int dn = (int)xdiv((uint32_t)p, P.mHoWo), pi = p - dn * P.HoWo;
+        const int yo = (int)xdiv((uint32_t)pi, P.mWo), xo = pi - yo * P.Wo;
+        const int r = (n0 + dn) * P.VR + yo * P.stride - Vfirst;
+        mbase[mt] = (r * P.WPp + xo * P.stride) * XPIX;
+    }
+    int toff[XKS];
+#pragma unroll
+    for (int s = 0; s < XKS; ++s) {
+        int tap = 2 * s + (kl >> 1);
+        if (tap > 8) tap = 8;                                      // zero weights: any finite data
+        const int dy = tap / 3, dx = tap - dy * 3;
+        toff[s] = ((dy * P.dil) * P.WPp + dx * P.dil) * XPIX + (kl & 1) * 16;
+    }
+
+    f32x4 acc[MTW][NTW];
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) acc[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // Fragment pipeline: the LDS reads of the next n-tile (and, at the last n-tile of a k-step, of the next step's pixel
+    // fragments) are issued before the 12 MFMAs of the current one, so no MFMA waits on an LDS round trip.
+    auto mfma_phase = [&]() __attribute__((always_inline)) {
+        bf16x8 ah[2][MTW], al[2][MTW], bh[2], bl[2];
+        auto load_a = [&](int buf, int s) __attribute__((always_inline)) {
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt) {
+                const unsigned char* a = win + mbase[mt] + toff[s];
+                ah[buf][mt] = *reinterpret_cast<const bf16x8*>(a);
+                al[buf][mt] = *reinterpret_cast<const bf16x8*>(a + 32);
+            }
+        };
+        auto load_b = [&](int buf, int s, int t) __attribute__((always_inline)) {
+            const unsigned char* b = wl + ((s * NTW + t) * 2) * 1024 + lane * 16;
+            bh[buf] = *reinterpret_cast<const bf16x8*>(b);
+            bl[buf] = *reinterpret_cast<const bf16x8*>(b + 1024);
+        };
+        load_a(0, 0);
+        load_b(0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < XKS; ++s)
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) {
+                const int cur = (s * NTW + t) & 1, sa = s & 1;
+                if (t + 1 < NTW) {
+                    load_b(cur ^ 1, s, t + 1);
+                } else if (s + 1 < XKS) {
+                    load_b(cur ^ 1, s + 1, 0);
+                    load_a(sa ^ 1, s + 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt) {
+                    acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[sa][mt], bh[cur], acc[mt][t], 0, 0, 0);
+                    acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[sa][mt], bl[cur], acc[mt][t], 0, 0, 0);
+                    acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[sa][mt], bh[cur], acc[mt][t], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    };
+
+    __syncthreads();                                               // window zeroed
+    XSTAMP(1);
+    for (int c = 0; c < P.nChunks - 1; ++c) {
+        store_chunk();
+        if (c == 0) XSTAMP(2);
+        __syncthreads();
+        if (c == 0) XSTAMP(3);
+        load_chunk(c + 1);                                         // in flight under the MFMAs
+        __builtin_amdgcn_sched_barrier(0);                         // (hipcc otherwise sinks the loads below the MFMAs)
+        mfma_phase();
+        if (c == 0) XSTAMP(4);
+        __syncthreads();                                           // every wave is done with the LDS image of chunk c
+        if (c == 0) XSTAMP(5);
+    }
+    store_chunk();
+    __syncthreads();
+    XSTAMP(6);
+
+    // ---- epilogue addresses + residual prefetch (the staging registers are free now) -------------------------------------------
+    const int co0 = (cb * NTW) * 16 + i16;
+    int eo[MTW], ro[MTW];
+    bool ev[MTW];
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) {
+        const int m = (wave * MTW + mt) * 16 + 4 * kl;
+        ev[mt] = P0 + m < P.total;
+        const int p = p0 + (ev[mt] ? m : 0);
+        const int dn = (int)xdiv((uint32_t)p, P.mHoWo), pi = p - dn * P.HoWo;
+        eo[mt] = ((n0 + dn) * P.out_ctot + P.out_coff) * P.HoWo + pi;
+        ro[mt] = ((n0 + dn) * P.res_ctot + P.res_coff) * P.HoWo + pi;
+    }
+    // residual: unconditional loads (a masked element re-reads a valid address of the output's own first pixel row)
+    f32x4 rv[MTW][NTW];
+    const float* rp = res ? res : out;
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const int co = co0 + 16 * t;
+            const bool ok = res && ev[mt] && co < P.Cout;
+            const size_t o = ok ? (size_t)ro[mt] + (size_t)co * P.HoWo : 0;
+            rv[mt][t] = *reinterpret_cast<const f32x4*>(rp + o);
+            if (!ok) rv[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    float shv[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+        const int co = co0 + 16 * t;
+        const bool ok = shift && co < P.Cout;
+        shv[t] = (shift ? shift : rp)[ok ? co : 0];
+        if (!ok) shv[t] = 0.f;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_phase();
+    XSTAMP(7);
+
+    const float lo = P.act == OTP_ACT_RELU ? 0.f : -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+        const int co = co0 + 16 * t;
+        const float sh = shv[t];
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) {
+            f32x4 y = acc[mt][t] + sh + rv[mt][t];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[r] = fmaxf(y[r], lo);
+            if (ev[mt] && co < P.Cout) *reinterpret_cast<f32x4*>(out + (size_t)eo[mt] + (size_t)co * P.HoWo) = y;
+        }
+    }
+    XSTAMP(8);
+#ifdef OTP_CONVX_TIMING
+    if (threadIdx.x == 0 && blockIdx.x < 8192) otp_convx_stamps[blockIdx.x * 16 + 10] = __builtin_amdgcn_s_memrealtime();
+#endif
+}
+
+bool convx_plan(const otp_conv_desc& d, XPlan& P) {
+    if (d.kh != 3 || d.kw != 3 || d.res_up > 1 || d.frame_split > 0 || d.in2_ctot > 0) return false;
+    if (d.stride != 1 || d.act == OTP_ACT_GELU) return false;
+    if (d.Cin % XCK) return false;
+    const int Ho = (d.H + 2 * d.pad - d.dil * 2 - 1) / d.stride + 1, Wo = (d.W + 2 * d.pad - d.dil * 2 - 1) / d.stride + 1;
+    if (Ho != d.Ho || Wo != d.Wo || Ho <= 0 || Wo <= 0) return false;
+    if ((Ho * Wo) & 3) return false;                               // a lane's 4 pixels stay inside one image, 16-byte aligned
+    P.N = d.N; P.Cin = d.Cin; P.H = d.H; P.W = d.W; P.HW = d.H * d.W; P.Cout = d.Cout;
+    P.Ho = Ho; P.Wo = Wo; P.HoWo = Ho * Wo; P.total = d.N * P.HoWo;
+    P.in_ctot = d.in_ctot; P.in_coff = d.in_coff; P.out_ctot = d.out_ctot; P.out_coff = d.out_coff;
+    P.res_ctot = d.res_ctot; P.res_coff = d.res_coff; P.act = d.act;
+    P.stride = d.stride; P.pad = d.pad; P.dil = d.dil;
+    const int c16 = (d.Cout + 15) / 16;
+    P.NTW = (c16 % 3 == 0) ? 3 : (c16 % 4 == 0 ? 4 : (c16 <= 2 ? 2 : (c16 % 2 == 0 ? 2 : 3)));
+    P.nN = (c16 + P.NTW - 1) / P.NTW;
+    P.nTiles = (P.total + XBM - 1) / XBM;
+    P.nChunks = d.Cin / XCK;
+    P.tpx = (P.nTiles + 7) / 8;
+    P.VR = d.H + d.pad;
+    P.WPp = d.W + 2 * d.pad;
+    P.VW = (d.W % 4 == 0 && P.HW % 4 == 0) ? 4 : ((d.W % 2 == 0 && P.HW % 2 == 0) ? 2 : 1);
+    P.QW = d.W / P.VW;
+    int rows = 0;
+    for (int t = 0; t < P.nTiles; ++t) {
+        const int a = t * XBM, b = (a + XBM < P.total ? a + XBM : P.total) - 1;
+        const int na = a / P.HoWo, ya = (a % P.HoWo) / Wo, nb = b / P.HoWo, yb = (b % P.HoWo) / Wo;
+        const int r = (nb * P.VR + yb * d.stride + 2 * d.dil) - (na * P.VR + ya * d.stride) + 1;
+        if (r > rows) rows = r;
+    }
+    P.rowsMax = rows;
+    P.NI = (2 * rows * P.QW + 255) / 256;
+    P.winBytes = (rows * P.WPp + 2 * d.dil + 4) * XPIX;             // + slack: the clamped tenth tap / tail pixels stay inside
+    P.winBytes = (P.winBytes + 15) & ~15;
+    P.wBytes = XKS * P.NTW * 2 * 1024;
+    P.mHoWo = xmagic(P.HoWo); P.mWo = xmagic(Wo); P.mVR = xmagic(P.VR); P.mQW = xmagic(P.QW); P.mRQ = xmagic(rows * P.QW); P.mPad = xmagic(2 * d.pad);
+    // exactness of the magic divisions (numerators < 2^32 / divisor) and 31-bit byte offsets
+    if ((long)(P.HoWo + XBM) * P.HoWo >= (1l << 32) || (long)P.N * P.VR * P.VR >= (1l << 32)) return false;
+    if ((long)(XBM / P.HoWo + 2) * d.in_ctot * P.HW * 4 >= (1l << 31)) return false;
+    if ((long)P.N * d.out_ctot * P.HoWo >= (1l << 31) || (long)P.N * (d.res_ctot > 0 ? d.res_ctot : 1) * P.HoWo >= (1l << 31)) return false;
+    if ((size_t)P.nN * P.nChunks * XKS * P.NTW * 2 * 1024 >= (1ull << 31)) return false;
+    if (P.NI > 3 || (P.VW == 4 && P.NI > 2)) return false;
+    return P.winBytes + P.wBytes <= OTP_LDS_LIMIT;
+}
+
+template <int VW, int NI, int NTW>
+int convx_launch(const float* in, const u32x4* wpk, const float* shift, const float* res, float* out, const XPlan& P, hipStream_t st) {
+    auto kern = convx_kernel<VW, NI, NTW>;
+    const size_t lds = (size_t)P.winBytes + P.wBytes;
+    OTP_ALLOW_BIG_LDS(kern, lds);
+    const dim3 grid(8 * P.tpx * P.nN);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, in, wpk, shift, res, out, P);
+    return otp_launch_status();
+}
+
+template <int NTW>
+int convx_dispatch(const float* in, const u32x4* wpk, const float* shift, const float* res, float* out, const XPlan& P, hipStream_t st) {
+    if (P.VW == 4 && P.NI == 1) return convx_launch<4, 1, NTW>(in, wpk, shift, res, out, P, st);
+    if (P.VW == 4 && P.NI == 2) return convx_launch<4, 2, NTW>(in, wpk, shift, res, out, P, st);
+    if (P.VW == 2 && P.NI <= 2) return convx_launch<2, 2, NTW>(in, wpk, shift, res, out, P, st);
+    if (P.VW == 2) return convx_launch<2, 3, NTW>(in, wpk, shift, res, out, P, st);
+    return convx_launch<1, 3, NTW>(in, wpk, shift, res, out, P, st);
+}
+
+}  // namespace
+
+#ifdef OTP_CONVX_TIMING
+extern "C" int otp_convx_read_stamps(void* host_out, size_t bytes) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(otp_convx_stamps), bytes) == hipSuccess ? OTP_OK : OTP_ERR_LAUNCH;
+}
+#endif
+
+extern "C" int otp_conv2d_x3_supported(const otp_conv_desc* desc) {
+    if (!desc) return 0;
+    XPlan P{};
+    return convx_plan(*desc, P) ? 1 : 0;
+}
+
+extern "C" size_t otp_conv2d_x3_weight_bytes(int Cout, int Cin) {
+    if (Cout <= 0 || Cin <= 0 || Cin % XCK) return 0;
+    otp_conv_desc d{};
+    d.Cout = Cout; d.Cin = Cin;
+    const int c16 = (Cout + 15) / 16;
+    const int NTW = (c16 % 3 == 0) ? 3 : (c16 % 4 == 0 ? 4 : (c16 <= 2 ? 2 : (c16 % 2 == 0 ? 2 : 3)));
+    const int nN = (c16 + NTW - 1) / NTW;
+    return (size_t)nN * (Cin / XCK) * XKS * NTW * 2 * 1024;
+}
+
+extern "C" int otp_conv2d_x3_pack_weight(const void* weight, const void* scale, void* wpacked, int Cout, int Cin, void* stream) {
+    if (!weight || !wpacked || Cout <= 0 || Cin <= 0) return OTP_ERR_BAD_ARG;
+    if (Cin % XCK) return OTP_ERR_UNSUPPORTED;
+    const int c16 = (Cout + 15) / 16;
+    const int NTW = (c16 % 3 == 0) ? 3 : (c16 % 4 == 0 ? 4 : (c16 <= 2 ? 2 : (c16 % 2 == 0 ? 2 : 3)));
+    const int nN = (c16 + NTW - 1) / NTW, nChunks = Cin / XCK;
+    const int total = nN * nChunks * XKS * NTW * 64;
+    hipLaunchKernelGGL(convx_pack_kernel, dim3(otp_ceil_div(total, 256) > 2048 ? 2048 : otp_ceil_div(total, 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), static_cast<const float*>(weight), static_cast<const float*>(scale),
+                       static_cast<u32x4*>(wpacked), Cout, Cin, NTW, nN, nChunks);
+    return otp_launch_status();
+}
+
+extern "C" int otp_conv2d_x3(const void* in, const void* wpacked, const void* shift, const void* res, void* out,
+                             const otp_conv_desc* desc, void* stream) {
+    if (!in || !wpacked || !out || !desc) return OTP_ERR_BAD_ARG;
+    const otp_conv_desc& d = *desc;
+    if (d.N <= 0 || d.Cin <= 0 || d.Cout <= 0 || d.H <= 0 || d.W <= 0) return OTP_ERR_BAD_ARG;
+    if (d.in_ctot < d.in_coff + d.Cin || d.out_ctot < d.out_coff + d.Cout || (res && d.res_ctot < d.res_coff + d.Cout))
+        return OTP_ERR_BAD_ARG;
+    if ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(wpacked) | reinterpret_cast<uintptr_t>(out) |
+         reinterpret_cast<uintptr_t>(res)) & 15)
+        return OTP_ERR_UNSUPPORTED;
+    XPlan P{};
+    if (!convx_plan(d, P)) return OTP_ERR_UNSUPPORTED;
+    auto st = static_cast<hipStream_t>(stream);
+    auto fi = static_cast<const float*>(in);
+    auto fw = static_cast<const u32x4*>(wpacked);
+    auto fs = static_cast<const float*>(shift);
+    auto fr = static_cast<const float*>(res);
+    auto fo = static_cast<float*>(out);
+    switch (P.NTW) {
+        case 2: return convx_dispatch<2>(fi, fw, fs, fr, fo, P, st);
+        case 3: return convx_dispatch<3>(fi, fw, fs, fr, fo, P, st);
+        default: return convx_dispatch<4>(fi, fw, fs, fr, fo, P, st);
+    }
+}

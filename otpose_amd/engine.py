@@ -50,6 +50,9 @@ class InferenceEngine:
             use_graph = os.environ.get("OTPOSE_HIP_GRAPH", "1") != "0"
         self.use_graph = use_graph
         self.use_winograd = os.environ.get("OTPOSE_WINOGRAD", "1") != "0"     # 3x3 stride-1 convs via csrc/wino.hip
+        # conv products: "x3" = fp32 operands split into two bf16 pieces, three bf16 MFMAs per product, fp32 accumulate
+        # (csrc/convx.hip); "f32" = the f32 MFMA kernels only (Winograd / direct)
+        self.use_x3 = os.environ.get("OTPOSE_CONV_MATH", "x3") != "f32"
         self.use_fused_mlp = os.environ.get("OTPOSE_FUSED_MLP", "1") != "0"   # transformer MLP via csrc/mlp.hip
         self.fuse_shortcut = os.environ.get("OTPOSE_FUSE_SHORTCUT", "1") != "0"  # layer1 shortcut folded into conv3
         self.fuse_upsample = os.environ.get("OTPOSE_FUSE_UPSAMPLE", "1") != "0"  # a fuse row's upsampled terms in one pass
@@ -170,6 +173,17 @@ class InferenceEngine:
         d = ops.conv_desc(inp, out, cout, kh, kw, stride, pad, dil, act, in2, res, res_up, frame_split, cin)
         self._keep.append(d)
         L = self.lib
+        if self.use_x3 and in2 is None and (kh, kw) == (3, 3) and ops.x3_supported(d):
+            # 3x3 / stride 1 with Cin % 16 == 0: split-bf16 (bf16x3) products on the bf16 matrix cores, fp32 storage and
+            # accumulation (csrc/convx.hip); the per-channel scale is folded into the packed weights
+            xp = ops.pack_x3_weight(w, sc)
+            self._keep.append(xp)
+            xargs = (hip.ptr(inp.t), hip.ptr(xp), hip.ptr(sh), hip.ptr(res.t if res is not None else None), hip.ptr(out.t), d)
+
+            def run_x3():
+                hip.check(L.otp_conv2d_x3(*xargs, self._stream), "otp_conv2d_x3")
+            self._emit(run_x3)
+            return out
         if self.use_winograd and in2 is None and self.winograd_pays(cin_w, cout) and ops.wino_supported(d):
             # 3x3 / stride 1 / pad 1 with enough channels: Winograd F(2x2,3x3) kernel (csrc/wino.hip), same epilogue
             up = ops.pack_wino_weight(w)

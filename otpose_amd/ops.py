@@ -319,6 +319,48 @@ def pack_wino_weight(weight):
     return u
 
 
+def pack_x3_weight(weight, scale=None):
+    """(Cout, Cin, 3, 3) fp32 (times scale[cout]) -> bf16 hi / lo MFMA fragments for :func:`conv2d_x3_launch`."""
+    _require_gpu(weight)
+    _check_f32(weight)
+    w = weight.detach().contiguous()
+    cout, cin, kh, kw = w.shape
+    assert (kh, kw) == (3, 3)
+    L = hip.lib()
+    nbytes = L.otp_conv2d_x3_weight_bytes(cout, cin)
+    if not nbytes:
+        raise ValueError(f"otp_conv2d_x3: unsupported channel counts ({cout}, {cin})")
+    u = torch.empty(nbytes // 4, dtype=torch.int32, device=w.device)
+    sc = scale.detach().contiguous().float() if scale is not None else None
+    hip.check(L.otp_conv2d_x3_pack_weight(hip.ptr(w), hip.ptr(sc), hip.ptr(u), cout, cin, hip.stream_of(w)),
+              "otp_conv2d_x3_pack_weight")
+    return u
+
+
+def x3_supported(desc) -> bool:
+    return bool(hip.lib().otp_conv2d_x3_supported(desc))
+
+
+def conv2d_x3_launch(inp: View, wpacked, shift, out: View, desc, res: View = None, stream=None):
+    st = hip.lib().otp_conv2d_x3(hip.ptr(inp.t), hip.ptr(wpacked), hip.ptr(shift), hip.ptr(res.t if res is not None else None),
+                                 hip.ptr(out.t), desc, stream if stream is not None else hip.stream_of(out.t))
+    hip.check(st, "otp_conv2d_x3")
+
+
+def conv2d_x3(x, weight, scale=None, shift=None, act=ACT_NONE, res=None, pad=1, dil=1):
+    """act(conv2d(x, weight, stride 1, pad, dil) * scale + shift + res) with split-bf16 products (csrc/convx.hip)."""
+    _require_gpu(x, weight)
+    n, cin, h, w = x.shape
+    cout = weight.shape[0]
+    ho, wo = h + 2 * pad - 2 * dil, w + 2 * pad - 2 * dil
+    out = torch.empty(n, cout, ho, wo, dtype=torch.float32, device=x.device)
+    iv, ov = View(x.contiguous()), View(out)
+    rv = View(res.contiguous()) if res is not None else None
+    d = conv_desc(iv, ov, cout, 3, 3, 1, pad, dil, act, None, rv)
+    conv2d_x3_launch(iv, pack_x3_weight(weight, scale), shift, ov, d, rv)
+    return out
+
+
 def ln_mlp_fused(y, gamma, beta, eps, packed, scale, shift, out=None, hid=None, stream=None):
     """out = y + scale * (W2 . gelu(W1 . LN(y) + b1)) + shift: ln2 + MLP + residual of TransformerBlock.forward
     (model/blocks.py:277-279) in one launch."""
