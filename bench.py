@@ -208,7 +208,10 @@ def golden_parity(model, cfg, dev):
         outs = [o.clone() for o in model(x.to(dev), margin=margin.to(dev))]
     names = ("output", "rough", "intersection", "prev_b", "context", "squeezed", "total_b")
     deltas = {n: float((o.cpu() - torch.from_numpy(z[n])).abs().max()) for n, o in zip(names, outs) if n in z.files}
+    ranges = {n: float(np.abs(z[n]).max()) for n in deltas}
     return {"max_abs_delta": max(deltas.values()), "max_abs_delta_output_heatmaps": deltas.get("output"),
+            "max_rel_delta": max(deltas[n] / max(ranges[n], 1e-30) for n in deltas),
+            "per_output": {n: {"max_abs_delta": deltas[n], "max_abs_ref": ranges[n]} for n in deltas},
             "tolerance": 1e-3, "vs": "tests/golden/e2e_cfg2_b1.npz (reference model, 1 clip of this config)"}
 
 

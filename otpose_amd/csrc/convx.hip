@@ -27,10 +27,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int XCK = 16;        // input channels per chunk
-constexpr int XPIX = 80;       // bytes of a window pixel record
-constexpr int XBM = 256;       // output pixels per workgroup
-constexpr int XKS = 5;         // k-steps per chunk of a 3x3 kernel (2 taps each, the tenth tap has zero weights)
+// Two shapes.  Stride 1: chunks of CK = 16 channels (k-step = 2 taps x 16 channels, 5 steps, the tenth tap has zero
+// weights), 256 pixels (4 m-tiles per wave).  Stride 2 reads 4x the input per output pixel: chunks of 8 channels (k-step =
+// 4 taps x 8 channels, 3 steps) and 128 pixels (2 m-tiles per wave) keep the window inside half the LDS.
+constexpr int xck(int stride) { return stride == 2 ? 8 : 16; }            // input channels per chunk
+constexpr int xmtw(int stride) { return stride == 2 ? 2 : 4; }            // m-tiles (16 pixels) per wave
+constexpr int xpix(int ck) { return ck * 4 + 16; }                        // bytes of a window pixel record: hi | lo | 16 B pad
+constexpr int xks(int ck) { return (9 * (ck / 8) + 3) / 4; }              // k-steps per chunk of a 3x3 kernel
 constexpr int XOOB = -16;      // buffer offset past any descriptor: the load returns zeros
 
 #ifdef OTP_CONVX_TIMING
@@ -52,9 +55,9 @@ struct XPlan {
     int in_ctot, in_coff, out_ctot, out_coff, res_ctot, res_coff, act;
     int stride, pad, dil;
     int NTW, nN, nTiles, nChunks, tpx;
-    int VR, WPp, rowsMax, QW, VW, NI;
+    int VR, WPp, CS, rowsMax, S, NI;
     int winBytes, wBytes;
-    uint32_t mHoWo, mWo, mVR, mQW, mRQ, mPad;
+    uint32_t mHoWo, mWo, mW;
 };
 
 // split 8 floats into bf16 hi / lo vectors
@@ -75,9 +78,11 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo
 }
 
 // (Cout, Cin, 3, 3) fp32 (x scale[cout]) -> [cout block][chunk][k-step][n-tile][hi, lo][lane][8] bf16: the B fragments of
-// v_mfma_f32_16x16x32_bf16 (lane = (cout & 15) + 16 * kl; kl -> tap 2s + (kl >> 1), channels 8 (kl & 1) .. + 7 of the chunk)
+// v_mfma_f32_16x16x32_bf16 (lane = (cout & 15) + 16 * kl; G = CK / 8 channel groups: kl -> tap (4 / G) s + kl / G, channels
+// 8 (kl % G) .. + 7 of the chunk)
 __global__ void convx_pack_kernel(const float* __restrict__ w, const float* __restrict__ scale, u32x4* __restrict__ out, int Cout,
-                                  int Cin, int NTW, int nN, int nChunks) {
+                                  int Cin, int NTW, int nN, int nChunks, int CK) {
+    const int G = CK / 8, XKS = xks(CK);
     const int total = nN * nChunks * XKS * NTW * 64;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
         const int lane = idx & 63;
@@ -86,7 +91,7 @@ __global__ void convx_pack_kernel(const float* __restrict__ w, const float* __re
         const int s = r % XKS; r /= XKS;
         const int chunk = r % nChunks, cb = r / nChunks;
         const int cout = (cb * NTW + t) * 16 + (lane & 15), kl = lane >> 4;
-        const int tap = 2 * s + (kl >> 1), ci0 = chunk * XCK + 8 * (kl & 1);
+        const int tap = (4 / G) * s + kl / G, ci0 = chunk * CK + 8 * (kl % G);
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -101,11 +106,11 @@ __global__ void convx_pack_kernel(const float* __restrict__ w, const float* __re
     }
 }
 
-template <int VW, int NI, int NTW>
+template <int CK, int MTW, int NI, int NTW>
 __global__ __launch_bounds__(256, 2) void convx_kernel(const float* __restrict__ in, const u32x4* __restrict__ wpk,
                                                         const float* __restrict__ shift, const float* res, float* out,
                                                         const XPlan P) {
-    constexpr int MTW = 4;                                         // m-tiles (16 pixels) per wave
+    constexpr int G = CK / 8, XKS = xks(CK), XPIX = xpix(CK), XBM = 64 * MTW, LO = CK * 2;
     constexpr int WUNITS = XKS * NTW * 2 * 64;                     // 16-byte units of a chunk's weights
     constexpr int NWL = (WUNITS + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -131,19 +136,38 @@ __global__ __launch_bounds__(256, 2) void convx_kernel(const float* __restrict__
     const int yo0 = p0 / P.Wo;
     const int Vfirst = n0 * P.VR + yo0 * P.stride;                // first virtual row (image n: rows n*VR .. n*VR+pad-1 are zero rows)
 
-    // ---- window items: (channel group g, window row r, VW-pixel column group q) -> 8 channel loads + VW records ------------
-    int goff[NI], ldst[NI];
+    // ---- window items: (channel group g, float4 f of an image plane) -> 8 channel loads + 4 pixel records ------------------
+    // The window rows of image n are one contiguous run of its NCHW plane, so the items of a channel group walk aligned
+    // float4s of that run (any W; H*W % 4 == 0); each of the 4 pixels finds its own record (row, de-interleaved column).
+    int T = 0;                                                     // items per channel group of this tile (uniform)
+    for (int sl = 0; sl < P.S; ++sl) {
+        const int n = n0 + sl, ya = max(0, Vfirst - n * P.VR - P.pad), yb = min(P.H, Vfirst + P.rowsMax - n * P.VR - P.pad);
+        T += (n < P.N && yb > ya) ? ((yb * P.W + 3) >> 2) - ((ya * P.W) >> 2) : 0;
+    }
+    int goff[NI], ldst[NI][4];
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int i = tid + 256 * j;
-        const int g = (int)xdiv((uint32_t)i, P.mRQ), r2 = i - g * (P.rowsMax * P.QW);
-        const int r = (int)xdiv((uint32_t)r2, P.mQW), q = r2 - r * P.QW;
-        const int V = Vfirst + r;
-        const int n = (int)xdiv((uint32_t)V, P.mVR), y = V - n * P.VR - P.pad;
-        const bool live = g < 2;
-        const bool valid = live && y >= 0 && n < P.N;
-        goff[j] = valid ? ((((n - n0) * P.in_ctot + 8 * g) * P.HW) + y * P.W + q * VW) * 4 : XOOB;
-        ldst[j] = live ? (r * P.WPp + P.pad + q * VW) * XPIX + g * 16 : -1;
+        const int g = (G == 2 && i >= T) ? 1 : 0;
+        int rem = i - g * T, f = -1, n = 0;
+        if (rem >= T) rem = -1;
+        for (int sl = 0; sl < P.S; ++sl) {
+            const int ns = n0 + sl, ya = max(0, Vfirst - ns * P.VR - P.pad), yb = min(P.H, Vfirst + P.rowsMax - ns * P.VR - P.pad);
+            const int c = (ns < P.N && yb > ya) ? ((yb * P.W + 3) >> 2) - ((ya * P.W) >> 2) : 0;
+            if (f < 0 && rem >= 0 && rem < c) { f = ((ya * P.W) >> 2) + rem; n = ns; }
+            rem -= (f < 0) ? c : 0;
+        }
+        goff[j] = f >= 0 ? ((((n - n0) * P.in_ctot + 8 * g) * P.HW) + 4 * f) * 4 : XOOB;
+        const int y0 = (int)xdiv((uint32_t)(f >= 0 ? 4 * f : 0), P.mW);
+        int y = y0, x = (f >= 0 ? 4 * f : 0) - y0 * P.W;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = n * P.VR + P.pad + y - Vfirst;
+            const int xw = x + P.pad;
+            const int col = P.stride == 2 ? (xw & 1) * P.CS + (xw >> 1) : xw;
+            ldst[j][k] = (f >= 0 && r >= 0 && r < P.rowsMax && y < P.H) ? (r * P.WPp + col) * XPIX + g * 16 : -1;
+            if (++x == P.W) { x = 0; ++y; }
+        }
     }
     const size_t in_base = ((size_t)n0 * P.in_ctot + P.in_coff) * P.HW;
     const size_t in_left = ((size_t)P.N * P.in_ctot) * P.HW - in_base;
@@ -151,25 +175,15 @@ __global__ __launch_bounds__(256, 2) void convx_kernel(const float* __restrict__
     const otp_rsrc rin = make_rsrc32(in + in_base, in_left * 4 > 0x7fffffffull ? 0x7fffffffu : (unsigned)(in_left * 4));
     const otp_rsrc rw = make_rsrc32(wpk, (unsigned)((size_t)P.nN * P.nChunks * WUNITS * 16));
 
-    float xv[NI][8][VW];
+    f32x4 xv[NI][8];
     u32x4 wv[NWL];
     auto load_chunk = [&](int c) __attribute__((always_inline)) {
-        const int cs = c * XCK * P.HW * 4;                         // scalar byte offset of the chunk's first channel
+        const int cs = c * CK * P.HW * 4;                          // scalar byte offset of the chunk's first channel
 #pragma unroll
         for (int j = 0; j < NI; ++j)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int so = cs + e * P.HW * 4;
-                if constexpr (VW == 4) {
-                    const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, goff[j], so, 0));
-                    xv[j][e][0] = v[0]; xv[j][e][1] = v[1]; xv[j][e][2] = v[2]; xv[j][e][3] = v[3];
-                } else if constexpr (VW == 2) {
-                    const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rin, goff[j], so, 0));
-                    xv[j][e][0] = v[0]; xv[j][e][1] = v[1];
-                } else {
-                    xv[j][e][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, goff[j], so, 0));
-                }
-            }
+            for (int e = 0; e < 8; ++e)
+                xv[j][e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, goff[j], cs + e * P.HW * 4, 0));
         const int wb = ((cb * P.nChunks + c) * WUNITS) * 16;
 #pragma unroll
         for (int j = 0; j < NWL; ++j) {
@@ -179,20 +193,19 @@ __global__ __launch_bounds__(256, 2) void convx_kernel(const float* __restrict__
     };
     auto store_chunk = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            if (ldst[j] >= 0) {
+        for (int j = 0; j < NI; ++j)
 #pragma unroll
-                for (int k = 0; k < VW; ++k) {
-                    float v[8];
+            for (int k = 0; k < 4; ++k) {
+                float v[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = xv[j][e][k];
-                    u32x4 hi, lo;
-                    split8(v, hi, lo);
-                    *reinterpret_cast<u32x4*>(win + ldst[j] + k * XPIX) = hi;
-                    *reinterpret_cast<u32x4*>(win + ldst[j] + k * XPIX + 32) = lo;
+                for (int e = 0; e < 8; ++e) v[e] = xv[j][e][k];
+                u32x4 hi, lo;
+                split8(v, hi, lo);
+                if (ldst[j][k] >= 0) {
+                    *reinterpret_cast<u32x4*>(win + ldst[j][k]) = hi;
+                    *reinterpret_cast<u32x4*>(win + ldst[j][k] + LO) = lo;
                 }
             }
-        }
 #pragma unroll
         for (int j = 0; j < NWL; ++j) {
             const int i = tid + 256 * j;
@@ -201,22 +214,9 @@ __global__ __launch_bounds__(256, 2) void convx_kernel(const float* __restrict__
     };
 
     load_chunk(0);
-    // zero the left / right padding columns of every window row and the slack records behind the last row once: the
-    // staging never writes them (hi and lo halves of a record; its last 16 bytes are never read)
-    {
-        const int npad = 2 * P.pad, nrec = P.rowsMax * npad + 2 * P.dil + 4;
-        for (int i = tid; i < nrec; i += 256) {
-            int rec;
-            if (i < P.rowsMax * npad) {
-                const int r = (int)xdiv((uint32_t)i, P.mPad), k = i - r * npad;
-                rec = r * P.WPp + (k < P.pad ? k : P.W + k);
-            } else {
-                rec = P.rowsMax * P.WPp + (i - P.rowsMax * npad);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) *reinterpret_cast<u32x4*>(win + rec * XPIX + 16 * q) = (u32x4){0u, 0u, 0u, 0u};
-        }
-    }
+    // zero the window once: the zero rows between / around the images, the left / right padding columns and the slack records
+    // behind the last row are never written by the staging
+    for (int i = tid; i < P.winBytes / 16; i += 256) reinterpret_cast<u32x4*>(win)[i] = (u32x4){0u, 0u, 0u, 0u};
 
     // ---- fragment addresses ---------------------------------------------------------------------------------------------------
     int mbase[MTW];
@@ -228,15 +228,16 @@ __global__ __launch_bounds__(256, 2) void convx_kernel(const float* __restrict__
         const int dn = (int)xdiv((uint32_t)p, P.mHoWo), pi = p - dn * P.HoWo;
         const int yo = (int)xdiv((uint32_t)pi, P.mWo), xo = pi - yo * P.Wo;
         const int r = (n0 + dn) * P.VR + yo * P.stride - Vfirst;
-        mbase[mt] = (r * P.WPp + xo * P.stride) * XPIX;
+        mbase[mt] = (r * P.WPp + xo) * XPIX;                        // (columns are de-interleaved by x mod stride)
     }
     int toff[XKS];
 #pragma unroll
     for (int s = 0; s < XKS; ++s) {
-        int tap = 2 * s + (kl >> 1);
+        int tap = (4 / G) * s + kl / G;
         if (tap > 8) tap = 8;                                      // zero weights: any finite data
         const int dy = tap / 3, dx = tap - dy * 3;
-        toff[s] = ((dy * P.dil) * P.WPp + dx * P.dil) * XPIX + (kl & 1) * 16;
+        const int xs = dx * P.dil;
+        toff[s] = ((dy * P.dil) * P.WPp + (P.stride == 2 ? (xs & 1) * P.CS + (xs >> 1) : xs)) * XPIX + (kl % G) * 16;
     }
 
     f32x4 acc[MTW][NTW];
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void convx_kernel(const float* __restrict__
             for (int mt = 0; mt < MTW; ++mt) {
                 const unsigned char* a = win + mbase[mt] + toff[s];
                 ah[buf][mt] = *reinterpret_cast<const bf16x8*>(a);
-                al[buf][mt] = *reinterpret_cast<const bf16x8*>(a + 32);
+                al[buf][mt] = *reinterpret_cast<const bf16x8*>(a + LO);
             }
         };
         auto load_b = [&](int buf, int s, int t) __attribute__((always_inline)) {
@@ -361,10 +362,13 @@ __global__ __launch_bounds__(256, 2) void convx_kernel(const float* __restrict__
 #endif
 }
 
+int x3_ntw(int Cout);
+
 bool convx_plan(const otp_conv_desc& d, XPlan& P) {
     if (d.kh != 3 || d.kw != 3 || d.res_up > 1 || d.frame_split > 0 || d.in2_ctot > 0) return false;
-    if (d.stride != 1 || d.act == OTP_ACT_GELU) return false;
-    if (d.Cin % XCK) return false;
+    if ((d.stride != 1 && d.stride != 2) || d.act == OTP_ACT_GELU) return false;
+    const int CK = xck(d.stride), XBM = 64 * xmtw(d.stride), XKS = xks(CK), XPIX = xpix(CK);
+    if (d.Cin % CK || ((d.H * d.W) & 3)) return false;
     const int Ho = (d.H + 2 * d.pad - d.dil * 2 - 1) / d.stride + 1, Wo = (d.W + 2 * d.pad - d.dil * 2 - 1) / d.stride + 1;
     if (Ho != d.Ho || Wo != d.Wo || Ho <= 0 || Wo <= 0) return false;
     if ((Ho * Wo) & 3) return false;                               // a lane's 4 pixels stay inside one image, 16-byte aligned
@@ -374,15 +378,15 @@ bool convx_plan(const otp_conv_desc& d, XPlan& P) {
     P.res_ctot = d.res_ctot; P.res_coff = d.res_coff; P.act = d.act;
     P.stride = d.stride; P.pad = d.pad; P.dil = d.dil;
     const int c16 = (d.Cout + 15) / 16;
-    P.NTW = (c16 % 3 == 0) ? 3 : (c16 % 4 == 0 ? 4 : (c16 <= 2 ? 2 : (c16 % 2 == 0 ? 2 : 3)));
+    P.NTW = x3_ntw(d.Cout);
     P.nN = (c16 + P.NTW - 1) / P.NTW;
     P.nTiles = (P.total + XBM - 1) / XBM;
-    P.nChunks = d.Cin / XCK;
+    P.nChunks = d.Cin / CK;
     P.tpx = (P.nTiles + 7) / 8;
-    P.VR = d.H + d.pad;
-    P.WPp = d.W + 2 * d.pad;
-    P.VW = (d.W % 4 == 0 && P.HW % 4 == 0) ? 4 : ((d.W % 2 == 0 && P.HW % 2 == 0) ? 2 : 1);
-    P.QW = d.W / P.VW;
+    P.VR = d.H + d.pad;                                            // virtual rows per image: pad zero rows, then the H image rows
+    if ((Ho - 1) * d.stride >= P.VR) return false;
+    P.CS = (d.W + 2 * d.pad + d.stride - 1) / d.stride;            // records per column-parity class
+    P.WPp = P.CS * d.stride;
     int rows = 0;
     for (int t = 0; t < P.nTiles; ++t) {
         const int a = t * XBM, b = (a + XBM < P.total ? a + XBM : P.total) - 1;
@@ -391,23 +395,37 @@ bool convx_plan(const otp_conv_desc& d, XPlan& P) {
         if (r > rows) rows = r;
     }
     P.rowsMax = rows;
-    P.NI = (2 * rows * P.QW + 255) / 256;
+    int Tmax = 0, S = 1;
+    for (int t = 0; t < P.nTiles; ++t) {                           // window items / image slots of every tile (as the kernel counts them)
+        const int a = t * XBM, n0 = a / P.HoWo, Vfirst = n0 * P.VR + ((a % P.HoWo) / Wo) * d.stride;
+        int T = 0, sl = 0;
+        for (;; ++sl) {
+            const int n = n0 + sl, lo = Vfirst - n * P.VR - d.pad, hi = Vfirst + rows - n * P.VR - d.pad;
+            if (hi <= 0 || n >= d.N) break;
+            const int ya = lo > 0 ? lo : 0, yb = hi < d.H ? hi : d.H;
+            if (yb > ya) T += ((yb * d.W + 3) >> 2) - ((ya * d.W) >> 2);
+        }
+        if (T > Tmax) Tmax = T;
+        if (sl > S) S = sl;
+    }
+    P.S = S;
+    P.NI = ((CK / 8) * Tmax + 255) / 256;
     P.winBytes = (rows * P.WPp + 2 * d.dil + 4) * XPIX;             // + slack: the clamped tenth tap / tail pixels stay inside
     P.winBytes = (P.winBytes + 15) & ~15;
     P.wBytes = XKS * P.NTW * 2 * 1024;
-    P.mHoWo = xmagic(P.HoWo); P.mWo = xmagic(Wo); P.mVR = xmagic(P.VR); P.mQW = xmagic(P.QW); P.mRQ = xmagic(rows * P.QW); P.mPad = xmagic(2 * d.pad);
+    P.mHoWo = xmagic(P.HoWo); P.mWo = xmagic(Wo); P.mW = xmagic(d.W);
     // exactness of the magic divisions (numerators < 2^32 / divisor) and 31-bit byte offsets
-    if ((long)(P.HoWo + XBM) * P.HoWo >= (1l << 32) || (long)P.N * P.VR * P.VR >= (1l << 32)) return false;
-    if ((long)(XBM / P.HoWo + 2) * d.in_ctot * P.HW * 4 >= (1l << 31)) return false;
+    if ((long)(P.HoWo + XBM) * P.HoWo >= (1l << 32) || (long)P.HW * d.W >= (1l << 32)) return false;
+    if ((long)(S + 1) * d.in_ctot * P.HW * 4 >= (1l << 31)) return false;
     if ((long)P.N * d.out_ctot * P.HoWo >= (1l << 31) || (long)P.N * (d.res_ctot > 0 ? d.res_ctot : 1) * P.HoWo >= (1l << 31)) return false;
     if ((size_t)P.nN * P.nChunks * XKS * P.NTW * 2 * 1024 >= (1ull << 31)) return false;
-    if (P.NI > 3 || (P.VW == 4 && P.NI > 2)) return false;
+    if (P.NI > 2 || S > 64) return false;
     return P.winBytes + P.wBytes <= OTP_LDS_LIMIT;
 }
 
-template <int VW, int NI, int NTW>
+template <int CK, int MTW, int NI, int NTW>
 int convx_launch(const float* in, const u32x4* wpk, const float* shift, const float* res, float* out, const XPlan& P, hipStream_t st) {
-    auto kern = convx_kernel<VW, NI, NTW>;
+    auto kern = convx_kernel<CK, MTW, NI, NTW>;
     const size_t lds = (size_t)P.winBytes + P.wBytes;
     OTP_ALLOW_BIG_LDS(kern, lds);
     const dim3 grid(8 * P.tpx * P.nN);
@@ -417,11 +435,16 @@ int convx_launch(const float* in, const u32x4* wpk, const float* shift, const fl
 
 template <int NTW>
 int convx_dispatch(const float* in, const u32x4* wpk, const float* shift, const float* res, float* out, const XPlan& P, hipStream_t st) {
-    if (P.VW == 4 && P.NI == 1) return convx_launch<4, 1, NTW>(in, wpk, shift, res, out, P, st);
-    if (P.VW == 4 && P.NI == 2) return convx_launch<4, 2, NTW>(in, wpk, shift, res, out, P, st);
-    if (P.VW == 2 && P.NI <= 2) return convx_launch<2, 2, NTW>(in, wpk, shift, res, out, P, st);
-    if (P.VW == 2) return convx_launch<2, 3, NTW>(in, wpk, shift, res, out, P, st);
-    return convx_launch<1, 3, NTW>(in, wpk, shift, res, out, P, st);
+    if (P.stride == 2)
+        return P.NI <= 1 ? convx_launch<xck(2), xmtw(2), 1, NTW>(in, wpk, shift, res, out, P, st)
+                         : convx_launch<xck(2), xmtw(2), 2, NTW>(in, wpk, shift, res, out, P, st);
+    return P.NI <= 1 ? convx_launch<xck(1), xmtw(1), 1, NTW>(in, wpk, shift, res, out, P, st)
+                     : convx_launch<xck(1), xmtw(1), 2, NTW>(in, wpk, shift, res, out, P, st);
+}
+
+int x3_ntw(int Cout) {
+    const int c16 = (Cout + 15) / 16;
+    return (c16 % 3 == 0) ? 3 : (c16 % 4 == 0 ? 4 : (c16 <= 2 ? 2 : (c16 % 2 == 0 ? 2 : 3)));
 }
 
 }  // namespace
@@ -438,26 +461,21 @@ extern "C" int otp_conv2d_x3_supported(const otp_conv_desc* desc) {
     return convx_plan(*desc, P) ? 1 : 0;
 }
 
-extern "C" size_t otp_conv2d_x3_weight_bytes(int Cout, int Cin) {
-    if (Cout <= 0 || Cin <= 0 || Cin % XCK) return 0;
-    otp_conv_desc d{};
-    d.Cout = Cout; d.Cin = Cin;
-    const int c16 = (Cout + 15) / 16;
-    const int NTW = (c16 % 3 == 0) ? 3 : (c16 % 4 == 0 ? 4 : (c16 <= 2 ? 2 : (c16 % 2 == 0 ? 2 : 3)));
-    const int nN = (c16 + NTW - 1) / NTW;
-    return (size_t)nN * (Cin / XCK) * XKS * NTW * 2 * 1024;
+extern "C" size_t otp_conv2d_x3_weight_bytes(int Cout, int Cin, int stride) {
+    if (Cout <= 0 || Cin <= 0 || (stride != 1 && stride != 2) || Cin % xck(stride)) return 0;
+    const int CK = xck(stride), NTW = x3_ntw(Cout), nN = ((Cout + 15) / 16 + NTW - 1) / NTW;
+    return (size_t)nN * (Cin / CK) * xks(CK) * NTW * 2 * 1024;
 }
 
-extern "C" int otp_conv2d_x3_pack_weight(const void* weight, const void* scale, void* wpacked, int Cout, int Cin, void* stream) {
+extern "C" int otp_conv2d_x3_pack_weight(const void* weight, const void* scale, void* wpacked, int Cout, int Cin, int stride,
+                                         void* stream) {
     if (!weight || !wpacked || Cout <= 0 || Cin <= 0) return OTP_ERR_BAD_ARG;
-    if (Cin % XCK) return OTP_ERR_UNSUPPORTED;
-    const int c16 = (Cout + 15) / 16;
-    const int NTW = (c16 % 3 == 0) ? 3 : (c16 % 4 == 0 ? 4 : (c16 <= 2 ? 2 : (c16 % 2 == 0 ? 2 : 3)));
-    const int nN = (c16 + NTW - 1) / NTW, nChunks = Cin / XCK;
-    const int total = nN * nChunks * XKS * NTW * 64;
+    if ((stride != 1 && stride != 2) || Cin % xck(stride)) return OTP_ERR_UNSUPPORTED;
+    const int CK = xck(stride), NTW = x3_ntw(Cout), nN = ((Cout + 15) / 16 + NTW - 1) / NTW, nChunks = Cin / CK;
+    const int total = nN * nChunks * xks(CK) * NTW * 64;
     hipLaunchKernelGGL(convx_pack_kernel, dim3(otp_ceil_div(total, 256) > 2048 ? 2048 : otp_ceil_div(total, 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), static_cast<const float*>(weight), static_cast<const float*>(scale),
-                       static_cast<u32x4*>(wpacked), Cout, Cin, NTW, nN, nChunks);
+                       static_cast<u32x4*>(wpacked), Cout, Cin, NTW, nN, nChunks, CK);
     return otp_launch_status();
 }
 

@@ -1,0 +1,85 @@
+"""Split-bf16 (bf16x3) convolution kernel (csrc/convx.hip, otp_conv2d_x3) against a float64 ``F.conv2d`` of the same
+operands: the HRNet 3x3 convs of model/HRNet.py:500-571 (stride 1) and :442-470 (stride-2 transitions / fuse downsamples),
+plus the dilated offset / mask convs of model/OTPose.py:168-177.  Tolerance: 2e-5 of the output range (measured 4e-6; the
+f32-MFMA kernels sit at 3e-7 .. 2e-6): two bf16 pieces carry 16 mantissa bits + rounding, see the kernel header."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from otpose_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+# (N, Cin, Cout, H, W, pad, dil, stride, residual, relu)
+CASES = [
+    (5, 48, 48, 96, 72, 1, 1, 1, True, True),        # tiles end inside rows, 27 tiles per image
+    (3, 96, 96, 48, 36, 1, 1, 1, False, True),       # tiles straddle images
+    (3, 192, 192, 24, 18, 1, 1, 1, True, False),     # W % 4 != 0: float4 items wrap rows
+    (7, 384, 96, 12, 9, 1, 1, 1, True, True),        # several images per tile, odd width
+    (2, 64, 64, 96, 72, 1, 1, 1, False, False),      # 4 n-tiles per workgroup
+    (2, 32, 40, 10, 6, 1, 1, 1, True, True),         # tiny maps, Cout not a multiple of 16, tail tile
+    (1, 16, 17, 8, 4, 1, 1, 1, False, False),        # one partial tile
+    (2, 32, 459, 24, 20, 3, 3, 1, False, False),     # dilated offset conv shape (pad = dilation)
+    (2, 32, 153, 40, 28, 6, 6, 1, False, False),     # dilation 6: half of the window is padding
+    (2, 16, 16, 12, 12, 0, 1, 1, False, True),       # valid convolution (no padding)
+    (5, 48, 48, 96, 72, 1, 1, 2, False, True),       # stride 2: de-interleaved columns, 8-channel chunks
+    (3, 48, 96, 96, 72, 1, 1, 2, True, True),
+    (3, 96, 192, 48, 36, 1, 1, 2, True, False),
+    (5, 192, 384, 24, 18, 1, 1, 2, True, True),
+    (2, 64, 64, 64, 48, 1, 1, 2, False, True),
+    (2, 24, 40, 20, 12, 1, 1, 2, True, False),       # Cin % 8 == 0 only (stride-2 chunking)
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "x".join(str(v) for v in c[:8]))
+def test_conv2d_x3_matches_float64(case):
+    n, ci, co, h, w, pad, dil, st, with_res, relu = case
+    g = torch.Generator(device="cpu").manual_seed(sum(case[:8]))
+    x = torch.randn(n, ci, h, w, generator=g).cuda()
+    wt = (torch.randn(co, ci, 3, 3, generator=g) * (2.0 / (ci * 9)) ** 0.5).cuda()
+    sc = (torch.rand(co, generator=g) + 0.5).cuda()
+    sh = torch.randn(co, generator=g).cuda()
+    ho, wo = (h + 2 * pad - 2 * dil - 1) // st + 1, (w + 2 * pad - 2 * dil - 1) // st + 1
+    res = torch.randn(n, co, ho, wo, generator=g).cuda() if with_res else None
+    ref = F.conv2d(x.double(), wt.double(), None, st, pad, dil) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)
+    if with_res:
+        ref = ref + res.double()
+    if relu:
+        ref = torch.relu(ref)
+    y = ops.conv2d_x3(x, wt, sc, sh, ops.ACT_RELU if relu else ops.ACT_NONE, res, pad, dil, st)
+    assert y.shape == ref.shape
+    err = float((y.double() - ref).abs().max()) / float(ref.abs().max())
+    assert err <= 2e-5, err
+
+
+def test_conv2d_x3_channel_sliced_views():
+    """Input, output and residual as channel windows of wider tensors (the engine's concat-free layout)."""
+    g = torch.Generator(device="cpu").manual_seed(5)
+    big_in = torch.randn(3, 80, 24, 20, generator=g).cuda()
+    big_out = torch.full((3, 70, 24, 20), 7.0).cuda()
+    big_res = torch.randn(3, 50, 24, 20, generator=g).cuda()
+    wt = (torch.randn(24, 32, 3, 3, generator=g) * 0.1).cuda()
+    sh = torch.randn(24, generator=g).cuda()
+    iv, ov, rv = ops.View(big_in, 16, 32), ops.View(big_out, 40, 24), ops.View(big_res, 8, 24)
+    d = ops.conv_desc(iv, ov, 24, 3, 3, 1, 1, 1, ops.ACT_RELU, None, rv)
+    assert ops.x3_supported(d)
+    ops.conv2d_x3_launch(iv, ops.pack_x3_weight(wt), sh, ov, d, rv)
+    ref = torch.relu(F.conv2d(big_in[:, 16:48].double(), wt.double(), None, 1, 1) + sh.double().view(1, -1, 1, 1)
+                     + big_res[:, 8:32].double())
+    assert float((big_out[:, 40:64].double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    assert bool((big_out[:, :40] == 7.0).all()) and bool((big_out[:, 64:] == 7.0).all())
+
+
+def test_conv2d_x3_rejects_what_it_does_not_cover():
+    x = torch.zeros(1, 20, 8, 8).cuda()
+    out = torch.zeros(1, 16, 8, 8).cuda()
+    d = ops.conv_desc(ops.View(x), ops.View(out), 16, 3, 3, 1, 1, 1)
+    assert not ops.x3_supported(d)                    # Cin % 16 != 0
+    with pytest.raises(ValueError):
+        ops.pack_x3_weight(torch.zeros(16, 20, 3, 3).cuda())
+    x = torch.zeros(1, 32, 96, 72).cuda()             # dilation 15 at 96x72: the window does not fit the LDS
+    out = torch.zeros(1, 16, 96, 72).cuda()
+    assert not ops.x3_supported(ops.conv_desc(ops.View(x), ops.View(out), 16, 3, 3, 1, 15, 15))
+    x = torch.zeros(1, 16, 9, 7).cuda()               # H*W % 4 != 0
+    out = torch.zeros(1, 16, 9, 7).cuda()
+    assert not ops.x3_supported(ops.conv_desc(ops.View(x), ops.View(out), 16, 3, 3, 1, 1, 1))
