@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256, 2) void convx_kernel(const float* __restrict__
 #endif
 }
 
-int x3_ntw(int Cout);
+int x3_ntw(int Cout, int stride);
 
 bool convx_plan(const otp_conv_desc& d, XPlan& P) {
     if (d.kh != 3 || d.kw != 3 || d.res_up > 1 || d.frame_split > 0 || d.in2_ctot > 0) return false;
@@ -378,7 +378,7 @@ bool convx_plan(const otp_conv_desc& d, XPlan& P) {
     P.res_ctot = d.res_ctot; P.res_coff = d.res_coff; P.act = d.act;
     P.stride = d.stride; P.pad = d.pad; P.dil = d.dil;
     const int c16 = (d.Cout + 15) / 16;
-    P.NTW = x3_ntw(d.Cout);
+    P.NTW = x3_ntw(d.Cout, d.stride);
     P.nN = (c16 + P.NTW - 1) / P.NTW;
     P.nTiles = (P.total + XBM - 1) / XBM;
     P.nChunks = d.Cin / CK;
@@ -442,9 +442,12 @@ int convx_dispatch(const float* in, const u32x4* wpk, const float* shift, const 
                      : convx_launch<xck(1), xmtw(1), 2, NTW>(in, wpk, shift, res, out, P, st);
 }
 
-int x3_ntw(int Cout) {
+int x3_ntw(int Cout, int stride) {
     const int c16 = (Cout + 15) / 16;
-    return (c16 % 3 == 0) ? 3 : (c16 % 4 == 0 ? 4 : (c16 <= 2 ? 2 : (c16 % 2 == 0 ? 2 : 3)));
+    if (stride == 2) return (c16 % 3 == 0) ? 3 : (c16 % 4 == 0 ? 4 : (c16 <= 2 ? 2 : (c16 % 2 == 0 ? 2 : 3)));
+    // stride 1: 3 n-tiles per workgroup when they divide Cout, else 2: with 4 the accumulators + staging registers spill and
+    // the LDS image (window + 40 KB of weights) leaves one workgroup per CU (64 -> 64 @96x72: 220 us with 4, 194 with 2)
+    return (c16 % 3 == 0) ? 3 : (c16 % 2 == 0 || c16 <= 2 ? 2 : 3);
 }
 
 }  // namespace
@@ -463,7 +466,7 @@ extern "C" int otp_conv2d_x3_supported(const otp_conv_desc* desc) {
 
 extern "C" size_t otp_conv2d_x3_weight_bytes(int Cout, int Cin, int stride) {
     if (Cout <= 0 || Cin <= 0 || (stride != 1 && stride != 2) || Cin % xck(stride)) return 0;
-    const int CK = xck(stride), NTW = x3_ntw(Cout), nN = ((Cout + 15) / 16 + NTW - 1) / NTW;
+    const int CK = xck(stride), NTW = x3_ntw(Cout, stride), nN = ((Cout + 15) / 16 + NTW - 1) / NTW;
     return (size_t)nN * (Cin / CK) * xks(CK) * NTW * 2 * 1024;
 }
 
@@ -471,7 +474,7 @@ extern "C" int otp_conv2d_x3_pack_weight(const void* weight, const void* scale, 
                                          void* stream) {
     if (!weight || !wpacked || Cout <= 0 || Cin <= 0) return OTP_ERR_BAD_ARG;
     if ((stride != 1 && stride != 2) || Cin % xck(stride)) return OTP_ERR_UNSUPPORTED;
-    const int CK = xck(stride), NTW = x3_ntw(Cout), nN = ((Cout + 15) / 16 + NTW - 1) / NTW, nChunks = Cin / CK;
+    const int CK = xck(stride), NTW = x3_ntw(Cout, stride), nN = ((Cout + 15) / 16 + NTW - 1) / NTW, nChunks = Cin / CK;
     const int total = nN * nChunks * xks(CK) * NTW * 64;
     hipLaunchKernelGGL(convx_pack_kernel, dim3(otp_ceil_div(total, 256) > 2048 ? 2048 : otp_ceil_div(total, 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), static_cast<const float*>(weight), static_cast<const float*>(scale),

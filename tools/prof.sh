@@ -14,4 +14,5 @@ trace=$(find "$out" -name '*kernel_trace.csv' | tail -1)
 stats=$(find "$out" -name '*kernel_stats.csv' | tail -1)
 python3 tools/profile_summary.py "$trace" "gpurun_out/${tag}_by_grid.txt" "$(basename "$script") $*"
 [ -n "$stats" ] && cp "$stats" "gpurun_out/${tag}_kernel_stats.csv"
+[ -n "${PROF_TIMELINE:-}" ] && python3 tools/profile_summary.py --timeline "$trace" "gpurun_out/${tag}_timeline.txt" "$PROF_TIMELINE"
 rm -rf "$out"

@@ -33,6 +33,41 @@ def main():
             o.write("%9.3f %6.2f%% %6d %8.1f %8d %5d  %s\n" % (t / 1e3, 100 * t / total, n, t / n, g, b, k))
 
 
+def timeline(src, dst, marker, bin_us=1000.0):
+    """One steady-state forward (the interval between two consecutive dispatches of `marker`, a kernel launched once per
+    forward), cut into bins: per bin the kernel families by busy time summed over the streams."""
+    rows = []
+    with open(src) as f:
+        for r in csv.DictReader(f):
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])))
+    rows.sort()
+    marks = [s_ for s_, e, k in rows if marker in k]
+    if len(marks) < 4:
+        return
+    gaps = sorted((marks[i + 1] - marks[i], i) for i in range(len(marks) - 1))
+    _, i = gaps[len(gaps) // 2]                                   # a median-length period
+    t0, t1 = marks[i], marks[i + 1]
+    nb = int((t1 - t0) / 1e3 / bin_us) + 1
+    bins = [collections.defaultdict(float) for _ in range(nb)]
+    for s_, e, k in rows:
+        if e <= t0 or s_ >= t1:
+            continue
+        a, b = max(s_, t0), min(e, t1)
+        fam = re.sub(r"<.*", "", k)
+        j = int((a - t0) / 1e3 / bin_us)
+        while a < b and j < nb:
+            edge = t0 + int((j + 1) * bin_us * 1e3)
+            bins[j][fam] += (min(b, edge) - a) / 1e3
+            a, j = edge, j + 1
+    with open(dst, "w") as o:
+        o.write("# one forward period (%.2f ms) between two dispatches of %s; per %.0f us bin: busy us per kernel family\n"
+                % ((t1 - t0) / 1e6, marker, bin_us))
+        for j, b in enumerate(bins):
+            top = sorted(b.items(), key=lambda kv: -kv[1])[:5]
+            o.write("%5.1f ms  busy %6.0f us  %s\n" % (j * bin_us / 1e3, sum(b.values()),
+                                                       "  ".join("%s %.0f" % (k, v) for k, v in top)))
+
+
 def isolated(src, dst, kernel_substr, grid, last):
     """bench.py's stand-alone roofline launches of one (kernel, grid): the run of `last` consecutive dispatches of that kernel
     with the shortest span (back-to-back launches; inside the captured graph the same kernel overlaps with launches of other
@@ -59,6 +94,9 @@ def isolated(src, dst, kernel_substr, grid, last):
                    sum(d[1:]) / (last - 1) + sum(gaps) / len(gaps)))
 
 
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "--timeline":
+    timeline(sys.argv[2], sys.argv[3], sys.argv[4])
+    sys.exit(0)
 if __name__ == "__main__":
     main()
     if len(sys.argv) >= 6:
