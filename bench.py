@@ -105,9 +105,27 @@ def kernel_rooflines(dev, batch):
     d = ops.conv_desc(iv, ov, 48, 3, 3, 1, 1, 1, act=ops.ACT_RELU)
     conv_flop = 2.0 * 48 * 48 * 9 * 96 * 72 * n
     from otpose_amd.engine import InferenceEngine
-    use_wino = (os.environ.get("OTPOSE_WINOGRAD", "1") != "0" and InferenceEngine.winograd_pays(48, 48)
+    use_x3 = os.environ.get("OTPOSE_CONV_MATH", "x3") != "f32" and ops.x3_supported(d)
+    use_wino = (not use_x3 and os.environ.get("OTPOSE_WINOGRAD", "1") != "0" and InferenceEngine.winograd_pays(48, 48)
                 and ops.wino_supported(d))
-    if use_wino:
+    peak = PEAK_F32_MATRIX
+    extra = {}
+    if use_x3:
+        # the kernel the engine runs for this layer: split-bf16 products on the bf16 matrix cores (csrc/convx.hip).  Every
+        # fp32 product is three bf16 MFMA products and a chunk's 9 taps occupy 10 tap slots, so the pipe executes
+        # 3 * 10/9 of the algorithmic FLOPs - against the dense bf16 peak.  The kernel is bound by the LDS (fragment reads:
+        # 108 B/clk/CU measured, tools/micro/lds_b128.hip), see DESIGN.md section 3.1c.
+        xp = ops.pack_x3_weight(w, sc, 1)
+        t_conv = event_time_ms(lambda: ops.conv2d_x3_launch(iv, xp, sh, ov, d), 20, st)
+        kname = "convx_kernel<16,4,1,3> (bf16x3 split products) 48->48 3x3 @96x72 x%d frames (grid %d x 256 threads)" % (
+            n, ((n * 96 * 72 // 256 + 7) // 8) * 8)
+        executed = conv_flop * 3.0 * 10.0 / 9.0
+        peak = PEAK_BF16_MATRIX
+        lds_bytes = (n * 96 * 72 // 256) * 3 * (280 + 62) * 1024.0            # per (tile, chunk): 280 KB read + 62 KB written
+        extra = {"lds_bytes_per_launch": lds_bytes, "lds_peak_bytes_per_s": 256 * 108 * 2.0e9,
+                 "lds_frac": lds_bytes / (t_conv * 1e-3) / (256 * 108 * 2.0e9),
+                 "arithmetic": "fp32 storage / accumulate, products as bf16 hi*hi + hi*lo + lo*hi (csrc/convx.hip)"}
+    elif use_wino:
         # the kernel the engine runs for this layer: Winograd F(2x2,3x3) (csrc/wino.hip).  `achieved` stays ALGORITHMIC
         # (direct-convolution) FLOPs per second; the kernel itself executes 16/36 of them on the MFMA pipe.
         up = ops.pack_wino_weight(w)
@@ -127,18 +145,21 @@ def kernel_rooflines(dev, batch):
         kname = ("conv_win_kernel<%d,%d,3,true> 48->48 3x3 @96x72 x%d frames (grid %d x %d threads)"
                  % (plan[0], plan[1], n, plan[5], 64 * plan[2] * plan[3]))
         executed = conv_flop
-    traffic = measured_traffic("conv_wino_48_48_3x3_96x72_x80" if use_wino else "conv_48_48_3x3_96x72_x80")
+    traffic = None if use_x3 else measured_traffic("conv_wino_48_48_3x3_96x72_x80" if use_wino else "conv_48_48_3x3_96x72_x80")
     # `achieved` is ALGORITHMIC (direct-convolution) FLOP/s as the bench contract defines it; `frac` is what the matrix
     # pipe actually does (executed MFMA FLOPs / peak), so a Winograd launch can never read above its pipe occupancy.
     # `algorithmic_frac` keeps the achieved / peak quotient, `hbm_frac` the measured HBM traffic against 8 TB/s.
+    conv_bytes = 2.0 * 4 * 48 * 96 * 72 * n                      # algorithmic: input read once, output written once
     conv = {"kernel": kname,
-            "bound": "mfma", "achieved": conv_flop / (t_conv * 1e-3) / 1e12, "peak": PEAK_F32_MATRIX / 1e12,
-            "unit": "TFLOP/s", "frac": executed / (t_conv * 1e-3) / PEAK_F32_MATRIX,
-            "algorithmic_frac": conv_flop / (t_conv * 1e-3) / PEAK_F32_MATRIX,
-            "hbm_frac": None if traffic is None else traffic / (t_conv * 1e-3) / PEAK_HBM,
+            "bound": "mfma", "achieved": conv_flop / (t_conv * 1e-3) / 1e12, "peak": peak / 1e12,
+            "unit": "TFLOP/s", "frac": executed / (t_conv * 1e-3) / peak,
+            "algorithmic_frac": conv_flop / (t_conv * 1e-3) / peak,
+            "hbm_frac": (traffic if traffic is not None else conv_bytes) / (t_conv * 1e-3) / PEAK_HBM,
+            "hbm_frac_basis": "measured" if traffic is not None else "algorithmic bytes",
             "traffic": traffic,
             "ms_per_launch": t_conv, "algorithmic_flop_per_launch": conv_flop,
-            "executed_mfma_flop_per_launch": executed, "mfma_pipe_frac": executed / (t_conv * 1e-3) / PEAK_F32_MATRIX}
+            "executed_mfma_flop_per_launch": executed, "mfma_pipe_frac": executed / (t_conv * 1e-3) / peak}
+    conv.update(extra)
     # one DCN call (one dilation) over the batch
     xd = torch.randn(batch, 17, 96, 72, generator=g).to(dev)
     off = (torch.randn(batch, 306, 96, 72, generator=g) * 3).to(dev)
