@@ -223,6 +223,18 @@ int otp_mlp_fused(const void* x, const void* packed, const void* scale, const vo
 int otp_ln_mlp_fused(const void* y, const void* ln_gamma, const void* ln_beta, float ln_eps, const void* packed,
                      const void* scale, const void* shift, void* out, int B, int C, int HID, int T, void* stream);
 
+/* The same operator with split-bf16 ("bf16x3") products on the bf16 matrix cores (csrc/mlpx.hip): fp32 storage, fp32
+ * accumulation, LayerNorm / bias / GELU in fp32; each product is lo*hi + hi*lo + hi*hi of two bf16 pieces per operand.
+ * Own packed image (otp_mlp_x3_weight_bytes / otp_mlp_x3_pack); same arguments and aliasing rules as otp_mlp_fused /
+ * otp_ln_mlp_fused. */
+int otp_mlp_x3_supported(int C, int HID, int T);
+size_t otp_mlp_x3_weight_bytes(int C, int HID);
+int otp_mlp_x3_pack(const void* w1, const void* b1, const void* w2, void* packed, int C, int HID, void* stream);
+int otp_mlp_x3(const void* x, const void* packed, const void* scale, const void* shift, const void* res, void* out, int B,
+               int C, int HID, int T, void* stream);
+int otp_ln_mlp_x3(const void* y, const void* ln_gamma, const void* ln_beta, float ln_eps, const void* packed,
+                  const void* scale, const void* shift, void* out, int B, int C, int HID, int T, void* stream);
+
 /* The C -> C pointwise projections of MaskedMHCA (query / key / value / proj: model/blocks.py:383-386, applied at :417-419
  * and :450) on (B, C, T) tensors, nprob (1..3) independent problems of one shape per launch:
  *   out[p] = scale[p] * (W[p] . x[p]) + shift[p] (+ res[p]);   res may be NULL, or hold NULL entries.

@@ -450,6 +450,16 @@ class InferenceEngine:
         sm = blk.drop_path_mlp.scale.detach().reshape(-1)
         out = self.new(B, C, To)
         hid = blk.mlp[0].out_channels
+        if self.use_fused_mlp and self.use_x3 and ops.mlp_x3_supported(C, hid, To):
+            # the same single launch with split-bf16 products on the bf16 matrix cores (csrc/mlpx.hip)
+            dev = lambda t: t.detach().to(self.dev, torch.float32)     # noqa: E731
+            packed = ops.pack_mlp_x3_weights(dev(blk.mlp[0].weight), dev(blk.mlp[0].bias), dev(blk.mlp[3].weight))
+            scd = dev(sm).contiguous()
+            shd = (dev(blk.mlp[3].bias) * scd).contiguous()
+            self._keep += [packed, scd, shd]
+            self.call(L.otp_ln_mlp_x3, "otp_ln_mlp_x3", hip.ptr(y), hip.ptr(p(blk.ln2.weight)), hip.ptr(p(blk.ln2.bias)),
+                      blk.ln2.eps, hip.ptr(packed), hip.ptr(scd), hip.ptr(shd), hip.ptr(out), B, C, hid, To)
+            return out
         if self.use_fused_mlp and ops.mlp_fused_supported(C, hid, To):
             # ln2 -> Conv1d -> GELU -> Conv1d + residual as one launch, hidden activation kept on chip (csrc/mlp.hip)
             dev = lambda t: t.detach().to(self.dev, torch.float32)     # noqa: E731

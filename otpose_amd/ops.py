@@ -472,6 +472,52 @@ def mlp_fused(x, packed, scale, shift, res, out=None, hid=None, stream=None):
     return out
 
 
+def mlp_x3_supported(c, hid, t) -> bool:
+    return bool(hip.lib().otp_mlp_x3_supported(int(c), int(hid), int(t)))
+
+
+def pack_mlp_x3_weights(w1, b1, w2):
+    """The same MLP weights as :func:`pack_mlp_weights`, split into bf16 hi / lo MFMA fragments per 32 hidden channels
+    (csrc/mlpx.hip)."""
+    _require_gpu(w1, b1, w2)
+    hid, c = w1.shape[:2]
+    L = hip.lib()
+    nbytes = L.otp_mlp_x3_weight_bytes(c, hid)
+    if not nbytes:
+        raise RuntimeError(f"otp_mlp_x3: unsupported widths C={c}, HID={hid}")
+    packed = torch.empty(nbytes // 4, dtype=torch.int32, device=w1.device)
+    w1c, w2c, b1c = (t.detach().contiguous().float() for t in (w1, w2, b1))
+    hip.check(L.otp_mlp_x3_pack(hip.ptr(w1c), hip.ptr(b1c), hip.ptr(w2c), hip.ptr(packed), c, hid, hip.stream_of(w1c)),
+              "otp_mlp_x3_pack")
+    return packed
+
+
+def mlp_x3(x, packed, scale, shift, res, out=None, hid=None, stream=None):
+    """:func:`mlp_fused` with split-bf16 products on the bf16 matrix cores (fp32 storage / accumulation)."""
+    _require_gpu(x, packed, res)
+    _check_f32(x)
+    b, c, t = x.shape
+    hid = 4 * c if hid is None else hid
+    out = torch.empty_like(x) if out is None else out
+    hip.check(hip.lib().otp_mlp_x3(hip.ptr(x), hip.ptr(packed), hip.ptr(scale), hip.ptr(shift), hip.ptr(res),
+                                   hip.ptr(out), b, c, hid, t, stream if stream is not None else hip.stream_of(x)),
+              "otp_mlp_x3")
+    return out
+
+
+def ln_mlp_x3(y, gamma, beta, eps, packed, scale, shift, out=None, hid=None, stream=None):
+    """:func:`ln_mlp_fused` with split-bf16 products."""
+    _require_gpu(y, packed)
+    _check_f32(y)
+    b, c, t = y.shape
+    hid = 4 * c if hid is None else hid
+    out = torch.empty_like(y) if out is None else out
+    hip.check(hip.lib().otp_ln_mlp_x3(hip.ptr(y), hip.ptr(gamma), hip.ptr(beta), eps, hip.ptr(packed), hip.ptr(scale),
+                                      hip.ptr(shift), hip.ptr(out), b, c, hid, t,
+                                      stream if stream is not None else hip.stream_of(y)), "otp_ln_mlp_x3")
+    return out
+
+
 def wino_supported(desc) -> bool:
     return bool(hip.lib().otp_conv2d_wino_supported(desc))
 

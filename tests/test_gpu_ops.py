@@ -271,6 +271,35 @@ def test_mlp_fused_matches_fp64(T, monkeypatch):
     assert torch.equal(r2, out)
 
 
+@pytest.mark.parametrize("T", [32, 250, 1152, 864])
+def test_mlp_x3_matches_fp64(T, monkeypatch):
+    """csrc/mlpx.hip (split-bf16 products) vs the same fp64 MLP as test_mlp_fused_matches_fp64.  Tolerance 2e-5 of the output
+    range: two bf16 pieces per operand carry 16 mantissa bits + rounding (measured 3e-6; the f32-MFMA kernel 4e-7)."""
+    B, C, HID = 2, 136, 544
+    if T % 432 == 0:
+        monkeypatch.setenv("OTP_MLP_BALANCED", "2")
+    x, res = seeded((B, C, T), 11), seeded((B, C, T), 12)
+    w1, w2 = seeded((HID, C, 1), 13) / C ** 0.5, seeded((C, HID, 1), 14) / HID ** 0.5
+    b1, b2, sc = seeded((HID,), 15) * 0.5, seeded((C,), 16), seeded((C,), 17)
+    hidden = F.gelu(F.conv1d(x.double(), w1.double(), b1.double()))
+    ref = res.double() + sc.double()[None, :, None] * F.conv1d(hidden, w2.double(), b2.double())
+    assert ops.mlp_x3_supported(C, HID, T) and not ops.mlp_x3_supported(C, HID, T + 1)
+    packed = ops.pack_mlp_x3_weights(w1.cuda(), b1.cuda(), w2.cuda())
+    out = ops.mlp_x3(x.cuda(), packed, sc.cuda(), (b2 * sc).cuda(), res.cuda())
+    _close(out, ref.float(), 2e-5)
+    g, be = 1.0 + 0.3 * seeded((C,), 18), 0.2 * seeded((C,), 19)
+    mu = res.double().mean(1, keepdim=True)
+    rc = res.double() - mu
+    ln = rc / torch.sqrt((rc * rc).mean(1, keepdim=True) + 1e-5) * g.double()[None, :, None] + be.double()[None, :, None]
+    ref_ln = res.double() + sc.double()[None, :, None] * F.conv1d(F.gelu(F.conv1d(ln, w1.double(), b1.double())), w2.double(),
+                                                                  b2.double())
+    out_ln = ops.ln_mlp_x3(res.cuda(), g.cuda(), be.cuda(), 1e-5, packed, sc.cuda(), (b2 * sc).cuda())
+    _close(out_ln, ref_ln.float(), 2e-5)
+    r2 = res.cuda().clone()
+    ops.mlp_x3(x.cuda(), packed, sc.cuda(), (b2 * sc).cuda(), r2, out=r2)
+    assert torch.equal(r2, out)
+
+
 @pytest.mark.parametrize("T", [32, 250, 1152])
 def test_dense_cc_matches_fp64(T):
     """csrc/dense.hip vs the pointwise projections of MaskedMHCA (model/blocks.py:383-386) in fp64: three problems in one
