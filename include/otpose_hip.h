@@ -223,6 +223,17 @@ int otp_mlp_fused(const void* x, const void* packed, const void* scale, const vo
 int otp_ln_mlp_fused(const void* y, const void* ln_gamma, const void* ln_beta, float ln_eps, const void* packed,
                      const void* scale, const void* shift, void* out, int B, int C, int HID, int T, void* stream);
 
+/* otp_dense_cc / otp_qkv_front (csrc/dense.hip) with split-bf16 ("bf16x3") products on the bf16 matrix cores
+ * (csrc/densex.hip): same arguments; the packed images come from otp_dense_x3_pack (otp_dense_x3_weight_bytes bytes each),
+ * the parameter table of otp_qkv_front_x3 is the one otp_qkv_front_pack_table writes. */
+int otp_dense_x3_supported(int C, int T);
+size_t otp_dense_x3_weight_bytes(int C);
+int otp_dense_x3_pack(const void* w, const void* scale, const void* shift, void* packed, int C, void* stream);
+int otp_dense_x3(const void* const* x, const void* const* packed, const void* const* res, void* const* out, int nprob, int B,
+                 int C, int T, void* stream);
+int otp_qkv_front_x3(const void* x, const void* table, const void* packed_q, const void* packed_k, const void* packed_v,
+                     void* q, void* k, void* v, int B, int C, int T, float eps, void* stream);
+
 /* The same operator with split-bf16 ("bf16x3") products on the bf16 matrix cores (csrc/mlpx.hip): fp32 storage, fp32
  * accumulation, LayerNorm / bias / GELU in fp32; each product is lo*hi + hi*lo + hi*hi of two bf16 pieces per operand.
  * Own packed image (otp_mlp_x3_weight_bytes / otp_mlp_x3_pack); same arguments and aliasing rules as otp_mlp_fused /

@@ -226,10 +226,11 @@ class InferenceEngine:
                          res_up=res_up, **kw)
 
     def dense(self, xs, packs, ress, outs, B, C, T):
-        """Emit one otp_dense_cc launch over len(xs) problems."""
+        """Emit one otp_dense_cc (or, with split-bf16 products, otp_dense_x3) launch over len(xs) problems."""
         ax, ap, ar, ao = ops.dense_cc_args(xs, packs, ress, outs)
         self._keep += [ax, ap, ar, ao, *packs]
-        self.call(self.lib.otp_dense_cc, "otp_dense_cc", ax, ap, ar, ao, len(xs), B, C, T)
+        x3 = self.use_x3 and ops.dense_x3_supported(C, T)
+        self.call(self.lib.otp_dense_x3 if x3 else self.lib.otp_dense_cc, "otp_dense_cc", ax, ap, ar, ao, len(xs), B, C, T)
 
     def call(self, fn, name, *args):
         def run():
@@ -407,15 +408,18 @@ class InferenceEngine:
                   hip.ptr(ln1), hip.ptr(skip), B, C, T, blk.ln1.eps)
         q, k, v = self.new(B, C, To), self.new(B, C, To), self.new(B, C, To)
         dense = self.use_dense_cc and ops.dense_cc_supported(C, To)
+        dx3 = dense and self.use_x3 and ops.dense_x3_supported(C, To)
         if dense:
-            packs = [ops.pack_dense_cc(m.weight.to(self.dev), None, m.bias.to(self.dev)) for m in (a.query, a.key, a.value)]
+            packs = [ops.pack_dense_cc(m.weight.to(self.dev), None, m.bias.to(self.dev), x3=dx3)
+                     for m in (a.query, a.key, a.value)]
         if dense and stride == 1 and self.use_qkv_front:
             # depthwise convs + LayerNorms + the three projections in one launch (csrc/dense.hip, qkv_front_kernel)
             table = ops.pack_qkv_table(*[p(t) for t in (a.query_conv.weight, a.key_conv.weight, a.value_conv.weight,
                                                          a.query_norm.weight, a.query_norm.bias, a.key_norm.weight,
                                                          a.key_norm.bias, a.value_norm.weight, a.value_norm.bias)])
             self._keep += [table, *packs]
-            self.call(L.otp_qkv_front, "otp_qkv_front", hip.ptr(ln1), hip.ptr(table), *[hip.ptr(t) for t in packs],
+            self.call(L.otp_qkv_front_x3 if dx3 else L.otp_qkv_front, "otp_qkv_front", hip.ptr(ln1), hip.ptr(table),
+                      *[hip.ptr(t) for t in packs],
                       hip.ptr(q), hip.ptr(k), hip.ptr(v), B, C, T, a.query_norm.eps)
         else:
             qn, kn, vn = self.new(B, C, To), self.new(B, C, To), self.new(B, C, To)
@@ -442,7 +446,8 @@ class InferenceEngine:
         y = self.new(B, C, To)
         if dense:
             sad = sa.to(self.dev, torch.float32)
-            pk = ops.pack_dense_cc(a.proj.weight.to(self.dev), sad, a.proj.bias.detach().to(self.dev) * sad)
+            pk = ops.pack_dense_cc(a.proj.weight.to(self.dev), sad, a.proj.bias.detach().to(self.dev) * sad,
+                                   x3=self.use_x3 and ops.dense_x3_supported(C, To))
             self.dense((att,), [pk], (skip if stride > 1 else x,), (y,), B, C, To)
         else:
             self.conv(self.v3(att), a.proj.weight, self.v3(y), scale=sa,

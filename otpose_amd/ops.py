@@ -380,20 +380,25 @@ def dense_cc_supported(c, t) -> bool:
     return bool(hip.lib().otp_dense_cc_supported(int(c), int(t)))
 
 
-def pack_dense_cc(weight, scale=None, shift=None):
+def dense_x3_supported(c, t) -> bool:
+    return bool(hip.lib().otp_dense_x3_supported(int(c), int(t)))
+
+
+def pack_dense_cc(weight, scale=None, shift=None, x3=False):
     """(C, C[, 1]) pointwise weight (+ per-output-channel scale / shift) -> the per-16-row fragment image of
-    :func:`dense_cc` (MaskedMHCA query / key / value / proj, model/blocks.py:383-386)."""
+    :func:`dense_cc` (MaskedMHCA query / key / value / proj, model/blocks.py:383-386).  ``x3``: the split-bf16 image of
+    csrc/densex.hip (pass the same flag to :func:`dense_cc` / :func:`qkv_front`)."""
     _require_gpu(weight)
     c = weight.shape[0]
     L = hip.lib()
-    nbytes = L.otp_dense_cc_weight_bytes(c)
+    nbytes = (L.otp_dense_x3_weight_bytes if x3 else L.otp_dense_cc_weight_bytes)(c)
     if not nbytes or weight.shape[1] != c:
         raise RuntimeError(f"otp_dense_cc: unsupported weight shape {tuple(weight.shape)}")
     f = lambda t: None if t is None else t.detach().to(weight.device, torch.float32).contiguous()   # noqa: E731
     w, sc, sh = f(weight), f(scale), f(shift)
     packed = torch.empty(nbytes // 4, dtype=torch.float32, device=weight.device)
-    hip.check(L.otp_dense_cc_pack(hip.ptr(w), hip.ptr(sc), hip.ptr(sh), hip.ptr(packed), c, hip.stream_of(w)),
-              "otp_dense_cc_pack")
+    hip.check((L.otp_dense_x3_pack if x3 else L.otp_dense_cc_pack)(hip.ptr(w), hip.ptr(sc), hip.ptr(sh), hip.ptr(packed), c,
+                                                                    hip.stream_of(w)), "otp_dense_cc_pack")
     return packed
 
 
@@ -404,14 +409,14 @@ def dense_cc_args(xs, packs, ress, outs):
     return arr(xs), arr(packs), arr(ress if ress is not None else [None] * n), arr(outs)
 
 
-def dense_cc(xs, packs, ress=None, outs=None, stream=None):
+def dense_cc(xs, packs, ress=None, outs=None, stream=None, x3=False):
     """out[p] = scale[p] * (W[p] . x[p]) + shift[p] (+ res[p]) for up to three (B, C, T) problems in one launch."""
     _require_gpu(*xs)
     b, c, t = xs[0].shape
     outs = [torch.empty_like(x) for x in xs] if outs is None else outs
     ax, ap, ar, ao = dense_cc_args(xs, packs, ress, outs)
-    hip.check(hip.lib().otp_dense_cc(ax, ap, ar, ao, len(xs), b, c, t, stream if stream is not None else hip.stream_of(xs[0])),
-              "otp_dense_cc")
+    fn = hip.lib().otp_dense_x3 if x3 else hip.lib().otp_dense_cc
+    hip.check(fn(ax, ap, ar, ao, len(xs), b, c, t, stream if stream is not None else hip.stream_of(xs[0])), "otp_dense_cc")
     return outs
 
 
@@ -428,13 +433,14 @@ def pack_qkv_table(dwq, dwk, dwv, gq, bq, gk, bk, gv, bv):
     return table
 
 
-def qkv_front(x, table, packs, eps=1e-5, outs=None, stream=None):
+def qkv_front(x, table, packs, eps=1e-5, outs=None, stream=None, x3=False):
     """q, k, v = W_p . LN_p(dwconv3_p(x)) + b_p (stride 1) in one launch; ``packs`` = three :func:`pack_dense_cc` images."""
     _require_gpu(x, table)
     b, c, t = x.shape
     outs = [torch.empty_like(x) for _ in range(3)] if outs is None else outs
-    hip.check(hip.lib().otp_qkv_front(hip.ptr(x), hip.ptr(table), *[hip.ptr(p) for p in packs], *[hip.ptr(o) for o in outs],
-                                      b, c, t, eps, stream if stream is not None else hip.stream_of(x)), "otp_qkv_front")
+    fn = hip.lib().otp_qkv_front_x3 if x3 else hip.lib().otp_qkv_front
+    hip.check(fn(hip.ptr(x), hip.ptr(table), *[hip.ptr(p) for p in packs], *[hip.ptr(o) for o in outs],
+                 b, c, t, eps, stream if stream is not None else hip.stream_of(x)), "otp_qkv_front")
     return outs
 
 

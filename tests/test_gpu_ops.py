@@ -321,6 +321,38 @@ def test_dense_cc_matches_fp64(T):
 
 
 @pytest.mark.parametrize("T", [32, 250, 1152])
+def test_dense_and_qkv_front_x3_match_fp64(T):
+    """csrc/densex.hip (split-bf16 products) vs the same fp64 references as test_dense_cc_matches_fp64 /
+    test_qkv_front_matches_fp64; 2e-5 of the output range (measured 3e-6)."""
+    B, C, eps = 2, 136, 1e-5
+    xs = [seeded((B, C, T), 21 + i) for i in range(3)]
+    ws = [seeded((C, C, 1), 31 + i) / C ** 0.5 for i in range(3)]
+    bs = [seeded((C,), 41 + i) for i in range(3)]
+    assert ops.dense_x3_supported(C, T) and not ops.dense_x3_supported(C, T + 1) and not ops.dense_x3_supported(17, T)
+    packs = [ops.pack_dense_cc(w.cuda(), None, b.cuda(), x3=True) for w, b in zip(ws, bs)]
+    outs = ops.dense_cc([x.cuda() for x in xs], packs, x3=True)
+    for x, w, b, o in zip(xs, ws, bs, outs):
+        _close(o, F.conv1d(x.double(), w.double(), b.double()).float(), 2e-5)
+    sc, res = seeded((C,), 51), seeded((B, C, T), 52)
+    pk = ops.pack_dense_cc(ws[0].cuda(), sc.cuda(), (bs[0] * sc).cuda(), x3=True)
+    (o,) = ops.dense_cc([xs[1].cuda()], [pk], [res.cuda()], x3=True)
+    ref = res.double() + sc.double()[None, :, None] * F.conv1d(xs[1].double(), ws[0].double(), bs[0].double())
+    _close(o, ref.float(), 2e-5)
+    x = seeded((B, C, T), 61)
+    dws = [seeded((C, 1, 3), 62 + i) * 0.6 for i in range(3)]
+    gs = [1.0 + 0.3 * seeded((C,), 65 + i) for i in range(3)]
+    be = [0.2 * seeded((C,), 68 + i) for i in range(3)]
+    table = ops.pack_qkv_table(dws[0].cuda(), dws[1].cuda(), dws[2].cuda(), gs[0].cuda(), be[0].cuda(), gs[1].cuda(),
+                               be[1].cuda(), gs[2].cuda(), be[2].cuda())
+    outs = ops.qkv_front(x.cuda(), table, packs, eps, x3=True)
+    for i in range(3):
+        d = F.conv1d(x.double(), dws[i].double(), None, 1, 1, 1, C)
+        r = d - d.mean(1, keepdim=True)
+        ln = r / torch.sqrt((r * r).mean(1, keepdim=True) + eps) * gs[i].double()[None, :, None] + be[i].double()[None, :, None]
+        _close(outs[i], F.conv1d(ln, ws[i].double(), bs[i].double()).float(), 2e-5)
+
+
+@pytest.mark.parametrize("T", [32, 250, 1152])
 def test_qkv_front_matches_fp64(T):
     """csrc/dense.hip qkv_front vs MaskedMHCA's depthwise conv -> channel LayerNorm -> pointwise projection chain
     (model/blocks.py:406-419, LayerNorm of :95-110) in fp64, and vs the two-launch path it replaces."""
