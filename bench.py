@@ -185,18 +185,28 @@ def kernel_rooflines(dev, batch):
     b1, one, zero = torch.zeros(HID, device=dev), torch.ones(C, device=dev), torch.zeros(C, device=dev)
     om = torch.empty_like(xm)
     mlp_r = None
-    if ops.mlp_fused_supported(C, HID, T):
-        packed = ops.pack_mlp_weights(w1, b1, w2)
-        t_mlp = event_time_ms(lambda: ops.ln_mlp_fused(xm, one, zero, 1e-5, packed, one, zero, out=om), 20, st)
+    x3 = os.environ.get("OTPOSE_CONV_MATH", "x3") != "f32" and ops.mlp_x3_supported(C, HID, T)
+    if x3 or ops.mlp_fused_supported(C, HID, T):
         mlp_flop = 4.0 * C * HID * batch * T
         balanced = T % 432 == 0 and batch * (T // 432) >= 192 and os.environ.get("OTP_MLP_BALANCED", "1") != "0"
-        mlp_r = {"kernel": ("%s ln2 + 136->544->gelu->136 + residual, T=6912 x%d clips"
-                            % ("mlp_fused_balanced_kernel<136,544,true>" if balanced else "mlp_fused_kernel<136,544,4,true>",
-                               batch)),
-                 "bound": "mfma", "achieved": mlp_flop / (t_mlp * 1e-3) / 1e12, "peak": PEAK_F32_MATRIX / 1e12,
-                 "unit": "TFLOP/s", "frac": mlp_flop / (t_mlp * 1e-3) / PEAK_F32_MATRIX,
-                 "traffic": measured_traffic("ln_mlp_fused_136_544_T6912_x16"),
-                 "ms_per_launch": t_mlp, "algorithmic_flop_per_launch": mlp_flop}
+        if x3:
+            # split-bf16 kernel (csrc/mlpx.hip): 3 bf16 MFMA products per fp32 product, K padded 136 -> 160 in the first GEMM
+            packed = ops.pack_mlp_x3_weights(w1, b1, w2)
+            t_mlp = event_time_ms(lambda: ops.ln_mlp_x3(xm, one, zero, 1e-5, packed, one, zero, out=om), 20, st)
+            executed = 3.0 * 2.0 * (160 * HID + HID * 144) * batch * T
+            peak, kn = PEAK_BF16_MATRIX, ("mlpx_balanced_kernel<136,544,true>" if balanced else "mlpx_kernel<136,544,8,true>")
+        else:
+            packed = ops.pack_mlp_weights(w1, b1, w2)
+            t_mlp = event_time_ms(lambda: ops.ln_mlp_fused(xm, one, zero, 1e-5, packed, one, zero, out=om), 20, st)
+            executed = mlp_flop
+            peak = PEAK_F32_MATRIX
+            kn = "mlp_fused_balanced_kernel<136,544,true>" if balanced else "mlp_fused_kernel<136,544,4,true>"
+        mlp_r = {"kernel": "%s ln2 + 136->544->gelu->136 + residual, T=6912 x%d clips" % (kn, batch),
+                 "bound": "mfma", "achieved": mlp_flop / (t_mlp * 1e-3) / 1e12, "peak": peak / 1e12,
+                 "unit": "TFLOP/s", "frac": executed / (t_mlp * 1e-3) / peak,
+                 "algorithmic_frac": mlp_flop / (t_mlp * 1e-3) / peak,
+                 "traffic": None if x3 else measured_traffic("ln_mlp_fused_136_544_T6912_x16"),
+                 "ms_per_launch": t_mlp, "algorithmic_flop_per_launch": mlp_flop, "executed_mfma_flop_per_launch": executed}
     # channel attention of one temporal-encoder block (blocks.py:427-447): S = (q*scale) k^T (68 x 68 per head, contraction
     # over T), softmax, O = P v in the transposed-contiguous image - the QK^T / PV kernels the north star asks the MFMA
     # utilisation of.  4*hs^2*T FLOP per (clip, head); the op is HBM-bound (q, k, v read, out written: 16 B per element).

@@ -119,16 +119,17 @@ int otp_conv2d_wino_last_plan(int* out4);
 int otp_conv2d_wino(const void* in, const void* upacked, const void* scale, const void* shift, const void* res, void* out,
                     const otp_conv_desc* desc, void* stream);
 
-/* fp32 3x3 convolutions (stride 1 or 2) on the bf16 matrix cores with split ("bf16x3") products: every fp32 operand is the sum
+/* fp32 3x3 (stride 1 or 2) and 1x1 (stride 1) convolutions on the bf16 matrix cores with split ("bf16x3") products: every fp32 operand is the sum
  * of two bf16 pieces (hi = rne(a), lo = rne(a - hi)), a product is lo*hi + hi*lo + hi*hi accumulated in fp32 (dropped terms
  * <= 3 * 2^-18 |a b|), storage stays fp32 NCHW.  Same descriptor and fused epilogue (shift, residual, activation,
  * channel-sliced views) as otp_conv2d_wino; the per-channel scale is folded into the packed weights.  Replaces the cuDNN
  * convs behind model/HRNet.py:500-571 (BasicBlock / Bottleneck conv2) and the 3x3 transition / dilated convs.
- * otp_conv2d_x3_supported: 3x3, stride 1 or 2, any pad / dilation, Cin % 16 == 0, H*W % 4 == 0, Ho*Wo % 4 == 0, no second
- * input / res_up / GELU. */
-/* the packed layout depends on the stride (16-channel chunks for stride 1, 8-channel chunks for stride 2) */
-size_t otp_conv2d_x3_weight_bytes(int Cout, int Cin, int stride);
-int otp_conv2d_x3_pack_weight(const void* weight, const void* scale, void* wpacked, int Cout, int Cin, int stride,
+ * otp_conv2d_x3_supported: 3x3 with stride 1 (Cin % 16 == 0) or 2 (Cin % 8 == 0), any pad / dilation whose window fits the
+ * LDS, or 1x1 with stride 1 and no padding (Cin % 32 == 0); H*W % 4 == 0, Ho*Wo % 4 == 0, no second input / res_up / GELU. */
+/* the packed layout depends on the kernel size k (1 or 3) and the stride (channels per chunk: 16 / 8 for 3x3 stride 1 / 2,
+ * 32 for 1x1) */
+size_t otp_conv2d_x3_weight_bytes(int Cout, int Cin, int k, int stride);
+int otp_conv2d_x3_pack_weight(const void* weight, const void* scale, void* wpacked, int Cout, int Cin, int k, int stride,
                               void* stream);
 int otp_conv2d_x3_supported(const otp_conv_desc* desc);
 int otp_conv2d_x3(const void* in, const void* wpacked, const void* shift, const void* res, void* out,

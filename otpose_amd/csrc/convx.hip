@@ -30,10 +30,11 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // Two shapes.  Stride 1: chunks of CK = 16 channels (k-step = 2 taps x 16 channels, 5 steps, the tenth tap has zero
 // weights), 256 pixels (4 m-tiles per wave).  Stride 2 reads 4x the input per output pixel: chunks of 8 channels (k-step =
 // 4 taps x 8 channels, 3 steps) and 128 pixels (2 m-tiles per wave) keep the window inside half the LDS.
-constexpr int xck(int stride) { return stride == 2 ? 8 : 16; }            // input channels per chunk
+// Pointwise (1x1, stride 1) convolutions: chunks of 32 channels = one k-step, 256 pixels, no halo.
+constexpr int xck(int stride, int taps = 9) { return taps == 1 ? 32 : (stride == 2 ? 8 : 16); }   // input channels per chunk
 constexpr int xmtw(int stride) { return stride == 2 ? 2 : 4; }            // m-tiles (16 pixels) per wave
 constexpr int xpix(int ck) { return ck * 4 + 16; }                        // bytes of a window pixel record: hi | lo | 16 B pad
-constexpr int xks(int ck) { return (9 * (ck / 8) + 3) / 4; }              // k-steps per chunk of a 3x3 kernel
+constexpr int xks(int ck, int taps = 9) { return (taps * (ck / 8) + 3) / 4; }   // k-steps per chunk
 constexpr int XOOB = -16;      // buffer offset past any descriptor: the load returns zeros
 
 #ifdef OTP_CONVX_TIMING
@@ -53,7 +54,7 @@ uint32_t xmagic(uint32_t d) { return d <= 1 ? 0u : (uint32_t)((1ull << 32) / d) 
 struct XPlan {
     int N, Cin, H, W, HW, Cout, Ho, Wo, HoWo, total;
     int in_ctot, in_coff, out_ctot, out_coff, res_ctot, res_coff, act;
-    int stride, pad, dil;
+    int stride, pad, dil, taps;
     int NTW, nN, nTiles, nChunks, tpx;
     int VR, WPp, CS, rowsMax, S, NI;
     int winBytes, wBytes;
@@ -81,8 +82,8 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo
 // v_mfma_f32_16x16x32_bf16 (lane = (cout & 15) + 16 * kl; G = CK / 8 channel groups: kl -> tap (4 / G) s + kl / G, channels
 // 8 (kl % G) .. + 7 of the chunk)
 __global__ void convx_pack_kernel(const float* __restrict__ w, const float* __restrict__ scale, u32x4* __restrict__ out, int Cout,
-                                  int Cin, int NTW, int nN, int nChunks, int CK) {
-    const int G = CK / 8, XKS = xks(CK);
+                                  int Cin, int NTW, int nN, int nChunks, int CK, int TAPS) {
+    const int G = CK / 8, XKS = xks(CK, TAPS);
     const int total = nN * nChunks * XKS * NTW * 64;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
         const int lane = idx & 63;
@@ -91,12 +92,12 @@ __global__ void convx_pack_kernel(const float* __restrict__ w, const float* __re
         const int s = r % XKS; r /= XKS;
         const int chunk = r % nChunks, cb = r / nChunks;
         const int cout = (cb * NTW + t) * 16 + (lane & 15), kl = lane >> 4;
-        const int tap = (4 / G) * s + kl / G, ci0 = chunk * CK + 8 * (kl % G);
+        const int q = 4 * s + kl, tap = q / G, ci0 = chunk * CK + 8 * (q % G);      // k-slot q of the chunk -> (tap, channel group)
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int ci = ci0 + j;
-            v[j] = (tap < 9 && cout < Cout && ci < Cin) ? w[((size_t)cout * Cin + ci) * 9 + tap] * (scale ? scale[cout] : 1.f) : 0.f;
+            v[j] = (tap < TAPS && cout < Cout && ci < Cin) ? w[((size_t)cout * Cin + ci) * TAPS + tap] * (scale ? scale[cout] : 1.f) : 0.f;
         }
         u32x4 hi, lo;
         split8(v, hi, lo);
@@ -106,11 +107,11 @@ __global__ void convx_pack_kernel(const float* __restrict__ w, const float* __re
     }
 }
 
-template <int CK, int MTW, int NI, int NTW>
+template <int CK, int MTW, int NI, int NTW, int TAPS>
 __global__ __launch_bounds__(256, 2) void convx_kernel(const float* __restrict__ in, const u32x4* __restrict__ wpk,
                                                         const float* __restrict__ shift, const float* res, float* out,
                                                         const XPlan P) {
-    constexpr int G = CK / 8, XKS = xks(CK), XPIX = xpix(CK), XBM = 64 * MTW, LO = CK * 2;
+    constexpr int G = CK / 8, XKS = xks(CK, TAPS), XPIX = xpix(CK), XBM = 64 * MTW, LO = CK * 2;
     constexpr int WUNITS = XKS * NTW * 2 * 64;                     // 16-byte units of a chunk's weights
     constexpr int NWL = (WUNITS + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -148,9 +149,11 @@ __global__ __launch_bounds__(256, 2) void convx_kernel(const float* __restrict__
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int i = tid + 256 * j;
-        const int g = (G == 2 && i >= T) ? 1 : 0;
+        int g = 0;
+#pragma unroll
+        for (int gg = 1; gg < G; ++gg) g += i >= gg * T ? 1 : 0;
         int rem = i - g * T, f = -1, n = 0;
-        if (rem >= T) rem = -1;
+        if (i >= G * T) rem = -1;
         for (int sl = 0; sl < P.S; ++sl) {
             const int ns = n0 + sl, ya = max(0, Vfirst - ns * P.VR - P.pad), yb = min(P.H, Vfirst + P.rowsMax - ns * P.VR - P.pad);
             const int c = (ns < P.N && yb > ya) ? ((yb * P.W + 3) >> 2) - ((ya * P.W) >> 2) : 0;
@@ -233,11 +236,12 @@ __global__ __launch_bounds__(256, 2) void convx_kernel(const float* __restrict__
     int toff[XKS];
 #pragma unroll
     for (int s = 0; s < XKS; ++s) {
-        int tap = (4 / G) * s + kl / G;
-        if (tap > 8) tap = 8;                                      // zero weights: any finite data
+        const int q = 4 * s + kl;
+        int tap = q / G;
+        if (tap > TAPS - 1) tap = TAPS - 1;                        // zero weights: any finite data
         const int dy = tap / 3, dx = tap - dy * 3;
         const int xs = dx * P.dil;
-        toff[s] = ((dy * P.dil) * P.WPp + (P.stride == 2 ? (xs & 1) * P.CS + (xs >> 1) : xs)) * XPIX + (kl % G) * 16;
+        toff[s] = ((dy * P.dil) * P.WPp + (P.stride == 2 ? (xs & 1) * P.CS + (xs >> 1) : xs)) * XPIX + (q % G) * 16;
     }
 
     f32x4 acc[MTW][NTW];
@@ -362,14 +366,17 @@ __global__ __launch_bounds__(256, 2) void convx_kernel(const float* __restrict__
 #endif
 }
 
-int x3_ntw(int Cout, int stride);
+int x3_ntw(int Cout, int stride, int taps);
 
 bool convx_plan(const otp_conv_desc& d, XPlan& P) {
-    if (d.kh != 3 || d.kw != 3 || d.res_up > 1 || d.frame_split > 0 || d.in2_ctot > 0) return false;
+    const bool pointwise = d.kh == 1 && d.kw == 1;
+    if (!(pointwise || (d.kh == 3 && d.kw == 3)) || d.res_up > 1 || d.frame_split > 0 || d.in2_ctot > 0) return false;
     if ((d.stride != 1 && d.stride != 2) || d.act == OTP_ACT_GELU) return false;
-    const int CK = xck(d.stride), XBM = 64 * xmtw(d.stride), XKS = xks(CK), XPIX = xpix(CK);
+    if (pointwise && (d.stride != 1 || d.pad != 0)) return false;
+    const int TAPS = pointwise ? 1 : 9, KE = pointwise ? 0 : 2 * d.dil;       // kernel extent - 1
+    const int CK = xck(d.stride, TAPS), XBM = 64 * xmtw(d.stride), XKS = xks(CK, TAPS), XPIX = xpix(CK);
     if (d.Cin % CK || ((d.H * d.W) & 3)) return false;
-    const int Ho = (d.H + 2 * d.pad - d.dil * 2 - 1) / d.stride + 1, Wo = (d.W + 2 * d.pad - d.dil * 2 - 1) / d.stride + 1;
+    const int Ho = (d.H + 2 * d.pad - KE - 1) / d.stride + 1, Wo = (d.W + 2 * d.pad - KE - 1) / d.stride + 1;
     if (Ho != d.Ho || Wo != d.Wo || Ho <= 0 || Wo <= 0) return false;
     if ((Ho * Wo) & 3) return false;                               // a lane's 4 pixels stay inside one image, 16-byte aligned
     P.N = d.N; P.Cin = d.Cin; P.H = d.H; P.W = d.W; P.HW = d.H * d.W; P.Cout = d.Cout;
@@ -378,7 +385,7 @@ bool convx_plan(const otp_conv_desc& d, XPlan& P) {
     P.res_ctot = d.res_ctot; P.res_coff = d.res_coff; P.act = d.act;
     P.stride = d.stride; P.pad = d.pad; P.dil = d.dil;
     const int c16 = (d.Cout + 15) / 16;
-    P.NTW = x3_ntw(d.Cout, d.stride);
+    P.NTW = x3_ntw(d.Cout, d.stride, TAPS);
     P.nN = (c16 + P.NTW - 1) / P.NTW;
     P.nTiles = (P.total + XBM - 1) / XBM;
     P.nChunks = d.Cin / CK;
@@ -391,7 +398,7 @@ bool convx_plan(const otp_conv_desc& d, XPlan& P) {
     for (int t = 0; t < P.nTiles; ++t) {
         const int a = t * XBM, b = (a + XBM < P.total ? a + XBM : P.total) - 1;
         const int na = a / P.HoWo, ya = (a % P.HoWo) / Wo, nb = b / P.HoWo, yb = (b % P.HoWo) / Wo;
-        const int r = (nb * P.VR + yb * d.stride + 2 * d.dil) - (na * P.VR + ya * d.stride) + 1;
+        const int r = (nb * P.VR + yb * d.stride + KE) - (na * P.VR + ya * d.stride) + 1;
         if (r > rows) rows = r;
     }
     P.rowsMax = rows;
@@ -410,7 +417,7 @@ bool convx_plan(const otp_conv_desc& d, XPlan& P) {
     }
     P.S = S;
     P.NI = ((CK / 8) * Tmax + 255) / 256;
-    P.winBytes = (rows * P.WPp + 2 * d.dil + 4) * XPIX;             // + slack: the clamped tenth tap / tail pixels stay inside
+    P.winBytes = (rows * P.WPp + KE + 4) * XPIX;                   // + slack: the clamped tenth tap / tail pixels stay inside
     P.winBytes = (P.winBytes + 15) & ~15;
     P.wBytes = XKS * P.NTW * 2 * 1024;
     P.mHoWo = xmagic(P.HoWo); P.mWo = xmagic(Wo); P.mW = xmagic(d.W);
@@ -419,13 +426,14 @@ bool convx_plan(const otp_conv_desc& d, XPlan& P) {
     if ((long)(S + 1) * d.in_ctot * P.HW * 4 >= (1l << 31)) return false;
     if ((long)P.N * d.out_ctot * P.HoWo >= (1l << 31) || (long)P.N * (d.res_ctot > 0 ? d.res_ctot : 1) * P.HoWo >= (1l << 31)) return false;
     if ((size_t)P.nN * P.nChunks * XKS * P.NTW * 2 * 1024 >= (1ull << 31)) return false;
+    P.taps = TAPS;
     if (P.NI > 2 || S > 64) return false;
     return P.winBytes + P.wBytes <= OTP_LDS_LIMIT;
 }
 
-template <int CK, int MTW, int NI, int NTW>
+template <int CK, int MTW, int NI, int NTW, int TAPS>
 int convx_launch(const float* in, const u32x4* wpk, const float* shift, const float* res, float* out, const XPlan& P, hipStream_t st) {
-    auto kern = convx_kernel<CK, MTW, NI, NTW>;
+    auto kern = convx_kernel<CK, MTW, NI, NTW, TAPS>;
     const size_t lds = (size_t)P.winBytes + P.wBytes;
     OTP_ALLOW_BIG_LDS(kern, lds);
     const dim3 grid(8 * P.tpx * P.nN);
@@ -435,16 +443,19 @@ int convx_launch(const float* in, const u32x4* wpk, const float* shift, const fl
 
 template <int NTW>
 int convx_dispatch(const float* in, const u32x4* wpk, const float* shift, const float* res, float* out, const XPlan& P, hipStream_t st) {
+    if (P.taps == 1)
+        return P.NI <= 1 ? convx_launch<xck(1, 1), xmtw(1), 1, NTW, 1>(in, wpk, shift, res, out, P, st)
+                         : convx_launch<xck(1, 1), xmtw(1), 2, NTW, 1>(in, wpk, shift, res, out, P, st);
     if (P.stride == 2)
-        return P.NI <= 1 ? convx_launch<xck(2), xmtw(2), 1, NTW>(in, wpk, shift, res, out, P, st)
-                         : convx_launch<xck(2), xmtw(2), 2, NTW>(in, wpk, shift, res, out, P, st);
-    return P.NI <= 1 ? convx_launch<xck(1), xmtw(1), 1, NTW>(in, wpk, shift, res, out, P, st)
-                     : convx_launch<xck(1), xmtw(1), 2, NTW>(in, wpk, shift, res, out, P, st);
+        return P.NI <= 1 ? convx_launch<xck(2), xmtw(2), 1, NTW, 9>(in, wpk, shift, res, out, P, st)
+                         : convx_launch<xck(2), xmtw(2), 2, NTW, 9>(in, wpk, shift, res, out, P, st);
+    return P.NI <= 1 ? convx_launch<xck(1), xmtw(1), 1, NTW, 9>(in, wpk, shift, res, out, P, st)
+                     : convx_launch<xck(1), xmtw(1), 2, NTW, 9>(in, wpk, shift, res, out, P, st);
 }
 
-int x3_ntw(int Cout, int stride) {
+int x3_ntw(int Cout, int stride, int taps) {
     const int c16 = (Cout + 15) / 16;
-    if (stride == 2) return (c16 % 3 == 0) ? 3 : (c16 % 4 == 0 ? 4 : (c16 <= 2 ? 2 : (c16 % 2 == 0 ? 2 : 3)));
+    if (stride == 2 || taps == 1) return (c16 % 3 == 0) ? 3 : (c16 % 4 == 0 ? 4 : (c16 <= 2 ? 2 : (c16 % 2 == 0 ? 2 : 3)));
     // stride 1: 3 n-tiles per workgroup when they divide Cout, else 2: with 4 the accumulators + staging registers spill and
     // the LDS image (window + 40 KB of weights) leaves one workgroup per CU (64 -> 64 @96x72: 220 us with 4, 194 with 2)
     return (c16 % 3 == 0) ? 3 : (c16 % 2 == 0 || c16 <= 2 ? 2 : 3);
@@ -464,21 +475,24 @@ extern "C" int otp_conv2d_x3_supported(const otp_conv_desc* desc) {
     return convx_plan(*desc, P) ? 1 : 0;
 }
 
-extern "C" size_t otp_conv2d_x3_weight_bytes(int Cout, int Cin, int stride) {
-    if (Cout <= 0 || Cin <= 0 || (stride != 1 && stride != 2) || Cin % xck(stride)) return 0;
-    const int CK = xck(stride), NTW = x3_ntw(Cout, stride), nN = ((Cout + 15) / 16 + NTW - 1) / NTW;
-    return (size_t)nN * (Cin / CK) * xks(CK) * NTW * 2 * 1024;
+extern "C" size_t otp_conv2d_x3_weight_bytes(int Cout, int Cin, int k, int stride) {
+    if (Cout <= 0 || Cin <= 0 || (k != 1 && k != 3) || (stride != 1 && stride != 2) || (k == 1 && stride != 1)) return 0;
+    const int TAPS = k * k, CK = xck(stride, TAPS);
+    if (Cin % CK) return 0;
+    const int NTW = x3_ntw(Cout, stride, TAPS), nN = ((Cout + 15) / 16 + NTW - 1) / NTW;
+    return (size_t)nN * (Cin / CK) * xks(CK, TAPS) * NTW * 2 * 1024;
 }
 
-extern "C" int otp_conv2d_x3_pack_weight(const void* weight, const void* scale, void* wpacked, int Cout, int Cin, int stride,
-                                         void* stream) {
+extern "C" int otp_conv2d_x3_pack_weight(const void* weight, const void* scale, void* wpacked, int Cout, int Cin, int k,
+                                         int stride, void* stream) {
     if (!weight || !wpacked || Cout <= 0 || Cin <= 0) return OTP_ERR_BAD_ARG;
-    if ((stride != 1 && stride != 2) || Cin % xck(stride)) return OTP_ERR_UNSUPPORTED;
-    const int CK = xck(stride), NTW = x3_ntw(Cout, stride), nN = ((Cout + 15) / 16 + NTW - 1) / NTW, nChunks = Cin / CK;
-    const int total = nN * nChunks * xks(CK) * NTW * 64;
+    if (!otp_conv2d_x3_weight_bytes(Cout, Cin, k, stride)) return OTP_ERR_UNSUPPORTED;
+    const int TAPS = k * k, CK = xck(stride, TAPS), NTW = x3_ntw(Cout, stride, TAPS);
+    const int nN = ((Cout + 15) / 16 + NTW - 1) / NTW, nChunks = Cin / CK;
+    const int total = nN * nChunks * xks(CK, TAPS) * NTW * 64;
     hipLaunchKernelGGL(convx_pack_kernel, dim3(otp_ceil_div(total, 256) > 2048 ? 2048 : otp_ceil_div(total, 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), static_cast<const float*>(weight), static_cast<const float*>(scale),
-                       static_cast<u32x4*>(wpacked), Cout, Cin, NTW, nN, nChunks, CK);
+                       static_cast<u32x4*>(wpacked), Cout, Cin, NTW, nN, nChunks, CK, TAPS);
     return otp_launch_status();
 }
 

@@ -175,12 +175,12 @@ class InferenceEngine:
         self._keep.append(d)
         L = self.lib
         if os.environ.get("OTPOSE_CONV_LOG"):                       # development aid: one line per emitted convolution
-            route = ("x3" if self.use_x3 and in2 is None and (kh, kw) == (3, 3) and ops.x3_supported(d) else
+            route = ("x3" if self.use_x3 and in2 is None and (kh, kw) in ((3, 3), (1, 1)) and ops.x3_supported(d) else
                      "wino" if self.use_winograd and in2 is None and self.winograd_pays(cin_w, cout) and ops.wino_supported(d)
                      else "direct")
             print(f"conv {d.N}x{d.Cin}->{cout} k{kh} s{stride} p{pad} d{dil} {d.H}x{d.W} in2={in2 is not None} "
                   f"res={res is not None} up={res_up} fs={frame_split} {route}", file=sys.stderr)
-        if self.use_x3 and in2 is None and (kh, kw) == (3, 3) and ops.x3_supported(d):
+        if self.use_x3 and in2 is None and (kh, kw) in ((3, 3), (1, 1)) and ops.x3_supported(d):
             # 3x3 / stride 1 with Cin % 16 == 0: split-bf16 (bf16x3) products on the bf16 matrix cores, fp32 storage and
             # accumulation (csrc/convx.hip); the per-channel scale is folded into the packed weights
             xp = ops.pack_x3_weight(w, sc, stride)

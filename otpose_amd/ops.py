@@ -320,20 +320,22 @@ def pack_wino_weight(weight):
 
 
 def pack_x3_weight(weight, scale=None, stride=1):
-    """(Cout, Cin, 3, 3) fp32 (times scale[cout]) -> bf16 hi / lo MFMA fragments for :func:`conv2d_x3_launch` (the chunking
-    depends on the stride)."""
+    """(Cout, Cin, k, k) fp32, k = 3 or 1 (times scale[cout]) -> bf16 hi / lo MFMA fragments for :func:`conv2d_x3_launch` (the
+    chunking depends on k and the stride)."""
     _require_gpu(weight)
     _check_f32(weight)
     w = weight.detach().contiguous()
+    if w.dim() == 3:
+        w = w.unsqueeze(-1)
     cout, cin, kh, kw = w.shape
-    assert (kh, kw) == (3, 3)
+    assert kh == kw and kh in (1, 3)
     L = hip.lib()
-    nbytes = L.otp_conv2d_x3_weight_bytes(cout, cin, stride)
+    nbytes = L.otp_conv2d_x3_weight_bytes(cout, cin, kh, stride)
     if not nbytes:
         raise ValueError(f"otp_conv2d_x3: unsupported channel counts ({cout}, {cin})")
     u = torch.empty(nbytes // 4, dtype=torch.int32, device=w.device)
     sc = scale.detach().contiguous().float() if scale is not None else None
-    hip.check(L.otp_conv2d_x3_pack_weight(hip.ptr(w), hip.ptr(sc), hip.ptr(u), cout, cin, stride, hip.stream_of(w)),
+    hip.check(L.otp_conv2d_x3_pack_weight(hip.ptr(w), hip.ptr(sc), hip.ptr(u), cout, cin, kh, stride, hip.stream_of(w)),
               "otp_conv2d_x3_pack_weight")
     return u
 
@@ -352,12 +354,13 @@ def conv2d_x3(x, weight, scale=None, shift=None, act=ACT_NONE, res=None, pad=1, 
     """act(conv2d(x, weight, stride, pad, dil) * scale + shift + res) with split-bf16 products (csrc/convx.hip)."""
     _require_gpu(x, weight)
     n, cin, h, w = x.shape
-    cout = weight.shape[0]
-    ho, wo = (h + 2 * pad - 2 * dil - 1) // stride + 1, (w + 2 * pad - 2 * dil - 1) // stride + 1
+    cout, k = weight.shape[0], weight.shape[2]
+    ke = dil * (k - 1)
+    ho, wo = (h + 2 * pad - ke - 1) // stride + 1, (w + 2 * pad - ke - 1) // stride + 1
     out = torch.empty(n, cout, ho, wo, dtype=torch.float32, device=x.device)
     iv, ov = View(x.contiguous()), View(out)
     rv = View(res.contiguous()) if res is not None else None
-    d = conv_desc(iv, ov, cout, 3, 3, stride, pad, dil, act, None, rv)
+    d = conv_desc(iv, ov, cout, k, k, stride, pad, dil, act, None, rv)
     conv2d_x3_launch(iv, pack_x3_weight(weight, scale, stride), shift, ov, d, rv)
     return out
 

@@ -1,6 +1,7 @@
 """Split-bf16 (bf16x3) convolution kernel (csrc/convx.hip, otp_conv2d_x3) against a float64 ``F.conv2d`` of the same
 operands: the HRNet 3x3 convs of model/HRNet.py:500-571 (stride 1) and :442-470 (stride-2 transitions / fuse downsamples),
-plus the dilated offset / mask convs of model/OTPose.py:168-177.  Tolerance: 2e-5 of the output range (measured 4e-6; the
+its 1x1 convs (Bottleneck conv1 / conv3 / shortcut :533-571, fuse-layer 1x1s :455-462), plus the dilated offset / mask convs
+of model/OTPose.py:168-177.  Tolerance: 2e-5 of the output range (measured 4e-6; the
 f32-MFMA kernels sit at 3e-7 .. 2e-6): two bf16 pieces carry 16 mantissa bits + rounding, see the kernel header."""
 import pytest
 import torch
@@ -48,6 +49,34 @@ def test_conv2d_x3_matches_float64(case):
         ref = torch.relu(ref)
     y = ops.conv2d_x3(x, wt, sc, sh, ops.ACT_RELU if relu else ops.ACT_NONE, res, pad, dil, st)
     assert y.shape == ref.shape
+    err = float((y.double() - ref).abs().max()) / float(ref.abs().max())
+    assert err <= 2e-5, err
+
+
+POINTWISE = [  # (N, Cin, Cout, H, W, residual, relu)
+    (5, 64, 256, 96, 72, True, True),       # layer1 conv3 + shortcut sum
+    (5, 256, 64, 96, 72, False, True),
+    (3, 96, 48, 48, 36, False, False),      # fuse-layer 1x1 on a low-resolution branch
+    (7, 384, 96, 12, 9, False, False),      # several images per tile, odd width
+    (2, 32, 17, 10, 6, True, False),        # Cout not a multiple of 16, one partial tile
+]
+
+
+@pytest.mark.parametrize("case", POINTWISE, ids=lambda c: "x".join(str(v) for v in c[:5]))
+def test_conv2d_x3_pointwise_matches_float64(case):
+    n, ci, co, h, w, with_res, relu = case
+    g = torch.Generator(device="cpu").manual_seed(sum(case[:5]))
+    x = torch.randn(n, ci, h, w, generator=g).cuda()
+    wt = (torch.randn(co, ci, 1, 1, generator=g) * (2.0 / ci) ** 0.5).cuda()
+    sc = (torch.rand(co, generator=g) + 0.5).cuda()
+    sh = torch.randn(co, generator=g).cuda()
+    res = torch.randn(n, co, h, w, generator=g).cuda() if with_res else None
+    ref = F.conv2d(x.double(), wt.double()) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)
+    if with_res:
+        ref = ref + res.double()
+    if relu:
+        ref = torch.relu(ref)
+    y = ops.conv2d_x3(x, wt, sc, sh, ops.ACT_RELU if relu else ops.ACT_NONE, res, 0, 1, 1)
     err = float((y.double() - ref).abs().max()) / float(ref.abs().max())
     assert err <= 2e-5, err
 

@@ -14,6 +14,8 @@ SHAPES = [  # (N, Cin, Cout, H, W, pad, dil, stride)
     (80, 48, 48, 96, 72, 1, 1, 2), (80, 48, 96, 96, 72, 1, 1, 2), (80, 96, 192, 48, 36, 1, 1, 2), (80, 192, 384, 24, 18, 1, 1, 2),
     (80, 64, 64, 192, 144, 1, 1, 2), (80, 256, 96, 96, 72, 1, 1, 2), (3, 16, 24, 20, 12, 1, 1, 2),
 ]
+POINTWISE = [(80, 64, 256, 96, 72), (80, 256, 64, 96, 72), (80, 64, 64, 96, 72), (80, 128, 256, 96, 72), (80, 96, 48, 48, 36),
+             (80, 192, 48, 24, 18), (80, 192, 96, 24, 18), (80, 384, 48, 12, 9)]
 
 
 def timed(fn, reps):
@@ -63,5 +65,28 @@ def main():
         print(f"{n:3d}x{ci:3d}->{co:3d} {h:3d}x{w:<3d} p{pad} d{dil:<2d} s{st}   {t3:8.1f} {tw:8.1f} {tf:8.1f}   {e3:9.2e} {ew:9.2e} {ef:9.2e}  {fl / t3 * 1e-6:6.1f}  nores {t30:6.1f}")
 
 
+def pointwise():
+    reps = 20
+    print("1x1 convs (+ residual, ReLU):   x3 us   f32 us   x3 err")
+    for n, ci, co, h, w in POINTWISE:
+        x = torch.randn(n, ci, h, w, device="cuda")
+        wt = torch.randn(co, ci, 1, 1, device="cuda") * (2.0 / ci) ** 0.5
+        sc, sh = torch.rand(co, device="cuda") + 0.5, torch.randn(co, device="cuda")
+        res = torch.randn(n, co, h, w, device="cuda")
+        y = ops.conv2d_x3(x, wt, sc, sh, ops.ACT_RELU, res, 0, 1, 1)
+        ref = torch.relu(F.conv2d(x[:2].double(), wt.double()) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1) + res[:2].double())
+        e3 = float((y[:2].double() - ref).abs().max()) / float(ref.abs().max())
+        wp = ops.pack_x3_weight(wt, sc, 1)
+        iv, ov, rv = ops.View(x), ops.View(y), ops.View(res)
+        d = ops.conv_desc(iv, ov, co, 1, 1, 1, 0, 1, ops.ACT_RELU, None, rv)
+        t3 = timed(lambda: ops.conv2d_x3_launch(iv, wp, sh, ov, d, rv), reps)
+        wpf = ops.pack_conv_weight(wt)
+        tf = timed(lambda: ops.conv2d_launch(iv, wpf, sc, sh, ov, d, None, rv), reps)
+        print(f"{n:3d}x{ci:3d}->{co:3d} {h:3d}x{w:<3d}            {t3:8.1f} {tf:8.1f}   {e3:9.2e}")
+
+
 if __name__ == "__main__":
-    main()
+    if "--pointwise" in sys.argv:
+        pointwise()
+    else:
+        main()
