@@ -172,6 +172,26 @@ int otp_bn_train_backward(const void* grad_y, const void* x, const void* y_relu,
 int otp_channel_sum(const void* a, void* out, void* workspace, size_t workspace_bytes, int N, int C, int HW, int a_ctot,
                     int a_coff, void* stream);
 
+/* ---- offset / mask convolutions fused into the deformable-convolution gather ------------------
+ * All ND dilations of the warping head (model/OTPose.py:381-392) in one launch:
+ *   out = alpha * sum_i [ ModulatedDeformConv_i(x, Conv_off_i(trans), Conv_mask_i(trans)) + bias_i ]
+ * trans (B, 32, H, W), x = def_heatmaps (B, J, H, W), out (B, J, H, W), all fp32; 3x3 kernels, stride 1, padding = dilation,
+ * deformable_groups = J, groups = 1 (the only form model/OTPose.py:141-157 builds).  The 27 J offset / mask channels per pixel
+ * and dilation exist only in registers / LDS; the 32 -> 27 J convolutions run on the bf16 matrix cores with split products
+ * (see otp_conv2d_x3), the sampling follows deform_conv_cuda_kernel.cu:403-432, 549-556 exactly.
+ * packed: otp_dcn_fused_weight_bytes(ND, J) bytes written by otp_dcn_fused_pack from DEVICE arrays of ND device pointers
+ * (w_off[i] (18 J, 32, 3, 3), w_mask[i] (9 J, 32, 3, 3), w_dcn[i] (J, J, 3, 3), bias[i] (J) or NULL).
+ * workspace: otp_dcn_fused_workspace(B, H, W) bytes (the bf16 hi / lo NHWC copy of trans).
+ * otp_dcn_fused_supported: Cin == 32, J == 17, H * W % 128 == 0, ND <= 8. */
+int otp_dcn_fused_supported(int Cin, int J, int H, int W, int ND);
+size_t otp_dcn_fused_weight_bytes(int ND, int J);
+int otp_dcn_fused_pack(const void* const* w_off, const void* const* w_mask, const void* const* w_dcn, const void* const* bias,
+                       void* packed, int ND, int J, void* stream);
+size_t otp_dcn_fused_workspace(int B, int H, int W);
+int otp_dcn_fused_forward(const void* trans, const void* x, const void* packed, void* out, void* workspace,
+                          size_t workspace_bytes, int B, int Cin, int J, int H, int W, const int* dilations, int ND, float alpha,
+                          void* stream);
+
 /* ---- OTPose glue (model/OTPose.py:317-359) ------------------------------------------------------ */
 /* rough (5B,J,HW) -> total (B,J,HW), squeezed (B,J,HW), intersection (B,J,HW), flow_in = total + pe (pe: (J,HW)) */
 int otp_glue_total(const void* rough, void* total, void* squeezed, void* inter, void* flow_in, const void* pe,

@@ -1,0 +1,313 @@
+// the offset / mask convolutions fused into the deformable-convolution gather, all dilations of
+// the warping head in ONE launch.  Replaces, per dilation d of model/OTPose.py:381-392,
+//     offsets = Conv2d(32 -> 18 J, 3x3, dilation d, no bias)(trans)            (model/OTPose.py:168-177, 382)
+//     masks   = Conv2d(32 ->  9 J, 3x3, dilation d, no bias)(trans)            (:383)
+//     warped  = ModulatedDeformConv(J -> J, 3x3, dilation d, deformable_groups J)(def_heatmaps, offsets, masks)   (:384)
+// and the weighted sum over the dilations (:387-392): the 459 offset / mask channels per pixel and dilation (1.0 GB per
+// forward at batch 16) are never written to HBM.
+//
+// A workgroup (8 waves) owns 128 consecutive pixels of one image, a wave 16 of them.  Per dilation:
+//   * the wave's A operand - its 16 pixels x 9 dilated taps x 32 channels of `trans`, split into bf16 hi / lo pieces - is 18
+//     16-byte loads per lane from an NHWC split copy of `trans` (a 14 MB pre-pass, L2 resident) and stays in registers for
+//     all J deformable groups (zero padding = loads past the descriptor);
+//   * per group g the 27 (padded to 32) offset / mask channels are one [16 pixels x 288] x [288 x 32] product on the bf16
+//     matrix cores with split products (csrc/convx.hip): 54 MFMAs, the weight fragments streamed through the LDS by the
+//     LDS-DMA (40 KB per group, double buffered);
+//   * the 16 x 32 result goes through a per-wave LDS scratch so that four lanes per pixel share the nine taps: each reads
+//     its taps' (dy, dx, mask), gathers the four bilinear corners of plane g of `def_heatmaps` from global memory (7.5 MB,
+//     L2 resident; corners outside the image are loads past the descriptor = 0, the sample is dropped outside the open
+//     interval (-1, H) x (-1, W) exactly like deform_conv_cuda_kernel.cu:403-432, 549-556) and accumulates
+//     mask * sample * W_dcn[:, g, tap] into J output registers.
+// The J outputs accumulate over groups AND dilations in registers; one store per pixel at the end.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int FCIN = 32;                      // channels of `trans`
+constexpr int FBLK = 40960;                   // bytes of one (dilation, group) weight block: 9 taps x 2 n-tiles x (hi, lo) x 1 KB, padded
+constexpr int FPIX = 128;                     // pixels per workgroup
+constexpr int FMAXD = 8;                      // dilations per launch
+
+struct FusedPlan {
+    int B, J, H, W, HW, ND, tilesPerImg;
+    int dil[FMAXD];
+    float alpha;
+};
+
+__device__ __forceinline__ void f_split8(const float (&v)[8], u32x4& hi, u32x4& lo) {
+    uint32_t h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x2 a = {v[2 * i], v[2 * i + 1]};
+        const uint32_t hb = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, bf16x2));
+        const f32x2 af = {__builtin_bit_cast(float, hb << 16), __builtin_bit_cast(float, hb & 0xffff0000u)};
+        h[i] = hb;
+        l[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(a - af, bf16x2));
+    }
+    hi = (u32x4){h[0], h[1], h[2], h[3]};
+    lo = (u32x4){l[0], l[1], l[2], l[3]};
+}
+
+// trans (B, 32, H, W) fp32 -> (B, H, W, [32 bf16 hi | 32 bf16 lo]): thread = (pixel, 8-channel group)
+__global__ __launch_bounds__(256) void dcnf_split_kernel(const float* __restrict__ trans, u32x4* __restrict__ ws, int B, int HW) {
+    const size_t total = (size_t)B * HW * 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i & 3);
+        const size_t px = i >> 2;
+        const size_t n = px / HW, p = px - n * HW;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = trans[(n * FCIN + 8 * q + j) * HW + p];
+        u32x4 hi, lo;
+        f_split8(v, hi, lo);
+        ws[px * 8 + q] = hi;
+        ws[px * 8 + 4 + q] = lo;
+    }
+}
+
+// packed image: [ND][J] weight blocks of FBLK bytes, then [ND][J][9][20] floats (W_dcn[o][g][k], o padded to 20), then the
+// J bias sums.  Weight block: [tap][n-tile][hi, lo][lane][8 bf16], lane = (channel 16 nt + (lane & 15) of the group's 32:
+// 0..17 offsets 18 g + c, 18..26 masks 9 g + c - 18, 27..31 zero; kq = lane >> 4 -> input channels 8 kq .. + 7)
+__global__ void dcnf_pack_kernel(const float* const* __restrict__ w_off, const float* const* __restrict__ w_mask,
+                                 const float* const* __restrict__ w_dcn, const float* const* __restrict__ bias,
+                                 unsigned char* __restrict__ packed, int ND, int J) {
+    const int units = FBLK / 16;
+    const size_t nW = (size_t)ND * J * units, nT = (size_t)ND * J * 9 * 5, total = nW + nT + 5;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        u32x4 o = {0u, 0u, 0u, 0u};
+        if (idx < nW) {
+            const int blk = (int)(idx / units), u = (int)(idx - (size_t)blk * units);
+            const int di = blk / J, g = blk - di * J;
+            if (u < 9 * 2 * 2 * 64) {
+                const int frag = u >> 6, lane = u & 63, part = frag & 1, nt = (frag >> 1) & 1, tap = frag >> 2;
+                const int ch = 16 * nt + (lane & 15), kq = lane >> 4;
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int ci = 8 * kq + j;
+                    v[j] = ch < 18 ? w_off[di][((size_t)(18 * g + ch) * FCIN + ci) * 9 + tap]
+                                   : (ch < 27 ? w_mask[di][((size_t)(9 * g + ch - 18) * FCIN + ci) * 9 + tap] : 0.f);
+                }
+                u32x4 hi, lo;
+                f_split8(v, hi, lo);
+                o = part ? lo : hi;
+            }
+        } else if (idx < nW + nT) {
+            const size_t t = idx - nW;
+            const int q = (int)(t % 5), k = (int)((t / 5) % 9), g = (int)((t / 45) % J), di = (int)(t / (45 * (size_t)J));
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int oc = 4 * q + i;
+                v[i] = oc < J ? w_dcn[di][((size_t)oc * J + g) * 9 + k] : 0.f;
+            }
+            o = (u32x4){__builtin_bit_cast(uint32_t, v[0]), __builtin_bit_cast(uint32_t, v[1]), __builtin_bit_cast(uint32_t, v[2]),
+                        __builtin_bit_cast(uint32_t, v[3])};
+        } else {
+            const int q = (int)(idx - nW - nT);
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int oc = 4 * q + i;
+                float s = 0.f;
+                for (int di = 0; di < ND; ++di) s += (oc < J && bias[di]) ? bias[di][oc] : 0.f;
+                v[i] = s;
+            }
+            o = (u32x4){__builtin_bit_cast(uint32_t, v[0]), __builtin_bit_cast(uint32_t, v[1]), __builtin_bit_cast(uint32_t, v[2]),
+                        __builtin_bit_cast(uint32_t, v[3])};
+        }
+        reinterpret_cast<u32x4*>(packed)[idx] = o;
+    }
+}
+
+__device__ __forceinline__ void f_stage(const unsigned char* __restrict__ src, unsigned char* lds) {
+    constexpr int NST = FBLK / 16 / 512;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+        const int u0 = i * 512 + wave * 64;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)(u0 + lane) * 16),
+                                         (__attribute__((address_space(3))) void*)(lds + u0 * 16), 16, 0, 0);
+    }
+}
+
+template <int J>
+__global__ __launch_bounds__(512, 2) void dcn_fused_kernel(const unsigned char* __restrict__ ws, const float* __restrict__ x,
+                                                            const unsigned char* __restrict__ packed, float* __restrict__ out,
+                                                            const FusedPlan P) {
+    constexpr int JP = (J + 3) & ~3;                                // outputs padded to float4s (20 for J = 17)
+    static_assert(JP <= 20, "the W_dcn table rows hold 20 floats");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* wbuf = smem;                                     // 2 x FBLK
+    float* scratch = reinterpret_cast<float*>(smem + 2 * FBLK);     // [8 waves][16 pixels][32 channels]
+    float* wd = scratch + 8 * 16 * 32;                              // [J][9][20]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int n = (int)blockIdx.x / P.tilesPerImg, p0 = ((int)blockIdx.x - n * P.tilesPerImg) * FPIX;
+    const int p = p0 + wave * 16 + i16;                             // the lane's pixel (both as fragment row and as sampling pixel)
+    const int y = p / P.W, xx0 = p - y * P.W;
+    float* scr = scratch + wave * (16 * 32);
+
+    const otp_rsrc rws = make_rsrc32(ws + (size_t)n * P.HW * 128, (unsigned)P.HW * 128u);
+    const otp_rsrc rx = make_rsrc32(x + (size_t)n * J * P.HW, (unsigned)(J * P.HW) * 4u);
+    const size_t table_off = (size_t)P.ND * J * FBLK;
+
+    float part[JP];
+#pragma unroll
+    for (int o = 0; o < JP; ++o) part[o] = 0.f;
+    // the lane's taps in the sampling phase: sub 0 -> taps 0, 1, 2; sub s > 0 -> taps 2 s + 1, 2 s + 2
+    const int kbase = kq == 0 ? 0 : 2 * kq + 1, kcnt = kq == 0 ? 3 : 2;
+
+    for (int di = 0; di < P.ND; ++di) {
+        const int d = P.dil[di];
+        __syncthreads();                                            // the previous dilation's table / weight buffers are free
+        for (int i = tid; i < J * 9 * 5; i += 512)
+            reinterpret_cast<u32x4*>(wd)[i] = reinterpret_cast<const u32x4*>(packed + table_off)[(size_t)di * J * 45 + i];
+        // pixel fragments of all nine taps (rows outside the image / columns outside the row: offset past the descriptor = 0)
+        u32x4 ah[9], al[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int yy = y + (k / 3 - 1) * d, xx = xx0 + (k % 3 - 1) * d;
+            const bool ok = yy >= 0 && yy < P.H && xx >= 0 && xx < P.W;
+            const int off = ok ? (yy * P.W + xx) * 128 + kq * 16 : -128;
+            ah[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rws, off, 0, 0));
+            al[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rws, off, 64, 0));
+        }
+        f_stage(packed + (size_t)(di * J) * FBLK, wbuf);
+        __syncthreads();                                            // block 0 landed, table visible
+
+#pragma unroll 1
+        for (int g = 0; g < J; ++g) {
+            if (g + 1 < J) f_stage(packed + (size_t)(di * J + g + 1) * FBLK, wbuf + ((g + 1) & 1) * FBLK);
+            const unsigned char* wb = wbuf + (g & 1) * FBLK + lane * 16;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const bf16x8 b0h = *reinterpret_cast<const bf16x8*>(wb + (k * 4 + 0) * 1024);
+                const bf16x8 b0l = *reinterpret_cast<const bf16x8*>(wb + (k * 4 + 1) * 1024);
+                const bf16x8 b1h = *reinterpret_cast<const bf16x8*>(wb + (k * 4 + 2) * 1024);
+                const bf16x8 b1l = *reinterpret_cast<const bf16x8*>(wb + (k * 4 + 3) * 1024);
+                const bf16x8 a_h = __builtin_bit_cast(bf16x8, ah[k]), a_l = __builtin_bit_cast(bf16x8, al[k]);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_l, b0h, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_l, b1h, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h, b0l, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h, b1l, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h, b0h, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h, b1h, acc1, 0, 0, 0);
+            }
+            // accumulator (channel i16 / 16 + i16, pixels 4 kq + r) -> scratch[pixel][channel]
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                scr[(4 * kq + r) * 32 + i16] = acc0[r];
+                scr[(4 * kq + r) * 32 + 16 + i16] = acc1[r];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // sampling: lane = (pixel i16, sub kq)
+#pragma unroll
+            for (int it = 0; it < 3; ++it) {
+                const bool live = it < kcnt;
+                const int k = live ? kbase + it : kbase;
+                const float oh = scr[i16 * 32 + 2 * k], ow = scr[i16 * 32 + 2 * k + 1], m = scr[i16 * 32 + 18 + k];
+                const int ky = k / 3, kx = k - 3 * ky;
+                const float h = (float)(y + (ky - 1) * d) + oh, w = (float)(xx0 + (kx - 1) * d) + ow;
+                const bool inside = h > -1.f && w > -1.f && h < (float)P.H && w < (float)P.W;
+                const float hc = inside ? h : 0.f, wc = inside ? w : 0.f;
+                const float hf = floorf(hc), wf = floorf(wc);
+                const int hl = (int)hf, wl = (int)wf;
+                const float lh = hc - hf, lw = wc - wf, hh = 1.f - lh, hw = 1.f - lw;
+                const int base = (g * P.H + hl) * P.W + wl;
+                const bool t_ok = hl >= 0, b_ok = hl + 1 < P.H, l_ok = wl >= 0, r_ok = wl + 1 < P.W;
+                const float v1 = bload(rx, (t_ok && l_ok) ? base * 4 : -16, 0);
+                const float v2 = bload(rx, (t_ok && r_ok) ? (base + 1) * 4 : -16, 0);
+                const float v3 = bload(rx, (b_ok && l_ok) ? (base + P.W) * 4 : -16, 0);
+                const float v4 = bload(rx, (b_ok && r_ok) ? (base + P.W + 1) * 4 : -16, 0);
+                const float smp = hh * hw * v1 + hh * lw * v2 + lh * hw * v3 + lh * lw * v4;
+                const float val = (live && inside) ? smp * m : 0.f;
+                const float* wrow = wd + (g * 9 + k) * 20;
+#pragma unroll
+                for (int q = 0; q < JP / 4; ++q) {
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(wrow + 4 * q);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) part[4 * q + i] = fmaf(w4[i], val, part[4 * q + i]);
+                }
+            }
+            __syncthreads();                                        // weight buffer swap; the wave's scratch is free again
+        }
+    }
+    // the four subs of a pixel hold partial sums over their taps
+#pragma unroll
+    for (int o = 0; o < JP; ++o) {
+        part[o] += __shfl_xor(part[o], 16, 64);
+        part[o] += __shfl_xor(part[o], 32, 64);
+    }
+    if (kq == 0) {
+        const float* bs = reinterpret_cast<const float*>(packed + table_off + (size_t)P.ND * J * 45 * 16);
+#pragma unroll
+        for (int o = 0; o < J; ++o) out[((size_t)n * J + o) * P.HW + p] = P.alpha * (part[o] + bs[o]);
+    }
+}
+
+}  // namespace
+
+extern "C" int otp_dcn_fused_supported(int Cin, int J, int H, int W, int ND) {
+    return (Cin == FCIN && J == 17 && H > 0 && W > 0 && (H * W) % FPIX == 0 && ND >= 1 && ND <= FMAXD &&
+            (long)H * W * 128 < (1l << 31) && (long)J * H * W * 4 < (1l << 31))
+               ? 1 : 0;
+}
+
+extern "C" size_t otp_dcn_fused_weight_bytes(int ND, int J) {
+    if (ND <= 0 || J <= 0 || J > 20) return 0;
+    return (size_t)ND * J * FBLK + (size_t)ND * J * 45 * 16 + 5 * 16;
+}
+
+// w_off[i] (18 J, 32, 3, 3), w_mask[i] (9 J, 32, 3, 3), w_dcn[i] (J, J, 3, 3), bias[i] (J) or NULL: device pointer arrays
+// (device memory) of ND entries each
+extern "C" int otp_dcn_fused_pack(const void* const* w_off, const void* const* w_mask, const void* const* w_dcn,
+                                  const void* const* bias, void* packed, int ND, int J, void* stream) {
+    if (!w_off || !w_mask || !w_dcn || !bias || !packed) return OTP_ERR_BAD_ARG;
+    const size_t bytes = otp_dcn_fused_weight_bytes(ND, J);
+    if (!bytes) return OTP_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(dcnf_pack_kernel, dim3(1024), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const float* const*>(w_off), reinterpret_cast<const float* const*>(w_mask),
+                       reinterpret_cast<const float* const*>(w_dcn), reinterpret_cast<const float* const*>(bias),
+                       static_cast<unsigned char*>(packed), ND, J);
+    return otp_launch_status();
+}
+
+extern "C" size_t otp_dcn_fused_workspace(int B, int H, int W) {
+    return (B > 0 && H > 0 && W > 0) ? (size_t)B * H * W * 128 : 0;
+}
+
+extern "C" int otp_dcn_fused_forward(const void* trans, const void* x, const void* packed, void* out, void* workspace,
+                                     size_t workspace_bytes, int B, int Cin, int J, int H, int W, const int* dilations, int ND,
+                                     float alpha, void* stream) {
+    if (!trans || !x || !packed || !out || !workspace || !dilations || B <= 0) return OTP_ERR_BAD_ARG;
+    if (!otp_dcn_fused_supported(Cin, J, H, W, ND)) return OTP_ERR_UNSUPPORTED;
+    if (workspace_bytes < otp_dcn_fused_workspace(B, H, W)) return OTP_ERR_WORKSPACE;
+    if ((reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(workspace)) & 15) return OTP_ERR_BAD_ARG;
+    auto st = static_cast<hipStream_t>(stream);
+    FusedPlan P{};
+    P.B = B; P.J = J; P.H = H; P.W = W; P.HW = H * W; P.ND = ND; P.tilesPerImg = P.HW / FPIX; P.alpha = alpha;
+    for (int i = 0; i < ND; ++i) {
+        if (dilations[i] <= 0) return OTP_ERR_BAD_ARG;
+        P.dil[i] = dilations[i];
+    }
+    const size_t nsplit = (size_t)B * P.HW * 4;
+    hipLaunchKernelGGL(dcnf_split_kernel, dim3((unsigned)((nsplit + 255) / 256 > 4096 ? 4096 : (nsplit + 255) / 256)), dim3(256), 0,
+                       st, static_cast<const float*>(trans), static_cast<u32x4*>(workspace), B, P.HW);
+    const size_t lds = 2 * (size_t)FBLK + 8 * 16 * 32 * 4 + (size_t)17 * 9 * 20 * 4 + 64;
+    auto kern = dcn_fused_kernel<17>;
+    OTP_ALLOW_BIG_LDS(kern, lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(B * P.tilesPerImg)), dim3(512), lds, st, static_cast<const unsigned char*>(workspace),
+                       static_cast<const float*>(x), static_cast<const unsigned char*>(packed), static_cast<float*>(out), P);
+    return otp_launch_status();
+}

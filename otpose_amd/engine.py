@@ -54,6 +54,8 @@ class InferenceEngine:
         # conv products: "x3" = fp32 operands split into two bf16 pieces, three bf16 MFMAs per product, fp32 accumulate
         # (csrc/convx.hip); "f32" = the f32 MFMA kernels only (Winograd / direct)
         self.use_x3 = os.environ.get("OTPOSE_CONV_MATH", "x3") != "f32"
+        # offset / mask convs + DCN gathers of all dilations in one launch (split-bf16 products for the convs)
+        self.use_dcn_fused = self.use_x3 and os.environ.get("OTPOSE_DCN_FUSED", "1") != "0"
         self.use_fused_mlp = os.environ.get("OTPOSE_FUSED_MLP", "1") != "0"   # transformer MLP via csrc/mlp.hip
         self.fuse_shortcut = os.environ.get("OTPOSE_FUSE_SHORTCUT", "1") != "0"  # layer1 shortcut folded into conv3
         self.fuse_upsample = os.environ.get("OTPOSE_FUSE_UPSAMPLE", "1") != "0"  # a fuse row's upsampled terms in one pass
@@ -592,8 +594,27 @@ class InferenceEngine:
         self.copy_into(def_h, View(cat3, 2 * J, J))
         trans = self.rsb_chain(m.offset_mask_combine_conv, View(cat3))
         out = self.new(B, J, h, w)
-        off_buf, msk_buf = self.new(B, J * 18, h, w), self.new(B, J * 9, h, w)
         nd = len(m.deformable_conv_dilations)
+        dils = [int(d) for d in m.deformable_conv_dilations]
+        cin_t = trans.C
+        if (self.use_dcn_fused and trans.coff == 0 and trans.C == trans.ctot and ops.dcn_fused_supported(cin_t, J, h, w, nd)
+                and all(c[0].kernel_size == (3, 3) and c[0].bias is None for c in list(m.offsets_list) + list(m.masks_list))):
+            # the ten offset / mask convs and the five DCN gathers as ONE launch; the 459
+            # offset / mask channels per pixel and dilation never reach HBM (csrc/dcn_fused.hip)
+            dcs = [mm.deform_conv for mm in m.modulated_deform_conv_list]
+            packed = ops.pack_dcn_fused([self.dev_param(c[0].weight) for c in m.offsets_list],
+                                        [self.dev_param(c[0].weight) for c in m.masks_list],
+                                        [self.dev_param(dc.weight) for dc in dcs],
+                                        [None if dc.bias is None else self.dev_param(dc.bias) for dc in dcs])
+            ws = self.new(B, 32, h, w)                               # bf16 hi / lo NHWC copy of trans: 128 bytes per pixel
+            dl = (ctypes.c_int * nd)(*dils)
+            self._keep += [packed, dl]
+            self.call(L.otp_dcn_fused_forward, "otp_dcn_fused_forward", hip.ptr(trans.t), hip.ptr(def_h.t), hip.ptr(packed),
+                      hip.ptr(out), hip.ptr(ws), ws.numel() * 4, B, cin_t, J, h, w, dl, nd, 1.0 / nd)
+            self.outputs = (out, rough, inter, prev_b, ctx.view(B, J, h, w), squeezed, total)
+            torch.cuda.synchronize(self.dev)
+            return
+        off_buf, msk_buf = self.new(B, J * 18, h, w), self.new(B, J * 9, h, w)
         for i, d in enumerate(m.deformable_conv_dilations):
             self.conv(trans, m.offsets_list[i][0].weight, View(off_buf), 1, d, d)
             self.conv(trans, m.masks_list[i][0].weight, View(msk_buf), 1, d, d)

@@ -94,6 +94,11 @@ SIGNATURES = {
     "otp_mlp_fused_pack": (c_int, [c_void_p] * 4 + [c_int] * 2 + [c_void_p]),
     "otp_mlp_fused": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_void_p]),
     "otp_ln_mlp_fused": (c_int, [c_void_p] * 3 + [c_float] + [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
+    "otp_dcn_fused_supported": (c_int, [c_int] * 5),
+    "otp_dcn_fused_weight_bytes": (c_size_t, [c_int] * 2),
+    "otp_dcn_fused_pack": (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p]),
+    "otp_dcn_fused_workspace": (c_size_t, [c_int] * 3),
+    "otp_dcn_fused_forward": (c_int, [c_void_p] * 5 + [c_size_t] + [c_int] * 5 + [ctypes.POINTER(c_int), c_int, c_float, c_void_p]),
     "otp_dense_x3_supported": (c_int, [c_int] * 2),
     "otp_dense_x3_weight_bytes": (c_size_t, [c_int]),
     "otp_dense_x3_pack": (c_int, [c_void_p] * 4 + [c_int, c_void_p]),

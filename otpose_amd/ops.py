@@ -481,6 +481,48 @@ def mlp_fused(x, packed, scale, shift, res, out=None, hid=None, stream=None):
     return out
 
 
+def dcn_fused_supported(cin, j, h, w, nd) -> bool:
+    return bool(hip.lib().otp_dcn_fused_supported(int(cin), int(j), int(h), int(w), int(nd)))
+
+
+def pack_dcn_fused(w_offs, w_masks, w_dcns, biases):
+    """Per-dilation offset / mask conv weights ((18 J, 32, 3, 3) / (9 J, 32, 3, 3)), DCN weights (J, J, 3, 3) and biases (J or
+    None) -> the packed image of :func:`dcn_fused` (csrc/dcn_fused.hip)."""
+    nd, j = len(w_offs), w_dcns[0].shape[0]
+    dev = w_offs[0].device
+    _require_gpu(*w_offs, *w_masks, *w_dcns)
+    keep = [[t.detach().contiguous().float() for t in ts] for ts in (w_offs, w_masks, w_dcns)]
+    keep.append([None if b is None else b.detach().contiguous().float() for b in biases])
+    ptrs = [torch.tensor([0 if t is None else t.data_ptr() for t in ts], dtype=torch.int64, device=dev) for ts in keep]
+    L = hip.lib()
+    nbytes = L.otp_dcn_fused_weight_bytes(nd, j)
+    if not nbytes:
+        raise RuntimeError(f"otp_dcn_fused: unsupported ND={nd}, J={j}")
+    packed = torch.empty(nbytes // 4, dtype=torch.int32, device=dev)
+    hip.check(L.otp_dcn_fused_pack(*[hip.ptr(t) for t in ptrs], hip.ptr(packed), nd, j, hip.stream_of(packed)),
+              "otp_dcn_fused_pack")
+    torch.cuda.current_stream(dev).synchronize()          # the pointer arrays and fp32 copies die with this frame
+    return packed
+
+
+def dcn_fused(trans, x, packed, dilations, alpha, out=None, workspace=None, stream=None):
+    """out = alpha * sum over dilations of ModulatedDeformConv(x, Conv_off(trans), Conv_mask(trans)) + bias (SURVEY.md
+    section 8 row f-2; model/OTPose.py:381-392) in one launch; the offsets and masks never reach HBM."""
+    _require_gpu(trans, x, packed)
+    _check_f32(trans)
+    b, cin, h, w = trans.shape
+    j = x.shape[1]
+    L = hip.lib()
+    out = torch.empty_like(x) if out is None else out
+    nws = L.otp_dcn_fused_workspace(b, h, w)
+    workspace = torch.empty(nws // 4, dtype=torch.int32, device=x.device) if workspace is None else workspace
+    dl = (ctypes.c_int * len(dilations))(*[int(d) for d in dilations])
+    hip.check(L.otp_dcn_fused_forward(hip.ptr(trans), hip.ptr(x), hip.ptr(packed), hip.ptr(out), hip.ptr(workspace), nws, b, cin, j,
+                                      h, w, dl, len(dilations), float(alpha),
+                                      stream if stream is not None else hip.stream_of(x)), "otp_dcn_fused_forward")
+    return out
+
+
 def mlp_x3_supported(c, hid, t) -> bool:
     return bool(hip.lib().otp_mlp_x3_supported(int(c), int(hid), int(t)))
 
