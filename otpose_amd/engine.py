@@ -626,6 +626,13 @@ class InferenceEngine:
         self.outputs = (out, rough, inter, prev_b, ctx.view(B, J, h, w), squeezed, total)
         torch.cuda.synchronize(self.dev)
 
+    def __del__(self):
+        try:
+            if getattr(self, "graph", None) is not None:
+                torch.cuda.synchronize(self.dev)
+        except Exception:                           # interpreter shutdown
+            pass
+
     def copy_into(self, src: View, dst: View):
         """dst channels <- src (per-sample strided copy through the upsample kernel with f = 1)."""
         n, _, h, w = src.t.shape
