@@ -40,6 +40,16 @@ def test_e2e_tiny_matches_reference_golden(golden):
     print(_check(outs, golden("e2e_tiny")))
 
 
+def test_e2e_tiny_exact_fp32_kernels(golden, monkeypatch):
+    """OTPOSE_CONV_MATH=f32: the exact-fp32 MFMA kernels of round 1 (Winograd / direct convs, f32 MLP and projections,
+    offset / mask convs and DCN as separate launches) stay selectable and green."""
+    monkeypatch.setenv("OTPOSE_CONV_MATH", "f32")
+    m, outs = _run(tiny_cfg(8, (64, 96)), 2)
+    assert not m._engine.use_x3 and not m._engine.use_dcn_fused
+    worst = _check(outs, golden("e2e_tiny"))
+    assert worst["output"] <= 1e-4
+
+
 def test_e2e_cfg1_matches_reference_golden(golden):
     _, outs = _run(cfg1(), 1)
     print(_check(outs, golden("e2e_cfg1")))
