@@ -290,10 +290,21 @@ __global__ __launch_bounds__(256) void attn_softmax_kernel(const float* __restri
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int col = lane + 64 * h;
+        // the NS partial slabs: independent loads, eight in flight (one after the other they were a 40 us latency chain);
+        // a masked lane re-reads element 0 of its slab, same summation order as before for the live ones
+        const bool live = row < hs && col < hs;
+        const float* sp = sb + (live ? (size_t)row * HSP + col : 0);
         float a = 0.f;
-        if (row < hs && col < hs)
-            for (int s = 0; s < NS; ++s) a += sb[((size_t)s * HSP + row) * HSP + col];
-        v[h] = (row < hs && col < hs) ? a * scale : -INFINITY;
+        int s = 0;
+        for (; s + 8 <= NS; s += 8) {
+            float t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = sp[(size_t)(s + j) * HSP * HSP];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a += t[j];
+        }
+        for (; s < NS; ++s) a += sp[(size_t)s * HSP * HSP];
+        v[h] = live ? a * scale : -INFINITY;
     }
     const float m = wave_max(fmaxf(v[0], v[1]));
     float e0 = (row < hs && lane < hs) ? expf(v[0] - m) : 0.f;
