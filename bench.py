@@ -222,7 +222,28 @@ def kernel_rooflines(dev, batch):
               "algorithmic_bytes_per_call": att_bytes, "mfma_flop_per_call": att_flop,
               "mfma_achieved_TFLOPs": att_flop / (t_att * 1e-3) / 1e12,
               "mfma_frac": att_flop / (t_att * 1e-3) / PEAK_F32_MATRIX}
-    return conv, dcn_r, mlp_r, attn_r
+    # the warping head (ten offset / mask convs + five DCN gathers + weighted sum) as one launch
+    head_r = None
+    if os.environ.get("OTPOSE_CONV_MATH", "x3") != "f32" and ops.dcn_fused_supported(32, 17, 96, 72, 5):
+        dils = (3, 6, 9, 12, 15)
+        tr = torch.randn(batch, 32, 96, 72, generator=g).to(dev)
+        w_off = [(torch.randn(306, 32, 3, 3, generator=g) / 17.0).to(dev) for _ in dils]
+        w_msk = [(torch.randn(153, 32, 3, 3, generator=g) / 17.0).to(dev) for _ in dils]
+        w_dcn = [(torch.randn(17, 17, 3, 3, generator=g) * 0.2).to(dev) for _ in dils]
+        packed = ops.pack_dcn_fused(w_off, w_msk, w_dcn, [None] * 5)
+        ws = torch.empty(batch * 96 * 72 * 32, dtype=torch.int32, device=dev)
+        t_head = event_time_ms(lambda: ops.dcn_fused(tr, xd, packed, dils, 0.2, out=od, workspace=ws), 10, st)
+        conv_fl = 2.0 * 459 * 32 * 9 * 96 * 72 * batch * 5                     # the ten 32 -> 306 / 153 convs
+        unfused_bytes = (DCN_BYTES_PER_CLIP_DIL + 2 * 459 * 6912 * 4.0) * batch * 5   # DCN streams + conv outputs written
+        head_r = {"kernel": "dcn_fused_kernel<17> + dcnf_split_kernel: 5 dilations x (32->306, 32->153 convs + DCN 17->17), "
+                            "96x72 x%d clips, one launch" % batch,
+                  "bound": "lds", "ms_per_launch": t_head, "algorithmic_conv_flop_per_launch": conv_fl,
+                  "achieved": conv_fl / (t_head * 1e-3) / 1e12, "unit": "TFLOP/s (conv part, algorithmic)",
+                  "executed_mfma_frac": conv_fl * 3.0 * 32.0 / 27.0 / (t_head * 1e-3) / PEAK_BF16_MATRIX,
+                  "hbm_bytes_per_launch": (32 * 3 + 17 * 2) * 6912 * 4.0 * batch,
+                  "hbm_bytes_of_the_unfused_launches": unfused_bytes,
+                  "note": "offsets / masks never leave the chip; bound by LDS fragment reads (DESIGN.md section 3.2b)"}
+    return conv, dcn_r, mlp_r, attn_r, head_r
 
 
 def golden_parity(model, cfg, dev):
@@ -427,13 +448,15 @@ def main():
                                  "frac": FLOP_PER_CLIP * a.batch * fwd_per_s / PEAK_F32_MATRIX, "traffic": None},
         }
         log("timed region done: %.2f ms/step" % (1e3 * dt / a.steps))
-        conv, dcn, mlp, attn = kernel_rooflines(dev, a.batch)
+        conv, dcn, mlp, attn, head = kernel_rooflines(dev, a.batch)
         log("kernel rooflines done")
         line["roofline"] = conv
         line["roofline_dcn"] = dcn
         if mlp is not None:
             line["roofline_mlp"] = mlp
         line["roofline_attn"] = attn
+        if head is not None:
+            line["roofline_warp_head"] = head
         line["vs_eager_rocm"] = eager_ratio(1e3 * dt / a.steps / 1.0, a.batch)
         line["parity"] = golden_parity(model, cfg, dev)     # the "heatmap max-abs delta vs ref" half of the metric
         log("golden parity done")

@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void nhwc_conv_kernel(const bf16* __restrict__
 
     const int wunits = p.ldsW / 16;
     const int rowUnits = p.RW * p.CK8;
-    const otp_rsrc xres = make_rsrc(x, (size_t)p.N * p.H * p.W * p.CinS * 2), wres = make_rsrc(wpk, p.wbytes);
+    const otp_rsrc xres = make_rsrc(x, (size_t)p.N * p.H * p.W * p.CinS * 2);
     OTP_STAMP(1);
     for (int ch = 0; ch < p.nChunks; ++ch) {
         if (ch) __syncthreads();
@@ -341,12 +341,14 @@ __global__ __launch_bounds__(256) void nhwc_conv_kernel(const bf16* __restrict__
         // (column, channel group) and walks the rows, so the column arithmetic is done once per chunk).
         const int wbase = (ch * p.nM + mt) * wunits * 16;
         const int c0 = ch * p.CK;
-        u32x4 wv[8], xv[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int i = j * 256 + tid;
-            wv[j] = bload16(wres, i < wunits ? wbase + i * 16 : OOB);
-        }
+        u32x4 xv[8];
+        // weight slab of this (chunk, m-tile): global -> LDS by the LDS-DMA (the packed slab IS the LDS image: unit i lands at
+        // sW + 16 i), no staging registers, no ds_write pass
+        for (int u0 = wave * 64; u0 < wunits; u0 += 256)
+            if (u0 + lane < wunits)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(reinterpret_cast<const unsigned char*>(wpk) + wbase + (size_t)(u0 + lane) * 16),
+                    (__attribute__((address_space(3))) void*)(reinterpret_cast<unsigned char*>(sW) + u0 * 16), 16, 0, 0);
         const int col0 = tid / p.CK8, cg0 = tid - col0 * p.CK8;
         const int ix0 = col0 - p.pad;
         const bool colOK0 = tid < rowUnits && ix0 >= 0 && ix0 < p.W && c0 + cg0 * 8 < p.CinS;
@@ -358,27 +360,9 @@ __global__ __launch_bounds__(256) void nhwc_conv_kernel(const bf16* __restrict__
             xv[j] = bload16(xres, ok ? (n * p.H + iy) * (p.W * p.CinS * 2) + gcol0 : OOB);
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int i = j * 256 + tid;
-            if (i < wunits) reinterpret_cast<u32x4*>(sW)[i] = wv[j];
-        }
-#pragma unroll
         for (int j = 0; j < 8; ++j)
             if (tid < rowUnits && j < nrows) *reinterpret_cast<u32x4*>(sX + j * (p.RW * p.CKp) + ldst0) = xv[j];
-        // the rest (more than 2048 weight units, rows past 8, rows wider than 256 units)
-        for (int base = 256 * 8; base < wunits; base += 256 * 8) {
-            u32x4 v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int i = base + j * 256 + tid;
-                v[j] = bload16(wres, i < wunits ? wbase + i * 16 : OOB);
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int i = base + j * 256 + tid;
-                if (i < wunits) reinterpret_cast<u32x4*>(sW)[i] = v[j];
-            }
-        }
+        // the rest (rows past 8, rows wider than 256 units)
         for (int sub = 0; sub * 256 < rowUnits; ++sub) {
             const int cu = sub * 256 + tid;
             const int col = cu / p.CK8, cgi = cu - col * p.CK8;
