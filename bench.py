@@ -373,6 +373,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-step", action="store_true", help="skip the training-step probe (extra field of the line)")
     ap.add_argument("--train-f32", action="store_true", help="also time the fp32 training step (1 GPU)")
+    ap.add_argument("--no-exact-fp32", action="store_true", help="skip the exact-fp32-kernel forward reported beside the headline")
     a = ap.parse_args()
 
     # stdout carries exactly ONE JSON line: native libraries (RCCL prints a version banner through C stdio) get stderr
@@ -422,6 +423,29 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     finite = bool(torch.isfinite(outs[0]).all())
+    # the same forward on the exact-fp32 MFMA kernels of round 1 (OTPOSE_CONV_MATH=f32), reported beside the headline so that
+    # both arithmetic choices are on one line; 1 GPU only, never part of `value`
+    exact = None
+    math = os.environ.get("OTPOSE_CONV_MATH", "x3")
+    if world == 1 and math != "f32" and not a.no_exact_fp32:
+        os.environ["OTPOSE_CONV_MATH"] = "f32"
+        try:
+            model.invalidate_engine()
+            with torch.no_grad():
+                for _ in range(2):
+                    model(x, margin=margin)
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                for _ in range(a.steps):
+                    model(x, margin=margin)
+                torch.cuda.synchronize(dev)
+                de = time.perf_counter() - t1
+            exact = {"frames_per_s": 5 * a.batch * a.steps / de, "ms_per_step": 1e3 * de / a.steps,
+                     "kernels": "f32 MFMA: Winograd F(2x2,3x3) / direct convs, csrc/mlp.hip, csrc/dense.hip, unfused warping head",
+                     "parity": golden_parity(model, cfg, dev)}
+        finally:
+            os.environ["OTPOSE_CONV_MATH"] = math
+            model.invalidate_engine()
     train = None
     if not a.no_train_step:
         del outs
@@ -439,6 +463,9 @@ def main():
             "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "arithmetic": ("fp32 storage and accumulation everywhere; conv / MLP / projection products as three bf16 MFMA "
+                           "products of two-piece operands (a = hi + lo, |a - hi - lo| <= 2^-18 |a|: DESIGN.md section 3.1c)"
+                           if math != "f32" else "fp32 throughout (f32 MFMA)"),
             "config": {"workload": "BASELINE configs[1]: batch %d x 5-frame x 384x288, HRNet-W48 + DCN warp + "
                                    "ConvVideoTransformer, fp32 forward (eval), seeded synthetic weights" % a.batch,
                        "clips_per_gpu": a.batch, "frames_per_step_per_gpu": 5 * a.batch, "parallelism": "dp%d" % world,
@@ -457,6 +484,8 @@ def main():
         line["roofline_attn"] = attn
         if head is not None:
             line["roofline_warp_head"] = head
+        if exact is not None:
+            line["exact_fp32_kernels"] = exact
         line["vs_eager_rocm"] = eager_ratio(1e3 * dt / a.steps / 1.0, a.batch)
         line["parity"] = golden_parity(model, cfg, dev)     # the "heatmap max-abs delta vs ref" half of the metric
         log("golden parity done")
