@@ -50,6 +50,17 @@ def test_e2e_tiny_exact_fp32_kernels(golden, monkeypatch):
     assert worst["output"] <= 1e-4
 
 
+def test_e2e_tiny_unfused_warping_head(golden, monkeypatch):
+    """OTPOSE_DCN_FUSED=0: offset / mask convs and DCN gathers as separate launches (the path shapes outside
+    otp_dcn_fused_supported take) give the same heat-maps as the fused launch."""
+    _, fused = _run(tiny_cfg(8, (64, 96)), 2)
+    monkeypatch.setenv("OTPOSE_DCN_FUSED", "0")
+    m, outs = _run(tiny_cfg(8, (64, 96)), 2)
+    assert m._engine.use_x3 and not m._engine.use_dcn_fused
+    _check(outs, golden("e2e_tiny"))
+    assert float((outs[0] - fused[0]).abs().max()) <= 2e-4 * float(fused[0].abs().max())
+
+
 def test_e2e_cfg1_matches_reference_golden(golden):
     _, outs = _run(cfg1(), 1)
     print(_check(outs, golden("e2e_cfg1")))
