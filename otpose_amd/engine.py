@@ -28,6 +28,10 @@ from .ops import ACT_GELU, ACT_NONE, ACT_RELU, View
 BN_EPS = 1e-5
 
 
+def _pair(v):
+    return (int(v), int(v)) if isinstance(v, int) else (int(v[0]), int(v[1]))
+
+
 class InferenceEngine:
     def __init__(self, model, batch: int, device, use_graph: bool | None = None):
         device = torch.device(device)
@@ -598,7 +602,14 @@ class InferenceEngine:
         dils = [int(d) for d in m.deformable_conv_dilations]
         cin_t = trans.C
         if (self.use_dcn_fused and trans.coff == 0 and trans.C == trans.ctot and ops.dcn_fused_supported(cin_t, J, h, w, nd)
-                and all(c[0].kernel_size == (3, 3) and c[0].bias is None for c in list(m.offsets_list) + list(m.masks_list))):
+                and all(c[0].kernel_size == (3, 3) and c[0].bias is None and c[0].stride == (1, 1)
+                        for c in list(m.offsets_list) + list(m.masks_list))
+                and all(tuple(c[0].padding) == (d, d) == tuple(c[0].dilation)
+                        for cs in (m.offsets_list, m.masks_list) for c, d in zip(cs, dils))
+                and all(tuple(mm.deform_conv.weight.shape) == (J, J, 3, 3) and mm.deform_conv.deformable_groups == J
+                        and mm.deform_conv.groups == 1 and _pair(mm.deform_conv.stride) == (1, 1)
+                        and _pair(mm.deform_conv.padding) == (d, d) == _pair(mm.deform_conv.dilation)
+                        for mm, d in zip(m.modulated_deform_conv_list, dils))):
             # the ten offset / mask convs and the five DCN gathers as ONE launch; the 459
             # offset / mask channels per pixel and dilation never reach HBM (csrc/dcn_fused.hip)
             dcs = [mm.deform_conv for mm in m.modulated_deform_conv_list]
