@@ -119,6 +119,16 @@ int otp_conv2d_wino_last_plan(int* out4);
 int otp_conv2d_wino(const void* in, const void* upacked, const void* scale, const void* shift, const void* res, void* out,
                     const otp_conv_desc* desc, void* stream);
 
+/* 3x3 / stride 1 / pad 1 convolutions with at most 24 input and 24 output channels and an optional pre-added second input
+ * (the RSB staircase convs, model/RSB.py:80-92): one thread per output pixel, exact fp32 FMAs, same scale / shift / ReLU
+ * epilogue and channel-sliced views as otp_conv2d (no residual).  `wpacked`: otp_conv3x3_small_weight_bytes bytes written by
+ * otp_conv3x3_small_pack from the plain (Cout, Cin, 3, 3) tensor ([ci][tap][co] order, read through the scalar cache). */
+int otp_conv3x3_small_supported(const otp_conv_desc* desc);
+size_t otp_conv3x3_small_weight_bytes(int Cout, int Cin);
+int otp_conv3x3_small_pack(const void* weight, void* wpacked, int Cout, int Cin, void* stream);
+int otp_conv3x3_small(const void* in, const void* in2, const void* wpacked, const void* scale, const void* shift, void* out,
+                      const otp_conv_desc* desc, void* stream);
+
 /* fp32 3x3 (stride 1 or 2) and 1x1 (stride 1) convolutions on the bf16 matrix cores with split ("bf16x3") products: every fp32 operand is the sum
  * of two bf16 pieces (hi = rne(a), lo = rne(a - hi)), a product is lo*hi + hi*lo + hi*hi accumulated in fp32 (dropped terms
  * <= 3 * 2^-18 |a b|), storage stays fp32 NCHW.  Same descriptor and fused epilogue (shift, residual, activation,

@@ -60,6 +60,7 @@ class InferenceEngine:
         self.use_x3 = os.environ.get("OTPOSE_CONV_MATH", "x3") != "f32"
         # offset / mask convs + DCN gathers of all dilations in one launch (split-bf16 products for the convs)
         self.use_dcn_fused = self.use_x3 and os.environ.get("OTPOSE_DCN_FUSED", "1") != "0"
+        self.use_small_conv = os.environ.get("OTPOSE_SMALL_CONV", "1") != "0"       # RSB staircase convs via csrc/conv_small.hip
         self.use_fused_mlp = os.environ.get("OTPOSE_FUSED_MLP", "1") != "0"   # transformer MLP via csrc/mlp.hip
         self.fuse_shortcut = os.environ.get("OTPOSE_FUSE_SHORTCUT", "1") != "0"  # layer1 shortcut folded into conv3
         self.fuse_upsample = os.environ.get("OTPOSE_FUSE_UPSAMPLE", "1") != "0"  # a fuse row's upsampled terms in one pass
@@ -186,6 +187,16 @@ class InferenceEngine:
                      else "direct")
             print(f"conv {d.N}x{d.Cin}->{cout} k{kh} s{stride} p{pad} d{dil} {d.H}x{d.W} in2={in2 is not None} "
                   f"res={res is not None} up={res_up} fs={frame_split} {route}", file=sys.stderr)
+        if self.use_small_conv and in2 is not None and res is None and (kh, kw) == (3, 3) and ops.small_conv_supported(d):
+            # RSB staircase convs (a few channels, pre-added second input): one thread per pixel, exact fp32 (csrc/conv_small.hip)
+            wc = ops.pack_small_conv_weight(w)
+            self._keep.append(wc)
+            sargs = (hip.ptr(inp.t), hip.ptr(in2.t), hip.ptr(wc), hip.ptr(sc), hip.ptr(sh), hip.ptr(out.t), d)
+
+            def run_small():
+                hip.check(L.otp_conv3x3_small(*sargs, self._stream), "otp_conv3x3_small")
+            self._emit(run_small)
+            return out
         if self.use_x3 and in2 is None and (kh, kw) in ((3, 3), (1, 1)) and ops.x3_supported(d):
             # 3x3 / stride 1 with Cin % 16 == 0: split-bf16 (bf16x3) products on the bf16 matrix cores, fp32 storage and
             # accumulation (csrc/convx.hip); the per-channel scale is folded into the packed weights

@@ -55,6 +55,10 @@ SIGNATURES = {
     "otp_conv2d_wino_supported": (c_int, [ctypes.POINTER(ConvDesc)]),
     "otp_conv2d_wino_last_plan": (c_int, [ctypes.POINTER(c_int)]),
     "otp_conv2d_wino": (c_int, [c_void_p] * 6 + [ctypes.POINTER(ConvDesc), c_void_p]),
+    "otp_conv3x3_small_supported": (c_int, [ctypes.POINTER(ConvDesc)]),
+    "otp_conv3x3_small_weight_bytes": (c_size_t, [c_int, c_int]),
+    "otp_conv3x3_small_pack": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "otp_conv3x3_small": (c_int, [c_void_p] * 6 + [ctypes.POINTER(ConvDesc), c_void_p]),
     "otp_conv2d_x3_weight_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "otp_conv2d_x3_pack_weight": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "otp_conv2d_x3_supported": (c_int, [ctypes.POINTER(ConvDesc)]),

@@ -319,6 +319,40 @@ def pack_wino_weight(weight):
     return u
 
 
+def small_conv_supported(desc) -> bool:
+    return bool(hip.lib().otp_conv3x3_small_supported(desc))
+
+
+def pack_small_conv_weight(weight):
+    """(Cout, Cin, 3, 3) -> the [ci][tap][co] image :func:`conv3x3_small` reads through the scalar cache."""
+    _require_gpu(weight)
+    w = weight.detach().contiguous().float()
+    cout, cin = w.shape[:2]
+    L = hip.lib()
+    nbytes = L.otp_conv3x3_small_weight_bytes(cout, cin)
+    if not nbytes:
+        raise ValueError(f"otp_conv3x3_small: unsupported channel counts ({cout}, {cin})")
+    wt = torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)
+    hip.check(L.otp_conv3x3_small_pack(hip.ptr(w), hip.ptr(wt), cout, cin, hip.stream_of(w)), "otp_conv3x3_small_pack")
+    return wt
+
+
+def conv3x3_small(x, weight, scale=None, shift=None, act=ACT_NONE, in2=None):
+    """act(scale * conv2d(x (+ in2), weight, 3x3, stride 1, pad 1) + shift) for <= 24 channels (csrc/conv_small.hip)."""
+    _require_gpu(x, weight)
+    _check_f32(x)
+    n, cin, h, w = x.shape
+    cout = weight.shape[0]
+    out = torch.empty(n, cout, h, w, dtype=torch.float32, device=x.device)
+    iv, ov = View(x.contiguous()), View(out)
+    i2 = View(in2.contiguous()) if in2 is not None else None
+    d = conv_desc(iv, ov, cout, 3, 3, 1, 1, 1, act, i2)
+    wt = pack_small_conv_weight(weight)
+    hip.check(hip.lib().otp_conv3x3_small(hip.ptr(iv.t), hip.ptr(i2.t if i2 is not None else None), hip.ptr(wt), hip.ptr(scale),
+                                          hip.ptr(shift), hip.ptr(out), d, hip.stream_of(x)), "otp_conv3x3_small")
+    return out
+
+
 def pack_x3_weight(weight, scale=None, stride=1):
     """(Cout, Cin, k, k) fp32, k = 3 or 1 (times scale[cout]) -> bf16 hi / lo MFMA fragments for :func:`conv2d_x3_launch` (the
     chunking depends on k and the stride)."""

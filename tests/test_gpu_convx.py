@@ -112,3 +112,20 @@ def test_conv2d_x3_rejects_what_it_does_not_cover():
     x = torch.zeros(1, 16, 9, 7).cuda()               # H*W % 4 != 0
     out = torch.zeros(1, 16, 9, 7).cuda()
     assert not ops.x3_supported(ops.conv_desc(ops.View(x), ops.View(out), 16, 3, 3, 1, 1, 1))
+
+
+@pytest.mark.parametrize("case", [(16, 6, 6, 96, 72, True), (3, 13, 13, 24, 20, True), (2, 20, 20, 17, 9, False),
+                                  (1, 24, 5, 8, 8, True), (2, 3, 24, 33, 70, False)],
+                         ids=lambda c: "x".join(str(v) for v in c[:5]))
+def test_conv3x3_small_matches_float64(case):
+    """csrc/conv_small.hip (RSB staircase convs, model/RSB.py:80-92): exact fp32, pre-added second input, ragged tiles."""
+    n, ci, co, h, w, with_in2 = case
+    g = torch.Generator(device="cpu").manual_seed(sum(case[:5]))
+    x = torch.randn(n, ci, h, w, generator=g).cuda()
+    x2 = torch.randn(n, ci, h, w, generator=g).cuda() if with_in2 else None
+    wt = (torch.randn(co, ci, 3, 3, generator=g) * (2.0 / (ci * 9)) ** 0.5).cuda()
+    sc, sh = (torch.rand(co, generator=g) + 0.5).cuda(), torch.randn(co, generator=g).cuda()
+    xin = x.double() + (x2.double() if with_in2 else 0.0)
+    ref = torch.relu(F.conv2d(xin, wt.double(), None, 1, 1) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1))
+    y = ops.conv3x3_small(x, wt, sc, sh, ops.ACT_RELU, x2)
+    assert float((y.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
