@@ -129,3 +129,23 @@ def test_conv3x3_small_matches_float64(case):
     ref = torch.relu(F.conv2d(xin, wt.double(), None, 1, 1) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1))
     y = ops.conv3x3_small(x, wt, sc, sh, ops.ACT_RELU, x2)
     assert float((y.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+
+
+def test_conv2d_x3_full_size_properties():
+    """BASELINE configs[1] size (80 frames, 48 ch, 96x72): size-independent checks instead of a float64 reference.
+    (a) a delta kernel reproduces its input channel up to the split's remainder (2^-18 relative); (b) linearity in the
+    weights; (c) batch slices are independent (frame 17 alone == frame 17 inside the batch, bit for bit)."""
+    g = torch.Generator(device="cpu").manual_seed(123)
+    x = torch.randn(80, 48, 96, 72, generator=g).cuda()
+    delta = torch.zeros(48, 48, 3, 3).cuda()
+    for c in range(48):
+        delta[c, (c * 7) % 48, 1, 1] = 1.0
+    y = ops.conv2d_x3(x, delta)
+    perm = [(c * 7) % 48 for c in range(48)]
+    assert float((y - x[:, perm]).abs().max()) <= 2.0 ** -17 * float(x.abs().max())
+    w1 = (torch.randn(48, 48, 3, 3, generator=g) * 0.05).cuda()
+    w2 = (torch.randn(48, 48, 3, 3, generator=g) * 0.05).cuda()
+    y1, y2, y12 = ops.conv2d_x3(x, w1), ops.conv2d_x3(x, w2), ops.conv2d_x3(x, w1 + w2)
+    assert float((y12 - (y1 + y2)).abs().max()) <= 3e-5 * float(y12.abs().max())
+    solo = ops.conv2d_x3(x[17:18].contiguous(), w1)
+    assert torch.equal(solo, y1[17:18])

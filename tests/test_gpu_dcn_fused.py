@@ -74,3 +74,20 @@ def test_dcn_fused_without_bias_and_unsupported_shapes():
     assert float((out.cpu().double() - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
     assert not ops.dcn_fused_supported(32, J, 9, 7, 1)       # H * W % 128 != 0
     assert not ops.dcn_fused_supported(24, J, 8, 16, 1)      # other channel counts of `trans`
+
+
+def test_dcn_fused_full_size_batch_slices_are_independent():
+    """BASELINE configs[1] size (16 clips, 96x72, five dilations): clip 5 alone gives bit-identical heat-maps to clip 5
+    inside the batch, and zero offset / mask weights reduce the head to the DCN biases."""
+    b, h, w, dils = 16, 96, 72, (3, 6, 9, 12, 15)
+    trans, x, w_off, w_msk, w_dcn, bias = _case(b, h, w, dils, 21, 1.0)
+    cu = lambda ts: [t.cuda() for t in ts]      # noqa: E731
+    packed = ops.pack_dcn_fused(cu(w_off), cu(w_msk), cu(w_dcn), cu(bias))
+    full = ops.dcn_fused(trans.cuda(), x.cuda(), packed, dils, 0.2)
+    solo = ops.dcn_fused(trans[5:6].cuda().contiguous(), x[5:6].cuda().contiguous(), packed, dils, 0.2)
+    assert torch.equal(solo, full[5:6])
+    zeros = [torch.zeros_like(t) for t in w_msk]
+    packed0 = ops.pack_dcn_fused(cu(w_off), cu(zeros), cu(w_dcn), cu(bias))
+    out0 = ops.dcn_fused(trans.cuda(), x.cuda(), packed0, dils, 0.2)
+    expect = (sum(bias) * 0.2).cuda().view(1, J, 1, 1).expand_as(out0)
+    assert float((out0 - expect).abs().max()) <= 1e-6
