@@ -315,6 +315,9 @@ int otp_upsample_add_multi(const void* const* lows, const int* factors, int nlow
  * Channel attention backward is assembled on the host side from these (otpose_amd/train_ops.py): with O^T = the
  * transposed-contiguous image otp_chan_attn writes, dO = transpose(d_out), dP = dO v^T (scores + slab sum),
  * dS = softmax'(P, dP), dq = scale * dS k, dk = scale * dS^T q, dv = P^T dO (three otp_chan_attn_apply + transposes). */
+/* Arithmetic of the q.k^T score products of otp_chan_attn / otp_chan_attn_scores: 1 (default) = split-bf16 products on the
+ * bf16 matrix cores (fp32 accumulation, see otp_conv2d_x3), 0 = the f32 MFMA kernel.  Process-wide switch. */
+int otp_chan_attn_set_split(int on);
 int otp_chan_attn_splits(int BH, int T);
 int otp_chan_attn_scores(const void* a, const void* b, void* slabs, int BH, int hs, int T, void* stream);
 int otp_chan_attn_apply(const void* v, const void* M, void* out, int BH, int hs, int T, void* stream);

@@ -276,6 +276,121 @@ __global__ __launch_bounds__(256) void attn_scores_kernel(const float* __restric
     }
 }
 
+// Phase 1 with split-bf16 products: the same partial scores on v_mfma_f32_16x16x32_bf16.  The staged
+// q / k tiles are split once into bf16 hi / lo images [row][64 tokens] (row pitch 144 B: an odd multiple of 16 B, so the 16
+// rows of a fragment read hit 16 distinct bank groups); a fragment is one ds_read_b128 (8 consecutive tokens of a row), a
+// 16 x 16 score tile takes 3 MFMAs per 32 tokens instead of 8 f32 ones at twice the cycles.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 sx_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 sx_bf16x2 __attribute__((ext_vector_type(2)));
+constexpr int SX_PITCH = ATT_TC * 2 + 16;          // bytes per LDS row
+
+template <int NB>
+__global__ __launch_bounds__(256) void attn_scores_x3_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                              float* __restrict__ slabs, int hs, int T, int chunk) {
+    constexpr int HSP = NB * 16, NT = NB * NB, TPW = (NT + 3) / 4;
+    constexpr int NQ = (HSP * (ATT_TC / 4) + 255) / 256;
+    __shared__ __attribute__((aligned(16))) unsigned char qh[HSP * SX_PITCH], ql[HSP * SX_PITCH];
+    __shared__ __attribute__((aligned(16))) unsigned char kh[HSP * SX_PITCH], kl_[HSP * SX_PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bh = blockIdx.x, s = blockIdx.y;
+    const float* qb = q + (size_t)bh * hs * T;
+    const float* kb = k + (size_t)bh * hs * T;
+    const int t_begin = s * chunk, t_end = min(T, t_begin + chunk);
+    f32x4 acc[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int r16 = lane & 15, kk = lane >> 4;
+    const bool vec = (T & 3) == 0 && ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k)) & 15) == 0;
+    f32x4 pq[NQ], pk[NQ];
+    auto load_tile = [&](int t0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const int idx = tid + j * 256;
+            const int row = idx / (ATT_TC / 4), t = t0 + 4 * (idx - row * (ATT_TC / 4));
+            f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+            if (row < hs && idx < HSP * (ATT_TC / 4)) {
+                const float* qp = qb + (size_t)row * T + t;
+                const float* kp = kb + (size_t)row * T + t;
+                if (vec && t + 3 < t_end) {
+                    a = *reinterpret_cast<const f32x4*>(qp);
+                    b = *reinterpret_cast<const f32x4*>(kp);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (t + e < t_end) { a[e] = qp[e]; b[e] = kp[e]; }
+                }
+            }
+            pq[j] = a;
+            pk[j] = b;
+        }
+    };
+    auto split4 = [](f32x4 v, unsigned long long& hi, unsigned long long& lo) __attribute__((always_inline)) {
+        uint32_t h[2], l[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const f32x2 a = {v[2 * i], v[2 * i + 1]};
+            const uint32_t hb = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, sx_bf16x2));
+            const f32x2 af = {__builtin_bit_cast(float, hb << 16), __builtin_bit_cast(float, hb & 0xffff0000u)};
+            h[i] = hb;
+            l[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(a - af, sx_bf16x2));
+        }
+        hi = (unsigned long long)h[0] | ((unsigned long long)h[1] << 32);
+        lo = (unsigned long long)l[0] | ((unsigned long long)l[1] << 32);
+    };
+    auto store_tile = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const int idx = tid + j * 256;
+            if (idx < HSP * (ATT_TC / 4)) {
+                const int row = idx / (ATT_TC / 4), tt = 4 * (idx - row * (ATT_TC / 4));
+                unsigned long long h, l;
+                split4(pq[j], h, l);
+                *reinterpret_cast<unsigned long long*>(qh + row * SX_PITCH + tt * 2) = h;
+                *reinterpret_cast<unsigned long long*>(ql + row * SX_PITCH + tt * 2) = l;
+                split4(pk[j], h, l);
+                *reinterpret_cast<unsigned long long*>(kh + row * SX_PITCH + tt * 2) = h;
+                *reinterpret_cast<unsigned long long*>(kl_ + row * SX_PITCH + tt * 2) = l;
+            }
+        }
+    };
+    load_tile(t_begin);
+    for (int t0 = t_begin; t0 < t_end; t0 += ATT_TC) {
+        __syncthreads();                                       // previous tile fully read
+        store_tile();
+        __syncthreads();
+        if (t0 + ATT_TC < t_end) load_tile(t0 + ATT_TC);
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int tile = wave + 4 * i;
+            if (tile < NT) {
+                const int ib = tile / NB, jb = tile - ib * NB;
+                const int qo = (ib * 16 + r16) * SX_PITCH + kk * 16, ko = (jb * 16 + r16) * SX_PITCH + kk * 16;
+#pragma unroll
+                for (int ks = 0; ks < ATT_TC / 32; ++ks) {
+                    const sx_bf16x8 a_h = *reinterpret_cast<const sx_bf16x8*>(qh + qo + ks * 64);
+                    const sx_bf16x8 a_l = *reinterpret_cast<const sx_bf16x8*>(ql + qo + ks * 64);
+                    const sx_bf16x8 b_h = *reinterpret_cast<const sx_bf16x8*>(kh + ko + ks * 64);
+                    const sx_bf16x8 b_l = *reinterpret_cast<const sx_bf16x8*>(kl_ + ko + ks * 64);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_l, b_h, acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h, b_l, acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h, b_h, acc[i], 0, 0, 0);
+                }
+            }
+        }
+    }
+    float* slab = slabs + ((size_t)bh * gridDim.y + s) * HSP * HSP;
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int tile = wave + 4 * i;
+        if (tile < NT) {
+            const int ib = tile / NB, jb = tile - ib * NB;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) slab[(ib * 16 + kk * 4 + r) * HSP + jb * 16 + r16] = acc[i][r];
+        }
+    }
+}
+
 // Phase 2: sum the slabs, scale, row softmax (one wave per row, shuffles for max / sum).
 // P (B*nh, HSP, HSP) with zero padding columns.  grid (B*nh, ceil(HSP / 4)): every wave of the chip gets a row
 // (a grid of B*nh workgroups alone left 7/8 of the CUs idle for 120 us).
@@ -479,6 +594,7 @@ extern "C" int otp_dwconv_ln3(const void* x, const void* dwq, const void* dwk, c
 }
 
 namespace {
+std::atomic<int> g_attn_split{1};       // 1: score products as split bf16 (default), 0: f32 MFMA (otp_chan_attn_set_split)
 int attn_splits(int BH, int T) {
     int ns = 1;
     while (BH * ns < 768 && T / (ns * 2) >= 2 * ATT_TC) ns *= 2;
@@ -514,7 +630,14 @@ extern "C" int otp_chan_attn(const void* q, const void* k, const void* v, void* 
     dim3 g1(BH, NS), g3(BH, otp_ceil_div(T, TT));
 #define OTP_ATT(NB_)                                                                                           \
     {                                                                                                          \
-        hipLaunchKernelGGL(attn_scores_kernel<NB_>, g1, dim3(256), 0, st, qf, kf, slabs, hs, T, chunk);        \
+        bool split_ = false;                                                                                   \
+        if constexpr (NB_ <= 5) {                                                                              \
+            if (g_attn_split.load(std::memory_order_relaxed)) {                                                \
+                split_ = true;                                                                                 \
+                hipLaunchKernelGGL(attn_scores_x3_kernel<NB_>, g1, dim3(256), 0, st, qf, kf, slabs, hs, T, chunk); \
+            }                                                                                                  \
+        }                                                                                                      \
+        if (!split_) hipLaunchKernelGGL(attn_scores_kernel<NB_>, g1, dim3(256), 0, st, qf, kf, slabs, hs, T, chunk); \
         hipLaunchKernelGGL(attn_softmax_kernel, dim3(BH, otp_ceil_div(HSP, 4)), dim3(256), 0, st, slabs, P, hs, HSP, NS, scale);      \
         auto kern = attn_pv_kernel<NB_>;                                                                       \
         OTP_ALLOW_BIG_LDS(kern, pv_lds);                                                                       \
@@ -535,6 +658,12 @@ extern "C" int otp_chan_attn(const void* q, const void* k, const void* v, void* 
 
 // ---- pieces of the channel attention exposed for its backward (otpose_amd/train_ops.py) -------------------------
 // number of T-splits / score slabs the kernels use for (BH, T), and where otp_chan_attn leaves P inside its workspace
+// 1 (default): q.k^T products as split bf16 on the bf16 matrix cores; 0: the f32 MFMA kernel.  Process-wide.
+extern "C" int otp_chan_attn_set_split(int on) {
+    g_attn_split.store(on ? 1 : 0, std::memory_order_relaxed);
+    return OTP_OK;
+}
+
 extern "C" int otp_chan_attn_splits(int BH, int T) { return (BH > 0 && T > 0) ? attn_splits(BH, T) : 0; }
 
 // slabs[bh][s] (HSP x HSP, zero padded) = partial a . b^T over the s-th slice of T, no scale: sum the slabs for a . b^T
@@ -549,7 +678,17 @@ extern "C" int otp_chan_attn_scores(const void* a, const void* b, void* slabs, i
     auto af = static_cast<const float*>(a);
     auto bf = static_cast<const float*>(b);
     auto sf = static_cast<float*>(slabs);
-#define OTP_SC(NB_) hipLaunchKernelGGL(attn_scores_kernel<NB_>, g1, dim3(256), 0, st, af, bf, sf, hs, T, chunk);
+#define OTP_SC(NB_)                                                                                       \
+    {                                                                                                     \
+        bool split_ = false;                                                                              \
+        if constexpr (NB_ <= 5) {                                                                         \
+            if (g_attn_split.load(std::memory_order_relaxed)) {                                           \
+                split_ = true;                                                                            \
+                hipLaunchKernelGGL(attn_scores_x3_kernel<NB_>, g1, dim3(256), 0, st, af, bf, sf, hs, T, chunk); \
+            }                                                                                             \
+        }                                                                                                 \
+        if (!split_) hipLaunchKernelGGL(attn_scores_kernel<NB_>, g1, dim3(256), 0, st, af, bf, sf, hs, T, chunk); \
+    }
     switch (NB) {
         case 1: OTP_SC(1) break;
         case 2: OTP_SC(2) break;

@@ -116,6 +116,7 @@ SIGNATURES = {
     "otp_chan_attn": (c_int, [c_void_p] * 4 + [c_void_p, c_size_t] + [c_int] * 4 + [c_float, c_void_p]),
     "otp_chan_attn_splits": (c_int, [c_int, c_int]),
     "otp_chan_attn_scores": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p]),
+    "otp_chan_attn_set_split": (c_int, [c_int]),
     "otp_chan_attn_apply": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p]),
     "otp_transpose_scale": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "otp_softmax_backward": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_void_p]),
@@ -178,6 +179,8 @@ def lib():
             fn = getattr(cdll, name)
             fn.restype = res
             fn.argtypes = args
+        # one arithmetic switch for the whole library: OTPOSE_CONV_MATH=f32 keeps every product on the f32 MFMA
+        cdll.otp_chan_attn_set_split(0 if os.environ.get("OTPOSE_CONV_MATH", "x3") == "f32" else 1)
         _lib = _DeviceGuarded(cdll)
     return _lib
 
