@@ -529,6 +529,145 @@ __global__ __launch_bounds__(256) void attn_pv_kernel(const float* __restrict__ 
         }
 }
 
+// Phase 3 with split-bf16 products: O^T[t, i] = sum_j v[j, t] P[i, j] on v_mfma_f32_16x16x32_bf16 (M = 128 tokens per
+// workgroup, N = i, K = j).  Both operands want 8 consecutive j per lane: P rows have them; the v tile is transposed while it
+// is staged (a thread loads 8 rows j x 4 tokens and writes four per-token records of 8 j each, hi and lo), like the window
+// staging of csrc/convx.hip.  Records: [HSP j hi | HSP j lo | 16 B pad] (an odd multiple of 16 bytes).
+constexpr int PVX_TT = 128;
+template <int NB>
+__global__ __launch_bounds__(256) void attn_pv_x3_kernel(const float* __restrict__ v, const float* __restrict__ P,
+                                                          float* __restrict__ out, int hs, int T) {
+    constexpr int HSP = NB * 16, KS = (HSP + 31) / 32, G = HSP / 8;
+    constexpr int REC = HSP * 4 + 16;                              // bytes of a token (v) / row (P) record
+    constexpr int NVI = (G * (PVX_TT / 4) + 255) / 256;            // v items (8 rows x 4 tokens) per thread
+    constexpr int NP4 = (HSP * HSP / 4 + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char pvs[];
+    unsigned char* vrec = pvs;                                     // [PVX_TT][REC]
+    unsigned char* prec = pvs + PVX_TT * REC;                      // [HSP][REC]
+    unsigned char* zrec = prec + HSP * REC;                        // 16 zero bytes
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bh = blockIdx.x, t0 = blockIdx.y * PVX_TT;
+    const float* vb = v + (size_t)bh * hs * T;
+    const float* pb = P + (size_t)bh * HSP * HSP;
+    auto split4 = [](f32x4 x, unsigned long long& hi, unsigned long long& lo) __attribute__((always_inline)) {
+        uint32_t h[2], l[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const f32x2 a = {x[2 * i], x[2 * i + 1]};
+            const uint32_t hb = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, sx_bf16x2));
+            const f32x2 af = {__builtin_bit_cast(float, hb << 16), __builtin_bit_cast(float, hb & 0xffff0000u)};
+            h[i] = hb;
+            l[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(a - af, sx_bf16x2));
+        }
+        hi = (unsigned long long)h[0] | ((unsigned long long)h[1] << 32);
+        lo = (unsigned long long)l[0] | ((unsigned long long)l[1] << 32);
+    };
+    if (tid < 4) reinterpret_cast<uint32_t*>(zrec)[tid] = 0u;
+    // P (HSP x HSP fp32, zero padded) -> rows of bf16 hi / lo
+    {
+        f32x4 rp[NP4];
+#pragma unroll
+        for (int j = 0; j < NP4; ++j) {
+            const int idx = tid + j * 256;
+            rp[j] = idx < HSP * HSP / 4 ? reinterpret_cast<const f32x4*>(pb)[idx] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < NP4; ++j) {
+            const int idx = tid + j * 256;
+            if (idx < HSP * HSP / 4) {
+                const int i = (4 * idx) / HSP, jj = 4 * idx - i * HSP;
+                unsigned long long h, l;
+                split4(rp[j], h, l);
+                *reinterpret_cast<unsigned long long*>(prec + i * REC + jj * 2) = h;
+                *reinterpret_cast<unsigned long long*>(prec + i * REC + HSP * 2 + jj * 2) = l;
+            }
+        }
+    }
+    // v tile, transposed: item = (8-row group g, 4 tokens)
+    const bool vecv = (T & 3) == 0 && (reinterpret_cast<uintptr_t>(v) & 15) == 0;
+#pragma unroll
+    for (int it = 0; it < NVI; ++it) {
+        const int idx = tid + it * 256;
+        const int g = idx / (PVX_TT / 4), f4 = idx - g * (PVX_TT / 4);
+        const int t = t0 + 4 * f4;
+        f32x4 x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int row = 8 * g + e;
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            if (idx < G * (PVX_TT / 4) && row < hs) {
+                const float* vp = vb + (size_t)row * T + t;
+                if (vecv && t + 3 < T) {
+                    a = *reinterpret_cast<const f32x4*>(vp);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (t + c < T) a[c] = vp[c];
+                }
+            }
+            x[e] = a;
+        }
+        if (idx < G * (PVX_TT / 4)) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                unsigned long long h0, l0, h1, l1;
+                split4((f32x4){x[0][c], x[1][c], x[2][c], x[3][c]}, h0, l0);
+                split4((f32x4){x[4][c], x[5][c], x[6][c], x[7][c]}, h1, l1);
+                unsigned char* r = vrec + (4 * f4 + c) * REC + g * 16;
+                *reinterpret_cast<unsigned long long*>(r) = h0;
+                *reinterpret_cast<unsigned long long*>(r + 8) = h1;
+                *reinterpret_cast<unsigned long long*>(r + HSP * 2) = l0;
+                *reinterpret_cast<unsigned long long*>(r + HSP * 2 + 8) = l1;
+            }
+        }
+    }
+    __syncthreads();
+    const int r16 = lane & 15, kk = lane >> 4;
+    f32x4 acc[2][NB];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NB; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int kg = 4 * ks + kk;                                // 8-wide j group of this lane
+        const bool kv = kg < G;
+        sx_bf16x8 ah[2], al[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const unsigned char* a = kv ? vrec + ((wave * 2 + mt) * 16 + r16) * REC + kg * 16 : zrec;
+            ah[mt] = *reinterpret_cast<const sx_bf16x8*>(a);
+            al[mt] = *reinterpret_cast<const sx_bf16x8*>(kv ? a + HSP * 2 : zrec);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NB; ++nt) {
+            const unsigned char* b = kv ? prec + (nt * 16 + r16) * REC + kg * 16 : zrec;
+            const sx_bf16x8 b_h = *reinterpret_cast<const sx_bf16x8*>(b);
+            const sx_bf16x8 b_l = *reinterpret_cast<const sx_bf16x8*>(kv ? b + HSP * 2 : zrec);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], b_h, acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], b_l, acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], b_h, acc[mt][nt], 0, 0, 0);
+            }
+        }
+    }
+    float* ob = out + (size_t)bh * T * hs;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int t = t0 + (wave * 2 + mt) * 16 + kk * 4 + r;
+            if (t < T) {
+#pragma unroll
+                for (int nt = 0; nt < NB; ++nt) {
+                    const int i = nt * 16 + r16;
+                    if (i < hs) ob[(size_t)t * hs + i] = acc[mt][nt][r];
+                }
+            }
+        }
+}
+
 // ---- nn.Upsample(scale_factor = f, mode = 'linear', align_corners = False) on (B, C, T) ------------
 __global__ void upsample_linear_kernel(const float* __restrict__ x, float* __restrict__ out, int C, int T, int f,
                                        int out_ctot, int out_coff) {
@@ -639,9 +778,16 @@ extern "C" int otp_chan_attn(const void* q, const void* k, const void* v, void* 
         }                                                                                                      \
         if (!split_) hipLaunchKernelGGL(attn_scores_kernel<NB_>, g1, dim3(256), 0, st, qf, kf, slabs, hs, T, chunk); \
         hipLaunchKernelGGL(attn_softmax_kernel, dim3(BH, otp_ceil_div(HSP, 4)), dim3(256), 0, st, slabs, P, hs, HSP, NS, scale);      \
-        auto kern = attn_pv_kernel<NB_>;                                                                       \
-        OTP_ALLOW_BIG_LDS(kern, pv_lds);                                                                       \
-        hipLaunchKernelGGL(kern, g3, dim3(256), pv_lds, st, vf, P, of, hs, T);                                 \
+        if (split_) {                                                                                          \
+            auto kx = attn_pv_x3_kernel<NB_>;                                                                  \
+            const size_t lx = (size_t)(PVX_TT + HSP) * (HSP * 4 + 16) + 16;                                    \
+            OTP_ALLOW_BIG_LDS(kx, lx);                                                                         \
+            hipLaunchKernelGGL(kx, dim3(BH, otp_ceil_div(T, PVX_TT)), dim3(256), lx, st, vf, P, of, hs, T);    \
+        } else {                                                                                               \
+            auto kern = attn_pv_kernel<NB_>;                                                                   \
+            OTP_ALLOW_BIG_LDS(kern, pv_lds);                                                                   \
+            hipLaunchKernelGGL(kern, g3, dim3(256), pv_lds, st, vf, P, of, hs, T);                             \
+        }                                                                                                      \
     }
     switch (NB) {
         case 1: OTP_ATT(1) break;
@@ -714,11 +860,23 @@ extern "C" int otp_chan_attn_apply(const void* v, const void* M, void* out, int 
     auto vf = static_cast<const float*>(v);
     auto mf = static_cast<const float*>(M);
     auto of = static_cast<float*>(out);
-#define OTP_APPLY(NB_)                                                          \
-    {                                                                           \
-        auto kern = attn_pv_kernel<NB_>;                                        \
-        OTP_ALLOW_BIG_LDS(kern, pv_lds);                                        \
-        hipLaunchKernelGGL(kern, g3, dim3(256), pv_lds, st, vf, mf, of, hs, T); \
+#define OTP_APPLY(NB_)                                                                                      \
+    {                                                                                                       \
+        bool split_ = false;                                                                                \
+        if constexpr (NB_ <= 5) {                                                                           \
+            if (g_attn_split.load(std::memory_order_relaxed)) {                                             \
+                split_ = true;                                                                              \
+                auto kx = attn_pv_x3_kernel<NB_>;                                                           \
+                const size_t lx = (size_t)(PVX_TT + HSP) * (HSP * 4 + 16) + 16;                             \
+                OTP_ALLOW_BIG_LDS(kx, lx);                                                                  \
+                hipLaunchKernelGGL(kx, dim3(BH, otp_ceil_div(T, PVX_TT)), dim3(256), lx, st, vf, mf, of, hs, T); \
+            }                                                                                               \
+        }                                                                                                   \
+        if (!split_) {                                                                                      \
+            auto kern = attn_pv_kernel<NB_>;                                                                \
+            OTP_ALLOW_BIG_LDS(kern, pv_lds);                                                                \
+            hipLaunchKernelGGL(kern, g3, dim3(256), pv_lds, st, vf, mf, of, hs, T);                         \
+        }                                                                                                   \
     }
     switch (NB) {
         case 1: OTP_APPLY(1) break;
