@@ -194,9 +194,9 @@ __global__ __launch_bounds__(256, 2) void qkvx_front_kernel(const float* __restr
         reinterpret_cast<f32x4*>(tab)[i] = reinterpret_cast<const f32x4*>(table)[i];
     __syncthreads();
 
-#pragma unroll 1
-    for (int p = 0; p < 3; ++p) {
-        dx_stage<BLKB>(A.packed[p], lds);             // (every wave is past the last block of the previous problem)
+    // one problem (q, k or v) per workgroup: blockIdx.y (three times the workgroups, a third of the serial work each)
+    for (int p = (int)blockIdx.y; p <= (int)blockIdx.y; ++p) {
+        dx_stage<BLKB>(A.packed[p], lds);
         const float* tp = tab + p * C * 8;
         // depthwise k = 3 over the wave's token pair and its two neighbours (re-read per problem: L1 / L2 hits), per channel
         float X0[KS][8], X1[KS][8];
@@ -308,7 +308,7 @@ extern "C" int otp_qkv_front_x3(const void* x, const void* table, const void* pa
     a.packed[2] = static_cast<const unsigned char*>(packed_v);
     a.out[0] = static_cast<float*>(q); a.out[1] = static_cast<float*>(k); a.out[2] = static_cast<float*>(v);
     const int tiles = otp_ceil_div(T, 128);
-    hipLaunchKernelGGL(qkvx_front_kernel<136>, dim3((unsigned)(B * tiles)), dim3(256), 0, static_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL(qkvx_front_kernel<136>, dim3((unsigned)(B * tiles), 3u), dim3(256), 0, static_cast<hipStream_t>(stream),
                        static_cast<const float*>(x), static_cast<const float*>(table), a, T, tiles, eps);
     return otp_launch_status();
 }
