@@ -429,6 +429,7 @@ def main():
     math = os.environ.get("OTPOSE_CONV_MATH", "x3")
     if world == 1 and math != "f32" and not a.no_exact_fp32:
         os.environ["OTPOSE_CONV_MATH"] = "f32"
+        hip.lib().otp_chan_attn_set_split(0)                    # the library-wide switch is read once at load time
         try:
             model.invalidate_engine()
             with torch.no_grad():
@@ -441,10 +442,12 @@ def main():
                 torch.cuda.synchronize(dev)
                 de = time.perf_counter() - t1
             exact = {"frames_per_s": 5 * a.batch * a.steps / de, "ms_per_step": 1e3 * de / a.steps,
-                     "kernels": "f32 MFMA: Winograd F(2x2,3x3) / direct convs, csrc/mlp.hip, csrc/dense.hip, unfused warping head",
+                     "kernels": "f32 MFMA: Winograd F(2x2,3x3) / direct convs, csrc/mlp.hip, csrc/dense.hip, f32 attention products, "
+                                "unfused warping head",
                      "parity": golden_parity(model, cfg, dev)}
         finally:
             os.environ["OTPOSE_CONV_MATH"] = math
+            hip.lib().otp_chan_attn_set_split(1)
             model.invalidate_engine()
     train = None
     if not a.no_train_step:
