@@ -29,6 +29,11 @@ CASES = [
     (5, 192, 384, 24, 18, 1, 1, 2, True, True),
     (2, 64, 64, 64, 48, 1, 1, 2, False, True),
     (2, 24, 40, 20, 12, 1, 1, 2, True, False),       # Cin % 8 == 0 only (stride-2 chunking)
+    # launches of a few hundred workgroups (XCD-interleaved tile ranges with ragged ends)
+    (80, 384, 384, 12, 9, 1, 1, 1, True, True),
+    (40, 192, 192, 24, 18, 1, 1, 1, True, False),
+    (20, 48, 96, 48, 36, 1, 1, 1, False, True),
+    (16, 48, 48, 96, 72, 1, 1, 1, True, True),
 ]
 
 
@@ -59,6 +64,7 @@ POINTWISE = [  # (N, Cin, Cout, H, W, residual, relu)
     (3, 96, 48, 48, 36, False, False),      # fuse-layer 1x1 on a low-resolution branch
     (7, 384, 96, 12, 9, False, False),      # several images per tile, odd width
     (2, 32, 17, 10, 6, True, False),        # Cout not a multiple of 16, one partial tile
+    (40, 192, 192, 24, 18, True, True),
 ]
 
 
