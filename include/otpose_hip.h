@@ -433,6 +433,13 @@ int otp_nhwc_conv_plan(const otp_nhwc_conv_desc* desc, int* out8);
  * the FORWARD conv and the packed operator is its input gradient (channels transposed, taps flipped; the caller sets
  * desc->pad = dil*(k-1) - pad and feeds a zero-inserted gradient for stride > 1, otp_nhwc_dilate). */
 int otp_nhwc_conv_pack(const void* weight, void* wpacked, const otp_nhwc_conv_desc* desc, int dgrad, void* stream);
+/* The same re-layouts batched: a training step repacks every fp32 master weight twice (forward operator + input-gradient
+ * operator, ~670 launches of a few microseconds at cfg2).  otp_nhwc_conv_pack_job writes the otp_nhwc_conv_pack_job_bytes()
+ * bytes of one job (pointers, strides, launch plan; opaque to the caller) to HOST memory; the caller keeps the jobs of a step
+ * as one contiguous table in device memory and otp_nhwc_conv_pack_batch(table, n) performs all of them in one launch. */
+size_t otp_nhwc_conv_pack_job_bytes(void);
+int otp_nhwc_conv_pack_job(const void* weight, void* wpacked, const otp_nhwc_conv_desc* desc, int dgrad, void* job_host);
+int otp_nhwc_conv_pack_batch(const void* jobs_device, int n_jobs, void* stream);
 /* out = conv(x) (+ bias, fp32 (Cout), may be NULL); stats may be NULL */
 int otp_nhwc_conv_bf16(const void* x, const void* wpacked, const void* bias, void* out, void* stats,
                        const otp_nhwc_conv_desc* desc, void* stream);

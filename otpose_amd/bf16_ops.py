@@ -65,7 +65,9 @@ def to_nchw(x: torch.Tensor, c: int) -> torch.Tensor:
     return out
 
 
-def _pack(weight, d, dgrad):
+def _pack(weight, d, dgrad, packs=None):
+    if packs is not None:
+        return packs.get(weight, d, dgrad)
     L = hip.lib()
     nbytes = L.otp_nhwc_conv_weight_bytes(ctypes.byref(d))
     if nbytes == 0:
@@ -76,14 +78,82 @@ def _pack(weight, d, dgrad):
     return wp
 
 
-def conv_forward(x, weight, bias=None, stride=1, pad=0, dil=1, out_mode=0, want_stats=True):
+class PackCache:
+    """The packed bf16 operators (forward and input-gradient form) of one model's convolution weights, refreshed by ONE launch
+    per training step instead of one per use (~670 launches of a few microseconds at cfg2, and as many allocations on the
+    host, which bounds the forward once the branches overlap on the device).
+
+    The first step packs every operator where it is first needed and records a job for it (weight pointer, destination,
+    launch plan - ``otp_nhwc_conv_pack_job``); from then on :meth:`repack` at the start of a forward rewrites all
+    destinations from the current fp32 master weights (``otp_nhwc_conv_pack_batch``) and the uses only look their tensor
+    up.  The input-gradient operators are therefore those of the weights the forward saw.  Entries keep the weight storage
+    alive, so a job never reads freed memory; a weight that moved (``model.to(...)``) gets new entries."""
+
+    LIMIT = 8192                              # entries; past it the table is rebuilt from scratch
+
+    def __init__(self):
+        self.entries = {}                     # (data_ptr, dgrad, desc bytes) -> (packed tensor, storage keep-alive)
+        self.jobs = bytearray()
+        self.table = None
+        self.dirty = False
+
+    def __len__(self):
+        return len(self.entries)
+
+    def __deepcopy__(self, memo):             # jobs hold raw pointers: a copied / unpickled model starts with an empty table
+        return PackCache()
+
+    def __reduce__(self):
+        return (PackCache, ())
+
+    def clear(self):
+        self.__init__()
+
+    def get(self, weight, d, dgrad):
+        key = (weight.data_ptr(), int(dgrad), bytes(d))
+        e = self.entries.get(key)
+        if e is not None:
+            return e[0]
+        if len(self.entries) >= self.LIMIT:
+            self.clear()
+        wp = _pack(weight, d, dgrad)
+        L = hip.lib()
+        job = ctypes.create_string_buffer(L.otp_nhwc_conv_pack_job_bytes())
+        hip.check(L.otp_nhwc_conv_pack_job(hip.ptr(weight), hip.ptr(wp), ctypes.byref(d), int(dgrad), job),
+                  "otp_nhwc_conv_pack_job")
+        self.jobs += job.raw
+        self.entries[key] = (wp, weight.detach())
+        self.dirty = True
+        return wp
+
+    def repack(self, device):
+        """All recorded operators from the current weights, on the current stream of ``device``."""
+        if not self.entries:
+            return
+        if self.dirty or self.table is None or self.table.device != device:
+            self.table = torch.frombuffer(bytearray(self.jobs), dtype=torch.uint8).to(device)
+            self.dirty = False
+        hip.check(hip.lib().otp_nhwc_conv_pack_batch(hip.ptr(self.table), len(self.entries), hip.stream_of(self.table)),
+                  "otp_nhwc_conv_pack_batch")
+
+
+_ACTIVE_PACKS = None          # the PackCache of the training forward being built (train.TrainGraphBF16.forward), else None
+
+
+def set_active_packs(cache):
+    global _ACTIVE_PACKS
+    prev, _ACTIVE_PACKS = _ACTIVE_PACKS, cache
+    return prev
+
+
+def conv_forward(x, weight, bias=None, stride=1, pad=0, dil=1, out_mode=0, want_stats=True, packs=None):
     """x (N, H, W, CinS) bf16, weight (Cout, Cin, kh, kw) fp32.  Returns (out, stats, rows): ``out`` NHWC bf16 (out_mode 0)
     or NCHW fp32 (out_mode 1); ``stats`` = per-tile [rows][2][CoutS] fp32 sums / sums of squares (out_mode 0 only)."""
     cout, cin, kh, kw = weight.shape
     n, h, w, cins = x.shape
     assert cins == cs(cin) and x.dtype == BF16 and x.is_contiguous()
     d = _desc(n, h, w, cin, cout, kh, kw, stride, pad, dil, out_mode)
-    wp = _pack(weight.contiguous(), d, 0)
+    wp = _pack(weight.contiguous(), d, 0, packs)
     ho = (h + 2 * pad - dil * (kh - 1) - 1) // stride + 1
     wo = (w + 2 * pad - dil * (kw - 1) - 1) // stride + 1
     L = hip.lib()
@@ -100,7 +170,7 @@ def conv_forward(x, weight, bias=None, stride=1, pad=0, dil=1, out_mode=0, want_
     return out, stats, rows
 
 
-def conv_dgrad(gy, weight, in_hw, stride, pad, dil):
+def conv_dgrad(gy, weight, in_hw, stride, pad, dil, packs=None):
     """dL/dx of ``conv_forward``: gy (N, Ho, Wo, CoutS) bf16 -> (N, H, W, CinS) bf16."""
     cout, cin, kh, kw = weight.shape
     n = gy.shape[0]
@@ -114,7 +184,7 @@ def conv_dgrad(gy, weight, in_hw, stride, pad, dil):
                                     hip.stream_of(gy)), "otp_nhwc_dilate")
         g = gd
     d = _desc(n, g.shape[1], g.shape[2], cout, cin, kh, kw, 1, dil * (kh - 1) - pad, dil, 0)
-    wp = _pack(weight.contiguous(), d, 1)
+    wp = _pack(weight.contiguous(), d, 1, packs)
     gx = _new((n, h, w, cs(cin)), BF16, gy)
     hip.check(L.otp_nhwc_conv_bf16(hip.ptr(g), hip.ptr(wp), None, hip.ptr(gx), None, ctypes.byref(d), hip.stream_of(gy)),
               "otp_nhwc_conv_bf16(dgrad)")
@@ -125,11 +195,13 @@ _WS = {}
 
 
 def _workspace(device, nbytes):
-    """Grow-only scratch per device (stream-ordered reuse: every user launches on the current stream)."""
-    buf = _WS.get(device)
+    """Grow-only scratch per (device, stream): every user launches on the current stream, so reuse is stream-ordered; the
+    HRNet branches of a training step run on several streams and each gets its own."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _WS.get(key)
     if buf is None or buf.numel() * 4 < nbytes:
         buf = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
-        _WS[device] = buf
+        _WS[key] = buf
     return buf
 
 
@@ -196,7 +268,8 @@ class ConvBnFunction(Function):
         _require_gpu(x, weight, gamma, beta)
         x = x.contiguous()
         cout = weight.shape[0]
-        c, stats, rows = conv_forward(x, weight, None, stride, pad, 1)
+        ctx.packs = _ACTIVE_PACKS
+        c, stats, rows = conv_forward(x, weight, None, stride, pad, 1, packs=ctx.packs)
         count = c.numel() // c.shape[-1]
         vec = bn_finalize(stats, rows, cout, count, gamma, beta, running_mean, running_var, momentum, eps)
         r = res.contiguous() if res is not None else None
@@ -214,7 +287,7 @@ class ConvBnFunction(Function):
         pw, pg, pb = ctx.params
         gc, gres, dg, db = bn_backward(gy, y, c, vec[0], vec[1], gamma, weight.shape[0], relu, has_res, grad_slot(pg),
                                        grad_slot(pb))
-        gx = conv_dgrad(gc, weight, x.shape[1:3], stride, pad, 1) if ctx.needs_input_grad[0] else None
+        gx = conv_dgrad(gc, weight, x.shape[1:3], stride, pad, 1, ctx.packs) if ctx.needs_input_grad[0] else None
         gw = conv_wgrad(x, gc, weight.shape, stride, pad, 1, grad_slot(pw)) if ctx.needs_input_grad[1] else None
         return gx, gw, dg, db, gres, None, None, None, None, None, None, None
 
@@ -232,7 +305,8 @@ class ConvOutFunction(Function):
     def forward(ctx, x, weight, bias, stride, pad, dil):
         _require_gpu(x, weight)
         x = x.contiguous()
-        out, _, _ = conv_forward(x, weight, bias, stride, pad, dil, out_mode=1)
+        ctx.packs = _ACTIVE_PACKS
+        out, _, _ = conv_forward(x, weight, bias, stride, pad, dil, out_mode=1, packs=ctx.packs)
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, pad, dil, bias is not None)
         ctx.params = (weight, bias)
@@ -245,7 +319,7 @@ class ConvOutFunction(Function):
         stride, pad, dil, has_bias = ctx.cfg
         gy = gy.contiguous()
         g = to_nhwc(gy)
-        gx = conv_dgrad(g, weight, x.shape[1:3], stride, pad, dil) if ctx.needs_input_grad[0] else None
+        gx = conv_dgrad(g, weight, x.shape[1:3], stride, pad, dil, ctx.packs) if ctx.needs_input_grad[0] else None
         gw = conv_wgrad(x, g, weight.shape, stride, pad, dil, grad_slot(ctx.params[0])) if ctx.needs_input_grad[1] else None
         gb = channel_sum(gy, grad_slot(ctx.params[1])) if has_bias and ctx.needs_input_grad[2] else None
         return gx, gw, gb, None, None, None
@@ -309,7 +383,8 @@ class ConvBiasFunction(Function):
     def forward(ctx, x, weight, bias, stride, pad, dil):
         _require_gpu(x, weight)
         x = x.contiguous()
-        out, _, _ = conv_forward(x, weight, bias, stride, pad, dil, out_mode=0, want_stats=False)
+        ctx.packs = _ACTIVE_PACKS
+        out, _, _ = conv_forward(x, weight, bias, stride, pad, dil, out_mode=0, want_stats=False, packs=ctx.packs)
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, pad, dil, bias is not None)
         ctx.params = (weight, bias)
@@ -320,7 +395,7 @@ class ConvBiasFunction(Function):
         x, weight = ctx.saved_tensors
         stride, pad, dil, has_bias = ctx.cfg
         gy = gy.contiguous()
-        gx = conv_dgrad(gy, weight, x.shape[1:3], stride, pad, dil) if ctx.needs_input_grad[0] else None
+        gx = conv_dgrad(gy, weight, x.shape[1:3], stride, pad, dil, ctx.packs) if ctx.needs_input_grad[0] else None
         gw = conv_wgrad(x, gy, weight.shape, stride, pad, dil, grad_slot(ctx.params[0])) if ctx.needs_input_grad[1] else None
         gb = (channel_sum_nhwc(gy, weight.shape[0], grad_slot(ctx.params[1]))
               if has_bias and ctx.needs_input_grad[2] else None)

@@ -17,6 +17,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include <cstring>
 
 namespace {
 
@@ -154,9 +155,17 @@ bool make_plan(const otp_nhwc_conv_desc* d, ConvPlan* p) {
 // element (o, i, dy, dx) of the EFFECTIVE conv is w[base + o*so + i*si + dy*sdy + dx*sdx] (the input-gradient conv
 // reads the same tensor with o <-> i swapped and the taps flipped)
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ void nhwc_pack_kernel(const float* __restrict__ w, bf16* __restrict__ out, ConvPlan p, long so, long si, long sdy,
-                                 long sdx, long base, size_t total) {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+struct PackJob {                       // one weight re-layout: everything nhwc_pack_kernel takes by value
+    const float* w;
+    bf16* out;
+    long so, si, sdy, sdx, base;
+    size_t total;
+    ConvPlan p;
+};
+
+__device__ __forceinline__ void pack_range(const float* __restrict__ w, bf16* __restrict__ out, const ConvPlan& p, long so, long si,
+                                           long sdy, long sdx, long base, size_t total, size_t first, size_t step) {
+    for (size_t i = first; i < total; i += step) {
         size_t r = i;
         const int j = r % 8; r /= 8;
         const int co = r % p.BM; r /= p.BM;
@@ -171,6 +180,20 @@ __global__ void nhwc_pack_kernel(const float* __restrict__ w, bf16* __restrict__
         }
         out[i] = (bf16)v;
     }
+}
+
+__global__ void nhwc_pack_kernel(const float* __restrict__ w, bf16* __restrict__ out, ConvPlan p, long so, long si, long sdy,
+                                 long sdx, long base, size_t total) {
+    pack_range(w, out, p, so, si, sdy, sdx, base, total, blockIdx.x * (size_t)blockDim.x + threadIdx.x,
+               (size_t)gridDim.x * blockDim.x);
+}
+
+// every weight of a training step in one launch: blockIdx.y = job (the table lives in device memory, its fields arrive
+// through the scalar cache), blockIdx.x strides over the job's elements
+__global__ void nhwc_pack_batch_kernel(const PackJob* __restrict__ jobs) {
+    const PackJob& jb = jobs[blockIdx.y];
+    pack_range(jb.w, jb.out, jb.p, jb.so, jb.si, jb.sdy, jb.sdx, jb.base, jb.total,
+               blockIdx.x * (size_t)blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1207,20 +1230,50 @@ extern "C" int otp_nhwc_conv_plan(const otp_nhwc_conv_desc* d, int* out8) {
     return OTP_OK;
 }
 
-extern "C" int otp_nhwc_conv_pack(const void* weight, void* wpacked, const otp_nhwc_conv_desc* d, int dgrad, void* stream) {
-    ConvPlan p;
-    if (!weight || !wpacked) return OTP_ERR_BAD_ARG;
-    if (!make_plan(d, &p)) return OTP_ERR_UNSUPPORTED;
+namespace {
+bool make_pack_job(const void* weight, void* wpacked, const otp_nhwc_conv_desc* d, int dgrad, PackJob* jb) {
+    if (!make_plan(d, &jb->p)) return false;
+    const ConvPlan& p = jb->p;
     const long taps = (long)p.kh * p.kw;
-    long so, si, sdy, sdx, base;
     if (!dgrad) {
-        so = p.Cin * taps, si = taps, sdy = p.kw, sdx = 1, base = 0;
+        jb->so = p.Cin * taps, jb->si = taps, jb->sdy = p.kw, jb->sdx = 1, jb->base = 0;
     } else {      // original weight is (O = d->Cin, I = d->Cout, kh, kw); this conv maps O -> I with flipped taps
-        so = taps, si = (long)p.Cout * taps, sdy = -p.kw, sdx = -1, base = taps - 1;
+        jb->so = taps, jb->si = (long)p.Cout * taps, jb->sdy = -p.kw, jb->sdx = -1, jb->base = taps - 1;
     }
-    const size_t total = p.wbytes / 2;
-    nhwc_pack_kernel<<<grid_for(total), 256, 0, static_cast<hipStream_t>(stream)>>>(
-        static_cast<const float*>(weight), static_cast<bf16*>(wpacked), p, so, si, sdy, sdx, base, total);
+    jb->total = p.wbytes / 2;
+    jb->w = static_cast<const float*>(weight);
+    jb->out = static_cast<bf16*>(wpacked);
+    return true;
+}
+}  // namespace
+
+extern "C" int otp_nhwc_conv_pack(const void* weight, void* wpacked, const otp_nhwc_conv_desc* d, int dgrad, void* stream) {
+    PackJob jb;
+    if (!weight || !wpacked) return OTP_ERR_BAD_ARG;
+    if (!make_pack_job(weight, wpacked, d, dgrad, &jb)) return OTP_ERR_UNSUPPORTED;
+    nhwc_pack_kernel<<<grid_for(jb.total), 256, 0, static_cast<hipStream_t>(stream)>>>(jb.w, jb.out, jb.p, jb.so, jb.si, jb.sdy,
+                                                                                      jb.sdx, jb.base, jb.total);
+    return otp_launch_status();
+}
+
+extern "C" size_t otp_nhwc_conv_pack_job_bytes(void) { return sizeof(PackJob); }
+
+extern "C" int otp_nhwc_conv_pack_job(const void* weight, void* wpacked, const otp_nhwc_conv_desc* d, int dgrad, void* job_host) {
+    if (!weight || !wpacked || !job_host) return OTP_ERR_BAD_ARG;
+    PackJob jb;
+    memset(&jb, 0, sizeof(jb));
+    if (!make_pack_job(weight, wpacked, d, dgrad, &jb)) return OTP_ERR_UNSUPPORTED;
+    memcpy(job_host, &jb, sizeof(jb));
+    return OTP_OK;
+}
+
+extern "C" int otp_nhwc_conv_pack_batch(const void* jobs_device, int n_jobs, void* stream) {
+    if (!jobs_device || n_jobs < 0) return OTP_ERR_BAD_ARG;
+    if (n_jobs == 0) return OTP_OK;
+    // 32 workgroups per job: the largest weight of the path (384 x 384 x 9 -> 1.5 M packed elements) takes ~180 iterations
+    // per thread, a 48 x 48 x 9 one finishes in the first
+    nhwc_pack_batch_kernel<<<dim3(32, (unsigned)n_jobs), 256, 0, static_cast<hipStream_t>(stream)>>>(
+        static_cast<const PackJob*>(jobs_device));
     return otp_launch_status();
 }
 

@@ -143,6 +143,9 @@ SIGNATURES = {
     "otp_nhwc_conv_stats_rows": (c_int, [_ND]),
     "otp_nhwc_conv_plan": (c_int, [_ND, ctypes.POINTER(c_int)]),
     "otp_nhwc_conv_pack": (c_int, [c_void_p, c_void_p, _ND, c_int, c_void_p]),
+    "otp_nhwc_conv_pack_job_bytes": (c_size_t, []),
+    "otp_nhwc_conv_pack_job": (c_int, [c_void_p, c_void_p, _ND, c_int, c_void_p]),
+    "otp_nhwc_conv_pack_batch": (c_int, [c_void_p, c_int, c_void_p]),
     "otp_nhwc_conv_bf16": (c_int, [c_void_p] * 5 + [_ND, c_void_p]),
     "otp_nhwc_wgrad_workspace": (c_size_t, [_ND]),
     "otp_nhwc_wgrad_bf16": (c_int, [c_void_p] * 4 + [c_size_t, _ND, c_void_p]),
@@ -222,5 +225,6 @@ def ptr(t):
 def stream_of(t):
     """The HIP stream PyTorch is currently enqueuing on for ``t``'s device."""
     import torch
-    _tls.dev = t.device.index
-    return c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    dev = t.device.index
+    _tls.dev = dev
+    return c_void_p(torch._C._cuda_getCurrentRawStream(dev))

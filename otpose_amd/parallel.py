@@ -178,6 +178,14 @@ class GradBuckets:
 
     def _pack_and_launch(self, i: int) -> None:
         flat = self.flat[i]
+        if flat.is_cuda:
+            # hook mode runs this on the stream of the gradient that completed the bucket; the other gradients of the bucket
+            # may have been written on the side streams of the HRNet branches (train.TrainGraph.hr_module)
+            from .train import _SIDE_STREAMS
+            cur = torch.cuda.current_stream(flat.device)
+            for s in [torch.cuda.default_stream(flat.device)] + _SIDE_STREAMS.get(flat.device, []):
+                if s != cur:
+                    cur.wait_stream(s)
         for p, o in zip(self.buckets[i], self._offsets(i)):
             g = p.grad
             if g is None:

@@ -158,17 +158,28 @@ def build_loss(cfg, **kwargs):
     raise ValueError(f"unknown LOSS.NAME {name!r}")
 
 
+_SIDE_STREAMS = {}            # device -> side streams of the HRNet branches (created once, reused by every step)
+
+
 class TrainGraph:
     """Functional walk over the module's own parameters / buffers (same names as the reference state dict)."""
 
     def __init__(self, model):
         self.model = model
-        self.P = dict(model.named_parameters())
-        self.Bf = dict(model.named_buffers())
+        # one walk over the module tree per forward (named_parameters / named_buffers / named_modules would be three)
+        self.mods = dict(model.named_modules())
+        self.P, self.Bf = {}, {}
+        for name, mod in self.mods.items():
+            pre = name + "." if name else ""
+            for k, v in mod._parameters.items():
+                if v is not None:
+                    self.P[pre + k] = v
+            for k, v in mod._buffers.items():
+                if v is not None:
+                    self.Bf[pre + k] = v
         self.cfg = model.cfg
         self.taps = None                      # dict -> forward() records named intermediates (tools/grad_noise.py)
         self.stochastic = bool(getattr(model, "train_dropout", True))
-        self.mods = dict(model.named_modules())
         self._nbt = []
 
     # ---- conv / BN helpers ------------------------------------------------------------------------------------
@@ -217,35 +228,70 @@ class TrainGraph:
             res = self.conv_bn(p + ".downsample.0", p + ".downsample.1", x, 1, 0, False)
         return self.conv_bn(p + ".conv3", p + ".bn3", y, 1, 0, True, res)
 
+    def branch_streams(self, like, n):
+        """The launching stream plus n - 1 side streams (one per HRNet branch).  ``OTPOSE_TRAIN_STREAMS=0`` keeps the whole
+        step on one stream."""
+        main = torch.cuda.current_stream(like.device)
+        if os.environ.get("OTPOSE_TRAIN_STREAMS", "1") == "0" or n < 2:
+            return [main] * n
+        pool = _SIDE_STREAMS.setdefault(like.device, [])
+        while len(pool) < n - 1:
+            pool.append(torch.cuda.Stream(like.device))
+        return [main] + pool[:n - 1]
+
     def hr_module(self, p, xs, n_out):
+        """One HighResolutionModule (model/HRNet.py:400-497).  The branches are independent until the fuse layers and each
+        fuse row is independent of the others: branch i and fuse row i are enqueued on stream i (fork / join around both
+        phases), so the low-resolution branches - a few hundred workgroups per launch, half a wave of the chip - run beside
+        the high-resolution one instead of after it.  autograd replays every node on the stream its forward ran on, so the
+        backward overlaps the same way.  Tensors that cross streams are registered with the caching allocator
+        (``record_stream``) so their memory is not handed out again while the other stream still reads it."""
         n = len(xs)
         xs = list(xs)
+        st = self.branch_streams(xs[0], n)
+        main, par = st[0], n > 1 and st[-1] is not st[0]
         for i in range(n):
-            b = 0
-            while self.has(f"{p}.branches.{i}.{b}.conv1.weight"):
-                xs[i] = self.basic_block(f"{p}.branches.{i}.{b}", xs[i])
-                b += 1
+            if par and i:
+                st[i].wait_stream(main)
+                xs[i].record_stream(st[i])
+            with torch.cuda.stream(st[i]):
+                b = 0
+                while self.has(f"{p}.branches.{i}.{b}.conv1.weight"):
+                    xs[i] = self.basic_block(f"{p}.branches.{i}.{b}", xs[i])
+                    b += 1
         if n == 1:
             return xs
+        if par:
+            for i in range(1, n):
+                main.wait_stream(st[i])
+            for i in range(1, n_out):
+                st[i].wait_stream(main)
         outs = []
         for i in range(n_out):
             # y = relu(sum_j f_ij(x_j)) (HRNet.py:487-494).  The identity term seeds the sum and every other term rides
             # on a fused add (BatchNorm residual input / up-sample accumulate); the last one applies the ReLU.
-            y = xs[i]
-            terms = [j for j in range(n) if j != i]
-            for idx, j in enumerate(terms):
-                last = idx == len(terms) - 1
-                q = f"{p}.fuse_layers.{i}.{j}"
-                if j > i:
-                    low = self.conv_bn(q + ".0", q + ".1", xs[j], 1, 0, False)
-                    y = self.upsample_add(low, y, 2 ** (j - i), last)
-                else:
-                    t = xs[j]
-                    for k in range(i - j - 1):
-                        t = self.conv_bn(f"{q}.{k}.0", f"{q}.{k}.1", t, 2, 1, True)
-                    k = i - j - 1
-                    y = self.conv_bn(f"{q}.{k}.0", f"{q}.{k}.1", t, 2, 1, relu=last, res=y)
+            with torch.cuda.stream(st[i]):
+                y = xs[i]
+                terms = [j for j in range(n) if j != i]
+                for idx, j in enumerate(terms):
+                    last = idx == len(terms) - 1
+                    q = f"{p}.fuse_layers.{i}.{j}"
+                    if par:
+                        xs[j].record_stream(st[i])
+                    if j > i:
+                        low = self.conv_bn(q + ".0", q + ".1", xs[j], 1, 0, False)
+                        y = self.upsample_add(low, y, 2 ** (j - i), last)
+                    else:
+                        t = xs[j]
+                        for k in range(i - j - 1):
+                            t = self.conv_bn(f"{q}.{k}.0", f"{q}.{k}.1", t, 2, 1, True)
+                        k = i - j - 1
+                        y = self.conv_bn(f"{q}.{k}.0", f"{q}.{k}.1", t, 2, 1, relu=last, res=y)
             outs.append(y)
+        if par:
+            for i in range(1, n_out):
+                main.wait_stream(st[i])
+                outs[i].record_stream(main)
         return outs
 
     def upsample_add(self, low, y, f, relu):
@@ -400,6 +446,15 @@ class TrainGraph:
             total_b = total_b + f_
         squeezed = total_b.sum(1, keepdim=True).expand(-1, J, -1, -1).contiguous()
         inter = total_b * squeezed
+        # three independent paths follow (as in the inference engine): def_fuse needs only ``total_b``, and the two temporal
+        # encoders (with their final layers) only share their inputs - def_fuse and encoder 1 go to side streams
+        st = self.branch_streams(total_b, 3)
+        main, par = st[0], st[1] is not st[0]
+        if par:
+            st[2].wait_stream(main)
+            total_b.record_stream(st[2])
+        with torch.cuda.stream(st[2]):
+            def_h = self.rsb_chain("def_fuse", total_b)
         ctx = self.conv_transformer("flow_encoder", total_b, 1, (0, 6, 0))[0].reshape(B, J, pe_h, pe_w)
         mg = margin.to(x.dtype)
         div = lambda t, k: t / (mg[:, k] + 1)[:, None, None, None]           # noqa: E731
@@ -420,14 +475,22 @@ class TrainGraph:
             b2.append(side(nxt[1:]))
         x1 = torch.stack([inter, ctx] + b1 + [t * squeezed for t in b1], 2).flatten(1, 2)
         x2 = torch.stack([inter, ctx] + b2 + [t * squeezed for t in b2], 2).flatten(1, 2)
-        t1 = self.conv_transformer("temporal_encoder1", x1, 2, (0, 6, 2))
-        t2 = self.conv_transformer("temporal_encoder2", x2, 2, (0, 6, 2))
-        s1 = torch.stack(t1, 1).contiguous().view(B, -1, pe_h, pe_w)
-        s2 = torch.stack(t2, 1).contiguous().view(B, -1, pe_h, pe_w)
         fk = self.P["final_layer1.weight"].shape[-1]
-        f1 = self.conv("final_layer1", s1, 1, fk // 2)
+        if par:
+            st[1].wait_stream(main)
+            x1.record_stream(st[1])
+        with torch.cuda.stream(st[1]):
+            t1 = self.conv_transformer("temporal_encoder1", x1, 2, (0, 6, 2))
+            s1 = torch.stack(t1, 1).contiguous().view(B, -1, pe_h, pe_w)
+            f1 = self.conv("final_layer1", s1, 1, fk // 2)
+        t2 = self.conv_transformer("temporal_encoder2", x2, 2, (0, 6, 2))
+        s2 = torch.stack(t2, 1).contiguous().view(B, -1, pe_h, pe_w)
         f2 = self.conv("final_layer2", s2, 1, fk // 2)
-        def_h = self.rsb_chain("def_fuse", total_b)
+        if par:
+            main.wait_stream(st[1])
+            main.wait_stream(st[2])
+            for t in (f1, def_h) + tuple(t1):
+                t.record_stream(main)
         trans = self.rsb_chain("offset_mask_combine_conv", torch.cat([f1, f2, def_h], 1))
         out = None
         if self.taps is not None:
@@ -453,6 +516,21 @@ class TrainGraphBF16(TrainGraph):
     BatchNorm statistics, fp32 master weights and weight gradients (BASELINE configs[2]).  The frames enter through one
     layout / precision conversion that also performs the ``cat(split(3, 1), 0)`` of model/OTPose.py:317, and the final
     1x1 layer hands fp32 NCHW heat-maps to the rest of the graph."""
+
+    def forward(self, x, margin):
+        """One launch refreshes every packed bf16 operator from the fp32 master weights (:class:`bf16_ops.PackCache`, kept on
+        the model; ``OTPOSE_PACK_BATCH=0`` packs at every use instead), then the walk of :meth:`TrainGraph.forward`."""
+        if os.environ.get("OTPOSE_PACK_BATCH", "1") == "0":
+            return super().forward(x, margin)
+        cache = self.model.__dict__.get("_otp_pack_cache")
+        if cache is None:
+            cache = self.model.__dict__["_otp_pack_cache"] = B16.PackCache()
+        cache.repack(x.device)
+        prev = B16.set_active_packs(cache)
+        try:
+            return super().forward(x, margin)
+        finally:
+            B16.set_active_packs(prev)
 
     def conv_bn(self, conv, bn, x, stride=1, pad=0, relu=False, res=None):
         if x.dtype != B16.BF16:

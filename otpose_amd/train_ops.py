@@ -111,12 +111,13 @@ _WS = {}
 
 
 def _workspace(device, nbytes):
-    """One grow-only scratch buffer per device for the wgrad partial sums (stream-ordered reuse: every user launches on
-    the current stream)."""
-    buf = _WS.get(device)
+    """One grow-only scratch buffer per (device, stream) for the wgrad partial sums: every user launches on the current
+    stream, so reuse is stream-ordered; the independent paths of a training step run on several streams and each has its own."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _WS.get(key)
     if buf is None or buf.numel() * 4 < nbytes:
         buf = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
-        _WS[device] = buf
+        _WS[key] = buf
     return buf
 
 

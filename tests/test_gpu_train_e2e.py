@@ -264,3 +264,53 @@ def test_bf16_step_on_a_cfg2_shaped_clip():
     # bf16, measured on MI355X: loss 9.7e-3, rough / total_b 3.4e-2 / 2.3e-2 of their range, backbone gradient |g| ratio 1.0000,
     # cosine 0.999999, relative L2 error 1.7e-3 (fp32: 2.8e-6, 3.7e-6 / 2.0e-6, 1.0000, 1.000000, 1.6e-5)
     assert b[0] <= 3e-2 and b[1] <= 8e-2 and b[2] <= 8e-2 and abs(b[3] - 1) <= 1e-2 and b[4] >= 0.9999 and b[5] <= 1e-2
+
+
+def test_bf16_step_same_with_and_without_streams_and_batched_packs(monkeypatch):
+    """The scheduling of the bf16 step - HRNet branches / temporal encoders on side streams, every weight re-layout in one
+    launch per step (bf16_ops.PackCache) - must not change its arithmetic: with both switched off (one stream, a pack
+    launch per use) three forward / backward passes give the same losses and gradients.  The weights are rescaled by 1 %
+    between the passes, so an operator left over from the previous pass (a job missed by the batched launch, a launch
+    ordered before the rescale) would show as a 1e-2 error; pass 2 and 3 are the ones that read batched re-layouts.
+    (No optimizer in the loop: Adam's first steps are lr * sign(g) and turn the last-bit differences of the atomically
+    accumulated gradients into 1e-4 loss differences.)"""
+    cfg = tiny_cfg()
+    ref = OTPose(cfg)
+    S.fill_synthetic_(ref)
+    sd = {k: v.detach().clone() for k, v in ref.state_dict().items()}
+    x, margin = S.synthetic_clip(2, cfg.MODEL.IMAGE_SIZE)
+    x, margin = x.cuda(), margin.cuda()
+    w, h = cfg.MODEL.HEATMAP_SIZE
+    g, wt = _targets(2, cfg.MODEL.NUM_JOINTS, h, w)
+    g, wt = g.cuda(), wt.cuda()
+    runs = {}
+    for name, env in (("plain", {"OTPOSE_TRAIN_STREAMS": "0", "OTPOSE_PACK_BATCH": "0"}), ("scheduled", {})):
+        for k in ("OTPOSE_TRAIN_STREAMS", "OTPOSE_PACK_BATCH"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m = OTPose(cfg)
+        m.load_state_dict(sd)
+        m = m.cuda().train()
+        m.train_dropout = False
+        m.train_dtype = "bf16"
+        params = [p for p in m.parameters() if p.requires_grad]
+        losses, grads = [], []
+        for it in range(3):
+            loss = TR.criterion(m(x, margin=margin), g, wt)
+            m.zero_grad(set_to_none=True)
+            loss.backward()
+            losses.append(float(loss))
+            grads.append(torch.cat([p.grad.flatten() for p in params if p.grad is not None]).double())
+            with torch.no_grad():
+                for p in params:
+                    p.mul_(1.01)
+        torch.cuda.synchronize()
+        runs[name] = (losses, grads, len(m.__dict__.get("_otp_pack_cache") or ()))
+    (la, ga, na), (lb, gb, nb) = runs["plain"], runs["scheduled"]
+    assert na == 0 and nb > 0                      # the scheduled run really went through the cache
+    assert abs(lb[0] - lb[2]) > 1e-3 * abs(lb[0])  # the rescale is visible: a stale operator would be, too
+    for a, b in zip(la, lb):
+        assert abs(a - b) <= 2e-6 * abs(a), (la, lb)
+    for a, b in zip(ga, gb):
+        assert float((a - b).norm() / a.norm()) <= 1e-5, float((a - b).norm() / a.norm())

@@ -55,19 +55,22 @@ def main():
         torch.cuda.reset_peak_memory_stats()
         t0 = sync()
         outs = model(x, margin=margin)
+        c1 = time.perf_counter()                # host time to enqueue the forward (before the device catches up)
         t1 = sync()
         loss = TR.criterion(outs, g, wt)
         t2 = sync()
         opt.zero_grad()
         loss.backward()
+        c3 = time.perf_counter()
         t3 = sync()
         if a.torch_optim:
             torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
         opt.step()
         t4 = sync()
-        print("step %d%s: forward %.1f ms  loss %.1f ms  backward %.1f ms  clip+AdamW %.1f ms  total %.1f ms  "
+        print("step %d%s: forward %.1f ms (host %.1f)  loss %.1f ms  backward %.1f ms (host %.1f)  clip+AdamW %.1f ms  total %.1f ms  "
               "(%.1f frames/s)  loss %.5f  peak mem %.1f GB" %
-              (it, " (warm-up)" if it == 0 else "", (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3,
+              (it, " (warm-up)" if it == 0 else "", (t1 - t0) * 1e3, (c1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3,
+               (c3 - t2) * 1e3, (t4 - t3) * 1e3,
                (t4 - t0) * 1e3, a.batch * 5 / (t4 - t0), float(loss), torch.cuda.max_memory_allocated() / 2**30),
               flush=True)
 
