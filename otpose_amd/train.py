@@ -17,6 +17,7 @@ import math
 import os
 
 import torch
+import torch.utils.checkpoint
 from torch.autograd import Function
 
 from . import bf16_ops as B16
@@ -205,12 +206,17 @@ class TrainGraph:
 
     def conv1d(self, p, x):
         """nn.Conv1d(k=1) on (B, C, T)."""
-        w = self.P[p + ".weight"]
+        return T.conv2d(x.unsqueeze(2), self._w4(p + ".weight"), self.P.get(p + ".bias"), 1, 0, 1).squeeze(2)
+
+    def _w4(self, name):
+        """(Cout, Cin, 1) Conv1d weight as the (Cout, Cin, 1, 1) view the conv kernels take; the view writes its gradient
+        into the parameter's slot."""
+        w = self.P[name]
         w4 = w.unsqueeze(-1)
         slot = getattr(w, "_otp_grad_slot", None)
-        if slot is not None:                      # the (Cout, Cin, 1, 1) view writes its gradient into the parameter's slot
+        if slot is not None:
             w4._otp_grad_slot, w4._otp_grad_owner = slot.unsqueeze(-1), w
-        return T.conv2d(x.unsqueeze(2), w4, self.P.get(p + ".bias"), 1, 0, 1).squeeze(2)
+        return w4
 
     # ---- HRNet (model/HRNet.py:116-152, 478-496, 514-571) -------------------------------------------------------
     def basic_block(self, p, x):
@@ -339,16 +345,27 @@ class TrainGraph:
     def layer_norm(self, p, x):
         return T.layer_norm(x, self.P[p + ".weight"], self.P[p + ".bias"], 1e-5)
 
-    def mhca(self, p, x, n_head, stride):
+    def mhca(self, p, x, ln1, n_head, stride):
+        """MultiHeadConvAttention (model/blocks.py:359-453) of ``ln1(x)``.  The front - ln1, then per q / k / v a depthwise
+        conv, a channel LayerNorm and the 1x1 projection - is one autograd node that keeps only ``x`` and rebuilds its seven
+        (B, C, T) intermediates in the backward (:class:`train_ops.AttnFrontFunction`: 5 GB less at cfg2 for ~2 ms of
+        recomputation per step).  ``OTPOSE_TRAIN_RECOMPUTE=0`` composes the per-layer nodes instead, keeping everything."""
         c = x.shape[1]
         hs = c // n_head
+        names = ("query", "key", "value")
+        if torch.is_grad_enabled() and os.environ.get("OTPOSE_TRAIN_RECOMPUTE", "1") != "0":
+            branches = [(self.P[f"{p}.{n}_conv.weight"], self.P[f"{p}.{n}_norm.weight"], self.P[f"{p}.{n}_norm.bias"],
+                         self._w4(f"{p}.{n}.weight"), self.P.get(f"{p}.{n}.bias")) for n in names]
+            q, k, v = T.attn_front(x, stride, 1e-5, (self.P[ln1 + ".weight"], self.P[ln1 + ".bias"]), branches)
+        else:
+            xn = self.layer_norm(ln1, x)
 
-        def branch(name):
-            y = T.dwconv3(x, self.P[f"{p}.{name}_conv.weight"], stride)
-            y = self.layer_norm(f"{p}.{name}_norm", y)
-            return self.conv1d(f"{p}.{name}", y)
+            def branch(name):
+                y = T.dwconv3(xn, self.P[f"{p}.{name}_conv.weight"], stride)
+                y = self.layer_norm(f"{p}.{name}_norm", y)
+                return self.conv1d(f"{p}.{name}", y)
 
-        q, k, v = branch("query"), branch("key"), branch("value")
+            q, k, v = (branch(n) for n in names)
         out = T.chan_attn(q, k, v, n_head, 1.0 / math.sqrt(hs))          # attn_pdrop is 0 in OTPose.py:209-216
         return self.dropout(self.conv1d(p + ".proj", out), self.mods[p].proj_pdrop)
 
@@ -365,7 +382,7 @@ class TrainGraph:
         return (keep + torch.rand((x.shape[0],), dtype=x.dtype, device=x.device)).floor_().div_(keep)
 
     def tblock(self, p, x, n_head, stride):
-        a = self.mhca(p + ".attn", self.layer_norm(p + ".ln1", x), n_head, stride)
+        a = self.mhca(p + ".attn", x, p + ".ln1", n_head, stride)
         skip = x if stride == 1 else T.maxpool3s2(x)
         blk = self.mods[p]
         y = T.scale_residual(skip, a, self.P[p + ".drop_path_attn.scale"], self.drop_path_mask(a, blk.path_pdrop))
@@ -558,15 +575,6 @@ class TrainGraphBF16(TrainGraph):
         if trans.dtype != B16.BF16:
             return super().offset_mask_conv(trans, weight, d)
         return B16.conv_out(trans, weight, None, 1, d, d)
-
-    def _w4(self, name):
-        """(Cout, Cin, 1) Conv1d weight as the (Cout, Cin, 1, 1) view the conv kernels take, gradient slot attached."""
-        w = self.P[name]
-        w4 = w.unsqueeze(-1)
-        slot = getattr(w, "_otp_grad_slot", None)
-        if slot is not None:
-            w4._otp_grad_slot, w4._otp_grad_owner = slot.unsqueeze(-1), w
-        return w4
 
     def mlp(self, p, yn, pdrop):
         """The MLP interior in bf16: the (B, C, T) fp32 LayerNorm output enters as a (B, 1, T, CS) NHWC bf16 view, the 4C-wide

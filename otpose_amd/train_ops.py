@@ -236,6 +236,38 @@ def _chan_sum3(t):
     return channel_sum(t.reshape(b, c, 1, n))
 
 
+def _ln_fwd(x, gamma, beta, eps):
+    """y = channel LayerNorm of a contiguous (B, C, T) tensor; gamma / beta flat (C)."""
+    b, c, t = x.shape
+    y = torch.empty_like(x)
+    hip.check(hip.lib().otp_ln_channel(hip.ptr(x), hip.ptr(gamma), hip.ptr(beta), hip.ptr(y), None, b, c, t, eps,
+                                       hip.stream_of(x)), "otp_ln_channel")
+    return y
+
+
+def _ln_bwd(x, g, gy, eps, pgamma, pbeta):
+    """(dx, dgamma (C), dbeta (C)) of :func:`_ln_fwd`; the parameter gradients land in the optimizer's slots when free."""
+    gy = gy.contiguous()
+    b, c, t = x.shape
+    L = hip.lib()
+    nbytes = L.otp_ln_channel_backward_workspace(b, c, t)
+    if nbytes:
+        # dx, dgamma and dbeta from one pass over x and dy
+        gx = torch.empty_like(x)
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+        sg, sb = grad_slot(pgamma), grad_slot(pbeta)
+        gg = sg if sg is not None else torch.empty(c, dtype=torch.float32, device=x.device)
+        gb = sb if sb is not None else torch.empty(c, dtype=torch.float32, device=x.device)
+        hip.check(L.otp_ln_channel_backward_params(hip.ptr(x), hip.ptr(gy), hip.ptr(g), hip.ptr(gx), hip.ptr(gg), hip.ptr(gb),
+                                                   hip.ptr(ws), nbytes, b, c, t, eps, hip.stream_of(x)),
+                  "otp_ln_channel_backward_params")
+        return gx, gg, gb
+    gx, dyxh = torch.empty_like(x), torch.empty_like(x)
+    hip.check(L.otp_ln_channel_backward(hip.ptr(x), hip.ptr(gy), hip.ptr(g), hip.ptr(gx), hip.ptr(dyxh), b, c, t,
+                                        eps, hip.stream_of(x)), "otp_ln_channel_backward")
+    return gx, _chan_sum3(dyxh), _chan_sum3(gy)
+
+
 class LayerNormFunction(Function):
     """Channel LayerNorm of (B, C, T) (model/blocks.py:95-110): biased variance over C, weight / bias (C)."""
 
@@ -244,11 +276,8 @@ class LayerNormFunction(Function):
         _require_gpu(x)
         _check_f32(x)
         x = x.contiguous()
-        b, c, t = x.shape
-        y = torch.empty_like(x)
         g, be = gamma.reshape(-1).contiguous(), beta.reshape(-1).contiguous()
-        hip.check(hip.lib().otp_ln_channel(hip.ptr(x), hip.ptr(g), hip.ptr(be), hip.ptr(y), None, b, c, t, eps,
-                                           hip.stream_of(x)), "otp_ln_channel")
+        y = _ln_fwd(x, g, be, eps)
         ctx.save_for_backward(x, g)
         ctx.eps, ctx.pshape = eps, gamma.shape
         ctx.params = (gamma, beta)
@@ -257,29 +286,30 @@ class LayerNormFunction(Function):
     @staticmethod
     def backward(ctx, gy):
         x, g = ctx.saved_tensors
-        gy = gy.contiguous()
-        b, c, t = x.shape
-        L = hip.lib()
-        nbytes = L.otp_ln_channel_backward_workspace(b, c, t)
-        if nbytes:
-            # dx, dgamma and dbeta from one pass over x and dy
-            gx = torch.empty_like(x)
-            ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
-            sg, sb = grad_slot(ctx.params[0]), grad_slot(ctx.params[1])
-            gg = sg if sg is not None else torch.empty(c, dtype=torch.float32, device=x.device)
-            gb = sb if sb is not None else torch.empty(c, dtype=torch.float32, device=x.device)
-            hip.check(L.otp_ln_channel_backward_params(hip.ptr(x), hip.ptr(gy), hip.ptr(g), hip.ptr(gx), hip.ptr(gg), hip.ptr(gb),
-                                                       hip.ptr(ws), nbytes, b, c, t, ctx.eps, hip.stream_of(x)),
-                      "otp_ln_channel_backward_params")
-            return gx, gg.reshape(ctx.pshape), gb.reshape(ctx.pshape), None
-        gx, dyxh = torch.empty_like(x), torch.empty_like(x)
-        hip.check(hip.lib().otp_ln_channel_backward(hip.ptr(x), hip.ptr(gy), hip.ptr(g), hip.ptr(gx), hip.ptr(dyxh), b, c, t,
-                                                    ctx.eps, hip.stream_of(x)), "otp_ln_channel_backward")
-        return gx, _chan_sum3(dyxh).reshape(ctx.pshape), _chan_sum3(gy).reshape(ctx.pshape), None
+        gx, gg, gb = _ln_bwd(x, g, gy, ctx.eps, ctx.params[0], ctx.params[1])
+        return gx, gg.reshape(ctx.pshape), gb.reshape(ctx.pshape), None
 
 
 def layer_norm(x, gamma, beta, eps=1e-5):
     return LayerNormFunction.apply(x, gamma, beta, eps)
+
+
+def _dw_fwd(x, w, stride):
+    b, c, t = x.shape
+    to = (t + 2 - 3) // stride + 1
+    y = torch.empty((b, c, to), dtype=torch.float32, device=x.device)
+    hip.check(hip.lib().otp_dwconv3_forward(hip.ptr(x), hip.ptr(w), hip.ptr(y), b, c, t, stride, hip.stream_of(x)),
+              "otp_dwconv3_forward")
+    return y
+
+
+def _dw_bwd(x, w, gy, stride, pw):
+    b, c, t = x.shape
+    sw = grad_slot(pw)                                     # zero-filled by the optimizer's zero_grad; the kernel accumulates
+    gx, gw = torch.empty_like(x), (sw if sw is not None else torch.zeros_like(w))
+    hip.check(hip.lib().otp_dwconv3_backward(hip.ptr(x), hip.ptr(w), hip.ptr(gy.contiguous()), hip.ptr(gx), hip.ptr(gw),
+                                             b, c, t, stride, hip.stream_of(x)), "otp_dwconv3_backward")
+    return gx, gw
 
 
 class DwConv3Function(Function):
@@ -289,11 +319,7 @@ class DwConv3Function(Function):
     def forward(ctx, x, w, stride):
         _require_gpu(x, w)
         x, w = x.contiguous(), w.contiguous()
-        b, c, t = x.shape
-        to = (t + 2 - 3) // stride + 1
-        y = torch.empty((b, c, to), dtype=torch.float32, device=x.device)
-        hip.check(hip.lib().otp_dwconv3_forward(hip.ptr(x), hip.ptr(w), hip.ptr(y), b, c, t, stride, hip.stream_of(x)),
-                  "otp_dwconv3_forward")
+        y = _dw_fwd(x, w, stride)
         ctx.save_for_backward(x, w)
         ctx.stride = stride
         ctx.params = (w,)
@@ -302,16 +328,76 @@ class DwConv3Function(Function):
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
-        b, c, t = x.shape
-        sw = grad_slot(ctx.params[0])                      # zero-filled by the optimizer's zero_grad; the kernel accumulates
-        gx, gw = torch.empty_like(x), (sw if sw is not None else torch.zeros_like(w))
-        hip.check(hip.lib().otp_dwconv3_backward(hip.ptr(x), hip.ptr(w), hip.ptr(gy.contiguous()), hip.ptr(gx), hip.ptr(gw),
-                                                 b, c, t, ctx.stride, hip.stream_of(x)), "otp_dwconv3_backward")
+        gx, gw = _dw_bwd(x, w, gy, ctx.stride, ctx.params[0])
         return gx, gw, None
 
 
 def dwconv3(x, w, stride=1):
     return DwConv3Function.apply(x, w, stride)
+
+
+class AttnFrontFunction(Function):
+    """The front of MultiHeadConvAttention (model/blocks.py:400-440) as one node: ``xn = ln1(x)`` and, for query / key /
+    value, ``conv1d_1x1(LayerNorm(dwconv3(xn)))``.  Only ``x`` is kept for the backward; ``xn``, the three depthwise-conv
+    outputs and the three LayerNorm outputs (seven (B, C, T) tensors, 420 MB per block at cfg2 - 5 GB over the two temporal
+    encoders) are rebuilt there by the same seven launches (~160 us per block), branch by branch, so at most three of them are
+    alive at a time.  Arguments after ``eps``: ln1 weight / bias, then per branch (dwconv weight, LayerNorm weight, bias,
+    projection weight as (C, C, 1, 1), projection bias or None)."""
+
+    @staticmethod
+    def forward(ctx, x, stride, eps, g1, b1, *bp):
+        _require_gpu(x)
+        _check_f32(x)
+        x = x.contiguous()
+        ctx.cfg = (stride, eps)
+        ctx.params = (g1, b1) + tuple(bp)
+        xn = _ln_fwd(x, g1.reshape(-1).contiguous(), b1.reshape(-1).contiguous(), eps)
+        outs = []
+        for i in range(3):
+            dw, lg, lb, w4, bias = bp[5 * i: 5 * i + 5]
+            z = _ln_fwd(_dw_fwd(xn, dw.contiguous(), stride), lg.reshape(-1).contiguous(), lb.reshape(-1).contiguous(), eps)
+            outs.append(conv2d_forward(z.unsqueeze(2), w4.contiguous(), bias, 1, 0, 1).squeeze(2))
+        ctx.save_for_backward(x)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        (x,) = ctx.saved_tensors
+        stride, eps = ctx.cfg
+        g1, b1 = ctx.params[:2]
+        bp = ctx.params[2:]
+        g1f = g1.reshape(-1).contiguous()
+        xn = _ln_fwd(x, g1f, b1.reshape(-1).contiguous(), eps)
+        gxn, out = None, []
+        for i in range(3):
+            dw, lg, lb, w4, bias = bp[5 * i: 5 * i + 5]
+            if grads[i] is None:
+                out += [None] * 5
+                continue
+            g4 = grads[i].contiguous().unsqueeze(2)
+            lgf = lg.reshape(-1).contiguous()
+            y = _dw_fwd(xn, dw.contiguous(), stride)
+            z4 = _ln_fwd(y, lgf, lb.reshape(-1).contiguous(), eps).unsqueeze(2)
+            gz = conv2d_grad_input(g4, w4.contiguous(), z4.shape, 1, 0, 1).squeeze(2)
+            gw = conv2d_grad_weight(z4, g4, w4.shape, 1, 0, 1, grad_slot(w4))
+            gb = channel_sum(g4, grad_slot(bias)) if bias is not None else None
+            del z4
+            gy, glg, glb = _ln_bwd(y, lgf, gz, eps, lg, lb)
+            del y, gz
+            gxi, gdw = _dw_bwd(xn, dw.contiguous(), gy, stride, dw)
+            gxn = gxi if gxn is None else gxn.add_(gxi)
+            out += [gdw, glg.reshape(lg.shape), glb.reshape(lb.shape), gw, gb]
+        if gxn is None:
+            return (None,) * (5 + 15)
+        gx, gg1, gb1 = _ln_bwd(x, g1f, gxn, eps, g1, b1)
+        return (gx, None, None, gg1.reshape(g1.shape), gb1.reshape(b1.shape)) + tuple(out)
+
+
+def attn_front(x, stride, eps, ln1, branches):
+    """``branches``: three (dwconv weight, LayerNorm weight, LayerNorm bias, projection weight (C, C, 1, 1), bias) tuples
+    (query, key, value); ``ln1`` = (weight, bias).  Returns (q, k, v)."""
+    flat = [t for br in branches for t in br]
+    return AttnFrontFunction.apply(x, stride, eps, ln1[0], ln1[1], *flat)
 
 
 class GeluFunction(Function):

@@ -175,6 +175,42 @@ def test_dwconv3_backward(stride):
     _check_op(lambda x, w: F.conv1d(x, w, None, stride, 1, 1, 40), lambda x, w: T.dwconv3(x, w, stride), [x, w])
 
 
+@pytest.mark.parametrize("c,t,stride,bias", [(136, 700, 1, True), (17, 300, 1, False), (40, 101, 2, True)])
+def test_attn_front_recompute_matches_autograd(c, t, stride, bias):
+    """AttnFrontFunction (ln1 -> per q / k / v: dwconv3 -> LayerNorm -> Conv1d(k=1), intermediates rebuilt in the
+    backward) against the same composition under torch autograd on the CPU (model/blocks.py:400-440)."""
+    from otpose_amd import train_ops as T
+    x = seeded((2, c, t), 1) * 2 + 0.3
+    ln1 = [1 + 0.1 * seeded((1, c, 1), 2), seeded((1, c, 1), 3)]
+    br = []
+    for i in range(3):
+        br += [seeded((c, 1, 3), 10 + i, 0.5), 1 + 0.1 * seeded((1, c, 1), 20 + i), seeded((1, c, 1), 30 + i),
+               seeded((c, c, 1, 1), 40 + i, c ** -0.5)]
+        if bias:
+            br.append(seeded((c,), 50 + i))
+    nb = 5 if bias else 4
+
+    def ln(x, g, b):
+        mu = x.mean(1, keepdim=True)
+        r = x - mu
+        return r / torch.sqrt((r ** 2).mean(1, keepdim=True) + 1e-5) * g + b
+
+    def ref(x, g1, b1, *bp):
+        xn = ln(x, g1, b1)
+        outs = []
+        for i in range(3):
+            q = bp[nb * i: nb * i + nb]
+            z = ln(F.conv1d(xn, q[0], None, stride, 1, 1, c), q[1], q[2])
+            outs.append(F.conv1d(z, q[3].squeeze(-1), q[4] if bias else None))
+        return torch.stack(outs)
+
+    def ours(x, g1, b1, *bp):
+        branches = [tuple(bp[nb * i: nb * i + nb]) + (() if bias else (None,)) for i in range(3)]
+        return torch.stack(T.attn_front(x, stride, 1e-5, (g1, b1), branches))
+
+    _check_op(ref, ours, [x] + ln1 + br, 2e-4)
+
+
 def test_gelu_maxpool_upsample_backward():
     from otpose_amd import train_ops as T
     x = seeded((2, 17, 96), 1) * 2
