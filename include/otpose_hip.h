@@ -443,6 +443,12 @@ int otp_nhwc_conv_pack_batch(const void* jobs_device, int n_jobs, void* stream);
 /* out = conv(x) (+ bias, fp32 (Cout), may be NULL); stats may be NULL */
 int otp_nhwc_conv_bf16(const void* x, const void* wpacked, const void* bias, void* out, void* stats,
                        const otp_nhwc_conv_desc* desc, void* stream);
+/* out = bf16(conv(x) + bias) + res: `res` (N, Ho, Wo, CoutS) bf16 is added to the ROUNDED conv result and the sum rounded
+ * again - bit for bit what a separate bf16 add of the two tensors gives (out_mode 0 only, stats must be NULL).  The input-
+ * gradient conv of a residual block's first layer takes the gradient of the skip connection here (a BasicBlock's dL/dx is
+ * dgrad(conv1) + dL/dres: one pass over the tensor less than summing afterwards); res == NULL is otp_nhwc_conv_bf16. */
+int otp_nhwc_conv_bf16_res(const void* x, const void* wpacked, const void* bias, const void* res, void* out, void* stats,
+                           const otp_nhwc_conv_desc* desc, void* stream);
 /* grad_weight (Cout, Cin, kh, kw) fp32 is OVERWRITTEN with sum over batch and pixels of grad_out x shifted input;
  * x (N, H, W, CinS) and grad_out (N, Ho, Wo, CoutS) bf16; 1x1 and 3x3 kernels */
 size_t otp_nhwc_wgrad_workspace(const otp_nhwc_conv_desc* desc);

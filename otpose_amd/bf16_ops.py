@@ -170,8 +170,9 @@ def conv_forward(x, weight, bias=None, stride=1, pad=0, dil=1, out_mode=0, want_
     return out, stats, rows
 
 
-def conv_dgrad(gy, weight, in_hw, stride, pad, dil, packs=None):
-    """dL/dx of ``conv_forward``: gy (N, Ho, Wo, CoutS) bf16 -> (N, H, W, CinS) bf16."""
+def conv_dgrad(gy, weight, in_hw, stride, pad, dil, packs=None, res=None):
+    """dL/dx of ``conv_forward``: gy (N, Ho, Wo, CoutS) bf16 -> (N, H, W, CinS) bf16.  ``res`` (same shape as the result) is
+    added in the kernel's epilogue: the gradient arriving over a skip connection (bit-identical to a separate bf16 add)."""
     cout, cin, kh, kw = weight.shape
     n = gy.shape[0]
     h, w = in_hw
@@ -186,8 +187,10 @@ def conv_dgrad(gy, weight, in_hw, stride, pad, dil, packs=None):
     d = _desc(n, g.shape[1], g.shape[2], cout, cin, kh, kw, 1, dil * (kh - 1) - pad, dil, 0)
     wp = _pack(weight.contiguous(), d, 1, packs)
     gx = _new((n, h, w, cs(cin)), BF16, gy)
-    hip.check(L.otp_nhwc_conv_bf16(hip.ptr(g), hip.ptr(wp), None, hip.ptr(gx), None, ctypes.byref(d), hip.stream_of(gy)),
-              "otp_nhwc_conv_bf16(dgrad)")
+    if res is not None:
+        assert res.shape == gx.shape and res.dtype == BF16 and res.is_contiguous()
+    hip.check(L.otp_nhwc_conv_bf16_res(hip.ptr(g), hip.ptr(wp), None, hip.ptr(res), hip.ptr(gx), None, ctypes.byref(d),
+                                       hip.stream_of(gy)), "otp_nhwc_conv_bf16_res(dgrad)")
     return gx
 
 
@@ -295,6 +298,50 @@ class ConvBnFunction(Function):
 def conv_bn(x, weight, gamma, beta, res=None, running_mean=None, running_var=None, stride=1, pad=0, relu=True,
             momentum=0.1, eps=1e-5):
     return ConvBnFunction.apply(x, weight, gamma, beta, res, running_mean, running_var, stride, pad, relu, momentum, eps)
+
+
+class BasicBlockFunction(Function):
+    """``relu(bn2(conv2(relu(bn1(conv1(x))))) + x)`` - an HRNet BasicBlock without down-sample path (model/HRNet.py:500-531;
+    every block of stages 2-4) as ONE autograd node.  Same kernels and the same saved tensors as two :class:`ConvBnFunction`
+    nodes; what the node adds is the backward's knowledge of the skip connection: dL/dx = dgrad(conv1) + dL/dres leaves the
+    input-gradient conv already summed (``otp_nhwc_conv_bf16_res``) instead of autograd adding two tensors afterwards (108
+    blocks at cfg2: a 160 MB pass each), and the host builds half as many nodes."""
+
+    @staticmethod
+    def forward(ctx, x, w1, g1, b1, rm1, rv1, w2, g2, b2, rm2, rv2, momentum, eps):
+        _require_gpu(x, w1, w2)
+        x = x.contiguous()
+        ctx.packs = _ACTIVE_PACKS
+        c1, st1, rows1 = conv_forward(x, w1, None, 1, 1, 1, packs=ctx.packs)
+        vec1 = bn_finalize(st1, rows1, w1.shape[0], c1.numel() // c1.shape[-1], g1, b1, rm1, rv1, momentum, eps)
+        y1, m1 = bn_apply(c1, vec1[2], vec1[3], None, True, want_mask=True)
+        c2, st2, rows2 = conv_forward(y1, w2, None, 1, 1, 1, packs=ctx.packs)
+        vec2 = bn_finalize(st2, rows2, w2.shape[0], c2.numel() // c2.shape[-1], g2, b2, rm2, rv2, momentum, eps)
+        y2, m2 = bn_apply(c2, vec2[2], vec2[3], x, True, want_mask=True)
+        ctx.save_for_backward(x, w1, g1, c1, m1, vec1, y1, w2, g2, c2, m2, vec2)
+        ctx.params = (w1, g1, b1, w2, g2, b2)
+        return y2
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w1, g1, c1, m1, vec1, y1, w2, g2, c2, m2, vec2 = ctx.saved_tensors
+        pw1, pg1, pb1, pw2, pg2, pb2 = ctx.params
+        gy = gy.contiguous()
+        gc2, gres, dg2, db2 = bn_backward(gy, m2, c2, vec2[0], vec2[1], g2, w2.shape[0], True, True, grad_slot(pg2),
+                                          grad_slot(pb2))
+        gy1 = conv_dgrad(gc2, w2, y1.shape[1:3], 1, 1, 1, ctx.packs)
+        gw2 = conv_wgrad(y1, gc2, w2.shape, 1, 1, 1, grad_slot(pw2))
+        del gc2
+        gc1, _, dg1, db1 = bn_backward(gy1, m1, c1, vec1[0], vec1[1], g1, w1.shape[0], True, False, grad_slot(pg1),
+                                       grad_slot(pb1))
+        del gy1
+        gx = conv_dgrad(gc1, w1, x.shape[1:3], 1, 1, 1, ctx.packs, res=gres)
+        gw1 = conv_wgrad(x, gc1, w1.shape, 1, 1, 1, grad_slot(pw1))
+        return gx, gw1, dg1, db1, None, None, gw2, dg2, db2, None, None, None, None
+
+
+def basic_block(x, w1, g1, b1, rm1, rv1, w2, g2, b2, rm2, rv2, momentum=0.1, eps=1e-5):
+    return BasicBlockFunction.apply(x, w1, g1, b1, rm1, rv1, w2, g2, b2, rm2, rv2, momentum, eps)
 
 
 class ConvOutFunction(Function):

@@ -222,9 +222,9 @@ __device__ __forceinline__ float row16_sum(float v) {
 // tools/nhwc_timing.py).  Contains workgroup barriers; every thread of the workgroup must call it.
 template <int MB, int NB>
 __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[MB][NB], const bool (&valid)[NB], const ConvPlan& p,
-                                              const float* __restrict__ bias, bf16* __restrict__ out,
-                                              float* __restrict__ out_f32, float* __restrict__ stats, unsigned char* smem,
-                                              float* sRed, int n, int tile, int mt, int p0, int npx) {
+                                              const float* __restrict__ bias, const bf16* __restrict__ res,
+                                              bf16* __restrict__ out, float* __restrict__ out_f32, float* __restrict__ stats,
+                                              unsigned char* smem, float* sRed, int n, int tile, int mt, int p0, int npx) {
     constexpr int BM = MB * 16, P = 64 * NB, BMS = BM + 8;      // LDS row stride: 16-byte aligned, odd multiple of 16 bytes
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
     if (p.out_mode == 1) {                                       // fp32 NCHW (hand-over to the fp32 NCHW kernels)
@@ -287,9 +287,16 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[MB][NB], const bool (
     const int pmax = min(P, npx - p0);
     for (int u = tid; u < units; u += 256) {
         const int px = u / cu8, cg = u - px * cu8;
-        if (px < pmax)
-            *reinterpret_cast<u32x4*>(out + ((size_t)n * npx + p0 + px) * p.CoutS + mt * BM + cg * 8) =
-                *reinterpret_cast<const u32x4*>(sOut + px * BMS + cg * 8);
+        if (px < pmax) {
+            const size_t o = ((size_t)n * npx + p0 + px) * p.CoutS + mt * BM + cg * 8;
+            bf16x8 v = *reinterpret_cast<const bf16x8*>(sOut + px * BMS + cg * 8);
+            if (res) {                                           // out = bf16(conv) + res, rounded once more: what a separate
+                const bf16x8 r = *reinterpret_cast<const bf16x8*>(res + o);       // bf16 add kernel would produce
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (bf16)(bf2f(v[e]) + bf2f(r[e]));
+            }
+            *reinterpret_cast<bf16x8*>(out + o) = v;
+        }
     }
     if (stats) {
         for (int i = tid; i < 2 * BM; i += 256) {
@@ -306,8 +313,9 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[MB][NB], const bool (
 
 template <int MB, int NB, bool K7>
 __global__ __launch_bounds__(256) void nhwc_conv_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wpk,
-                                                         const float* __restrict__ bias, bf16* __restrict__ out,
-                                                         float* __restrict__ out_f32, float* __restrict__ stats, ConvPlan p) {
+                                                         const float* __restrict__ bias, const bf16* __restrict__ res,
+                                                         bf16* __restrict__ out, float* __restrict__ out_f32,
+                                                         float* __restrict__ stats, ConvPlan p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16* sW = reinterpret_cast<bf16*>(smem);
     bf16* sX = reinterpret_cast<bf16*>(smem + p.ldsW);
@@ -430,24 +438,27 @@ __global__ __launch_bounds__(256) void nhwc_conv_kernel(const bf16* __restrict__
     }
 
     OTP_STAMP(4);
-    conv_epilogue<MB, NB>(acc, valid, p, bias, out, out_f32, stats, smem, sRed, n, tile, mt, p0, npx);
+    conv_epilogue<MB, NB>(acc, valid, p, bias, res, out, out_f32, stats, smem, sRed, n, tile, mt, p0, npx);
     OTP_STAMP(5);
 }
 
 template <int MB, int NB, bool K7>
-int launch_conv_k(const ConvPlan& p, const void* x, const void* wpk, const void* bias, void* out, void* stats, hipStream_t st) {
+int launch_conv_k(const ConvPlan& p, const void* x, const void* wpk, const void* bias, const void* res, void* out, void* stats,
+                  hipStream_t st) {
     auto kern = nhwc_conv_kernel<MB, NB, K7>;
     OTP_ALLOW_BIG_LDS(kern, p.lds);
     const int grid = p.N * p.tilesPerImg * p.nM;
     kern<<<grid, 256, p.lds, st>>>(static_cast<const bf16*>(x), static_cast<const bf16*>(wpk), static_cast<const float*>(bias),
-                                   static_cast<bf16*>(out), static_cast<float*>(out), static_cast<float*>(stats), p);
+                                   static_cast<const bf16*>(res), static_cast<bf16*>(out), static_cast<float*>(out),
+                                   static_cast<float*>(stats), p);
     return otp_launch_status();
 }
 
 template <int MB, int NB>
-int launch_conv(const ConvPlan& p, const void* x, const void* wpk, const void* bias, void* out, void* stats, hipStream_t st) {
-    return p.KS == 7 ? launch_conv_k<MB, NB, true>(p, x, wpk, bias, out, stats, st)
-                     : launch_conv_k<MB, NB, false>(p, x, wpk, bias, out, stats, st);
+int launch_conv(const ConvPlan& p, const void* x, const void* wpk, const void* bias, const void* res, void* out, void* stats,
+                hipStream_t st) {
+    return p.KS == 7 ? launch_conv_k<MB, NB, true>(p, x, wpk, bias, res, out, stats, st)
+                     : launch_conv_k<MB, NB, false>(p, x, wpk, bias, res, out, stats, st);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1277,19 +1288,25 @@ extern "C" int otp_nhwc_conv_pack_batch(const void* jobs_device, int n_jobs, voi
     return otp_launch_status();
 }
 
-extern "C" int otp_nhwc_conv_bf16(const void* x, const void* wpacked, const void* bias, void* out, void* stats,
-                                  const otp_nhwc_conv_desc* d, void* stream) {
+extern "C" int otp_nhwc_conv_bf16_res(const void* x, const void* wpacked, const void* bias, const void* res, void* out,
+                                      void* stats, const otp_nhwc_conv_desc* d, void* stream) {
     ConvPlan p;
     if (!x || !wpacked || !out) return OTP_ERR_BAD_ARG;
     if (!make_plan(d, &p)) return OTP_ERR_UNSUPPORTED;
+    if (res && (p.out_mode != 0 || stats)) return OTP_ERR_BAD_ARG;   // the sum is an NHWC bf16 tensor; statistics are of conv(x)
     hipStream_t st = static_cast<hipStream_t>(stream);
 #define OTP_NHWC_CASE(mb, nb) \
-    if (p.MB == mb && p.NB == nb) return launch_conv<mb, nb>(p, x, wpacked, bias, out, stats, st)
+    if (p.MB == mb && p.NB == nb) return launch_conv<mb, nb>(p, x, wpacked, bias, res, out, stats, st)
     OTP_NHWC_CASE(1, 2); OTP_NHWC_CASE(2, 2); OTP_NHWC_CASE(3, 2); OTP_NHWC_CASE(4, 2); OTP_NHWC_CASE(5, 2); OTP_NHWC_CASE(6, 2);
     OTP_NHWC_CASE(7, 2); OTP_NHWC_CASE(8, 2); OTP_NHWC_CASE(9, 2);
     OTP_NHWC_CASE(1, 4); OTP_NHWC_CASE(2, 4); OTP_NHWC_CASE(3, 4); OTP_NHWC_CASE(4, 4); OTP_NHWC_CASE(5, 4); OTP_NHWC_CASE(6, 4);
 #undef OTP_NHWC_CASE
     return OTP_ERR_UNSUPPORTED;
+}
+
+extern "C" int otp_nhwc_conv_bf16(const void* x, const void* wpacked, const void* bias, void* out, void* stats,
+                                  const otp_nhwc_conv_desc* d, void* stream) {
+    return otp_nhwc_conv_bf16_res(x, wpacked, bias, nullptr, out, stats, d, stream);
 }
 
 extern "C" size_t otp_nhwc_wgrad_workspace(const otp_nhwc_conv_desc* d) {

@@ -147,6 +147,7 @@ SIGNATURES = {
     "otp_nhwc_conv_pack_job": (c_int, [c_void_p, c_void_p, _ND, c_int, c_void_p]),
     "otp_nhwc_conv_pack_batch": (c_int, [c_void_p, c_int, c_void_p]),
     "otp_nhwc_conv_bf16": (c_int, [c_void_p] * 5 + [_ND, c_void_p]),
+    "otp_nhwc_conv_bf16_res": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, _ND, c_void_p]),
     "otp_nhwc_wgrad_workspace": (c_size_t, [_ND]),
     "otp_nhwc_wgrad_bf16": (c_int, [c_void_p] * 4 + [c_size_t, _ND, c_void_p]),
     "otp_nhwc_bn_finalize": (c_int, [c_void_p, c_int, c_int, c_int, c_float] + [c_void_p] * 8 + [c_float, c_float, c_void_p]),

@@ -556,6 +556,17 @@ class TrainGraphBF16(TrainGraph):
         return B16.conv_bn(x, self.P[conv + ".weight"], self.P[bn + ".weight"], self.P[bn + ".bias"], res,
                            self.Bf[bn + ".running_mean"], self.Bf[bn + ".running_var"], stride, pad, relu, 0.1, 1e-5)
 
+    def basic_block(self, p, x):
+        if (x.dtype != B16.BF16 or self.has(p + ".downsample.0.weight") or os.environ.get("OTPOSE_BLOCK_FUSE", "1") == "0"):
+            return super().basic_block(p, x)
+        self.count_batch(p + ".bn1")
+        self.count_batch(p + ".bn2")
+        P, Bf = self.P, self.Bf
+        return B16.basic_block(x, P[p + ".conv1.weight"], P[p + ".bn1.weight"], P[p + ".bn1.bias"],
+                               Bf[p + ".bn1.running_mean"], Bf[p + ".bn1.running_var"],
+                               P[p + ".conv2.weight"], P[p + ".bn2.weight"], P[p + ".bn2.bias"],
+                               Bf[p + ".bn2.running_mean"], Bf[p + ".bn2.running_var"], 0.1, 1e-5)
+
     def upsample_add(self, low, y, f, relu):
         if low.dtype != B16.BF16:
             return super().upsample_add(low, y, f, relu)

@@ -368,11 +368,10 @@ class AttnFrontFunction(Function):
         bp = ctx.params[2:]
         g1f = g1.reshape(-1).contiguous()
         xn = _ln_fwd(x, g1f, b1.reshape(-1).contiguous(), eps)
-        gxn, out = None, []
-        for i in range(3):
+        gxn, out = None, [None] * 15
+        for i in (2, 1, 0):                   # value, key, query: the order autograd would run (and sum) the per-layer nodes in
             dw, lg, lb, w4, bias = bp[5 * i: 5 * i + 5]
             if grads[i] is None:
-                out += [None] * 5
                 continue
             g4 = grads[i].contiguous().unsqueeze(2)
             lgf = lg.reshape(-1).contiguous()
@@ -386,7 +385,7 @@ class AttnFrontFunction(Function):
             del y, gz
             gxi, gdw = _dw_bwd(xn, dw.contiguous(), gy, stride, dw)
             gxn = gxi if gxn is None else gxn.add_(gxi)
-            out += [gdw, glg.reshape(lg.shape), glb.reshape(lb.shape), gw, gb]
+            out[5 * i: 5 * i + 5] = [gdw, glg.reshape(lg.shape), glb.reshape(lb.shape), gw, gb]
         if gxn is None:
             return (None,) * (5 + 15)
         gx, gg1, gb1 = _ln_bwd(x, g1f, gxn, eps, g1, b1)

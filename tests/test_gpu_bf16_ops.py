@@ -210,3 +210,47 @@ def test_mlp_interior_matches_fp32_reference():
     close(w2d.grad, w2r.grad, 2e-2)
     close(b1d.grad, b1r.grad, 2e-2)
     close(b2d.grad, b2r.grad, 1e-4)
+
+
+@pytest.mark.parametrize("case", [(3, 48, 48, 24, 18), (2, 96, 96, 12, 9), (2, 20, 44, 10, 7)])
+def test_conv_dgrad_with_skip_gradient_is_the_separate_add(case):
+    """otp_nhwc_conv_bf16_res: the input-gradient conv with the skip connection's gradient added in its epilogue equals
+    the plain launch followed by a bf16 tensor add, bit for bit (the conv result is rounded to bf16 before the add in both)."""
+    from otpose_amd import bf16_ops as B
+    from tests.conftest import seeded
+    n, cin, cout, h, w = case
+    wt = (seeded((cout, cin, 3, 3), 1) * (2.0 / (cin * 9)) ** 0.5).to(_dev())
+    gy = _nhwc(_rb(seeded((n, cout, h, w), 2)))
+    res = _nhwc(_rb(seeded((n, cin, h, w), 3)))
+    plain = B.conv_dgrad(gy, wt, (h, w), 1, 1, 1)
+    fused = B.conv_dgrad(gy, wt, (h, w), 1, 1, 1, res=res)
+    assert torch.equal(fused, plain + res)
+
+
+def test_basic_block_node_matches_two_conv_bn_nodes():
+    """BasicBlockFunction against the two ConvBnFunction nodes it replaces (model/HRNet.py:500-531): same launches, so
+    the output, the running statistics and every gradient agree exactly - dL/dx included, where the fused node adds the skip
+    gradient inside the input-gradient conv instead of leaving the sum to autograd."""
+    from otpose_amd import bf16_ops as B
+    from tests.conftest import seeded
+    n, c, h, w = 3, 48, 24, 18
+    x0 = _nhwc(_rb(seeded((n, c, h, w), 1)))
+    go = _nhwc(_rb(seeded((n, c, h, w), 9)))
+    mk = lambda s_, shape, k=1.0: (seeded(shape, s_) * k).to(_dev())                       # noqa: E731
+    base = dict(w1=mk(2, (c, c, 3, 3), 0.05), g1=1 + mk(3, (c,), 0.1), b1=mk(4, (c,), 0.1),
+                w2=mk(5, (c, c, 3, 3), 0.05), g2=1 + mk(6, (c,), 0.1), b2=mk(7, (c,), 0.1))
+    res = {}
+    for mode in ("nodes", "block"):
+        x = x0.clone().requires_grad_()
+        P = {k: v.clone().requires_grad_() for k, v in base.items()}
+        st = [torch.zeros(c, device=_dev()), torch.ones(c, device=_dev()), torch.zeros(c, device=_dev()),
+              torch.ones(c, device=_dev())]
+        if mode == "nodes":
+            y1 = B.conv_bn(x, P["w1"], P["g1"], P["b1"], None, st[0], st[1], 1, 1, True)
+            y = B.conv_bn(y1, P["w2"], P["g2"], P["b2"], x, st[2], st[3], 1, 1, True)
+        else:
+            y = B.basic_block(x, P["w1"], P["g1"], P["b1"], st[0], st[1], P["w2"], P["g2"], P["b2"], st[2], st[3])
+        y.backward(go)
+        res[mode] = [y.detach(), x.grad] + [P[k].grad for k in sorted(P)] + st
+    for a, b in zip(res["nodes"], res["block"]):
+        assert torch.equal(a, b)

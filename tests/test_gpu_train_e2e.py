@@ -268,8 +268,10 @@ def test_bf16_step_on_a_cfg2_shaped_clip():
 
 def test_bf16_step_same_with_and_without_streams_and_batched_packs(monkeypatch):
     """The scheduling of the bf16 step - HRNet branches / temporal encoders on side streams, every weight re-layout in one
-    launch per step (bf16_ops.PackCache) - must not change its arithmetic: with both switched off (one stream, a pack
-    launch per use) three forward / backward passes give the same losses and gradients.  The weights are rescaled by 1 %
+    launch per step (bf16_ops.PackCache), BasicBlocks and attention fronts as single autograd nodes (skip gradient added in
+    the input-gradient conv, intermediates rebuilt in the backward) - must not change its arithmetic: with all of it
+    switched off (one stream, a pack launch per use, per-layer nodes) three forward / backward passes give the same losses
+    and gradients.  The weights are rescaled by 1 %
     between the passes, so an operator left over from the previous pass (a job missed by the batched launch, a launch
     ordered before the rescale) would show as a 1e-2 error; pass 2 and 3 are the ones that read batched re-layouts.
     (No optimizer in the loop: Adam's first steps are lr * sign(g) and turn the last-bit differences of the atomically
@@ -284,8 +286,9 @@ def test_bf16_step_same_with_and_without_streams_and_batched_packs(monkeypatch):
     g, wt = _targets(2, cfg.MODEL.NUM_JOINTS, h, w)
     g, wt = g.cuda(), wt.cuda()
     runs = {}
-    for name, env in (("plain", {"OTPOSE_TRAIN_STREAMS": "0", "OTPOSE_PACK_BATCH": "0"}), ("scheduled", {})):
-        for k in ("OTPOSE_TRAIN_STREAMS", "OTPOSE_PACK_BATCH"):
+    for name, env in (("plain", {"OTPOSE_TRAIN_STREAMS": "0", "OTPOSE_PACK_BATCH": "0", "OTPOSE_BLOCK_FUSE": "0",
+                                 "OTPOSE_TRAIN_RECOMPUTE": "0"}), ("scheduled", {})):
+        for k in ("OTPOSE_TRAIN_STREAMS", "OTPOSE_PACK_BATCH", "OTPOSE_BLOCK_FUSE", "OTPOSE_TRAIN_RECOMPUTE"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
