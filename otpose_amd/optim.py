@@ -55,7 +55,8 @@ class FusedAdamW(torch.optim.Optimizer):
                 p._otp_grad_slot = p.grad
                 self.state[p] = {"step": 0, "exp_avg": fm[off:off + n].view_as(p), "exp_avg_sq": fv[off:off + n].view_as(p)}
                 off += n
-            self._flat.append({"p": fp, "g": fg, "m": fm, "v": fv, "params": ps, "step": 0})
+            self._flat.append({"p": fp, "g": fg, "m": fm, "v": fv, "params": ps, "step": 0,
+                               "gptr": [p._otp_grad_slot.data_ptr() for p in ps]})
         devs = {f["p"].device for f in self._flat if f}
         self._normsq = {d: torch.zeros(1, dtype=torch.float64, device=d) for d in devs}
 
@@ -68,17 +69,17 @@ class FusedAdamW(torch.optim.Optimizer):
         for f in self._flat:
             if not f:
                 continue
-            off = 0
-            for p in f["params"]:
-                n = p.numel()
-                slot = f["g"][off:off + n]
-                if p.grad is None:
+            # fast path (every step): one pointer comparison per parameter, no tensor objects created
+            for p, ptr in zip(f["params"], f["gptr"]):
+                g = p.grad
+                if g is not None and g.data_ptr() == ptr:
+                    continue
+                slot = p._otp_grad_slot
+                if g is None:
                     slot.zero_()
-                    p.grad = slot.view_as(p)
-                elif p.grad.data_ptr() != slot.data_ptr():
-                    slot.copy_(p.grad.reshape(-1))
-                    p.grad = slot.view_as(p)
-                off += n
+                else:
+                    slot.copy_(g.reshape(slot.shape))
+                p.grad = slot.view(slot.shape)
 
     def flat_grads(self):
         """The flat gradient buffers (one per group) - the units to all-reduce."""
@@ -97,10 +98,11 @@ class FusedAdamW(torch.optim.Optimizer):
                     p.grad = None
 
     @torch.no_grad()
-    def grad_norm(self):
+    def grad_norm(self, _rehomed=False):
         """Global L2 norm of all gradients as a device scalar (what clip_grad_norm_ returns), no host sync."""
         L = hip.lib()
-        self._rehome_grads()
+        if not _rehomed:
+            self._rehome_grads()
         for acc in self._normsq.values():
             acc.zero_()
         for f in self._flat:
@@ -117,7 +119,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self._rehome_grads()
         clip = self.max_grad_norm > 0.0
         if clip:
-            self.grad_norm()
+            self.grad_norm(_rehomed=True)
         for group, f in zip(self.param_groups, self._flat):
             if not f:
                 continue
@@ -128,10 +130,19 @@ class FusedAdamW(torch.optim.Optimizer):
                                        float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                                        float(group["weight_decay"]), f["step"], hip.ptr(acc) if clip else None,
                                        self.max_grad_norm, hip.stream_of(f["p"])), "otp_adamw_step")
-            for p in f["params"]:
-                self.state[p]["step"] = f["step"]
             _bump_versions(f["params"])
         return loss
+
+    def _sync_state_steps(self):
+        """``state[p]["step"]`` of every parameter from its group's counter (kept per group on the hot path)."""
+        for f in self._flat:
+            if f:
+                for p in f["params"]:
+                    self.state[p]["step"] = f["step"]
+
+    def state_dict(self):
+        self._sync_state_steps()
+        return super().state_dict()
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
