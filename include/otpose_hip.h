@@ -277,6 +277,22 @@ int otp_mlp_x3(const void* x, const void* packed, const void* scale, const void*
 int otp_ln_mlp_x3(const void* y, const void* ln_gamma, const void* ln_beta, float ln_eps, const void* packed,
                   const void* scale, const void* shift, void* out, int B, int C, int HID, int T, void* stream);
 
+/* TransformerBlock of the flow encoder (C = num_joints = 17 channels, stride 1; model/blocks.py:264-280, 400-453 as built
+ * by model/OTPose.py:209-216) around the channel attention as two launches (csrc/flowenc.hip): a thread owns a time step
+ * and its 17 channels, weights arrive through the scalar cache.
+ *   otp_flow_front: q, k, v (B, C, T) = Conv1d_1x1(LayerNorm(dwconv3(ln1(x))))  [blocks.py:411-419 behind :272]
+ *   otp_flow_back : out = y + s_m * (W_2 gelu(W_1 ln2(y) + b_1) + b_2),  y = x + s_a * (W_p att + b_p)   [blocks.py:450, 272-279]
+ * with `att` the (B, C, T) view of otp_chan_attn's output.  Parameter blocks (fp32, device memory):
+ *   front: ln1 gamma[C], beta[C]; for q, k, v: dw[C][3], norm gamma[C], norm beta[C], W[C][C] (out, in), bias[C]
+ *   back : W_p[C][C] * s_a[out], b_p[C] * s_a; ln2 gamma[C], beta[C]; W_1[H][C], b_1[H]; W_2^T[H][C] * s_m[out], b_2[C] * s_m
+ * (otp_flow_*_param_floats give their sizes; 0 = unsupported C). */
+int otp_flow_block_supported(int C, int hidden, int T);
+size_t otp_flow_front_param_floats(int C);
+size_t otp_flow_back_param_floats(int C, int hidden);
+int otp_flow_front(const void* x, const void* params, void* q, void* k, void* v, int B, int C, int T, float eps, void* stream);
+int otp_flow_back(const void* x, const void* att, const void* params, void* out, int B, int C, int hidden, int T, float eps,
+                  void* stream);
+
 /* The C -> C pointwise projections of MaskedMHCA (query / key / value / proj: model/blocks.py:383-386, applied at :417-419
  * and :450) on (B, C, T) tensors, nprob (1..3) independent problems of one shape per launch:
  *   out[p] = scale[p] * (W[p] . x[p]) + shift[p] (+ res[p]);   res may be NULL, or hold NULL entries.

@@ -60,6 +60,7 @@ class InferenceEngine:
         self.use_x3 = os.environ.get("OTPOSE_CONV_MATH", "x3") != "f32"
         # offset / mask convs + DCN gathers of all dilations in one launch (split-bf16 products for the convs)
         self.use_dcn_fused = self.use_x3 and os.environ.get("OTPOSE_DCN_FUSED", "1") != "0"
+        self.use_flow_fused = os.environ.get("OTPOSE_FLOW_FUSED", "1") != "0"       # flow-encoder blocks via csrc/flowenc.hip
         self.use_small_conv = os.environ.get("OTPOSE_SMALL_CONV", "1") != "0"       # RSB staircase convs via csrc/conv_small.hip
         self.use_fused_mlp = os.environ.get("OTPOSE_FUSED_MLP", "1") != "0"   # transformer MLP via csrc/mlp.hip
         self.fuse_shortcut = os.environ.get("OTPOSE_FUSE_SHORTCUT", "1") != "0"  # layer1 shortcut folded into conv3
@@ -418,6 +419,21 @@ class InferenceEngine:
         To = T if stride == 1 else (T + 2 - 3) // 2 + 1
         L = self.lib
         a = blk.attn
+        if self.use_flow_fused and stride == 1 and ops.flow_block_supported(blk, C, T):
+            # the C = 17 flow encoder: per-token chains in two launches around the attention (csrc/flowenc.hip); the generic
+            # kernels below are latency bound at this width (12 launches per block on the serial path)
+            fp, bp = ops.pack_flow_front(blk, self.dev), ops.pack_flow_back(blk, self.dev)
+            self._keep += [fp, bp]
+            q, k, v, att, out = (self.new(B, C, T) for _ in range(5))
+            self.call(L.otp_flow_front, "otp_flow_front", hip.ptr(x), hip.ptr(fp), hip.ptr(q), hip.ptr(k), hip.ptr(v),
+                      B, C, T, blk.ln1.eps)
+            nbytes = L.otp_chan_attn_workspace(B, C, T, a.n_head)
+            ws = self.new(max(nbytes // 4, 1))
+            self.call(L.otp_chan_attn, "otp_chan_attn", hip.ptr(q), hip.ptr(k), hip.ptr(v), hip.ptr(att), hip.ptr(ws),
+                      nbytes, B, C, T, a.n_head, a.scale)
+            self.call(L.otp_flow_back, "otp_flow_back", hip.ptr(x), hip.ptr(att), hip.ptr(bp), hip.ptr(out), B, C,
+                      blk.mlp[0].out_channels, T, blk.ln2.eps)
+            return out
         ln1 = self.new(B, C, T)
         skip = self.new(B, C, To) if stride > 1 else None
         p = self.dev_param

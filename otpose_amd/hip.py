@@ -112,6 +112,11 @@ SIGNATURES = {
     "otp_mlp_x3_weight_bytes": (c_size_t, [c_int] * 2),
     "otp_mlp_x3_pack": (c_int, [c_void_p] * 4 + [c_int] * 2 + [c_void_p]),
     "otp_mlp_x3": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_void_p]),
+    "otp_flow_block_supported": (c_int, [c_int] * 3),
+    "otp_flow_front_param_floats": (c_size_t, [c_int]),
+    "otp_flow_back_param_floats": (c_size_t, [c_int, c_int]),
+    "otp_flow_front": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_float, c_void_p]),
+    "otp_flow_back": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_float, c_void_p]),
     "otp_ln_mlp_x3": (c_int, [c_void_p] * 3 + [c_float] + [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
     "otp_chan_attn": (c_int, [c_void_p] * 4 + [c_void_p, c_size_t] + [c_int] * 4 + [c_float, c_void_p]),
     "otp_chan_attn_splits": (c_int, [c_int, c_int]),

@@ -839,3 +839,72 @@ def joint_mse_loss(output, target, target_weight=None, effective_num_joints=None
     """JointMSELoss.forward (model/loss.py:158-182) on the GPU: a scalar (and its gradient when requested)."""
     res, go = _joints_mse(output, target, target_weight, 1, False, effective_num_joints, with_grad)
     return (res[2], go) if with_grad else res[2]
+
+
+# ---- flow-encoder TransformerBlock (C = 17) as two launches around the channel attention (csrc/flowenc.hip) ---------------
+def flow_block_supported(blk, c, t) -> bool:
+    """Stride-1 TransformerBlock with 17 channels, biases everywhere and one epsilon for ln1 and the q / k / v norms."""
+    a = blk.attn
+    try:
+        eps = {float(m.eps) for m in (blk.ln1, a.query_norm, a.key_norm, a.value_norm)}
+        has_bias = all(m.bias is not None for m in (a.query, a.key, a.value, a.proj, blk.mlp[0], blk.mlp[3]))
+        dw_ok = all(tuple(m.weight.shape) == (c, 1, 3) and m.bias is None for m in (a.query_conv, a.key_conv, a.value_conv))
+    except AttributeError:
+        return False
+    return (len(eps) == 1 and has_bias and dw_ok
+            and bool(hip.lib().otp_flow_block_supported(int(c), int(blk.mlp[0].out_channels), int(t))))
+
+
+def pack_flow_front(blk, device):
+    """Parameter block of ``otp_flow_front`` (layout: include/otpose_hip.h) from a TransformerBlock's modules."""
+    a = blk.attn
+    f = lambda t: t.detach().to(device, torch.float32).reshape(-1)                     # noqa: E731
+    parts = [f(blk.ln1.weight), f(blk.ln1.bias)]
+    for conv, norm, proj in ((a.query_conv, a.query_norm, a.query), (a.key_conv, a.key_norm, a.key),
+                             (a.value_conv, a.value_norm, a.value)):
+        parts += [f(conv.weight), f(norm.weight), f(norm.bias), f(proj.weight), f(proj.bias)]
+    prm = torch.cat(parts).contiguous()
+    c = blk.ln1.weight.numel()
+    assert prm.numel() == hip.lib().otp_flow_front_param_floats(c), (prm.numel(), c)
+    return prm
+
+
+def pack_flow_back(blk, device):
+    """Parameter block of ``otp_flow_back``: the drop-path scales (model/blocks.py:298-301, eval: plain per-channel factors)
+    folded into the projection / down-projection rows and biases; W_2 transposed to (hidden, C)."""
+    a = blk.attn
+    d = lambda t: t.detach().to(device, torch.float32)                                 # noqa: E731
+    c = blk.ln1.weight.numel()
+    hid = blk.mlp[0].out_channels
+    sa, sm = d(blk.drop_path_attn.scale).reshape(-1), d(blk.drop_path_mlp.scale).reshape(-1)
+    wp = d(a.proj.weight).reshape(c, c) * sa[:, None]
+    w2 = d(blk.mlp[3].weight).reshape(c, hid) * sm[:, None]
+    parts = [wp.reshape(-1), d(a.proj.bias) * sa, d(blk.ln2.weight).reshape(-1), d(blk.ln2.bias).reshape(-1),
+             d(blk.mlp[0].weight).reshape(-1), d(blk.mlp[0].bias), w2.t().contiguous().reshape(-1), d(blk.mlp[3].bias) * sm]
+    prm = torch.cat(parts).contiguous()
+    assert prm.numel() == hip.lib().otp_flow_back_param_floats(c, hid), (prm.numel(), c, hid)
+    return prm
+
+
+def flow_front(x, prm, eps=1e-5):
+    """q, k, v of a flow-encoder block from its input (B, 17, T)."""
+    _require_gpu(x, prm)
+    _check_f32(x)
+    x = x.contiguous()
+    b, c, t = x.shape
+    q, k, v = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    hip.check(hip.lib().otp_flow_front(hip.ptr(x), hip.ptr(prm), hip.ptr(q), hip.ptr(k), hip.ptr(v), b, c, t, float(eps),
+                                       hip.stream_of(x)), "otp_flow_front")
+    return q, k, v
+
+
+def flow_back(x, att, prm, hidden, eps=1e-5):
+    """Block output from its input ``x`` and the attention output ``att`` (both (B, 17, T))."""
+    _require_gpu(x, att, prm)
+    _check_f32(x)
+    x, att = x.contiguous(), att.contiguous()
+    b, c, t = x.shape
+    out = torch.empty_like(x)
+    hip.check(hip.lib().otp_flow_back(hip.ptr(x), hip.ptr(att), hip.ptr(prm), hip.ptr(out), b, c, int(hidden), t, float(eps),
+                                      hip.stream_of(x)), "otp_flow_back")
+    return out

@@ -201,6 +201,36 @@ def test_fused_transformer_block_matches_golden(golden):
     _close(out, g["tblock_136_s1_y"], 5e-5)
 
 
+def test_flow_encoder_block_matches_golden(golden):
+    """The C = 17 TransformerBlock of the flow encoder as the engine runs it - otp_flow_front (ln1 + depthwise convs +
+    LayerNorms + q / k / v projections), otp_chan_attn, otp_flow_back (proj + residual, ln2, MLP + residual) - against the
+    vectors the reference's TransformerBlock produced (tests/golden/blocks.npz, tblock_17_s1; model/blocks.py:264-280)."""
+    c, nh = 17, 1
+    g = golden("blocks")
+    blk = M.TransformerBlock(c, nh, (1, 1), proj_pdrop=0.1, path_pdrop=0.1)
+    S.fill_synthetic_(blk, 12)
+    x = g["tblock_17_s1_x"].cuda()
+    assert ops.flow_block_supported(blk, c, x.shape[2])
+    dev = x.device
+    q, k, v = ops.flow_front(x, ops.pack_flow_front(blk, dev), blk.ln1.eps)
+    att = ops.chan_attn(q, k, v, nh, blk.attn.scale)
+    out = ops.flow_back(x, att, ops.pack_flow_back(blk, dev), blk.mlp[0].out_channels, blk.ln2.eps)
+    _close(out, g["tblock_17_s1_y"], 5e-5)
+    # ragged length (T not a multiple of the 256-token workgroup) and the sequence ends of the depthwise conv: the three
+    # projections against the generic launches they replace
+    xr = seeded((3, c, 333), 5).cuda()
+    a = blk.attn
+    d = lambda p: p.detach().cuda().float().contiguous()          # noqa: E731
+    ln1 = ops.ln_channel(xr, d(blk.ln1.weight).reshape(-1), d(blk.ln1.bias).reshape(-1), blk.ln1.eps)
+    qn, kn, vn = ops.dwconv_ln3(ln1, [d(a.query_conv.weight), d(a.key_conv.weight), d(a.value_conv.weight)],
+                                [d(a.query_norm.weight), d(a.key_norm.weight), d(a.value_norm.weight)],
+                                [d(a.query_norm.bias), d(a.key_norm.bias), d(a.value_norm.bias)], 1)
+    lin = lambda m_, z: ops.conv2d(z.unsqueeze(2), d(m_.weight), None, d(m_.bias)).squeeze(2)   # noqa: E731
+    for got, ref in zip(ops.flow_front(xr, ops.pack_flow_front(blk, dev), blk.ln1.eps),
+                        (lin(a.query, qn), lin(a.key, kn), lin(a.value, vn))):
+        _close(got, ref.cpu(), 2e-5)
+
+
 def test_chan_attn_full_size_vs_oracle_slice():
     """cfg2 size (B=2 of 16, C=136, T=6912): compare with the CPU oracle arithmetic."""
     b, c, t, nh = 2, 136, 6912, 2
