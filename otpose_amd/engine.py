@@ -610,19 +610,23 @@ class InferenceEngine:
                   B, J, T, self.F)
         levels = m.scale_arch[-1] + 1
         s1, s2 = self.new(B, levels * D, T), self.new(B, levels * D, T)
-        # the two temporal encoders are independent: two streams
+        # the two temporal encoders are independent: two streams.  Each is followed on its own stream by its final 1x1 layer,
+        # which writes straight into the channel-concatenated tensor (OTPose.py:372-378); def_heatmaps feeds the DCN as a
+        # dense (B, J, h, w) tensor and the concat as a channel slice: copied once, on def_fuse's stream
+        cat3 = self.new(B, 3 * J, h, w)
+        final = lambda fl, s, i: self.conv(View(s.view(B, levels * D, h, w)), fl.weight, View(cat3, i * J, J), 1,   # noqa: E731
+                                           fl.padding[0], 1, bias=fl.bias)
+        self.on_stream(2)
+        self.copy_into(def_h, View(cat3, 2 * J, J))
+        self.on_stream(0)
         self.fork((1,))
         self.conv_transformer(m.temporal_encoder1, x1, s1)
+        final(m.final_layer1, s1, 0)
         self.on_stream(1)
         self.conv_transformer(m.temporal_encoder2, x2, s2)
+        final(m.final_layer2, s2, 1)
         self.on_stream(0)
         self.join((1, 2))
-        # final 1x1 layers write straight into the channel-concatenated tensor (OTPose.py:372-378)
-        cat3 = self.new(B, 3 * J, h, w)
-        for i, (fl, s) in enumerate(((m.final_layer1, s1), (m.final_layer2, s2))):
-            self.conv(View(s.view(B, levels * D, h, w)), fl.weight, View(cat3, i * J, J), 1, fl.padding[0], 1, bias=fl.bias)
-        # def_heatmaps feeds the DCN as a dense (B, J, h, w) tensor and the concat as a channel slice: copy once
-        self.copy_into(def_h, View(cat3, 2 * J, J))
         trans = self.rsb_chain(m.offset_mask_combine_conv, View(cat3))
         out = self.new(B, J, h, w)
         nd = len(m.deformable_conv_dilations)
