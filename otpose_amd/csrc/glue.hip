@@ -40,7 +40,9 @@ __global__ void glue_stack_kernel(const float* __restrict__ rough, const float* 
                                   const float* __restrict__ pe2, float* __restrict__ x1, float* __restrict__ x2,
                                   float* __restrict__ prev_b_out, int B, int J, int HW) {
     constexpr int NB = R == 2 ? 3 : 5, M = 2 + 2 * NB;       // "b" maps per encoder, stacked maps per joint
-    const int p = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    // one thread per (clip, joint, pixel): 7344 workgroups at cfg2 instead of 432 threads walking the 17 joints one after the
+    // other through dependent loads (145 -> 40 us)
+    const int p = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y / J, j = blockIdx.y - b * J;
     if (p >= HW) return;
     const size_t fs = (size_t)B * J * HW;
     const size_t base = (size_t)b * J * HW + p;
@@ -48,7 +50,7 @@ __global__ void glue_stack_kernel(const float* __restrict__ rough, const float* 
 #pragma unroll
     for (int k = 0; k < 2 * R; ++k) mg[k] = margin[b * 2 * R + k] + 1.f;
     const float sq = squeezed[base];
-    for (int j = 0; j < J; ++j) {
+    {
         const size_t i = base + (size_t)j * HW;
         const float cur = rough[i];
         float prev[R], next[R];
@@ -368,7 +370,7 @@ extern "C" int otp_glue_stack_n(const void* rough, const void* margin, const voi
     if (B <= 0 || J <= 0 || HW <= 0) return OTP_ERR_BAD_ARG;
     if (F != 5 && F != 7) return OTP_ERR_UNSUPPORTED;
     auto f = [](const void* p) { return static_cast<const float*>(p); };
-    const dim3 grid(otp_ceil_div(HW, 256), B);
+    const dim3 grid(otp_ceil_div(HW, 256), B * J);
     if (F == 5)
         hipLaunchKernelGGL(glue_stack_kernel<2>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), f(rough), f(margin),
                            f(squeezed), f(inter), f(ctx), f(pe1), f(pe2), static_cast<float*>(x1), static_cast<float*>(x2),

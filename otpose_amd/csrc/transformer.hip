@@ -54,6 +54,52 @@ __global__ __launch_bounds__(256) void ln_channel_kernel(const float* __restrict
     }
 }
 
+// The same LayerNorm for wide channel counts (C = 136 of the temporal encoders): workgroup = 64 time steps x 4 waves that
+// split the channels (lane = time step: 256-byte coalesced rows), statistics reduced across the waves through LDS, mean first,
+// then the biased variance of the centred values.  One thread walking all 136 channels (ln_channel_kernel<136>) left the chip
+// with 432 workgroups of dependent loads: 34 us for a 120 MB pass; this form runs 1728 workgroups.
+template <int CW>
+__global__ __launch_bounds__(256) void ln_channel_split_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float* __restrict__ y,
+                                                                int C, int T, float eps) {
+    __shared__ float red[2][4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = blockIdx.x * 64 + lane;
+    const bool live = t < T;
+    const size_t base = (size_t)blockIdx.y * C * T + (live ? t : 0);
+    const float inv_c = 1.f / (float)C;
+    const int cw = (C + 3) / 4, cbeg = wave * cw;
+    float v[CW];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < CW; ++i) {
+        const int c = cbeg + i;
+        v[i] = (i < cw && c < C) ? x[base + (size_t)c * T] : 0.f;
+        s += v[i];
+    }
+    red[0][wave][lane] = s;
+    __syncthreads();
+    const float mu = ((red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane])) * inv_c;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < CW; ++i) {
+        const int c = cbeg + i;
+        if (i < cw && c < C) {
+            v[i] -= mu;
+            q += v[i] * v[i];
+        }
+    }
+    red[1][wave][lane] = q;
+    __syncthreads();
+    const float rs = 1.f / sqrtf(((red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane])) * inv_c + eps);
+    if (!live) return;
+#pragma unroll
+    for (int i = 0; i < CW; ++i) {
+        const int c = cbeg + i;
+        if (i < cw && c < C) y[base + (size_t)c * T] = v[i] * rs * gamma[c] + beta[c];
+    }
+}
+
 // MaxPool1d(kernel 3, stride 2, padding 1): To = (T + 2 - 3) / 2 + 1
 __global__ void maxpool3s2_kernel(const float* __restrict__ x, float* __restrict__ y, int T, int To) {
     const int to = blockIdx.x * blockDim.x + threadIdx.x;
@@ -702,7 +748,8 @@ extern "C" int otp_ln_channel(const void* x, const void* gamma, const void* beta
     auto yf = static_cast<float*>(y);
     dim3 grid(otp_ceil_div(T, 256), B);
     if (C <= 17) hipLaunchKernelGGL(ln_channel_kernel<17>, grid, dim3(256), 0, st, xf, gf, bf, yf, C, T, eps);
-    else if (C <= 136) hipLaunchKernelGGL(ln_channel_kernel<136>, grid, dim3(256), 0, st, xf, gf, bf, yf, C, T, eps);
+    else if (C <= 136)
+        hipLaunchKernelGGL(ln_channel_split_kernel<34>, dim3(otp_ceil_div(T, 64), B), dim3(256), 0, st, xf, gf, bf, yf, C, T, eps);
     else hipLaunchKernelGGL(ln_channel_kernel<0>, grid, dim3(256), 0, st, xf, gf, bf, yf, C, T, eps);
     if (pool) {
         int To = (T + 2 - 3) / 2 + 1;
