@@ -5,7 +5,7 @@
 // here a thread owns one output pixel and all output channels in registers, the (in + in2) tile with its one-pixel halo and the
 // weights (pre-transposed to [ci][tap][co] by otp_conv3x3_small_pack) are read with uniform addresses through the scalar cache,
 // so the inner loop is one LDS read of the input value per (input channel, tap) feeding Cout FMAs with scalar weight operands
-// - exact fp32.  Measured at 16 x 96x72: 15.6 / 30.8 / 56 us for 6 / 13 / 20 channels (conv_igemm_kernel: 37 / 37 / 83 us);
+// - exact fp32.  Measured at 16 x 96x72: 15 / 26 / 44 us for 6 / 13 / 20 channels (conv_igemm_kernel: 37 / 37 / 83 us);
 // still latency bound (weight fetches per input channel), not by the 4320 FMAs per pixel.  (Splitting the output channels over several lighter workgroups was
 // measured slower: the launch is bound by the tile staging, not by occupancy.)
 // Epilogue as otp_conv2d: y = act(scale * acc + shift); channel-sliced views for in / in2 / out.
@@ -47,17 +47,25 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(const float* __restr
         pos[s2] = r < plane ? r : -1;
         off[s2] = (r < plane && y >= 0 && y < P.H && x >= 0 && x < P.W) ? y * P.W + x : -1;
     }
-    for (int c = 0; c < P.Cin; ++c) {
+    // four channels per trip: their (up to 16) loads are issued together - one channel per trip was one HBM / L2 round trip per
+    // channel (2.7 us per input channel of the launch, most of it this latency)
+    for (int c0 = 0; c0 < P.Cin; c0 += 4) {
+        float v[4][2];
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            if (pos[s2] >= 0) {
-                float v = 0.f;
-                if (off[s2] >= 0) {
-                    v = ib[(size_t)c * P.HW + off[s2]];
-                    if (ib2) v += ib2[(size_t)c * P.HW + off[s2]];
-                }
-                tile[c * plane + pos[s2]] = v;
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bool ok = c0 + u < P.Cin && off[s2] >= 0;
+                const size_t a = (size_t)(c0 + u) * P.HW + (ok ? off[s2] : 0);
+                v[u][s2] = ok ? ib[a] : 0.f;
+                if (ib2) v[u][s2] += ok ? ib2[a] : 0.f;
             }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+                if (c0 + u < P.Cin && pos[s2] >= 0) tile[(c0 + u) * plane + pos[s2]] = v[u][s2];
         }
     }
     __syncthreads();
@@ -68,6 +76,8 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(const float* __restr
 #pragma unroll
     for (int o = 0; o < BCP; ++o) acc[o] = 0.f;
     const float* tp = tile + (live ? ly * LW + lx : 0);
+    constexpr int CI_UNROLL = BCP <= 16 ? 2 : 1;      // two channels' weights in flight (24 outputs: SGPR spills instead)
+#pragma unroll CI_UNROLL
     for (int ci = 0; ci < P.Cin; ++ci) {
         const float* tc = tp + ci * plane;
         // the weights of (ci, tap) are the same for every thread: uniform addresses, so they arrive through the scalar cache
