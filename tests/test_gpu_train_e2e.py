@@ -271,11 +271,14 @@ def test_bf16_step_same_with_and_without_streams_and_batched_packs(monkeypatch):
     launch per step (bf16_ops.PackCache), BasicBlocks and attention fronts as single autograd nodes (skip gradient added in
     the input-gradient conv, intermediates rebuilt in the backward) - must not change its arithmetic: with all of it
     switched off (one stream, a pack launch per use, per-layer nodes) three forward / backward passes give the same losses
-    and gradients.  The weights are rescaled by 1 %
-    between the passes, so an operator left over from the previous pass (a job missed by the batched launch, a launch
-    ordered before the rescale) would show as a 1e-2 error; pass 2 and 3 are the ones that read batched re-layouts.
-    (No optimizer in the loop: Adam's first steps are lr * sign(g) and turn the last-bit differences of the atomically
-    accumulated gradients into 1e-4 loss differences.)"""
+    and gradients.  The weights are rescaled by 10 % between the passes, so an operator left over from the previous pass (a job
+    missed by the batched launch, a launch ordered before the rescale) would show as a 10 % error; pass 2 and 3 are the ones
+    that read batched re-layouts.  The forward has no atomics: its outputs must agree bit for bit.  The backward has a few
+    (DCN input gradient, fp32 weight gradients), and on this fixture a last-bit difference entering the flow encoder's
+    LayerNorm comes out of the backbone as up to 3e-3 (see test_bf16_step_on_a_cfg2_shaped_clip), so the gradients are held
+    to 1e-2 - ten times under what a stale operator does.
+    (No optimizer in the loop: Adam's first steps are lr * sign(g) and turn such last-bit differences into 1e-4 loss
+    differences.)"""
     cfg = tiny_cfg()
     ref = OTPose(cfg)
     S.fill_synthetic_(ref)
@@ -298,22 +301,27 @@ def test_bf16_step_same_with_and_without_streams_and_batched_packs(monkeypatch):
         m.train_dropout = False
         m.train_dtype = "bf16"
         params = [p for p in m.parameters() if p.requires_grad]
-        losses, grads = [], []
+        losses, grads, fwd = [], [], []
         for it in range(3):
-            loss = TR.criterion(m(x, margin=margin), g, wt)
+            outs = m(x, margin=margin)
+            loss = TR.criterion(outs, g, wt)
             m.zero_grad(set_to_none=True)
             loss.backward()
             losses.append(float(loss))
+            fwd.append([o.detach().clone() for o in outs])
             grads.append(torch.cat([p.grad.flatten() for p in params if p.grad is not None]).double())
             with torch.no_grad():
                 for p in params:
-                    p.mul_(1.01)
+                    p.mul_(1.1)
         torch.cuda.synchronize()
-        runs[name] = (losses, grads, len(m.__dict__.get("_otp_pack_cache") or ()))
-    (la, ga, na), (lb, gb, nb) = runs["plain"], runs["scheduled"]
+        runs[name] = (losses, grads, fwd, len(m.__dict__.get("_otp_pack_cache") or ()))
+    (la, ga, fa, na), (lb, gb, fb, nb) = runs["plain"], runs["scheduled"]
     assert na == 0 and nb > 0                      # the scheduled run really went through the cache
-    assert abs(lb[0] - lb[2]) > 1e-3 * abs(lb[0])  # the rescale is visible: a stale operator would be, too
+    assert abs(lb[0] - lb[2]) > 1e-2 * abs(lb[0])  # the rescale is visible: a stale operator would be, too
+    for oa, ob in zip(fa, fb):
+        for a, b in zip(oa, ob):
+            assert torch.equal(a, b)
     for a, b in zip(la, lb):
         assert abs(a - b) <= 2e-6 * abs(a), (la, lb)
     for a, b in zip(ga, gb):
-        assert float((a - b).norm() / a.norm()) <= 1e-5, float((a - b).norm() / a.norm())
+        assert float((a - b).norm() / a.norm()) <= 1e-2, float((a - b).norm() / a.norm())
