@@ -64,13 +64,18 @@ def event_time_ms(fn, iters, stream):
 
 def measured_traffic(key):
     """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE / WRITE_SIZE collected
-    in separate passes and corrected as MI355X_MICROARCH.md prescribes; see profiles/r01_traffic.json).  None when the
-    file or the key is absent: PMC counters cannot be read from inside this process."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-            return json.load(f).get(key, {}).get("hbm_bytes_per_launch")
-    except (OSError, ValueError):
-        return None
+    in separate passes and corrected as MI355X_MICROARCH.md prescribes; see profiles/r02_traffic.json for the split-bf16
+    kernels and profiles/r01_traffic.json for the f32 ones).  None when the files or the key are absent: PMC counters cannot
+    be read from inside this process."""
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                v = json.load(f).get(key, {}).get("hbm_bytes_per_launch")
+        except (OSError, ValueError):
+            v = None
+        if v is not None:
+            return v
+    return None
 
 
 def eager_ratio(ms_per_step, batch):
@@ -145,7 +150,8 @@ def kernel_rooflines(dev, batch):
         kname = ("conv_win_kernel<%d,%d,3,true> 48->48 3x3 @96x72 x%d frames (grid %d x %d threads)"
                  % (plan[0], plan[1], n, plan[5], 64 * plan[2] * plan[3]))
         executed = conv_flop
-    traffic = None if use_x3 else measured_traffic("conv_wino_48_48_3x3_96x72_x80" if use_wino else "conv_48_48_3x3_96x72_x80")
+    traffic = measured_traffic("convx_48_48_3x3_96x72_x80" if use_x3 else
+                               ("conv_wino_48_48_3x3_96x72_x80" if use_wino else "conv_48_48_3x3_96x72_x80"))
     # `achieved` is ALGORITHMIC (direct-convolution) FLOP/s as the bench contract defines it; `frac` is what the matrix
     # pipe actually does (executed MFMA FLOPs / peak), so a Winograd launch can never read above its pipe occupancy.
     # `algorithmic_frac` keeps the achieved / peak quotient, `hbm_frac` the measured HBM traffic against 8 TB/s.
@@ -205,7 +211,7 @@ def kernel_rooflines(dev, batch):
                  "bound": "mfma", "achieved": mlp_flop / (t_mlp * 1e-3) / 1e12, "peak": peak / 1e12,
                  "unit": "TFLOP/s", "frac": executed / (t_mlp * 1e-3) / peak,
                  "algorithmic_frac": mlp_flop / (t_mlp * 1e-3) / peak,
-                 "traffic": None if x3 else measured_traffic("ln_mlp_fused_136_544_T6912_x16"),
+                 "traffic": measured_traffic("ln_mlp_x3_136_544_T6912_x16" if x3 else "ln_mlp_fused_136_544_T6912_x16"),
                  "ms_per_launch": t_mlp, "algorithmic_flop_per_launch": mlp_flop, "executed_mfma_flop_per_launch": executed}
     # channel attention of one temporal-encoder block (blocks.py:427-447): S = (q*scale) k^T (68 x 68 per head, contraction
     # over T), softmax, O = P v in the transposed-contiguous image - the QK^T / PV kernels the north star asks the MFMA
