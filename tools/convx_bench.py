@@ -73,7 +73,11 @@ def pointwise():
         wt = torch.randn(co, ci, 1, 1, device="cuda") * (2.0 / ci) ** 0.5
         sc, sh = torch.rand(co, device="cuda") + 0.5, torch.randn(co, device="cuda")
         res = torch.randn(n, co, h, w, device="cuda")
-        y = ops.conv2d_x3(x, wt, sc, sh, ops.ACT_RELU, res, 0, 1, 1)
+        try:
+            y = ops.conv2d_x3(x, wt, sc, sh, ops.ACT_RELU, res, 0, 1, 1)
+        except (RuntimeError, ValueError):
+            print(f"{n:3d}x{ci:3d}->{co:3d} {h:3d}x{w:<3d}            not covered by the split kernel")
+            continue
         ref = torch.relu(F.conv2d(x[:2].double(), wt.double()) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1) + res[:2].double())
         e3 = float((y[:2].double() - ref).abs().max()) / float(ref.abs().max())
         wp = ops.pack_x3_weight(wt, sc, 1)
