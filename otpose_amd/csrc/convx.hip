@@ -216,11 +216,14 @@ __global__ __launch_bounds__(256, 2) void convx_kernel(const float* __restrict__
         }
     };
 
+    XSTAMP(11);
     load_chunk(0);
+    XSTAMP(12);
     // zero the window once: the zero rows between / around the images, the left / right padding columns and the slack records
     // behind the last row are never written by the staging
     for (int i = tid; i < P.winBytes / 16; i += 256) reinterpret_cast<u32x4*>(win)[i] = (u32x4){0u, 0u, 0u, 0u};
 
+    XSTAMP(13);
     // ---- fragment addresses ---------------------------------------------------------------------------------------------------
     int mbase[MTW];
 #pragma unroll
@@ -291,6 +294,7 @@ __global__ __launch_bounds__(256, 2) void convx_kernel(const float* __restrict__
             }
     };
 
+    XSTAMP(14);
     __syncthreads();                                               // window zeroed
     XSTAMP(1);
     for (int c = 0; c < P.nChunks - 1; ++c) {

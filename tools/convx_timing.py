@@ -13,11 +13,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from otpose_amd import hip, ops                 # noqa: E402
 
 n, cin, cout, h, w = (int(a) for a in sys.argv[1:6])
+ksz = int(sys.argv[6]) if len(sys.argv) > 6 else 3          # 1: pointwise conv (with a residual input, as in layer1)
 raw = ctypes.CDLL(hip.LIB_PATH)
 x = torch.randn(n, cin, h, w, device="cuda")
-wt = torch.randn(cout, cin, 3, 3, device="cuda") * 0.05
+wt = torch.randn(cout, cin, ksz, ksz, device="cuda") * 0.05
+res = torch.randn(n, cout, h, w, device="cuda") if ksz == 1 else None
+run = lambda: ops.conv2d_x3(x, wt, None, None, ops.ACT_RELU if ksz == 1 else ops.ACT_NONE, res, ksz // 2, 1, 1)   # noqa: E731
 for _ in range(3):
-    y = ops.conv2d_x3(x, wt)
+    y = run()
 torch.cuda.synchronize()
 buf = np.zeros(8192 * 16, dtype=np.uint64)
 raw.otp_convx_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
@@ -27,7 +30,7 @@ live = t[:, 0] > 0
 spans = [int(t[live & (np.arange(8192) % 8 == x), 8].max() - t[live & (np.arange(8192) % 8 == x), 0].min()) for x in range(8)]
 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 ev0.record()
-y = ops.conv2d_x3(x, wt)
+y = run()
 ev1.record()
 torch.cuda.synchronize()
 print("per-XCD kernel span (ticks):", spans, " one call incl. pack: %.1f us" % (ev0.elapsed_time(ev1) * 1e3))
@@ -41,6 +44,11 @@ print(f"{len(t)} workgroups; lifetime {np.median(rt):.2f} us median (real time) 
 for i, nm in enumerate(names):
     dt = t[:, i + 1] - t[:, i]
     print("%-62s median %7d  p90 %7d" % (nm, np.median(dt), np.percentile(dt, 90)))
+if t[:, 11].max() > 0:                      # finer stamps inside the prologue
+    for a, b, nm in ((0, 11, "index math (items, addresses)"), (11, 12, "issue chunk 0 loads"), (12, 13, "zero the window"),
+                     (13, 14, "fragment addresses, accumulators"), (14, 1, "barrier")):
+        dt = t[:, b] - t[:, a]
+        print("   prologue: %-50s median %7d  p90 %7d" % (nm, np.median(dt), np.percentile(dt, 90)))
 life = t[:, 8] - t[:, 0]
 print("workgroup lifetime median %d p90 %d; kernel span %d; starts spread over %d"
       % (np.median(life), np.percentile(life, 90), t[:, 8].max() - t[:, 0].min(), t[:, 0].max() - t[:, 0].min()))
