@@ -72,7 +72,7 @@ class InferenceEngine:
         # (640-960 workgroups on 512 resident slots) fill each other's tails
         self.multi_stream = os.environ.get("OTPOSE_STREAMS", "1") != "0"
         self._sid = 0
-        self._side = [torch.cuda.Stream(device) for _ in range(3)] if self.multi_stream else []
+        self._side = hip.side_streams(device, 3) if self.multi_stream else []      # process-wide pool (see hip.side_streams)
         self.graph = None
         self.param_version = self._param_version()
         with torch.no_grad():

@@ -234,3 +234,23 @@ def stream_of(t):
     dev = t.device.index
     _tls.dev = dev
     return c_void_p(torch._C._cuda_getCurrentRawStream(dev))
+
+
+_SIDE_STREAMS = {}            # device -> side streams shared by every inference engine and training graph of the process
+
+
+def side_streams(device, n):
+    """``n`` side streams of ``device`` from one process-wide pool (created on first use, never more than asked for).
+    The runtime multiplexes HIP streams onto a handful of hardware queues (four by default): an engine and a training graph
+    that each created their own three would share queues and serialise branches that are meant to overlap (measured: the
+    training step after two engines had been built ran 158 instead of 142 ms).  Engines and training steps of one process
+    do not run concurrently, so they can share the streams."""
+    import torch
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    pool = _SIDE_STREAMS.setdefault(device, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device))
+    return pool[:n]
+

@@ -181,7 +181,7 @@ class GradBuckets:
         if flat.is_cuda:
             # hook mode runs this on the stream of the gradient that completed the bucket; the other gradients of the bucket
             # may have been written on the side streams of the HRNet branches (train.TrainGraph.hr_module)
-            from .train import _SIDE_STREAMS
+            from .hip import _SIDE_STREAMS
             cur = torch.cuda.current_stream(flat.device)
             for s in [torch.cuda.default_stream(flat.device)] + _SIDE_STREAMS.get(flat.device, []):
                 if s != cur:

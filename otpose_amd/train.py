@@ -159,9 +159,6 @@ def build_loss(cfg, **kwargs):
     raise ValueError(f"unknown LOSS.NAME {name!r}")
 
 
-_SIDE_STREAMS = {}            # device -> side streams of the HRNet branches (created once, reused by every step)
-
-
 class TrainGraph:
     """Functional walk over the module's own parameters / buffers (same names as the reference state dict)."""
 
@@ -240,10 +237,7 @@ class TrainGraph:
         main = torch.cuda.current_stream(like.device)
         if os.environ.get("OTPOSE_TRAIN_STREAMS", "1") == "0" or n < 2:
             return [main] * n
-        pool = _SIDE_STREAMS.setdefault(like.device, [])
-        while len(pool) < n - 1:
-            pool.append(torch.cuda.Stream(like.device))
-        return [main] + pool[:n - 1]
+        return [main] + hip.side_streams(like.device, n - 1)
 
     def hr_module(self, p, xs, n_out):
         """One HighResolutionModule (model/HRNet.py:400-497).  The branches are independent until the fuse layers and each
