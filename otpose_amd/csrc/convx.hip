@@ -140,36 +140,56 @@ __global__ __launch_bounds__(256, 2) void convx_kernel(const float* __restrict__
     // ---- window items: (channel group g, float4 f of an image plane) -> 8 channel loads + 4 pixel records ------------------
     // The window rows of image n are one contiguous run of its NCHW plane, so the items of a channel group walk aligned
     // float4s of that run (any W; H*W % 4 == 0); each of the 4 pixels finds its own record (row, de-interleaved column).
-    int T = 0;                                                     // items per channel group of this tile (uniform)
-    for (int sl = 0; sl < P.S; ++sl) {
-        const int n = n0 + sl, ya = max(0, Vfirst - n * P.VR - P.pad), yb = min(P.H, Vfirst + P.rowsMax - n * P.VR - P.pad);
-        T += (n < P.N && yb > ya) ? ((yb * P.W + 3) >> 2) - ((ya * P.W) >> 2) : 0;
-    }
     int goff[NI], ldst[NI][4];
+    if constexpr (TAPS == 1) {
+        // pointwise: no halo, the window is the tile - XBM / 4 float4 items per channel group, item q of a group = flat output
+        // pixels P0 + 4 q .. + 3 (one image: HW % 4 == 0), record index = flat pixel - first pixel of the tile's first row.
+        // (The general walk below covers whole rows: one more item than a thread per group can hold in one pass, and 4 k cycles
+        // of index arithmetic per workgroup - a third of a 64 -> 256 workgroup's prologue.)
+        constexpr int TQ = XBM / 4;
+        const int row0 = n0 * P.HW + yo0 * P.W;                    // flat index of the first pixel of the tile's first row
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        const int i = tid + 256 * j;
-        int g = 0;
+        for (int j = 0; j < NI; ++j) {
+            const int i = tid + 256 * j, g = i / TQ, q = i - g * TQ;
+            const int flat = P0 + 4 * q;
+            const bool ok = g < G && flat < P.total;
+            const int n = (int)xdiv((uint32_t)(ok ? flat - n0 * P.HW : 0), P.mHoWo);      // images past the tile's first
+            const int pin = (ok ? flat - n0 * P.HW : 0) - n * P.HW;
+            goff[j] = ok ? ((n * P.in_ctot + 8 * g) * P.HW + pin) * 4 : XOOB;
 #pragma unroll
-        for (int gg = 1; gg < G; ++gg) g += i >= gg * T ? 1 : 0;
-        int rem = i - g * T, f = -1, n = 0;
-        if (i >= G * T) rem = -1;
-        for (int sl = 0; sl < P.S; ++sl) {
-            const int ns = n0 + sl, ya = max(0, Vfirst - ns * P.VR - P.pad), yb = min(P.H, Vfirst + P.rowsMax - ns * P.VR - P.pad);
-            const int c = (ns < P.N && yb > ya) ? ((yb * P.W + 3) >> 2) - ((ya * P.W) >> 2) : 0;
-            if (f < 0 && rem >= 0 && rem < c) { f = ((ya * P.W) >> 2) + rem; n = ns; }
-            rem -= (f < 0) ? c : 0;
+            for (int k = 0; k < 4; ++k) ldst[j][k] = ok ? (flat + k - row0) * XPIX + g * 16 : -1;
         }
-        goff[j] = f >= 0 ? ((((n - n0) * P.in_ctot + 8 * g) * P.HW) + 4 * f) * 4 : XOOB;
-        const int y0 = (int)xdiv((uint32_t)(f >= 0 ? 4 * f : 0), P.mW);
-        int y = y0, x = (f >= 0 ? 4 * f : 0) - y0 * P.W;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int r = n * P.VR + P.pad + y - Vfirst;
-            const int xw = x + P.pad;
-            const int col = P.stride == 2 ? (xw & 1) * P.CS + (xw >> 1) : xw;
-            ldst[j][k] = (f >= 0 && r >= 0 && r < P.rowsMax && y < P.H) ? (r * P.WPp + col) * XPIX + g * 16 : -1;
-            if (++x == P.W) { x = 0; ++y; }
+    } else {
+        int T = 0;                                                     // items per channel group of this tile (uniform)
+        for (int sl = 0; sl < P.S; ++sl) {
+            const int n = n0 + sl, ya = max(0, Vfirst - n * P.VR - P.pad), yb = min(P.H, Vfirst + P.rowsMax - n * P.VR - P.pad);
+            T += (n < P.N && yb > ya) ? ((yb * P.W + 3) >> 2) - ((ya * P.W) >> 2) : 0;
+        }
+    #pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int i = tid + 256 * j;
+            int g = 0;
+    #pragma unroll
+            for (int gg = 1; gg < G; ++gg) g += i >= gg * T ? 1 : 0;
+            int rem = i - g * T, f = -1, n = 0;
+            if (i >= G * T) rem = -1;
+            for (int sl = 0; sl < P.S; ++sl) {
+                const int ns = n0 + sl, ya = max(0, Vfirst - ns * P.VR - P.pad), yb = min(P.H, Vfirst + P.rowsMax - ns * P.VR - P.pad);
+                const int c = (ns < P.N && yb > ya) ? ((yb * P.W + 3) >> 2) - ((ya * P.W) >> 2) : 0;
+                if (f < 0 && rem >= 0 && rem < c) { f = ((ya * P.W) >> 2) + rem; n = ns; }
+                rem -= (f < 0) ? c : 0;
+            }
+            goff[j] = f >= 0 ? ((((n - n0) * P.in_ctot + 8 * g) * P.HW) + 4 * f) * 4 : XOOB;
+            const int y0 = (int)xdiv((uint32_t)(f >= 0 ? 4 * f : 0), P.mW);
+            int y = y0, x = (f >= 0 ? 4 * f : 0) - y0 * P.W;
+    #pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = n * P.VR + P.pad + y - Vfirst;
+                const int xw = x + P.pad;
+                const int col = P.stride == 2 ? (xw & 1) * P.CS + (xw >> 1) : xw;
+                ldst[j][k] = (f >= 0 && r >= 0 && r < P.rowsMax && y < P.H) ? (r * P.WPp + col) * XPIX + g * 16 : -1;
+                if (++x == P.W) { x = 0; ++y; }
+            }
         }
     }
     const size_t in_base = ((size_t)n0 * P.in_ctot + P.in_coff) * P.HW;
@@ -221,7 +241,10 @@ __global__ __launch_bounds__(256, 2) void convx_kernel(const float* __restrict__
     XSTAMP(12);
     // zero the window once: the zero rows between / around the images, the left / right padding columns and the slack records
     // behind the last row are never written by the staging
-    for (int i = tid; i < P.winBytes / 16; i += 256) reinterpret_cast<u32x4*>(win)[i] = (u32x4){0u, 0u, 0u, 0u};
+    // (a pointwise window has no such records: every record a fragment reads is written, the rows of a ragged last tile read
+    // a clamped valid record)
+    if constexpr (TAPS != 1)
+        for (int i = tid; i < P.winBytes / 16; i += 256) reinterpret_cast<u32x4*>(win)[i] = (u32x4){0u, 0u, 0u, 0u};
 
     XSTAMP(13);
     // ---- fragment addresses ---------------------------------------------------------------------------------------------------
@@ -420,7 +443,7 @@ bool convx_plan(const otp_conv_desc& d, XPlan& P) {
         if (sl > S) S = sl;
     }
     P.S = S;
-    P.NI = ((CK / 8) * Tmax + 255) / 256;
+    P.NI = pointwise ? ((CK / 8) * (XBM / 4) + 255) / 256 : ((CK / 8) * Tmax + 255) / 256;   // pointwise: exactly the tile
     P.winBytes = (rows * P.WPp + KE + 4) * XPIX;                   // + slack: the clamped tenth tap / tail pixels stay inside
     P.winBytes = (P.winBytes + 15) & ~15;
     P.wBytes = XKS * P.NTW * 2 * 1024;
