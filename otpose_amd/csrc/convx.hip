@@ -16,6 +16,7 @@
 // groups), the packed weights arrive in MFMA fragment order (lane-linear, conflict-free).  One k-step = 2 taps x 16 channels;
 // the loads of chunk c+1 are in flight under the MFMAs of chunk c.
 #include "common.h"
+#include <type_traits>
 #include <cstdlib>
 
 namespace {
@@ -198,30 +199,35 @@ __global__ __launch_bounds__(256, 2) void convx_kernel(const float* __restrict__
     const otp_rsrc rin = make_rsrc32(in + in_base, in_left * 4 > 0x7fffffffull ? 0x7fffffffu : (unsigned)(in_left * 4));
     const otp_rsrc rw = make_rsrc32(wpk, (unsigned)((size_t)P.nN * P.nChunks * WUNITS * 16));
 
-    f32x4 xv[NI][8];
-    u32x4 wv[NWL];
-    auto load_chunk = [&](int c) __attribute__((always_inline)) {
+    // staging registers: one set (the loads of chunk c + 1 fly under the MFMAs of chunk c); pointwise launches - one item per
+    // thread, short MFMA phases, bound by the HBM round trip - keep two sets and load two chunks ahead
+    constexpr int NBUF = TAPS == 1 ? 2 : 1;
+    f32x4 xv[NBUF][NI][8];
+    u32x4 wv[NBUF][NWL];
+    auto load_chunk = [&](int c, auto bufc) __attribute__((always_inline)) {
+        constexpr int b = decltype(bufc)::value;
         const int cs = c * CK * P.HW * 4;                          // scalar byte offset of the chunk's first channel
 #pragma unroll
         for (int j = 0; j < NI; ++j)
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-                xv[j][e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, goff[j], cs + e * P.HW * 4, 0));
+                xv[b][j][e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, goff[j], cs + e * P.HW * 4, 0));
         const int wb = ((cb * P.nChunks + c) * WUNITS) * 16;
 #pragma unroll
         for (int j = 0; j < NWL; ++j) {
             const int i = tid + 256 * j;
-            wv[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, i < WUNITS ? wb + i * 16 : XOOB, 0, 0));
+            wv[b][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, i < WUNITS ? wb + i * 16 : XOOB, 0, 0));
         }
     };
-    auto store_chunk = [&]() __attribute__((always_inline)) {
+    auto store_chunk = [&](auto bufc) __attribute__((always_inline)) {
+        constexpr int b = decltype(bufc)::value;
 #pragma unroll
         for (int j = 0; j < NI; ++j)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 float v[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = xv[j][e][k];
+                for (int e = 0; e < 8; ++e) v[e] = xv[b][j][e][k];
                 u32x4 hi, lo;
                 split8(v, hi, lo);
                 if (ldst[j][k] >= 0) {
@@ -232,12 +238,15 @@ __global__ __launch_bounds__(256, 2) void convx_kernel(const float* __restrict__
 #pragma unroll
         for (int j = 0; j < NWL; ++j) {
             const int i = tid + 256 * j;
-            if (i < WUNITS) reinterpret_cast<u32x4*>(wl)[i] = wv[j];
+            if (i < WUNITS) reinterpret_cast<u32x4*>(wl)[i] = wv[b][j];
         }
     };
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, NBUF - 1>;
 
     XSTAMP(11);
-    load_chunk(0);
+    load_chunk(0, B0{});
+    if (NBUF == 2 && P.nChunks > 1) load_chunk(1, B1{});
     XSTAMP(12);
     // zero the window once: the zero rows between / around the images, the left / right padding columns and the slack records
     // behind the last row are never written by the staging
@@ -320,19 +329,35 @@ __global__ __launch_bounds__(256, 2) void convx_kernel(const float* __restrict__
     XSTAMP(14);
     __syncthreads();                                               // window zeroed
     XSTAMP(1);
-    for (int c = 0; c < P.nChunks - 1; ++c) {
-        store_chunk();
+    // chunk c sits in register set c % NBUF; once it is in LDS the set takes chunk c + NBUF
+    auto step = [&](int c, auto bufc) __attribute__((always_inline)) {
+        store_chunk(bufc);
         if (c == 0) XSTAMP(2);
         __syncthreads();
         if (c == 0) XSTAMP(3);
-        load_chunk(c + 1);                                         // in flight under the MFMAs
+        if (c + NBUF < P.nChunks) load_chunk(c + NBUF, bufc);      // in flight under the MFMAs
         __builtin_amdgcn_sched_barrier(0);                         // (hipcc otherwise sinks the loads below the MFMAs)
         mfma_phase();
         if (c == 0) XSTAMP(4);
         __syncthreads();                                           // every wave is done with the LDS image of chunk c
         if (c == 0) XSTAMP(5);
+    };
+    int c = 0;
+    if constexpr (NBUF == 2) {
+        for (; c + 2 <= P.nChunks - 1; c += 2) {
+            step(c, B0{});
+            step(c + 1, B1{});
+        }
+        if (c < P.nChunks - 1) {
+            step(c, B0{});
+            store_chunk(B1{});
+        } else {
+            store_chunk(B0{});
+        }
+    } else {
+        for (; c < P.nChunks - 1; ++c) step(c, B0{});
+        store_chunk(B0{});
     }
-    store_chunk();
     __syncthreads();
     XSTAMP(6);
 
