@@ -233,7 +233,10 @@ def stream_of(t):
     import torch
     dev = t.device.index
     _tls.dev = dev
-    return c_void_p(torch._C._cuda_getCurrentRawStream(dev))
+    raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)     # the handle without building a torch.cuda.Stream object
+    if raw is not None:                                              # (5 us per launch on the host-bound training forward)
+        return c_void_p(raw(dev))
+    return c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
 _SIDE_STREAMS = {}            # device -> side streams shared by every inference engine and training graph of the process
