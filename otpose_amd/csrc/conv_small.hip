@@ -5,7 +5,7 @@
 // here a thread owns one output pixel and all output channels in registers, the (in + in2) tile with its one-pixel halo and the
 // weights (pre-transposed to [ci][tap][co] by otp_conv3x3_small_pack) are read with uniform addresses through the scalar cache,
 // so the inner loop is one LDS read of the input value per (input channel, tap) feeding Cout FMAs with scalar weight operands
-// - exact fp32.  Measured at 16 x 96x72: 15 / 26 / 44 us for 6 / 13 / 20 channels (conv_igemm_kernel: 37 / 37 / 83 us);
+// - exact fp32.  Measured at 16 x 96x72: 15 / 17 / 29 us for 6 / 13 / 20 channels (conv_igemm_kernel: 37 / 37 / 83 us);
 // still latency bound (weight fetches per input channel), not by the 4320 FMAs per pixel.  (Splitting the output channels over several lighter workgroups was
 // measured slower: the launch is bound by the tile staging, not by occupancy.)
 // Epilogue as otp_conv2d: y = act(scale * acc + shift); channel-sliced views for in / in2 / out.
@@ -21,28 +21,33 @@ struct SmallPlan {
     int TW, TH, tilesX, tilesY;              // output tile of a workgroup (TW * TH <= 256), tiles per image
 };
 
-// BCP: output channels padded to a multiple of 4 (accumulators per thread)
-template <int BCP>
-__global__ __launch_bounds__(256) void conv3x3_small_kernel(const float* __restrict__ in, const float* __restrict__ in2,
-                                                            const float* __restrict__ w, const float* __restrict__ scale,
-                                                            const float* __restrict__ shift, float* __restrict__ out,
-                                                            const SmallPlan P) {
+// BCP: output channels padded to a multiple of 4 (accumulators per thread).  SPLIT = 2: 512 threads, the second group of four
+// waves owns the second half of the input channels of the same 256 pixels and hands its partial sums over through LDS - twice
+// the waves to hide the weight fetches behind (13 / 20 channels: 26 -> 18 / 44 -> 28 us).
+template <int BCP, int SPLIT>
+__global__ __launch_bounds__(256 * SPLIT) void conv3x3_small_kernel(const float* __restrict__ in, const float* __restrict__ in2,
+                                                                    const float* __restrict__ w, const float* __restrict__ scale,
+                                                                    const float* __restrict__ shift, float* __restrict__ out,
+                                                                    const SmallPlan P) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int NT = 256 * SPLIT;
     const int LW = P.TW + 2, LH = P.TH + 2, plane = LW * LH;
     float* tile = sm;                               // [Cin][LH][LW]
+    float* part = sm + P.Cin * plane;               // SPLIT == 2: [BCP][256] partial sums of the second channel half
     const int tid = threadIdx.x;
     const int n = (int)blockIdx.x / (P.tilesX * P.tilesY), t = (int)blockIdx.x - n * (P.tilesX * P.tilesY);
     const int ty0 = (t / P.tilesX) * P.TH, tx0 = (t - (t / P.tilesX) * P.tilesX) * P.TW;
     const int co0 = (int)blockIdx.y * BCP;          // output-channel block of this workgroup (one block today)
 
-    // input tile with halo: in (+ in2), zeros outside the image.  A thread owns up to two tile positions (the tile has at most
-    // 512 of them) and walks the channels: no integer division inside the channel loop
+    // input tile with halo: in (+ in2), zeros outside the image.  A thread owns up to 2 / SPLIT tile positions (the tile has at
+    // most 512 of them) and walks the channels: no integer division inside the channel loop
     const float* ib = in + ((size_t)n * P.in_ctot + P.in_coff) * P.HW;
     const float* ib2 = in2 ? in2 + ((size_t)n * P.in2_ctot + P.in2_coff) * P.HW : nullptr;
-    int pos[2], off[2];
+    constexpr int NP = 2 / SPLIT;
+    int pos[NP], off[NP];
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-        const int r = tid + 256 * s2, py = r / LW, px = r - py * LW;
+    for (int s2 = 0; s2 < NP; ++s2) {
+        const int r = tid + NT * s2, py = r / LW, px = r - py * LW;
         const int y = ty0 + py - 1, x = tx0 + px - 1;
         pos[s2] = r < plane ? r : -1;
         off[s2] = (r < plane && y >= 0 && y < P.H && x >= 0 && x < P.W) ? y * P.W + x : -1;
@@ -50,11 +55,11 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(const float* __restr
     // four channels per trip: their (up to 16) loads are issued together - one channel per trip was one HBM / L2 round trip per
     // channel (2.7 us per input channel of the launch, most of it this latency)
     for (int c0 = 0; c0 < P.Cin; c0 += 4) {
-        float v[4][2];
+        float v[4][NP];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
+            for (int s2 = 0; s2 < NP; ++s2) {
                 const bool ok = c0 + u < P.Cin && off[s2] >= 0;
                 const size_t a = (size_t)(c0 + u) * P.HW + (ok ? off[s2] : 0);
                 v[u][s2] = ok ? ib[a] : 0.f;
@@ -64,21 +69,25 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(const float* __restr
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
+            for (int s2 = 0; s2 < NP; ++s2)
                 if (c0 + u < P.Cin && pos[s2] >= 0) tile[(c0 + u) * plane + pos[s2]] = v[u][s2];
         }
     }
     __syncthreads();
 
-    const int ly = tid / P.TW, lx = tid - ly * P.TW;
+    const int half = __builtin_amdgcn_readfirstlane(tid >> 8);      // 0 / 1: which half of the input channels (uniform per wave)
+    const int pt = tid & 255;
+    const int ly = pt / P.TW, lx = pt - ly * P.TW;
     const bool live = ly < P.TH && ty0 + ly < P.H && tx0 + lx < P.W;
     float acc[BCP];
 #pragma unroll
     for (int o = 0; o < BCP; ++o) acc[o] = 0.f;
     const float* tp = tile + (live ? ly * LW + lx : 0);
+    const int cmid = SPLIT == 2 ? (P.Cin + 1) / 2 : P.Cin;
+    const int cbeg = half ? cmid : 0, cend = half ? P.Cin : cmid;
     constexpr int CI_UNROLL = BCP <= 16 ? 2 : 1;      // two channels' weights in flight (24 outputs: SGPR spills instead)
 #pragma unroll CI_UNROLL
-    for (int ci = 0; ci < P.Cin; ++ci) {
+    for (int ci = cbeg; ci < cend; ++ci) {
         const float* tc = tp + ci * plane;
         // the weights of (ci, tap) are the same for every thread: uniform addresses, so they arrive through the scalar cache
         // (s_load) and feed the FMAs as scalar operands - the LDS serves one read per tap only
@@ -90,6 +99,16 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(const float* __restr
         for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
             for (int o = 0; o < BCP; ++o) acc[o] = fmaf(wc[tap * BCP + o], xin[tap], acc[o]);
+    }
+    if constexpr (SPLIT == 2) {
+        if (half) {
+#pragma unroll
+            for (int o = 0; o < BCP; ++o) part[o * 256 + pt] = acc[o];
+        }
+        __syncthreads();
+        if (half) return;
+#pragma unroll
+        for (int o = 0; o < BCP; ++o) acc[o] += part[o * 256 + pt];
     }
     if (!live) return;
     float* ob = out + ((size_t)n * P.out_ctot + P.out_coff) * P.HW + (size_t)(ty0 + ly) * P.W + tx0 + lx;
@@ -111,6 +130,7 @@ __global__ void conv3x3_small_pack_kernel(const float* __restrict__ w, float* __
 }
 
 int small_bcp(int Cout) { return Cout <= 8 ? 8 : (Cout <= 16 ? 16 : 24); }
+int small_split(int Cin) { return Cin >= 12 ? 2 : 1; }      // input-channel halves on two wave groups
 
 bool small_plan(const otp_conv_desc& d, SmallPlan& P, size_t& lds, int& bcp) {
     if (d.kh != 3 || d.kw != 3 || d.stride != 1 || d.pad != 1 || d.dil != 1 || d.res_up > 1 || d.frame_split > 0) return false;
@@ -134,7 +154,7 @@ bool small_plan(const otp_conv_desc& d, SmallPlan& P, size_t& lds, int& bcp) {
     P.tilesX = (d.W + P.TW - 1) / P.TW; P.tilesY = (d.H + P.TH - 1) / P.TH;
     bcp = small_bcp(d.Cout);                        // output channels per workgroup (accumulators per thread)
     if ((P.TW + 2) * (P.TH + 2) > 512) return false;
-    lds = (size_t)d.Cin * (P.TW + 2) * (P.TH + 2) * sizeof(float);
+    lds = ((size_t)d.Cin * (P.TW + 2) * (P.TH + 2) + (small_split(d.Cin) == 2 ? (size_t)bcp * 256 : 0)) * sizeof(float);
     return lds <= 64 * 1024 && (long)d.N * P.tilesX * P.tilesY < (1l << 31);
 }
 
@@ -178,8 +198,16 @@ extern "C" int otp_conv3x3_small(const void* in, const void* in2, const void* we
     auto fi = static_cast<const float*>(in), f2 = static_cast<const float*>(in2), fw = static_cast<const float*>(weight);
     auto fs = static_cast<const float*>(scale), fh = static_cast<const float*>(shift);
     auto fo = static_cast<float*>(out);
-    if (bcp == 8) hipLaunchKernelGGL(conv3x3_small_kernel<8>, grid, dim3(256), lds, st, fi, f2, fw, fs, fh, fo, P);
-    else if (bcp == 16) hipLaunchKernelGGL(conv3x3_small_kernel<16>, grid, dim3(256), lds, st, fi, f2, fw, fs, fh, fo, P);
-    else hipLaunchKernelGGL(conv3x3_small_kernel<24>, grid, dim3(256), lds, st, fi, f2, fw, fs, fh, fo, P);
+#define OTP_SMALL(B_, S_) hipLaunchKernelGGL((conv3x3_small_kernel<B_, S_>), grid, dim3(256 * S_), lds, st, fi, f2, fw, fs, fh, fo, P)
+    if (small_split(d.Cin) == 2) {
+        if (bcp == 8) OTP_SMALL(8, 2);
+        else if (bcp == 16) OTP_SMALL(16, 2);
+        else OTP_SMALL(24, 2);
+    } else {
+        if (bcp == 8) OTP_SMALL(8, 1);
+        else if (bcp == 16) OTP_SMALL(16, 1);
+        else OTP_SMALL(24, 1);
+    }
+#undef OTP_SMALL
     return otp_launch_status();
 }
