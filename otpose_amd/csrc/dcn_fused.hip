@@ -31,7 +31,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int FCIN = 32;                      // channels of `trans`
 constexpr int FBLK = 40960;                   // bytes of one (dilation, group) weight block: 9 taps x 2 n-tiles x (hi, lo) x 1 KB, padded
-constexpr int FPIX = 128;                     // pixels per workgroup
+constexpr int FPIX = 128;                     // pixels per workgroup (8 waves); the 9-wave form owns 144
 constexpr int FMAXD = 8;                      // dilations per launch
 
 struct FusedPlan {
@@ -126,19 +126,24 @@ __global__ void dcnf_pack_kernel(const float* const* __restrict__ w_off, const f
     }
 }
 
+template <int NW>
 __device__ __forceinline__ void f_stage(const unsigned char* __restrict__ src, unsigned char* lds) {
-    constexpr int NST = FBLK / 16 / 512;
+    constexpr int UNITS = FBLK / 16, NST = (UNITS + NW * 64 - 1) / (NW * 64);   // 64-unit runs, one wave each
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
 #pragma unroll
     for (int i = 0; i < NST; ++i) {
-        const int u0 = i * 512 + wave * 64;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)(u0 + lane) * 16),
-                                         (__attribute__((address_space(3))) void*)(lds + u0 * 16), 16, 0, 0);
+        const int u0 = i * NW * 64 + wave * 64;
+        if (UNITS % (NW * 64) == 0 || u0 < UNITS)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)(u0 + lane) * 16),
+                                             (__attribute__((address_space(3))) void*)(lds + u0 * 16), 16, 0, 0);
     }
 }
 
-template <int J>
-__global__ __launch_bounds__(512, 2) void dcn_fused_kernel(const unsigned char* __restrict__ ws, const float* __restrict__ x,
+// NW waves per workgroup = 16 NW pixels.  8 is the general form; 9 exists for the maps it divides into a whole number of
+// rounds: 16 x 96x72 is 864 workgroups of 128 pixels = 3.4 rounds of the 256 CUs (one workgroup per CU: the fourth round runs
+// at 38 %), but 768 of 144 pixels = exactly 3.
+template <int J, int NW>
+__global__ __launch_bounds__(64 * NW) void dcn_fused_kernel(const unsigned char* __restrict__ ws, const float* __restrict__ x,
                                                             const unsigned char* __restrict__ packed, float* __restrict__ out,
                                                             const FusedPlan P) {
     constexpr int JP = (J + 3) & ~3;                                // outputs padded to float4s (20 for J = 17)
@@ -146,11 +151,11 @@ __global__ __launch_bounds__(512, 2) void dcn_fused_kernel(const unsigned char* 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* wbuf = smem;                                     // 2 x FBLK
     float* scratch = reinterpret_cast<float*>(smem + 2 * FBLK);     // [8 waves][16 pixels][32 channels]
-    float* wd = scratch + 8 * 16 * 32;                              // [J][9][20]
+    float* wd = scratch + NW * 16 * 32;                             // [J][9][20]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i16 = lane & 15, kq = lane >> 4;
-    const int n = (int)blockIdx.x / P.tilesPerImg, p0 = ((int)blockIdx.x - n * P.tilesPerImg) * FPIX;
+    const int n = (int)blockIdx.x / P.tilesPerImg, p0 = ((int)blockIdx.x - n * P.tilesPerImg) * (16 * NW);
     const int p = p0 + wave * 16 + i16;                             // the lane's pixel (both as fragment row and as sampling pixel)
     const int y = p / P.W, xx0 = p - y * P.W;
     float* scr = scratch + wave * (16 * 32);
@@ -168,7 +173,7 @@ __global__ __launch_bounds__(512, 2) void dcn_fused_kernel(const unsigned char* 
     for (int di = 0; di < P.ND; ++di) {
         const int d = P.dil[di];
         __syncthreads();                                            // the previous dilation's table / weight buffers are free
-        for (int i = tid; i < J * 9 * 5; i += 512)
+        for (int i = tid; i < J * 9 * 5; i += 64 * NW)
             reinterpret_cast<u32x4*>(wd)[i] = reinterpret_cast<const u32x4*>(packed + table_off)[(size_t)di * J * 45 + i];
         // pixel fragments of all nine taps (rows outside the image / columns outside the row: offset past the descriptor = 0)
         u32x4 ah[9], al[9];
@@ -180,12 +185,12 @@ __global__ __launch_bounds__(512, 2) void dcn_fused_kernel(const unsigned char* 
             ah[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rws, off, 0, 0));
             al[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rws, off, 64, 0));
         }
-        f_stage(packed + (size_t)(di * J) * FBLK, wbuf);
+        f_stage<NW>(packed + (size_t)(di * J) * FBLK, wbuf);
         __syncthreads();                                            // block 0 landed, table visible
 
 #pragma unroll 1
         for (int g = 0; g < J; ++g) {
-            if (g + 1 < J) f_stage(packed + (size_t)(di * J + g + 1) * FBLK, wbuf + ((g + 1) & 1) * FBLK);
+            if (g + 1 < J) f_stage<NW>(packed + (size_t)(di * J + g + 1) * FBLK, wbuf + ((g + 1) & 1) * FBLK);
             const unsigned char* wb = wbuf + (g & 1) * FBLK + lane * 16;
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -258,6 +263,16 @@ __global__ __launch_bounds__(512, 2) void dcn_fused_kernel(const unsigned char* 
 
 }  // namespace
 
+namespace {
+// 144-pixel workgroups: the map divides, and 8-wave workgroups would leave the last round of the 256 CUs under 70 % full
+bool P_nine(int B, int HW) {
+    if (HW % 144) return false;
+    const long t8 = (long)B * (HW / FPIX), t9 = (long)B * (HW / 144);
+    const double fill8 = (double)t8 / (((t8 + 255) / 256) * 256.0), fill9 = (double)t9 / (((t9 + 255) / 256) * 256.0);
+    return t9 >= 256 && fill9 * 8.0 / 9.0 > fill8;          // a 9-wave workgroup takes 9/8 of the time (LDS-bound per CU)
+}
+}  // namespace
+
 extern "C" int otp_dcn_fused_supported(int Cin, int J, int H, int W, int ND) {
     return (Cin == FCIN && J == 17 && H > 0 && W > 0 && (H * W) % FPIX == 0 && ND >= 1 && ND <= FMAXD &&
             (long)H * W * 128 < (1l << 31) && (long)J * H * W * 4 < (1l << 31))
@@ -296,7 +311,10 @@ extern "C" int otp_dcn_fused_forward(const void* trans, const void* x, const voi
     if ((reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(workspace)) & 15) return OTP_ERR_BAD_ARG;
     auto st = static_cast<hipStream_t>(stream);
     FusedPlan P{};
-    P.B = B; P.J = J; P.H = H; P.W = W; P.HW = H * W; P.ND = ND; P.tilesPerImg = P.HW / FPIX; P.alpha = alpha;
+    // nine-wave workgroups when they tile the map and make the launch a whole number of rounds of the chip
+    const bool nine = P_nine(B, H * W);
+    const int px = nine ? 144 : FPIX;
+    P.B = B; P.J = J; P.H = H; P.W = W; P.HW = H * W; P.ND = ND; P.tilesPerImg = P.HW / px; P.alpha = alpha;
     for (int i = 0; i < ND; ++i) {
         if (dilations[i] <= 0) return OTP_ERR_BAD_ARG;
         P.dil[i] = dilations[i];
@@ -304,10 +322,17 @@ extern "C" int otp_dcn_fused_forward(const void* trans, const void* x, const voi
     const size_t nsplit = (size_t)B * P.HW * 4;
     hipLaunchKernelGGL(dcnf_split_kernel, dim3((unsigned)((nsplit + 255) / 256 > 4096 ? 4096 : (nsplit + 255) / 256)), dim3(256), 0,
                        st, static_cast<const float*>(trans), static_cast<u32x4*>(workspace), B, P.HW);
-    const size_t lds = 2 * (size_t)FBLK + 8 * 16 * 32 * 4 + (size_t)17 * 9 * 20 * 4 + 64;
-    auto kern = dcn_fused_kernel<17>;
-    OTP_ALLOW_BIG_LDS(kern, lds);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(B * P.tilesPerImg)), dim3(512), lds, st, static_cast<const unsigned char*>(workspace),
-                       static_cast<const float*>(x), static_cast<const unsigned char*>(packed), static_cast<float*>(out), P);
+    const size_t lds = 2 * (size_t)FBLK + (size_t)(px / 16) * 16 * 32 * 4 + (size_t)17 * 9 * 20 * 4 + 64;
+    if (nine) {
+        auto kern = dcn_fused_kernel<17, 9>;
+        OTP_ALLOW_BIG_LDS(kern, lds);
+        hipLaunchKernelGGL(kern, dim3((unsigned)(B * P.tilesPerImg)), dim3(576), lds, st, static_cast<const unsigned char*>(workspace),
+                           static_cast<const float*>(x), static_cast<const unsigned char*>(packed), static_cast<float*>(out), P);
+    } else {
+        auto kern = dcn_fused_kernel<17, 8>;
+        OTP_ALLOW_BIG_LDS(kern, lds);
+        hipLaunchKernelGGL(kern, dim3((unsigned)(B * P.tilesPerImg)), dim3(512), lds, st, static_cast<const unsigned char*>(workspace),
+                           static_cast<const float*>(x), static_cast<const unsigned char*>(packed), static_cast<float*>(out), P);
+    }
     return otp_launch_status();
 }
