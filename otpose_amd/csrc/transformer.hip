@@ -736,6 +736,33 @@ __global__ void upsample_linear_kernel(const float* __restrict__ x, float* __res
     out[((size_t)b * out_ctot + out_coff + c) * To + to] = r;
 }
 
+// four consecutive outputs per thread, one 16-byte store (rows of To = T f floats, To % 4 == 0, 16-byte aligned rows): the
+// scalar form above moves the 60 MB pyramid levels of a temporal encoder at 2 TB/s
+__global__ void upsample_linear4_kernel(const float* __restrict__ x, float* __restrict__ out, int C, int T, int f,
+                                        int out_ctot, int out_coff) {
+    const int To = T * f;
+    const int t4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (t4 >= To) return;
+    const int c = blockIdx.y % C, b = blockIdx.y / C;
+    const float* xr = x + ((size_t)b * C + c) * T;
+    f32x4 r;
+    if (f == 1) {
+        r = *reinterpret_cast<const f32x4*>(xr + t4);
+    } else {
+        const float inv = 1.f / (float)f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float src = ((float)(t4 + k) + 0.5f) * inv - 0.5f;
+            src = src < 0.f ? 0.f : src;
+            const int i0 = (int)src;
+            const int i1 = i0 + (i0 < T - 1 ? 1 : 0);
+            const float l1 = src - (float)i0, l0 = 1.f - l1;
+            r[k] = l0 * xr[i0] + l1 * xr[i1];
+        }
+    }
+    *reinterpret_cast<f32x4*>(out + ((size_t)b * out_ctot + out_coff + c) * To + t4) = r;
+}
+
 }  // namespace
 
 extern "C" int otp_ln_channel(const void* x, const void* gamma, const void* beta, void* y, void* pool, int B,
@@ -949,8 +976,15 @@ extern "C" int otp_maxpool3s2_forward(const void* x, void* y, int rows, int T, v
 extern "C" int otp_upsample_linear(const void* x, void* out, int B, int C, int T, int f, int out_ctot, int out_coff,
                                    void* stream) {
     if (!x || !out || B <= 0 || C <= 0 || T <= 0 || f <= 0 || out_ctot < out_coff + C) return OTP_ERR_BAD_ARG;
-    hipLaunchKernelGGL(upsample_linear_kernel, dim3(otp_ceil_div(T * f, 256), B * C), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), static_cast<const float*>(x), static_cast<float*>(out), C, T,
-                       f, out_ctot, out_coff);
+    const bool vec = (T * f) % 4 == 0 && (f > 1 || T % 4 == 0) &&
+                     ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    if (vec)
+        hipLaunchKernelGGL(upsample_linear4_kernel, dim3(otp_ceil_div(T * f / 4, 256), B * C), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), static_cast<const float*>(x), static_cast<float*>(out), C, T,
+                           f, out_ctot, out_coff);
+    else
+        hipLaunchKernelGGL(upsample_linear_kernel, dim3(otp_ceil_div(T * f, 256), B * C), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), static_cast<const float*>(x), static_cast<float*>(out), C, T,
+                           f, out_ctot, out_coff);
     return otp_launch_status();
 }
