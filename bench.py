@@ -14,10 +14,53 @@ import os
 import sys
 import time
 
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="clips per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-step", action="store_true", help="skip the training-step probe (extra field of the line)")
+    ap.add_argument("--train-f32", action="store_true", help="also time the fp32 training step (1 GPU)")
+    ap.add_argument("--no-exact-fp32", action="store_true", help="skip the exact-fp32-kernel forward reported beside the headline")
+    return ap.parse_args(argv)
+
+
+def launch_ranks(a):
+    """``python bench.py --gpus N`` with N > 1 and no launcher environment: start one rank per GPU through
+    ``torch.distributed.run`` (the reference's counterpart is the single-process ``nn.DataParallel`` of train.py:78-79 /
+    eval.py:112-113).  Runs BEFORE anything touches the GPU - the parent only counts devices, starts the children, relays
+    their exit code; rank 0 of the children prints the JSON line on the stdout it inherits.  Fails loudly when the box has
+    fewer GPUs than asked for (never a silent 1-rank run)."""
+    import socket
+    import subprocess
+    import torch                                       # device_count() does not initialise the GPU runtime
+    have = torch.cuda.device_count()
+    if have < a.gpus:
+        sys.stderr.write("bench.py: --gpus %d asked for, %d GPU(s) visible on this machine - refusing to run fewer ranks\n"
+                         % (a.gpus, have))
+        sys.exit(2)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % a.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this host driver
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ:
+    _a = parse_args()
+    if _a.gpus > 1:
+        launch_ranks(_a)                               # never returns
+
+import torch                                           # noqa: E402
 
 from otpose_amd import OTPose, cfg2, hip, ops          # noqa: E402
 from otpose_amd import synthetic as S                  # noqa: E402
@@ -26,6 +69,7 @@ FLOP_PER_CLIP = 409.0e9          # conv + bmm FLOPs of one 5-frame 384x288 W48 c
 DCN_BYTES_PER_CLIP_DIL = 13_630_464   # x + offset + mask read, out written, fp32
 PEAK_F32_MATRIX = 157.3e12       # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 PEAK_HBM = 8.0e12                # MI355X_MICROARCH.md: HBM3E spec peak
+PEAK_BF16_MATRIX = 2.5e15        # MI355X_MICROARCH.md: dense bf16 MFMA peak
 
 
 T_START = time.perf_counter()
@@ -62,20 +106,20 @@ def event_time_ms(fn, iters, stream):
     return e0.elapsed_time(e1) / iters
 
 
-def measured_traffic(key):
+def measured_traffic(key, with_source=False):
     """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE / WRITE_SIZE collected
     in separate passes and corrected as MI355X_MICROARCH.md prescribes; see profiles/r02_traffic.json for the split-bf16
     kernels and profiles/r01_traffic.json for the f32 ones).  None when the files or the key are absent: PMC counters cannot
     be read from inside this process."""
-    for name in ("r02_traffic.json", "r01_traffic.json"):
+    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 v = json.load(f).get(key, {}).get("hbm_bytes_per_launch")
         except (OSError, ValueError):
             v = None
         if v is not None:
-            return v
-    return None
+            return (v, "profiles/" + name) if with_source else v
+    return (None, None) if with_source else None
 
 
 def eager_ratio(ms_per_step, batch):
@@ -126,10 +170,7 @@ def kernel_rooflines(dev, batch):
             n, ((n * 96 * 72 // 256 + 7) // 8) * 8)
         executed = conv_flop * 3.0 * 10.0 / 9.0
         peak = PEAK_BF16_MATRIX
-        lds_bytes = (n * 96 * 72 // 256) * 3 * (280 + 62) * 1024.0            # per (tile, chunk): 280 KB read + 62 KB written
-        extra = {"lds_bytes_per_launch": lds_bytes, "lds_peak_bytes_per_s": 256 * 108 * 2.0e9,
-                 "lds_frac": lds_bytes / (t_conv * 1e-3) / (256 * 108 * 2.0e9),
-                 "arithmetic": "fp32 storage / accumulate, products as bf16 hi*hi + hi*lo + lo*hi (csrc/convx.hip)"}
+        extra = {"arithmetic": "fp32 storage / accumulate, products as bf16 hi*hi + hi*lo + lo*hi (csrc/convx.hip)"}
     elif use_wino:
         # the kernel the engine runs for this layer: Winograd F(2x2,3x3) (csrc/wino.hip).  `achieved` stays ALGORITHMIC
         # (direct-convolution) FLOPs per second; the kernel itself executes 16/36 of them on the MFMA pipe.
@@ -150,8 +191,8 @@ def kernel_rooflines(dev, batch):
         kname = ("conv_win_kernel<%d,%d,3,true> 48->48 3x3 @96x72 x%d frames (grid %d x %d threads)"
                  % (plan[0], plan[1], n, plan[5], 64 * plan[2] * plan[3]))
         executed = conv_flop
-    traffic = measured_traffic("convx_48_48_3x3_96x72_x80" if use_x3 else
-                               ("conv_wino_48_48_3x3_96x72_x80" if use_wino else "conv_48_48_3x3_96x72_x80"))
+    traffic, tsrc = measured_traffic("convx_48_48_3x3_96x72_x80" if use_x3 else
+                                     ("conv_wino_48_48_3x3_96x72_x80" if use_wino else "conv_48_48_3x3_96x72_x80"), True)
     # `achieved` is ALGORITHMIC (direct-convolution) FLOP/s as the bench contract defines it; `frac` is what the matrix
     # pipe actually does (executed MFMA FLOPs / peak), so a Winograd launch can never read above its pipe occupancy.
     # `algorithmic_frac` keeps the achieved / peak quotient, `hbm_frac` the measured HBM traffic against 8 TB/s.
@@ -161,7 +202,8 @@ def kernel_rooflines(dev, batch):
             "unit": "TFLOP/s", "frac": executed / (t_conv * 1e-3) / peak,
             "algorithmic_frac": conv_flop / (t_conv * 1e-3) / peak,
             "hbm_frac": (traffic if traffic is not None else conv_bytes) / (t_conv * 1e-3) / PEAK_HBM,
-            "hbm_frac_basis": "measured" if traffic is not None else "algorithmic bytes",
+            "hbm_frac_basis": ("%s (rocprofv3 PMC passes replayed from the committed file, not collected in this run)" % tsrc)
+            if traffic is not None else "algorithmic bytes",
             "traffic": traffic,
             "ms_per_launch": t_conv, "algorithmic_flop_per_launch": conv_flop,
             "executed_mfma_flop_per_launch": executed, "mfma_pipe_frac": executed / (t_conv * 1e-3) / peak}
@@ -220,6 +262,7 @@ def kernel_rooflines(dev, batch):
     hs = C // nh
     q, k_, v = (torch.randn(batch, C, T, generator=g).to(dev) for _ in range(3))
     t_att = event_time_ms(lambda: ops.chan_attn(q, k_, v, nh, hs ** -0.5), 20, st)
+    att_x3 = os.environ.get("OTPOSE_CONV_MATH", "x3") != "f32"
     att_flop = 4.0 * hs * hs * T * nh * batch
     att_bytes = 4.0 * 4 * batch * C * T
     attn_r = {"kernel": "attn_scores_kernel + attn_softmax_kernel + attn_pv_kernel, C=136 nh=2 T=6912 x%d clips" % batch,
@@ -227,7 +270,11 @@ def kernel_rooflines(dev, batch):
               "frac": att_bytes / (t_att * 1e-3) / PEAK_HBM, "traffic": None, "ms_per_call": t_att,
               "algorithmic_bytes_per_call": att_bytes, "mfma_flop_per_call": att_flop,
               "mfma_achieved_TFLOPs": att_flop / (t_att * 1e-3) / 1e12,
-              "mfma_frac": att_flop / (t_att * 1e-3) / PEAK_F32_MATRIX}
+              # the pipe the kernels use: split products = 3 bf16 MFMAs per fp32 product on the 2.5 PFLOP/s bf16 pipe; the f32
+              # kernels (OTPOSE_CONV_MATH=f32) run on the 157.3 TFLOP/s f32 MFMA
+              "mfma_pipe": "bf16 (3 products per fp32 product)" if att_x3 else "f32",
+              "mfma_frac": (3.0 * att_flop / (t_att * 1e-3) / PEAK_BF16_MATRIX) if att_x3
+              else att_flop / (t_att * 1e-3) / PEAK_F32_MATRIX}
     # the warping head (ten offset / mask convs + five DCN gathers + weighted sum) as one launch
     head_r = None
     if os.environ.get("OTPOSE_CONV_MATH", "x3") != "f32" and ops.dcn_fused_supported(32, 17, 96, 72, 5):
@@ -252,6 +299,19 @@ def kernel_rooflines(dev, batch):
     return conv, dcn_r, mlp_r, attn_r, head_r
 
 
+def forward_roofline(alg_flops_per_s, math):
+    """Whole-forward MFMA roofline against the pipe the kernels run on.  Split mode: every fp32 product is three bf16 MFMA
+    products, so the pipe executes >= 3x the algorithmic FLOPs (tap-slot / channel padding on top, not counted here) on the
+    2.5 PFLOP/s dense bf16 pipe (MI355X_MICROARCH.md, Matrix cores); exact mode: the 157.3 TFLOP/s f32 MFMA."""
+    if math == "f32":
+        return {"bound": "mfma", "pipe": "f32 MFMA", "achieved": alg_flops_per_s / 1e12, "peak": PEAK_F32_MATRIX / 1e12,
+                "unit": "TFLOP/s", "frac": alg_flops_per_s / PEAK_F32_MATRIX, "traffic": None}
+    return {"bound": "mfma", "pipe": "bf16 MFMA, 3 products per fp32 product", "achieved": alg_flops_per_s / 1e12,
+            "executed": 3.0 * alg_flops_per_s / 1e12, "peak": PEAK_BF16_MATRIX / 1e12, "unit": "TFLOP/s",
+            "frac": 3.0 * alg_flops_per_s / PEAK_BF16_MATRIX, "algorithmic_frac": alg_flops_per_s / PEAK_BF16_MATRIX,
+            "traffic": None}
+
+
 def golden_parity(model, cfg, dev):
     """Max-abs difference of the 7 forward outputs against the committed reference-generated golden of this very
     configuration (tests/golden/e2e_cfg2_b1.npz: one 384x288 W48 clip run through the reference model in the build
@@ -271,9 +331,6 @@ def golden_parity(model, cfg, dev):
             "max_rel_delta": max(deltas[n] / max(ranges[n], 1e-30) for n in deltas),
             "per_output": {n: {"max_abs_delta": deltas[n], "max_abs_ref": ranges[n]} for n in deltas},
             "tolerance": 1e-3, "vs": "tests/golden/e2e_cfg2_b1.npz (reference model, 1 clip of this config)"}
-
-
-PEAK_BF16_MATRIX = 2.5e15       # MI355X_MICROARCH.md: dense bf16 MFMA peak
 
 
 def train_step_probe(cfg, dev, batch, dtype="bf16", steps=3, dist=None):
@@ -371,16 +428,7 @@ def cpu_baseline():
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16, help="clips per GPU")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-train-step", action="store_true", help="skip the training-step probe (extra field of the line)")
-    ap.add_argument("--train-f32", action="store_true", help="also time the fp32 training step (1 GPU)")
-    ap.add_argument("--no-exact-fp32", action="store_true", help="skip the exact-fp32-kernel forward reported beside the headline")
-    a = ap.parse_args()
+    a = parse_args()
 
     # stdout carries exactly ONE JSON line: native libraries (RCCL prints a version banner through C stdio) get stderr
     json_out = os.fdopen(os.dup(1), "w")
@@ -389,6 +437,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        # the launcher's world and --gpus must agree: a line that says n_gpus = N was measured on N ranks
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d (launch N ranks with torch.distributed.run, or run "
+                         "`python bench.py --gpus N` and let it start them)\n" % (a.gpus, world))
+        sys.exit(2)
     dist = None
     if world > 1 or os.environ.get("OTPOSE_BENCH_DIST") == "1":     # env: exercise the RCCL path on a 1-GPU box
         import torch.distributed as dist
@@ -471,7 +524,12 @@ def main():
             "metric": "frames/sec at 384x288, 5-frame window, batch 16; heatmap max-abs delta vs ref",
             "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            # the arithmetic that was timed: every tensor, accumulator, normalisation and activation is fp32; the products of the
+            # convolutions / projections / MLPs / attention are three bf16 MFMA products of two-piece fp32 operands (~2^-17 per
+            # product; the reference's fp32 is 2^-24, its default TF32 convolutions on NVIDIA hardware 2^-11).  The same forward
+            # on exact-fp32 MFMA kernels is `exact_fp32_kernels` of this line.
+            "dtype": "f32" if math == "f32" else "f32 storage+accumulate / bf16x3 split products", "data": "synthetic",
+            "rccl_world": dist.get_world_size() if dist is not None else 1,
             "arithmetic": ("fp32 storage and accumulation everywhere; conv / MLP / projection products as three bf16 MFMA "
                            "products of two-piece operands (a = hi + lo, |a - hi - lo| <= 2^-18 |a|: DESIGN.md section 3.1c)"
                            if math != "f32" else "fp32 throughout (f32 MFMA)"),
@@ -479,9 +537,7 @@ def main():
                                    "ConvVideoTransformer, fp32 forward (eval), seeded synthetic weights" % a.batch,
                        "clips_per_gpu": a.batch, "frames_per_step_per_gpu": 5 * a.batch, "parallelism": "dp%d" % world,
                        "outputs_finite": finite},
-            "roofline_forward": {"bound": "mfma", "achieved": FLOP_PER_CLIP * a.batch * fwd_per_s / 1e12,
-                                 "peak": PEAK_F32_MATRIX / 1e12, "unit": "TFLOP/s",
-                                 "frac": FLOP_PER_CLIP * a.batch * fwd_per_s / PEAK_F32_MATRIX, "traffic": None},
+            "roofline_forward": forward_roofline(FLOP_PER_CLIP * a.batch * fwd_per_s, math),
         }
         log("timed region done: %.2f ms/step" % (1e3 * dt / a.steps))
         conv, dcn, mlp, attn, head = kernel_rooflines(dev, a.batch)

@@ -31,6 +31,9 @@ class FusedAdamW(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.max_grad_norm = float(max_grad_norm)
         self._flat = []                                  # per group: dict(p, g, m, v, params, step)
+        # [epoch, clean]: zero_grad() opens an epoch in which every slot is known to be zero (train_ops.grad_slot hands a
+        # slot out once per epoch); step() closes it.  One cell shared by all parameters of this optimizer.
+        self._slot_epoch = [0, False]
         for group in self.param_groups:
             ps = [p for p in group["params"] if p.requires_grad]
             if not ps:
@@ -53,6 +56,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 # destination of this parameter's gradient inside the flat buffer: the backward kernels of otpose_amd write
                 # there directly (grad_slot() below), so autograd neither allocates nor accumulates per-parameter tensors
                 p._otp_grad_slot = p.grad
+                p._otp_slot_epoch = self._slot_epoch
                 self.state[p] = {"step": 0, "exp_avg": fm[off:off + n].view_as(p), "exp_avg_sq": fv[off:off + n].view_as(p)}
                 off += n
             self._flat.append({"p": fp, "g": fg, "m": fm, "v": fv, "params": ps, "step": 0,
@@ -96,6 +100,8 @@ class FusedAdamW(torch.optim.Optimizer):
                 f["g"].zero_()
                 for p in f["params"]:
                     p.grad = None
+        self._slot_epoch[0] += 1
+        self._slot_epoch[1] = True
 
     @torch.no_grad()
     def grad_norm(self, _rehomed=False):
@@ -117,6 +123,7 @@ class FusedAdamW(torch.optim.Optimizer):
         loss = closure() if closure is not None else None
         L = hip.lib()
         self._rehome_grads()
+        self._slot_epoch[1] = False                      # the slots now hold this step's gradients: not clean until zero_grad()
         clip = self.max_grad_norm > 0.0
         if clip:
             self.grad_norm(_rehomed=True)

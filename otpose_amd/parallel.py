@@ -58,6 +58,16 @@ def world_size() -> int:
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def collectives_on() -> bool:
+    """True when the gradient / flag collectives must be issued: a world of more than one rank, or an initialised process
+    group of ONE rank with ``OTPOSE_FORCE_COLLECTIVES=1`` - the latter sends every tensor through RCCL on a single GPU
+    (sum over one rank = identity), so the device-side ordering of the exchange (side-stream gradients -> collective ->
+    optimizer) runs on a 1-GPU box exactly as it does on eight."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("OTPOSE_FORCE_COLLECTIVES") == "1"
+
+
 def rank() -> int:
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
@@ -92,17 +102,16 @@ def gather_clips(t: torch.Tensor, dst: int = 0) -> Optional[torch.Tensor]:
 
 def allreduce_joint_flags(flags: torch.Tensor) -> torch.Tensor:
     """MAX over ranks of the per-joint "ground truth has an exact-1 peak" flags (model/loss.py:47)."""
-    if world_size() > 1:
+    if collectives_on():
         dist.all_reduce(flags, op=dist.ReduceOp.MAX)
     return flags
 
 
 def allreduce_mean_(t: torch.Tensor) -> torch.Tensor:
     """In-place mean over ranks (loss scalars: the reference computes them on the gathered batch)."""
-    w = world_size()
-    if w > 1:
+    if collectives_on():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        t.div_(w)
+        t.div_(world_size())
     return t
 
 
@@ -111,13 +120,25 @@ def allreduce_flat_grads(optimizer) -> None:
     hyper-parameter group, so the exchange is one all-reduce(SUM) per group (three for ``make_optimizer``'s groups; the
     backbone group is 254 MB at W48 - few, large messages suit the point-to-point xGMI links) and a 1/world scale, with no
     packing or copy-back.  Call between ``loss.backward()`` and ``optimizer.step()``."""
-    w = world_size()
-    if w == 1:
+    if not collectives_on():
         return
-    works = [dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True) for g in optimizer.flat_grads()]
-    for work, g in zip(works, optimizer.flat_grads()):
+    w = world_size()
+    grads = optimizer.flat_grads()
+    if grads and grads[0].is_cuda:
+        # the exchange runs after ``loss.backward()`` has returned (no overlap with the backward: at a 140-160 ms step the
+        # 272 MB exchange is ~2-3 ms over xGMI).  Gradients of the HRNet branches were written on side streams; autograd syncs
+        # them with the stream backward() was called from when it finishes, and waiting for them once more here keeps the
+        # collective correct even when a caller drove the backward by hand.
+        from .hip import _SIDE_STREAMS
+        cur = torch.cuda.current_stream(grads[0].device)
+        for s in [torch.cuda.default_stream(grads[0].device)] + _SIDE_STREAMS.get(grads[0].device, []):
+            if s != cur:
+                cur.wait_stream(s)
+    works = [dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True) for g in grads]
+    for work, g in zip(works, grads):
         work.wait()
-        g.div_(w)
+        if w > 1:
+            g.div_(w)
 
 
 def broadcast_buffers(module: torch.nn.Module, src: int = 0) -> None:
@@ -144,6 +165,7 @@ class GradBuckets:
                  hooks: bool = False):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.world = world_size()
+        self.active = collectives_on()
         self.buckets: List[List[torch.nn.Parameter]] = []
         self.flat: List[torch.Tensor] = []
         cur: List[torch.nn.Parameter] = []
@@ -164,7 +186,7 @@ class GradBuckets:
         self._work: List[Optional[object]] = [None] * len(self.buckets)
         self._next = 0                      # hook mode: the next bucket allowed to launch (strict index order)
         self._handles = []
-        if hooks and self.world > 1:
+        if hooks and self.active:
             for p in self.params:
                 self._handles.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
@@ -209,7 +231,7 @@ class GradBuckets:
     # ---- public -------------------------------------------------------------------------------
     def reduce(self) -> None:
         """All-reduce every bucket now (no-hook mode) and write the averaged gradients back."""
-        if self.world == 1:
+        if not self.active:
             return
         for i in range(len(self.buckets)):
             if self._work[i] is None:
@@ -218,7 +240,7 @@ class GradBuckets:
 
     def finish(self) -> None:
         """Wait for the launched buckets, scale by 1/world, scatter back into ``p.grad``."""
-        if self.world == 1:
+        if not self.active:
             return
         for i, bk in enumerate(self.buckets):
             if self._work[i] is None:          # hook mode: a parameter of this bucket got no gradient
@@ -269,7 +291,7 @@ def train_step_dp(model, optimizer, x, margin, target, target_weight, forward=No
     loss.backward()
     if hasattr(optimizer, "flat_grads"):
         allreduce_flat_grads(optimizer)
-    elif world_size() > 1:
+    elif collectives_on():
         bk = getattr(optimizer, "_otp_buckets", None)
         if bk is None:
             bk = GradBuckets([p for g in optimizer.param_groups for p in g["params"]])

@@ -20,12 +20,23 @@ from .ops import (ACT_NONE, View, _check_f32, _require_gpu, conv2d_launch, conv2
 
 def grad_slot(param):
     """Where the gradient of ``param`` should be written: its slot inside the optimizer's flat gradient buffer
-    (:class:`otpose_amd.optim.FusedAdamW`, zero-filled by ``zero_grad``) when this is the first gradient of the step,
-    else None (the caller allocates; autograd accumulates as usual)."""
+    (:class:`otpose_amd.optim.FusedAdamW`) when that slot is known to be zero-filled AND this is the first request for it in
+    the current step, else None (the caller allocates; autograd accumulates as usual).
+
+    Some backward kernels accumulate into their destination (conv2d_grad_weight, dwconv3) and others overwrite, so a slot
+    is handed out only while the optimizer vouches for it: ``FusedAdamW.zero_grad()`` opens a new epoch (slots memset),
+    ``step()`` closes it.  ``model.zero_grad()`` / ``p.grad = None`` do not open one - the slot then still holds the last
+    step's gradient and ordinary tensors are used instead (``FusedAdamW._rehome_grads`` copies them in).  A parameter that
+    feeds two autograd nodes of one backward (two forwards summed, shared weights) gets the slot for the first node only:
+    autograd sums the second gradient as an ordinary tensor instead of seeing the same memory twice."""
     slot = getattr(param, "_otp_grad_slot", None)
-    owner = getattr(param, "_otp_grad_owner", param)        # a reshaped view of a parameter names its owner (TrainGraph.conv1d)
-    if slot is None or owner.grad is not None or slot.shape != param.shape:
+    if slot is None or slot.shape != param.shape:
         return None
+    owner = getattr(param, "_otp_grad_owner", param)        # a reshaped view of a parameter names its owner (TrainGraph.conv1d)
+    epoch = getattr(owner, "_otp_slot_epoch", None)          # shared [epoch, clean] cell of the owning optimizer
+    if epoch is None or not epoch[1] or owner.grad is not None or getattr(owner, "_otp_slot_taken", -1) == epoch[0]:
+        return None
+    owner._otp_slot_taken = epoch[0]
     # a fresh tensor object over the same memory: autograd adopts an incoming gradient without cloning it only when nobody
     # else holds a reference to that tensor object
     return slot.view(slot.shape)

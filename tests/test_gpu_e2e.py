@@ -161,10 +161,7 @@ def test_headline_batch_agrees_with_the_single_clip_the_golden_pins(golden):
         solo = [o.cpu() for o in m(x[7:8].cuda(), margin=margin[7:8].cuda())]      # rebuilds the engine for batch 1
     g = golden("e2e_cfg2_b1")
     rows = lambda t, k: t[k:k + 1] if t.shape[0] == 16 else t[k::16]      # `rough` stacks frames: (5 * 16, J, h, w)   # noqa: E731
-    for n, o in zip(NAMES, outs):
-        r = rows(o, 0)
-        assert r.shape == g[n].shape, n
-        assert float((r - g[n]).abs().max()) <= TOL * max(1.0, float(g[n].abs().max())), n
+    print(_check([rows(o, 0) for o in outs], g))          # heat-maps (output, rough): 1e-3 ABSOLUTE, like the 1-clip tests
     for n, a, b in zip(NAMES, solo, outs):
         r = rows(b, 7)
         assert float((a - r).abs().max()) <= 2e-5 * max(1.0, float(r.abs().max())), n

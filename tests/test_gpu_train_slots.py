@@ -1,0 +1,190 @@
+"""The optimisation step of the reference loop (script/Common.py:118-144: forward, two ST_OHKW terms, backward,
+clip_grad_norm_, AdamW) with the backward kernels writing parameter gradients straight into FusedAdamW's flat buffer
+(``train_ops.grad_slot``), against the SAME HIP graph with ordinary per-parameter gradients fed to torch.optim.AdamW +
+clip_grad_norm_.  Covers the accumulate-vs-overwrite and aliasing hazards of the direct-to-slot path: optimizer.zero_grad(),
+``model.zero_grad()`` (set_to_none), two forwards summed into one backward, f32 and bf16 graphs, and the RCCL exchange
+forced through a one-rank process group."""
+import copy
+import os
+
+import pytest
+import torch
+
+from otpose_amd import OTPose, tiny_cfg
+from otpose_amd import parallel as PAR
+from otpose_amd import synthetic as S
+from otpose_amd import train as TR
+from otpose_amd.optim import FusedAdamW
+from tests.conftest import seeded
+
+pytestmark = pytest.mark.gpu
+
+LR, WD, CLIP = 1e-3, 0.01, 1.0
+
+
+def _targets(b, j, h, w, seed=11):
+    g = seeded((b, j, h, w), seed).abs() * 0.2
+    g[:, ::2, 3, 4] = 1.0
+    g.clamp_(max=1.0)
+    wt = (seeded((b, j, 1), seed + 1) > -1.0).float()
+    return g.cuda(), wt.cuda()
+
+
+def _pair(dtype):
+    cfg = tiny_cfg(8, (64, 96))
+    a = OTPose(cfg)
+    S.fill_synthetic_(a)
+    b = copy.deepcopy(a)
+    for m in (a, b):
+        m.cuda().train()
+        m.train_dropout = False                           # the two replicas must see the same graph
+        m.train_dtype = dtype
+    return cfg, a, b
+
+
+def _loss(model, x, margin, g, wt):
+    return TR.criterion(TR.forward_train(model, x, margin), g, wt)
+
+
+def _grad_err(pa, pb):
+    """relative L2 error of the whole gradient and the worst per-tensor one (tensors with a non-negligible norm)."""
+    num = den = 0.0
+    worst, wname = 0.0, ""
+    for n, ga, gb in pa:
+        d = float((ga.double() - gb.double()).norm()) ** 2
+        r = float(gb.double().norm()) ** 2
+        num, den = num + d, den + r
+        if r > 1e-16 and (d / r) ** 0.5 > worst:
+            worst, wname = (d / r) ** 0.5, n
+    return (num / max(den, 1e-300)) ** 0.5, worst, wname
+
+
+# run-to-run spread of the HIP backward itself (float atomics in the DCN weight gradient, fp32 reductions): the two replicas
+# agree to ~1e-6; a stale or doubled gradient is an O(1) error
+GRAD_TOL = {"f32": 2e-4, "bf16": 2e-3}
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("zero_mode", ["optimizer", "model"])
+def test_slot_gradients_and_weights_match_per_parameter_path(dtype, zero_mode):
+    cfg, a, b = _pair(dtype)
+    x, margin = S.synthetic_clip(2, cfg.MODEL.IMAGE_SIZE)
+    x, margin = x.cuda(), margin.cuda()
+    J, (w, h) = cfg.MODEL.NUM_JOINTS, cfg.MODEL.HEATMAP_SIZE
+    opt_a = FusedAdamW([p for p in a.parameters() if p.requires_grad], lr=LR, weight_decay=WD, max_grad_norm=CLIP)
+    opt_b = torch.optim.AdamW([p for p in b.parameters() if p.requires_grad], lr=LR, weight_decay=WD)
+    assert all(hasattr(p, "_otp_grad_slot") for p in a.parameters() if p.requires_grad)
+    assert not any(hasattr(p, "_otp_grad_slot") for p in b.parameters())
+    names = [n for n, p in a.named_parameters() if p.requires_grad]
+    for it in range(3):
+        g, wt = _targets(2, J, h, w, seed=11 + 5 * it)
+        if zero_mode == "optimizer":
+            opt_a.zero_grad()
+        else:
+            a.zero_grad()                                   # set_to_none: slots keep the previous step's values
+        opt_b.zero_grad()
+        la = _loss(a, x, margin, g, wt)
+        lb = _loss(b, x, margin, g, wt)
+        assert abs(float(la) - float(lb)) <= 1e-5 * max(1.0, abs(float(lb)))
+        la.backward()
+        lb.backward()
+        if zero_mode == "optimizer" and it == 0:
+            # the direct path really ran: autograd adopted the slot views
+            pa = dict(a.named_parameters())
+            adopted = sum(1 for n in names if pa[n].grad is not None and pa[n].grad.data_ptr() == pa[n]._otp_grad_slot.data_ptr())
+            assert adopted > 0.9 * len(names), adopted
+        opt_a.flat_grads()                                  # re-homes any ordinary gradient into its slot
+        pb = dict(b.named_parameters())
+        triples = [(n, p.grad, pb[n].grad if pb[n].grad is not None else torch.zeros_like(p))
+                   for n, p in a.named_parameters() if p.requires_grad]
+        glob, worst, wname = _grad_err(triples, None)
+        print("step %d %s/%s: whole-gradient rel L2 %.2e, worst tensor %.2e (%s)" % (it, dtype, zero_mode, glob, worst, wname))
+        assert glob <= GRAD_TOL[dtype], (it, glob)
+        torch.nn.utils.clip_grad_norm_([p for p in b.parameters() if p.requires_grad], CLIP)
+        opt_a.step()
+        opt_b.step()
+    # weights after three AdamW steps: Adam normalises, so a per-step difference is bounded by lr per step
+    diff = max(float((p.detach() - pb[n].detach()).abs().max()) for n, p in a.named_parameters() if p.requires_grad)
+    print("max |w_slot - w_per_param| after 3 steps: %.3e (lr %.0e)" % (diff, LR))
+    assert diff <= 0.35 * LR, diff                          # a stale / doubled gradient moves weights by ~lr per step
+    sa, sb = a.state_dict(), b.state_dict()
+    k = "rough_pose_estimation_net.bn1.running_var"
+    assert float((sa[k] - sb[k]).abs().max()) <= 1e-4 * float(sb[k].abs().max())
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_two_forwards_one_backward(dtype):
+    """One parameter feeding two autograd nodes of the same backward: the slot goes to one of them only."""
+    cfg, a, b = _pair(dtype)
+    x, margin = S.synthetic_clip(2, cfg.MODEL.IMAGE_SIZE)
+    x, margin = x.cuda(), margin.cuda()
+    x2 = torch.roll(x, 1, 0) * 0.9
+    J, (w, h) = cfg.MODEL.NUM_JOINTS, cfg.MODEL.HEATMAP_SIZE
+    g, wt = _targets(2, J, h, w)
+    opt_a = FusedAdamW([p for p in a.parameters() if p.requires_grad], lr=LR, weight_decay=WD, max_grad_norm=CLIP)
+    opt_a.zero_grad()
+    (_loss(a, x, margin, g, wt) + _loss(a, x2, margin, g, wt)).backward()
+    (_loss(b, x, margin, g, wt) + _loss(b, x2, margin, g, wt)).backward()
+    opt_a.flat_grads()
+    pb = dict(b.named_parameters())
+    triples = [(n, p.grad, pb[n].grad if pb[n].grad is not None else torch.zeros_like(p))
+               for n, p in a.named_parameters() if p.requires_grad]
+    glob, worst, wname = _grad_err(triples, None)
+    print("two forwards %s: whole-gradient rel L2 %.2e, worst tensor %.2e (%s)" % (dtype, glob, worst, wname))
+    assert glob <= GRAD_TOL[dtype], glob
+
+
+def test_rccl_exchange_on_one_rank_matches_no_exchange():
+    """RCCL path on ONE GPU: a process group of a single rank with OTPOSE_FORCE_COLLECTIVES=1 sends the joint flags, the
+    flat gradient buffers (FusedAdamW) and GradBuckets' packed buckets (hook mode, launched from inside the backward with
+    gradients written on the HRNet side streams) through ``dist.all_reduce`` on device tensors.  A sum over one rank is the
+    identity, so the step must reproduce the step without any process group."""
+    import socket
+    import torch.distributed as dist
+    cfg, a, b = _pair("bf16")
+    x, margin = S.synthetic_clip(2, cfg.MODEL.IMAGE_SIZE)
+    x, margin = x.cuda(), margin.cuda()
+    J, (w, h) = cfg.MODEL.NUM_JOINTS, cfg.MODEL.HEATMAP_SIZE
+    g, wt = _targets(2, J, h, w)
+    c, d = copy.deepcopy(b), copy.deepcopy(b)                         # before any forward: no cached packs travel
+    for m in (c, d):
+        m.train_dropout, m.train_dtype = False, "bf16"
+    opt_a = FusedAdamW([p for p in a.parameters() if p.requires_grad], lr=LR, weight_decay=WD, max_grad_norm=CLIP)
+    opt_b = FusedAdamW([p for p in b.parameters() if p.requires_grad], lr=LR, weight_decay=WD, max_grad_norm=CLIP)
+    loss_b = PAR.train_step_dp(b, opt_b, x, margin, g, wt)          # no process group: no collective
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ["OTPOSE_FORCE_COLLECTIVES"] = "1"
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        assert PAR.collectives_on() and PAR.world_size() == 1
+        loss_a = PAR.train_step_dp(a, opt_a, x, margin, g, wt)      # flags MAX, 3 flat all-reduces, loss mean: all RCCL
+        torch.cuda.synchronize()
+        assert abs(float(loss_a) - float(loss_b)) <= 1e-5 * max(1.0, abs(float(loss_b)))
+        pb = dict(b.named_parameters())
+        diff = max(float((p.detach() - pb[n].detach()).abs().max()) for n, p in a.named_parameters() if p.requires_grad)
+        print("FusedAdamW + forced RCCL vs none: max weight diff %.3e" % diff)
+        assert diff <= 0.05 * LR, diff
+        # bucketed exchange launched by hooks from inside the backward (per-parameter gradients, torch optimizer)
+        params = [p for p in c.parameters() if p.requires_grad]
+        bk = PAR.GradBuckets(params, bucket_bytes=1 << 20, hooks=True)
+        assert bk.active and len(bk.buckets) > 1
+        _loss(c, x, margin, g, wt).backward()
+        launched = sum(1 for wk in bk._work if wk is not None)
+        bk.finish()
+        bk.remove_hooks()
+        torch.cuda.synchronize()
+        assert launched >= len(bk.buckets) - 1, launched          # buckets went out during the backward
+        # reference: the same backward with no exchange at all
+        os.environ["OTPOSE_FORCE_COLLECTIVES"] = "0"
+        _loss(d, x, margin, g, wt).backward()
+        pd = dict(d.named_parameters())
+        triples = [(n, p.grad, pd[n].grad) for n, p in c.named_parameters() if p.grad is not None and pd[n].grad is not None]
+        glob, worst, wname = _grad_err(triples, None)
+        print("GradBuckets (hooks, RCCL world 1) vs plain backward: rel L2 %.2e, worst %.2e (%s)" % (glob, worst, wname))
+        assert len(triples) > 300 and glob <= GRAD_TOL["bf16"]
+    finally:
+        os.environ.pop("OTPOSE_FORCE_COLLECTIVES", None)
+        dist.destroy_process_group()
