@@ -28,7 +28,7 @@ def pytest_collection_modifyitems(config, items):
 def golden():
     def load(name):
         z = np.load(os.path.join(GOLDEN, name + ".npz"))
-        return {k: torch.from_numpy(z[k]) for k in z.files}
+        return {k: torch.from_numpy(z[k]) for k in z.files if z[k].dtype.kind in "fiub"}
     return load
 
 

@@ -245,6 +245,100 @@ def gen_e2e_cfg2():
     _e2e(C.cfg2(), 1, "e2e_cfg2_b1")
 
 
+TRAIN_GRAD_KEYS = (
+    "rough_pose_estimation_net.conv1.weight",                                   # stem conv
+    "rough_pose_estimation_net.bn1.weight",
+    "rough_pose_estimation_net.layer1.0.conv2.weight",                          # Bottleneck
+    "rough_pose_estimation_net.stage2.0.branches.0.0.conv1.weight",             # BasicBlock
+    "rough_pose_estimation_net.stage3.0.fuse_layers.0.1.0.weight",              # fuse 1x1 (+ upsample)
+    "rough_pose_estimation_net.stage3.0.fuse_layers.2.0.0.0.weight",            # fuse 3x3 stride 2
+    "rough_pose_estimation_net.final_layer.weight",
+    "flow_encoder.stem.0.attn.query.weight",
+    "temporal_encoder1.stem.0.attn.query.weight", "temporal_encoder1.stem.2.attn.value_conv.weight",
+    "temporal_encoder1.stem.3.ln2.weight", "temporal_encoder1.stem.5.mlp.0.weight", "temporal_encoder1.branch.1.mlp.3.weight",
+    "temporal_encoder2.stem.1.attn.proj.weight", "temporal_encoder2.branch.0.drop_path_mlp.scale",
+    "final_layer1.weight", "def_fuse.layers.0.conv_bn_relu2_3_2.conv.weight",
+    "offset_mask_combine_conv.layers.1.conv_bn_relu3.conv.weight",
+    "offsets_list.0.0.weight", "masks_list.4.0.weight",
+    "modulated_deform_conv_list.2.deform_conv.weight", "modulated_deform_conv_list.2.deform_conv.bias",
+)
+
+
+def gen_train_step():
+    """one optimisation step of the reference loop (script/Common.py:118-144) on the imported reference
+    model in ``train()`` mode (BatchNorm batch statistics + running-stat update) with every Dropout p = 0 and every drop-path
+    probability 0 (the only stochastic pieces): forward, the two ST_OHKW terms of Common.py:122-130 through the reference's
+    own ``ST_OHKW_MSELoss``, backward, ``clip_grad_norm_(1.0)``, one AdamW step through the reference's ``make_optimizer``
+    groups.  Stored: the 7 outputs' checksums + heat-maps, the loss dict, the global gradient norm, per-parameter gradient
+    norms of ALL parameters, a handful of gradient tensors, BatchNorm running statistics after the step and a few updated
+    weights.  (The DCN arithmetic inside is the oracle's - see the module docstring.)"""
+    import_reference()
+    from model.loss import ST_OHKW_MSELoss
+    from model.blocks import AffineDropPath
+    from thirdparty.utils.train_utils import make_optimizer
+    cfg = C.tiny_cfg(8, (64, 96))
+    m = ref_otpose(cfg)
+    S.fill_synthetic_(m, S.WEIGHT_SEED, S.gains_for(cfg))
+    m.train()
+    n_do = n_dp = 0
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p, n_do = 0.0, n_do + 1
+        if isinstance(mod, AffineDropPath):
+            mod.drop_prob, n_dp = 0.0, n_dp + 1
+    print(f"  dropout modules zeroed: {n_do}, drop-path modules zeroed: {n_dp}")
+    B = 2
+    x, margin = S.synthetic_clip(B, cfg.MODEL.IMAGE_SIZE)
+    J = cfg.MODEL.NUM_JOINTS
+    g, tw = S.synthetic_targets(B, cfg.MODEL.HEATMAP_SIZE, J, sigma=1.5, seed=77)
+    g[:, 3] *= 0.5                                         # joint 3: no exact-1 peak -> teacher branch of loss.py:47
+    crit = ST_OHKW_MSELoss(True)
+    ocfg = C.CfgNode({"TRAIN": {"LR": 1e-3, "WD": 0.01, "OPTIMIZER": "AdamW"}})
+    opt = make_optimizer(m, ocfg)
+    outs = m(x, margin=margin)
+    pred_t = outs[1].split(B, dim=0)[0]                    # Common.py:124
+    loss = crit(outs[0], pred_t, g, tw)                    # :126
+    first_final = loss["final_loss"].detach().clone()
+    occlusion = (g + outs[2]) / 2                          # :127
+    second = crit(outs[4], outs[4], occlusion, tw)         # :129
+    loss["final_loss"] = loss["final_loss"] + second["final_loss"]
+    opt.zero_grad()
+    loss["final_loss"].backward()                          # :137
+    grads = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+    total_norm = torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)       # :138-142
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    opt.step()
+    names = ("output", "rough", "intersection", "prev_b", "context", "squeezed", "total_b")
+    arrays = {"out_" + n: o.detach() for n, o in zip(names, outs)}
+    arrays.update(target=g, target_weight=tw,
+                  loss_first_final=first_final, loss_second_final=second["final_loss"].detach(),
+                  loss_final=loss["final_loss"].detach(), loss_ohkm_s=loss["ohkm_loss_s"].detach(),
+                  loss_mse_s=loss["mse_loss_s"].detach(), grad_total_norm=total_norm.detach())
+    pnames = sorted(grads)
+    arrays["grad_norm_names"] = np.array(pnames)
+    arrays["grad_norms"] = np.array([float(grads[n].double().norm()) for n in pnames])
+    missing = [k for k in TRAIN_GRAD_KEYS if k not in grads]
+    assert not missing, missing
+    for k in TRAIN_GRAD_KEYS:
+        arrays["grad/" + k] = grads[k]
+    sd = m.state_dict()
+    for k in ("rough_pose_estimation_net.bn1.running_mean", "rough_pose_estimation_net.bn1.running_var",
+              "rough_pose_estimation_net.stage4.2.branches.3.3.bn2.running_var",
+              "def_fuse.layers.0.conv_bn_relu1.bn.running_mean", "rough_pose_estimation_net.bn1.num_batches_tracked"):
+        arrays["buf/" + k] = sd[k].detach()
+    # one AdamW step (groups of make_optimizer: lr / 100 for the backbone, no decay on norms / biases / scales)
+    for k in ("rough_pose_estimation_net.conv1.weight", "temporal_encoder1.stem.0.attn.query.weight", "final_layer1.weight",
+              "flow_encoder.stem.0.ln1.weight", "offsets_list.0.0.weight"):
+        arrays["step/" + k] = dict(m.named_parameters())[k].detach() - before[k]
+    arrays["opt_group_sizes"] = np.array([len(pg["params"]) for pg in opt.param_groups])
+    arrays["opt_group_lr"] = np.array([pg["lr"] for pg in opt.param_groups])
+    arrays["opt_group_wd"] = np.array([pg["weight_decay"] for pg in opt.param_groups])
+    save("train_step_tiny", **arrays)
+    print("  loss", {k: float(v) for k, v in loss.items()}, "second", float(second["final_loss"]), "|g|", float(total_norm))
+    big = sorted(((float(grads[n].norm()), n) for n in pnames), reverse=True)[:5]
+    print("  largest gradient tensors:", big)
+
+
 def _oracle_run(cfg, b, gains):
     from otpose_amd import OTPose
     m = OTPose(cfg)
@@ -284,7 +378,7 @@ def calibrate():
 
 
 GENS = {"keys": gen_state_dict_keys, "blocks": gen_blocks, "hrnet_tiny": gen_hrnet_tiny,
-        "losses": gen_losses, "decode": gen_decode, "accuracy": gen_accuracy, "e2e_tiny": gen_e2e_tiny, "e2e_cfg1": gen_e2e_cfg1, "e2e_cfg2": gen_e2e_cfg2}
+        "losses": gen_losses, "decode": gen_decode, "accuracy": gen_accuracy, "e2e_tiny": gen_e2e_tiny, "e2e_cfg1": gen_e2e_cfg1, "e2e_cfg2": gen_e2e_cfg2, "train_step": gen_train_step}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

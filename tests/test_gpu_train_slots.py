@@ -103,10 +103,18 @@ def test_slot_gradients_and_weights_match_per_parameter_path(dtype, zero_mode):
         torch.nn.utils.clip_grad_norm_([p for p in b.parameters() if p.requires_grad], CLIP)
         opt_a.step()
         opt_b.step()
-    # weights after three AdamW steps: Adam normalises, so a per-step difference is bounded by lr per step
-    diff = max(float((p.detach() - pb[n].detach()).abs().max()) for n, p in a.named_parameters() if p.requires_grad)
-    print("max |w_slot - w_per_param| after 3 steps: %.3e (lr %.0e)" % (diff, LR))
-    assert diff <= 0.35 * LR, diff                          # a stale / doubled gradient moves weights by ~lr per step
+        # one AdamW step from identical weights and (to 1e-6) identical gradients: Adam normalises, so a stale / doubled
+        # gradient would move weights by ~lr; rounding of the two implementations by ~1e-3 lr
+        with torch.no_grad():
+            diff = max(float((p - pb[n]).abs().max()) for n, p in a.named_parameters() if p.requires_grad)
+            print("step %d: max |w_slot - w_per_param| %.3e (lr %.0e)" % (it, diff, LR))
+            assert diff <= 0.05 * LR, (it, diff)
+            # re-align the replicas: the graph amplifies 1e-7 weight differences (ReLU / top-k decisions that flip) into
+            # 1e-3 gradient differences one step later, which would mask what this test is looking for
+            for n, p in b.named_parameters():
+                p.copy_(dict(a.named_parameters())[n])
+            for (_, ba), (_, bb) in zip(a.named_buffers(), b.named_buffers()):
+                bb.copy_(ba)
     sa, sb = a.state_dict(), b.state_dict()
     k = "rough_pose_estimation_net.bn1.running_var"
     assert float((sa[k] - sb[k]).abs().max()) <= 1e-4 * float(sb[k].abs().max())

@@ -7,6 +7,14 @@ from otpose_amd import OTPose, cfg1, cfg2, tiny_cfg
 from otpose_amd import modules as M
 from otpose_amd import synthetic as S
 
+def golden_names(name, key):
+    """String arrays of a fixture (the ``golden`` fixture hands out tensors only)."""
+    import os
+    import numpy as np
+    from tests.conftest import GOLDEN
+    return [str(s) for s in np.load(os.path.join(GOLDEN, name + ".npz"))[key]]
+
+
 TOL = 2e-5   # fp32 re-association noise between the module graph and the functional restatement
 
 
@@ -119,3 +127,62 @@ def test_e2e_cfg1(golden):
 
 def test_e2e_cfg2_one_clip(golden):
     _e2e(golden, "e2e_cfg2_b1", cfg2(), 1, 5e-5)
+
+
+def _oracle_train_step(g, dtype):
+    """The training step of script/Common.py:118-144 through the oracle (``training_bn=True``: BatchNorm batch statistics;
+    the golden was made with every Dropout / drop-path probability 0) under torch autograd, on the seeded tiny model."""
+    cfg = tiny_cfg(8, (64, 96))
+    m = OTPose(cfg)
+    S.fill_synthetic_(m)
+    params = dict(m.named_parameters())
+    sd = {k: (v.detach().to(dtype) if v.is_floating_point() else v.detach()) for k, v in m.state_dict().items()}
+    leaves = {k: sd[k].clone().requires_grad_() for k in params}
+    sd.update(leaves)
+    x, margin = S.synthetic_clip(2, cfg.MODEL.IMAGE_SIZE)
+    outs = O.otpose_forward(sd, cfg, x.to(dtype), margin, training_bn=True)
+    tg, tw = g["target"].to(dtype), g["target_weight"].to(dtype)
+    first = O.st_ohkw_mse_loss(outs[0], outs[1][:2], tg, tw)
+    second = O.st_ohkw_mse_loss(outs[4], outs[4], (tg + outs[2]) / 2, tw)
+    (first["final_loss"] + second["final_loss"]).backward()
+    return outs, first, second, leaves
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_train_step_matches_reference_golden(golden, dtype):
+    """loss dict, global gradient norm, the norm of EVERY parameter gradient and 22 whole gradient tensors
+    of one reference training step (tests/golden/make_golden.py::gen_train_step) pin ``otpose_forward(training_bn=True)`` +
+    autograd - the yardstick of the HIP training tests (tests/test_gpu_train_e2e.py)."""
+    g = golden("train_step_tiny")
+    outs, first, second, leaves = _oracle_train_step(g, dtype)
+    for n, o in zip(NAMES, outs):
+        _close(o.detach().float(), g["out_" + n], 5e-5)
+    _close(first["final_loss"].detach().float(), g["loss_first_final"], 1e-5)
+    _close(first["ohkm_loss_s"].detach().float(), g["loss_ohkm_s"], 1e-5)
+    _close(first["mse_loss_s"].detach().float(), g["loss_mse_s"], 1e-5)
+    _close(second["final_loss"].detach().float(), g["loss_second_final"], 1e-5)
+    # fp32 on both sides of a graph that amplifies rounding (BatchNorm at batch 2, DCN offset branch): per-tensor relative
+    # L2 and cosine, not element-wise equality; the reference itself ran in fp32, so the fp64 oracle sees the reference's
+    # rounding as the error
+    tol = 2e-3
+    names = golden_names("train_step_tiny", "grad_norm_names")
+    norms = g["grad_norms"].double()
+    assert len(names) == len(leaves) == norms.numel()
+    tot = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in leaves.values())))
+    assert abs(tot - float(g["grad_total_norm"])) <= 1e-3 * float(g["grad_total_norm"]), (tot, float(g["grad_total_norm"]))
+    worst = 0.0
+    for n, ref in zip(names, norms.tolist()):
+        mine = float(leaves[n].grad.double().norm())
+        if ref > 1e-3 * float(g["grad_total_norm"]):
+            worst = max(worst, abs(mine - ref) / ref)
+    assert worst <= 5e-3, worst
+    bad = []
+    for k in g:
+        if not k.startswith("grad/"):
+            continue
+        ref, mine = g[k].double(), leaves[k[5:]].grad.double()
+        rel = float((mine - ref).norm() / ref.norm().clamp_min(1e-30))
+        cos = float((mine * ref).sum() / (mine.norm() * ref.norm()).clamp_min(1e-30))
+        if rel > tol or cos < 1 - 1e-5:
+            bad.append((k, rel, cos))
+    assert not bad, bad
