@@ -145,6 +145,34 @@ int otp_conv2d_x3_supported(const otp_conv_desc* desc);
 int otp_conv2d_x3(const void* in, const void* wpacked, const void* shift, const void* res, void* out,
                   const otp_conv_desc* desc, void* stream);
 
+/* ---- split-record ("S8") activations + LDS-DMA fed 3x3 convolutions (csrc/convs.hip) ----------------------------------------
+ * The 3x3 / stride 1 / pad 1 convs of the HRNet BasicBlocks (model/HRNet.py:500-530: conv1 + bn1 + relu, conv2 + bn2 +
+ * residual + relu; 73 % of the forward's MACs) with the split-product arithmetic of otp_conv2d_x3, on activations the
+ * PRODUCER already stored as MFMA operand records:
+ *   S8 image of a logical (N, C, H, W) fp32 tensor, C % 8 == 0:  [N][C/8][2][H*W] records of 16 bytes = 8 bf16;
+ *   record (n, g, part, p): part 0 = hi = rne_bf16(x), part 1 = lo = rne_bf16(x - hi) of channels 8g .. 8g+7 at pixel p
+ *   (4 bytes per element, otp_s8_bytes);
+ *   C4 image of the same tensor: [N][C/4][H*W][4] fp32 - the layout a lane's accumulators have (4 output channels of one
+ *   pixel), used for the residual chain inside a branch: no transposition in any epilogue.
+ * otp_s8_pack converts a channel slice of an fp32 NCHW tensor to S8 (and, with out_c4 != NULL, to C4); otp_s8_unpack gives
+ * hi + lo back as fp32 NCHW, otp_c4_unpack the C4 image (tests).
+ * otp_conv3x3_s8: out = act(conv3x3(in) [scale folded into wpacked] + shift (+ res)); `in_s8` an S8 image, `wpacked` from
+ * otp_conv3x3_s8_pack_weight, `res_c4` a C4 image of (N, Cout, H, W) or NULL, `out_f32` NULL or the fp32 result as a C4 image
+ * (out_f32_layout = OTP_S8_F32_C4) or as a channel slice of an NCHW tensor (OTP_S8_F32_NCHW, desc->out_ctot / out_coff),
+ * `out_s8` NULL or the S8 image of the result.  desc: kh = kw = 3, stride 1, pad 1, dil 1, Cin % 16 == 0, Cout % 8 == 0,
+ * H*W % 4 == 0, act NONE / RELU.  Never allocates, never synchronises. */
+#define OTP_S8_F32_C4 1
+#define OTP_S8_F32_NCHW 2
+size_t otp_s8_bytes(int N, int C, int H, int W);
+int otp_s8_pack(const void* in_f32, void* out_s8, void* out_c4, int N, int C, int H, int W, int in_ctot, int in_coff, void* stream);
+int otp_s8_unpack(const void* in_s8, void* out_f32, int N, int C, int H, int W, void* stream);
+int otp_c4_unpack(const void* in_c4, void* out_f32, int N, int C, int H, int W, void* stream);
+int otp_conv3x3_s8_supported(const otp_conv_desc* desc);
+size_t otp_conv3x3_s8_weight_bytes(int Cout, int Cin);
+int otp_conv3x3_s8_pack_weight(const void* weight, const void* scale, void* wpacked, int Cout, int Cin, void* stream);
+int otp_conv3x3_s8(const void* in_s8, const void* wpacked, const void* shift, const void* res_c4, void* out_f32,
+                   int out_f32_layout, void* out_s8, const otp_conv_desc* desc, void* stream);
+
 /* ---- training-step building blocks for the convolutional layers (script/Common.py:91,136-144 run the reference under
  * model.train(): BatchNorm2d uses batch statistics, every conv needs both gradients) -----------------------------
  * Gradient w.r.t. the input of a stride-1 conv = otp_conv2d of grad_out with the weights packed by

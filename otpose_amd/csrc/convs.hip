@@ -1,0 +1,597 @@
+// 3x3 / stride 1 / pad 1 convolutions of the HRNet BasicBlocks (reference model/HRNet.py:500-530, 73 % of the forward's
+// MACs) on activations kept in the SPLIT RECORD format, fed by the LDS-DMA.
+//
+// Arithmetic: the split ("bf16x3") products of csrc/convx.hip - a = hi + lo (+ r, |r| <= 2^-18 |a|), products accumulated in
+// fp32 as lo*hi + hi*lo + hi*hi on v_mfma_f32_16x16x32_bf16.  What changes is WHERE the split happens and how operands reach
+// the matrix cores.  convx.hip reads fp32 NCHW, splits every window element in the consumer (3.1 vector instructions per
+// MFMA, 4-pixel-stride LDS writes with 44 % bank-conflict cycles, staging phases the matrix pipe idles through: VERDICT r02
+// item 4).  Here the PRODUCER's epilogue emits, next to (or instead of) the fp32 NCHW tensor, the record image the consumer's
+// MFMA operands are made of:
+//
+//     S8 format of a logical (N, C, H, W) fp32 tensor, C % 8 == 0:   [N][C/8][2][H*W] records of 16 bytes
+//     record (n, g, part, p) = 8 bf16: part 0 = hi, part 1 = lo of channels 8g .. 8g+7 at pixel p     (4 bytes / element)
+//
+// A pixel's record is exactly one lane's B operand of a k-slot, and a plane (n, g, part) is contiguous in the pixel index,
+// so a consumer stages its input window with `buffer_load_dwordx4 ... lds` only: 64 lanes x 16 bytes = 64 consecutive window
+// records per instruction, destination lane-linear in LDS, source offset per lane (computed ONCE per tile; the chunk / plane
+// is the instruction's scalar offset), padding columns / rows between images = lanes whose offset is out of the descriptor's
+// range (the hardware writes zeros).  No staging registers, no vector instructions, no ds_write in the main loop.
+//
+// LDS window: per (channel group of the chunk, part) a plane of 512 records; record index = (virtual row) * (W + 1) + 1 + x
+// with one zero record between rows (the right neighbour of x = W - 1 IS the left neighbour of the next row's x = 0) and one
+// zero row above every image.  Sixteen consecutive output pixels are sixteen consecutive records (17 across a row end), so
+// the ds_read_b128 of a B fragment is conflict-free; the two channel groups of a k-slot pair sit 2 planes = 16 KB apart.
+// Orientation: A = weights (M = 16 output channels), B = pixels (N = 16 pixels): a lane's accumulator registers are 4
+// output channels of ONE pixel.  Epilogue: accumulators (+ shift) -> LDS [cout][pixel] -> rows of 256 pixels: residual add,
+// ReLU, fp32 NCHW store as 1 KB runs, then per pixel 8 channels -> hi / lo records -> S8 store as 1 KB runs.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int SBM = 256;                  // output pixels per workgroup (4 waves x 4 pixel tiles of 16)
+constexpr int SPLANE = 512 * 16;          // bytes of one (channel group, part) window plane: 512 records
+constexpr int SWIN = 4 * SPLANE;          // a chunk = 16 channels = 2 groups x (hi, lo)
+constexpr int SKS = 5;                    // k-steps per chunk: 18 (tap, group) slots of 8 channels in 5 x 4 (2 zero-weight slots)
+constexpr int SOOB = -16;                 // buffer offset outside every descriptor: the load returns / writes zeros
+
+__device__ __forceinline__ uint32_t sdiv(uint32_t i, uint32_t magic) { return magic ? __umulhi(i, magic) : i; }
+uint32_t smagic(uint32_t d) { return d <= 1 ? 0u : (uint32_t)((1ull << 32) / d) + 1u; }   // exact while i * d < 2^32
+
+#ifdef OTP_CONVS_TIMING
+// development build only (tools/convs_timing.sh): per-workgroup phase stamps, never in libotpose_hip.so
+__device__ unsigned long long otp_convs_stamps[8192 * 32];
+#define SSTAMP(slot)                                                                                  \
+    do {                                                                                              \
+        if (threadIdx.x == 0 && blockIdx.x < 8192) otp_convs_stamps[blockIdx.x * 32 + (slot)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define SSTAMP(slot)
+#endif
+
+struct SPlan {
+    int N, C, H, W, HW, Cout, total;
+    int out_ctot, out_coff, act, f32_mode;
+    int NTW, nN, nTiles, nChunks, tpx;
+    int VR, W1, NIW;                      // virtual rows per image (H + 1), records per window row (W + 1), 64-record pieces per plane
+    uint32_t mHW, mW, mW1, mVR;
+};
+
+// 8 floats -> bf16 hi / lo records
+__device__ __forceinline__ void ssplit8(const float (&v)[8], u32x4& hi, u32x4& lo) {
+    uint32_t h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x2 a = {v[2 * i], v[2 * i + 1]};
+        const bf16x2 ah = __builtin_convertvector(a, bf16x2);
+        const uint32_t hb = __builtin_bit_cast(uint32_t, ah);
+        const f32x2 af = {__builtin_bit_cast(float, hb << 16), __builtin_bit_cast(float, hb & 0xffff0000u)};
+        const bf16x2 al = __builtin_convertvector(a - af, bf16x2);
+        h[i] = hb;
+        l[i] = __builtin_bit_cast(uint32_t, al);
+    }
+    hi = (u32x4){h[0], h[1], h[2], h[3]};
+    lo = (u32x4){l[0], l[1], l[2], l[3]};
+}
+
+// fp32 NCHW (channel-sliced view) -> S8 (+ the C4 image [N][C/4][H*W][4] of the same values, the residual layout of
+// otp_conv3x3_s8).  A thread owns 4 consecutive pixels of one channel group: 8 coalesced float4 loads, 4 + 4 record stores
+// (64 contiguous bytes per part) and 2 x 4 float4 stores.
+__global__ __launch_bounds__(256) void s8_pack_kernel(const float* __restrict__ in, u32x4* __restrict__ out, float* __restrict__ c4,
+                                                       int N, int C, int HW, int ctot, int coff) {
+    const int q4 = HW >> 2, G8 = C >> 3;
+    const size_t items = (size_t)N * G8 * q4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < items; i += (size_t)gridDim.x * 256) {
+        const int q = (int)(i % q4);
+        const size_t r = i / q4;
+        const int g = (int)(r % G8), n = (int)(r / G8);
+        const float* src = in + ((size_t)n * ctot + coff + 8 * g) * HW + 4 * q;
+        f32x4 v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = *reinterpret_cast<const f32x4*>(src + (size_t)e * HW);
+        u32x4* dst = out + ((size_t)(n * G8 + g) * 2) * HW + 4 * q;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float f[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = v[e][k];
+            u32x4 hi, lo;
+            ssplit8(f, hi, lo);
+            dst[k] = hi;
+            dst[(size_t)HW + k] = lo;
+            if (c4) {
+                f32x4* d4 = reinterpret_cast<f32x4*>(c4) + ((size_t)n * (C >> 2) + 2 * g) * HW + 4 * q + k;
+                d4[0] = (f32x4){f[0], f[1], f[2], f[3]};
+                d4[HW] = (f32x4){f[4], f[5], f[6], f[7]};
+            }
+        }
+    }
+}
+
+// C4 -> fp32 NCHW: test / debugging aid
+__global__ __launch_bounds__(256) void c4_unpack_kernel(const f32x4* __restrict__ in, float* __restrict__ out, int N, int C, int HW) {
+    const size_t items = (size_t)N * (C >> 2) * HW;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < items; i += (size_t)gridDim.x * 256) {
+        const int p = (int)(i % HW);
+        const size_t r = i / HW;
+        const int c4 = (int)(r % (C >> 2)), n = (int)(r / (C >> 2));
+        const f32x4 v = in[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[((size_t)n * C + 4 * c4 + e) * HW + p] = v[e];
+    }
+}
+
+// S8 -> fp32 NCHW (hi + lo in fp32): test / debugging aid, not on the forward path
+__global__ __launch_bounds__(256) void s8_unpack_kernel(const u32x4* __restrict__ in, float* __restrict__ out, int N, int C, int HW) {
+    const int G8 = C >> 3;
+    const size_t items = (size_t)N * G8 * HW;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < items; i += (size_t)gridDim.x * 256) {
+        const int p = (int)(i % HW);
+        const size_t r = i / HW;
+        const int g = (int)(r % G8), n = (int)(r / G8);
+        const u32x4 hi = in[((size_t)(n * G8 + g) * 2) * HW + p], lo = in[((size_t)(n * G8 + g) * 2 + 1) * HW + p];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const uint32_t hw = hi[e >> 1], lw = lo[e >> 1];
+            const float fh = __builtin_bit_cast(float, (e & 1) ? (hw & 0xffff0000u) : (hw << 16));
+            const float fl = __builtin_bit_cast(float, (e & 1) ? (lw & 0xffff0000u) : (lw << 16));
+            out[((size_t)n * C + 8 * g + e) * HW + p] = fh + fl;
+        }
+    }
+}
+
+// output-channel row of an MFMA tile <-> channel of the tile: rows 4..7 and 8..11 trade places, so that the two lanes that
+// meet in v_permlane32_swap (kl and kl + 2: rows 4 kl + r and 4 (kl + 2) + r) hold 8 CONSECUTIVE channels between them
+__host__ __device__ constexpr int srow2ch(int row) { return ((row & 4) << 1) | ((row & 8) >> 1) | (row & 3); }
+
+// packed weights of otp_conv3x3_s8: the image of otp_conv2d_x3_pack_weight (k = 3, stride 1) with the rows of every 16-row
+// tile in srow2ch order: [cout block][chunk][k-step][cout tile][hi, lo][lane][8] bf16, lane (i16, kl): row i16 of the tile =
+// channel 16 tile + srow2ch(i16), k-slot q = 4 s + kl -> tap q / 2, input channels 16 chunk + 8 (q % 2) .. + 7
+__global__ void s8_wpack_kernel(const float* __restrict__ w, const float* __restrict__ scale, u32x4* __restrict__ out, int Cout,
+                                int Cin, int NTW, int nN, int nChunks) {
+    const int total = nN * nChunks * SKS * NTW * 64;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int lane = idx & 63;
+        int r = idx >> 6;
+        const int t = r % NTW; r /= NTW;
+        const int s = r % SKS; r /= SKS;
+        const int chunk = r % nChunks, cb = r / nChunks;
+        const int cout = (cb * NTW + t) * 16 + srow2ch(lane & 15), kl = lane >> 4;
+        const int q = 4 * s + kl, tap = q >> 1, ci0 = chunk * 16 + 8 * (q & 1);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int ci = ci0 + j;
+            v[j] = (tap < 9 && cout < Cout && ci < Cin) ? w[((size_t)cout * Cin + ci) * 9 + tap] * (scale ? scale[cout] : 1.f) : 0.f;
+        }
+        u32x4 hi, lo;
+        ssplit8(v, hi, lo);
+        const size_t o = ((((size_t)(cb * nChunks + chunk) * SKS + s) * NTW + t) * 2) * 64 + lane;
+        out[o] = hi;
+        out[o + 64] = lo;
+    }
+}
+
+// v_permlane32_swap: a[lanes 32..63] <-> b[lanes 0..31].  Inline asm: the second result of __builtin_amdgcn_permlane32_swap
+// comes back as a copy of the first with hipcc / ROCm 7.2 (both extractvalue indices are 0 in the emitted IR); the s_nops
+// stand in for the wait states hipcc does not insert around an asm statement.
+__device__ __forceinline__ void swap32(float& a, float& b) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+
+// residual / fp32 output layouts of otp_conv3x3_s8
+enum { S_F32_NONE = 0, S_F32_C4 = 1, S_F32_NCHW = 2 };
+
+template <int NTW>
+__global__ __launch_bounds__(256, 2) void convs_kernel(const unsigned char* __restrict__ xs, const u32x4* __restrict__ wpk,
+                                                        const float* __restrict__ shift, const float* res, float* outf,
+                                                        u32x4* outs, const SPlan P) {
+    constexpr int WCH = SKS * NTW * 2;                             // 1 KB pieces of a chunk's weights
+    constexpr int WBYTES = WCH * 1024;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* win = smem;
+    unsigned char* wl = smem + SWIN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, kl = lane >> 4;
+
+    // workgroup -> (pixel tile, output-channel block); XCD x (block id mod 8) walks a contiguous tile range, the blocks of a
+    // tile back to back: the window rows neighbouring tiles share and the re-read window of the next block hit that L2
+    const int xcd = (int)blockIdx.x & 7, jb = (int)blockIdx.x >> 3;
+    const int tl = jb / P.nN, cb = jb - tl * P.nN;
+    const int tile = xcd * P.tpx + tl;
+    if (tile >= P.nTiles) return;
+    SSTAMP(0);
+#ifdef OTP_CONVS_TIMING
+    if (threadIdx.x == 0 && blockIdx.x < 8192) otp_convs_stamps[blockIdx.x * 32 + 30] = __builtin_amdgcn_s_memrealtime();
+#endif
+    const int P0 = tile * SBM;
+    const int n0 = P0 / P.HW, p0 = P0 - n0 * P.HW;            // (uniform, once per workgroup)
+    const int y0 = (int)sdiv((uint32_t)p0, P.mW);
+    const int Vf = n0 * P.VR + y0;                                 // first virtual row of the window (one above the first pixel's)
+    const int imgB = P.C * P.HW * 4;                               // bytes of one image of the S8 tensor
+
+    // ---- window pieces of this wave: piece k = wave + 4 j covers window records 64 k .. 64 k + 63 ------------------------------
+    int voff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int v = 64 * (wave + 4 * j) + lane;
+        const int r = (int)sdiv((uint32_t)v, P.mW1), cp = v - r * P.W1;
+        const int V = Vf + r;
+        const int n = (int)sdiv((uint32_t)V, P.mVR), yy = V - n * P.VR;
+        const bool ok = cp >= 1 && yy >= 1 && n < P.N;
+        voff[j] = ok ? (n - n0) * imgB + ((yy - 1) * P.W + cp - 1) * 16 : SOOB;
+    }
+    const size_t left = (size_t)(P.N - n0) * imgB;
+    const otp_rsrc rin = make_rsrc32(xs + (size_t)n0 * imgB, left > 0x7fffff00ull ? 0x7fffff00u : (unsigned)left);
+    const otp_rsrc rw = make_rsrc32(wpk, (unsigned)((size_t)P.nN * P.nChunks * WBYTES));
+    const int woff = lane * 16;
+
+    auto stage = [&](int c) __attribute__((always_inline)) {
+        // window: planes (group gl, part) of chunk c; plane index gl * 2 + part
+#pragma unroll
+        for (int pl = 0; pl < 4; ++pl) {
+            const int so = (((2 * c + (pl >> 1)) * 2 + (pl & 1)) * P.HW) * 16;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int k = wave + 4 * j;
+                if (k < P.NIW)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(win + pl * SPLANE + k * 1024),
+                                                             16, voff[j], so, 0, 0);
+            }
+        }
+        const int wb = (cb * P.nChunks + c) * WBYTES;
+#pragma unroll
+        for (int j = 0; j < (WCH + 3) / 4; ++j) {
+            const int k = wave + 4 * j;
+            if (k < WCH)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(wl + k * 1024), 16, woff,
+                                                         wb + k * 1024, 0, 0);
+        }
+    };
+    stage(0);
+    SSTAMP(1);
+
+    // ---- per pixel tile: fragment address, output offsets ---------------------------------------------------------------------
+    // lane (i16, kl) of pixel tile p: pixel m = (4 wave + p) 16 + i16 of the tile; accumulator register r of cout tile t =
+    // channel co_blk + 16 t + 4 pk + r of that pixel, pk = srow2ch(4 kl) / 4 (the row permutation of the packed weights)
+    const int pk = ((kl & 1) << 1) | (kl >> 1);
+    const int co_blk = cb * NTW * 16;
+    int pbase[4], pimg[4], ppix[4];
+    bool pval[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        int m = (wave * 4 + p) * 16 + i16;
+        pval[p] = P0 + m < P.total;
+        if (!pval[p]) m = P.total - 1 - P0;                        // tail tile: a finite address, the result is dropped
+        const int q = p0 + m;
+        const int dn = (int)sdiv((uint32_t)q, P.mHW), pi = q - dn * P.HW;
+        const int y = (int)sdiv((uint32_t)pi, P.mW), x = pi - y * P.W;
+        pbase[p] = (((n0 + dn) * P.VR + y - Vf) * P.W1 + x) * 16;   // record of tap (0, 0): one row up, one column left
+        pimg[p] = n0 + dn;
+        ppix[p] = pi;
+    }
+    int toff[SKS];
+#pragma unroll
+    for (int s = 0; s < SKS; ++s) {
+        const int q = 4 * s + kl;
+        int tap = q >> 1;
+        if (tap > 8) tap = 8;                                      // zero weights: any finite data
+        const int dy = tap / 3, dx = tap - dy * 3;
+        toff[s] = (dy * P.W1 + dx) * 16 + (q & 1) * (2 * SPLANE);
+    }
+
+    // accumulators start from shift (+ residual): the residual tensor is in the C4 layout [N][C/4][H*W][4], so a lane's four
+    // channels of a pixel are one float4 - loaded while the first chunk's DMA is in flight
+    f32x4 acc[NTW][4];
+    const int C4o = P.Cout >> 2;
+    {
+        f32x4 sh[NTW];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const int co = co_blk + 16 * t + 4 * pk;
+            sh[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (shift && co < P.Cout) sh[t] = *reinterpret_cast<const f32x4*>(shift + co);
+        }
+        if (res) {
+            // every load is issued before the first use (a load behind a per-element condition makes hipcc wait for each one)
+            f32x4 rv[NTW][4];
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) {
+                const int co = co_blk + 16 * t + 4 * pk;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const bool ok = co < P.Cout && pval[p];
+                    rv[t][p] = *reinterpret_cast<const f32x4*>(res + (ok ? (((size_t)pimg[p] * C4o + (co >> 2)) * P.HW + ppix[p]) * 4 : 0));
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NTW; ++t)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const bool ok = co_blk + 16 * t + 4 * pk < P.Cout && pval[p];
+                    acc[t][p] = ok ? sh[t] + rv[t][p] : sh[t];
+                }
+        } else {
+#pragma unroll
+            for (int t = 0; t < NTW; ++t)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) acc[t][p] = sh[t];
+        }
+    }
+
+    // One chunk = SKS k-steps x 4 pixel tiles x NTW cout tiles x 3 products.  The fragments of the next pixel tile (and, at
+    // the last pixel tile of a k-step, the weight fragments of the next step) are read before the MFMAs of the current one.
+    auto mfma_phase = [&]() __attribute__((always_inline)) {
+        bf16x8 ah[2][NTW], al[2][NTW], bh[2], bl[2];
+        auto load_a = [&](int buf, int s) __attribute__((always_inline)) {
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) {
+                const unsigned char* a = wl + ((s * NTW + t) * 2) * 1024 + lane * 16;
+                ah[buf][t] = *reinterpret_cast<const bf16x8*>(a);
+                al[buf][t] = *reinterpret_cast<const bf16x8*>(a + 1024);
+            }
+        };
+        auto load_b = [&](int buf, int s, int p) __attribute__((always_inline)) {
+            const unsigned char* b = win + pbase[p] + toff[s];
+            bh[buf] = *reinterpret_cast<const bf16x8*>(b);
+            bl[buf] = *reinterpret_cast<const bf16x8*>(b + SPLANE);
+        };
+        load_a(0, 0);
+        load_b(0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < SKS; ++s)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int cur = (s * 4 + p) & 1, sa = s & 1;
+                if (p + 1 < 4) {
+                    load_b(cur ^ 1, s, p + 1);
+                } else if (s + 1 < SKS) {
+                    load_b(cur ^ 1, s + 1, 0);
+                    load_a(sa ^ 1, s + 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) {
+                    acc[t][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[sa][t], bh[cur], acc[t][p], 0, 0, 0);
+                    acc[t][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[sa][t], bl[cur], acc[t][p], 0, 0, 0);
+                    acc[t][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[sa][t], bh[cur], acc[t][p], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    };
+
+    SSTAMP(2);
+    for (int c = 0; c < P.nChunks; ++c) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's pieces of chunk c have landed
+        if (c < 3) SSTAMP(3 + 4 * c);
+        __syncthreads();                                           // ... and everybody else's
+        if (c < 3) SSTAMP(4 + 4 * c);
+        mfma_phase();
+        if (c < 3) SSTAMP(5 + 4 * c);
+        if (c + 1 < P.nChunks) {
+            __syncthreads();                                       // every wave is done with the LDS image of chunk c
+            stage(c + 1);
+        }
+        if (c < 3) SSTAMP(6 + 4 * c);
+    }
+    SSTAMP(16);
+
+    // ---- epilogue: no LDS, no barrier - every lane stores what its accumulators hold --------------------------------------------
+    if (P.act == OTP_ACT_RELU) {
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[t][p][r] = fmaxf(acc[t][p][r], 0.f);
+    }
+    if (P.f32_mode == S_F32_C4) {
+        // [N][Cout/4][H*W][4]: one float4 per (cout tile, pixel tile); the 16 lanes of a row write 256 contiguous bytes
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const int co = co_blk + 16 * t + 4 * pk;
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                if (pval[p] && co < P.Cout)
+                    *reinterpret_cast<f32x4*>(outf + (((size_t)pimg[p] * C4o + (co >> 2)) * P.HW + ppix[p]) * 4) = acc[t][p];
+        }
+    } else if (P.f32_mode == S_F32_NCHW) {
+        // channel slice of an NCHW tensor (the tensor a fuse layer / another kernel family reads): 4 planes per lane
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const int co = co_blk + 16 * t + 4 * pk;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                float* o = outf + ((size_t)pimg[p] * P.out_ctot + P.out_coff + co) * P.HW + ppix[p];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (pval[p] && co + r < P.Cout) o[(size_t)r * P.HW] = acc[t][p][r];
+            }
+        }
+    }
+    SSTAMP(17);
+    if (outs) {
+        // S8 records: lanes kl and kl + 2 (l and l + 32) hold rows 4 kl + r and 4 (kl + 2) + r = channels 8 b .. 8 b + 7 of the tile
+        // (b = kl & 1, srow2ch).  v_permlane32_swap on a pair of cout tiles (ta, tb) hands the lower half of the wave tile ta's
+        // eight channels and the upper half tile tb's; each lane splits its eight values and stores one hi and one lo record.
+        const int Go = P.Cout >> 3;
+        const bool upper = kl >= 2;
+#pragma unroll
+        for (int tp = 0; tp < (NTW + 1) / 2; ++tp) {
+            const int ta = 2 * tp, tb = (2 * tp + 1 < NTW) ? 2 * tp + 1 : 2 * tp;
+            const int tile16 = upper ? tb : ta;
+            const int g = ((co_blk >> 4) + tile16) * 2 + (kl & 1);
+            const bool lanes_on = (ta != tb) || !upper;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                float f[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float a = acc[ta][p][r], b = acc[tb][p][r];
+                    swap32(a, b);
+                    // lower lanes: a = own rows (channels 8 b + r), b = the partner's (8 b + 4 + r); upper lanes: a = the
+                    // partner's rows of tile tb (8 b + r), b = own (8 b + 4 + r)
+                    f[r] = a;
+                    f[4 + r] = b;
+                }
+                u32x4 hi, lo;
+                ssplit8(f, hi, lo);
+                if (lanes_on && pval[p] && g < Go) {
+                    u32x4* d = outs + ((size_t)(pimg[p] * Go + g) * 2) * P.HW + ppix[p];
+                    d[0] = hi;
+                    d[P.HW] = lo;
+                }
+            }
+        }
+    }
+    SSTAMP(19);
+#ifdef OTP_CONVS_TIMING
+    if (threadIdx.x == 0 && blockIdx.x < 8192) otp_convs_stamps[blockIdx.x * 32 + 31] = __builtin_amdgcn_s_memrealtime();
+#endif
+}
+
+int s8_ntw(int Cout) {
+    const int c16 = (Cout + 15) / 16;
+    return (c16 % 3 == 0) ? 3 : (c16 % 2 == 0 || c16 <= 2 ? 2 : 3);          // same rule as csrc/convx.hip (shared weight image)
+}
+
+bool convs_plan(const otp_conv_desc& d, SPlan& P) {
+    if (d.kh != 3 || d.kw != 3 || d.stride != 1 || d.pad != 1 || d.dil != 1) return false;
+    if (d.res_up > 1 || d.frame_split > 0 || d.in2_ctot > 0 || d.act == OTP_ACT_GELU) return false;
+    if (d.Cin % 16 || d.Cout % 8 || ((d.H * d.W) & 3) || d.Ho != d.H || d.Wo != d.W) return false;
+    P.N = d.N; P.C = d.Cin; P.H = d.H; P.W = d.W; P.HW = d.H * d.W; P.Cout = d.Cout; P.total = d.N * P.HW;
+    P.out_ctot = d.out_ctot; P.out_coff = d.out_coff; P.act = d.act; P.f32_mode = S_F32_NONE;
+    P.NTW = s8_ntw(d.Cout);
+    P.nN = ((d.Cout + 15) / 16 + P.NTW - 1) / P.NTW;
+    P.nTiles = (P.total + SBM - 1) / SBM;
+    P.nChunks = d.Cin / 16;
+    P.tpx = (P.nTiles + 7) / 8;
+    P.VR = d.H + 1;
+    P.W1 = d.W + 1;
+    int rows = 0;
+    for (int t = 0; t < P.nTiles; ++t) {
+        const int a = t * SBM, b = (a + SBM < P.total ? a + SBM : P.total) - 1;
+        const int na = a / P.HW, ya = (a % P.HW) / d.W, nb = b / P.HW, yb = (b % P.HW) / d.W;
+        const int r = (nb * P.VR + yb + 2) - (na * P.VR + ya) + 1;   // virtual rows Vf .. V(last pixel) + 1
+        if (r > rows) rows = r;
+    }
+    const int NV = rows * P.W1 + 1;                                 // + the record right of the last row's last pixel
+    if (NV > 512) return false;
+    P.NIW = (NV + 63) / 64;
+    P.mHW = smagic(P.HW); P.mW = smagic(d.W); P.mW1 = smagic(P.W1); P.mVR = smagic(P.VR);
+    // exactness of the magic divisions (numerator * divisor < 2^32) and 31-bit byte offsets
+    if ((long)(P.HW + SBM) * P.HW >= (1l << 32) || (long)P.HW * d.W >= (1l << 32)) return false;
+    if ((long)(d.N + 1) * P.VR * P.VR >= (1l << 32)) return false;
+    if ((long)d.Cin * P.HW * 4 * 8 >= (1l << 31)) return false;    // a tile spans < 8 images: per-lane offsets stay 31-bit
+    if (P.HW < 32) return false;
+    if ((size_t)P.nN * P.nChunks * SKS * P.NTW * 2 * 1024 >= (1ull << 31)) return false;
+    return true;
+}
+
+template <int NTW>
+int convs_launch(const void* xs, const void* wpk, const float* shift, const float* res, float* outf, void* outs, const SPlan& P,
+                 hipStream_t st) {
+    auto kern = convs_kernel<NTW>;
+    const size_t need = (size_t)SWIN + SKS * NTW * 2 * 1024;
+    OTP_ALLOW_BIG_LDS(kern, need);
+    hipLaunchKernelGGL(kern, dim3(8 * P.tpx * P.nN), dim3(256), need, st, static_cast<const unsigned char*>(xs),
+                       static_cast<const u32x4*>(wpk), shift, res, outf, static_cast<u32x4*>(outs), P);
+    return otp_launch_status();
+}
+
+}  // namespace
+
+#ifdef OTP_CONVS_TIMING
+extern "C" int otp_convs_read_stamps(void* host_out, size_t bytes) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(otp_convs_stamps), bytes) == hipSuccess ? OTP_OK : OTP_ERR_LAUNCH;
+}
+#endif
+
+extern "C" size_t otp_s8_bytes(int N, int C, int H, int W) {
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || C % 8) return 0;
+    return (size_t)N * C * H * W * 4;
+}
+
+extern "C" int otp_s8_pack(const void* in, void* out, void* out_c4, int N, int C, int H, int W, int in_ctot, int in_coff,
+                           void* stream) {
+    if (!in || !out || N <= 0 || C <= 0 || H <= 0 || W <= 0 || in_ctot < in_coff + C || in_coff < 0) return OTP_ERR_BAD_ARG;
+    if (C % 8 || ((H * W) & 3) ||
+        ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(out_c4)) & 15))
+        return OTP_ERR_UNSUPPORTED;
+    const size_t items = (size_t)N * (C / 8) * (H * W / 4);
+    const int grid = (int)((items + 255) / 256 > 8192 ? 8192 : (items + 255) / 256);
+    hipLaunchKernelGGL(s8_pack_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const float*>(in),
+                       static_cast<u32x4*>(out), static_cast<float*>(out_c4), N, C, H * W, in_ctot, in_coff);
+    return otp_launch_status();
+}
+
+extern "C" int otp_s8_unpack(const void* in, void* out, int N, int C, int H, int W, void* stream) {
+    if (!in || !out || N <= 0 || C <= 0 || H <= 0 || W <= 0) return OTP_ERR_BAD_ARG;
+    if (C % 8) return OTP_ERR_UNSUPPORTED;
+    const size_t items = (size_t)N * (C / 8) * H * W;
+    const int grid = (int)((items + 255) / 256 > 8192 ? 8192 : (items + 255) / 256);
+    hipLaunchKernelGGL(s8_unpack_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const u32x4*>(in),
+                       static_cast<float*>(out), N, C, H * W);
+    return otp_launch_status();
+}
+
+extern "C" int otp_c4_unpack(const void* in, void* out, int N, int C, int H, int W, void* stream) {
+    if (!in || !out || N <= 0 || C <= 0 || H <= 0 || W <= 0) return OTP_ERR_BAD_ARG;
+    if (C % 4) return OTP_ERR_UNSUPPORTED;
+    const size_t items = (size_t)N * (C / 4) * H * W;
+    const int grid = (int)((items + 255) / 256 > 8192 ? 8192 : (items + 255) / 256);
+    hipLaunchKernelGGL(c4_unpack_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const f32x4*>(in),
+                       static_cast<float*>(out), N, C, H * W);
+    return otp_launch_status();
+}
+
+extern "C" int otp_conv3x3_s8_supported(const otp_conv_desc* desc) {
+    if (!desc) return 0;
+    SPlan P{};
+    return convs_plan(*desc, P) ? 1 : 0;
+}
+
+extern "C" size_t otp_conv3x3_s8_weight_bytes(int Cout, int Cin) {
+    if (Cout <= 0 || Cin <= 0 || Cin % 16) return 0;
+    const int NTW = s8_ntw(Cout), nN = ((Cout + 15) / 16 + NTW - 1) / NTW;
+    return (size_t)nN * (Cin / 16) * SKS * NTW * 2 * 1024;
+}
+
+extern "C" int otp_conv3x3_s8_pack_weight(const void* weight, const void* scale, void* wpacked, int Cout, int Cin, void* stream) {
+    if (!weight || !wpacked || Cout <= 0 || Cin <= 0) return OTP_ERR_BAD_ARG;
+    if (!otp_conv3x3_s8_weight_bytes(Cout, Cin)) return OTP_ERR_UNSUPPORTED;
+    const int NTW = s8_ntw(Cout), nN = ((Cout + 15) / 16 + NTW - 1) / NTW, nChunks = Cin / 16;
+    const int total = nN * nChunks * SKS * NTW * 64;
+    hipLaunchKernelGGL(s8_wpack_kernel, dim3(otp_ceil_div(total, 256) > 2048 ? 2048 : otp_ceil_div(total, 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), static_cast<const float*>(weight), static_cast<const float*>(scale),
+                       static_cast<u32x4*>(wpacked), Cout, Cin, NTW, nN, nChunks);
+    return otp_launch_status();
+}
+
+extern "C" int otp_conv3x3_s8(const void* in_s8, const void* wpacked, const void* shift, const void* res_c4, void* out_f32,
+                              int out_f32_layout, void* out_s8, const otp_conv_desc* desc, void* stream) {
+    if (!in_s8 || !wpacked || !desc || (!out_f32 && !out_s8)) return OTP_ERR_BAD_ARG;
+    const otp_conv_desc& d = *desc;
+    if (d.N <= 0 || d.Cin <= 0 || d.Cout <= 0 || d.H <= 0 || d.W <= 0) return OTP_ERR_BAD_ARG;
+    if (out_f32 && out_f32_layout != OTP_S8_F32_C4 && out_f32_layout != OTP_S8_F32_NCHW) return OTP_ERR_BAD_ARG;
+    if (out_f32 && out_f32_layout == OTP_S8_F32_NCHW && d.out_ctot < d.out_coff + d.Cout) return OTP_ERR_BAD_ARG;
+    if ((reinterpret_cast<uintptr_t>(in_s8) | reinterpret_cast<uintptr_t>(wpacked) | reinterpret_cast<uintptr_t>(out_f32) |
+         reinterpret_cast<uintptr_t>(out_s8) | reinterpret_cast<uintptr_t>(res_c4) | reinterpret_cast<uintptr_t>(shift)) & 15)
+        return OTP_ERR_UNSUPPORTED;
+    SPlan P{};
+    if (!convs_plan(d, P)) return OTP_ERR_UNSUPPORTED;
+    P.f32_mode = out_f32 ? (out_f32_layout == OTP_S8_F32_C4 ? S_F32_C4 : S_F32_NCHW) : S_F32_NONE;
+    auto st = static_cast<hipStream_t>(stream);
+    auto fs = static_cast<const float*>(shift);
+    auto fr = static_cast<const float*>(res_c4);
+    auto fo = static_cast<float*>(out_f32);
+    return P.NTW == 2 ? convs_launch<2>(in_s8, wpacked, fs, fr, fo, out_s8, P, st)
+                      : convs_launch<3>(in_s8, wpacked, fs, fr, fo, out_s8, P, st);
+}

@@ -63,6 +63,14 @@ SIGNATURES = {
     "otp_conv2d_x3_pack_weight": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "otp_conv2d_x3_supported": (c_int, [ctypes.POINTER(ConvDesc)]),
     "otp_conv2d_x3": (c_int, [c_void_p] * 5 + [ctypes.POINTER(ConvDesc), c_void_p]),
+    "otp_s8_bytes": (c_size_t, [c_int] * 4),
+    "otp_s8_pack": (c_int, [c_void_p] * 3 + [c_int] * 6 + [c_void_p]),
+    "otp_s8_unpack": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
+    "otp_c4_unpack": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
+    "otp_conv3x3_s8_supported": (c_int, [ctypes.POINTER(ConvDesc)]),
+    "otp_conv3x3_s8_weight_bytes": (c_size_t, [c_int, c_int]),
+    "otp_conv3x3_s8_pack_weight": (c_int, [c_void_p] * 3 + [c_int, c_int, c_void_p]),
+    "otp_conv3x3_s8": (c_int, [c_void_p] * 5 + [c_int, c_void_p, ctypes.POINTER(ConvDesc), c_void_p]),
     "otp_conv2d_set_tile": (c_int, [c_int] * 4),
     "otp_conv2d_last_plan": (c_int, [ctypes.POINTER(c_int)]),
     "otp_conv2d_plan": (c_int, [ctypes.POINTER(ConvDesc), ctypes.POINTER(c_int)]),

@@ -399,6 +399,112 @@ def conv2d_x3(x, weight, scale=None, shift=None, act=ACT_NONE, res=None, pad=1, 
     return out
 
 
+# ---- split-record (S8) activations and the LDS-DMA fed 3x3 convolution (csrc/convs.hip) --------------------------------
+S8_F32_C4, S8_F32_NCHW = 1, 2
+
+
+def s8_empty(n, c, h, w, device):
+    """Storage of the S8 image of a logical (n, c, h, w) fp32 tensor: [n][c/8][2][h*w] records of 8 bf16 (hi | lo)."""
+    nbytes = hip.lib().otp_s8_bytes(n, c, h, w)
+    if not nbytes:
+        raise ValueError(f"S8 images need a channel count that is a multiple of 8, got {c}")
+    return torch.empty(nbytes // 4, dtype=torch.int32, device=device)
+
+
+def c4_empty(n, c, h, w, device):
+    """Storage of the C4 image [n][c/4][h*w][4] fp32 of a logical (n, c, h, w) tensor."""
+    assert c % 4 == 0
+    return torch.empty(n * c * h * w, dtype=torch.float32, device=device)
+
+
+def s8_pack(inp, out=None, out_c4=None, stream=None):
+    """fp32 NCHW tensor or channel-slice :class:`View` -> S8 image (hi = rne_bf16(x), lo = rne_bf16(x - hi)) and, when
+    ``out_c4`` is given, the C4 image of the same values."""
+    iv = inp if isinstance(inp, View) else View(inp.contiguous())
+    _require_gpu(iv.t)
+    n, _, h, w = iv.t.shape
+    out = s8_empty(n, iv.C, h, w, iv.t.device) if out is None else out
+    hip.check(hip.lib().otp_s8_pack(hip.ptr(iv.t), hip.ptr(out), hip.ptr(out_c4), n, iv.C, h, w, iv.ctot, iv.coff,
+                                    stream if stream is not None else hip.stream_of(iv.t)), "otp_s8_pack")
+    return out
+
+
+def s8_unpack(s8, n, c, h, w):
+    """S8 image -> fp32 (n, c, h, w) = hi + lo (tests / debugging)."""
+    _require_gpu(s8)
+    out = torch.empty(n, c, h, w, dtype=torch.float32, device=s8.device)
+    hip.check(hip.lib().otp_s8_unpack(hip.ptr(s8), hip.ptr(out), n, c, h, w, hip.stream_of(s8)), "otp_s8_unpack")
+    return out
+
+
+def c4_unpack(c4, n, c, h, w):
+    """C4 image -> fp32 NCHW (tests / debugging)."""
+    _require_gpu(c4)
+    out = torch.empty(n, c, h, w, dtype=torch.float32, device=c4.device)
+    hip.check(hip.lib().otp_c4_unpack(hip.ptr(c4), hip.ptr(out), n, c, h, w, hip.stream_of(c4)), "otp_c4_unpack")
+    return out
+
+
+def s8_conv_supported(desc) -> bool:
+    return bool(hip.lib().otp_conv3x3_s8_supported(desc))
+
+
+def s8_conv_desc(n, cin, cout, h, w, act=ACT_NONE, out: View = None):
+    d = hip.ConvDesc()
+    d.N, d.Cin, d.H, d.W, d.Cout = n, cin, h, w, cout
+    d.kh = d.kw = 3
+    d.stride, d.pad, d.dil = 1, 1, 1
+    d.in_ctot, d.in_coff, d.in2_ctot, d.in2_coff = cin, 0, 0, 0
+    d.out_ctot, d.out_coff = (out.ctot, out.coff) if out is not None else (cout, 0)
+    d.res_ctot, d.res_coff, d.res_up = 0, 0, 1
+    d.act, d.Ho, d.Wo, d.frame_split = act, h, w, 0
+    return d
+
+
+def pack_s8_weight(weight, scale=None):
+    """(Cout, Cin, 3, 3) fp32 (times scale[cout]) -> bf16 hi / lo MFMA fragments for :func:`conv3x3_s8_launch`."""
+    _require_gpu(weight)
+    _check_f32(weight)
+    w = weight.detach().contiguous()
+    cout, cin, kh, kw = w.shape
+    assert kh == kw == 3
+    L = hip.lib()
+    nbytes = L.otp_conv3x3_s8_weight_bytes(cout, cin)
+    if not nbytes:
+        raise ValueError(f"otp_conv3x3_s8: unsupported channel counts ({cout}, {cin})")
+    u = torch.empty(nbytes // 4, dtype=torch.int32, device=w.device)
+    sc = scale.detach().contiguous().float() if scale is not None else None
+    hip.check(L.otp_conv3x3_s8_pack_weight(hip.ptr(w), hip.ptr(sc), hip.ptr(u), cout, cin, hip.stream_of(w)),
+              "otp_conv3x3_s8_pack_weight")
+    return u
+
+
+def conv3x3_s8_launch(in_s8, wpacked, shift, desc, res_c4=None, out_f32=None, f32_layout=S8_F32_C4, out_s8=None, stream=None):
+    st = hip.lib().otp_conv3x3_s8(hip.ptr(in_s8), hip.ptr(wpacked), hip.ptr(shift), hip.ptr(res_c4), hip.ptr(out_f32),
+                                  f32_layout, hip.ptr(out_s8), desc, stream if stream is not None else hip.stream_of(in_s8))
+    hip.check(st, "otp_conv3x3_s8")
+
+
+def conv3x3_s8(x_s8, shape, weight, scale=None, shift=None, act=ACT_NONE, res_c4=None, f32="nchw", want_s8=True):
+    """act(conv2d(x, weight, 3x3, stride 1, pad 1) * scale + shift + res) from an S8 image ``x_s8`` of logical ``shape``
+    (n, cin, h, w); ``res_c4`` a C4 image of the residual.  Returns (fp32 result - an NCHW tensor for f32 = "nchw", a C4 image
+    for "c4", None for None -, S8 image of the result or None)."""
+    _require_gpu(x_s8, weight)
+    n, cin, h, w = shape
+    cout = weight.shape[0]
+    out = out_s8 = None
+    layout = S8_F32_C4
+    if f32 == "nchw":
+        out, layout = torch.empty(n, cout, h, w, dtype=torch.float32, device=x_s8.device), S8_F32_NCHW
+    elif f32 == "c4":
+        out = c4_empty(n, cout, h, w, x_s8.device)
+    if want_s8:
+        out_s8 = s8_empty(n, cout, h, w, x_s8.device)
+    d = s8_conv_desc(n, cin, cout, h, w, act)
+    conv3x3_s8_launch(x_s8, pack_s8_weight(weight, scale), shift, d, res_c4, out, layout, out_s8)
+    return out, out_s8
+
+
 def ln_mlp_fused(y, gamma, beta, eps, packed, scale, shift, out=None, hid=None, stream=None):
     """out = y + scale * (W2 . gelu(W1 . LN(y) + b1)) + shift: ln2 + MLP + residual of TransformerBlock.forward
     (model/blocks.py:277-279) in one launch."""

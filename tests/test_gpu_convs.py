@@ -1,0 +1,127 @@
+"""Split-record (S8) activations and the LDS-DMA fed 3x3 convolution (csrc/convs.hip, otp_conv3x3_s8) - the HRNet BasicBlock
+convs of model/HRNet.py:500-530 - against a float64 ``F.conv2d`` of the same operands, and the S8 converters against their
+definition.  Tolerance as for otp_conv2d_x3 (tests/test_gpu_convx.py): 2e-5 of the output range for the fp32 result; the
+S8 result additionally carries the split's own remainder (2^-17 relative per element)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from otpose_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf16_rne(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+@pytest.mark.parametrize("shape,coff,ctot", [((3, 48, 12, 8), 0, 48), ((2, 16, 6, 6), 8, 40), ((5, 96, 24, 18), 0, 96)])
+def test_s8_pack_is_hi_lo_of_the_definition(shape, coff, ctot):
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(c + h)
+    full = (torch.randn(n, ctot, h, w, generator=g) * 3).cuda()
+    full[0, coff, 0, 0] = 0.0
+    full[0, coff + 1, 0, 1] = 1e-30                       # hi carries it, lo = 0
+    x = full[:, coff:coff + c]
+    s8 = ops.s8_pack(ops.View(full, coff, c))
+    rec = s8.view(torch.int16).view(n, c // 8, 2, h * w, 8)       # [n][g][part][p][e] bf16 bit patterns
+    hi = _bf16_rne(x)
+    lo = _bf16_rne(x - hi)
+    want = torch.stack([hi, lo], 0).view(2, n, c // 8, 8, h * w).permute(1, 2, 0, 4, 3)   # -> [n][g][part][p][e]
+    got = rec.view(torch.bfloat16).to(torch.float32)
+    assert torch.equal(got, want.contiguous())
+    back = ops.s8_unpack(s8, n, c, h, w)
+    assert torch.equal(back, hi + lo)
+    assert float((back - x).abs().max()) <= 2.0 ** -16 * float(x.abs().max())
+
+
+# (N, Cin, Cout, H, W, residual, relu)
+CASES = [
+    (5, 48, 48, 96, 72, True, True),         # HRNet-W48 branch 0: tiles end inside rows, windows of 7 rows (512 records)
+    (3, 96, 96, 48, 36, False, True),        # branch 1: tiles straddle images, two cout blocks share a window
+    (3, 192, 192, 24, 18, True, False),      # branch 2
+    (7, 384, 96, 12, 9, True, True),         # branch 3 maps: up to four images per tile
+    (2, 64, 64, 96, 72, False, False),       # NTW = 2 (layer1 width)
+    (2, 32, 40, 10, 6, True, True),          # Cout not a multiple of 16: partial last cout tile, tail tile
+    (1, 16, 24, 8, 4, False, False),         # one partial tile, one chunk
+    (80, 384, 384, 12, 9, True, True),       # launches of a few hundred workgroups (XCD-interleaved ranges with ragged ends)
+    (40, 192, 192, 24, 18, True, False),
+    (16, 48, 48, 96, 72, True, True),
+    (3, 32, 32, 64, 48, True, True),         # HRNet-W32 branch 0 (cfg1)
+    (3, 128, 128, 16, 12, False, True),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "x".join(str(v) for v in c[:5]))
+def test_conv3x3_s8_matches_float64(case):
+    n, ci, co, h, w, with_res, relu = case
+    g = torch.Generator(device="cpu").manual_seed(sum(case[:5]))
+    x = torch.randn(n, ci, h, w, generator=g).cuda()
+    wt = (torch.randn(co, ci, 3, 3, generator=g) * (2.0 / (ci * 9)) ** 0.5).cuda()
+    sc = (torch.rand(co, generator=g) + 0.5).cuda()
+    sh = torch.randn(co, generator=g).cuda()
+    res = torch.randn(n, co, h, w, generator=g).cuda() if with_res else None
+    xs = ops.s8_pack(x)
+    res_c4 = None
+    if with_res:                                          # the residual travels in the C4 layout
+        res_c4 = ops.c4_empty(n, co, h, w, "cuda")
+        ops.s8_pack(res, out_c4=res_c4)
+        assert torch.equal(ops.c4_unpack(res_c4, n, co, h, w), res)
+    # the kernel's input IS hi + lo (the S8 image); the float64 reference convolves exactly that
+    xin = ops.s8_unpack(xs, n, ci, h, w).double()
+    ref = F.conv2d(xin, wt.double(), None, 1, 1, 1) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)
+    if with_res:
+        ref = ref + res.double()
+    if relu:
+        ref = torch.relu(ref)
+    act = ops.ACT_RELU if relu else ops.ACT_NONE
+    y, ys = ops.conv3x3_s8(xs, (n, ci, h, w), wt, sc, sh, act, res_c4)
+    scale = float(ref.abs().max())
+    err = float((y.double() - ref).abs().max()) / scale
+    assert err <= 2e-5, err
+    # against the fp32 input itself (what the engine compares with): the split drops 2^-18 of every input element
+    ref0 = F.conv2d(x.double(), wt.double(), None, 1, 1, 1) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)
+    ref0 = ref0 + res.double() if with_res else ref0
+    ref0 = torch.relu(ref0) if relu else ref0
+    assert float((y.double() - ref0).abs().max()) / scale <= 2e-5
+    # the S8 output is the split of the fp32 output, bit for bit
+    assert torch.equal(ys, ops.s8_pack(y))
+    # the C4 output holds the same values; the single-output variants write the same values
+    yc, none_s8 = ops.conv3x3_s8(xs, (n, ci, h, w), wt, sc, sh, act, res_c4, f32="c4", want_s8=False)
+    assert none_s8 is None and torch.equal(ops.c4_unpack(yc, n, co, h, w), y)
+    none_f, ys2 = ops.conv3x3_s8(xs, (n, ci, h, w), wt, sc, sh, act, res_c4, f32=None)
+    assert none_f is None and torch.equal(ys2, ys)
+
+
+def test_conv3x3_s8_writes_a_channel_slice_of_an_nchw_tensor():
+    g = torch.Generator(device="cpu").manual_seed(9)
+    x = torch.randn(3, 32, 20, 12, generator=g).cuda()
+    wt = (torch.randn(16, 32, 3, 3, generator=g) * 0.1).cuda()
+    big = torch.full((3, 40, 20, 12), 7.0, device="cuda")
+    d = ops.s8_conv_desc(3, 32, 16, 20, 12, ops.ACT_NONE, ops.View(big, 8, 16))
+    ops.conv3x3_s8_launch(ops.s8_pack(x), ops.pack_s8_weight(wt), None, d, None, big, ops.S8_F32_NCHW, None)
+    y, _ = ops.conv3x3_s8(ops.s8_pack(x), tuple(x.shape), wt, want_s8=False)
+    assert torch.equal(big[:, 8:24], y) and float((big[:, :8] - 7).abs().max()) == 0 and float((big[:, 24:] - 7).abs().max()) == 0
+
+
+def test_conv3x3_s8_agrees_with_the_fp32_input_kernel():
+    """Same arithmetic as otp_conv2d_x3 on the same operands (the split of the input commutes with where it happens): the
+    two kernels differ only in summation order."""
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.randn(4, 96, 48, 36, generator=g).cuda()
+    wt = (torch.randn(96, 96, 3, 3, generator=g) * 0.05).cuda()
+    sh = torch.randn(96, generator=g).cuda()
+    a = ops.conv2d_x3(x, wt, None, sh, ops.ACT_RELU)
+    b, _ = ops.conv3x3_s8(ops.s8_pack(x), tuple(x.shape), wt, None, sh, ops.ACT_RELU)
+    assert float((a - b).abs().max()) <= 3e-6 * float(a.abs().max())
+
+
+def test_conv3x3_s8_rejects_what_it_does_not_cover():
+    d = ops.s8_conv_desc(2, 48, 48, 96, 72)
+    assert ops.s8_conv_supported(d)
+    for field, val in (("stride", 2), ("dil", 2), ("Cin", 24), ("kh", 1), ("W", 500), ("Cout", 20)):
+        e = ops.hip.ConvDesc.from_buffer_copy(bytes(d))
+        setattr(e, field, val)
+        if field == "W":
+            e.Wo = val
+        assert not ops.s8_conv_supported(e), field
