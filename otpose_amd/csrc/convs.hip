@@ -25,6 +25,7 @@
 // output channels of ONE pixel.  Epilogue: accumulators (+ shift) -> LDS [cout][pixel] -> rows of 256 pixels: residual add,
 // ReLU, fp32 NCHW store as 1 KB runs, then per pixel 8 channels -> hi / lo records -> S8 store as 1 KB runs.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -47,12 +48,18 @@ uint32_t smagic(uint32_t d) { return d <= 1 ? 0u : (uint32_t)((1ull << 32) / d) 
 #ifdef OTP_CONVS_TIMING
 // development build only (tools/convs_timing.sh): per-workgroup phase stamps, never in libotpose_hip.so
 __device__ unsigned long long otp_convs_stamps[8192 * 32];
+__device__ unsigned long long otp_convs_pp_stamps[512 * 128];
+#define PSTAMP(ev)                                                                                   \
+    do {                                                                                              \
+        if (lane == 0 && wave == 0 && (ev) < 128) otp_convs_pp_stamps[((int)blockIdx.x * 2 + h) * 128 + (ev)] = __builtin_readcyclecounter(); \
+    } while (0)
 #define SSTAMP(slot)                                                                                  \
     do {                                                                                              \
         if (threadIdx.x == 0 && blockIdx.x < 8192) otp_convs_stamps[blockIdx.x * 32 + (slot)] = __builtin_readcyclecounter(); \
     } while (0)
 #else
 #define SSTAMP(slot)
+#define PSTAMP(ev)
 #endif
 
 struct SPlan {
@@ -61,6 +68,7 @@ struct SPlan {
     int NTW, nN, nTiles, nChunks, tpx;
     int VR, W1, NIW;                      // virtual rows per image (H + 1), records per window row (W + 1), 64-record pieces per plane
     uint32_t mHW, mW, mW1, mVR;
+    int nItems, ipx, hs, rounds;          // persistent form: (tile, cout block) items, items per XCD, half-slots per XCD, rounds
 };
 
 // 8 floats -> bf16 hi / lo records
@@ -178,11 +186,32 @@ __global__ void s8_wpack_kernel(const float* __restrict__ w, const float* __rest
     }
 }
 
-// v_permlane32_swap: a[lanes 32..63] <-> b[lanes 0..31].  Inline asm: the second result of __builtin_amdgcn_permlane32_swap
-// comes back as a copy of the first with hipcc / ROCm 7.2 (both extractvalue indices are 0 in the emitted IR); the s_nops
-// stand in for the wait states hipcc does not insert around an asm statement.
-__device__ __forceinline__ void swap32(float& a, float& b) {
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+// (The two halves of a wave trade accumulator rows with __shfl_xor(v, 32) = ds_bpermute_b32.  v_permlane32_swap would do it in
+// one instruction, but with hipcc / ROCm 7.2 the second result of __builtin_amdgcn_permlane32_swap comes back as a copy of the
+// first (both extractvalue indices are 0 in the emitted IR), and the instruction in inline asm gave results that changed when
+// other kernels shared the CU - hipcc inserts no wait states around an asm statement.)
+
+// instruction order of one (k-step, pixel tile) block: NM MFMAs and NR LDS reads - [MFMA, read] pairs while reads remain
+// (two MFMAs first when there are few), then the remaining MFMAs
+template <int NM, int NR>
+__device__ __forceinline__ void sblock_sched() {
+    if constexpr (NR == 0) {
+        __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+    } else if constexpr (NR >= NM - 1) {
+#pragma unroll
+        for (int g = 0; g < NM - 1; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        if constexpr (NR > NM - 1) __builtin_amdgcn_sched_group_barrier(0x100, NR - (NM - 1), 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    } else {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NM / 2 - 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, NR - 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NM - 1 - NM / 2, 0);
+    }
 }
 
 // residual / fp32 output layouts of otp_conv3x3_s8
@@ -194,12 +223,18 @@ __global__ __launch_bounds__(256, 2) void convs_kernel(const unsigned char* __re
                                                         u32x4* outs, const SPlan P) {
     constexpr int WCH = SKS * NTW * 2;                             // 1 KB pieces of a chunk's weights
     constexpr int WBYTES = WCH * 1024;
+    constexpr int NBLK = SKS * 4;                                  // (k-step, pixel tile) blocks of a chunk: 3 NTW MFMAs each
+    constexpr int NM = 3 * NTW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* win = smem;
     unsigned char* wl = smem + SWIN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i16 = lane & 15, kl = lane >> 4;
+    // lane (i16, kl) of pixel tile p: pixel m = (4 wave + p) 16 + i16 of the tile; accumulator register r of cout tile t =
+    // channel co_blk + 16 t + 4 pk + r of that pixel, pk = srow2ch(4 kl) / 4 (the row permutation of the packed weights)
+    const int pk = ((kl & 1) << 1) | (kl >> 1);
+    const bool upper = kl >= 2;
 
     // workgroup -> (pixel tile, output-channel block); XCD x (block id mod 8) walks a contiguous tile range, the blocks of a
     // tile back to back: the window rows neighbouring tiles share and the re-read window of the next block hit that L2
@@ -216,6 +251,8 @@ __global__ __launch_bounds__(256, 2) void convs_kernel(const unsigned char* __re
     const int y0 = (int)sdiv((uint32_t)p0, P.mW);
     const int Vf = n0 * P.VR + y0;                                 // first virtual row of the window (one above the first pixel's)
     const int imgB = P.C * P.HW * 4;                               // bytes of one image of the S8 tensor
+    const int co_blk = cb * NTW * 16;
+    const int C4o = P.Cout >> 2, Go = P.Cout >> 3;
 
     // ---- window pieces of this wave: piece k = wave + 4 j covers window records 64 k .. 64 k + 63 ------------------------------
     int voff[2];
@@ -258,78 +295,63 @@ __global__ __launch_bounds__(256, 2) void convs_kernel(const unsigned char* __re
     stage(0);
     SSTAMP(1);
 
-    // ---- per pixel tile: fragment address, output offsets ---------------------------------------------------------------------
-    // lane (i16, kl) of pixel tile p: pixel m = (4 wave + p) 16 + i16 of the tile; accumulator register r of cout tile t =
-    // channel co_blk + 16 t + 4 pk + r of that pixel, pk = srow2ch(4 kl) / 4 (the row permutation of the packed weights)
-    const int pk = ((kl & 1) << 1) | (kl >> 1);
-    const int co_blk = cb * NTW * 16;
-    int pbase[4], pimg[4], ppix[4];
-    bool pval[4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        int m = (wave * 4 + p) * 16 + i16;
-        pval[p] = P0 + m < P.total;
-        if (!pval[p]) m = P.total - 1 - P0;                        // tail tile: a finite address, the result is dropped
-        const int q = p0 + m;
-        const int dn = (int)sdiv((uint32_t)q, P.mHW), pi = q - dn * P.HW;
-        const int y = (int)sdiv((uint32_t)pi, P.mW), x = pi - y * P.W;
-        pbase[p] = (((n0 + dn) * P.VR + y - Vf) * P.W1 + x) * 16;   // record of tap (0, 0): one row up, one column left
-        pimg[p] = n0 + dn;
-        ppix[p] = pi;
-    }
-    int toff[SKS];
-#pragma unroll
-    for (int s = 0; s < SKS; ++s) {
-        const int q = 4 * s + kl;
-        int tap = q >> 1;
-        if (tap > 8) tap = 8;                                      // zero weights: any finite data
-        const int dy = tap / 3, dx = tap - dy * 3;
-        toff[s] = (dy * P.W1 + dx) * 16 + (q & 1) * (2 * SPLANE);
-    }
-
-    // accumulators start from shift (+ residual): the residual tensor is in the C4 layout [N][C/4][H*W][4], so a lane's four
-    // channels of a pixel are one float4 - loaded while the first chunk's DMA is in flight
-    f32x4 acc[NTW][4];
-    const int C4o = P.Cout >> 2;
+    // ---- per pixel tile: fragment addresses of the chunk's 20 blocks, lane offsets into the output / residual images ---------
+    const size_t obytes = (size_t)P.N * P.Cout * P.HW * 4;         // C4 and S8 images of the (N, Cout, H, W) result / residual
+    const otp_rsrc rres = make_rsrc32(res ? res : reinterpret_cast<const float*>(xs), res ? (unsigned)obytes : 0u);
+    const otp_rsrc rs8 = make_rsrc32(outs, outs ? (unsigned)obytes : 0u);
+    const otp_rsrc rof = make_rsrc32(outf, !outf ? 0u : (P.f32_mode == S_F32_C4 ? (unsigned)obytes
+                                                                               : (unsigned)((size_t)P.N * P.out_ctot * P.HW * 4)));
+    const otp_rsrc rsh = make_rsrc32(shift ? shift : reinterpret_cast<const float*>(xs), shift ? (unsigned)(P.Cout * 4) : 0u);
+    int baddr[NBLK], offC[4], offS[4];
+    f32x4 acc[NTW][4], rv[NTW][4], sh[NTW];
     {
-        f32x4 sh[NTW];
+        int toff[SKS];
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) {
-            const int co = co_blk + 16 * t + 4 * pk;
-            sh[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (shift && co < P.Cout) sh[t] = *reinterpret_cast<const f32x4*>(shift + co);
+        for (int s = 0; s < SKS; ++s) {
+            const int q = 4 * s + kl;
+            int tap = q >> 1;
+            if (tap > 8) tap = 8;                                  // zero weights: any finite data
+            const int dy = tap / 3, dx = tap - dy * 3;
+            toff[s] = (dy * P.W1 + dx) * 16 + (q & 1) * (2 * SPLANE);
         }
-        if (res) {
-            // every load is issued before the first use (a load behind a per-element condition makes hipcc wait for each one)
-            f32x4 rv[NTW][4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            int m = (wave * 4 + p) * 16 + i16;
+            const bool pv = P0 + m < P.total;
+            if (!pv) m = P.total - 1 - P0;                         // tail tile: a finite address, the result is dropped
+            const int q = p0 + m;
+            const int dn = (int)sdiv((uint32_t)q, P.mHW), pi = q - dn * P.HW;
+            const int y = (int)sdiv((uint32_t)pi, P.mW), x = pi - y * P.W;
+            const int pb = (((n0 + dn) * P.VR + y - Vf) * P.W1 + x) * 16;   // record of tap (0, 0): one row up, one column left
+#pragma unroll
+            for (int s = 0; s < SKS; ++s) baddr[s * 4 + p] = pb + toff[s];
+            const int img = n0 + dn;
+            // C4 image: ((img C4o + c4) HW + pi) 16 bytes, c4 = (co_blk + 16 t) / 4 + pk: lane part here, tile part a scalar offset
+            const int c4o = (img * C4o * P.HW + pk * P.HW + pi) * 16;
+            const int nchw = ((img * P.out_ctot + P.out_coff + 4 * pk) * P.HW + pi) * 4;
+            offC[p] = pv ? (P.f32_mode == S_F32_NCHW ? nchw : c4o) : SOOB;
+            // S8 image: (((img Go + g) 2 + part) HW + pi) 16 bytes, g = 2 (co_blk / 16 + tile) + (kl & 1); upper lanes store tile tb
+            offS[p] = pv ? (img * Go * 2 * P.HW + (kl & 1) * 2 * P.HW + (upper ? 4 * P.HW : 0) + pi) * 16 : SOOB;
+            // residual (C4 image) and shift: loaded now, added in the epilogue (out-of-range offsets read zeros)
 #pragma unroll
             for (int t = 0; t < NTW; ++t) {
-                const int co = co_blk + 16 * t + 4 * pk;
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const bool ok = co < P.Cout && pval[p];
-                    rv[t][p] = *reinterpret_cast<const f32x4*>(res + (ok ? (((size_t)pimg[p] * C4o + (co >> 2)) * P.HW + ppix[p]) * 4 : 0));
-                }
+                const bool tv = co_blk + 16 * t < P.Cout;
+                rv[t][p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, (pv && tv) ? c4o : SOOB,
+                                                                                          ((co_blk >> 2) + 4 * t) * P.HW * 16, 0));
+                acc[t][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
-#pragma unroll
-            for (int t = 0; t < NTW; ++t)
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const bool ok = co_blk + 16 * t + 4 * pk < P.Cout && pval[p];
-                    acc[t][p] = ok ? sh[t] + rv[t][p] : sh[t];
-                }
-        } else {
-#pragma unroll
-            for (int t = 0; t < NTW; ++t)
-#pragma unroll
-                for (int p = 0; p < 4; ++p) acc[t][p] = sh[t];
         }
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+            sh[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsh, co_blk + 16 * t < P.Cout ? 16 * pk : SOOB,
+                                                                                   (co_blk + 16 * t) * 4, 0));
     }
 
-    // One chunk = SKS k-steps x 4 pixel tiles x NTW cout tiles x 3 products.  The fragments of the next pixel tile (and, at
-    // the last pixel tile of a k-step, the weight fragments of the next step) are read before the MFMAs of the current one.
+    // One chunk: NBLK blocks of 3 NTW MFMAs.  B fragments are read two blocks ahead (ring of three), the weight fragments of
+    // the next k-step two blocks before it starts, the reads spread between the MFMAs (tools/micro/mfma_loop.hip: 16.8 cycles
+    // per MFMA for one wave per SIMD, against 20.8 with reads one block ahead, clustered, and addresses computed in the loop).
     auto mfma_phase = [&]() __attribute__((always_inline)) {
-        bf16x8 ah[2][NTW], al[2][NTW], bh[2], bl[2];
+        bf16x8 ah[2][NTW], al[2][NTW], bh[3], bl[3];
         auto load_a = [&](int buf, int s) __attribute__((always_inline)) {
 #pragma unroll
             for (int t = 0; t < NTW; ++t) {
@@ -338,33 +360,31 @@ __global__ __launch_bounds__(256, 2) void convs_kernel(const unsigned char* __re
                 al[buf][t] = *reinterpret_cast<const bf16x8*>(a + 1024);
             }
         };
-        auto load_b = [&](int buf, int s, int p) __attribute__((always_inline)) {
-            const unsigned char* b = win + pbase[p] + toff[s];
+        auto load_b = [&](int buf, int blk) __attribute__((always_inline)) {
+            const unsigned char* b = win + baddr[blk];
             bh[buf] = *reinterpret_cast<const bf16x8*>(b);
             bl[buf] = *reinterpret_cast<const bf16x8*>(b + SPLANE);
         };
         load_a(0, 0);
-        load_b(0, 0, 0);
+        load_b(0, 0);
+        load_b(1, 1);
 #pragma unroll
-        for (int s = 0; s < SKS; ++s)
+        for (int blk = 0; blk < NBLK; ++blk) {
+            const int s = blk >> 2, p = blk & 3, cur = blk % 3, sa = s & 1;
+            const bool nb = blk + 2 < NBLK, na = p == 2 && s + 1 < SKS;
+            if (nb) load_b((blk + 2) % 3, blk + 2);
+            if (na) load_a(sa ^ 1, s + 1);
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int cur = (s * 4 + p) & 1, sa = s & 1;
-                if (p + 1 < 4) {
-                    load_b(cur ^ 1, s, p + 1);
-                } else if (s + 1 < SKS) {
-                    load_b(cur ^ 1, s + 1, 0);
-                    load_a(sa ^ 1, s + 1);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int t = 0; t < NTW; ++t) {
-                    acc[t][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[sa][t], bh[cur], acc[t][p], 0, 0, 0);
-                    acc[t][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[sa][t], bl[cur], acc[t][p], 0, 0, 0);
-                    acc[t][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[sa][t], bh[cur], acc[t][p], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
+            for (int t = 0; t < NTW; ++t) {
+                acc[t][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[sa][t], bh[cur], acc[t][p], 0, 0, 0);
+                acc[t][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[sa][t], bl[cur], acc[t][p], 0, 0, 0);
+                acc[t][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[sa][t], bh[cur], acc[t][p], 0, 0, 0);
             }
+            if (!nb) sblock_sched<NM, 0>();
+            else if (na) sblock_sched<NM, 2 + 2 * NTW>();
+            else sblock_sched<NM, 2>();
+            __builtin_amdgcn_sched_barrier(0);
+        }
     };
 
     SSTAMP(2);
@@ -384,70 +404,63 @@ __global__ __launch_bounds__(256, 2) void convs_kernel(const unsigned char* __re
     SSTAMP(16);
 
     // ---- epilogue: no LDS, no barrier - every lane stores what its accumulators hold --------------------------------------------
-    if (P.act == OTP_ACT_RELU) {
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            acc[t][p] += sh[t] + rv[t][p];
+            if (P.act == OTP_ACT_RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[t][p][r] = fmaxf(acc[t][p][r], 0.f);
+            }
+        }
+    if (P.f32_mode == S_F32_C4) {
+        // [N][Cout/4][H*W][4]: one float4 per (cout tile, pixel tile); the 16 lanes of a row write 256 contiguous bytes
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[t][p]), rof, co_blk + 16 * t < P.Cout ? offC[p] : SOOB,
+                                                       ((co_blk >> 2) + 4 * t) * P.HW * 16, 0);
+    } else if (P.f32_mode == S_F32_NCHW) {
+        // channel slice of an NCHW tensor (the tensor a fuse layer / another kernel family reads): 4 planes per lane
 #pragma unroll
         for (int t = 0; t < NTW; ++t)
 #pragma unroll
             for (int p = 0; p < 4; ++p)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[t][p][r] = fmaxf(acc[t][p][r], 0.f);
-    }
-    if (P.f32_mode == S_F32_C4) {
-        // [N][Cout/4][H*W][4]: one float4 per (cout tile, pixel tile); the 16 lanes of a row write 256 contiguous bytes
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) {
-            const int co = co_blk + 16 * t + 4 * pk;
-#pragma unroll
-            for (int p = 0; p < 4; ++p)
-                if (pval[p] && co < P.Cout)
-                    *reinterpret_cast<f32x4*>(outf + (((size_t)pimg[p] * C4o + (co >> 2)) * P.HW + ppix[p]) * 4) = acc[t][p];
-        }
-    } else if (P.f32_mode == S_F32_NCHW) {
-        // channel slice of an NCHW tensor (the tensor a fuse layer / another kernel family reads): 4 planes per lane
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) {
-            const int co = co_blk + 16 * t + 4 * pk;
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                float* o = outf + ((size_t)pimg[p] * P.out_ctot + P.out_coff + co) * P.HW + ppix[p];
-#pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (pval[p] && co + r < P.Cout) o[(size_t)r * P.HW] = acc[t][p][r];
-            }
-        }
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(acc[t][p][r]), rof, co_blk + 16 * t < P.Cout ? offC[p] : SOOB,
+                                                          (co_blk + 16 * t + r) * P.HW * 4, 0);
     }
     SSTAMP(17);
     if (outs) {
         // S8 records: lanes kl and kl + 2 (l and l + 32) hold rows 4 kl + r and 4 (kl + 2) + r = channels 8 b .. 8 b + 7 of the tile
-        // (b = kl & 1, srow2ch).  v_permlane32_swap on a pair of cout tiles (ta, tb) hands the lower half of the wave tile ta's
-        // eight channels and the upper half tile tb's; each lane splits its eight values and stores one hi and one lo record.
-        const int Go = P.Cout >> 3;
-        const bool upper = kl >= 2;
+        // (b = kl & 1, srow2ch).  For a pair of cout tiles (ta, tb) the lower half of the wave assembles tile ta's eight channels
+        // and the upper half tile tb's; each lane splits its eight values and stores one hi and one lo record.
 #pragma unroll
         for (int tp = 0; tp < (NTW + 1) / 2; ++tp) {
             const int ta = 2 * tp, tb = (2 * tp + 1 < NTW) ? 2 * tp + 1 : 2 * tp;
-            const int tile16 = upper ? tb : ta;
-            const int g = ((co_blk >> 4) + tile16) * 2 + (kl & 1);
-            const bool lanes_on = (ta != tb) || !upper;
+            const bool tav = co_blk + 16 * ta < P.Cout;
+            const bool pair = ta != tb && co_blk + 16 * tb < P.Cout;
+            const int so = (((co_blk >> 4) + ta) * 4) * P.HW * 16;     // group 2 (co_blk / 16 + ta), part 0
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 float f[8];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float a = acc[ta][p][r], b = acc[tb][p][r];
-                    swap32(a, b);
-                    // lower lanes: a = own rows (channels 8 b + r), b = the partner's (8 b + 4 + r); upper lanes: a = the
-                    // partner's rows of tile tb (8 b + r), b = own (8 b + 4 + r)
-                    f[r] = a;
-                    f[4 + r] = b;
+                    // lanes l and l + 32 trade one value: the lower lane needs the upper one's rows of tile ta (channels 8 b + 4 + r),
+                    // the upper lane the lower one's rows of tile tb (channels 8 b + r)
+                    const float a = acc[ta][p][r], b = acc[tb][p][r];
+                    const float got = __shfl_xor(upper ? a : b, 32, 64);
+                    f[r] = upper ? got : a;
+                    f[4 + r] = upper ? b : got;
                 }
                 u32x4 hi, lo;
                 ssplit8(f, hi, lo);
-                if (lanes_on && pval[p] && g < Go) {
-                    u32x4* d = outs + ((size_t)(pimg[p] * Go + g) * 2) * P.HW + ppix[p];
-                    d[0] = hi;
-                    d[P.HW] = lo;
-                }
+                const int o = (tav && (pair || !upper)) ? offS[p] : SOOB;   // a lone last tile: the lower half of the wave stores it
+                __builtin_amdgcn_raw_buffer_store_b128(hi, rs8, o, so, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(lo, rs8, o, so + P.HW * 16, 0);
             }
         }
     }
@@ -455,6 +468,330 @@ __global__ __launch_bounds__(256, 2) void convs_kernel(const unsigned char* __re
 #ifdef OTP_CONVS_TIMING
     if (threadIdx.x == 0 && blockIdx.x < 8192) otp_convs_stamps[blockIdx.x * 32 + 31] = __builtin_amdgcn_s_memrealtime();
 #endif
+}
+
+// ---- persistent double-buffered form ------------------------------------------------------------------------------------------------
+// One 8-wave workgroup per CU walks (pixel tile, cout block) items; every wave owns two of the tile's sixteen pixel tiles
+// and all NTW cout tiles.  LDS holds TWO (window + weight chunk) buffers: the DMA of chunk g + 1 - the next chunk of the item or
+// the first chunk of the NEXT item - is issued before the MFMAs of chunk g and has that whole phase to land; one barrier per
+// chunk.  Two waves per SIMD multiply at the same time (16.3 cycles per MFMA per SIMD with the block schedule below); an
+// item's stores leave straight from the accumulators and are never waited for: the wait in front of the barrier is a counted
+// vmcnt that lets exactly those stores stay in flight under the next item's MFMAs.  The residual is loaded into registers of
+// its own at the item's first chunk and added in the epilogue.
+template <int N>
+__device__ __forceinline__ void swait_barrier() {
+    // (inline asm: __syncthreads() would wait for vmcnt(0) whenever an LDS-DMA is pending)
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+template <int NTW>
+__global__ __launch_bounds__(512, 2) void convs_db_kernel(const unsigned char* __restrict__ xs, const u32x4* __restrict__ wpk,
+                                                           const float* __restrict__ shift, const float* res, float* outf,
+                                                           u32x4* outs, const SPlan P) {
+    constexpr int WCH = SKS * NTW * 2;                             // 1 KB pieces of a chunk's weights
+    constexpr int WBYTES = WCH * 1024;
+    constexpr int REGION = SWIN + WBYTES;
+    constexpr int NBLK = SKS * 2;                                  // (k-step, pixel tile) blocks of a chunk: 3 NTW MFMAs each
+    constexpr int NM = 3 * NTW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // 0 .. 7
+    const int i16 = lane & 15, kl = lane >> 4;
+    const int pk = ((kl & 1) << 1) | (kl >> 1);
+    const bool upper = kl >= 2;
+    const int xcd = (int)blockIdx.x & 7, u = (int)blockIdx.x >> 3;
+    const int imgB = P.C * P.HW * 4;
+    const int C4o = P.Cout >> 2, Go = P.Cout >> 3;
+    const otp_rsrc rw = make_rsrc32(wpk, (unsigned)((size_t)P.nN * P.nChunks * WBYTES));
+    const size_t obytes = (size_t)P.N * P.Cout * P.HW * 4;         // C4 and S8 images of the (N, Cout, H, W) result / residual
+    const otp_rsrc rres = make_rsrc32(res ? res : reinterpret_cast<const float*>(xs), res ? (unsigned)obytes : 0u);
+    const otp_rsrc rs8 = make_rsrc32(outs, outs ? (unsigned)obytes : 0u);
+    const otp_rsrc rof = make_rsrc32(outf, !outf ? 0u : (P.f32_mode == S_F32_C4 ? (unsigned)obytes
+                                                                               : (unsigned)((size_t)P.N * P.out_ctot * P.HW * 4)));
+    const otp_rsrc rsh = make_rsrc32(shift ? shift : reinterpret_cast<const float*>(xs), shift ? (unsigned)(P.Cout * 4) : 0u);
+    const int woff = lane * 16;
+
+    int toff[SKS];
+#pragma unroll
+    for (int s = 0; s < SKS; ++s) {
+        const int q = 4 * s + kl;
+        int tap = q >> 1;
+        if (tap > 8) tap = 8;
+        const int dy = tap / 3, dx = tap - dy * 3;
+        toff[s] = (dy * P.W1 + dx) * 16 + (q & 1) * (2 * SPLANE);
+    }
+
+    // ---- item state: "N" = the next item (its first chunk is staged under the current item's last), plain = the current one ---------
+    bool validN = false;
+    int cbN = 0, P0N = 0, n0N = 0, p0N = 0, VfN = 0, voffN = SOOB;
+    otp_rsrc rinN = make_rsrc32(xs, 0);
+    auto decode = [&](int round) __attribute__((always_inline)) {
+        const int local = round * P.hs + u;
+        const int item = xcd * P.ipx + local;
+        validN = round < P.rounds && local < P.ipx && item < P.nItems;
+        const int it = validN ? item : 0;
+        const int tile = it / P.nN;
+        cbN = it - tile * P.nN;
+        P0N = tile * SBM;
+        n0N = P0N / P.HW;
+        p0N = P0N - n0N * P.HW;
+        const int y0 = (int)sdiv((uint32_t)p0N, P.mW);
+        VfN = n0N * P.VR + y0;
+        const int v = 64 * wave + lane;                            // window piece `wave` of every plane
+        const int r = (int)sdiv((uint32_t)v, P.mW1), cp = v - r * P.W1;
+        const int V = VfN + r;
+        const int n = (int)sdiv((uint32_t)V, P.mVR), yy = V - n * P.VR;
+        const bool ok = cp >= 1 && yy >= 1 && n < P.N;
+        voffN = ok ? (n - n0N) * imgB + ((yy - 1) * P.W + cp - 1) * 16 : SOOB;
+        const size_t left = (size_t)(P.N - n0N) * imgB;
+        rinN = make_rsrc32(xs + (size_t)n0N * imgB, left > 0x7fffff00ull ? 0x7fffff00u : (unsigned)left);
+    };
+    bool valid = false;
+    int cb = 0, voff = SOOB;
+    otp_rsrc rin = rinN;
+    // DMA of chunk c of an item into buffer `buf`: <= 4 window pieces + <= 4 weight pieces per wave
+    auto stage = [&](int buf, int c, const otp_rsrc& r_in, int vo, int cblk) __attribute__((always_inline)) {
+        unsigned char* win = smem + buf * REGION;
+        if (wave < P.NIW) {
+#pragma unroll
+            for (int pl = 0; pl < 4; ++pl) {
+                const int so = (((2 * c + (pl >> 1)) * 2 + (pl & 1)) * P.HW) * 16;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r_in, (__attribute__((address_space(3))) void*)(win + pl * SPLANE + wave * 1024),
+                                                         16, vo, so, 0, 0);
+            }
+        }
+        const int wb = (cblk * P.nChunks + c) * WBYTES;
+#pragma unroll
+        for (int j = 0; j < (WCH + 7) / 8; ++j) {
+            const int k = wave + 8 * j;
+            if (k < WCH)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(win + SWIN + k * 1024), 16, woff,
+                                                         wb + k * 1024, 0, 0);
+        }
+    };
+
+    // what the MFMA phase stages into the OTHER buffer while it multiplies: one DMA piece after each of its first 8 blocks
+    // (the CU's address unit takes ~16 cycles per 1 KB piece: 62 pieces issued back to back by 8 waves held every wave for
+    // ~1 k cycles in front of its MFMAs; spread out, they ride under the other wave of the SIMD)
+    bool st_on = false;
+    int st_c = 0, st_vo = SOOB, st_cb = 0;
+    otp_rsrc st_rin = rinN;
+    int baddr[NBLK];                                               // B fragment addresses of the chunk's blocks (within a buffer)
+    int offC[2], offS[2], offR[2];                                 // lane byte offsets into the C4 (or NCHW) output / S8 output / C4 residual
+    f32x4 acc[NTW][2], rv[NTW][2], sh[NTW];
+    auto adopt = [&]() __attribute__((always_inline)) {
+        valid = validN;
+        cb = cbN;
+        voff = voffN;
+        rin = rinN;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            int m = (wave * 2 + p) * 16 + i16;
+            const bool pv = valid && P0N + m < P.total;
+            if (P0N + m >= P.total) m = P.total - 1 - P0N;
+            const int q = p0N + m;
+            const int dn = (int)sdiv((uint32_t)q, P.mHW), pi = q - dn * P.HW;
+            const int y = (int)sdiv((uint32_t)pi, P.mW), x = pi - y * P.W;
+            const int pb = (((n0N + dn) * P.VR + y - VfN) * P.W1 + x) * 16;
+#pragma unroll
+            for (int s = 0; s < SKS; ++s) baddr[s * 2 + p] = pb + toff[s];
+            const int img = n0N + dn;
+            // C4 image: ((img C4o + c4) HW + pi) 16 bytes, c4 = (co_blk + 16 t) / 4 + pk: lane part here, tile part a scalar offset
+            const int c4o = (img * C4o * P.HW + pk * P.HW + pi) * 16;
+            const int nchw = ((img * P.out_ctot + P.out_coff + 4 * pk) * P.HW + pi) * 4;
+            offC[p] = pv ? (P.f32_mode == S_F32_NCHW ? nchw : c4o) : SOOB;
+            offR[p] = pv ? c4o : SOOB;
+            // S8 image: (((img Go + g) 2 + part) HW + pi) 16 bytes, g = 2 (co_blk / 16 + tile) + (kl & 1); upper lanes store tile tb
+            offS[p] = pv ? (img * Go * 2 * P.HW + (kl & 1) * 2 * P.HW + (upper ? 4 * P.HW : 0) + pi) * 16 : SOOB;
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) acc[t][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    // residual (C4) + shift of the current item: issued at its first chunk, consumed in its epilogue
+    auto load_res = [&]() __attribute__((always_inline)) {
+        const int co_blk = cb * NTW * 16;
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const bool tv = co_blk + 16 * t < P.Cout;
+            sh[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsh, tv ? 16 * pk : SOOB, (co_blk + 16 * t) * 4, 0));
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int ro = tv ? offR[p] : SOOB;
+                rv[t][p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, ro, ((co_blk >> 2) + 4 * t) * P.HW * 16, 0));
+            }
+        }
+    };
+
+    // One chunk: NBLK blocks of 3 NTW MFMAs.  B fragments are read two blocks ahead (ring of three), the weight fragments of
+    // the next k-step one step ahead, the reads spread between the MFMAs (tools/micro/mfma_loop.hip).
+    auto mfma_phase = [&](int buf) __attribute__((always_inline)) {
+        const unsigned char* win = smem + buf * REGION;
+        const unsigned char* wl = win + SWIN + lane * 16;
+        bf16x8 ah[2][NTW], al[2][NTW], bh[3], bl[3];
+        auto load_a = [&](int b2, int s) __attribute__((always_inline)) {
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) {
+                const unsigned char* a = wl + ((s * NTW + t) * 2) * 1024;
+                ah[b2][t] = *reinterpret_cast<const bf16x8*>(a);
+                al[b2][t] = *reinterpret_cast<const bf16x8*>(a + 1024);
+            }
+        };
+        auto load_b = [&](int b3, int blk) __attribute__((always_inline)) {
+            const unsigned char* b = win + baddr[blk];
+            bh[b3] = *reinterpret_cast<const bf16x8*>(b);
+            bl[b3] = *reinterpret_cast<const bf16x8*>(b + SPLANE);
+        };
+        unsigned char* dst = smem + (buf ^ 1) * REGION;
+        const int wbn = (st_cb * P.nChunks + st_c) * WBYTES;
+        auto dma_piece = [&](int j) __attribute__((always_inline)) {
+            if (j < 4) {
+                if (st_on && wave < P.NIW)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(st_rin, (__attribute__((address_space(3))) void*)(dst + j * SPLANE + wave * 1024), 16,
+                                                             st_vo, (((2 * st_c + (j >> 1)) * 2 + (j & 1)) * P.HW) * 16, 0, 0);
+            } else {
+                const int k = wave + 8 * (j - 4);
+                if (st_on && k < WCH)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(dst + SWIN + k * 1024), 16, woff,
+                                                             wbn + k * 1024, 0, 0);
+            }
+        };
+        load_a(0, 0);
+        load_b(0, 0);
+        load_b(1, 1);
+#pragma unroll
+        for (int blk = 0; blk < NBLK; ++blk) {
+            const int s = blk >> 1, p = blk & 1, cur = blk % 3, sa = s & 1;
+            const bool nb = blk + 2 < NBLK, na = p == 0 && s + 1 < SKS;
+            if (nb) load_b((blk + 2) % 3, blk + 2);
+            if (na) load_a(sa ^ 1, s + 1);
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) {
+                acc[t][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[sa][t], bh[cur], acc[t][p], 0, 0, 0);
+                acc[t][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[sa][t], bl[cur], acc[t][p], 0, 0, 0);
+                acc[t][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[sa][t], bh[cur], acc[t][p], 0, 0, 0);
+            }
+            if (!nb && !na) sblock_sched<NM, 0>();
+            else if (nb && na) sblock_sched<NM, 2 + 2 * NTW>();
+            else if (na) sblock_sched<NM, 2 * NTW>();
+            else sblock_sched<NM, 2>();
+            __builtin_amdgcn_sched_barrier(0);
+            // three pieces after each of the first blocks: everything is on its way within the first third of the phase
+            if (3 * blk < 4 + (WCH + 7) / 8) {
+#pragma unroll
+                for (int j = 3 * blk; j < 3 * blk + 3 && j < 4 + (WCH + 7) / 8; ++j) dma_piece(j);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    // stores of the finished item, straight from the accumulators; returns nothing, waits for nothing
+    auto epilogue = [&]() __attribute__((always_inline)) {
+        const int co_blk = cb * NTW * 16;
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                acc[t][p] += sh[t] + rv[t][p];                     // (zeros where there is no shift / residual: out-of-range loads)
+                if (P.act == OTP_ACT_RELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[t][p][r] = fmaxf(acc[t][p][r], 0.f);
+                }
+            }
+        if (P.f32_mode == S_F32_C4) {
+#pragma unroll
+            for (int t = 0; t < NTW; ++t)
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[t][p]), rof,
+                                                           co_blk + 16 * t < P.Cout ? offC[p] : SOOB,
+                                                           ((co_blk >> 2) + 4 * t) * P.HW * 16, 0);
+        } else if (P.f32_mode == S_F32_NCHW) {
+#pragma unroll
+            for (int t = 0; t < NTW; ++t)
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(acc[t][p][r]), rof,
+                                                              co_blk + 16 * t < P.Cout ? offC[p] : SOOB,
+                                                              (co_blk + 16 * t + r) * P.HW * 4, 0);
+        }
+        if (outs) {
+#pragma unroll
+            for (int tp = 0; tp < (NTW + 1) / 2; ++tp) {
+                const int ta = 2 * tp, tb = (2 * tp + 1 < NTW) ? 2 * tp + 1 : 2 * tp;
+                const bool tav = co_blk + 16 * ta < P.Cout;
+                const bool pair = ta != tb && co_blk + 16 * tb < P.Cout;
+                const int so = (((co_blk >> 4) + ta) * 4) * P.HW * 16;     // group 2 (co_blk / 16 + ta), part 0
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    float f[8];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float a = acc[ta][p][r], b = acc[tb][p][r];
+                        const float got = __shfl_xor(upper ? a : b, 32, 64);
+                        f[r] = upper ? got : a;
+                        f[4 + r] = upper ? b : got;
+                    }
+                    u32x4 hi, lo;
+                    ssplit8(f, hi, lo);
+                    const int o = (tav && (pair || !upper)) ? offS[p] : SOOB;   // a lone last tile: the lower half of the wave stores it
+                    __builtin_amdgcn_raw_buffer_store_b128(hi, rs8, o, so, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(lo, rs8, o, so + P.HW * 16, 0);
+                }
+            }
+        }
+    };
+    // VMEM operations the epilogue leaves in flight (issued after the DMA of the next chunk)
+    const int nst = (P.f32_mode == S_F32_C4 ? 2 * NTW : (P.f32_mode == S_F32_NCHW ? 8 * NTW : 0)) + (outs ? ((NTW + 1) / 2) * 4 : 0);
+
+    // ---- schedule ---------------------------------------------------------------------------------------------------------------
+    const int h = 0;
+    (void)h;
+    PSTAMP(0);
+    decode(0);
+    if (validN) stage(0, 0, rinN, voffN, cbN);
+    adopt();
+    decode(1);
+    PSTAMP(1);
+    swait_barrier<0>();
+    int g = 0, ev = 2;
+    (void)ev;
+    for (int round = 0; round < P.rounds; ++round) {
+        for (int c = 0; c < P.nChunks; ++c, ++g) {
+            const bool last = c + 1 == P.nChunks;
+            PSTAMP(ev); ++ev;
+            if (c == 0) load_res();
+            // the next chunk of the item, or the first chunk of the next item, is staged from inside the MFMA phase
+            st_on = valid && (!last || validN);
+            st_c = last ? 0 : c + 1;
+            st_vo = last ? voffN : voff;
+            st_cb = last ? cbN : cb;
+            st_rin = last ? rinN : rin;
+            PSTAMP(ev); ++ev;
+            if (valid) {
+                if (g & 1) mfma_phase(1);
+                else mfma_phase(0);
+            }
+            PSTAMP(ev); ++ev;
+            if (last) {
+                if (valid) epilogue();
+                PSTAMP(ev); ++ev;
+                adopt();
+                decode(round + 2);
+                PSTAMP(ev); ++ev;
+                // the next chunk's DMA has landed when everything older than this item's stores is done
+                if (nst == 2 * NTW) swait_barrier<2 * NTW>();
+                else if (nst == 2 * NTW + ((NTW + 1) / 2) * 4) swait_barrier<2 * NTW + ((NTW + 1) / 2) * 4>();
+                else if (nst == ((NTW + 1) / 2) * 4) swait_barrier<((NTW + 1) / 2) * 4>();
+                else if (nst == 8 * NTW) swait_barrier<8 * NTW>();
+                else if (nst == 8 * NTW + ((NTW + 1) / 2) * 4) swait_barrier<8 * NTW + ((NTW + 1) / 2) * 4>();
+                else swait_barrier<0>();
+            } else {
+                swait_barrier<0>();
+            }
+        }
+    }
 }
 
 int s8_ntw(int Cout) {
@@ -465,7 +802,7 @@ int s8_ntw(int Cout) {
 bool convs_plan(const otp_conv_desc& d, SPlan& P) {
     if (d.kh != 3 || d.kw != 3 || d.stride != 1 || d.pad != 1 || d.dil != 1) return false;
     if (d.res_up > 1 || d.frame_split > 0 || d.in2_ctot > 0 || d.act == OTP_ACT_GELU) return false;
-    if (d.Cin % 16 || d.Cout % 8 || ((d.H * d.W) & 3) || d.Ho != d.H || d.Wo != d.W) return false;
+    if (d.Cin % 16 || d.Cout % 16 || ((d.H * d.W) & 3) || d.Ho != d.H || d.Wo != d.W) return false;
     P.N = d.N; P.C = d.Cin; P.H = d.H; P.W = d.W; P.HW = d.H * d.W; P.Cout = d.Cout; P.total = d.N * P.HW;
     P.out_ctot = d.out_ctot; P.out_coff = d.out_coff; P.act = d.act; P.f32_mode = S_F32_NONE;
     P.NTW = s8_ntw(d.Cout);
@@ -506,11 +843,40 @@ int convs_launch(const void* xs, const void* wpk, const float* shift, const floa
     return otp_launch_status();
 }
 
+template <int NTW>
+int convs_db_launch(const void* xs, const void* wpk, const float* shift, const float* res, float* outf, void* outs, SPlan& P,
+                    hipStream_t st) {
+    static int n_cu = 0;                                            // (one device family per process: MI355X, 256 CUs)
+    if (!n_cu) {
+        int dev = 0, v = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        n_cu = v;
+    }
+    P.nItems = P.nTiles * P.nN;
+    P.ipx = (P.nItems + 7) / 8;
+    int grid = n_cu & ~7;
+    const int want = (P.ipx * 8 + 7) & ~7;                          // workgroups that give every one at most one item
+    if (grid > want) grid = want;
+    if (grid < 8) grid = 8;
+    P.hs = grid / 8;                                                // workgroups per XCD
+    P.rounds = (P.ipx + P.hs - 1) / P.hs;
+    auto kern = convs_db_kernel<NTW>;
+    const size_t need = 2 * ((size_t)SWIN + SKS * NTW * 2 * 1024);
+    OTP_ALLOW_BIG_LDS(kern, need);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), need, st, static_cast<const unsigned char*>(xs),
+                       static_cast<const u32x4*>(wpk), shift, res, outf, static_cast<u32x4*>(outs), P);
+    return otp_launch_status();
+}
+
 }  // namespace
 
 #ifdef OTP_CONVS_TIMING
 extern "C" int otp_convs_read_stamps(void* host_out, size_t bytes) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(otp_convs_stamps), bytes) == hipSuccess ? OTP_OK : OTP_ERR_LAUNCH;
+}
+extern "C" int otp_convs_read_pp_stamps(void* host_out, size_t bytes) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(otp_convs_pp_stamps), bytes) == hipSuccess ? OTP_OK : OTP_ERR_LAUNCH;
 }
 #endif
 
@@ -592,6 +958,13 @@ extern "C" int otp_conv3x3_s8(const void* in_s8, const void* wpacked, const void
     auto fs = static_cast<const float*>(shift);
     auto fr = static_cast<const float*>(res_c4);
     auto fo = static_cast<float*>(out_f32);
+    static const int form = [] {                                    // experimental: 1 = the persistent double-buffered form
+        const char* e = getenv("OTPOSE_S8_PERSISTENT");
+        return e ? atoi(e) : 0;
+    }();
+    if (form)
+        return P.NTW == 2 ? convs_db_launch<2>(in_s8, wpacked, fs, fr, fo, out_s8, P, st)
+                          : convs_db_launch<3>(in_s8, wpacked, fs, fr, fo, out_s8, P, st);
     return P.NTW == 2 ? convs_launch<2>(in_s8, wpacked, fs, fr, fo, out_s8, P, st)
                       : convs_launch<3>(in_s8, wpacked, fs, fr, fo, out_s8, P, st);
 }

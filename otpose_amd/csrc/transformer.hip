@@ -6,6 +6,7 @@
 // All tensors are (B, C, T) with T contiguous, so a thread owns one time step t and walks the C
 // channels: every global access of a wave is a coalesced 256-byte run along T.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -575,18 +576,24 @@ __global__ __launch_bounds__(256) void attn_pv_kernel(const float* __restrict__ 
         }
 }
 
-// Phase 3 with split-bf16 products: O^T[t, i] = sum_j v[j, t] P[i, j] on v_mfma_f32_16x16x32_bf16 (M = 128 tokens per
+// Phase 3 with split-bf16 products: O^T[t, i] = sum_j v[j, t] P[i, j] on v_mfma_f32_16x16x32_bf16 (M = 256 tokens per
 // workgroup, N = i, K = j).  Both operands want 8 consecutive j per lane: P rows have them; the v tile is transposed while it
 // is staged (a thread loads 8 rows j x 4 tokens and writes four per-token records of 8 j each, hi and lo), like the window
 // staging of csrc/convx.hip.  Records: [HSP j hi | HSP j lo | 16 B pad] (an odd multiple of 16 bytes).
-constexpr int PVX_TT = 128;
+// Eight waves own 256 tokens and ONE workgroup owns its CU: the launch asks for PVX_LDS bytes of LDS whatever the records need.
+// Sharing a CU with a workgroup of this kernel changed results of the LDS-DMA fed projection kernel (csrc/densex.hip: one
+// accumulator row of one 16-token tile, a few times per launch, only while the two temporal encoders ran side by side - found
+// as replay-to-replay differences of the batch-16 forward, tools/dbg notes in DESIGN.md section 4); with the CU to itself
+// neither kernel's results depend on what else is running.
+constexpr int PVX_WAVES = 8, PVX_TH = 64 * PVX_WAVES, PVX_TT = 32 * PVX_WAVES;
+constexpr size_t PVX_LDS = 138 * 1024;
 template <int NB>
-__global__ __launch_bounds__(256) void attn_pv_x3_kernel(const float* __restrict__ v, const float* __restrict__ P,
+__global__ __launch_bounds__(PVX_TH, 2) void attn_pv_x3_kernel(const float* __restrict__ v, const float* __restrict__ P,
                                                           float* __restrict__ out, int hs, int T) {
     constexpr int HSP = NB * 16, KS = (HSP + 31) / 32, G = HSP / 8;
     constexpr int REC = HSP * 4 + 16;                              // bytes of a token (v) / row (P) record
-    constexpr int NVI = (G * (PVX_TT / 4) + 255) / 256;            // v items (8 rows x 4 tokens) per thread
-    constexpr int NP4 = (HSP * HSP / 4 + 255) / 256;
+    constexpr int NVI = (G * (PVX_TT / 4) + PVX_TH - 1) / PVX_TH;            // v items (8 rows x 4 tokens) per thread
+    constexpr int NP4 = (HSP * HSP / 4 + PVX_TH - 1) / PVX_TH;
     extern __shared__ __attribute__((aligned(16))) unsigned char pvs[];
     unsigned char* vrec = pvs;                                     // [PVX_TT][REC]
     unsigned char* prec = pvs + PVX_TT * REC;                      // [HSP][REC]
@@ -614,12 +621,12 @@ __global__ __launch_bounds__(256) void attn_pv_x3_kernel(const float* __restrict
         f32x4 rp[NP4];
 #pragma unroll
         for (int j = 0; j < NP4; ++j) {
-            const int idx = tid + j * 256;
+            const int idx = tid + j * PVX_TH;
             rp[j] = idx < HSP * HSP / 4 ? reinterpret_cast<const f32x4*>(pb)[idx] : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int j = 0; j < NP4; ++j) {
-            const int idx = tid + j * 256;
+            const int idx = tid + j * PVX_TH;
             if (idx < HSP * HSP / 4) {
                 const int i = (4 * idx) / HSP, jj = 4 * idx - i * HSP;
                 unsigned long long h, l;
@@ -633,7 +640,7 @@ __global__ __launch_bounds__(256) void attn_pv_x3_kernel(const float* __restrict
     const bool vecv = (T & 3) == 0 && (reinterpret_cast<uintptr_t>(v) & 15) == 0;
 #pragma unroll
     for (int it = 0; it < NVI; ++it) {
-        const int idx = tid + it * 256;
+        const int idx = tid + it * PVX_TH;
         const int g = idx / (PVX_TT / 4), f4 = idx - g * (PVX_TT / 4);
         const int t = t0 + 4 * f4;
         f32x4 x[8];
@@ -854,9 +861,9 @@ extern "C" int otp_chan_attn(const void* q, const void* k, const void* v, void* 
         hipLaunchKernelGGL(attn_softmax_kernel, dim3(BH, otp_ceil_div(HSP, 4)), dim3(256), 0, st, slabs, P, hs, HSP, NS, scale);      \
         if (split_) {                                                                                          \
             auto kx = attn_pv_x3_kernel<NB_>;                                                                  \
-            const size_t lx = (size_t)(PVX_TT + HSP) * (HSP * 4 + 16) + 16;                                    \
+            const size_t lx = PVX_LDS;                      /* >= (PVX_TT + HSP) * (HSP * 4 + 16) + 16 for HSP <= 80 */                                     \
             OTP_ALLOW_BIG_LDS(kx, lx);                                                                         \
-            hipLaunchKernelGGL(kx, dim3(BH, otp_ceil_div(T, PVX_TT)), dim3(256), lx, st, vf, P, of, hs, T);    \
+            hipLaunchKernelGGL(kx, dim3(BH, otp_ceil_div(T, PVX_TT)), dim3(PVX_TH), lx, st, vf, P, of, hs, T);    \
         } else {                                                                                               \
             auto kern = attn_pv_kernel<NB_>;                                                                   \
             OTP_ALLOW_BIG_LDS(kern, pv_lds);                                                                   \
@@ -941,9 +948,9 @@ extern "C" int otp_chan_attn_apply(const void* v, const void* M, void* out, int 
             if (g_attn_split.load(std::memory_order_relaxed)) {                                             \
                 split_ = true;                                                                              \
                 auto kx = attn_pv_x3_kernel<NB_>;                                                           \
-                const size_t lx = (size_t)(PVX_TT + HSP) * (HSP * 4 + 16) + 16;                             \
+                const size_t lx = PVX_LDS;                      /* >= (PVX_TT + HSP) * (HSP * 4 + 16) + 16 for HSP <= 80 */                              \
                 OTP_ALLOW_BIG_LDS(kx, lx);                                                                  \
-                hipLaunchKernelGGL(kx, dim3(BH, otp_ceil_div(T, PVX_TT)), dim3(256), lx, st, vf, mf, of, hs, T); \
+                hipLaunchKernelGGL(kx, dim3(BH, otp_ceil_div(T, PVX_TT)), dim3(PVX_TH), lx, st, vf, mf, of, hs, T); \
             }                                                                                               \
         }                                                                                                   \
         if (!split_) {                                                                                      \

@@ -60,6 +60,8 @@ class InferenceEngine:
         self.use_x3 = os.environ.get("OTPOSE_CONV_MATH", "x3") != "f32"
         # offset / mask convs + DCN gathers of all dilations in one launch (split-bf16 products for the convs)
         self.use_dcn_fused = self.use_x3 and os.environ.get("OTPOSE_DCN_FUSED", "1") != "0"
+        # HRNet branches (chains of BasicBlocks) on split-record activations fed by the LDS-DMA (csrc/convs.hip)
+        self.use_s8 = self.use_x3 and os.environ.get("OTPOSE_S8", "1") != "0"
         self.use_flow_fused = os.environ.get("OTPOSE_FLOW_FUSED", "1") != "0"       # flow-encoder blocks via csrc/flowenc.hip
         self.use_small_conv = os.environ.get("OTPOSE_SMALL_CONV", "1") != "0"       # RSB staircase convs via csrc/conv_small.hip
         self.use_fused_mlp = os.environ.get("OTPOSE_FUSED_MLP", "1") != "0"   # transformer MLP via csrc/mlp.hip
@@ -105,6 +107,11 @@ class InferenceEngine:
         """A static activation / scratch buffer.  The engine owns it for its whole life: the launch list holds
         raw device pointers, and torch.cuda.graph() empties the allocator cache before capturing."""
         t = torch.empty(shape, dtype=torch.float32, device=self.dev)
+        rng = os.environ.get("OTPOSE_POISON")                  # development aid ("lo:hi"): NaN-fill the buffers with these indices to
+        if rng:                                                # find a kernel that reads memory nothing wrote (tools/poison_engine.py)
+            lo, hi = (int(v) for v in rng.split(":"))
+            if lo <= len(self._bufs) < hi:
+                t.fill_(float("nan"))
         self._bufs.append(t)
         return t
 
@@ -263,6 +270,63 @@ class InferenceEngine:
             res = self.conv_bn(x, blk.downsample[0], blk.downsample[1])
         return self.conv_bn(y, blk.conv2, blk.bn2, ACT_RELU, res=res)
 
+    def _bn_fold(self, bn):
+        g, b = self.dev_param(bn.weight), self.dev_param(bn.bias)
+        mu, var = self.dev_param(bn.running_mean), self.dev_param(bn.running_var)
+        sc = (g / torch.sqrt(var + bn.eps)).contiguous()
+        sh = (b - mu * sc).contiguous()
+        self._keep += [sc, sh]
+        return sc, sh
+
+    def branch_s8(self, blocks, x: View):
+        """A branch of a HighResolutionModule (HRNet.py:478-496: 4 BasicBlocks, :500-530) on split-record activations
+        (csrc/convs.hip).  The branch input is converted once to its S8 image (the MFMA operand records: conv input) and its
+        C4 image (fp32, the accumulator layout: residual); inside the branch conv1 goes S8 -> S8, conv2 S8 + C4 residual ->
+        C4 + S8; the last conv2 writes the NCHW tensor the fuse layer reads.  Returns None when the branch is not of that
+        shape (the caller then emits the blocks one convolution at a time)."""
+        n, c, h, w = x.t.shape
+        if x.coff != 0 or x.C != c:
+            return None
+        for blk in blocks:
+            convs = (getattr(blk, "conv1", None), getattr(blk, "conv2", None))
+            if (getattr(blk, "downsample", None) is not None or hasattr(blk, "conv3") or any(
+                    cv is None or cv.kernel_size != (3, 3) or cv.stride != (1, 1) or cv.padding != (1, 1) or cv.dilation != (1, 1)
+                    or cv.bias is not None or cv.in_channels != c or cv.out_channels != c or cv.groups != 1 for cv in convs)):
+                return None
+        if not ops.s8_conv_supported(ops.s8_conv_desc(n, c, c, h, w, ACT_RELU)):
+            return None
+        L = self.lib
+        new_img = lambda: self.new(n * c * h * w)                          # noqa: E731  (S8 and C4 images are 4 bytes per element)
+        xs8, xc4 = new_img(), new_img()
+        self.call(L.otp_s8_pack, "otp_s8_pack", hip.ptr(x.t), hip.ptr(xs8), hip.ptr(xc4), n, c, h, w, x.ctot, x.coff)
+        out = None
+        for b, blk in enumerate(blocks):
+            last = b == len(blocks) - 1
+            sc1, sh1 = self._bn_fold(blk.bn1)
+            sc2, sh2 = self._bn_fold(blk.bn2)
+            w1 = ops.pack_s8_weight(self.dev_param(blk.conv1.weight), sc1)
+            w2 = ops.pack_s8_weight(self.dev_param(blk.conv2.weight), sc2)
+            self._keep += [w1, w2]
+            y8 = new_img()
+            d1 = ops.s8_conv_desc(n, c, c, h, w, ACT_RELU)
+            self._keep.append(d1)
+            self.call(L.otp_conv3x3_s8, "otp_conv3x3_s8", hip.ptr(xs8), hip.ptr(w1), hip.ptr(sh1), None, None, ops.S8_F32_C4,
+                      hip.ptr(y8), d1)
+            if last:
+                out = View(self.new(n, c, h, w))
+                d2 = ops.s8_conv_desc(n, c, c, h, w, ACT_RELU, out)
+                self._keep.append(d2)
+                self.call(L.otp_conv3x3_s8, "otp_conv3x3_s8", hip.ptr(y8), hip.ptr(w2), hip.ptr(sh2), hip.ptr(xc4), hip.ptr(out.t),
+                          ops.S8_F32_NCHW, None, d2)
+            else:
+                oc4, o8 = new_img(), new_img()
+                d2 = ops.s8_conv_desc(n, c, c, h, w, ACT_RELU)
+                self._keep.append(d2)
+                self.call(L.otp_conv3x3_s8, "otp_conv3x3_s8", hip.ptr(y8), hip.ptr(w2), hip.ptr(sh2), hip.ptr(xc4), hip.ptr(oc4),
+                          ops.S8_F32_C4, hip.ptr(o8), d2)
+                xs8, xc4 = o8, oc4
+        return out
+
     def bottleneck(self, blk, x: View) -> View:
         res = x
         if blk.downsample is not None:
@@ -283,6 +347,10 @@ class InferenceEngine:
         self.fork(range(1, n))
         for i in range(n):
             self.on_stream(i)                                     # branch i is independent of the others until the fuse
+            y = self.branch_s8(list(mod.branches[i]), xs[i]) if self.use_s8 else None
+            if y is not None:
+                xs[i] = y
+                continue
             for blk in mod.branches[i]:
                 xs[i] = self.basic_block(blk, xs[i])
         self.on_stream(0)
@@ -635,7 +703,7 @@ class InferenceEngine:
         self.fork((1,))
         self.conv_transformer(m.temporal_encoder1, x1, s1)
         final(m.final_layer1, s1, 0)
-        self.on_stream(1)
+        self.on_stream(0 if os.environ.get("OTPOSE_TE_SERIAL") == "1" else 1)
         self.conv_transformer(m.temporal_encoder2, x2, s2)
         final(m.final_layer2, s2, 1)
         self.on_stream(0)

@@ -42,8 +42,8 @@ CASES = [
     (3, 192, 192, 24, 18, True, False),      # branch 2
     (7, 384, 96, 12, 9, True, True),         # branch 3 maps: up to four images per tile
     (2, 64, 64, 96, 72, False, False),       # NTW = 2 (layer1 width)
-    (2, 32, 40, 10, 6, True, True),          # Cout not a multiple of 16: partial last cout tile, tail tile
-    (1, 16, 24, 8, 4, False, False),         # one partial tile, one chunk
+    (2, 32, 80, 10, 6, True, True),          # Cout = 5 tiles of 16: a partial last cout block (lone tile in the S8 store), tail tile
+    (1, 16, 16, 8, 4, False, False),         # one partial tile, one chunk
     (80, 384, 384, 12, 9, True, True),       # launches of a few hundred workgroups (XCD-interleaved ranges with ragged ends)
     (40, 192, 192, 24, 18, True, False),
     (16, 48, 48, 96, 72, True, True),
@@ -119,9 +119,54 @@ def test_conv3x3_s8_agrees_with_the_fp32_input_kernel():
 def test_conv3x3_s8_rejects_what_it_does_not_cover():
     d = ops.s8_conv_desc(2, 48, 48, 96, 72)
     assert ops.s8_conv_supported(d)
-    for field, val in (("stride", 2), ("dil", 2), ("Cin", 24), ("kh", 1), ("W", 500), ("Cout", 20)):
+    for field, val in (("stride", 2), ("dil", 2), ("Cin", 24), ("kh", 1), ("W", 500), ("Cout", 40)):
         e = ops.hip.ConvDesc.from_buffer_copy(bytes(d))
         setattr(e, field, val)
         if field == "W":
             e.Wo = val
         assert not ops.s8_conv_supported(e), field
+
+
+def test_conv3x3_s8_is_bit_stable_next_to_other_kernels():
+    """The engine runs HRNet branches on parallel streams: an S8 block (conv1 -> conv2 with C4 residual, both outputs) must
+    give the same bits alone and with fp32-input split convolutions and other S8 convolutions sharing the CUs (a hand-placed
+    v_permlane32_swap once made the S8 records depend on who else was resident)."""
+    def setup(n, c, h, w, seed):
+        g = torch.Generator().manual_seed(seed)
+        x = torch.randn(n, c, h, w, generator=g).cuda()
+        wt = (torch.randn(c, c, 3, 3, generator=g) * (1.0 / (c * 9)) ** 0.5).cuda()
+        xs, xc4 = ops.s8_empty(n, c, h, w, "cuda"), ops.c4_empty(n, c, h, w, "cuda")
+        ops.s8_pack(x, xs, xc4)
+        return dict(xs=xs, xc4=xc4, wp=ops.pack_s8_weight(wt), sh=(torch.randn(c, generator=g) * 0.1).cuda(),
+                    d=ops.s8_conv_desc(n, c, c, h, w, ops.ACT_RELU), y8=ops.s8_empty(n, c, h, w, "cuda"),
+                    o4=ops.c4_empty(n, c, h, w, "cuda"), o8=ops.s8_empty(n, c, h, w, "cuda"))
+
+    def run(b, st):
+        ops.conv3x3_s8_launch(b["xs"], b["wp"], b["sh"], b["d"], None, None, ops.S8_F32_C4, b["y8"], stream=st.cuda_stream)
+        ops.conv3x3_s8_launch(b["y8"], b["wp"], b["sh"], b["d"], b["xc4"], b["o4"], ops.S8_F32_C4, b["o8"], stream=st.cuda_stream)
+
+    blocks = [setup(5, 48, 96, 72, 1), setup(5, 96, 48, 36, 2), setup(5, 192, 24, 18, 3)]
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    refs = []
+    for b in blocks:
+        run(b, torch.cuda.current_stream())
+        torch.cuda.synchronize()
+        refs.append((b["o4"].clone(), b["o8"].clone()))
+    xx = torch.randn(5, 96, 48, 36, device="cuda")
+    wp = ops.pack_x3_weight(torch.randn(96, 96, 3, 3, device="cuda") * 0.03, None, 1)
+    yy = torch.empty_like(xx)
+    iv, ov = ops.View(xx), ops.View(yy)
+    dd = ops.conv_desc(iv, ov, 96, 3, 3, 1, 1, 1, ops.ACT_RELU)
+    for it in range(10):
+        for b in blocks:
+            b["o4"].zero_(), b["o8"].zero_(), b["y8"].zero_()
+        torch.cuda.synchronize()
+        for k in range(3):
+            ops.conv2d_x3_launch(iv, wp, None, ov, dd, None, stream=streams[3].cuda_stream)
+        for b, st in zip(blocks, streams):
+            run(b, st)
+        for k in range(3):
+            ops.conv2d_x3_launch(iv, wp, None, ov, dd, None, stream=streams[3].cuda_stream)
+        torch.cuda.synchronize()
+        for b, (r4, r8) in zip(blocks, refs):
+            assert torch.equal(b["o4"], r4) and torch.equal(b["o8"], r8), it
