@@ -339,6 +339,43 @@ def gen_train_step():
     print("  largest gradient tensors:", big)
 
 
+def gen_e2e_seeds():
+    """the split-product eval path must hold 1e-3 on more than one clip / one weight draw.  cfg1
+    (256x192, W32) for 3 input seeds x 2 weight seeds - stored: the output heat-maps and the rough heat-maps of the current
+    frame, plus max|.| of all seven outputs - and a 2-clip cfg2 batch (384x288, W48) whose second clip sits at a sequence
+    border (margin row [0, 1, 0, 2], reference dataset/PoseTrackDataset.py:263-293)."""
+    names = ("output", "rough", "intersection", "prev_b", "context", "squeezed", "total_b")
+    arrays = {}
+    cfg = C.cfg1()
+    with torch.no_grad():
+        for ws in (S.WEIGHT_SEED, 777):
+            m = ref_otpose(cfg)
+            S.fill_synthetic_(m, ws, S.gains_for(cfg))
+            m.eval()
+            for xs in (S.INPUT_SEED, 11, 12):
+                x, margin = S.synthetic_clip(1, cfg.MODEL.IMAGE_SIZE, seed=xs)
+                outs = m(x, margin=margin)
+                tag = f"cfg1_w{ws}_x{xs}"
+                arrays[tag + "_output"] = outs[0]
+                arrays[tag + "_rough_cur"] = outs[1][:1]
+                arrays[tag + "_context"] = outs[4]
+                arrays[tag + "_absmax"] = np.array([float(o.abs().max()) for o in outs])
+                print(f"  {tag}: " + " ".join(f"{n}={float(o.abs().max()):.3g}" for n, o in zip(names, outs)))
+        cfg = C.cfg2()
+        m = ref_otpose(cfg)
+        S.fill_synthetic_(m, S.WEIGHT_SEED, S.gains_for(cfg))
+        m.eval()
+        x, margin = S.synthetic_clip(2, cfg.MODEL.IMAGE_SIZE, seed=21)
+        margin[1] = torch.tensor([0.0, 1.0, 0.0, 2.0])
+        outs = m(x, margin=margin)
+        for n, o in zip(names, outs):
+            if n in ("output", "prev_b", "context"):
+                arrays["cfg2_b2_" + n] = o
+        arrays["cfg2_b2_absmax"] = np.array([float(o.abs().max()) for o in outs])
+        print("  cfg2_b2: " + " ".join(f"{n}={float(o.abs().max()):.3g}" for n, o in zip(names, outs)))
+    save("e2e_seeds", **arrays)
+
+
 def _oracle_run(cfg, b, gains):
     from otpose_amd import OTPose
     m = OTPose(cfg)
@@ -378,7 +415,7 @@ def calibrate():
 
 
 GENS = {"keys": gen_state_dict_keys, "blocks": gen_blocks, "hrnet_tiny": gen_hrnet_tiny,
-        "losses": gen_losses, "decode": gen_decode, "accuracy": gen_accuracy, "e2e_tiny": gen_e2e_tiny, "e2e_cfg1": gen_e2e_cfg1, "e2e_cfg2": gen_e2e_cfg2, "train_step": gen_train_step}
+        "losses": gen_losses, "decode": gen_decode, "accuracy": gen_accuracy, "e2e_tiny": gen_e2e_tiny, "e2e_cfg1": gen_e2e_cfg1, "e2e_cfg2": gen_e2e_cfg2, "train_step": gen_train_step, "e2e_seeds": gen_e2e_seeds}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

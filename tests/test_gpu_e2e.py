@@ -165,3 +165,47 @@ def test_headline_batch_agrees_with_the_single_clip_the_golden_pins(golden):
     for n, a, b in zip(NAMES, solo, outs):
         r = rows(b, 7)
         assert float((a - r).abs().max()) <= 2e-5 * max(1.0, float(r.abs().max())), n
+
+
+@pytest.mark.parametrize("ws", [S.WEIGHT_SEED, 777])
+def test_e2e_cfg1_three_input_seeds_two_weight_seeds(golden, ws):
+    """The split-product eval path against reference-generated goldens of cfg1 for 3 input seeds x 2 weight seeds
+    (tests/golden/make_golden.py::gen_e2e_seeds): heat-maps <= 1e-3 ABSOLUTE everywhere."""
+    g = golden("e2e_seeds")
+    cfg = cfg1()
+    m = OTPose(cfg)
+    S.fill_synthetic_(m, ws, S.gains_for(cfg))
+    m = m.cuda().eval()
+    for xs in (S.INPUT_SEED, 11, 12):
+        x, margin = S.synthetic_clip(1, cfg.MODEL.IMAGE_SIZE, seed=xs)
+        with torch.no_grad():
+            outs = [o.cpu() for o in m(x.cuda(), margin=margin.cuda())]
+        tag = f"cfg1_w{ws}_x{xs}"
+        errs = {"output": float((outs[0] - g[tag + "_output"]).abs().max()),
+                "rough": float((outs[1][:1] - g[tag + "_rough_cur"]).abs().max()),
+                "context": float((outs[4] - g[tag + "_context"]).abs().max())}
+        print(tag, errs)
+        assert errs["output"] <= TOL and errs["rough"] <= TOL, (tag, errs)
+        assert errs["context"] <= TOL * max(1.0, float(g[tag + "_context"].abs().max())), (tag, errs)
+        for o, mx in zip(outs, g[tag + "_absmax"].tolist()):
+            assert abs(float(o.abs().max()) - mx) <= TOL * max(1.0, mx)
+
+
+def test_e2e_cfg2_two_clips_with_a_sequence_border(golden):
+    """cfg2 (384x288, W48), 2 clips, the second at a sequence border (margin row [0, 1, 0, 2]: the prev / pprev frames are
+    copies of the current one and their heat-maps are NOT penalised, OTPose.py:339-346)."""
+    g = golden("e2e_seeds")
+    cfg = cfg2()
+    m = OTPose(cfg)
+    S.fill_synthetic_(m)
+    m = m.cuda().eval()
+    x, margin = S.synthetic_clip(2, cfg.MODEL.IMAGE_SIZE, seed=21)
+    margin[1] = torch.tensor([0.0, 1.0, 0.0, 2.0])
+    with torch.no_grad():
+        outs = [o.cpu() for o in m(x.cuda(), margin=margin.cuda())]
+    errs = {n: float((outs[NAMES.index(n)] - g["cfg2_b2_" + n]).abs().max()) for n in ("output", "prev_b", "context")}
+    print(errs)
+    assert errs["output"] <= TOL and errs["prev_b"] <= TOL
+    assert errs["context"] <= TOL * max(1.0, float(g["cfg2_b2_context"].abs().max()))
+    for o, mx in zip(outs, g["cfg2_b2_absmax"].tolist()):
+        assert abs(float(o.abs().max()) - mx) <= TOL * max(1.0, mx)

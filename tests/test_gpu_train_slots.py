@@ -59,9 +59,12 @@ def _grad_err(pa, pb):
     return (num / max(den, 1e-300)) ** 0.5, worst, wname
 
 
-# run-to-run spread of the HIP backward itself (float atomics in the DCN weight gradient, fp32 reductions): the two replicas
-# agree to ~1e-6; a stale or doubled gradient is an O(1) error
-GRAD_TOL = {"f32": 2e-4, "bf16": 2e-3}
+# Run-to-run spread of the HIP backward itself on identical weights and inputs (measured with tools/train_determinism.py):
+# f32 1e-7 (float atomics in the DCN weight gradient, fp32 reduction order); bf16 usually 1e-9, but about one backward in
+# five deviates by 1e-3 .. 6e-3 in the whole-gradient L2 sense (same loss to the last bit; seen with and without side
+# streams - an fp32 summation-order difference that flips bf16 roundings of activation gradients, amplified by the
+# BatchNorm backward at batch 2).  A stale or doubled gradient - what this test is about - is an O(1) error.
+GRAD_TOL = {"f32": 2e-4, "bf16": 2e-2}
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])

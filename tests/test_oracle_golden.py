@@ -186,3 +186,24 @@ def test_train_step_matches_reference_golden(golden, dtype):
         if rel > tol or cos < 1 - 1e-5:
             bad.append((k, rel, cos))
     assert not bad, bad
+
+
+SEED_CASES = [(ws, xs) for ws in (S.WEIGHT_SEED, 777) for xs in (S.INPUT_SEED, 11, 12)]
+
+
+@pytest.mark.parametrize("ws,xs", SEED_CASES[::3])       # one per weight seed on the CPU (the GPU suite runs all six)
+def test_e2e_cfg1_other_seeds(golden, ws, xs):
+    g = golden("e2e_seeds")
+    cfg = cfg1()
+    m = OTPose(cfg)
+    S.fill_synthetic_(m, ws, S.gains_for(cfg))
+    sd = {k: v.detach() for k, v in m.state_dict().items()}
+    x, margin = S.synthetic_clip(1, cfg.MODEL.IMAGE_SIZE, seed=xs)
+    with torch.no_grad():
+        outs = O.otpose_forward(sd, cfg, x, margin)
+    tag = f"cfg1_w{ws}_x{xs}"
+    _close(outs[0], g[tag + "_output"], 5e-5)
+    _close(outs[1][:1], g[tag + "_rough_cur"], 5e-5)
+    _close(outs[4], g[tag + "_context"], 5e-5)
+    for o, mx in zip(outs, g[tag + "_absmax"].tolist()):
+        assert abs(float(o.abs().max()) - mx) <= 1e-4 * max(1.0, mx)
