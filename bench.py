@@ -159,11 +159,38 @@ def kernel_rooflines(dev, batch):
                 and ops.wino_supported(d))
     peak = PEAK_F32_MATRIX
     extra = {}
-    if use_x3:
-        # the kernel the engine runs for this layer: split-bf16 products on the bf16 matrix cores (csrc/convx.hip).  Every
-        # fp32 product is three bf16 MFMA products and a chunk's 9 taps occupy 10 tap slots, so the pipe executes
-        # 3 * 10/9 of the algorithmic FLOPs - against the dense bf16 peak.  The kernel is bound by the LDS (fragment reads:
-        # 108 B/clk/CU measured, tools/micro/lds_b128.hip), see DESIGN.md section 3.1c.
+    use_s8 = (use_x3 and os.environ.get("OTPOSE_S8", "1") != "0"
+              and ops.s8_conv_supported(ops.s8_conv_desc(n, 48, 48, 96, 72, ops.ACT_RELU)))
+    if use_s8:
+        # the kernel the engine runs for this layer inside an HRNet branch (csrc/convs.hip): split-bf16 products on activations
+        # kept as MFMA operand records (S8), staged by the LDS-DMA.  A BasicBlock runs it twice: conv1 S8 -> S8 (timed here as
+        # `roofline`) and conv2 S8 + C4 residual -> C4 + S8 (`conv2_form`).  Every fp32 product is three bf16 MFMA products and
+        # a chunk's 9 taps occupy 10 tap slots: the pipe executes 3 * 10/9 of the algorithmic FLOPs, priced at the dense bf16 peak.
+        xs = ops.s8_pack(x)
+        ys = ops.s8_empty(n, 48, 96, 72, dev)
+        ws = ops.pack_s8_weight(w, sc)
+        ds = ops.s8_conv_desc(n, 48, 48, 96, 72, ops.ACT_RELU)
+        t_conv = event_time_ms(lambda: ops.conv3x3_s8_launch(xs, ws, sh, ds, None, None, ops.S8_F32_C4, ys), 20, st)
+        rc4, oc4 = ops.c4_empty(n, 48, 96, 72, dev), ops.c4_empty(n, 48, 96, 72, dev)
+        ops.s8_pack(torch.randn(n, 48, 96, 72, generator=g).to(dev), out_c4=rc4)
+        t_conv2 = event_time_ms(lambda: ops.conv3x3_s8_launch(xs, ws, sh, ds, rc4, oc4, ops.S8_F32_C4, ys), 20, st)
+        kname = ("convs_kernel<3> (bf16x3 split products, S8 operand records, LDS-DMA) 48->48 3x3 @96x72 x%d frames, S8 -> S8 "
+                 "(grid %d x 256 threads)" % (n, ((n * 96 * 72 // 256 + 7) // 8) * 8))
+        executed = conv_flop * 3.0 * 10.0 / 9.0
+        peak = PEAK_BF16_MATRIX
+        tr2, _ = measured_traffic("convs_48_48_3x3_96x72_x80_conv2", True)
+        extra = {"arithmetic": "fp32 accumulate; operands stored as bf16 hi | lo records (hi = rne(x), lo = rne(x - hi)), products "
+                               "lo*hi + hi*lo + hi*hi (csrc/convs.hip)",
+                 "pmc": "profiles/r03_convs_pmc_fold.txt: 2.4 VALU per MFMA (prologue / epilogue; the chunk loop has none), "
+                        "SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 5 %",
+                 "conv2_form": {"what": "S8 + C4 residual -> C4 + S8 (BasicBlock conv2)", "ms_per_launch": t_conv2,
+                                "achieved": conv_flop / (t_conv2 * 1e-3) / 1e12, "frac": executed / (t_conv2 * 1e-3) / peak,
+                                "traffic": tr2, "algorithmic_bytes_per_launch": 4.0 * 4 * 48 * 96 * 72 * n,
+                                "hbm_frac": (tr2 if tr2 is not None else 4.0 * 4 * 48 * 96 * 72 * n) / (t_conv2 * 1e-3) / PEAK_HBM}}
+    elif use_x3:
+        # the kernel the engine runs for this layer outside the S8 path: split-bf16 products on the bf16 matrix cores from fp32
+        # NCHW input (csrc/convx.hip).  Every fp32 product is three bf16 MFMA products and a chunk's 9 taps occupy 10 tap
+        # slots, so the pipe executes 3 * 10/9 of the algorithmic FLOPs - against the dense bf16 peak.
         xp = ops.pack_x3_weight(w, sc, 1)
         t_conv = event_time_ms(lambda: ops.conv2d_x3_launch(iv, xp, sh, ov, d), 20, st)
         kname = "convx_kernel<16,4,1,3> (bf16x3 split products) 48->48 3x3 @96x72 x%d frames (grid %d x 256 threads)" % (
@@ -191,7 +218,7 @@ def kernel_rooflines(dev, batch):
         kname = ("conv_win_kernel<%d,%d,3,true> 48->48 3x3 @96x72 x%d frames (grid %d x %d threads)"
                  % (plan[0], plan[1], n, plan[5], 64 * plan[2] * plan[3]))
         executed = conv_flop
-    traffic, tsrc = measured_traffic("convx_48_48_3x3_96x72_x80" if use_x3 else
+    traffic, tsrc = measured_traffic("convs_48_48_3x3_96x72_x80" if use_s8 else "convx_48_48_3x3_96x72_x80" if use_x3 else
                                      ("conv_wino_48_48_3x3_96x72_x80" if use_wino else "conv_48_48_3x3_96x72_x80"), True)
     # `achieved` is ALGORITHMIC (direct-convolution) FLOP/s as the bench contract defines it; `frac` is what the matrix
     # pipe actually does (executed MFMA FLOPs / peak), so a Winograd launch can never read above its pipe occupancy.
@@ -530,8 +557,10 @@ def main():
             # on exact-fp32 MFMA kernels is `exact_fp32_kernels` of this line.
             "dtype": "f32" if math == "f32" else "f32 storage+accumulate / bf16x3 split products", "data": "synthetic",
             "rccl_world": dist.get_world_size() if dist is not None else 1,
-            "arithmetic": ("fp32 storage and accumulation everywhere; conv / MLP / projection products as three bf16 MFMA "
-                           "products of two-piece operands (a = hi + lo, |a - hi - lo| <= 2^-18 |a|: DESIGN.md section 3.1c)"
+            "arithmetic": ("fp32 accumulation everywhere; conv / MLP / projection products as three bf16 MFMA products of two-piece "
+                           "operands (a = hi + lo, |a - hi - lo| <= 2^-18 |a|: DESIGN.md section 3.1c); tensors are fp32 except, "
+                           "inside an HRNet branch, the conv1 output of a BasicBlock, which exists only as that hi | lo pair "
+                           "(the residual chain stays fp32: DESIGN.md section 3.1d)"
                            if math != "f32" else "fp32 throughout (f32 MFMA)"),
             "config": {"workload": "BASELINE configs[1]: batch %d x 5-frame x 384x288, HRNet-W48 + DCN warp + "
                                    "ConvVideoTransformer, fp32 forward (eval), seeded synthetic weights" % a.batch,
