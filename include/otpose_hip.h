@@ -165,6 +165,11 @@ int otp_conv2d_x3(const void* in, const void* wpacked, const void* shift, const 
 #define OTP_S8_F32_NCHW 2
 size_t otp_s8_bytes(int N, int C, int H, int W);
 int otp_s8_pack(const void* in_f32, void* out_s8, void* out_c4, int N, int C, int H, int W, int in_ctot, int in_coff, void* stream);
+/* otp_upsample_add_multi (a fuse row's upsampled terms, model/HRNet.py:487-494) writing the S8 and C4 images of its result -
+ * what the next module's branch reads - and the NCHW tensor only when out_nchw != NULL; same additions in the same order */
+int otp_s8_upsample_add(const void* const* lows, const int* factors, int nlow, const void* res, void* out_nchw, void* out_s8,
+                        void* out_c4, int N, int C, int Hh, int Wh, int relu, int res_ctot, int res_coff, int out_ctot,
+                        int out_coff, void* stream);
 int otp_s8_unpack(const void* in_s8, void* out_f32, int N, int C, int H, int W, void* stream);
 int otp_c4_unpack(const void* in_c4, void* out_f32, int N, int C, int H, int W, void* stream);
 int otp_conv3x3_s8_supported(const otp_conv_desc* desc);

@@ -122,6 +122,68 @@ __global__ __launch_bounds__(256) void s8_pack_kernel(const float* __restrict__ 
     }
 }
 
+// A fuse row's upsampled terms (HRNet.py:487-494; otp_upsample_add_multi: out = act(res + up_f0(low0) + up_f1(low1) + ...), added
+// in that order) written as the images the next module's branch reads: S8 + C4 (and the NCHW tensor only when somebody else
+// needs it).  Same additions in the same order as upsample_add_multi_kernel: bit-identical values.  A thread owns 4
+// consecutive pixels of one 8-channel group.
+struct S8Up {
+    const float* low[3];
+    int f[3];
+    int n;
+};
+__global__ __launch_bounds__(256) void s8_upsample_add_kernel(S8Up U, const float* __restrict__ res, float* out_nchw,
+                                                               u32x4* __restrict__ out_s8, float* __restrict__ out_c4, int N, int C,
+                                                               int Hh, int Wh, int relu, int res_ctot, int res_coff, int out_ctot,
+                                                               int out_coff) {
+    const int HW = Hh * Wh, q4 = HW >> 2, G8 = C >> 3, Wh4 = Wh >> 2;
+    const size_t items = (size_t)N * G8 * q4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < items; i += (size_t)gridDim.x * 256) {
+        const int q = (int)(i % q4);
+        const size_t r = i / q4;
+        const int g = (int)(r % G8), n = (int)(r / G8);
+        const int y = q / Wh4, x4 = q - y * Wh4;
+        f32x4 v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = 8 * g + e;
+            f32x4 o = *reinterpret_cast<const f32x4*>(res + ((size_t)n * res_ctot + res_coff + c) * HW + 4 * q);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if (k < U.n) {
+                    const int f = U.f[k], Wl = Wh / f, Hl = Hh / f;
+                    const float* lrow = U.low[k] + (((size_t)n * C + c) * Hl + y / f) * Wl;
+                    if (f >= 4) {
+                        o = o + lrow[(4 * x4) / f];
+                    } else {
+                        const float l0 = lrow[2 * x4], l1 = lrow[2 * x4 + 1];
+                        o = o + (f32x4){l0, l0, l1, l1};
+                    }
+                }
+            }
+            if (relu) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.f);
+            }
+            v[e] = o;
+            if (out_nchw) *reinterpret_cast<f32x4*>(out_nchw + ((size_t)n * out_ctot + out_coff + c) * HW + 4 * q) = o;
+        }
+        u32x4* dst = out_s8 + ((size_t)(n * G8 + g) * 2) * HW + 4 * q;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float f[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = v[e][k];
+            u32x4 hi, lo;
+            ssplit8(f, hi, lo);
+            dst[k] = hi;
+            dst[(size_t)HW + k] = lo;
+            f32x4* d4 = reinterpret_cast<f32x4*>(out_c4) + ((size_t)n * (C >> 2) + 2 * g) * HW + 4 * q + k;
+            d4[0] = (f32x4){f[0], f[1], f[2], f[3]};
+            d4[HW] = (f32x4){f[4], f[5], f[6], f[7]};
+        }
+    }
+}
+
 // C4 -> fp32 NCHW: test / debugging aid
 __global__ __launch_bounds__(256) void c4_unpack_kernel(const f32x4* __restrict__ in, float* __restrict__ out, int N, int C, int HW) {
     const size_t items = (size_t)N * (C >> 2) * HW;
@@ -895,6 +957,32 @@ extern "C" int otp_s8_pack(const void* in, void* out, void* out_c4, int N, int C
     const int grid = (int)((items + 255) / 256 > 8192 ? 8192 : (items + 255) / 256);
     hipLaunchKernelGGL(s8_pack_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const float*>(in),
                        static_cast<u32x4*>(out), static_cast<float*>(out_c4), N, C, H * W, in_ctot, in_coff);
+    return otp_launch_status();
+}
+
+extern "C" int otp_s8_upsample_add(const void* const* lows, const int* factors, int nlow, const void* res, void* out_nchw,
+                                   void* out_s8, void* out_c4, int N, int C, int Hh, int Wh, int relu, int res_ctot, int res_coff,
+                                   int out_ctot, int out_coff, void* stream) {
+    if (!lows || !factors || !res || !out_s8 || !out_c4 || nlow < 1 || nlow > 3 || N <= 0 || C <= 0 || Hh <= 0 || Wh <= 0)
+        return OTP_ERR_BAD_ARG;
+    if (Wh % 4 || C % 8 || res_ctot < res_coff + C || (out_nchw && out_ctot < out_coff + C)) return OTP_ERR_UNSUPPORTED;
+    S8Up U{};
+    U.n = nlow;
+    for (int k = 0; k < nlow; ++k) {
+        const int f = factors[k];
+        if (!lows[k]) return OTP_ERR_BAD_ARG;
+        if (f < 2 || (f & (f - 1)) || Hh % f || Wh % f) return OTP_ERR_UNSUPPORTED;
+        U.low[k] = static_cast<const float*>(lows[k]);
+        U.f[k] = f;
+    }
+    if ((reinterpret_cast<uintptr_t>(res) | reinterpret_cast<uintptr_t>(out_nchw) | reinterpret_cast<uintptr_t>(out_s8) |
+         reinterpret_cast<uintptr_t>(out_c4)) & 15)
+        return OTP_ERR_UNSUPPORTED;
+    const size_t items = (size_t)N * (C / 8) * (Hh * Wh / 4);
+    const int grid = (int)((items + 255) / 256 > 8192 ? 8192 : (items + 255) / 256);
+    hipLaunchKernelGGL(s8_upsample_add_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), U,
+                       static_cast<const float*>(res), static_cast<float*>(out_nchw), static_cast<u32x4*>(out_s8),
+                       static_cast<float*>(out_c4), N, C, Hh, Wh, relu, res_ctot, res_coff, out_ctot, out_coff);
     return otp_launch_status();
 }
 

@@ -48,6 +48,7 @@ class InferenceEngine:
         self.W_img, self.H_img = cfg.MODEL.IMAGE_SIZE
         self.h, self.w = model.pe_h, model.pe_w
         self.ops: List[Callable] = []
+        self._aux = {}                        # id(NCHW tensor) -> {"s8", "c4", "nchw_needed"}: S8 / C4 images written by its producer
         self._keep = []                       # parameter-derived tensors that must outlive the ops
         self._bufs = []                       # every activation buffer (see new())
         self._stream = None
@@ -164,6 +165,8 @@ class InferenceEngine:
     def conv(self, inp: View, weight, out: View, stride=1, pad=0, dil=1, bn=None, bias=None, act=ACT_NONE,
              res: View = None, in2: View = None, res_up=1, frame_split=0, cin=None, scale=None, shift=None):
         """Emit act(scale*conv(inp (+in2)) + shift (+res)) with BN / bias folded into scale / shift."""
+        for v_ in (inp, in2, res):
+            self._needs_nchw(v_)
         w = self.dev_param(weight)
         if w.dim() == 3:
             w = w.unsqueeze(-1)
@@ -270,6 +273,38 @@ class InferenceEngine:
             res = self.conv_bn(x, blk.downsample[0], blk.downsample[1])
         return self.conv_bn(y, blk.conv2, blk.bn2, ACT_RELU, res=res)
 
+    def _needs_nchw(self, v):
+        """A consumer reads the NCHW tensor of ``v``: its producer must write it (see fuse_s8)."""
+        a = self._aux.get(id(v.t)) if v is not None else None
+        if a is not None:
+            a["nchw_needed"] = True
+
+    def fuse_s8(self, lows, factors, res: View, tgt: View):
+        """Last op of a fuse row whose tail is upsampled terms (HRNet.py:487-494): relu(res + up(low0) + ...) written as the
+        S8 and C4 images the next module's branch reads (csrc/convs.hip, otp_s8_upsample_add); the NCHW tensor ``tgt`` is
+        written only if some other consumer asks for it before the first launch.  Returns False when the row is not eligible."""
+        n_, c_, hh, wh = tgt.t.shape
+        if not self.use_s8 or tgt.coff != 0 or tgt.C != c_ or c_ % 16 or wh % 4 or (hh * wh) % 4:
+            return False
+        if not ops.s8_conv_supported(ops.s8_conv_desc(n_, c_, c_, hh, wh, ACT_RELU)):
+            return False
+        self._needs_nchw(res)
+        s8, c4 = self.new(n_ * c_ * hh * wh), self.new(n_ * c_ * hh * wh)
+        aux = {"s8": s8, "c4": c4, "nchw_needed": False}
+        self._aux[id(tgt.t)] = aux
+        lp = (ctypes.c_void_p * len(lows))(*[hip.ptr(v.t) for v in lows])
+        fp = (ctypes.c_int * len(lows))(*factors)
+        self._keep += [lp, fp]
+        L = self.lib
+        args = (lp, fp, len(lows), hip.ptr(res.t))
+        tail = (hip.ptr(s8), hip.ptr(c4), n_, c_, hh, wh, 1, res.ctot, res.coff, tgt.ctot, tgt.coff)
+
+        def run():
+            hip.check(L.otp_s8_upsample_add(*args, hip.ptr(tgt.t) if aux["nchw_needed"] else None, *tail, self._stream),
+                      "otp_s8_upsample_add")
+        self._emit(run)
+        return True
+
     def _bn_fold(self, bn):
         g, b = self.dev_param(bn.weight), self.dev_param(bn.bias)
         mu, var = self.dev_param(bn.running_mean), self.dev_param(bn.running_var)
@@ -297,8 +332,12 @@ class InferenceEngine:
             return None
         L = self.lib
         new_img = lambda: self.new(n * c * h * w)                          # noqa: E731  (S8 and C4 images are 4 bytes per element)
-        xs8, xc4 = new_img(), new_img()
-        self.call(L.otp_s8_pack, "otp_s8_pack", hip.ptr(x.t), hip.ptr(xs8), hip.ptr(xc4), n, c, h, w, x.ctot, x.coff)
+        aux = self._aux.get(id(x.t))
+        if aux is not None:                                                # the producer (a fuse row) already wrote both images
+            xs8, xc4 = aux["s8"], aux["c4"]
+        else:
+            xs8, xc4 = new_img(), new_img()
+            self.call(L.otp_s8_pack, "otp_s8_pack", hip.ptr(x.t), hip.ptr(xs8), hip.ptr(xc4), n, c, h, w, x.ctot, x.coff)
         out = None
         for b, blk in enumerate(blocks):
             last = b == len(blocks) - 1
@@ -386,6 +425,10 @@ class InferenceEngine:
                         # accumulate kernel (measured faster than the conv kernel's element-wise upsample epilogue)
                         low = self.conv_bn(xs[j], fl[0], fl[1], ACT_NONE)
                         n_, c_, hl, wl = low.t.shape
+                        if act == ACT_RELU and low.coff == 0 and low.C == c_ and self.fuse_s8([low], [f], res, tgt):
+                            y = tgt
+                            continue
+                        self._needs_nchw(res)
                         self.call(self.lib.otp_upsample_add, "otp_upsample_add", hip.ptr(low.t), hip.ptr(res.t),
                                   hip.ptr(tgt.t), n_, c_, hl, wl, f, int(act == ACT_RELU), low.ctot, low.coff,
                                   res.ctot, res.coff, tgt.ctot, tgt.coff)
@@ -403,6 +446,10 @@ class InferenceEngine:
                 tgt = y if y is not None else View(self.new(*xs[i].t.shape))
                 lows = [self.conv_bn(xs[j], mod.fuse_layers[i][j][0], mod.fuse_layers[i][j][1], ACT_NONE) for j in ups]
                 n_, c_, hh, wh = tgt.t.shape[0], xs[i].C, xs[i].t.shape[2], xs[i].t.shape[3]
+                if self.fuse_s8(lows, [2 ** (j - i) for j in ups], res, tgt):
+                    outs.append(tgt)
+                    continue
+                self._needs_nchw(res)
                 lp = (ctypes.c_void_p * len(ups))(*[hip.ptr(v.t) for v in lows])
                 fp = (ctypes.c_int * len(ups))(*[2 ** (j - i) for j in ups])
                 self._keep += [lp, fp]

@@ -65,6 +65,7 @@ SIGNATURES = {
     "otp_conv2d_x3": (c_int, [c_void_p] * 5 + [ctypes.POINTER(ConvDesc), c_void_p]),
     "otp_s8_bytes": (c_size_t, [c_int] * 4),
     "otp_s8_pack": (c_int, [c_void_p] * 3 + [c_int] * 6 + [c_void_p]),
+    "otp_s8_upsample_add": (c_int, [ctypes.POINTER(c_void_p), ctypes.POINTER(c_int), c_int] + [c_void_p] * 4 + [c_int] * 9 + [c_void_p]),
     "otp_s8_unpack": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
     "otp_c4_unpack": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
     "otp_conv3x3_s8_supported": (c_int, [ctypes.POINTER(ConvDesc)]),

@@ -170,3 +170,32 @@ def test_conv3x3_s8_is_bit_stable_next_to_other_kernels():
         torch.cuda.synchronize()
         for b, (r4, r8) in zip(blocks, refs):
             assert torch.equal(b["o4"], r4) and torch.equal(b["o8"], r8), it
+
+
+@pytest.mark.parametrize("factors", [(2,), (2, 4), (2, 4, 8)])
+def test_s8_upsample_add_equals_upsample_add_multi_then_pack(factors):
+    """otp_s8_upsample_add = otp_upsample_add_multi followed by otp_s8_pack (S8 + C4), bit for bit, with and without the
+    NCHW output (HRNet fuse rows, model/HRNet.py:487-494)."""
+    import ctypes
+    from otpose_amd import hip
+    L = hip.lib()
+    n, c, hh, wh = 3, 48, 32, 24
+    g = torch.Generator().manual_seed(len(factors))
+    res = torch.randn(n, c, hh, wh, generator=g).cuda()
+    lows = [torch.randn(n, c, hh // f, wh // f, generator=g).cuda() for f in factors]
+    lp = (ctypes.c_void_p * len(lows))(*[hip.ptr(t) for t in lows])
+    fp = (ctypes.c_int * len(lows))(*factors)
+    want = torch.empty_like(res)
+    hip.check(L.otp_upsample_add_multi(lp, fp, len(lows), hip.ptr(res), hip.ptr(want), n, c, hh, wh, 1, c, 0, c, 0,
+                                       hip.stream_of(res)), "multi")
+    ref = torch.relu(res + sum(F.interpolate(t, scale_factor=f, mode="nearest") for t, f in zip(lows, factors)))
+    assert float((want - ref).abs().max()) <= 1e-6
+    want_c4 = ops.c4_empty(n, c, hh, wh, "cuda")
+    want_s8 = ops.s8_pack(want, out_c4=want_c4)
+    for with_nchw in (True, False):
+        out = torch.full_like(res, 7.0)
+        s8, c4 = ops.s8_empty(n, c, hh, wh, "cuda"), ops.c4_empty(n, c, hh, wh, "cuda")
+        hip.check(L.otp_s8_upsample_add(lp, fp, len(lows), hip.ptr(res), hip.ptr(out) if with_nchw else None, hip.ptr(s8),
+                                        hip.ptr(c4), n, c, hh, wh, 1, c, 0, c, 0, hip.stream_of(res)), "s8 up")
+        assert torch.equal(s8, want_s8) and torch.equal(c4, want_c4)
+        assert torch.equal(out, want) if with_nchw else bool((out == 7.0).all())
