@@ -126,15 +126,17 @@ def eager_ratio(ms_per_step, batch):
     """Speed-up over the north star's denominator, "the reference single-GPU PyTorch forward": the restated eager graph on
     stock PyTorch-ROCm ops, measured on an MI355X by tools/eager_baseline.py and committed under profiles/ (the log
     beside it).  `vs_baseline` itself stays null: BASELINE.md holds no published number for this metric."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r02_eager_baseline.json")) as f:
-            e = json.load(f)
-        if int(e.get("batch", -1)) != batch:
-            return None
-        return {"speedup": e["forward_ms"] / ms_per_step, "eager_forward_ms": e["forward_ms"], "target": 5.0,
-                "source": "profiles/r02_eager_baseline.json (tools/eager_baseline.py on MI355X, batch %d)" % batch}
-    except (OSError, ValueError, KeyError):
-        return None
+    for name in ("r03_eager_baseline.json", "r02_eager_baseline.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                e = json.load(f)
+            if int(e.get("batch", -1)) != batch:
+                continue
+            return {"speedup": e["forward_ms"] / ms_per_step, "eager_forward_ms": e["forward_ms"], "target": 5.0,
+                    "source": "profiles/%s (tools/eager_baseline.py on MI355X, batch %d)" % (name, batch)}
+        except (OSError, ValueError, KeyError):
+            continue
+    return None
 
 
 def kernel_rooflines(dev, batch):
