@@ -33,7 +33,7 @@ def _pair(v):
 
 
 class InferenceEngine:
-    def __init__(self, model, batch: int, device, use_graph: bool | None = None):
+    def __init__(self, model, batch: int, device, use_graph: bool | None = None, stream_set: int = 0, inp=None, margin=None):
         device = torch.device(device)
         if device.type != "cuda" or not torch.cuda.is_available():
             raise RuntimeError("otpose_amd.OTPose runs on an MI355X through libotpose_hip.so; "
@@ -75,7 +75,9 @@ class InferenceEngine:
         # (640-960 workgroups on 512 resident slots) fill each other's tails
         self.multi_stream = os.environ.get("OTPOSE_STREAMS", "1") != "0"
         self._sid = 0
-        self._side = hip.side_streams(device, 3) if self.multi_stream else []      # process-wide pool (see hip.side_streams)
+        # process-wide pool (see hip.side_streams); stream_set > 0: the streams of another sub-batch of a PipelinedEngine
+        self._side = hip.side_streams(device, 3, 4 * stream_set) if self.multi_stream else []
+        self._given = (inp, margin)
         self.graph = None
         self.param_version = self._param_version()
         with torch.no_grad():
@@ -700,9 +702,11 @@ class InferenceEngine:
     def _build(self):
         m, B, J, h, w = self.model, self.B, self.J, self.h, self.w
         L, T = self.lib, self.h * self.w
-        self.inp = self.new(B, 3 * self.F, self.H_img, self.W_img)
-        self.margin = self.new(B, self.F - 1)
+        self.inp = self._given[0] if self._given[0] is not None else self.new(B, 3 * self.F, self.H_img, self.W_img)
+        self.margin = self._given[1] if self._given[1] is not None else self.new(B, self.F - 1)
+        assert tuple(self.inp.shape) == (B, 3 * self.F, self.H_img, self.W_img) and self.inp.is_contiguous()
         rough = self.hrnet(m.rough_pose_estimation_net, View(self.inp)).t
+        self.hr_end = len(self.ops)               # launches [0, hr_end) = the backbone, the rest = everything behind it
 
         total, squeezed, inter = self.new(B, J, h, w), self.new(B, J, h, w), self.new(B, J, h, w)
         flow_in = self.new(B, J, T)
@@ -811,10 +815,11 @@ class InferenceEngine:
                   dst.ctot, dst.coff)
 
     # ---------------------------------------------------------------------------------------------
-    def _launch_all(self):
+    def _launch_all(self, first=0, last=None):
+        """Enqueue launches [first, last) of the list on the current stream (and the side streams they were emitted on)."""
         main = hip.stream_of(self.inp)
         handles = [main] + [s_.cuda_stream for s_ in self._side]
-        for op, sid in self.ops:
+        for op, sid in self.ops[first:last]:
             self._stream = handles[sid] if sid > 0 else main
             op()
         self._stream = main

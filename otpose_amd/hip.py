@@ -251,8 +251,8 @@ def stream_of(t):
 _SIDE_STREAMS = {}            # device -> side streams shared by every inference engine and training graph of the process
 
 
-def side_streams(device, n):
-    """``n`` side streams of ``device`` from one process-wide pool (created on first use, never more than asked for).
+def side_streams(device, n, first=0):
+    """Side streams ``first`` .. ``first + n - 1`` of ``device`` from one process-wide pool (created on first use).
     The runtime multiplexes HIP streams onto a handful of hardware queues (four by default): an engine and a training graph
     that each created their own three would share queues and serialise branches that are meant to overlap (measured: the
     training step after two engines had been built ran 158 instead of 142 ms).  Engines and training steps of one process
@@ -262,7 +262,7 @@ def side_streams(device, n):
     if device.index is None:
         device = torch.device("cuda", torch.cuda.current_device())
     pool = _SIDE_STREAMS.setdefault(device, [])
-    while len(pool) < n:
+    while len(pool) < first + n:
         pool.append(torch.cuda.Stream(device))
-    return pool[:n]
+    return pool[first:first + n]
 
