@@ -37,8 +37,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int SBM = 256;                  // output pixels per workgroup (4 waves x 4 pixel tiles of 16)
-constexpr int SPLANE = 512 * 16;          // bytes of one (channel group, part) window plane: 512 records
-constexpr int SWIN = 4 * SPLANE;          // a chunk = 16 channels = 2 groups x (hi, lo)
+// 1 KB pieces of a chunk's packed weights: 4 full k-steps x NTW tiles x (hi, lo) + the half-filled fifth (512 bytes per fragment)
+__host__ __device__ constexpr int swch(int ntw) { return 8 * ntw + ntw; }
 constexpr int SKS = 5;                    // k-steps per chunk: 18 (tap, group) slots of 8 channels in 5 x 4 (2 zero-weight slots)
 constexpr int SOOB = -16;                 // buffer offset outside every descriptor: the load returns / writes zeros
 
@@ -48,27 +48,21 @@ uint32_t smagic(uint32_t d) { return d <= 1 ? 0u : (uint32_t)((1ull << 32) / d) 
 #ifdef OTP_CONVS_TIMING
 // development build only (tools/convs_timing.sh): per-workgroup phase stamps, never in libotpose_hip.so
 __device__ unsigned long long otp_convs_stamps[8192 * 32];
-__device__ unsigned long long otp_convs_pp_stamps[512 * 128];
-#define PSTAMP(ev)                                                                                   \
-    do {                                                                                              \
-        if (lane == 0 && wave == 0 && (ev) < 128) otp_convs_pp_stamps[((int)blockIdx.x * 2 + h) * 128 + (ev)] = __builtin_readcyclecounter(); \
-    } while (0)
 #define SSTAMP(slot)                                                                                  \
     do {                                                                                              \
         if (threadIdx.x == 0 && blockIdx.x < 8192) otp_convs_stamps[blockIdx.x * 32 + (slot)] = __builtin_readcyclecounter(); \
     } while (0)
 #else
 #define SSTAMP(slot)
-#define PSTAMP(ev)
 #endif
 
 struct SPlan {
     int N, C, H, W, HW, Cout, total;
     int out_ctot, out_coff, act, f32_mode;
     int NTW, nN, nTiles, nChunks, tpx;
-    int VR, W1, NIW;                      // virtual rows per image (H + 1), records per window row (W + 1), 64-record pieces per plane
+    int VR, W1, NIW, NV, pl;              // virtual rows per image (H + 1), records per window row (W + 1), 64-record pieces per plane,
+                                          // records / bytes of a window plane
     uint32_t mHW, mW, mW1, mVR;
-    int nItems, ipx, hs, rounds;          // persistent form: (tile, cout block) items, items per XCD, half-slots per XCD, rounds
 };
 
 // 8 floats -> bf16 hi / lo records
@@ -216,35 +210,55 @@ __global__ __launch_bounds__(256) void s8_unpack_kernel(const u32x4* __restrict_
     }
 }
 
-// output-channel row of an MFMA tile <-> channel of the tile: rows 4..7 and 8..11 trade places, so that the two lanes that
-// meet in v_permlane32_swap (kl and kl + 2: rows 4 kl + r and 4 (kl + 2) + r) hold 8 CONSECUTIVE channels between them
-__host__ __device__ constexpr int srow2ch(int row) { return ((row & 4) << 1) | ((row & 8) >> 1) | (row & 3); }
+// Output-channel row of an MFMA tile <-> channel.  A lane's accumulator registers of a tile are rows 4 kl .. 4 kl + 3 (kl =
+// lane / 16) of one pixel.  Cout tiles go in pairs (2 tp, 2 tp + 1): row 4 kl + r of the even tile is channel 8 kl + r of the
+// pair's 32, of the odd tile channel 8 kl + 4 + r - a lane then holds 8 CONSECUTIVE channels of its pixel = one S8 record
+// group, and the epilogue splits and stores them without any cross-lane traffic.  A tile without a partner (odd tile count, or
+// the partner past Cout) keeps the identity: 4 consecutive channels per lane, stored as half records.
+__host__ __device__ inline bool stile_paired(int co_blk, int t, int ntw, int Cout) {
+    const int tb = t | 1;
+    return tb < ntw && co_blk + 16 * tb < Cout;
+}
+__host__ __device__ inline int srow2ch(int co_blk, int t, int row, int ntw, int Cout) {
+    return stile_paired(co_blk, t, ntw, Cout) ? co_blk + 32 * (t >> 1) + 8 * (row >> 2) + 4 * (t & 1) + (row & 3)
+                                               : co_blk + 16 * t + row;
+}
 
 // packed weights of otp_conv3x3_s8: the image of otp_conv2d_x3_pack_weight (k = 3, stride 1) with the rows of every 16-row
 // tile in srow2ch order: [cout block][chunk][k-step][cout tile][hi, lo][lane][8] bf16, lane (i16, kl): row i16 of the tile =
-// channel 16 tile + srow2ch(i16), k-slot q = 4 s + kl -> tap q / 2, input channels 16 chunk + 8 (q % 2) .. + 7
+// channel srow2ch(block, tile, i16), k-slot q = 4 s + kl -> tap q / 2, input channels 16 chunk + 8 (q % 2) .. + 7; the fifth
+// k-step holds k-slots 16, 17 only (lanes 0 .. 31 of a fragment): [cout tile][hi, lo][32 lanes] - 9 NTW KB per chunk, not 10
 __global__ void s8_wpack_kernel(const float* __restrict__ w, const float* __restrict__ scale, u32x4* __restrict__ out, int Cout,
                                 int Cin, int NTW, int nN, int nChunks) {
     const int total = nN * nChunks * SKS * NTW * 64;
+    const int WU = swch(NTW) * 64;                                 // 16-byte units of one (cout block, chunk) image
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
         const int lane = idx & 63;
         int r = idx >> 6;
         const int t = r % NTW; r /= NTW;
         const int s = r % SKS; r /= SKS;
         const int chunk = r % nChunks, cb = r / nChunks;
-        const int cout = (cb * NTW + t) * 16 + srow2ch(lane & 15), kl = lane >> 4;
+        const int cout = srow2ch(cb * NTW * 16, t, lane & 15, NTW, Cout), kl = lane >> 4;
         const int q = 4 * s + kl, tap = q >> 1, ci0 = chunk * 16 + 8 * (q & 1);
+        if (tap > 8) continue;                                     // k-slots 18, 19: not stored (the kernel multiplies zeros there)
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int ci = ci0 + j;
-            v[j] = (tap < 9 && cout < Cout && ci < Cin) ? w[((size_t)cout * Cin + ci) * 9 + tap] * (scale ? scale[cout] : 1.f) : 0.f;
+            v[j] = (cout < Cout && ci < Cin) ? w[((size_t)cout * Cin + ci) * 9 + tap] * (scale ? scale[cout] : 1.f) : 0.f;
         }
         u32x4 hi, lo;
         ssplit8(v, hi, lo);
-        const size_t o = ((((size_t)(cb * nChunks + chunk) * SKS + s) * NTW + t) * 2) * 64 + lane;
-        out[o] = hi;
-        out[o + 64] = lo;
+        const size_t base = (size_t)(cb * nChunks + chunk) * WU;
+        if (s < SKS - 1) {
+            const size_t o = base + ((s * NTW + t) * 2) * 64 + lane;
+            out[o] = hi;
+            out[o + 64] = lo;
+        } else {
+            const size_t o = base + (SKS - 1) * NTW * 128 + t * 64 + lane;   // lanes 0 .. 31: hi, then lo, 512 bytes each
+            out[o] = hi;
+            out[o + 32] = lo;
+        }
     }
 }
 
@@ -279,23 +293,25 @@ __device__ __forceinline__ void sblock_sched() {
 // residual / fp32 output layouts of otp_conv3x3_s8
 enum { S_F32_NONE = 0, S_F32_C4 = 1, S_F32_NCHW = 2 };
 
-template <int NTW>
-__global__ __launch_bounds__(256, 2) void convs_kernel(const unsigned char* __restrict__ xs, const u32x4* __restrict__ wpk,
+template <int NTW, bool NCHW>
+__global__ __launch_bounds__(256, NCHW ? 2 : 3) void convs_kernel(const unsigned char* __restrict__ xs, const u32x4* __restrict__ wpk,
                                                         const float* __restrict__ shift, const float* res, float* outf,
                                                         u32x4* outs, const SPlan P) {
-    constexpr int WCH = SKS * NTW * 2;                             // 1 KB pieces of a chunk's weights
+    constexpr int NPT = 4;                                         // pixel tiles of 16 per wave
+    constexpr int BM = SBM;
+    constexpr int WCH = swch(NTW);                                 // 1 KB pieces of a chunk's weights
     constexpr int WBYTES = WCH * 1024;
-    constexpr int NBLK = SKS * 4;                                  // (k-step, pixel tile) blocks of a chunk: 3 NTW MFMAs each
+    constexpr int NBLK = SKS * NPT;                                // (k-step, pixel tile) blocks of a chunk: 3 NTW MFMAs each
     constexpr int NM = 3 * NTW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* win = smem;
-    unsigned char* wl = smem + SWIN;
+    const int PL = P.pl;                                           // bytes between the planes of the window (no padding: three
+    unsigned char* win = smem;                                     // workgroups of 4 planes + 27 KB of weights share a CU's 160 KB)
+    unsigned char* wl = smem + 4 * PL;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i16 = lane & 15, kl = lane >> 4;
-    // lane (i16, kl) of pixel tile p: pixel m = (4 wave + p) 16 + i16 of the tile; accumulator register r of cout tile t =
-    // channel co_blk + 16 t + 4 pk + r of that pixel, pk = srow2ch(4 kl) / 4 (the row permutation of the packed weights)
-    const int pk = ((kl & 1) << 1) | (kl >> 1);
+    // lane (i16, kl) of pixel tile p: pixel m = (NPT wave + p) 16 + i16 of the tile; accumulator register r of cout tile t =
+    // channel ch0[t] + r of that pixel (srow2ch: the row permutation of the packed weights)
     const bool upper = kl >= 2;
 
     // workgroup -> (pixel tile, output-channel block); XCD x (block id mod 8) walks a contiguous tile range, the blocks of a
@@ -308,19 +324,23 @@ __global__ __launch_bounds__(256, 2) void convs_kernel(const unsigned char* __re
 #ifdef OTP_CONVS_TIMING
     if (threadIdx.x == 0 && blockIdx.x < 8192) otp_convs_stamps[blockIdx.x * 32 + 30] = __builtin_amdgcn_s_memrealtime();
 #endif
-    const int P0 = tile * SBM;
+    const int P0 = tile * BM;
     const int n0 = P0 / P.HW, p0 = P0 - n0 * P.HW;            // (uniform, once per workgroup)
     const int y0 = (int)sdiv((uint32_t)p0, P.mW);
+    const int x0 = p0 - y0 * P.W;                                  // the window starts at the first record any tap reads: (row above, x0 - 1)
     const int Vf = n0 * P.VR + y0;                                 // first virtual row of the window (one above the first pixel's)
     const int imgB = P.C * P.HW * 4;                               // bytes of one image of the S8 tensor
     const int co_blk = cb * NTW * 16;
-    const int C4o = P.Cout >> 2, Go = P.Cout >> 3;
+    const int C4o = P.Cout >> 2;
 
     // ---- window pieces of this wave: piece k = wave + 4 j covers window records 64 k .. 64 k + 63 ------------------------------
+    // window record w <-> record x0 + w of the row-major frame (virtual row r, column cp): r = (x0 + w) / (W + 1)
     int voff[2];
-#pragma unroll
+    bool vlive[2];                                                 // the last piece of a plane is partial: lanes past the plane's
+#pragma unroll                                                     // last record stay out of the DMA (they would write the next plane)
     for (int j = 0; j < 2; ++j) {
-        const int v = 64 * (wave + 4 * j) + lane;
+        vlive[j] = 64 * (wave + 4 * j) + lane < P.NV;
+        const int v = 64 * (wave + 4 * j) + lane + x0;
         const int r = (int)sdiv((uint32_t)v, P.mW1), cp = v - r * P.W1;
         const int V = Vf + r;
         const int n = (int)sdiv((uint32_t)V, P.mVR), yy = V - n * P.VR;
@@ -340,8 +360,8 @@ __global__ __launch_bounds__(256, 2) void convs_kernel(const unsigned char* __re
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int k = wave + 4 * j;
-                if (k < P.NIW)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(win + pl * SPLANE + k * 1024),
+                if (k < P.NIW && vlive[j])
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(win + pl * PL + k * 1024),
                                                              16, voff[j], so, 0, 0);
             }
         }
@@ -357,56 +377,60 @@ __global__ __launch_bounds__(256, 2) void convs_kernel(const unsigned char* __re
     stage(0);
     SSTAMP(1);
 
-    // ---- per pixel tile: fragment addresses of the chunk's 20 blocks, lane offsets into the output / residual images ---------
+    // ---- per pixel tile: fragment address, lane offsets into the output / residual images; accumulators start from
+    //      residual + shift (loaded while the first chunk's DMA is in flight: no registers of their own, no epilogue add) -----
     const size_t obytes = (size_t)P.N * P.Cout * P.HW * 4;         // C4 and S8 images of the (N, Cout, H, W) result / residual
     const otp_rsrc rres = make_rsrc32(res ? res : reinterpret_cast<const float*>(xs), res ? (unsigned)obytes : 0u);
     const otp_rsrc rs8 = make_rsrc32(outs, outs ? (unsigned)obytes : 0u);
     const otp_rsrc rof = make_rsrc32(outf, !outf ? 0u : (P.f32_mode == S_F32_C4 ? (unsigned)obytes
                                                                                : (unsigned)((size_t)P.N * P.out_ctot * P.HW * 4)));
     const otp_rsrc rsh = make_rsrc32(shift ? shift : reinterpret_cast<const float*>(xs), shift ? (unsigned)(P.Cout * 4) : 0u);
-    int baddr[NBLK], offC[4], offS[4];
-    f32x4 acc[NTW][4], rv[NTW][4], sh[NTW];
+    // (NCHW = false: the fp32 output, if any, is a C4 image, whose pixel offsets equal the S8 image's: Cout / 4 = 2 Cout / 8)
+    int pb[NPT], toff[SKS], offN[NCHW ? NPT : 1], offS[NPT], ch0[NTW];
+    f32x4 acc[NTW][NPT];
     {
-        int toff[SKS];
 #pragma unroll
         for (int s = 0; s < SKS; ++s) {
             const int q = 4 * s + kl;
             int tap = q >> 1;
             if (tap > 8) tap = 8;                                  // zero weights: any finite data
             const int dy = tap / 3, dx = tap - dy * 3;
-            toff[s] = (dy * P.W1 + dx) * 16 + (q & 1) * (2 * SPLANE);
+            toff[s] = (dy * P.W1 + dx - x0) * 16 + (q & 1) * (2 * PL);
+        }
+        f32x4 sh[NTW];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            ch0[t] = srow2ch(co_blk, t, 4 * kl, NTW, P.Cout);      // (a channel past Cout for tiles past it: never loaded / stored)
+            sh[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsh, co_blk + 16 * t < P.Cout ? ch0[t] * 4 : SOOB, 0, 0));
         }
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            int m = (wave * 4 + p) * 16 + i16;
+        for (int p = 0; p < NPT; ++p) {
+            int m = (wave * NPT + p) * 16 + i16;
             const bool pv = P0 + m < P.total;
             if (!pv) m = P.total - 1 - P0;                         // tail tile: a finite address, the result is dropped
             const int q = p0 + m;
             const int dn = (int)sdiv((uint32_t)q, P.mHW), pi = q - dn * P.HW;
             const int y = (int)sdiv((uint32_t)pi, P.mW), x = pi - y * P.W;
-            const int pb = (((n0 + dn) * P.VR + y - Vf) * P.W1 + x) * 16;   // record of tap (0, 0): one row up, one column left
-#pragma unroll
-            for (int s = 0; s < SKS; ++s) baddr[s * 4 + p] = pb + toff[s];
+            pb[p] = (((n0 + dn) * P.VR + y - Vf) * P.W1 + x) * 16;   // record of tap (0, 0): one row up, one column left (+ x0)
             const int img = n0 + dn;
-            // C4 image: ((img C4o + c4) HW + pi) 16 bytes, c4 = (co_blk + 16 t) / 4 + pk: lane part here, tile part a scalar offset
-            const int c4o = (img * C4o * P.HW + pk * P.HW + pi) * 16;
-            const int nchw = ((img * P.out_ctot + P.out_coff + 4 * pk) * P.HW + pi) * 4;
-            offC[p] = pv ? (P.f32_mode == S_F32_NCHW ? nchw : c4o) : SOOB;
-            // S8 image: (((img Go + g) 2 + part) HW + pi) 16 bytes, g = 2 (co_blk / 16 + tile) + (kl & 1); upper lanes store tile tb
-            offS[p] = pv ? (img * Go * 2 * P.HW + (kl & 1) * 2 * P.HW + (upper ? 4 * P.HW : 0) + pi) * 16 : SOOB;
-            // residual (C4 image) and shift: loaded now, added in the epilogue (out-of-range offsets read zeros)
+            // pixel part of the byte offsets; the channel part (ch0[t]) is added where it is used
+            //   C4 image   ((img C4o + ch / 4) HW + pi) 16          NCHW slice ((img ctot + coff + ch) HW + pi) 4
+            //   S8 image   (((img Go + ch / 8) 2 + part) HW + pi) 16
+            const int c4o = (img * C4o * P.HW + pi) * 16;
+            if (NCHW) offN[NCHW ? p : 0] = pv ? ((img * P.out_ctot + P.out_coff) * P.HW + pi) * 4 : SOOB;
+            offS[p] = pv ? c4o : SOOB;
+            // residual (C4 image; out-of-range offsets read zeros) + shift
 #pragma unroll
             for (int t = 0; t < NTW; ++t) {
                 const bool tv = co_blk + 16 * t < P.Cout;
-                rv[t][p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, (pv && tv) ? c4o : SOOB,
-                                                                                          ((co_blk >> 2) + 4 * t) * P.HW * 16, 0));
-                acc[t][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                acc[t][p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    rres, (pv && tv) ? c4o + (ch0[t] >> 2) * P.HW * 16 : SOOB, 0, 0));
             }
         }
 #pragma unroll
         for (int t = 0; t < NTW; ++t)
-            sh[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsh, co_blk + 16 * t < P.Cout ? 16 * pk : SOOB,
-                                                                                   (co_blk + 16 * t) * 4, 0));
+#pragma unroll
+            for (int p = 0; p < NPT; ++p) acc[t][p] += sh[t];
     }
 
     // One chunk: NBLK blocks of 3 NTW MFMAs.  B fragments are read two blocks ahead (ring of three), the weight fragments of
@@ -417,23 +441,33 @@ __global__ __launch_bounds__(256, 2) void convs_kernel(const unsigned char* __re
         auto load_a = [&](int buf, int s) __attribute__((always_inline)) {
 #pragma unroll
             for (int t = 0; t < NTW; ++t) {
-                const unsigned char* a = wl + ((s * NTW + t) * 2) * 1024 + lane * 16;
-                ah[buf][t] = *reinterpret_cast<const bf16x8*>(a);
-                al[buf][t] = *reinterpret_cast<const bf16x8*>(a + 1024);
+                if (s < SKS - 1) {
+                    const unsigned char* a = wl + ((s * NTW + t) * 2) * 1024 + lane * 16;
+                    ah[buf][t] = *reinterpret_cast<const bf16x8*>(a);
+                    al[buf][t] = *reinterpret_cast<const bf16x8*>(a + 1024);
+                } else {
+                    // last k-step: k-slots 16, 17 (tap 8) on the lanes kl = 0, 1; kl = 2, 3 (tap 9) multiply zeros - their half of
+                    // the fragment is not stored (512-byte half pieces behind the full ones)
+                    const unsigned char* a = wl + (SKS - 1) * NTW * 2048 + t * 1024 + (lane & 31) * 16;
+                    const bf16x8 h = *reinterpret_cast<const bf16x8*>(a), l = *reinterpret_cast<const bf16x8*>(a + 512);
+                    const bf16x8 z = __builtin_bit_cast(bf16x8, (u32x4){0u, 0u, 0u, 0u});
+                    ah[buf][t] = upper ? z : h;
+                    al[buf][t] = upper ? z : l;
+                }
             }
         };
         auto load_b = [&](int buf, int blk) __attribute__((always_inline)) {
-            const unsigned char* b = win + baddr[blk];
+            const unsigned char* b = win + (pb[blk % NPT] + toff[blk / NPT]);
             bh[buf] = *reinterpret_cast<const bf16x8*>(b);
-            bl[buf] = *reinterpret_cast<const bf16x8*>(b + SPLANE);
+            bl[buf] = *reinterpret_cast<const bf16x8*>(b + PL);
         };
         load_a(0, 0);
         load_b(0, 0);
         load_b(1, 1);
 #pragma unroll
         for (int blk = 0; blk < NBLK; ++blk) {
-            const int s = blk >> 2, p = blk & 3, cur = blk % 3, sa = s & 1;
-            const bool nb = blk + 2 < NBLK, na = p == 2 && s + 1 < SKS;
+            const int s = blk / NPT, p = blk % NPT, cur = blk % 3, sa = s & 1;
+            const bool nb = blk + 2 < NBLK, na = p == NPT - 2 && s + 1 < SKS;
             if (nb) load_b((blk + 2) % 3, blk + 2);
             if (na) load_a(sa ^ 1, s + 1);
 #pragma unroll
@@ -465,64 +499,78 @@ __global__ __launch_bounds__(256, 2) void convs_kernel(const unsigned char* __re
     }
     SSTAMP(16);
 
-    // ---- epilogue: no LDS, no barrier - every lane stores what its accumulators hold --------------------------------------------
+    // ---- epilogue: no LDS, no barrier, no cross-lane traffic - every lane stores what its accumulators hold ---------------------
+    // All arithmetic first, all stores last: no register a store reads is written again before the wave ends (the S8 records of
+    // one pixel tile used to be rebuilt in the registers the previous tile's stores were still reading - results then changed
+    // with the load on the memory pipeline, i.e. with who else was resident on the CU).
+    if (P.act == OTP_ACT_RELU) {
 #pragma unroll
-    for (int t = 0; t < NTW; ++t)
+        for (int t = 0; t < NTW; ++t)
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            acc[t][p] += sh[t] + rv[t][p];
-            if (P.act == OTP_ACT_RELU) {
+            for (int p = 0; p < NPT; ++p)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[t][p][r] = fmaxf(acc[t][p][r], 0.f);
+    }
+    // S8 records straight from the accumulators: a lane's registers of a tile PAIR are 8 consecutive channels of its pixel
+    // (srow2ch) - split, one hi and one lo record per (pair, pixel tile); a tile without a partner gives 4 consecutive channels
+    // = the lower or upper half of a record, stored as 8 bytes (the lane 16 away writes the other half)
+    u32x4 rec[(NTW + 1) / 2][NPT][2];
+    if (outs) {
+#pragma unroll
+        for (int t = 0; t < NTW; t += 2) {
+            const bool paired = stile_paired(co_blk, t, NTW, P.Cout);       // (uniform)
+            const int t1 = t + 1 < NTW ? t + 1 : t;
+#pragma unroll
+            for (int p = 0; p < NPT; ++p) {
+                const float f[8] = {acc[t][p][0], acc[t][p][1], acc[t][p][2], acc[t][p][3],
+                                    paired ? acc[t1][p][0] : 0.f, paired ? acc[t1][p][1] : 0.f,
+                                    paired ? acc[t1][p][2] : 0.f, paired ? acc[t1][p][3] : 0.f};
+                ssplit8(f, rec[t >> 1][p][0], rec[t >> 1][p][1]);
             }
         }
-    if (P.f32_mode == S_F32_C4) {
+    }
+    SSTAMP(17);
+    if (!NCHW && P.f32_mode == S_F32_C4) {
         // [N][Cout/4][H*W][4]: one float4 per (cout tile, pixel tile); the 16 lanes of a row write 256 contiguous bytes
 #pragma unroll
         for (int t = 0; t < NTW; ++t)
 #pragma unroll
-            for (int p = 0; p < 4; ++p)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[t][p]), rof, co_blk + 16 * t < P.Cout ? offC[p] : SOOB,
-                                                       ((co_blk >> 2) + 4 * t) * P.HW * 16, 0);
-    } else if (P.f32_mode == S_F32_NCHW) {
+            for (int p = 0; p < NPT; ++p)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[t][p]), rof,
+                                                       (co_blk + 16 * t < P.Cout && offS[p] != SOOB) ? offS[p] + (ch0[t] >> 2) * P.HW * 16 : SOOB,
+                                                       0, 0);
+    } else if (NCHW) {
         // channel slice of an NCHW tensor (the tensor a fuse layer / another kernel family reads): 4 planes per lane
 #pragma unroll
         for (int t = 0; t < NTW; ++t)
 #pragma unroll
-            for (int p = 0; p < 4; ++p)
+            for (int p = 0; p < NPT; ++p)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(acc[t][p][r]), rof, co_blk + 16 * t < P.Cout ? offC[p] : SOOB,
-                                                          (co_blk + 16 * t + r) * P.HW * 4, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(acc[t][p][r]), rof,
+                                                          (co_blk + 16 * t < P.Cout && offN[NCHW ? p : 0] != SOOB) ? offN[NCHW ? p : 0] + ch0[t] * P.HW * 4 : SOOB,
+                                                          r * P.HW * 4, 0);
     }
-    SSTAMP(17);
     if (outs) {
-        // S8 records: lanes kl and kl + 2 (l and l + 32) hold rows 4 kl + r and 4 (kl + 2) + r = channels 8 b .. 8 b + 7 of the tile
-        // (b = kl & 1, srow2ch).  For a pair of cout tiles (ta, tb) the lower half of the wave assembles tile ta's eight channels
-        // and the upper half tile tb's; each lane splits its eight values and stores one hi and one lo record.
 #pragma unroll
-        for (int tp = 0; tp < (NTW + 1) / 2; ++tp) {
-            const int ta = 2 * tp, tb = (2 * tp + 1 < NTW) ? 2 * tp + 1 : 2 * tp;
-            const bool tav = co_blk + 16 * ta < P.Cout;
-            const bool pair = ta != tb && co_blk + 16 * tb < P.Cout;
-            const int so = (((co_blk >> 4) + ta) * 4) * P.HW * 16;     // group 2 (co_blk / 16 + ta), part 0
+        for (int t = 0; t < NTW; t += 2) {
+            const bool tav = co_blk + 16 * t < P.Cout;
+            const int so = (ch0[t] >> 3) * 2 * P.HW * 16;           // record group of the lane's channels, part 0
+            if (stile_paired(co_blk, t, NTW, P.Cout)) {
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                float f[8];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    // lanes l and l + 32 trade one value: the lower lane needs the upper one's rows of tile ta (channels 8 b + 4 + r),
-                    // the upper lane the lower one's rows of tile tb (channels 8 b + r)
-                    const float a = acc[ta][p][r], b = acc[tb][p][r];
-                    const float got = __shfl_xor(upper ? a : b, 32, 64);
-                    f[r] = upper ? got : a;
-                    f[4 + r] = upper ? b : got;
+                for (int p = 0; p < NPT; ++p) {
+                    const int o = offS[p] != SOOB ? offS[p] + so : SOOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(rec[t >> 1][p][0], rs8, o, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(rec[t >> 1][p][1], rs8, o, P.HW * 16, 0);
                 }
-                u32x4 hi, lo;
-                ssplit8(f, hi, lo);
-                const int o = (tav && (pair || !upper)) ? offS[p] : SOOB;   // a lone last tile: the lower half of the wave stores it
-                __builtin_amdgcn_raw_buffer_store_b128(hi, rs8, o, so, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(lo, rs8, o, so + P.HW * 16, 0);
+            } else {
+                const int half = (ch0[t] >> 2) & 1;
+#pragma unroll
+                for (int p = 0; p < NPT; ++p) {
+                    const int o = (tav && offS[p] != SOOB) ? offS[p] + so + 8 * half : SOOB;
+                    __builtin_amdgcn_raw_buffer_store_b64((u32x2){rec[t >> 1][p][0][0], rec[t >> 1][p][0][1]}, rs8, o, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64((u32x2){rec[t >> 1][p][1][0], rec[t >> 1][p][1][1]}, rs8, o, P.HW * 16, 0);
+                }
             }
         }
     }
@@ -530,330 +578,6 @@ __global__ __launch_bounds__(256, 2) void convs_kernel(const unsigned char* __re
 #ifdef OTP_CONVS_TIMING
     if (threadIdx.x == 0 && blockIdx.x < 8192) otp_convs_stamps[blockIdx.x * 32 + 31] = __builtin_amdgcn_s_memrealtime();
 #endif
-}
-
-// ---- persistent double-buffered form ------------------------------------------------------------------------------------------------
-// One 8-wave workgroup per CU walks (pixel tile, cout block) items; every wave owns two of the tile's sixteen pixel tiles
-// and all NTW cout tiles.  LDS holds TWO (window + weight chunk) buffers: the DMA of chunk g + 1 - the next chunk of the item or
-// the first chunk of the NEXT item - is issued before the MFMAs of chunk g and has that whole phase to land; one barrier per
-// chunk.  Two waves per SIMD multiply at the same time (16.3 cycles per MFMA per SIMD with the block schedule below); an
-// item's stores leave straight from the accumulators and are never waited for: the wait in front of the barrier is a counted
-// vmcnt that lets exactly those stores stay in flight under the next item's MFMAs.  The residual is loaded into registers of
-// its own at the item's first chunk and added in the epilogue.
-template <int N>
-__device__ __forceinline__ void swait_barrier() {
-    // (inline asm: __syncthreads() would wait for vmcnt(0) whenever an LDS-DMA is pending)
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
-}
-
-template <int NTW>
-__global__ __launch_bounds__(512, 2) void convs_db_kernel(const unsigned char* __restrict__ xs, const u32x4* __restrict__ wpk,
-                                                           const float* __restrict__ shift, const float* res, float* outf,
-                                                           u32x4* outs, const SPlan P) {
-    constexpr int WCH = SKS * NTW * 2;                             // 1 KB pieces of a chunk's weights
-    constexpr int WBYTES = WCH * 1024;
-    constexpr int REGION = SWIN + WBYTES;
-    constexpr int NBLK = SKS * 2;                                  // (k-step, pixel tile) blocks of a chunk: 3 NTW MFMAs each
-    constexpr int NM = 3 * NTW;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // 0 .. 7
-    const int i16 = lane & 15, kl = lane >> 4;
-    const int pk = ((kl & 1) << 1) | (kl >> 1);
-    const bool upper = kl >= 2;
-    const int xcd = (int)blockIdx.x & 7, u = (int)blockIdx.x >> 3;
-    const int imgB = P.C * P.HW * 4;
-    const int C4o = P.Cout >> 2, Go = P.Cout >> 3;
-    const otp_rsrc rw = make_rsrc32(wpk, (unsigned)((size_t)P.nN * P.nChunks * WBYTES));
-    const size_t obytes = (size_t)P.N * P.Cout * P.HW * 4;         // C4 and S8 images of the (N, Cout, H, W) result / residual
-    const otp_rsrc rres = make_rsrc32(res ? res : reinterpret_cast<const float*>(xs), res ? (unsigned)obytes : 0u);
-    const otp_rsrc rs8 = make_rsrc32(outs, outs ? (unsigned)obytes : 0u);
-    const otp_rsrc rof = make_rsrc32(outf, !outf ? 0u : (P.f32_mode == S_F32_C4 ? (unsigned)obytes
-                                                                               : (unsigned)((size_t)P.N * P.out_ctot * P.HW * 4)));
-    const otp_rsrc rsh = make_rsrc32(shift ? shift : reinterpret_cast<const float*>(xs), shift ? (unsigned)(P.Cout * 4) : 0u);
-    const int woff = lane * 16;
-
-    int toff[SKS];
-#pragma unroll
-    for (int s = 0; s < SKS; ++s) {
-        const int q = 4 * s + kl;
-        int tap = q >> 1;
-        if (tap > 8) tap = 8;
-        const int dy = tap / 3, dx = tap - dy * 3;
-        toff[s] = (dy * P.W1 + dx) * 16 + (q & 1) * (2 * SPLANE);
-    }
-
-    // ---- item state: "N" = the next item (its first chunk is staged under the current item's last), plain = the current one ---------
-    bool validN = false;
-    int cbN = 0, P0N = 0, n0N = 0, p0N = 0, VfN = 0, voffN = SOOB;
-    otp_rsrc rinN = make_rsrc32(xs, 0);
-    auto decode = [&](int round) __attribute__((always_inline)) {
-        const int local = round * P.hs + u;
-        const int item = xcd * P.ipx + local;
-        validN = round < P.rounds && local < P.ipx && item < P.nItems;
-        const int it = validN ? item : 0;
-        const int tile = it / P.nN;
-        cbN = it - tile * P.nN;
-        P0N = tile * SBM;
-        n0N = P0N / P.HW;
-        p0N = P0N - n0N * P.HW;
-        const int y0 = (int)sdiv((uint32_t)p0N, P.mW);
-        VfN = n0N * P.VR + y0;
-        const int v = 64 * wave + lane;                            // window piece `wave` of every plane
-        const int r = (int)sdiv((uint32_t)v, P.mW1), cp = v - r * P.W1;
-        const int V = VfN + r;
-        const int n = (int)sdiv((uint32_t)V, P.mVR), yy = V - n * P.VR;
-        const bool ok = cp >= 1 && yy >= 1 && n < P.N;
-        voffN = ok ? (n - n0N) * imgB + ((yy - 1) * P.W + cp - 1) * 16 : SOOB;
-        const size_t left = (size_t)(P.N - n0N) * imgB;
-        rinN = make_rsrc32(xs + (size_t)n0N * imgB, left > 0x7fffff00ull ? 0x7fffff00u : (unsigned)left);
-    };
-    bool valid = false;
-    int cb = 0, voff = SOOB;
-    otp_rsrc rin = rinN;
-    // DMA of chunk c of an item into buffer `buf`: <= 4 window pieces + <= 4 weight pieces per wave
-    auto stage = [&](int buf, int c, const otp_rsrc& r_in, int vo, int cblk) __attribute__((always_inline)) {
-        unsigned char* win = smem + buf * REGION;
-        if (wave < P.NIW) {
-#pragma unroll
-            for (int pl = 0; pl < 4; ++pl) {
-                const int so = (((2 * c + (pl >> 1)) * 2 + (pl & 1)) * P.HW) * 16;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(r_in, (__attribute__((address_space(3))) void*)(win + pl * SPLANE + wave * 1024),
-                                                         16, vo, so, 0, 0);
-            }
-        }
-        const int wb = (cblk * P.nChunks + c) * WBYTES;
-#pragma unroll
-        for (int j = 0; j < (WCH + 7) / 8; ++j) {
-            const int k = wave + 8 * j;
-            if (k < WCH)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(win + SWIN + k * 1024), 16, woff,
-                                                         wb + k * 1024, 0, 0);
-        }
-    };
-
-    // what the MFMA phase stages into the OTHER buffer while it multiplies: one DMA piece after each of its first 8 blocks
-    // (the CU's address unit takes ~16 cycles per 1 KB piece: 62 pieces issued back to back by 8 waves held every wave for
-    // ~1 k cycles in front of its MFMAs; spread out, they ride under the other wave of the SIMD)
-    bool st_on = false;
-    int st_c = 0, st_vo = SOOB, st_cb = 0;
-    otp_rsrc st_rin = rinN;
-    int baddr[NBLK];                                               // B fragment addresses of the chunk's blocks (within a buffer)
-    int offC[2], offS[2], offR[2];                                 // lane byte offsets into the C4 (or NCHW) output / S8 output / C4 residual
-    f32x4 acc[NTW][2], rv[NTW][2], sh[NTW];
-    auto adopt = [&]() __attribute__((always_inline)) {
-        valid = validN;
-        cb = cbN;
-        voff = voffN;
-        rin = rinN;
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            int m = (wave * 2 + p) * 16 + i16;
-            const bool pv = valid && P0N + m < P.total;
-            if (P0N + m >= P.total) m = P.total - 1 - P0N;
-            const int q = p0N + m;
-            const int dn = (int)sdiv((uint32_t)q, P.mHW), pi = q - dn * P.HW;
-            const int y = (int)sdiv((uint32_t)pi, P.mW), x = pi - y * P.W;
-            const int pb = (((n0N + dn) * P.VR + y - VfN) * P.W1 + x) * 16;
-#pragma unroll
-            for (int s = 0; s < SKS; ++s) baddr[s * 2 + p] = pb + toff[s];
-            const int img = n0N + dn;
-            // C4 image: ((img C4o + c4) HW + pi) 16 bytes, c4 = (co_blk + 16 t) / 4 + pk: lane part here, tile part a scalar offset
-            const int c4o = (img * C4o * P.HW + pk * P.HW + pi) * 16;
-            const int nchw = ((img * P.out_ctot + P.out_coff + 4 * pk) * P.HW + pi) * 4;
-            offC[p] = pv ? (P.f32_mode == S_F32_NCHW ? nchw : c4o) : SOOB;
-            offR[p] = pv ? c4o : SOOB;
-            // S8 image: (((img Go + g) 2 + part) HW + pi) 16 bytes, g = 2 (co_blk / 16 + tile) + (kl & 1); upper lanes store tile tb
-            offS[p] = pv ? (img * Go * 2 * P.HW + (kl & 1) * 2 * P.HW + (upper ? 4 * P.HW : 0) + pi) * 16 : SOOB;
-#pragma unroll
-            for (int t = 0; t < NTW; ++t) acc[t][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-    };
-    // residual (C4) + shift of the current item: issued at its first chunk, consumed in its epilogue
-    auto load_res = [&]() __attribute__((always_inline)) {
-        const int co_blk = cb * NTW * 16;
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) {
-            const bool tv = co_blk + 16 * t < P.Cout;
-            sh[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsh, tv ? 16 * pk : SOOB, (co_blk + 16 * t) * 4, 0));
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const int ro = tv ? offR[p] : SOOB;
-                rv[t][p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, ro, ((co_blk >> 2) + 4 * t) * P.HW * 16, 0));
-            }
-        }
-    };
-
-    // One chunk: NBLK blocks of 3 NTW MFMAs.  B fragments are read two blocks ahead (ring of three), the weight fragments of
-    // the next k-step one step ahead, the reads spread between the MFMAs (tools/micro/mfma_loop.hip).
-    auto mfma_phase = [&](int buf) __attribute__((always_inline)) {
-        const unsigned char* win = smem + buf * REGION;
-        const unsigned char* wl = win + SWIN + lane * 16;
-        bf16x8 ah[2][NTW], al[2][NTW], bh[3], bl[3];
-        auto load_a = [&](int b2, int s) __attribute__((always_inline)) {
-#pragma unroll
-            for (int t = 0; t < NTW; ++t) {
-                const unsigned char* a = wl + ((s * NTW + t) * 2) * 1024;
-                ah[b2][t] = *reinterpret_cast<const bf16x8*>(a);
-                al[b2][t] = *reinterpret_cast<const bf16x8*>(a + 1024);
-            }
-        };
-        auto load_b = [&](int b3, int blk) __attribute__((always_inline)) {
-            const unsigned char* b = win + baddr[blk];
-            bh[b3] = *reinterpret_cast<const bf16x8*>(b);
-            bl[b3] = *reinterpret_cast<const bf16x8*>(b + SPLANE);
-        };
-        unsigned char* dst = smem + (buf ^ 1) * REGION;
-        const int wbn = (st_cb * P.nChunks + st_c) * WBYTES;
-        auto dma_piece = [&](int j) __attribute__((always_inline)) {
-            if (j < 4) {
-                if (st_on && wave < P.NIW)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(st_rin, (__attribute__((address_space(3))) void*)(dst + j * SPLANE + wave * 1024), 16,
-                                                             st_vo, (((2 * st_c + (j >> 1)) * 2 + (j & 1)) * P.HW) * 16, 0, 0);
-            } else {
-                const int k = wave + 8 * (j - 4);
-                if (st_on && k < WCH)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(dst + SWIN + k * 1024), 16, woff,
-                                                             wbn + k * 1024, 0, 0);
-            }
-        };
-        load_a(0, 0);
-        load_b(0, 0);
-        load_b(1, 1);
-#pragma unroll
-        for (int blk = 0; blk < NBLK; ++blk) {
-            const int s = blk >> 1, p = blk & 1, cur = blk % 3, sa = s & 1;
-            const bool nb = blk + 2 < NBLK, na = p == 0 && s + 1 < SKS;
-            if (nb) load_b((blk + 2) % 3, blk + 2);
-            if (na) load_a(sa ^ 1, s + 1);
-#pragma unroll
-            for (int t = 0; t < NTW; ++t) {
-                acc[t][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[sa][t], bh[cur], acc[t][p], 0, 0, 0);
-                acc[t][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[sa][t], bl[cur], acc[t][p], 0, 0, 0);
-                acc[t][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[sa][t], bh[cur], acc[t][p], 0, 0, 0);
-            }
-            if (!nb && !na) sblock_sched<NM, 0>();
-            else if (nb && na) sblock_sched<NM, 2 + 2 * NTW>();
-            else if (na) sblock_sched<NM, 2 * NTW>();
-            else sblock_sched<NM, 2>();
-            __builtin_amdgcn_sched_barrier(0);
-            // three pieces after each of the first blocks: everything is on its way within the first third of the phase
-            if (3 * blk < 4 + (WCH + 7) / 8) {
-#pragma unroll
-                for (int j = 3 * blk; j < 3 * blk + 3 && j < 4 + (WCH + 7) / 8; ++j) dma_piece(j);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    };
-
-    // stores of the finished item, straight from the accumulators; returns nothing, waits for nothing
-    auto epilogue = [&]() __attribute__((always_inline)) {
-        const int co_blk = cb * NTW * 16;
-#pragma unroll
-        for (int t = 0; t < NTW; ++t)
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                acc[t][p] += sh[t] + rv[t][p];                     // (zeros where there is no shift / residual: out-of-range loads)
-                if (P.act == OTP_ACT_RELU) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[t][p][r] = fmaxf(acc[t][p][r], 0.f);
-                }
-            }
-        if (P.f32_mode == S_F32_C4) {
-#pragma unroll
-            for (int t = 0; t < NTW; ++t)
-#pragma unroll
-                for (int p = 0; p < 2; ++p)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[t][p]), rof,
-                                                           co_blk + 16 * t < P.Cout ? offC[p] : SOOB,
-                                                           ((co_blk >> 2) + 4 * t) * P.HW * 16, 0);
-        } else if (P.f32_mode == S_F32_NCHW) {
-#pragma unroll
-            for (int t = 0; t < NTW; ++t)
-#pragma unroll
-                for (int p = 0; p < 2; ++p)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(acc[t][p][r]), rof,
-                                                              co_blk + 16 * t < P.Cout ? offC[p] : SOOB,
-                                                              (co_blk + 16 * t + r) * P.HW * 4, 0);
-        }
-        if (outs) {
-#pragma unroll
-            for (int tp = 0; tp < (NTW + 1) / 2; ++tp) {
-                const int ta = 2 * tp, tb = (2 * tp + 1 < NTW) ? 2 * tp + 1 : 2 * tp;
-                const bool tav = co_blk + 16 * ta < P.Cout;
-                const bool pair = ta != tb && co_blk + 16 * tb < P.Cout;
-                const int so = (((co_blk >> 4) + ta) * 4) * P.HW * 16;     // group 2 (co_blk / 16 + ta), part 0
-#pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    float f[8];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float a = acc[ta][p][r], b = acc[tb][p][r];
-                        const float got = __shfl_xor(upper ? a : b, 32, 64);
-                        f[r] = upper ? got : a;
-                        f[4 + r] = upper ? b : got;
-                    }
-                    u32x4 hi, lo;
-                    ssplit8(f, hi, lo);
-                    const int o = (tav && (pair || !upper)) ? offS[p] : SOOB;   // a lone last tile: the lower half of the wave stores it
-                    __builtin_amdgcn_raw_buffer_store_b128(hi, rs8, o, so, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(lo, rs8, o, so + P.HW * 16, 0);
-                }
-            }
-        }
-    };
-    // VMEM operations the epilogue leaves in flight (issued after the DMA of the next chunk)
-    const int nst = (P.f32_mode == S_F32_C4 ? 2 * NTW : (P.f32_mode == S_F32_NCHW ? 8 * NTW : 0)) + (outs ? ((NTW + 1) / 2) * 4 : 0);
-
-    // ---- schedule ---------------------------------------------------------------------------------------------------------------
-    const int h = 0;
-    (void)h;
-    PSTAMP(0);
-    decode(0);
-    if (validN) stage(0, 0, rinN, voffN, cbN);
-    adopt();
-    decode(1);
-    PSTAMP(1);
-    swait_barrier<0>();
-    int g = 0, ev = 2;
-    (void)ev;
-    for (int round = 0; round < P.rounds; ++round) {
-        for (int c = 0; c < P.nChunks; ++c, ++g) {
-            const bool last = c + 1 == P.nChunks;
-            PSTAMP(ev); ++ev;
-            if (c == 0) load_res();
-            // the next chunk of the item, or the first chunk of the next item, is staged from inside the MFMA phase
-            st_on = valid && (!last || validN);
-            st_c = last ? 0 : c + 1;
-            st_vo = last ? voffN : voff;
-            st_cb = last ? cbN : cb;
-            st_rin = last ? rinN : rin;
-            PSTAMP(ev); ++ev;
-            if (valid) {
-                if (g & 1) mfma_phase(1);
-                else mfma_phase(0);
-            }
-            PSTAMP(ev); ++ev;
-            if (last) {
-                if (valid) epilogue();
-                PSTAMP(ev); ++ev;
-                adopt();
-                decode(round + 2);
-                PSTAMP(ev); ++ev;
-                // the next chunk's DMA has landed when everything older than this item's stores is done
-                if (nst == 2 * NTW) swait_barrier<2 * NTW>();
-                else if (nst == 2 * NTW + ((NTW + 1) / 2) * 4) swait_barrier<2 * NTW + ((NTW + 1) / 2) * 4>();
-                else if (nst == ((NTW + 1) / 2) * 4) swait_barrier<((NTW + 1) / 2) * 4>();
-                else if (nst == 8 * NTW) swait_barrier<8 * NTW>();
-                else if (nst == 8 * NTW + ((NTW + 1) / 2) * 4) swait_barrier<8 * NTW + ((NTW + 1) / 2) * 4>();
-                else swait_barrier<0>();
-            } else {
-                swait_barrier<0>();
-            }
-        }
-    }
 }
 
 int s8_ntw(int Cout) {
@@ -874,15 +598,20 @@ bool convs_plan(const otp_conv_desc& d, SPlan& P) {
     P.tpx = (P.nTiles + 7) / 8;
     P.VR = d.H + 1;
     P.W1 = d.W + 1;
-    int rows = 0;
+    // window records of a tile: from the first pixel's tap (0, 0) = (row above, x0 - 1) to the last pixel's tap (2, 2), in the
+    // row-major frame of W + 1 records per virtual row; the maximum over the launch's tiles sizes the LDS planes
+    int NV = 0;
     for (int t = 0; t < P.nTiles; ++t) {
         const int a = t * SBM, b = (a + SBM < P.total ? a + SBM : P.total) - 1;
-        const int na = a / P.HW, ya = (a % P.HW) / d.W, nb = b / P.HW, yb = (b % P.HW) / d.W;
-        const int r = (nb * P.VR + yb + 2) - (na * P.VR + ya) + 1;   // virtual rows Vf .. V(last pixel) + 1
-        if (r > rows) rows = r;
+        const int na = a / P.HW, ya = (a % P.HW) / d.W, xa = (a % P.HW) % d.W;
+        const int nb = b / P.HW, yb = (b % P.HW) / d.W, xb = (b % P.HW) % d.W;
+        const int rows = (nb * P.VR + yb + 1) - (na * P.VR + ya);   // virtual rows between the window's first and the last pixel's
+        const int v = (rows + 1) * P.W1 + xb - xa + 3;
+        if (v > NV) NV = v;
     }
-    const int NV = rows * P.W1 + 1;                                 // + the record right of the last row's last pixel
     if (NV > 512) return false;
+    P.NV = NV;
+    P.pl = NV * 16;
     P.NIW = (NV + 63) / 64;
     P.mHW = smagic(P.HW); P.mW = smagic(d.W); P.mW1 = smagic(P.W1); P.mVR = smagic(P.VR);
     // exactness of the magic divisions (numerator * divisor < 2^32) and 31-bit byte offsets
@@ -890,43 +619,17 @@ bool convs_plan(const otp_conv_desc& d, SPlan& P) {
     if ((long)(d.N + 1) * P.VR * P.VR >= (1l << 32)) return false;
     if ((long)d.Cin * P.HW * 4 * 8 >= (1l << 31)) return false;    // a tile spans < 8 images: per-lane offsets stay 31-bit
     if (P.HW < 32) return false;
-    if ((size_t)P.nN * P.nChunks * SKS * P.NTW * 2 * 1024 >= (1ull << 31)) return false;
+    if ((size_t)P.nN * P.nChunks * swch(P.NTW) * 1024 >= (1ull << 31)) return false;
     return true;
 }
 
-template <int NTW>
+template <int NTW, bool NCHW>
 int convs_launch(const void* xs, const void* wpk, const float* shift, const float* res, float* outf, void* outs, const SPlan& P,
                  hipStream_t st) {
-    auto kern = convs_kernel<NTW>;
-    const size_t need = (size_t)SWIN + SKS * NTW * 2 * 1024;
+    auto kern = convs_kernel<NTW, NCHW>;
+    const size_t need = (size_t)4 * P.pl + swch(NTW) * 1024;
     OTP_ALLOW_BIG_LDS(kern, need);
     hipLaunchKernelGGL(kern, dim3(8 * P.tpx * P.nN), dim3(256), need, st, static_cast<const unsigned char*>(xs),
-                       static_cast<const u32x4*>(wpk), shift, res, outf, static_cast<u32x4*>(outs), P);
-    return otp_launch_status();
-}
-
-template <int NTW>
-int convs_db_launch(const void* xs, const void* wpk, const float* shift, const float* res, float* outf, void* outs, SPlan& P,
-                    hipStream_t st) {
-    static int n_cu = 0;                                            // (one device family per process: MI355X, 256 CUs)
-    if (!n_cu) {
-        int dev = 0, v = 0;
-        (void)hipGetDevice(&dev);
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        n_cu = v;
-    }
-    P.nItems = P.nTiles * P.nN;
-    P.ipx = (P.nItems + 7) / 8;
-    int grid = n_cu & ~7;
-    const int want = (P.ipx * 8 + 7) & ~7;                          // workgroups that give every one at most one item
-    if (grid > want) grid = want;
-    if (grid < 8) grid = 8;
-    P.hs = grid / 8;                                                // workgroups per XCD
-    P.rounds = (P.ipx + P.hs - 1) / P.hs;
-    auto kern = convs_db_kernel<NTW>;
-    const size_t need = 2 * ((size_t)SWIN + SKS * NTW * 2 * 1024);
-    OTP_ALLOW_BIG_LDS(kern, need);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), need, st, static_cast<const unsigned char*>(xs),
                        static_cast<const u32x4*>(wpk), shift, res, outf, static_cast<u32x4*>(outs), P);
     return otp_launch_status();
 }
@@ -936,9 +639,6 @@ int convs_db_launch(const void* xs, const void* wpk, const float* shift, const f
 #ifdef OTP_CONVS_TIMING
 extern "C" int otp_convs_read_stamps(void* host_out, size_t bytes) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(otp_convs_stamps), bytes) == hipSuccess ? OTP_OK : OTP_ERR_LAUNCH;
-}
-extern "C" int otp_convs_read_pp_stamps(void* host_out, size_t bytes) {
-    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(otp_convs_pp_stamps), bytes) == hipSuccess ? OTP_OK : OTP_ERR_LAUNCH;
 }
 #endif
 
@@ -1015,7 +715,7 @@ extern "C" int otp_conv3x3_s8_supported(const otp_conv_desc* desc) {
 extern "C" size_t otp_conv3x3_s8_weight_bytes(int Cout, int Cin) {
     if (Cout <= 0 || Cin <= 0 || Cin % 16) return 0;
     const int NTW = s8_ntw(Cout), nN = ((Cout + 15) / 16 + NTW - 1) / NTW;
-    return (size_t)nN * (Cin / 16) * SKS * NTW * 2 * 1024;
+    return (size_t)nN * (Cin / 16) * swch(NTW) * 1024;
 }
 
 extern "C" int otp_conv3x3_s8_pack_weight(const void* weight, const void* scale, void* wpacked, int Cout, int Cin, void* stream) {
@@ -1046,13 +746,9 @@ extern "C" int otp_conv3x3_s8(const void* in_s8, const void* wpacked, const void
     auto fs = static_cast<const float*>(shift);
     auto fr = static_cast<const float*>(res_c4);
     auto fo = static_cast<float*>(out_f32);
-    static const int form = [] {                                    // experimental: 1 = the persistent double-buffered form
-        const char* e = getenv("OTPOSE_S8_PERSISTENT");
-        return e ? atoi(e) : 0;
-    }();
-    if (form)
-        return P.NTW == 2 ? convs_db_launch<2>(in_s8, wpacked, fs, fr, fo, out_s8, P, st)
-                          : convs_db_launch<3>(in_s8, wpacked, fs, fr, fo, out_s8, P, st);
-    return P.NTW == 2 ? convs_launch<2>(in_s8, wpacked, fs, fr, fo, out_s8, P, st)
-                      : convs_launch<3>(in_s8, wpacked, fs, fr, fo, out_s8, P, st);
+    if (P.f32_mode == S_F32_NCHW)
+        return P.NTW == 2 ? convs_launch<2, true>(in_s8, wpacked, fs, fr, fo, out_s8, P, st)
+                          : convs_launch<3, true>(in_s8, wpacked, fs, fr, fo, out_s8, P, st);
+    return P.NTW == 2 ? convs_launch<2, false>(in_s8, wpacked, fs, fr, fo, out_s8, P, st)
+                      : convs_launch<3, false>(in_s8, wpacked, fs, fr, fo, out_s8, P, st);
 }
