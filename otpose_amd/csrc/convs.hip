@@ -36,7 +36,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int SBM = 256;                  // output pixels per workgroup (4 waves x 4 pixel tiles of 16)
 // 1 KB pieces of a chunk's packed weights: 4 full k-steps x NTW tiles x (hi, lo) + the half-filled fifth (512 bytes per fragment)
 __host__ __device__ constexpr int swch(int ntw) { return 8 * ntw + ntw; }
 constexpr int SKS = 5;                    // k-steps per chunk: 18 (tap, group) slots of 8 channels in 5 x 4 (2 zero-weight slots)
@@ -60,6 +59,7 @@ struct SPlan {
     int N, C, H, W, HW, Cout, total;
     int out_ctot, out_coff, act, f32_mode;
     int NTW, nN, nTiles, nChunks, tpx;
+    int NPT;                              // pixel tiles of 16 per wave (workgroup tile = 64 NPT pixels)
     int VR, W1, NIW, NV, pl;              // virtual rows per image (H + 1), records per window row (W + 1), 64-record pieces per plane,
                                           // records / bytes of a window plane
     uint32_t mHW, mW, mW1, mVR;
@@ -293,12 +293,13 @@ __device__ __forceinline__ void sblock_sched() {
 // residual / fp32 output layouts of otp_conv3x3_s8
 enum { S_F32_NONE = 0, S_F32_C4 = 1, S_F32_NCHW = 2 };
 
-template <int NTW, bool NCHW>
+template <int NTW, bool NCHW, int NPT>
 __global__ __launch_bounds__(256, NCHW ? 2 : 3) void convs_kernel(const unsigned char* __restrict__ xs, const u32x4* __restrict__ wpk,
                                                         const float* __restrict__ shift, const float* res, float* outf,
                                                         u32x4* outs, const SPlan P) {
-    constexpr int NPT = 4;                                         // pixel tiles of 16 per wave
-    constexpr int BM = SBM;
+    // NPT pixel tiles of 16 per wave: workgroup tiles of 256 pixels, or of 128 for launches that would leave CUs with fewer than
+    // three workgroups (the small maps: a workgroup's set-up, waits and epilogue only overlap with ANOTHER workgroup's MFMAs)
+    constexpr int BM = 64 * NPT;
     constexpr int WCH = swch(NTW);                                 // 1 KB pieces of a chunk's weights
     constexpr int WBYTES = WCH * 1024;
     constexpr int NBLK = SKS * NPT;                                // (k-step, pixel tile) blocks of a chunk: 3 NTW MFMAs each
@@ -580,6 +581,15 @@ __global__ __launch_bounds__(256, NCHW ? 2 : 3) void convs_kernel(const unsigned
 #endif
 }
 
+// development override of the pixel tiles per wave (OTPOSE_S8_NPT = 2 / 4; default: by launch size)
+int force_npt() {
+    static const int v = [] {
+        const char* e = getenv("OTPOSE_S8_NPT");
+        return e ? atoi(e) : 0;
+    }();
+    return v;
+}
+
 int s8_ntw(int Cout) {
     const int c16 = (Cout + 15) / 16;
     return (c16 % 3 == 0) ? 3 : (c16 % 2 == 0 || c16 <= 2 ? 2 : 3);          // same rule as csrc/convx.hip (shared weight image)
@@ -593,7 +603,11 @@ bool convs_plan(const otp_conv_desc& d, SPlan& P) {
     P.out_ctot = d.out_ctot; P.out_coff = d.out_coff; P.act = d.act; P.f32_mode = S_F32_NONE;
     P.NTW = s8_ntw(d.Cout);
     P.nN = ((d.Cout + 15) / 16 + P.NTW - 1) / P.NTW;
-    P.nTiles = (P.total + SBM - 1) / SBM;
+    P.NPT = 4;
+    if ((long)((P.total + 255) / 256) * P.nN < 3 * 256 && force_npt() != 4) P.NPT = 2;
+    if (force_npt() == 2) P.NPT = 2;
+    const int bm = 64 * P.NPT;
+    P.nTiles = (P.total + bm - 1) / bm;
     P.nChunks = d.Cin / 16;
     P.tpx = (P.nTiles + 7) / 8;
     P.VR = d.H + 1;
@@ -602,7 +616,7 @@ bool convs_plan(const otp_conv_desc& d, SPlan& P) {
     // row-major frame of W + 1 records per virtual row; the maximum over the launch's tiles sizes the LDS planes
     int NV = 0;
     for (int t = 0; t < P.nTiles; ++t) {
-        const int a = t * SBM, b = (a + SBM < P.total ? a + SBM : P.total) - 1;
+        const int a = t * bm, b = (a + bm < P.total ? a + bm : P.total) - 1;
         const int na = a / P.HW, ya = (a % P.HW) / d.W, xa = (a % P.HW) % d.W;
         const int nb = b / P.HW, yb = (b % P.HW) / d.W, xb = (b % P.HW) % d.W;
         const int rows = (nb * P.VR + yb + 1) - (na * P.VR + ya);   // virtual rows between the window's first and the last pixel's
@@ -615,7 +629,7 @@ bool convs_plan(const otp_conv_desc& d, SPlan& P) {
     P.NIW = (NV + 63) / 64;
     P.mHW = smagic(P.HW); P.mW = smagic(d.W); P.mW1 = smagic(P.W1); P.mVR = smagic(P.VR);
     // exactness of the magic divisions (numerator * divisor < 2^32) and 31-bit byte offsets
-    if ((long)(P.HW + SBM) * P.HW >= (1l << 32) || (long)P.HW * d.W >= (1l << 32)) return false;
+    if ((long)(P.HW + bm) * P.HW >= (1l << 32) || (long)P.HW * d.W >= (1l << 32)) return false;
     if ((long)(d.N + 1) * P.VR * P.VR >= (1l << 32)) return false;
     if ((long)d.Cin * P.HW * 4 * 8 >= (1l << 31)) return false;    // a tile spans < 8 images: per-lane offsets stay 31-bit
     if (P.HW < 32) return false;
@@ -623,10 +637,10 @@ bool convs_plan(const otp_conv_desc& d, SPlan& P) {
     return true;
 }
 
-template <int NTW, bool NCHW>
+template <int NTW, bool NCHW, int NPT>
 int convs_launch(const void* xs, const void* wpk, const float* shift, const float* res, float* outf, void* outs, const SPlan& P,
                  hipStream_t st) {
-    auto kern = convs_kernel<NTW, NCHW>;
+    auto kern = convs_kernel<NTW, NCHW, NPT>;
     const size_t need = (size_t)4 * P.pl + swch(NTW) * 1024;
     OTP_ALLOW_BIG_LDS(kern, need);
     hipLaunchKernelGGL(kern, dim3(8 * P.tpx * P.nN), dim3(256), need, st, static_cast<const unsigned char*>(xs),
@@ -746,9 +760,15 @@ extern "C" int otp_conv3x3_s8(const void* in_s8, const void* wpacked, const void
     auto fs = static_cast<const float*>(shift);
     auto fr = static_cast<const float*>(res_c4);
     auto fo = static_cast<float*>(out_f32);
-    if (P.f32_mode == S_F32_NCHW)
-        return P.NTW == 2 ? convs_launch<2, true>(in_s8, wpacked, fs, fr, fo, out_s8, P, st)
-                          : convs_launch<3, true>(in_s8, wpacked, fs, fr, fo, out_s8, P, st);
-    return P.NTW == 2 ? convs_launch<2, false>(in_s8, wpacked, fs, fr, fo, out_s8, P, st)
-                      : convs_launch<3, false>(in_s8, wpacked, fs, fr, fo, out_s8, P, st);
+#define OTP_CONVS_GO(NTW_, NCHW_, NPT_) return convs_launch<NTW_, NCHW_, NPT_>(in_s8, wpacked, fs, fr, fo, out_s8, P, st)
+    const bool nchw = P.f32_mode == S_F32_NCHW;
+    if (P.NPT == 2) {
+        if (P.NTW == 2) { if (nchw) OTP_CONVS_GO(2, true, 2); OTP_CONVS_GO(2, false, 2); }
+        if (nchw) OTP_CONVS_GO(3, true, 2);
+        OTP_CONVS_GO(3, false, 2);
+    }
+    if (P.NTW == 2) { if (nchw) OTP_CONVS_GO(2, true, 4); OTP_CONVS_GO(2, false, 4); }
+    if (nchw) OTP_CONVS_GO(3, true, 4);
+    OTP_CONVS_GO(3, false, 4);
+#undef OTP_CONVS_GO
 }
