@@ -161,10 +161,12 @@ def test_train_step_matches_reference_golden(golden, dtype):
     _close(first["ohkm_loss_s"].detach().float(), g["loss_ohkm_s"], 1e-5)
     _close(first["mse_loss_s"].detach().float(), g["loss_mse_s"], 1e-5)
     _close(second["final_loss"].detach().float(), g["loss_second_final"], 1e-5)
-    # fp32 on both sides of a graph that amplifies rounding (BatchNorm at batch 2, DCN offset branch): per-tensor relative
-    # L2 and cosine, not element-wise equality; the reference itself ran in fp32, so the fp64 oracle sees the reference's
-    # rounding as the error
-    tol = 2e-3
+    # Per-tensor relative L2 and cosine, not element-wise equality.  The fp32 oracle runs the reference's own CPU ops in the
+    # reference's order and reproduces the golden gradients to the last bit (measured 0.0); the fp64 oracle sees the fp32
+    # REFERENCE's rounding as the error: forward differences of ~5e-5 flip a handful of ReLU gates in the RSB chains, and every
+    # flip moves one entry of the (small) gradient tensors behind them by its full size - measured up to 1.5e-2 relative L2,
+    # 1 - cos up to 1.2e-4
+    tol, cos_tol = (2e-3, 1e-5) if dtype == torch.float32 else (3e-2, 5e-4)
     names = golden_names("train_step_tiny", "grad_norm_names")
     norms = g["grad_norms"].double()
     assert len(names) == len(leaves) == norms.numel()
@@ -183,7 +185,7 @@ def test_train_step_matches_reference_golden(golden, dtype):
         ref, mine = g[k].double(), leaves[k[5:]].grad.double()
         rel = float((mine - ref).norm() / ref.norm().clamp_min(1e-30))
         cos = float((mine * ref).sum() / (mine.norm() * ref.norm()).clamp_min(1e-30))
-        if rel > tol or cos < 1 - 1e-5:
+        if rel > tol or cos < 1 - cos_tol:
             bad.append((k, rel, cos))
     assert not bad, bad
 
