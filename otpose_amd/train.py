@@ -333,6 +333,8 @@ class TrainGraph:
             for mi in range(nm):
                 n_out = 1 if (s == 4 and mi == nm - 1) else nb
                 ys = self.hr_module(f"{p}.stage{s}.{mi}", ys, n_out)
+                if self.taps is not None:
+                    self.taps.update({f"hr:stage{s}.{mi}.out{i}": y for i, y in enumerate(ys)})
         return self.hrnet_output(p + ".final_layer", ys[0])
 
     # ---- ConvTransformer (model/blocks.py:264-280, 400-453; ConvVideoTransformer.py:123-184) ------------------------

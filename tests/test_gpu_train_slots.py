@@ -59,12 +59,33 @@ def _grad_err(pa, pb):
     return (num / max(den, 1e-300)) ** 0.5, worst, wname
 
 
-# Run-to-run spread of the HIP backward itself on identical weights and inputs (measured with tools/train_determinism.py):
-# f32 1e-7 (float atomics in the DCN weight gradient, fp32 reduction order); bf16 usually 1e-9, but about one backward in
-# five deviates by 1e-3 .. 6e-3 in the whole-gradient L2 sense (same loss to the last bit; seen with and without side
-# streams - an fp32 summation-order difference that flips bf16 roundings of activation gradients, amplified by the
-# BatchNorm backward at batch 2).  A stale or doubled gradient - what this test is about - is an O(1) error.
+# Run-to-run spread of the HIP backward itself on identical weights and inputs (tools/train_determinism.py,
+# tools/train_nondet_taps.py): f32 1e-7 (float atomics in the DCN / glue gradients, fp32 reduction order); bf16 usually 1e-9,
+# but about one backward in five deviates by 1e-3 .. 6e-3 in the whole-gradient L2 sense (same loss to the last bit).  Traced
+# in round 3 with gradient taps on every HRNet module: dL/d(heat-maps) agrees to 3e-8 (the atomics), the first bf16 activation
+# gradient behind it (final layer's input gradient) then differs in a handful of bf16 roundings (1e-7 .. 2e-5 relative), and
+# every further bf16-rounded layer of the backward decorrelates a little more: 1e-4 two modules down, 1.5e-2 at stage 2 -
+# rounding noise of a 60-layer bf16 chain seeded by summation order, not a wrong kernel (every tap of the fp32 graph behind
+# the backbone is bit-identical).  A stale or doubled gradient - what this test is about - is an O(1) error.
 GRAD_TOL = {"f32": 2e-4, "bf16": 2e-2}
+# Weights after one AdamW step from identical weights: Adam normalises, so a stale / doubled gradient moves EVERY weight by
+# ~lr.  f32: max |dw| <= 0.05 lr.  bf16: the rounding noise above flips the sign of a few near-zero gradient entries (those
+# weights then differ by up to 2 lr), so the bound is on the mean |dw| (measured 1e-3 .. 1e-2 lr) and on the share of weights
+# that moved apart by more than 0.05 lr
+W_MEAN_TOL_BF16, W_SHARE_TOL_BF16 = 0.05, 0.02
+
+
+def _assert_weights_close(a, b, dtype, tag):
+    pb = dict(b.named_parameters())
+    with torch.no_grad():
+        dws = torch.cat([(p.detach() - pb[n].detach()).abs().flatten() for n, p in a.named_parameters() if p.requires_grad])
+    diff, mean = float(dws.max()), float(dws.mean())
+    share = float((dws > 0.05 * LR).float().mean())
+    print("%s: |dw| max %.3e mean %.3e, share > 0.05 lr %.2e (lr %.0e)" % (tag, diff, mean, share, LR))
+    if dtype == "f32":
+        assert diff <= 0.05 * LR, (tag, diff)
+    else:
+        assert mean <= W_MEAN_TOL_BF16 * LR and share <= W_SHARE_TOL_BF16, (tag, mean, share)
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
@@ -108,10 +129,8 @@ def test_slot_gradients_and_weights_match_per_parameter_path(dtype, zero_mode):
         opt_b.step()
         # one AdamW step from identical weights and (to 1e-6) identical gradients: Adam normalises, so a stale / doubled
         # gradient would move weights by ~lr; rounding of the two implementations by ~1e-3 lr
+        _assert_weights_close(a, b, dtype, "step %d slot vs per-parameter" % it)
         with torch.no_grad():
-            diff = max(float((p - pb[n]).abs().max()) for n, p in a.named_parameters() if p.requires_grad)
-            print("step %d: max |w_slot - w_per_param| %.3e (lr %.0e)" % (it, diff, LR))
-            assert diff <= 0.05 * LR, (it, diff)
             # re-align the replicas: the graph amplifies 1e-7 weight differences (ReLU / top-k decisions that flip) into
             # 1e-3 gradient differences one step later, which would mask what this test is looking for
             for n, p in b.named_parameters():
@@ -174,10 +193,7 @@ def test_rccl_exchange_on_one_rank_matches_no_exchange():
         loss_a = PAR.train_step_dp(a, opt_a, x, margin, g, wt)      # flags MAX, 3 flat all-reduces, loss mean: all RCCL
         torch.cuda.synchronize()
         assert abs(float(loss_a) - float(loss_b)) <= 1e-5 * max(1.0, abs(float(loss_b)))
-        pb = dict(b.named_parameters())
-        diff = max(float((p.detach() - pb[n].detach()).abs().max()) for n, p in a.named_parameters() if p.requires_grad)
-        print("FusedAdamW + forced RCCL vs none: max weight diff %.3e" % diff)
-        assert diff <= 0.05 * LR, diff
+        _assert_weights_close(a, b, "bf16", "FusedAdamW + forced RCCL vs none")
         # bucketed exchange launched by hooks from inside the backward (per-parameter gradients, torch optimizer)
         params = [p for p in c.parameters() if p.requires_grad]
         bk = PAR.GradBuckets(params, bucket_bytes=1 << 20, hooks=True)
