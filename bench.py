@@ -28,6 +28,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-train-step", action="store_true", help="skip the training-step probe (extra field of the line)")
     ap.add_argument("--train-f32", action="store_true", help="also time the fp32 training step (1 GPU)")
     ap.add_argument("--no-exact-fp32", action="store_true", help="skip the exact-fp32-kernel forward reported beside the headline")
+    ap.add_argument("--no-config5", action="store_true", help="skip the 7-frame-window forward (BASELINE configs[4]) reported beside the headline")
     return ap.parse_args(argv)
 
 
@@ -537,6 +538,34 @@ def main():
             os.environ["OTPOSE_CONV_MATH"] = math
             hip.lib().otp_chan_attn_set_split(1)
             model.invalidate_engine()
+    # BASELINE configs[4] (extension: the reference has no 7-frame model): the same forward with a 7-frame window, batch 16 x 7 x
+    # 384 x 288 - 12 x 17 = 204 stacked maps per temporal encoder; 1 GPU only, never part of `value`
+    config5 = None
+    if world == 1 and not a.no_config5 and a.batch == 16:
+        from otpose_amd.config import cfg5
+        c5 = cfg5()
+        m5 = OTPose(c5)
+        S.fill_synthetic_(m5)
+        m5 = m5.to(dev).eval()
+        m5.alias_outputs = True
+        x5, g5 = S.synthetic_clip(a.batch, c5.MODEL.IMAGE_SIZE, frames=7)
+        x5, g5 = x5.to(dev), g5.to(dev)
+        with torch.no_grad():
+            for _ in range(3):
+                o5 = m5(x5, margin=g5)
+            torch.cuda.synchronize(dev)
+            t5 = time.perf_counter()
+            for _ in range(a.steps):
+                o5 = m5(x5, margin=g5)
+            torch.cuda.synchronize(dev)
+            d5 = time.perf_counter() - t5
+        config5 = {"workload": "BASELINE configs[4] as far as the reference defines it: batch 16 x 7-frame window x 384x288, HRNet-W48 "
+                               "(no RSN backbone / occlusion mask exists in the reference), fp32 storage, split-bf16 products",
+                   "frames_per_s": 7 * a.batch * a.steps / d5, "ms_per_step": 1e3 * d5 / a.steps,
+                   "outputs_finite": all(bool(torch.isfinite(o).all()) for o in o5),
+                   "encoder_kernels": "C = 204 instantiations of csrc/mlpx.hip / csrc/densex.hip (ln2 + MLP, q / k / v front end, projections)"}
+        del m5, o5, x5, g5
+        torch.cuda.empty_cache()
     train = None
     if not a.no_train_step:
         del outs
@@ -582,6 +611,8 @@ def main():
             line["roofline_warp_head"] = head
         if exact is not None:
             line["exact_fp32_kernels"] = exact
+        if config5 is not None:
+            line["config5"] = config5
         line["vs_eager_rocm"] = eager_ratio(1e3 * dt / a.steps / 1.0, a.batch)
         line["parity"] = golden_parity(model, cfg, dev)     # the "heatmap max-abs delta vs ref" half of the metric
         log("golden parity done")

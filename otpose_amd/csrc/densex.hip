@@ -254,10 +254,11 @@ __global__ __launch_bounds__(256, 2) void qkvx_front_kernel(const float* __restr
 
 }  // namespace
 
-extern "C" int otp_dense_x3_supported(int C, int T) { return (C == 136 && T > 0 && T % 2 == 0) ? 1 : 0; }
+// C = 136: 8 stacked maps x 17 joints (5-frame window); C = 204: 12 x 17 (the 7-frame window of BASELINE configs[4])
+extern "C" int otp_dense_x3_supported(int C, int T) { return ((C == 136 || C == 204) && T > 0 && T % 2 == 0) ? 1 : 0; }
 
 extern "C" size_t otp_dense_x3_weight_bytes(int C) {
-    if (C <= 0 || C % 8) return 0;
+    if (C <= 0 || C % 4) return 0;
     return (size_t)((C + 15) / 16) * dx_block_bytes(C);
 }
 
@@ -288,8 +289,12 @@ extern "C" int otp_dense_x3(const void* const* x, const void* const* packed, con
             return OTP_ERR_BAD_ARG;
     }
     const int tiles = otp_ceil_div(T, 128);
-    hipLaunchKernelGGL(densex_cc_kernel<136>, dim3((unsigned)(B * tiles), (unsigned)nprob), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), a, T, tiles);
+    if (C == 204)
+        hipLaunchKernelGGL(densex_cc_kernel<204>, dim3((unsigned)(B * tiles), (unsigned)nprob), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), a, T, tiles);
+    else
+        hipLaunchKernelGGL(densex_cc_kernel<136>, dim3((unsigned)(B * tiles), (unsigned)nprob), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), a, T, tiles);
     return otp_launch_status();
 }
 
@@ -308,7 +313,11 @@ extern "C" int otp_qkv_front_x3(const void* x, const void* table, const void* pa
     a.packed[2] = static_cast<const unsigned char*>(packed_v);
     a.out[0] = static_cast<float*>(q); a.out[1] = static_cast<float*>(k); a.out[2] = static_cast<float*>(v);
     const int tiles = otp_ceil_div(T, 128);
-    hipLaunchKernelGGL(qkvx_front_kernel<136>, dim3((unsigned)(B * tiles), 3u), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       static_cast<const float*>(x), static_cast<const float*>(table), a, T, tiles, eps);
+    if (C == 204)
+        hipLaunchKernelGGL(qkvx_front_kernel<204>, dim3((unsigned)(B * tiles), 3u), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           static_cast<const float*>(x), static_cast<const float*>(table), a, T, tiles, eps);
+    else
+        hipLaunchKernelGGL(qkvx_front_kernel<136>, dim3((unsigned)(B * tiles), 3u), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           static_cast<const float*>(x), static_cast<const float*>(table), a, T, tiles, eps);
     return otp_launch_status();
 }

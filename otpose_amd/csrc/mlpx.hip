@@ -84,7 +84,7 @@ __global__ void mlpx_pack_kernel(const float* __restrict__ w1, const float* __re
     const int KS1 = mx_ks1(C), W1B = mx_w1_bytes(C), W2B = mx_w2_bytes(C), BLKB = mx_block_bytes(C);
     const int units = BLKB / 16;                                   // 16-byte units per block
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (HID / 32) * units) return;
+    if (idx >= ((HID + 31) / 32) * units) return;                  // (a ragged last block - HID = 816 - is padded with zero weights)
     const int hb = idx / units, u = idx - hb * units;
     u32x4 o = {0u, 0u, 0u, 0u};
     float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -97,14 +97,14 @@ __global__ void mlpx_pack_kernel(const float* __restrict__ w1, const float* __re
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int c = 32 * ks + 8 * kq + j;
-                if (c < C) v[j] = w1[(size_t)hid * C + c];
+                if (c < C && hid < HID) v[j] = w1[(size_t)hid * C + c];
             }
         } else {
             const int mt = (frag - W1B / 1024) >> 1, c = 16 * mt + row;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int hid = 32 * hb + (j < 4 ? 4 * kq + j : 16 + 4 * kq + j - 4);
-                if (c < C) v[j] = w2[(size_t)c * HID + hid];
+                if (c < C && hid < HID) v[j] = w2[(size_t)c * HID + hid];
             }
         }
         bf16x8 hi, lo;
@@ -112,8 +112,10 @@ __global__ void mlpx_pack_kernel(const float* __restrict__ w1, const float* __re
         o = __builtin_bit_cast(u32x4, lo_part ? lo : hi);
     } else if (u < (W1B + W2B) / 16 + 8) {
         const int k = (u - (W1B + W2B) / 16) * 4;
-        o = (u32x4){__builtin_bit_cast(uint32_t, b1[32 * hb + k]), __builtin_bit_cast(uint32_t, b1[32 * hb + k + 1]),
-                    __builtin_bit_cast(uint32_t, b1[32 * hb + k + 2]), __builtin_bit_cast(uint32_t, b1[32 * hb + k + 3])};
+        const bool in = 32 * hb + k < HID;                         // (HID % 4 == 0)
+        o = in ? (u32x4){__builtin_bit_cast(uint32_t, b1[32 * hb + k]), __builtin_bit_cast(uint32_t, b1[32 * hb + k + 1]),
+                         __builtin_bit_cast(uint32_t, b1[32 * hb + k + 2]), __builtin_bit_cast(uint32_t, b1[32 * hb + k + 3])}
+               : (u32x4){0u, 0u, 0u, 0u};
     }
     reinterpret_cast<u32x4*>(packed)[idx] = o;
 }
@@ -140,7 +142,7 @@ __device__ __forceinline__ void mlpx_pass(const float* __restrict__ x, const uns
                                           const float* __restrict__ res, float* __restrict__ out, int T, size_t base, int tok0,
                                           unsigned char* lds, const float* __restrict__ ln_gamma,
                                           const float* __restrict__ ln_beta, float ln_eps) {
-    constexpr int KS1 = mx_ks1(C), MT = mx_mt(C), HB = HID / 32;
+    constexpr int KS1 = mx_ks1(C), MT = mx_mt(C), HB = (HID + 31) / 32;
     constexpr int W1B = mx_w1_bytes(C), W2B = mx_w2_bytes(C), BLKB = mx_block_bytes(C);
     const int lane = threadIdx.x & 63, kq = lane >> 4, n = lane & 15;
     const int tok = tok0 + NT * n;
@@ -283,7 +285,8 @@ __device__ __forceinline__ void mlpx_pass(const float* __restrict__ x, const uns
     }
 }
 
-template <int C, int HID, int WAVES, bool LN>
+// NT token tiles of 16 per wave: 2 at C = 136; 1 at C = 204 (7 + 7 input fragments and 13 accumulator tiles per token tile)
+template <int C, int HID, int WAVES, bool LN, int NT>
 __global__ __launch_bounds__(WAVES * 64, 2) void mlpx_kernel(
     const float* __restrict__ x, const unsigned char* __restrict__ packed, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ out, int T, int tiles_per_b,
@@ -291,8 +294,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void mlpx_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char mx_lds[];
     const int wave = threadIdx.x >> 6;
     const int b = blockIdx.x / tiles_per_b, tile = blockIdx.x - b * tiles_per_b;
-    mlpx_pass<C, HID, WAVES * 64, LN, 2>(x, packed, scale, shift, res, out, T, (size_t)b * C * T,
-                                         tile * (WAVES * 32) + wave * 32, mx_lds, ln_gamma, ln_beta, ln_eps);
+    mlpx_pass<C, HID, WAVES * 64, LN, NT>(x, packed, scale, shift, res, out, T, (size_t)b * C * T,
+                                          tile * (WAVES * 16 * NT) + wave * 16 * NT, mx_lds, ln_gamma, ln_beta, ln_eps);
 }
 
 // Balanced form for token counts that are multiples of 27 column tiles per workgroup (T = 6912 = 16 x 27 x 16), as
@@ -322,12 +325,12 @@ __global__ __launch_bounds__(512, 2) void mlpx_balanced_kernel(
 }  // namespace
 
 extern "C" int otp_mlp_x3_supported(int C, int HID, int T) {
-    return (C == 136 && HID == 544 && T > 0 && T % 2 == 0) ? 1 : 0;
+    return (((C == 136 && HID == 544) || (C == 204 && HID == 816)) && T > 0 && T % 2 == 0) ? 1 : 0;
 }
 
 extern "C" size_t otp_mlp_x3_weight_bytes(int C, int HID) {
-    if (C <= 0 || C % 8 || HID <= 0 || HID % 32) return 0;
-    return (size_t)(HID / 32) * mx_block_bytes(C);
+    if (C <= 0 || C % 4 || HID <= 0 || HID % 16) return 0;   // (partial k-slots / row tiles are masked: C = 204 = 6 x 32 + 12)
+    return (size_t)((HID + 31) / 32) * mx_block_bytes(C);
 }
 
 extern "C" int otp_mlp_x3_pack(const void* w1, const void* b1, const void* w2, void* packed, int C, int HID, void* stream) {
@@ -351,6 +354,16 @@ int mlpx_launch(const void* x, const void* packed, const void* scale, const void
         return OTP_ERR_BAD_ARG;
     auto f = [](const void* p) { return static_cast<const float*>(p); };
     auto pk = static_cast<const unsigned char*>(packed);
+    if (C == 204) {                                              // 7-frame window: one token tile per wave, 128 tokens per workgroup
+        constexpr int WAVES = 8;
+        const size_t lds204 = 2 * (size_t)mx_block_bytes(204);
+        const int tiles = otp_ceil_div(T, WAVES * 16);
+        auto kern = ln_gamma ? mlpx_kernel<204, 816, WAVES, true, 1> : mlpx_kernel<204, 816, WAVES, false, 1>;
+        OTP_ALLOW_BIG_LDS(kern, lds204);
+        hipLaunchKernelGGL(kern, dim3((unsigned)(B * tiles)), dim3(WAVES * 64), lds204, static_cast<hipStream_t>(stream), f(x), pk,
+                           f(scale), f(shift), f(res), static_cast<float*>(out), T, tiles, f(ln_gamma), f(ln_beta), ln_eps);
+        return otp_launch_status();
+    }
     const size_t lds = 2 * (size_t)mx_block_bytes(136);
     const char* bal = getenv("OTP_MLP_BALANCED");               // "0": never, "2": whenever the shape allows (tests)
     const bool bal_off = bal && bal[0] == '0', bal_force = bal && bal[0] == '2';
@@ -364,7 +377,7 @@ int mlpx_launch(const void* x, const void* packed, const void* scale, const void
     }
     constexpr int WAVES = 8;
     const int tiles = otp_ceil_div(T, WAVES * 32);
-    auto kern = ln_gamma ? mlpx_kernel<136, 544, WAVES, true> : mlpx_kernel<136, 544, WAVES, false>;
+    auto kern = ln_gamma ? mlpx_kernel<136, 544, WAVES, true, 2> : mlpx_kernel<136, 544, WAVES, false, 2>;
     OTP_ALLOW_BIG_LDS(kern, lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)(B * tiles)), dim3(WAVES * 64), lds, static_cast<hipStream_t>(stream), f(x), pk,
                        f(scale), f(shift), f(res), static_cast<float*>(out), T, tiles, f(ln_gamma), f(ln_beta), ln_eps);

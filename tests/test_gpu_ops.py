@@ -301,11 +301,13 @@ def test_mlp_fused_matches_fp64(T, monkeypatch):
     assert torch.equal(r2, out)
 
 
+@pytest.mark.parametrize("C", [136, 204])
 @pytest.mark.parametrize("T", [32, 250, 1152, 864])
-def test_mlp_x3_matches_fp64(T, monkeypatch):
+def test_mlp_x3_matches_fp64(T, C, monkeypatch):
     """csrc/mlpx.hip (split-bf16 products) vs the same fp64 MLP as test_mlp_fused_matches_fp64.  Tolerance 2e-5 of the output
-    range: two bf16 pieces per operand carry 16 mantissa bits + rounding (measured 3e-6; the f32-MFMA kernel 4e-7)."""
-    B, C, HID = 2, 136, 544
+    range: two bf16 pieces per operand carry 16 mantissa bits + rounding (measured 3e-6; the f32-MFMA kernel 4e-7).
+    C = 204: the 12 x 17 stacked maps of the 7-frame window (BASELINE configs[4])."""
+    B, HID = 2, 4 * C
     if T % 432 == 0:
         monkeypatch.setenv("OTP_MLP_BALANCED", "2")
     x, res = seeded((B, C, T), 11), seeded((B, C, T), 12)
@@ -350,11 +352,12 @@ def test_dense_cc_matches_fp64(T):
     _close(o, ref.float(), 2e-6)
 
 
+@pytest.mark.parametrize("C", [136, 204])
 @pytest.mark.parametrize("T", [32, 250, 1152])
-def test_dense_and_qkv_front_x3_match_fp64(T):
+def test_dense_and_qkv_front_x3_match_fp64(T, C):
     """csrc/densex.hip (split-bf16 products) vs the same fp64 references as test_dense_cc_matches_fp64 /
-    test_qkv_front_matches_fp64; 2e-5 of the output range (measured 3e-6)."""
-    B, C, eps = 2, 136, 1e-5
+    test_qkv_front_matches_fp64; 2e-5 of the output range (measured 3e-6).  C = 204: the 7-frame window's encoders."""
+    B, eps = 2, 1e-5
     xs = [seeded((B, C, T), 21 + i) for i in range(3)]
     ws = [seeded((C, C, 1), 31 + i) / C ** 0.5 for i in range(3)]
     bs = [seeded((C,), 41 + i) for i in range(3)]

@@ -66,3 +66,32 @@ def test_seven_frame_training_graph(dtype):
     TR.criterion(outs, g, wt).backward()
     for n, p in model.named_parameters():
         assert p.grad is not None and bool(torch.isfinite(p.grad).all()), n
+
+
+def test_seven_frame_full_size_properties():
+    """BASELINE configs[4] at full size - batch 16 x 7 frames x 384 x 288, HRNet-W48, 12 x 17 = 204 stacked maps per temporal
+    encoder (the C = 204 instantiations of csrc/mlpx.hip / csrc/densex.hip).  No reference exists at this configuration, so the
+    checks are properties: every output finite, clips independent of their batch neighbours (clip 5 alone == row 5 of the
+    batch, to the split-product rounding: different launch shapes, same arithmetic), replay deterministic."""
+    from otpose_amd.config import cfg5
+    cfg = cfg5()
+    model = OTPose(cfg)
+    S.fill_synthetic_(model)
+    model = model.cuda().eval()
+    x, margin = S.synthetic_clip(16, cfg.MODEL.IMAGE_SIZE, frames=7)
+    x, margin = x.cuda(), margin.cuda()
+    with torch.no_grad():
+        outs = model(x, margin=margin)
+        again = model(x, margin=margin)
+        assert model._engine.use_x3
+        assert outs[0].shape == (16, 17, 96, 72) and outs[1].shape == (7 * 16, 17, 96, 72)
+        for n, o, o2 in zip(NAMES, outs, again):
+            assert bool(torch.isfinite(o).all()), n
+            assert torch.equal(o, o2), n
+        one = model(x[5:6].contiguous(), margin=margin[5:6].contiguous())
+    rows = {"output": outs[0][5:6], "rough": outs[1].view(7, 16, 17, 96, 72)[:, 5], "context": outs[4][5:6], "total_b": outs[6][5:6]}
+    alone = {"output": one[0], "rough": one[1].view(7, 1, 17, 96, 72)[:, 0], "context": one[4], "total_b": one[6]}
+    for n in rows:
+        scale = max(1.0, float(rows[n].abs().max()))
+        err = float((rows[n] - alone[n]).abs().max())
+        assert err <= 2e-4 * scale, f"{n}: {err} at scale {scale}"
