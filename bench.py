@@ -272,7 +272,10 @@ def kernel_rooflines(dev, batch):
             packed = ops.pack_mlp_x3_weights(w1, b1, w2)
             t_mlp = event_time_ms(lambda: ops.ln_mlp_x3(xm, one, zero, 1e-5, packed, one, zero, out=om), 20, st)
             executed = 3.0 * 2.0 * (160 * HID + HID * 144) * batch * T
-            peak, kn = PEAK_BF16_MATRIX, ("mlpx_balanced_kernel<136,544,true>" if balanced else "mlpx_kernel<136,544,8,true>")
+            nt1 = os.environ.get("OTP_MLP_NT1", "1") != "0" and os.environ.get("OTP_MLP_BALANCED") != "2"
+            peak = PEAK_BF16_MATRIX
+            kn = ("mlpx_kernel<136,544,8,true,1> (one token tile per wave, two workgroups per CU)" if nt1 else
+                  "mlpx_balanced_kernel<136,544,true>" if balanced else "mlpx_kernel<136,544,8,true,2>")
         else:
             packed = ops.pack_mlp_weights(w1, b1, w2)
             t_mlp = event_time_ms(lambda: ops.ln_mlp_fused(xm, one, zero, 1e-5, packed, one, zero, out=om), 20, st)

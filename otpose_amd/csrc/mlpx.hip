@@ -287,7 +287,7 @@ __device__ __forceinline__ void mlpx_pass(const float* __restrict__ x, const uns
 
 // NT token tiles of 16 per wave: 2 at C = 136; 1 at C = 204 (7 + 7 input fragments and 13 accumulator tiles per token tile)
 template <int C, int HID, int WAVES, bool LN, int NT>
-__global__ __launch_bounds__(WAVES * 64, 2) void mlpx_kernel(
+__global__ __launch_bounds__(WAVES * 64, (NT == 1 && C <= 136) ? 4 : 2) void mlpx_kernel(
     const float* __restrict__ x, const unsigned char* __restrict__ packed, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ out, int T, int tiles_per_b,
     const float* __restrict__ ln_gamma, const float* __restrict__ ln_beta, float ln_eps) {
@@ -365,8 +365,23 @@ int mlpx_launch(const void* x, const void* packed, const void* scale, const void
         return otp_launch_status();
     }
     const size_t lds = 2 * (size_t)mx_block_bytes(136);
-    const char* bal = getenv("OTP_MLP_BALANCED");               // "0": never, "2": whenever the shape allows (tests)
+    // Default: one token tile per wave (NT = 1), 128 tokens per 8-wave workgroup, <= 128 VGPRs: TWO workgroups per CU, each
+    // hiding the other's barriers, weight-block DMA waits and GELU arithmetic (measured at cfg2, 16 x 6912 tokens: 132 us
+    // against 137 for two tiles per wave and 149 for the balanced two-pass form, which were one workgroup per CU).
+    // OTP_MLP_NT1=0 brings the older forms back (OTP_MLP_BALANCED "0": never balanced, "2": whenever the shape allows: tests).
+    const char* bal = getenv("OTP_MLP_BALANCED");
     const bool bal_off = bal && bal[0] == '0', bal_force = bal && bal[0] == '2';
+    const char* e1 = getenv("OTP_MLP_NT1");
+    const bool nt1 = !e1 || e1[0] != '0';
+    if (nt1 && !bal_force) {
+        constexpr int WAVES = 8;
+        const int tiles = otp_ceil_div(T, WAVES * 16);
+        auto kern = ln_gamma ? mlpx_kernel<136, 544, WAVES, true, 1> : mlpx_kernel<136, 544, WAVES, false, 1>;
+        OTP_ALLOW_BIG_LDS(kern, lds);
+        hipLaunchKernelGGL(kern, dim3((unsigned)(B * tiles)), dim3(WAVES * 64), lds, static_cast<hipStream_t>(stream), f(x), pk,
+                           f(scale), f(shift), f(res), static_cast<float*>(out), T, tiles, f(ln_gamma), f(ln_beta), ln_eps);
+        return otp_launch_status();
+    }
     if (!bal_off && T % (27 * 16) == 0 && (bal_force || (long)B * (T / (27 * 16)) >= 192)) {
         auto bk = ln_gamma ? mlpx_balanced_kernel<136, 544, true> : mlpx_balanced_kernel<136, 544, false>;
         OTP_ALLOW_BIG_LDS(bk, lds);

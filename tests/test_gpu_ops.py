@@ -309,7 +309,9 @@ def test_mlp_x3_matches_fp64(T, C, monkeypatch):
     C = 204: the 12 x 17 stacked maps of the 7-frame window (BASELINE configs[4])."""
     B, HID = 2, 4 * C
     if T % 432 == 0:
-        monkeypatch.setenv("OTP_MLP_BALANCED", "2")
+        monkeypatch.setenv("OTP_MLP_BALANCED", "2")         # the balanced two-pass form (one workgroup per 27 column tiles)
+    elif T == 250:
+        monkeypatch.setenv("OTP_MLP_NT1", "0")              # two token tiles per wave (the default is one: two workgroups per CU)
     x, res = seeded((B, C, T), 11), seeded((B, C, T), 12)
     w1, w2 = seeded((HID, C, 1), 13) / C ** 0.5, seeded((C, HID, 1), 14) / HID ** 0.5
     b1, b2, sc = seeded((HID,), 15) * 0.5, seeded((C,), 16), seeded((C,), 17)
