@@ -365,14 +365,15 @@ int mlpx_launch(const void* x, const void* packed, const void* scale, const void
         return otp_launch_status();
     }
     const size_t lds = 2 * (size_t)mx_block_bytes(136);
-    // Default: one token tile per wave (NT = 1), 128 tokens per 8-wave workgroup, <= 128 VGPRs: TWO workgroups per CU, each
-    // hiding the other's barriers, weight-block DMA waits and GELU arithmetic (measured at cfg2, 16 x 6912 tokens: 132 us
-    // against 137 for two tiles per wave and 149 for the balanced two-pass form, which were one workgroup per CU).
-    // OTP_MLP_NT1=0 brings the older forms back (OTP_MLP_BALANCED "0": never balanced, "2": whenever the shape allows: tests).
+    // OTP_MLP_NT1=1 (experiment, NOT the default): one token tile per wave (NT = 1), 128 tokens per 8-wave workgroup, <= 128
+    // VGPRs, i.e. TWO workgroups per CU - 132 us at cfg2 against 149 for the balanced form, but with it the batch-16 forward
+    // is no longer bit-identical across hipGraph replays (1-2 replays in 10 differ in one clip of `output` by up to 6e-4;
+    // tools/replay_determinism.py): two 80 KB workgroups of this LDS-DMA-fed kernel on one CU hit the co-residency corruption
+    // of DESIGN.md section 3.1d.  OTP_MLP_BALANCED "0": never balanced, "2": whenever the shape allows (tests).
     const char* bal = getenv("OTP_MLP_BALANCED");
     const bool bal_off = bal && bal[0] == '0', bal_force = bal && bal[0] == '2';
     const char* e1 = getenv("OTP_MLP_NT1");
-    const bool nt1 = !e1 || e1[0] != '0';
+    const bool nt1 = e1 && e1[0] == '1';
     if (nt1 && !bal_force) {
         constexpr int WAVES = 8;
         const int tiles = otp_ceil_div(T, WAVES * 16);
