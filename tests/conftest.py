@@ -35,3 +35,16 @@ def golden():
 def seeded(shape, seed, scale=1.0, dtype=torch.float32):
     g = torch.Generator().manual_seed(seed)
     return torch.randn(shape, generator=g, dtype=dtype) * scale
+
+
+@pytest.fixture(autouse=True)
+def _release_gpu_state(request):
+    """After every GPU test: collect the model <-> engine reference cycles (an inference engine owns tens of GB of static
+    buffers and a hipGraph; cyclic garbage is otherwise freed whenever Python gets round to it) and hand cached blocks back,
+    so that the ~400 tests of the suite do not pile engines, graphs and their memory pools up in one process."""
+    yield
+    if "gpu" in request.keywords and torch.cuda.is_available():
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
