@@ -87,15 +87,18 @@ class PackCache:
     launch plan - ``otp_nhwc_conv_pack_job``); from then on :meth:`repack` at the start of a forward rewrites all
     destinations from the current fp32 master weights (``otp_nhwc_conv_pack_batch``) and the uses only look their tensor
     up.  The input-gradient operators are therefore those of the weights the forward saw.  Entries keep the weight storage
-    alive, so a job never reads freed memory; a weight that moved (``model.to(...)``) gets new entries."""
+    alive, so a job never reads freed memory; a weight that moved (``model.to(...)``, FusedAdamW re-homing ``p.data`` into
+    its flat buffer) gets new entries, and :meth:`repack` RETIRES every entry the previous forward did not look up (their
+    old storage is released, they are no longer re-packed each step) and drops the whole table when the device changed."""
 
     LIMIT = 8192                              # entries; past it the table is rebuilt from scratch
 
     def __init__(self):
-        self.entries = {}                     # (data_ptr, dgrad, desc bytes) -> (packed tensor, storage keep-alive)
+        self.entries = {}                     # (data_ptr, dgrad, desc bytes) -> (packed tensor, storage keep-alive, job record)
         self.jobs = bytearray()
         self.table = None
         self.dirty = False
+        self.used = set()                     # keys looked up since the last repack()
 
     def __len__(self):
         return len(self.entries)
@@ -112,6 +115,7 @@ class PackCache:
     def get(self, weight, d, dgrad):
         key = (weight.data_ptr(), int(dgrad), bytes(d))
         e = self.entries.get(key)
+        self.used.add(key)
         if e is not None:
             return e[0]
         if len(self.entries) >= self.LIMIT:
@@ -122,12 +126,23 @@ class PackCache:
         hip.check(L.otp_nhwc_conv_pack_job(hip.ptr(weight), hip.ptr(wp), ctypes.byref(d), int(dgrad), job),
                   "otp_nhwc_conv_pack_job")
         self.jobs += job.raw
-        self.entries[key] = (wp, weight.detach())
+        self.entries[key] = (wp, weight.detach(), job.raw)
         self.dirty = True
         return wp
 
     def repack(self, device):
         """All recorded operators from the current weights, on the current stream of ``device``."""
+        if not self.entries:
+            return
+        if any(e[0].device != device for e in self.entries.values()):
+            self.clear()                          # the model moved: every pointer in the table belongs to the old device
+            return
+        if self.used and len(self.used) < len(self.entries):
+            # entries of weights that moved or of launches that no longer happen: retire them (keep-alives released)
+            self.entries = {k: e for k, e in self.entries.items() if k in self.used}
+            self.jobs = bytearray(b"".join(e[2] for e in self.entries.values()))
+            self.dirty = True
+        self.used = set()
         if not self.entries:
             return
         if self.dirty or self.table is None or self.table.device != device:

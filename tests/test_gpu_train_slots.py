@@ -162,3 +162,30 @@ def test_two_forwards_one_backward(dtype):
     glob, worst, wname = _grad_err(triples, None)
     print("two forwards %s: whole-gradient rel L2 %.2e, worst tensor %.2e (%s)" % (dtype, glob, worst, wname))
     assert glob <= GRAD_TOL[dtype], glob
+
+
+def test_pack_cache_retires_entries_of_weights_that_moved():
+    """bf16_ops.PackCache (one weight re-layout launch per step): building FusedAdamW after a first forward re-homes every
+    ``p.data`` into the flat buffer, so the next forward records new jobs - the old ones (which pin a full copy of the old fp32
+    weights and would be re-packed every step) must be gone one forward later, and the step must still match."""
+    cfg, a, b = _pair("bf16")
+    x, margin = S.synthetic_clip(2, cfg.MODEL.IMAGE_SIZE)
+    x, margin = x.cuda(), margin.cuda()
+    J, (w, h) = cfg.MODEL.NUM_JOINTS, cfg.MODEL.HEATMAP_SIZE
+    g, wt = _targets(2, J, h, w)
+    _loss(a, x, margin, g, wt).backward()
+    cache = a.__dict__["_otp_pack_cache"]
+    n0 = len(cache)
+    assert n0 > 100
+    for p in a.parameters():
+        p.grad = None
+    opt = FusedAdamW([p for p in a.parameters() if p.requires_grad], lr=LR, weight_decay=WD, max_grad_norm=CLIP)   # moves p.data
+    opt.zero_grad()
+    la = _loss(a, x, margin, g, wt)
+    la.backward()
+    assert len(cache) == 2 * n0                       # old + new storage addresses, until the next forward's repack
+    lb = _loss(b, x, margin, g, wt)
+    assert abs(float(la) - float(lb)) <= 1e-5 * max(1.0, abs(float(lb)))
+    opt.zero_grad()
+    _loss(a, x, margin, g, wt).backward()
+    assert len(cache) == n0
