@@ -74,10 +74,10 @@ __device__ __forceinline__ void mx_split8(const float (&v)[8], bf16x8& hi, bf16x
 constexpr int mx_ks1(int C) { return (C + 31) / 32; }
 constexpr int mx_mt(int C) { return (C + 15) / 16; }
 // bytes of one 32-hidden-channel block: W1 fragments [2 tiles][ks][hi, lo][1 KB], W2 fragments [mt][hi, lo][1 KB], b1[32],
-// rounded up to whole 8 KB (512 threads x 16 bytes) so that every copy pass is full
+// rounded up to whole KB (one LDS-DMA instruction of a wave); the last copy pass of a workgroup may be partial
 constexpr int mx_w1_bytes(int C) { return 2 * mx_ks1(C) * 2 * 1024; }
 constexpr int mx_w2_bytes(int C) { return mx_mt(C) * 2 * 1024; }
-constexpr int mx_block_bytes(int C) { return (mx_w1_bytes(C) + mx_w2_bytes(C) + 128 + 8191) / 8192 * 8192; }
+constexpr int mx_block_bytes(int C) { return (mx_w1_bytes(C) + mx_w2_bytes(C) + 128 + 1023) / 1024 * 1024; }
 
 __global__ void mlpx_pack_kernel(const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
                                  unsigned char* __restrict__ packed, int C, int HID) {
@@ -123,11 +123,12 @@ __global__ void mlpx_pack_kernel(const float* __restrict__ w1, const float* __re
 // copy one weight block global -> LDS with the LDS-DMA: unit u (16 bytes) of the block lands at lds + 16 u
 template <int NTHR, int BLKB>
 __device__ __forceinline__ void mx_stage(const unsigned char* __restrict__ src, unsigned char* lds) {
-    constexpr int NST = BLKB / 16 / NTHR;
+    constexpr int NST = (BLKB / 16 + NTHR - 1) / NTHR;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
 #pragma unroll
     for (int i = 0; i < NST; ++i) {
         const int u0 = i * NTHR + wave * 64;                       // wave-uniform first unit of this wave-instruction
+        if (u0 * 16 >= BLKB) break;                                // (whole KB: a wave-instruction is inside the block or past it)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)(u0 + lane) * 16),
                                          (__attribute__((address_space(3))) void*)(lds + u0 * 16), 16, 0, 0);
     }
