@@ -833,9 +833,10 @@ class InferenceEngine:
         if x.dtype == torch.uint8:
             # (B, 5, H, W, 3) uint8 frames: normalise + concatenate straight into the stem conv's input buffer
             ops.frames_to_clip(x, out=self.inp)
-        else:
+        elif x.data_ptr() != self.inp.data_ptr():         # (a caller that fills OTPose.input_buffers() in place skips the copy)
             self.inp.copy_(x)
-        self.margin.copy_(margin.to(torch.float32))
+        if margin.data_ptr() != self.margin.data_ptr():
+            self.margin.copy_(margin.to(torch.float32))
         if self.use_graph and self.graph is None:
             self._launch_all()                      # warm-up (sets kernel attributes) before capture
             torch.cuda.synchronize(self.dev)

@@ -216,6 +216,18 @@ class OTPose(nn.Module):
             self._engine = InferenceEngine(self, b, frames_u8.device)
         return self._engine.run(frames_u8, margin, self.alias_outputs)
 
+    def input_buffers(self, batch, device):
+        """The eval engine's own input tensors for ``batch`` clips on ``device``: ``(x (B, 3 F, H, W) fp32, margin (B, F - 1)
+        fp32)``.  A data loader that writes the next batch straight into them and passes them to ``forward`` saves the
+        per-call device-to-device copy (106 MB at cfg2) - ``forward`` recognises its own buffers by address."""
+        from .engine import InferenceEngine
+        device = torch.device(device)
+        w_img, h_img = self.cfg.MODEL.IMAGE_SIZE
+        f = getattr(self, "window_frames", 5)
+        if self._engine is None or not self._engine.matches_shape(batch, 3 * f, h_img, w_img, device):
+            self._engine = InferenceEngine(self, batch, device)
+        return self._engine.inp, self._engine.margin
+
     def invalidate_engine(self):
         """Drop packed weights (call after changing parameters, e.g. load_state_dict)."""
         self._engine = None

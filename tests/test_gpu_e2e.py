@@ -209,3 +209,23 @@ def test_e2e_cfg2_two_clips_with_a_sequence_border(golden):
     assert errs["context"] <= TOL * max(1.0, float(g["cfg2_b2_context"].abs().max()))
     for o, mx in zip(outs, g["cfg2_b2_absmax"].tolist()):
         assert abs(float(o.abs().max()) - mx) <= TOL * max(1.0, mx)
+
+
+def test_forward_from_the_engines_own_input_buffers():
+    """OTPose.input_buffers(): a caller that writes the batch into the engine's input tensors in place gets the same result as
+    one that hands in its own tensors (which the engine copies)."""
+    cfg = tiny_cfg(8, (64, 96))
+    m = OTPose(cfg)
+    S.fill_synthetic_(m)
+    m = m.cuda().eval()
+    x, margin = S.synthetic_clip(3, cfg.MODEL.IMAGE_SIZE)
+    with torch.no_grad():
+        ref = [o.clone() for o in m(x.cuda(), margin=margin.cuda())]
+        xb, mb = m.input_buffers(3, "cuda")
+        assert m._engine is not None and xb.shape == x.shape and mb.shape == margin.shape
+        xb.copy_(torch.roll(x, 1, 0).cuda())
+        mb.copy_(torch.roll(margin, 1, 0).cuda().float())
+        rolled = m(xb, margin=mb)
+        for a, b in zip(ref, rolled):
+            if a.shape[0] == 3:
+                assert torch.equal(torch.roll(a, 1, 0), b)
