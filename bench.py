@@ -272,7 +272,7 @@ def kernel_rooflines(dev, batch):
             packed = ops.pack_mlp_x3_weights(w1, b1, w2)
             t_mlp = event_time_ms(lambda: ops.ln_mlp_x3(xm, one, zero, 1e-5, packed, one, zero, out=om), 20, st)
             executed = 3.0 * 2.0 * (160 * HID + HID * 144) * batch * T
-            nt1 = os.environ.get("OTP_MLP_NT1", "0") == "1" and os.environ.get("OTP_MLP_BALANCED") != "2"
+            nt1 = os.environ.get("OTP_MLP_NT1", "1") != "0" and os.environ.get("OTP_MLP_BALANCED") != "2"
             peak = PEAK_BF16_MATRIX
             kn = ("mlpx_kernel<136,544,8,true,1> (one token tile per wave, two workgroups per CU)" if nt1 else
                   "mlpx_balanced_kernel<136,544,true>" if balanced else "mlpx_kernel<136,544,8,true,2>")

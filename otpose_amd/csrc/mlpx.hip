@@ -366,15 +366,15 @@ int mlpx_launch(const void* x, const void* packed, const void* scale, const void
         return otp_launch_status();
     }
     const size_t lds = 2 * (size_t)mx_block_bytes(136);
-    // OTP_MLP_NT1=1 (experiment, NOT the default): one token tile per wave (NT = 1), 128 tokens per 8-wave workgroup, <= 128
-    // VGPRs, i.e. TWO workgroups per CU - 132 us at cfg2 against 149 for the balanced form, but with it the batch-16 forward
-    // is no longer bit-identical across hipGraph replays (1-2 replays in 10 differ in one clip of `output` by up to 6e-4;
-    // tools/replay_determinism.py): two 80 KB workgroups of this LDS-DMA-fed kernel on one CU hit the co-residency corruption
-    // of DESIGN.md section 3.1d.  OTP_MLP_BALANCED "0": never balanced, "2": whenever the shape allows (tests).
+    // Default: one token tile per wave (NT = 1), 128 tokens per 8-wave workgroup, <= 128 VGPRs, i.e. TWO 80 KB workgroups per CU
+    // - 132 us at cfg2 against 149 for the balanced form.  (Opt-in until the packed-fp32 op_sel hazard of DESIGN.md section 3.1d
+    // was found: the forward's replays differed with it - through the kernels of csrc/densex.hip next to it, not through this
+    // one.)  OTP_MLP_NT1=0: the older forms - two token tiles per wave, or the balanced two-pass kernel from B * T / 432 >= 192;
+    // OTP_MLP_BALANCED "0": never balanced, "2": balanced whenever the shape allows (tests).
     const char* bal = getenv("OTP_MLP_BALANCED");
     const bool bal_off = bal && bal[0] == '0', bal_force = bal && bal[0] == '2';
     const char* e1 = getenv("OTP_MLP_NT1");
-    const bool nt1 = e1 && e1[0] == '1';
+    const bool nt1 = !(e1 && e1[0] == '0');
     if (nt1 && !bal_force) {
         constexpr int WAVES = 8;
         const int tiles = otp_ceil_div(T, WAVES * 16);

@@ -311,7 +311,7 @@ def test_mlp_x3_matches_fp64(T, C, monkeypatch):
     if T % 432 == 0:
         monkeypatch.setenv("OTP_MLP_BALANCED", "2")         # the balanced two-pass form (one workgroup per 27 column tiles)
     elif T == 250:
-        monkeypatch.setenv("OTP_MLP_NT1", "1")              # one token tile per wave, two workgroups per CU (opt-in form)
+        monkeypatch.setenv("OTP_MLP_NT1", "0")              # two token tiles per wave (the default is one: two workgroups per CU)
     x, res = seeded((B, C, T), 11), seeded((B, C, T), 12)
     w1, w2 = seeded((HID, C, 1), 13) / C ** 0.5, seeded((C, HID, 1), 14) / HID ** 0.5
     b1, b2, sc = seeded((HID,), 15) * 0.5, seeded((C,), 16), seeded((C,), 17)
