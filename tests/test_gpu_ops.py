@@ -302,7 +302,7 @@ def test_mlp_fused_matches_fp64(T, monkeypatch):
 
 
 @pytest.mark.parametrize("C", [136, 204])
-@pytest.mark.parametrize("T", [32, 250, 1152, 864])
+@pytest.mark.parametrize("T", [32, 250, -250, 1152, 864])
 def test_mlp_x3_matches_fp64(T, C, monkeypatch):
     """csrc/mlpx.hip (split-bf16 products) vs the same fp64 MLP as test_mlp_fused_matches_fp64.  Tolerance 2e-5 of the output
     range: two bf16 pieces per operand carry 16 mantissa bits + rounding (measured 3e-6; the f32-MFMA kernel 4e-7).
@@ -310,7 +310,8 @@ def test_mlp_x3_matches_fp64(T, C, monkeypatch):
     B, HID = 2, 4 * C
     if T % 432 == 0:
         monkeypatch.setenv("OTP_MLP_BALANCED", "2")         # the balanced two-pass form (one workgroup per 27 column tiles)
-    elif T == 250:
+    elif T < 0:
+        T = -T
         monkeypatch.setenv("OTP_MLP_NT1", "0")              # two token tiles per wave (the default is one: two workgroups per CU)
     x, res = seeded((B, C, T), 11), seeded((B, C, T), 12)
     w1, w2 = seeded((HID, C, 1), 13) / C ** 0.5, seeded((C, HID, 1), 14) / HID ** 0.5
