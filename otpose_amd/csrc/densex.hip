@@ -87,7 +87,12 @@ __device__ __forceinline__ void dx_stage(const unsigned char* __restrict__ src, 
     }
 }
 
-// all MT output blocks of one problem for the wave's 32 tokens: X (split fragments) x streamed weight blocks -> out
+// all MT output blocks of one problem for the wave's 32 tokens: X (split fragments) x streamed weight blocks -> out.
+// Every wave issues the SAME vector-memory instructions per block - residual loads, the DMA of the next block, four result stores,
+// lanes without a token or channel masked by an out-of-range buffer offset - so the barrier at the end of a block can wait for
+// the DMA alone (`s_waitcnt vmcnt(4)`: all but the four stores, which stay in flight under the next block's MFMAs) instead of
+// the `vmcnt(0)` of __syncthreads(), which made every block pay a store round trip.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 template <int C, bool RES>
 __device__ __forceinline__ void dx_project(const bf16x8 (&Xh)[dx_ks(C)][2], const bf16x8 (&Xl)[dx_ks(C)][2],
                                            const unsigned char* __restrict__ packed, unsigned char* lds,
@@ -95,9 +100,22 @@ __device__ __forceinline__ void dx_project(const bf16x8 (&Xh)[dx_ks(C)][2], cons
                                            bool valid) {
     constexpr int KS = dx_ks(C), MT = (C + 15) / 16, BLKB = dx_block_bytes(C);
     const int lane = threadIdx.x & 63, kq = lane >> 4;
+    const unsigned plane = (unsigned)((size_t)C * T * sizeof(float));
+    const otp_rsrc ro = make_rsrc32(out + base, plane);
+    const otp_rsrc rr = make_rsrc32(RES && res ? res + base : out, RES && res ? plane : 0u);   // no residual: every load reads 0
 #pragma unroll 1
     for (int mt = 0; mt < MT; ++mt) {
+        int voff[4];
+        f32x2 r[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = 16 * mt + 4 * kq + i;
+            voff[i] = (valid && c < C) ? (c * T + tok) * 4 : -16;                // masked lanes: past the descriptor
+            if (RES) r[i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rr, voff[i], 0, 0));
+        }
+        asm volatile("" ::: "memory");
         if (mt + 1 < MT) dx_stage<BLKB>(packed + (size_t)(mt + 1) * BLKB, lds + ((mt + 1) & 1) * BLKB);
+        asm volatile("" ::: "memory");
         const unsigned char* P = lds + (mt & 1) * BLKB;
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -113,21 +131,17 @@ __device__ __forceinline__ void dx_project(const bf16x8 (&Xh)[dx_ks(C)][2], cons
         }
         const f32x4 sc = *reinterpret_cast<const f32x4*>(P + KS * 2048 + 16 * kq);
         const f32x4 sh = *reinterpret_cast<const f32x4*>(P + KS * 2048 + 64 + 16 * kq);
-        if (valid) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int c = 16 * mt + 4 * kq + i;
-                if (c < C) {
-                    const size_t o = base + (size_t)c * T + tok;
-                    f32x2 v = {acc0[i] * sc[i] + sh[i], acc1[i] * sc[i] + sh[i]};
-                    if (RES) {
-                        if (res) v += *reinterpret_cast<const f32x2*>(res + o);
-                    }
-                    *reinterpret_cast<f32x2*>(out + o) = v;
-                }
-            }
+        for (int i = 0; i < 4; ++i) {
+            f32x2 v = {acc0[i] * sc[i] + sh[i], acc1[i] * sc[i] + sh[i]};
+            if (RES) v += r[i];
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), ro, voff[i], 0, 0);
         }
-        __syncthreads();                              // block mt consumed by every wave, block mt + 1 landed
+        if (mt + 1 < MT) {
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // this wave's part of block mt + 1 has landed; the stores fly on
+            __builtin_amdgcn_s_barrier();                         // block mt consumed by every wave, block mt + 1 landed for all
+            asm volatile("" ::: "memory");
+        }
     }
 }
 

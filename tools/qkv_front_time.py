@@ -25,3 +25,16 @@ for _ in range(20):
 b.record()
 torch.cuda.synchronize()
 print("qkv front x3: %.1f us (checksum %.6e)" % (a.elapsed_time(b) / 20 * 1e3, float(outs[0].double().abs().sum())))
+# the C -> C projection (+ residual) of the same encoder, one problem
+res = torch.randn(B, C, T, generator=g).cuda()
+pk = ops.pack_dense_cc(ws[0], gs[0], bs[0], x3=True)
+po = torch.empty_like(x)
+f2 = lambda: ops.dense_cc([x], [pk], [res], [po], x3=True)   # noqa: E731
+f2()
+torch.cuda.synchronize()
+a.record()
+for _ in range(20):
+    f2()
+b.record()
+torch.cuda.synchronize()
+print("projection x3: %.1f us (checksum %.6e)" % (a.elapsed_time(b) / 20 * 1e3, float(po.double().abs().sum())))
