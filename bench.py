@@ -177,14 +177,14 @@ def kernel_rooflines(dev, batch):
         rc4, oc4 = ops.c4_empty(n, 48, 96, 72, dev), ops.c4_empty(n, 48, 96, 72, dev)
         ops.s8_pack(torch.randn(n, 48, 96, 72, generator=g).to(dev), out_c4=rc4)
         t_conv2 = event_time_ms(lambda: ops.conv3x3_s8_launch(xs, ws, sh, ds, rc4, oc4, ops.S8_F32_C4, ys), 20, st)
-        kname = ("convs_kernel<3, false> (bf16x3 split products, S8 operand records, LDS-DMA, 3 workgroups / CU) 48->48 3x3 @96x72 x%d frames, S8 -> S8 "
+        kname = ("convs_kernel<3, false, 4> (bf16x3 split products, S8 operand records, LDS-DMA, 3 workgroups / CU) 48->48 3x3 @96x72 x%d frames, S8 -> S8 "
                  "(grid %d x 256 threads)" % (n, ((n * 96 * 72 // 256 + 7) // 8) * 8))
         executed = conv_flop * 3.0 * 10.0 / 9.0
         peak = PEAK_BF16_MATRIX
         tr2, _ = measured_traffic("convs_48_48_3x3_96x72_x80_conv2", True)
         extra = {"arithmetic": "fp32 accumulate; operands stored as bf16 hi | lo records (hi = rne(x), lo = rne(x - hi)), products "
                                "lo*hi + hi*lo + hi*hi (csrc/convs.hip)",
-                 "pmc": "profiles/r03b_convs_pmc_fold.txt: SQ_INSTS_VALU 10.65 M of which 4.67 M MFMA = 1.28 other vector "
+                 "pmc": "profiles/r03c_convs_pmc_fold.txt: SQ_INSTS_VALU 11.07 M of which 4.67 M MFMA = 1.37 other vector "
                         "instructions per MFMA (prologue / epilogue), SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 6 %",
                  "conv2_form": {"what": "S8 + C4 residual -> C4 + S8 (BasicBlock conv2)", "ms_per_launch": t_conv2,
                                 "achieved": conv_flop / (t_conv2 * 1e-3) / 1e12, "frac": executed / (t_conv2 * 1e-3) / peak,
