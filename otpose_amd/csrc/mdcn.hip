@@ -24,7 +24,13 @@
 namespace {
 
 constexpr int PADL = 4;      // LDS column PADL-1 holds x = -1 (zero); data starts 16-byte aligned at PADL
-constexpr int FWD_THREADS = 256;
+// 512 threads: 14 tiles x 16 images = 224 workgroups of 8 waves - one per CU, two waves per SIMD - at cfg2; a workgroup stages
+// every input plane whole, so twice the pixels per workgroup halve the staging per pixel (64.3 -> 58.3 us against 256 threads,
+// 432 workgroups, 1.7 per CU)
+#ifndef OTP_DCN_THREADS
+#define OTP_DCN_THREADS 512
+#endif
+constexpr int FWD_THREADS = OTP_DCN_THREADS;
 
 struct Geom {
     int N, C, H, W, Co, K, kh, kw, stride, pad, dil, Ho, Wo, P;
@@ -107,7 +113,7 @@ __device__ __forceinline__ void stage_plane(float* __restrict__ plane, const flo
 // forward
 // ------------------------------------------------------------------------------------------------
 // CO_T : output channels accumulated per workgroup pass (blockIdx.z walks Cout in chunks of CO_T)
-// VEC  : output pixels per thread (pixel p = tile*256*VEC + v*256 + tid: coalesced dword streams,
+// VEC  : output pixels per thread (pixel p = (tile*VEC + v)*FWD_THREADS + tid: coalesced dword streams,
 //        conflict-free LDS gathers for smooth offset fields)
 // K9   : kernel is 3x3 (taps unrolled, offset/mask streams of a plane prefetched into registers)
 template <int CO_T, int VEC, bool K9>
@@ -183,8 +189,8 @@ __global__ __launch_bounds__(FWD_THREADS, 2) void mdcn_fwd_kernel(
         };
         // Plane pipeline: while plane c is gathered out of one LDS buffer, plane c+1 travels global -> registers ->
         // the other buffer, so a plane change costs one barrier and no exposed memory round trip.  (W % 4 == 0 and
-        // planes of at most MAXQ*256 float4; otherwise the plane is staged in place between two barriers.)
-        constexpr int MAXQ = 8;
+        // planes of at most 2048 float4; otherwise the plane is staged in place between two barriers.)
+        constexpr int MAXQ = 8 * 256 / FWD_THREADS;
         const int wq = g.W >> 2, nq = g.H * wq;
         const bool piped = (g.W & 3) == 0 && nq <= MAXQ * FWD_THREADS;
         otp_f32x4 pq[MAXQ];                                    // (ext-vector type: stays in registers)
