@@ -9,6 +9,7 @@ kernels in both directions; PyTorch supplies memory, streams and the tape.  CPU 
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 from torch.autograd import Function
@@ -223,7 +224,35 @@ def _workspace(device, nbytes):
     return buf
 
 
+_WG_STREAMS = {}          # (device index, launching stream) -> its weight-gradient side stream
+_WG_PENDING = []          # side streams with work of the running backward pass on them
+
+
+def _wgrad_side_stream(device):
+    cur = torch.cuda.current_stream(device)
+    key = (device.index, cur.cuda_stream)
+    side = _WG_STREAMS.get(key)
+    if side is None:
+        side = _WG_STREAMS[key] = torch.cuda.Stream(device)
+    return cur, side
+
+
+def join_wgrad_streams():
+    """The current stream waits for every weight-gradient launch of the backward pass that has just run (they go to side
+    streams: :func:`conv_wgrad`).  Runs as an autograd engine callback at the end of the pass - on the stream ``backward()``
+    was called on - and again at the head of ``FusedAdamW.step`` / ``grad_norm``."""
+    while _WG_PENDING:
+        side = _WG_PENDING.pop()
+        torch.cuda.current_stream(side.device).wait_stream(side)
+
+
 def conv_wgrad(x, gy, weight_shape, stride, pad, dil, out=None):
+    """dL/dW of a convolution (fp32, summed over the batch).  A weight gradient is a LEAF of the backward pass - nothing of
+    the pass waits for it - while the input gradient next to it is on the critical chain: when the result goes straight
+    into the optimizer's flat gradient buffer (``out`` = :func:`otpose_amd.train_ops.grad_slot`, so autograd launches
+    nothing on it) the two kernels of the weight gradient are enqueued on a side stream of the launching stream and overlap
+    with the chain (``OTPOSE_WGRAD_STREAM=0``: same stream).  ``x`` / ``gy`` are registered with the caching allocator for
+    that stream; :func:`join_wgrad_streams` orders the consumers."""
     cout, cin, kh, kw = weight_shape
     n, h, w, _ = x.shape
     d = _desc(n, h, w, cin, cout, kh, kw, stride, pad, dil, 0)
@@ -231,6 +260,23 @@ def conv_wgrad(x, gy, weight_shape, stride, pad, dil, out=None):
     nbytes = L.otp_nhwc_wgrad_workspace(ctypes.byref(d))
     if nbytes == 0:
         raise RuntimeError("otp_nhwc_wgrad: unsupported convolution shape")
+    if out is not None and os.environ.get("OTPOSE_WGRAD_STREAM", "1") != "0":
+        cur, side = _wgrad_side_stream(x.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            ws = _workspace(x.device, nbytes)
+            hip.check(L.otp_nhwc_wgrad_bf16(hip.ptr(x), hip.ptr(gy), hip.ptr(out), hip.ptr(ws), nbytes, ctypes.byref(d),
+                                            hip.stream_of(x)), "otp_nhwc_wgrad_bf16")
+        x.record_stream(side)
+        gy.record_stream(side)
+        if not _WG_PENDING:
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(join_wgrad_streams)
+            except RuntimeError:              # called outside a backward pass: the optimizer (or the caller) joins
+                pass
+        if side not in _WG_PENDING:
+            _WG_PENDING.append(side)
+        return out
     ws = _workspace(x.device, nbytes)
     gw = out if out is not None else _new(weight_shape, torch.float32, x)
     hip.check(L.otp_nhwc_wgrad_bf16(hip.ptr(x), hip.ptr(gy), hip.ptr(gw), hip.ptr(ws), nbytes, ctypes.byref(d),

@@ -70,6 +70,8 @@ class FusedAdamW(torch.optim.Optimizer):
         allreduce_flat_grads() would see zeros: copy such a gradient back and re-point the view.  A parameter whose
         gradient is None keeps a zero slot (its weight decay / moment update then match torch.optim.AdamW only if the
         caller really meant "zero gradient"; use this optimizer's own zero_grad() to keep the views)."""
+        from .bf16_ops import join_wgrad_streams
+        join_wgrad_streams()                  # weight gradients enqueued on side streams (bf16_ops.conv_wgrad)
         for f in self._flat:
             if not f:
                 continue
