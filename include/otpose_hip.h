@@ -298,6 +298,19 @@ int otp_dense_x3(const void* const* x, const void* const* packed, const void* co
 int otp_qkv_front_x3(const void* x, const void* table, const void* packed_q, const void* packed_k, const void* packed_v,
                      void* q, void* k, void* v, int B, int C, int T, float eps, void* stream);
 
+/* Pointwise (1x1, stride 1) convolution Cin -> Cout on fp32 NCHW channel slices with split-bf16 products (csrc/pointx.hip):
+ * HRNet layer1's Bottleneck convs (model/HRNet.py:551-571: 256 -> 64, 64 -> 256 + residual, the shortcut folded over the
+ * concatenation 128 -> 256), what nn.Conv2d(k = 1) + folded BatchNorm2d + ReLU compute there:
+ *   out[b, out_coff + o, t] = act(scale[o] * sum_c w[o, c] * x[b, x_coff + c, t] + shift[o] (+ res[b, res_coff + o, t]))
+ * x / res / out: (B, ctot, T) fp32, T = H * W pixels; Cin in {64, 128, 256}, Cout <= 256 and a multiple of 4, T even;
+ * packed: otp_pointwise_x3_weight_bytes(Cin, Cout) bytes from otp_pointwise_x3_pack (w: (Cout, Cin) fp32; scale / shift may
+ * be NULL = 1 / 0); relu != 0 clamps at zero.  OTP_ERR_UNSUPPORTED for other shapes (the caller keeps otp_conv2d_x3). */
+int otp_pointwise_x3_supported(int Cin, int Cout, int T);
+size_t otp_pointwise_x3_weight_bytes(int Cin, int Cout);
+int otp_pointwise_x3_pack(const void* w, const void* scale, const void* shift, void* packed, int Cin, int Cout, void* stream);
+int otp_pointwise_x3(const void* x, const void* packed, const void* res, void* out, int B, int Cin, int Cout, int T, int x_ctot,
+                     int x_coff, int res_ctot, int res_coff, int out_ctot, int out_coff, int relu, void* stream);
+
 /* The same operator with split-bf16 ("bf16x3") products on the bf16 matrix cores (csrc/mlpx.hip): fp32 storage, fp32
  * accumulation, LayerNorm / bias / GELU in fp32; each product is lo*hi + hi*lo + hi*hi of two bf16 pieces per operand.
  * Own packed image (otp_mlp_x3_weight_bytes / otp_mlp_x3_pack); same arguments and aliasing rules as otp_mlp_fused /

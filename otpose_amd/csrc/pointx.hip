@@ -1,0 +1,247 @@
+// Pointwise (1x1) convolutions Cin -> Cout of HRNet's layer1 Bottlenecks (reference model/HRNet.py:551-571: conv1 256 -> 64,
+// conv3 64 -> 256 + residual, the folded shortcut 128 -> 256; BatchNorm folded into scale / shift, ReLU) with split-bf16
+// ("bf16x3") products - the same operator as csrc/convx.hip in its 1x1 mode, built like csrc/densex.hip instead: these
+// layers move 0.7 GB each at cfg2 and do 9 MFLOP per pixel, so they are bound by their HBM streams, and the implicit-GEMM
+// kernel (window through the LDS, one barrier per 32-channel chunk) ran them at a third of the HBM rate.
+// Register-resident input: a wave owns 32 pixels and holds their Cin channels as split B-operand fragments (lane (pixel
+// pair n, kq): channels 32 ks + 8 kq .. + 7); the weights stream through the LDS in blocks of 8 / KS sixteen-row output
+// tiles (16 KB: LDS-DMA, double buffered, one barrier per block that waits for the DMA alone - the result stores stay in flight);
+// a tile's 16 x 32 result is scaled, shifted, added to the residual, clamped and stored as soon as its 6 KS MFMAs are done.
+// Tensors are fp32 NCHW channel slices: (ctot, coff) per operand, as everywhere in the engine.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void px_split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+    uint32_t h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x2 a = {v[2 * i], v[2 * i + 1]};
+        const uint32_t hb = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, bf16x2));
+        const f32x2 af = {__builtin_bit_cast(float, hb << 16), __builtin_bit_cast(float, hb & 0xffff0000u)};
+        h[i] = hb;
+        l[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(a - af, bf16x2));
+    }
+    hi = __builtin_bit_cast(bf16x8, (u32x4){h[0], h[1], h[2], h[3]});
+    lo = __builtin_bit_cast(bf16x8, (u32x4){l[0], l[1], l[2], l[3]});
+}
+
+constexpr int px_ks(int CIN) { return CIN / 32; }
+constexpr int px_mpb(int CIN) { return 8 / px_ks(CIN); }                // 16-row output tiles per weight block
+// a weight block: A fragments [tile][ks][hi, lo][1 KB] = 16 KB for every Cin (four whole passes of the 256 threads); scale and
+// shift (Cout <= 256 floats each) follow the blocks in the packed image and stay in the LDS for the whole kernel
+constexpr int px_block_bytes(int CIN) { return px_mpb(CIN) * px_ks(CIN) * 2048; }
+constexpr int PX_MAX_COUT = 256;
+
+__global__ void pointx_pack_kernel(const float* __restrict__ w, const float* __restrict__ scale, const float* __restrict__ shift,
+                                   unsigned char* __restrict__ packed, int Cin, int Cout, int nblk) {
+    const int KS = Cin / 32, MPB = 8 / KS, units = 1024;                    // 16-byte units per 16 KB block
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < nblk * units) {
+        const int blk = idx / units, u = idx - blk * units;
+        const int frag = u >> 6, lane = u & 63, m = frag / (KS * 2), f2 = frag - m * KS * 2, ks = f2 >> 1;
+        const int row = 16 * (blk * MPB + m) + (lane & 15), kq = lane >> 4;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = row < Cout ? w[(size_t)row * Cin + 32 * ks + 8 * kq + j] : 0.f;
+        bf16x8 hi, lo;
+        px_split8(v, hi, lo);
+        reinterpret_cast<u32x4*>(packed)[idx] = __builtin_bit_cast(u32x4, (f2 & 1) ? lo : hi);
+    } else if (idx < nblk * units + 2 * PX_MAX_COUT / 4) {                  // [scale 256][shift 256] floats
+        const int q = idx - nblk * units;
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = 4 * q + i, c = e & (PX_MAX_COUT - 1);
+            v[i] = c < Cout ? (e < PX_MAX_COUT ? (scale ? scale[c] : 1.f) : (shift ? shift[c] : 0.f)) : 0.f;
+        }
+        reinterpret_cast<u32x4*>(packed)[idx] = (u32x4){__builtin_bit_cast(uint32_t, v[0]), __builtin_bit_cast(uint32_t, v[1]),
+                                                        __builtin_bit_cast(uint32_t, v[2]), __builtin_bit_cast(uint32_t, v[3])};
+    }
+}
+
+// one weight block global -> LDS with the LDS-DMA (256 threads, four passes): unit u (16 bytes) lands at lds + 16 u
+template <int BLKB>
+__device__ __forceinline__ void px_stage(const unsigned char* __restrict__ src, unsigned char* lds) {
+    constexpr int NST = BLKB / 16 / 256;
+    static_assert(NST * 256 * 16 == BLKB, "whole passes");
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+        const int u0 = i * 256 + wave * 64;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)(u0 + lane) * 16),
+                                         (__attribute__((address_space(3))) void*)(lds + u0 * 16), 16, 0, 0);
+    }
+}
+
+struct PxArgs {
+    const float* x;
+    const unsigned char* packed;
+    const float* res;
+    float* out;
+    int T, tiles_per_b, Cout, nblk, relu;
+    int x_ctot, x_coff, r_ctot, r_coff, o_ctot, o_coff;
+};
+
+template <int CIN, bool RES>
+__global__ __launch_bounds__(256, CIN <= 128 ? 3 : 2) void pointx_kernel(PxArgs A) {
+    constexpr int KS = px_ks(CIN), MPB = px_mpb(CIN), BLKB = px_block_bytes(CIN);
+    // (ONE LDS object: with scale / shift in an array of their own hipcc 7.2 drains vmcnt in front of the first fragment read
+    // after every DMA issue)
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BLKB + 2 * PX_MAX_COUT * 4];
+    float* ss = reinterpret_cast<float*>(lds + 2 * BLKB);                    // scale[256], shift[256]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kq = lane >> 4, n = lane & 15;
+    const int b = blockIdx.x / A.tiles_per_b, tile = blockIdx.x - b * A.tiles_per_b;
+    const int T = A.T, tok = tile * 128 + wave * 32 + 2 * n;
+    const bool valid = tok < T;
+    px_stage<BLKB>(A.packed, lds);
+    if (tid < 2 * PX_MAX_COUT / 4)
+        reinterpret_cast<f32x4*>(ss)[tid] = reinterpret_cast<const f32x4*>(A.packed + (size_t)A.nblk * BLKB)[tid];
+    const float* __restrict__ x = A.x + ((size_t)b * A.x_ctot + A.x_coff) * T + (valid ? tok : T - 2);
+    bf16x8 Xh[KS][2], Xl[KS][2];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        float v0[8], v1[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const f32x2 v = *reinterpret_cast<const f32x2*>(x + (size_t)(32 * ks + 8 * kq + j) * T);
+            v0[j] = v.x;
+            v1[j] = v.y;
+        }
+        px_split8(v0, Xh[ks][0], Xl[ks][0]);
+        px_split8(v1, Xh[ks][1], Xl[ks][1]);
+    }
+    const unsigned plane = (unsigned)((size_t)A.Cout * T * sizeof(float));
+    const otp_rsrc ro = make_rsrc32(A.out + ((size_t)b * A.o_ctot + A.o_coff) * T, plane);
+    const otp_rsrc rr = make_rsrc32(RES ? A.res + ((size_t)b * A.r_ctot + A.r_coff) * T : A.out, RES ? plane : 0u);
+    const float lo_clamp = A.relu ? 0.f : -__builtin_inff();
+    __syncthreads();                                   // weight block 0 and scale / shift landed
+    // Every wave issues the SAME vector-memory instructions per block - residual loads, the DMA of the next block, 4 MPB stores,
+    // lanes without a pixel or channel masked by an out-of-range offset - so the barrier can wait for the DMA alone
+    // (`s_waitcnt vmcnt(4 MPB)`: all but the stores, which stay in flight under the next block).  The compiler waits for
+    // EVERYTHING in front of the first use of a residual value (an LDS-DMA is pending), so all of a block's MFMAs come first.
+#pragma unroll 1
+    for (int blk = 0; blk < A.nblk; ++blk) {
+        int voff[MPB][4];
+        f32x2 r[MPB][4];
+#pragma unroll
+        for (int m = 0; m < MPB; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = 16 * (blk * MPB + m) + 4 * kq + i;
+                voff[m][i] = (valid && c < A.Cout) ? (c * T + tok) * 4 : -16;
+                if (RES) r[m][i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rr, voff[m][i], 0, 0));
+            }
+        asm volatile("" ::: "memory");
+        // (the last trip re-stages block 0, which nobody reads: every wave issues the same instructions on every trip)
+        px_stage<BLKB>(A.packed + (size_t)(blk + 1 < A.nblk ? blk + 1 : 0) * BLKB, lds + ((blk + 1) & 1) * BLKB);
+        asm volatile("" ::: "memory");
+        const unsigned char* P = lds + (blk & 1) * BLKB;
+        f32x4 acc[MPB][2];
+#pragma unroll
+        for (int m = 0; m < MPB; ++m) {
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(P + ((m * KS + ks) * 2) * 1024 + lane * 16);
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(P + ((m * KS + ks) * 2 + 1) * 1024 + lane * 16);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, Xh[ks][0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, Xh[ks][1], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, Xl[ks][0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, Xl[ks][1], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, Xh[ks][0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, Xh[ks][1], acc1, 0, 0, 0);
+            }
+            acc[m][0] = acc0;
+            acc[m][1] = acc1;
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int m = 0; m < MPB; ++m) {
+            const int c0 = (16 * (blk * MPB + m) + 4 * kq) & (PX_MAX_COUT - 1);
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(ss + c0);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(ss + PX_MAX_COUT + c0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x2 v = {acc[m][0][i] * sc[i] + sh[i], acc[m][1][i] * sc[i] + sh[i]};
+                if (RES) v += r[m][i];
+                v.x = fmaxf(v.x, lo_clamp);
+                v.y = fmaxf(v.y, lo_clamp);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), ro, voff[m][i], 0, 0);
+            }
+        }
+        static_assert(4 * MPB <= 16, "stores after the DMA");
+        if (MPB == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");       // this wave's part of the next block has landed
+        else if (MPB == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // (after the last trip: nothing may land in the LDS
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                 // once the wave has ended); the stores fly on
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+}
+
+bool px_cin_ok(int Cin) { return Cin == 64 || Cin == 128 || Cin == 256; }
+
+}  // namespace
+
+extern "C" int otp_pointwise_x3_supported(int Cin, int Cout, int T) {
+    return (px_cin_ok(Cin) && Cout > 0 && Cout <= PX_MAX_COUT && Cout % 4 == 0 && T >= 2 && T % 2 == 0 && (size_t)Cout * T * 4 < (1ull << 31)) ? 1 : 0;
+}
+
+extern "C" size_t otp_pointwise_x3_weight_bytes(int Cin, int Cout) {
+    if (!px_cin_ok(Cin) || Cout <= 0 || Cout > PX_MAX_COUT) return 0;
+    const int KS = Cin / 32, MPB = 8 / KS, MT = (Cout + 15) / 16, nblk = (MT + MPB - 1) / MPB;
+    return (size_t)nblk * 16384 + 2 * PX_MAX_COUT * sizeof(float);
+}
+
+extern "C" int otp_pointwise_x3_pack(const void* w, const void* scale, const void* shift, void* packed, int Cin, int Cout,
+                                     void* stream) {
+    if (!w || !packed) return OTP_ERR_BAD_ARG;
+    const size_t bytes = otp_pointwise_x3_weight_bytes(Cin, Cout);
+    if (!bytes) return OTP_ERR_UNSUPPORTED;
+    const int KS = Cin / 32, MPB = 8 / KS, MT = (Cout + 15) / 16, nblk = (MT + MPB - 1) / MPB;
+    const int total = (int)(bytes / 16);
+    hipLaunchKernelGGL(pointx_pack_kernel, dim3(otp_ceil_div(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const float*>(w), static_cast<const float*>(scale), static_cast<const float*>(shift),
+                       static_cast<unsigned char*>(packed), Cin, Cout, nblk);
+    return otp_launch_status();
+}
+
+extern "C" int otp_pointwise_x3(const void* x, const void* packed, const void* res, void* out, int B, int Cin, int Cout, int T,
+                                int x_ctot, int x_coff, int res_ctot, int res_coff, int out_ctot, int out_coff, int relu,
+                                void* stream) {
+    if (!x || !packed || !out || B <= 0) return OTP_ERR_BAD_ARG;
+    if (!otp_pointwise_x3_supported(Cin, Cout, T)) return OTP_ERR_UNSUPPORTED;
+    if (x_coff < 0 || x_coff + Cin > x_ctot || out_coff < 0 || out_coff + Cout > out_ctot ||
+        (res && (res_coff < 0 || res_coff + Cout > res_ctot)))
+        return OTP_ERR_BAD_ARG;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(res) | reinterpret_cast<uintptr_t>(out)) & 7 ||
+        reinterpret_cast<uintptr_t>(packed) & 15)
+        return OTP_ERR_BAD_ARG;
+    const int KS = Cin / 32, MPB = 8 / KS, MT = (Cout + 15) / 16;
+    PxArgs a;
+    a.x = static_cast<const float*>(x);
+    a.packed = static_cast<const unsigned char*>(packed);
+    a.res = static_cast<const float*>(res);
+    a.out = static_cast<float*>(out);
+    a.T = T, a.tiles_per_b = otp_ceil_div(T, 128), a.Cout = Cout, a.nblk = (MT + MPB - 1) / MPB, a.relu = relu ? 1 : 0;
+    a.x_ctot = x_ctot, a.x_coff = x_coff, a.r_ctot = res_ctot, a.r_coff = res_coff, a.o_ctot = out_ctot, a.o_coff = out_coff;
+    const dim3 grid((unsigned)(B * a.tiles_per_b));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define OTP_PX_GO(CIN_)                                                                                      \
+    {                                                                                                       \
+        if (res) hipLaunchKernelGGL((pointx_kernel<CIN_, true>), grid, dim3(256), 0, st, a);                \
+        else hipLaunchKernelGGL((pointx_kernel<CIN_, false>), grid, dim3(256), 0, st, a);                   \
+    }
+    if (Cin == 64) OTP_PX_GO(64)
+    else if (Cin == 128) OTP_PX_GO(128)
+    else OTP_PX_GO(256)
+#undef OTP_PX_GO
+    return otp_launch_status();
+}

@@ -70,6 +70,7 @@ class InferenceEngine:
         self.fuse_upsample = os.environ.get("OTPOSE_FUSE_UPSAMPLE", "1") != "0"  # a fuse row's upsampled terms in one pass
         self.use_dense_cc = os.environ.get("OTPOSE_DENSE_CC", "1") != "0"     # q / k / v / proj via csrc/dense.hip
         self.use_qkv_front = os.environ.get("OTPOSE_QKV_FRONT", "1") != "0"   # + dwconv / LayerNorm fused in front of them
+        self.use_pointx = self.use_x3 and os.environ.get("OTPOSE_POINTX", "1") != "0"   # layer1's 1x1 convs via csrc/pointx.hip
         # independent sub-graphs (the HRNet branches of a stage, the rows of its fuse layer, the two temporal encoders) are
         # emitted on side HIP streams: inside the captured graph they become parallel branches, so the small-map launches
         # (640-960 workgroups on 512 resident slots) fill each other's tails
@@ -209,6 +210,21 @@ class InferenceEngine:
             def run_small():
                 hip.check(L.otp_conv3x3_small(*sargs, self._stream), "otp_conv3x3_small")
             self._emit(run_small)
+            return out
+        if (self.use_pointx and in2 is None and (kh, kw) == (1, 1) and stride == 1 and pad == 0 and res_up <= 1 and not frame_split
+                and act in (ACT_NONE, ACT_RELU) and inp.C == cin_w
+                and ops.pointwise_x3_supported(cin_w, cout, inp.t.shape[2] * inp.t.shape[3])):
+            # HRNet layer1's 1x1 convs (64 / 128 / 256 channels in, <= 256 out): register-resident pixels, streamed weights
+            # (csrc/pointx.hip) - bound by their HBM streams, which the implicit-GEMM kernel ran at a third of the rate
+            pk = ops.pack_pointwise_x3(w, sc, sh)
+            self._keep.append(pk)
+            pargs = (hip.ptr(inp.t), hip.ptr(pk), hip.ptr(res.t if res is not None else None), hip.ptr(out.t), inp.t.shape[0],
+                     cin_w, cout, inp.t.shape[2] * inp.t.shape[3], inp.ctot, inp.coff, res.ctot if res is not None else 0,
+                     res.coff if res is not None else 0, out.ctot, out.coff, int(act == ACT_RELU))
+
+            def run_px():
+                hip.check(L.otp_pointwise_x3(*pargs, self._stream), "otp_pointwise_x3")
+            self._emit(run_px)
             return out
         if self.use_x3 and in2 is None and (kh, kw) in ((3, 3), (1, 1)) and ops.x3_supported(d):
             # 3x3 / stride 1 with Cin % 16 == 0: split-bf16 (bf16x3) products on the bf16 matrix cores, fp32 storage and

@@ -563,6 +563,39 @@ def dense_cc(xs, packs, ress=None, outs=None, stream=None, x3=False):
     return outs
 
 
+def pointwise_x3_supported(cin, cout, t) -> bool:
+    return bool(hip.lib().otp_pointwise_x3_supported(int(cin), int(cout), int(t)))
+
+
+def pack_pointwise_x3(weight, scale=None, shift=None):
+    """(Cout, Cin[, 1, 1]) weight (+ per-output-channel scale / shift, e.g. a folded BatchNorm) -> the block image of
+    :func:`pointwise_x3` (HRNet layer1's 1x1 convs, model/HRNet.py:551-571)."""
+    _require_gpu(weight)
+    cout, cin = weight.shape[:2]
+    L = hip.lib()
+    nbytes = L.otp_pointwise_x3_weight_bytes(cin, cout)
+    if not nbytes:
+        raise RuntimeError(f"otp_pointwise_x3: unsupported weight shape {tuple(weight.shape)}")
+    f = lambda t: None if t is None else t.detach().to(weight.device, torch.float32).contiguous()   # noqa: E731
+    w, sc, sh = f(weight).reshape(cout, cin), f(scale), f(shift)
+    packed = torch.empty(nbytes // 4, dtype=torch.float32, device=weight.device)
+    hip.check(L.otp_pointwise_x3_pack(hip.ptr(w), hip.ptr(sc), hip.ptr(sh), hip.ptr(packed), cin, cout, hip.stream_of(w)),
+              "otp_pointwise_x3_pack")
+    return packed
+
+
+def pointwise_x3(x: View, packed, out: View, res: View = None, relu=False, stream=None):
+    """out = act(scale * (W . x) + shift (+ res)) over channel-slice views of (B, ctot, H, W) fp32 tensors."""
+    _require_gpu(x.t, out.t)
+    b = x.t.shape[0]
+    t = x.t.shape[2] * x.t.shape[3]
+    hip.check(hip.lib().otp_pointwise_x3(hip.ptr(x.t), hip.ptr(packed), hip.ptr(res.t if res is not None else None), hip.ptr(out.t),
+                                         b, x.C, out.C, t, x.ctot, x.coff, res.ctot if res is not None else 0,
+                                         res.coff if res is not None else 0, out.ctot, out.coff, int(bool(relu)),
+                                         stream if stream is not None else hip.stream_of(x.t)), "otp_pointwise_x3")
+    return out
+
+
 def pack_qkv_table(dwq, dwk, dwv, gq, bq, gk, bk, gv, bv):
     """Depthwise (C, 1, 3) weights and LayerNorm (C) gamma / beta of MaskedMHCA's query / key / value paths
     (model/blocks.py:359-381) -> the per-channel table of :func:`qkv_front`."""

@@ -388,6 +388,38 @@ def test_dense_and_qkv_front_x3_match_fp64(T, C):
         _close(outs[i], F.conv1d(ln, ws[i].double(), bs[i].double()).float(), 2e-5)
 
 
+@pytest.mark.parametrize("cin,cout,res,relu", [(256, 64, False, True), (64, 256, True, True), (128, 256, False, True),
+                                                (64, 64, False, False), (256, 100, True, False)])
+@pytest.mark.parametrize("hw", [(8, 8), (25, 10), (24, 18)])
+def test_pointwise_x3_matches_fp64(cin, cout, res, relu, hw):
+    """csrc/pointx.hip (HRNet layer1's 1x1 convs, model/HRNet.py:551-571, with the BatchNorm folded into scale / shift) vs
+    fp64 on channel-slice views; 2e-5 of the output range like the other split-bf16 kernels.  25 x 10: a ragged last
+    workgroup; Cout = 100: a partial last 16-row tile and a partial last weight block."""
+    B, (h, w) = 3, hw
+    assert ops.pointwise_x3_supported(cin, cout, h * w) and not ops.pointwise_x3_supported(48, cout, h * w)
+    assert not ops.pointwise_x3_supported(cin, 260, h * w) and not ops.pointwise_x3_supported(cin, cout, h * w + 1)
+    xt = seeded((B, cin + 24, h, w), 71)                   # the input is channels [16, 16 + cin) of a wider tensor
+    wt, sc, sh = seeded((cout, cin), 72) / cin ** 0.5, 1.0 + 0.3 * seeded((cout,), 73), seeded((cout,), 74)
+    rt = seeded((B, cout + 8, h, w), 75)                   # residual: channels [8, 8 + cout)
+    ot = torch.full((B, cout + 5, h, w), 7.0)              # output: channels [2, 2 + cout); the rest must stay untouched
+    x, r = xt[:, 16:16 + cin].double(), rt[:, 8:8 + cout].double()
+    ref = torch.einsum("oc,bchw->bohw", wt.double(), x) * sc.double()[None, :, None, None] + sh.double()[None, :, None, None]
+    if res:
+        ref = ref + r
+    if relu:
+        ref = ref.clamp_min(0)
+    pk = ops.pack_pointwise_x3(wt.cuda(), sc.cuda(), sh.cuda())
+    od = ot.cuda()
+    ops.pointwise_x3(ops.View(xt.cuda(), 16, cin), pk, ops.View(od, 2, cout), ops.View(rt.cuda(), 8, cout) if res else None, relu)
+    _close(od[:, 2:2 + cout], ref.float(), 2e-5)
+    assert bool((od[:, :2] == 7).all()) and bool((od[:, 2 + cout:] == 7).all())
+    # no scale / shift: identity epilogue
+    pk1 = ops.pack_pointwise_x3(wt.cuda())
+    o1 = torch.empty(B, cout, h, w, device="cuda")
+    ops.pointwise_x3(ops.View(xt.cuda(), 16, cin), pk1, ops.View(o1), None, False)
+    _close(o1, torch.einsum("oc,bchw->bohw", wt.double(), x).float(), 2e-5)
+
+
 @pytest.mark.parametrize("T", [32, 250, 1152])
 def test_qkv_front_matches_fp64(T):
     """csrc/dense.hip qkv_front vs MaskedMHCA's depthwise conv -> channel LayerNorm -> pointwise projection chain
