@@ -1,5 +1,6 @@
 // Pointwise (1x1) convolutions Cin -> Cout of HRNet's layer1 Bottlenecks (reference model/HRNet.py:551-571: conv1 256 -> 64,
-// conv3 64 -> 256 + residual, the folded shortcut 128 -> 256; BatchNorm folded into scale / shift, ReLU) with split-bf16
+// conv3 64 -> 256 + residual, the folded shortcut 128 -> 256; BatchNorm folded into scale / shift, ReLU) and of the fuse
+// layers' up-sampling paths (:440-455: 96 -> 48, 192 -> 48, 192 -> 96; any Cin <= 256, padded with zero weights to 64 / 128 / 256) with split-bf16
 // ("bf16x3") products - the same operator as csrc/convx.hip in its 1x1 mode, built like csrc/densex.hip instead: these
 // layers move 0.7 GB each at cfg2 and do 9 MFLOP per pixel, so they are bound by their HBM streams, and the implicit-GEMM
 // kernel (window through the LDS, one barrier per 32-channel chunk) ran them at a third of the HBM rate.
@@ -41,8 +42,8 @@ constexpr int px_block_bytes(int CIN) { return px_mpb(CIN) * px_ks(CIN) * 2048; 
 constexpr int PX_MAX_COUT = 256;
 
 __global__ void pointx_pack_kernel(const float* __restrict__ w, const float* __restrict__ scale, const float* __restrict__ shift,
-                                   unsigned char* __restrict__ packed, int Cin, int Cout, int nblk) {
-    const int KS = Cin / 32, MPB = 8 / KS, units = 1024;                    // 16-byte units per 16 KB block
+                                   unsigned char* __restrict__ packed, int Cin, int CinP, int Cout, int nblk) {
+    const int KS = CinP / 32, MPB = 8 / KS, units = 1024;                   // 16-byte units per 16 KB block (CinP: Cin padded to 64 / 128 / 256)
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < nblk * units) {
         const int blk = idx / units, u = idx - blk * units;
@@ -50,7 +51,10 @@ __global__ void pointx_pack_kernel(const float* __restrict__ w, const float* __r
         const int row = 16 * (blk * MPB + m) + (lane & 15), kq = lane >> 4;
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = row < Cout ? w[(size_t)row * Cin + 32 * ks + 8 * kq + j] : 0.f;
+        for (int j = 0; j < 8; ++j) {
+            const int c = 32 * ks + 8 * kq + j;
+            v[j] = (row < Cout && c < Cin) ? w[(size_t)row * Cin + c] : 0.f;
+        }
         bf16x8 hi, lo;
         px_split8(v, hi, lo);
         reinterpret_cast<u32x4*>(packed)[idx] = __builtin_bit_cast(u32x4, (f2 & 1) ? lo : hi);
@@ -86,7 +90,7 @@ struct PxArgs {
     const unsigned char* packed;
     const float* res;
     float* out;
-    int T, tiles_per_b, Cout, nblk, relu;
+    int T, tiles_per_b, Cin, Cout, nblk, relu;
     int x_ctot, x_coff, r_ctot, r_coff, o_ctot, o_coff;
 };
 
@@ -111,9 +115,11 @@ __global__ __launch_bounds__(256, CIN <= 128 ? 3 : 2) void pointx_kernel(PxArgs 
         float v0[8], v1[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const f32x2 v = *reinterpret_cast<const f32x2*>(x + (size_t)(32 * ks + 8 * kq + j) * T);
-            v0[j] = v.x;
-            v1[j] = v.y;
+            const int c = 32 * ks + 8 * kq + j;                              // channels past Cin (Cin padded to the template's CIN):
+            const bool live = c < A.Cin;                                     // zero weights, and nothing is read
+            const f32x2 v = *reinterpret_cast<const f32x2*>(x + (size_t)(live ? c : 0) * T);
+            v0[j] = live ? v.x : 0.f;
+            v1[j] = live ? v.y : 0.f;
         }
         px_split8(v0, Xh[ks][0], Xl[ks][0]);
         px_split8(v1, Xh[ks][1], Xl[ks][1]);
@@ -186,7 +192,8 @@ __global__ __launch_bounds__(256, CIN <= 128 ? 3 : 2) void pointx_kernel(PxArgs 
     }
 }
 
-bool px_cin_ok(int Cin) { return Cin == 64 || Cin == 128 || Cin == 256; }
+bool px_cin_ok(int Cin) { return Cin >= 16 && Cin <= 256; }
+int px_cin_pad(int Cin) { return Cin <= 64 ? 64 : (Cin <= 128 ? 128 : 256); }              // the kernel instantiation that holds it
 
 }  // namespace
 
@@ -196,7 +203,7 @@ extern "C" int otp_pointwise_x3_supported(int Cin, int Cout, int T) {
 
 extern "C" size_t otp_pointwise_x3_weight_bytes(int Cin, int Cout) {
     if (!px_cin_ok(Cin) || Cout <= 0 || Cout > PX_MAX_COUT) return 0;
-    const int KS = Cin / 32, MPB = 8 / KS, MT = (Cout + 15) / 16, nblk = (MT + MPB - 1) / MPB;
+    const int KS = px_cin_pad(Cin) / 32, MPB = 8 / KS, MT = (Cout + 15) / 16, nblk = (MT + MPB - 1) / MPB;
     return (size_t)nblk * 16384 + 2 * PX_MAX_COUT * sizeof(float);
 }
 
@@ -205,11 +212,11 @@ extern "C" int otp_pointwise_x3_pack(const void* w, const void* scale, const voi
     if (!w || !packed) return OTP_ERR_BAD_ARG;
     const size_t bytes = otp_pointwise_x3_weight_bytes(Cin, Cout);
     if (!bytes) return OTP_ERR_UNSUPPORTED;
-    const int KS = Cin / 32, MPB = 8 / KS, MT = (Cout + 15) / 16, nblk = (MT + MPB - 1) / MPB;
+    const int CinP = px_cin_pad(Cin), KS = CinP / 32, MPB = 8 / KS, MT = (Cout + 15) / 16, nblk = (MT + MPB - 1) / MPB;
     const int total = (int)(bytes / 16);
     hipLaunchKernelGGL(pointx_pack_kernel, dim3(otp_ceil_div(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        static_cast<const float*>(w), static_cast<const float*>(scale), static_cast<const float*>(shift),
-                       static_cast<unsigned char*>(packed), Cin, Cout, nblk);
+                       static_cast<unsigned char*>(packed), Cin, CinP, Cout, nblk);
     return otp_launch_status();
 }
 
@@ -224,13 +231,13 @@ extern "C" int otp_pointwise_x3(const void* x, const void* packed, const void* r
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(res) | reinterpret_cast<uintptr_t>(out)) & 7 ||
         reinterpret_cast<uintptr_t>(packed) & 15)
         return OTP_ERR_BAD_ARG;
-    const int KS = Cin / 32, MPB = 8 / KS, MT = (Cout + 15) / 16;
+    const int CinP = px_cin_pad(Cin), KS = CinP / 32, MPB = 8 / KS, MT = (Cout + 15) / 16;
     PxArgs a;
     a.x = static_cast<const float*>(x);
     a.packed = static_cast<const unsigned char*>(packed);
     a.res = static_cast<const float*>(res);
     a.out = static_cast<float*>(out);
-    a.T = T, a.tiles_per_b = otp_ceil_div(T, 128), a.Cout = Cout, a.nblk = (MT + MPB - 1) / MPB, a.relu = relu ? 1 : 0;
+    a.T = T, a.tiles_per_b = otp_ceil_div(T, 128), a.Cin = Cin, a.Cout = Cout, a.nblk = (MT + MPB - 1) / MPB, a.relu = relu ? 1 : 0;
     a.x_ctot = x_ctot, a.x_coff = x_coff, a.r_ctot = res_ctot, a.r_coff = res_coff, a.o_ctot = out_ctot, a.o_coff = out_coff;
     const dim3 grid((unsigned)(B * a.tiles_per_b));
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -239,8 +246,8 @@ extern "C" int otp_pointwise_x3(const void* x, const void* packed, const void* r
         if (res) hipLaunchKernelGGL((pointx_kernel<CIN_, true>), grid, dim3(256), 0, st, a);                \
         else hipLaunchKernelGGL((pointx_kernel<CIN_, false>), grid, dim3(256), 0, st, a);                   \
     }
-    if (Cin == 64) OTP_PX_GO(64)
-    else if (Cin == 128) OTP_PX_GO(128)
+    if (CinP == 64) OTP_PX_GO(64)
+    else if (CinP == 128) OTP_PX_GO(128)
     else OTP_PX_GO(256)
 #undef OTP_PX_GO
     return otp_launch_status();
