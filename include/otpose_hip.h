@@ -311,6 +311,14 @@ size_t otp_pointwise_x3_weight_bytes(int Cin, int Cout);
 int otp_pointwise_x3_pack(const void* w, const void* scale, const void* shift, void* packed, int Cin, int Cout, void* stream);
 int otp_pointwise_x3(const void* x, const void* packed, const void* res, void* out, int B, int Cin, int Cout, int T, int x_ctot,
                      int x_coff, int res_ctot, int res_coff, int out_ctot, int out_coff, int relu, void* stream);
+/* The same convolution writing the S8 image of its result ([B][Cout / 8][hi | lo][T] records, otp_s8_bytes(B, Cout, H, W) bytes:
+ * the input format of otp_conv3x3_s8) instead of an fp32 tensor - a Bottleneck's conv1 in front of its 3x3 conv2.  Cin in
+ * {64, 256}, Cout a multiple of 32 (<= 256), T a multiple of 4; packed from otp_pointwise_x3_s8_pack (its own row order). */
+int otp_pointwise_x3_s8_supported(int Cin, int Cout, int T);
+size_t otp_pointwise_x3_s8_weight_bytes(int Cin, int Cout);
+int otp_pointwise_x3_s8_pack(const void* w, const void* scale, const void* shift, void* packed, int Cin, int Cout, void* stream);
+int otp_pointwise_x3_s8(const void* x, const void* packed, void* out_s8, int B, int Cin, int Cout, int T, int x_ctot, int x_coff,
+                        int relu, void* stream);
 
 /* The same operator with split-bf16 ("bf16x3") products on the bf16 matrix cores (csrc/mlpx.hip): fp32 storage, fp32
  * accumulation, LayerNorm / bias / GELU in fp32; each product is lo*hi + hi*lo + hi*hi of two bf16 pieces per operand.

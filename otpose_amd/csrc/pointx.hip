@@ -39,16 +39,21 @@ constexpr int px_mpb(int CIN) { return 8 / px_ks(CIN); }                // 16-ro
 // a weight block: A fragments [tile][ks][hi, lo][1 KB] = 16 KB for every Cin (four whole passes of the 256 threads); scale and
 // shift (Cout <= 256 floats each) follow the blocks in the packed image and stay in the LDS for the whole kernel
 constexpr int px_block_bytes(int CIN) { return px_mpb(CIN) * px_ks(CIN) * 2048; }
+// S8 output (records of 8 consecutive channels): tiles are processed in pairs, so at least two per block (32 KB at Cin = 256)
+constexpr int px_mpb_s8(int CIN) { return px_mpb(CIN) < 2 ? 2 : px_mpb(CIN); }
 constexpr int PX_MAX_COUT = 256;
 
 __global__ void pointx_pack_kernel(const float* __restrict__ w, const float* __restrict__ scale, const float* __restrict__ shift,
-                                   unsigned char* __restrict__ packed, int Cin, int CinP, int Cout, int nblk) {
-    const int KS = CinP / 32, MPB = 8 / KS, units = 1024;                   // 16-byte units per 16 KB block (CinP: Cin padded to 64 / 128 / 256)
+                                   unsigned char* __restrict__ packed, int Cin, int CinP, int Cout, int nblk, int s8) {
+    // (CinP: Cin padded to 64 / 128 / 256; s8: the row order of the S8-output kernel - rows (4 kq + i) of the tile pair (2 p, 2 p + 1)
+    // are channels 32 p + 8 kq + i and 32 p + 8 kq + 4 + i, so that a lane ends up with 8 consecutive channels of its pixels)
+    const int KS = CinP / 32, MPB = s8 && 8 / KS < 2 ? 2 : 8 / KS, units = MPB * KS * 128;   // 16-byte units per block
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < nblk * units) {
         const int blk = idx / units, u = idx - blk * units;
         const int frag = u >> 6, lane = u & 63, m = frag / (KS * 2), f2 = frag - m * KS * 2, ks = f2 >> 1;
-        const int row = 16 * (blk * MPB + m) + (lane & 15), kq = lane >> 4;
+        const int gt = blk * MPB + m, r16 = lane & 15, kq = lane >> 4;
+        const int row = s8 ? 32 * (gt >> 1) + 8 * (r16 >> 2) + 4 * (gt & 1) + (r16 & 3) : 16 * gt + r16;
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -58,7 +63,7 @@ __global__ void pointx_pack_kernel(const float* __restrict__ w, const float* __r
         bf16x8 hi, lo;
         px_split8(v, hi, lo);
         reinterpret_cast<u32x4*>(packed)[idx] = __builtin_bit_cast(u32x4, (f2 & 1) ? lo : hi);
-    } else if (idx < nblk * units + 2 * PX_MAX_COUT / 4) {                  // [scale 256][shift 256] floats
+    } else if (idx < nblk * units + 2 * PX_MAX_COUT / 4) {                  // [scale 256][shift 256] floats, by channel
         const int q = idx - nblk * units;
         float v[4];
 #pragma unroll
@@ -192,6 +197,94 @@ __global__ __launch_bounds__(256, CIN <= 128 ? 3 : 2) void pointx_kernel(PxArgs 
     }
 }
 
+// The same convolution writing the S8 image of its result ([B][Cout / 8][hi | lo][T] 16-byte records of 8 bf16: the operand
+// records of csrc/convs.hip) instead of fp32 NCHW: a Bottleneck's conv1 feeding its 3x3 conv2 (model/HRNet.py:551-571).  Tiles
+// are processed in pairs whose packed rows are permuted (pointx_pack_kernel, s8 = 1) so that lane (pixel pair n, kq) ends up with
+// channels 32 p + 8 kq .. + 7 of its two pixels: one hi and one lo record per pixel, 16 lanes = 512 contiguous bytes per store.
+template <int CIN>
+__global__ __launch_bounds__(256, CIN <= 128 ? 3 : 2) void pointx_s8_kernel(PxArgs A) {
+    constexpr int KS = px_ks(CIN), MPB = px_mpb_s8(CIN), BLKB = MPB * KS * 2048;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BLKB + 2 * PX_MAX_COUT * 4];
+    float* ss = reinterpret_cast<float*>(lds + 2 * BLKB);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kq = lane >> 4, n = lane & 15;
+    const int b = blockIdx.x / A.tiles_per_b, tile = blockIdx.x - b * A.tiles_per_b;
+    const int T = A.T, tok = tile * 128 + wave * 32 + 2 * n;
+    const bool valid = tok < T;
+    px_stage<BLKB>(A.packed, lds);
+    if (tid < 2 * PX_MAX_COUT / 4)
+        reinterpret_cast<f32x4*>(ss)[tid] = reinterpret_cast<const f32x4*>(A.packed + (size_t)A.nblk * BLKB)[tid];
+    const float* __restrict__ x = A.x + ((size_t)b * A.x_ctot + A.x_coff) * T + (valid ? tok : T - 2);
+    bf16x8 Xh[KS][2], Xl[KS][2];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        float v0[8], v1[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const f32x2 v = *reinterpret_cast<const f32x2*>(x + (size_t)(32 * ks + 8 * kq + j) * T);
+            v0[j] = v.x;
+            v1[j] = v.y;
+        }
+        px_split8(v0, Xh[ks][0], Xl[ks][0]);
+        px_split8(v1, Xh[ks][1], Xl[ks][1]);
+    }
+    const unsigned plane = (unsigned)((size_t)A.Cout * T * sizeof(float));         // an S8 image is 4 bytes per element too
+    const otp_rsrc ro = make_rsrc32(A.out + (size_t)b * A.Cout * T, plane);
+    const float lo_clamp = A.relu ? 0.f : -__builtin_inff();
+    __syncthreads();
+#pragma unroll 1
+    for (int blk = 0; blk < A.nblk; ++blk) {
+        px_stage<BLKB>(A.packed + (size_t)(blk + 1 < A.nblk ? blk + 1 : 0) * BLKB, lds + ((blk + 1) & 1) * BLKB);
+        asm volatile("" ::: "memory");
+        const unsigned char* P = lds + (blk & 1) * BLKB;
+        f32x4 acc[MPB][2];
+#pragma unroll
+        for (int m = 0; m < MPB; ++m) {
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(P + ((m * KS + ks) * 2) * 1024 + lane * 16);
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(P + ((m * KS + ks) * 2 + 1) * 1024 + lane * 16);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, Xh[ks][0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, Xh[ks][1], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, Xl[ks][0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, Xl[ks][1], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, Xh[ks][0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, Xh[ks][1], acc1, 0, 0, 0);
+            }
+            acc[m][0] = acc0;
+            acc[m][1] = acc1;
+        }
+#pragma unroll
+        for (int m = 0; m < MPB; m += 2) {
+            const int pr = (blk * MPB + m) >> 1, c8 = 32 * pr + 8 * kq, g = 4 * pr + kq;        // channel group of this lane
+            const f32x4 sc0 = *reinterpret_cast<const f32x4*>(ss + (c8 & (PX_MAX_COUT - 1)));
+            const f32x4 sc1 = *reinterpret_cast<const f32x4*>(ss + ((c8 + 4) & (PX_MAX_COUT - 1)));
+            const f32x4 sh0 = *reinterpret_cast<const f32x4*>(ss + PX_MAX_COUT + (c8 & (PX_MAX_COUT - 1)));
+            const f32x4 sh1 = *reinterpret_cast<const f32x4*>(ss + PX_MAX_COUT + ((c8 + 4) & (PX_MAX_COUT - 1)));
+            const bool live = valid && c8 < A.Cout;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v[i] = fmaxf(acc[m][h][i] * sc0[i] + sh0[i], lo_clamp);
+                    v[4 + i] = fmaxf(acc[m + 1][h][i] * sc1[i] + sh1[i], lo_clamp);
+                }
+                bf16x8 hi, lo;
+                px_split8(v, hi, lo);
+                const int o = live ? ((g * 2) * T + tok + h) * 16 : -16;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hi), ro, o, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, lo), ro, live ? o + T * 16 : -16, 0, 0);
+            }
+        }
+        static_assert(2 * MPB == 4 || 2 * MPB == 8, "stores after the DMA");
+        if (MPB == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+}
+
 bool px_cin_ok(int Cin) { return Cin >= 16 && Cin <= 256; }
 int px_cin_pad(int Cin) { return Cin <= 64 ? 64 : (Cin <= 128 ? 128 : 256); }              // the kernel instantiation that holds it
 
@@ -201,23 +294,45 @@ extern "C" int otp_pointwise_x3_supported(int Cin, int Cout, int T) {
     return (px_cin_ok(Cin) && Cout > 0 && Cout <= PX_MAX_COUT && Cout % 4 == 0 && T >= 2 && T % 2 == 0 && (size_t)Cout * T * 4 < (1ull << 31)) ? 1 : 0;
 }
 
+extern "C" int otp_pointwise_x3_s8_supported(int Cin, int Cout, int T) {
+    return ((Cin == 64 || Cin == 256) && Cout > 0 && Cout <= PX_MAX_COUT && Cout % 32 == 0 && T >= 4 && T % 4 == 0 &&
+            (size_t)Cout * T * 4 < (1ull << 31)) ? 1 : 0;
+}
+
+extern "C" size_t otp_pointwise_x3_s8_weight_bytes(int Cin, int Cout) {
+    if (!(Cin == 64 || Cin == 256) || Cout <= 0 || Cout > PX_MAX_COUT || Cout % 32) return 0;
+    const int KS = Cin / 32, MPB = 8 / KS < 2 ? 2 : 8 / KS, MT = Cout / 16, nblk = (MT + MPB - 1) / MPB;
+    return (size_t)nblk * MPB * KS * 2048 + 2 * PX_MAX_COUT * sizeof(float);
+}
+
 extern "C" size_t otp_pointwise_x3_weight_bytes(int Cin, int Cout) {
     if (!px_cin_ok(Cin) || Cout <= 0 || Cout > PX_MAX_COUT) return 0;
     const int KS = px_cin_pad(Cin) / 32, MPB = 8 / KS, MT = (Cout + 15) / 16, nblk = (MT + MPB - 1) / MPB;
     return (size_t)nblk * 16384 + 2 * PX_MAX_COUT * sizeof(float);
 }
 
-extern "C" int otp_pointwise_x3_pack(const void* w, const void* scale, const void* shift, void* packed, int Cin, int Cout,
-                                     void* stream) {
+namespace {
+int px_pack(const void* w, const void* scale, const void* shift, void* packed, int Cin, int Cout, int s8, void* stream) {
     if (!w || !packed) return OTP_ERR_BAD_ARG;
-    const size_t bytes = otp_pointwise_x3_weight_bytes(Cin, Cout);
+    const size_t bytes = s8 ? otp_pointwise_x3_s8_weight_bytes(Cin, Cout) : otp_pointwise_x3_weight_bytes(Cin, Cout);
     if (!bytes) return OTP_ERR_UNSUPPORTED;
-    const int CinP = px_cin_pad(Cin), KS = CinP / 32, MPB = 8 / KS, MT = (Cout + 15) / 16, nblk = (MT + MPB - 1) / MPB;
-    const int total = (int)(bytes / 16);
+    const int CinP = px_cin_pad(Cin), KS = CinP / 32, MPB = s8 && 8 / KS < 2 ? 2 : 8 / KS, MT = (Cout + 15) / 16;
+    const int nblk = (MT + MPB - 1) / MPB, total = (int)(bytes / 16);
     hipLaunchKernelGGL(pointx_pack_kernel, dim3(otp_ceil_div(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        static_cast<const float*>(w), static_cast<const float*>(scale), static_cast<const float*>(shift),
-                       static_cast<unsigned char*>(packed), Cin, CinP, Cout, nblk);
+                       static_cast<unsigned char*>(packed), Cin, CinP, Cout, nblk, s8);
     return otp_launch_status();
+}
+}  // namespace
+
+extern "C" int otp_pointwise_x3_pack(const void* w, const void* scale, const void* shift, void* packed, int Cin, int Cout,
+                                     void* stream) {
+    return px_pack(w, scale, shift, packed, Cin, Cout, 0, stream);
+}
+
+extern "C" int otp_pointwise_x3_s8_pack(const void* w, const void* scale, const void* shift, void* packed, int Cin, int Cout,
+                                        void* stream) {
+    return px_pack(w, scale, shift, packed, Cin, Cout, 1, stream);
 }
 
 extern "C" int otp_pointwise_x3(const void* x, const void* packed, const void* res, void* out, int B, int Cin, int Cout, int T,
@@ -250,5 +365,27 @@ extern "C" int otp_pointwise_x3(const void* x, const void* packed, const void* r
     else if (CinP == 128) OTP_PX_GO(128)
     else OTP_PX_GO(256)
 #undef OTP_PX_GO
+    return otp_launch_status();
+}
+
+extern "C" int otp_pointwise_x3_s8(const void* x, const void* packed, void* out_s8, int B, int Cin, int Cout, int T, int x_ctot,
+                                   int x_coff, int relu, void* stream) {
+    if (!x || !packed || !out_s8 || B <= 0) return OTP_ERR_BAD_ARG;
+    if (!otp_pointwise_x3_s8_supported(Cin, Cout, T)) return OTP_ERR_UNSUPPORTED;
+    if (x_coff < 0 || x_coff + Cin > x_ctot) return OTP_ERR_BAD_ARG;
+    if (reinterpret_cast<uintptr_t>(x) & 7 || (reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(out_s8)) & 15)
+        return OTP_ERR_BAD_ARG;
+    const int KS = Cin / 32, MPB = 8 / KS < 2 ? 2 : 8 / KS, MT = Cout / 16;
+    PxArgs a;
+    a.x = static_cast<const float*>(x);
+    a.packed = static_cast<const unsigned char*>(packed);
+    a.res = nullptr;
+    a.out = static_cast<float*>(out_s8);
+    a.T = T, a.tiles_per_b = otp_ceil_div(T, 128), a.Cin = Cin, a.Cout = Cout, a.nblk = (MT + MPB - 1) / MPB, a.relu = relu ? 1 : 0;
+    a.x_ctot = x_ctot, a.x_coff = x_coff, a.r_ctot = 0, a.r_coff = 0, a.o_ctot = Cout, a.o_coff = 0;
+    const dim3 grid((unsigned)(B * a.tiles_per_b));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (Cin == 64) hipLaunchKernelGGL(pointx_s8_kernel<64>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(pointx_s8_kernel<256>, grid, dim3(256), 0, st, a);
     return otp_launch_status();
 }

@@ -385,6 +385,39 @@ class InferenceEngine:
                 xs8, xc4 = o8, oc4
         return out
 
+    def conv1_conv2_s8(self, x: View, conv1, bn1, conv2, bn2, out: View = None):
+        """relu(bn2(conv2(relu(bn1(conv1(x)))))) of a Bottleneck (HRNet.py:551-571: 1x1 then 3x3) with the intermediate kept as S8
+        records: conv1 on csrc/pointx.hip writes the operand records of csrc/convs.hip, conv2 reads them and writes fp32 NCHW -
+        no fp32 round trip of the 64-channel tensor and the S8 conv kernel instead of the implicit-GEMM one (179 -> 115 us at
+        cfg2).  Returns None when the pair is not of that shape."""
+        if not (self.use_s8 and self.use_pointx and os.environ.get("OTPOSE_L1_S8", "1") != "0"):
+            return None
+        n, _, h, w = x.t.shape
+        c1i, c1o, c2o = conv1.in_channels, conv1.out_channels, conv2.out_channels
+        if (conv1.kernel_size != (1, 1) or conv1.stride != (1, 1) or conv1.padding != (0, 0) or conv1.bias is not None
+                or conv1.groups != 1 or conv2.kernel_size != (3, 3) or conv2.stride != (1, 1) or conv2.padding != (1, 1)
+                or conv2.dilation != (1, 1) or conv2.bias is not None or conv2.groups != 1 or conv2.in_channels != c1o
+                or x.C != c1i or not ops.pointwise_x3_s8_supported(c1i, c1o, h * w)):
+            return None
+        if out is None:
+            out = View(self.new(n, c2o, h, w))
+        d2 = ops.s8_conv_desc(n, c1o, c2o, h, w, ACT_RELU, out)
+        if not ops.s8_conv_supported(d2):
+            return None
+        L = self.lib
+        self._needs_nchw(x)
+        sc1, sh1 = self._bn_fold(bn1)
+        sc2, sh2 = self._bn_fold(bn2)
+        pk = ops.pack_pointwise_x3_s8(self.dev_param(conv1.weight), sc1, sh1)
+        w2 = ops.pack_s8_weight(self.dev_param(conv2.weight), sc2)
+        y8 = self.new(n * c1o * h * w)
+        self._keep += [pk, w2, d2]
+        self.call(L.otp_pointwise_x3_s8, "otp_pointwise_x3_s8", hip.ptr(x.t), hip.ptr(pk), hip.ptr(y8), n, c1i, c1o, h * w, x.ctot,
+                  x.coff, 1)
+        self.call(L.otp_conv3x3_s8, "otp_conv3x3_s8", hip.ptr(y8), hip.ptr(w2), hip.ptr(sh2), None, hip.ptr(out.t), ops.S8_F32_NCHW,
+                  None, d2)
+        return out
+
     def bottleneck(self, blk, x: View) -> View:
         res = x
         if blk.downsample is not None:
@@ -393,8 +426,10 @@ class InferenceEngine:
             self.on_stream(1)
             res = self.conv_bn(x, blk.downsample[0], blk.downsample[1])
             self.on_stream(0)
-        y = self.conv_bn(x, blk.conv1, blk.bn1, ACT_RELU)
-        y = self.conv_bn(y, blk.conv2, blk.bn2, ACT_RELU)
+        y = self.conv1_conv2_s8(x, blk.conv1, blk.bn1, blk.conv2, blk.bn2)
+        if y is None:
+            y = self.conv_bn(x, blk.conv1, blk.bn1, ACT_RELU)
+            y = self.conv_bn(y, blk.conv2, blk.bn2, ACT_RELU)
         if blk.downsample is not None:
             self.join((1,))
         return self.conv_bn(y, blk.conv3, blk.bn3, ACT_RELU, res=res)
@@ -497,8 +532,9 @@ class InferenceEngine:
             cx, cy = c2.out_channels, b0.conv2.out_channels
             cat = self.new(n, cx + cy, ho, wo)
             xin = self.conv_bn(x, c2, net.bn2, ACT_RELU, out=View(cat, 0, cx))
-            y = self.conv_bn(xin, b0.conv1, b0.bn1, ACT_RELU)
-            self.conv_bn(y, b0.conv2, b0.bn2, ACT_RELU, out=View(cat, cx, cy))
+            if self.conv1_conv2_s8(xin, b0.conv1, b0.bn1, b0.conv2, b0.bn2, out=View(cat, cx, cy)) is None:
+                y = self.conv_bn(xin, b0.conv1, b0.bn1, ACT_RELU)
+                self.conv_bn(y, b0.conv2, b0.bn2, ACT_RELU, out=View(cat, cx, cy))
 
             def fold(conv, bn):
                 g, b = self.dev_param(bn.weight), self.dev_param(bn.bias)

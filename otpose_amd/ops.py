@@ -596,6 +596,37 @@ def pointwise_x3(x: View, packed, out: View, res: View = None, relu=False, strea
     return out
 
 
+def pointwise_x3_s8_supported(cin, cout, t) -> bool:
+    return bool(hip.lib().otp_pointwise_x3_s8_supported(int(cin), int(cout), int(t)))
+
+
+def pack_pointwise_x3_s8(weight, scale=None, shift=None):
+    """Weight image of :func:`pointwise_x3_s8` (its own row order: pairs of 16-row tiles interleaved by groups of 4)."""
+    _require_gpu(weight)
+    cout, cin = weight.shape[:2]
+    L = hip.lib()
+    nbytes = L.otp_pointwise_x3_s8_weight_bytes(cin, cout)
+    if not nbytes:
+        raise RuntimeError(f"otp_pointwise_x3_s8: unsupported weight shape {tuple(weight.shape)}")
+    f = lambda t: None if t is None else t.detach().to(weight.device, torch.float32).contiguous()   # noqa: E731
+    w, sc, sh = f(weight).reshape(cout, cin), f(scale), f(shift)
+    packed = torch.empty(nbytes // 4, dtype=torch.float32, device=weight.device)
+    hip.check(L.otp_pointwise_x3_s8_pack(hip.ptr(w), hip.ptr(sc), hip.ptr(sh), hip.ptr(packed), cin, cout, hip.stream_of(w)),
+              "otp_pointwise_x3_s8_pack")
+    return packed
+
+
+def pointwise_x3_s8(x: View, packed, cout, out_s8=None, relu=False, stream=None):
+    """S8 image of act(scale * (W . x) + shift): a 1x1 conv feeding :func:`conv3x3_s8_launch` without an fp32 round trip."""
+    _require_gpu(x.t)
+    b, _, h, w = x.t.shape
+    out_s8 = s8_empty(b, cout, h, w, x.t.device) if out_s8 is None else out_s8
+    hip.check(hip.lib().otp_pointwise_x3_s8(hip.ptr(x.t), hip.ptr(packed), hip.ptr(out_s8), b, x.C, cout, h * w, x.ctot, x.coff,
+                                            int(bool(relu)), stream if stream is not None else hip.stream_of(x.t)),
+              "otp_pointwise_x3_s8")
+    return out_s8
+
+
 def pack_qkv_table(dwq, dwk, dwv, gq, bq, gk, bk, gv, bv):
     """Depthwise (C, 1, 3) weights and LayerNorm (C) gamma / beta of MaskedMHCA's query / key / value paths
     (model/blocks.py:359-381) -> the per-channel table of :func:`qkv_front`."""

@@ -421,6 +421,28 @@ def test_pointwise_x3_matches_fp64(cin, cout, res, relu, hw):
     _close(o1, torch.einsum("oc,bchw->bohw", wt.double(), x).float(), 2e-5)
 
 
+@pytest.mark.parametrize("cin,cout", [(256, 64), (64, 64), (64, 96)])
+@pytest.mark.parametrize("hw", [(8, 8), (25, 12), (24, 18)])
+def test_pointwise_x3_s8_matches_fp64_and_feeds_the_s8_conv(cin, cout, hw):
+    """csrc/pointx.hip writing S8 records (a Bottleneck's conv1 -> conv2, model/HRNet.py:551-571): the unpacked image against
+    fp64 (hi + lo carry 16 mantissa bits: 2e-5 of the range), and the records as input of otp_conv3x3_s8 against the same conv
+    on the records s8_pack makes from the fp32 result of otp_pointwise_x3 - bit-identical images, so bit-identical outputs."""
+    B, (h, w) = 3, hw
+    assert ops.pointwise_x3_s8_supported(cin, cout, h * w) and not ops.pointwise_x3_s8_supported(128, cout, h * w)
+    assert not ops.pointwise_x3_s8_supported(cin, 48, h * w)
+    xt = seeded((B, cin + 8, h, w), 81)
+    wt, sc, sh = seeded((cout, cin), 82) / cin ** 0.5, 1.0 + 0.3 * seeded((cout,), 83), seeded((cout,), 84)
+    x = xt[:, 8:8 + cin].double()
+    ref = (torch.einsum("oc,bchw->bohw", wt.double(), x) * sc.double()[None, :, None, None] + sh.double()[None, :, None, None]).clamp_min(0)
+    xv = ops.View(xt.cuda(), 8, cin)
+    s8 = ops.pointwise_x3_s8(xv, ops.pack_pointwise_x3_s8(wt.cuda(), sc.cuda(), sh.cuda()), cout, relu=True)
+    _close(ops.s8_unpack(s8, B, cout, h, w), ref.float(), 2e-5)
+    # the fp32 route: same arithmetic, then s8_pack
+    o = torch.empty(B, cout, h, w, device="cuda")
+    ops.pointwise_x3(xv, ops.pack_pointwise_x3(wt.cuda(), sc.cuda(), sh.cuda()), ops.View(o), None, True)
+    assert torch.equal(s8, ops.s8_pack(o))
+
+
 @pytest.mark.parametrize("T", [32, 250, 1152])
 def test_qkv_front_matches_fp64(T):
     """csrc/dense.hip qkv_front vs MaskedMHCA's depthwise conv -> channel LayerNorm -> pointwise projection chain
