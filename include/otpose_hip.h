@@ -298,6 +298,16 @@ int otp_dense_x3(const void* const* x, const void* const* packed, const void* co
 int otp_qkv_front_x3(const void* x, const void* table, const void* packed_q, const void* packed_k, const void* packed_v,
                      void* q, void* k, void* v, int B, int C, int T, float eps, void* stream);
 
+/* HRNet's first convolution (model/HRNet.py:33-36, :118-120) on the frames of the clip tensor (model/OTPose.py:317), csrc/stem.hip:
+ *   out (F * B, Cout, Ho, Wo) = relu(scale * conv3x3_stride2_pad1(frame n of in) + shift), frame n = f * B + b = channels
+ *   [3 f, 3 f + 3) of clip b of in (B, 3 F, H, W) fp32; Ho = (H - 1) / 2 + 1, Wo likewise (a multiple of 4), Cout <= 64.
+ * Split-bf16 products like otp_conv2d_x3; packed: otp_stem_conv_x3_weight_bytes(Cout) bytes from otp_stem_conv_x3_pack
+ * (w: (Cout, 3, 3, 3) fp32, scale / shift: the folded BatchNorm, NULL = 1 / 0). */
+int otp_stem_conv_x3_supported(int B, int F, int H, int W, int Cout);
+size_t otp_stem_conv_x3_weight_bytes(int Cout);
+int otp_stem_conv_x3_pack(const void* w, const void* scale, const void* shift, void* packed, int Cout, void* stream);
+int otp_stem_conv_x3(const void* in, const void* packed, void* out, int B, int F, int H, int W, int Cout, void* stream);
+
 /* Pointwise (1x1, stride 1) convolution Cin -> Cout on fp32 NCHW channel slices with split-bf16 products (csrc/pointx.hip):
  * HRNet layer1's Bottleneck convs (model/HRNet.py:551-571: 256 -> 64, 64 -> 256 + residual, the shortcut folded over the
  * concatenation 128 -> 256), what nn.Conv2d(k = 1) + folded BatchNorm2d + ReLU compute there:

@@ -116,6 +116,10 @@ SIGNATURES = {
     "otp_dense_x3_weight_bytes": (c_size_t, [c_int]),
     "otp_dense_x3_pack": (c_int, [c_void_p] * 4 + [c_int, c_void_p]),
     "otp_dense_x3": (c_int, [ctypes.POINTER(c_void_p)] * 4 + [c_int] * 4 + [c_void_p]),
+    "otp_stem_conv_x3_supported": (c_int, [c_int] * 5),
+    "otp_stem_conv_x3_weight_bytes": (c_size_t, [c_int]),
+    "otp_stem_conv_x3_pack": (c_int, [c_void_p] * 4 + [c_int, c_void_p]),
+    "otp_stem_conv_x3": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p]),
     "otp_pointwise_x3_supported": (c_int, [c_int] * 3),
     "otp_pointwise_x3_weight_bytes": (c_size_t, [c_int] * 2),
     "otp_pointwise_x3_pack": (c_int, [c_void_p] * 4 + [c_int, c_int, c_void_p]),

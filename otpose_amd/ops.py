@@ -563,6 +563,39 @@ def dense_cc(xs, packs, ress=None, outs=None, stream=None, x3=False):
     return outs
 
 
+def stem_conv_x3_supported(b, f, h, w, cout) -> bool:
+    return bool(hip.lib().otp_stem_conv_x3_supported(int(b), int(f), int(h), int(w), int(cout)))
+
+
+def pack_stem_conv_x3(weight, scale=None, shift=None):
+    """(Cout, 3, 3, 3) weight of HRNet's first conv (+ folded BatchNorm) -> the register image of :func:`stem_conv_x3`."""
+    _require_gpu(weight)
+    cout = weight.shape[0]
+    L = hip.lib()
+    nbytes = L.otp_stem_conv_x3_weight_bytes(cout)
+    if not nbytes or tuple(weight.shape[1:]) != (3, 3, 3):
+        raise RuntimeError(f"otp_stem_conv_x3: unsupported weight shape {tuple(weight.shape)}")
+    f = lambda t: None if t is None else t.detach().to(weight.device, torch.float32).contiguous()   # noqa: E731
+    w, sc, sh = f(weight), f(scale), f(shift)
+    packed = torch.empty(nbytes // 4, dtype=torch.float32, device=weight.device)
+    hip.check(L.otp_stem_conv_x3_pack(hip.ptr(w), hip.ptr(sc), hip.ptr(sh), hip.ptr(packed), cout, hip.stream_of(w)),
+              "otp_stem_conv_x3_pack")
+    return packed
+
+
+def stem_conv_x3(clip, packed, cout, frames=5, out=None, stream=None):
+    """relu(bn(conv3x3 stride 2 pad 1)) of the 3-channel frames of ``clip`` (B, 3 * frames, H, W) -> (frames * B, cout, Ho, Wo),
+    frame-major like model/OTPose.py:317."""
+    _require_gpu(clip)
+    b, c, h, w = clip.shape
+    assert c == 3 * frames and clip.is_contiguous() and clip.dtype == torch.float32
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    out = torch.empty(frames * b, cout, ho, wo, dtype=torch.float32, device=clip.device) if out is None else out
+    hip.check(hip.lib().otp_stem_conv_x3(hip.ptr(clip), hip.ptr(packed), hip.ptr(out), b, frames, h, w, cout,
+                                         stream if stream is not None else hip.stream_of(clip)), "otp_stem_conv_x3")
+    return out
+
+
 def pointwise_x3_supported(cin, cout, t) -> bool:
     return bool(hip.lib().otp_pointwise_x3_supported(int(cin), int(cout), int(t)))
 

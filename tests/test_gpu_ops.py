@@ -421,6 +421,20 @@ def test_pointwise_x3_matches_fp64(cin, cout, res, relu, hw):
     _close(o1, torch.einsum("oc,bchw->bohw", wt.double(), x).float(), 2e-5)
 
 
+@pytest.mark.parametrize("b,frames,h,w,cout", [(2, 5, 32, 24, 64), (3, 5, 30, 40, 64), (1, 7, 17, 15, 40), (2, 1, 8, 8, 64)])
+def test_stem_conv_x3_matches_fp64(b, frames, h, w, cout):
+    """csrc/stem.hip (HRNet's conv1 + bn1 + relu, model/HRNet.py:33-36, on the frames of the clip, model/OTPose.py:317) against
+    F.conv2d in fp64 on the re-arranged frames; odd sizes: the last row / column of taps reads the padding."""
+    clip = seeded((b, 3 * frames, h, w), 91)
+    wt, sc, sh = seeded((cout, 3, 3, 3), 92) * 0.3, 1.0 + 0.3 * seeded((cout,), 93), seeded((cout,), 94)
+    assert ops.stem_conv_x3_supported(b, frames, h, w, cout)
+    fr = clip.view(b, frames, 3, h, w).transpose(0, 1).reshape(frames * b, 3, h, w).double()       # frame n = f * B + b
+    ref = F.conv2d(fr, wt.double(), None, 2, 1) * sc.double()[None, :, None, None] + sh.double()[None, :, None, None]
+    out = ops.stem_conv_x3(clip.cuda(), ops.pack_stem_conv_x3(wt.cuda(), sc.cuda(), sh.cuda()), cout, frames)
+    _close(out, ref.clamp_min(0).float(), 2e-5)
+    assert not ops.stem_conv_x3_supported(b, frames, 30, 42, cout)        # Wo = 21: not a multiple of 4
+
+
 @pytest.mark.parametrize("cin,cout", [(256, 64), (64, 64), (64, 96)])
 @pytest.mark.parametrize("hw", [(8, 8), (25, 12), (24, 18)])
 def test_pointwise_x3_s8_matches_fp64_and_feeds_the_s8_conv(cin, cout, hw):
