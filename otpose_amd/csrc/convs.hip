@@ -541,16 +541,33 @@ __global__ __launch_bounds__(256, NCHW ? 2 : 3) void convs_kernel(const unsigned
                                                        (co_blk + 16 * t < P.Cout && offS[p] != SOOB) ? offS[p] + (ch0[t] >> 2) * P.HW * 16 : SOOB,
                                                        0, 0);
     } else if (NCHW) {
-        // channel slice of an NCHW tensor (the tensor a fuse layer / another kernel family reads): 4 planes per lane
+        // channel slice of an NCHW tensor (the tensor a fuse layer / another kernel family reads).  Straight from the accumulators
+        // a store instruction would write 64-byte runs (16 pixels of one channel per lane group) - measured at a third of the
+        // rate of long runs (csrc/stem.hip) - so the workgroup's [16 NTW channels][BM pixels] tile passes through the LDS (free
+        // once every wave has left the chunk loop) and leaves as 16-byte stores, 64 lanes = 1 KB of one channel row.
+        constexpr int RS = BM + 4;                                   // floats per channel row of the tile
+        float* tl = reinterpret_cast<float*>(smem);
+        __syncthreads();                                             // every wave is done with the window / weight images
 #pragma unroll
         for (int t = 0; t < NTW; ++t)
 #pragma unroll
             for (int p = 0; p < NPT; ++p)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(acc[t][p][r]), rof,
-                                                          (co_blk + 16 * t < P.Cout && offN[NCHW ? p : 0] != SOOB) ? offN[NCHW ? p : 0] + ch0[t] * P.HW * 4 : SOOB,
-                                                          r * P.HW * 4, 0);
+                    tl[(ch0[t] - co_blk + r) * RS + (wave * NPT + p) * 16 + i16] = acc[t][p][r];
+        __syncthreads();
+        constexpr int G = BM / 4, CPI = 256 / G;                     // 4-pixel groups per channel row, channel rows per pass
+        const int g = tid % G, c0 = tid / G;
+        const bool gv = P0 + 4 * g < P.total;                        // (a group of 4 stays inside one image: H W % 4 == 0)
+        const int q = gv ? p0 + 4 * g : p0;                          // relative to image n0, like the pixel tiles above
+        const int qn = (int)sdiv((uint32_t)q, P.mHW), qi = q - qn * P.HW;
+        const int ob = gv ? (((n0 + qn) * P.out_ctot + P.out_coff + co_blk) * P.HW + qi) * 4 : SOOB;
+#pragma unroll
+        for (int k = 0; k < NTW * 16 / CPI; ++k) {
+            const int ch = c0 + CPI * k;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(tl + ch * RS + 4 * g);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rof, (ob != SOOB && co_blk + ch < P.Cout) ? ob + ch * P.HW * 4 : SOOB, 0, 0);
+        }
     }
     if (outs) {
 #pragma unroll
@@ -641,7 +658,8 @@ template <int NTW, bool NCHW, int NPT>
 int convs_launch(const void* xs, const void* wpk, const float* shift, const float* res, float* outf, void* outs, const SPlan& P,
                  hipStream_t st) {
     auto kern = convs_kernel<NTW, NCHW, NPT>;
-    const size_t need = (size_t)4 * P.pl + swch(NTW) * 1024;
+    size_t need = (size_t)4 * P.pl + swch(NTW) * 1024;
+    if (NCHW && need < (size_t)NTW * 16 * (64 * NPT + 4) * 4) need = (size_t)NTW * 16 * (64 * NPT + 4) * 4;   // the output tile of the epilogue
     OTP_ALLOW_BIG_LDS(kern, need);
     hipLaunchKernelGGL(kern, dim3(8 * P.tpx * P.nN), dim3(256), need, st, static_cast<const unsigned char*>(xs),
                        static_cast<const u32x4*>(wpk), shift, res, outf, static_cast<u32x4*>(outs), P);

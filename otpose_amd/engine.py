@@ -518,13 +518,13 @@ class InferenceEngine:
     def hrnet(self, net, x_in: View) -> View:
         c1 = net.conv1
         n_in, c_in, h_in, w_in = x_in.t.shape
-        if (self.use_x3 and os.environ.get("OTPOSE_STEM_X3", "0") == "1" and x_in.coff == 0 and x_in.C == c_in and c_in == 3 * self.F
+        if (self.use_x3 and os.environ.get("OTPOSE_STEM_X3", "1") != "0" and x_in.coff == 0 and x_in.C == c_in and c_in == 3 * self.F
                 and c1.kernel_size == (3, 3) and c1.stride == (2, 2) and c1.padding == (1, 1) and c1.dilation == (1, 1)
                 and c1.in_channels == 3 and c1.bias is None and c1.groups == 1
                 and ops.stem_conv_x3_supported(n_in, self.F, h_in, w_in, c1.out_channels)):
             # conv1 + bn1 + relu on the frames of the clip (HRNet.py:118-120 after OTPose.py:317): one k-step of split products per
-            # 16 pixels x 16 channels, gathered straight from the image (csrc/stem.hip).  Opt-in (OTPOSE_STEM_X3=1): 311 against
-            # 426 us alone on the chip (tools/stem_time.py) but the forward does not move (26.67 / 26.68 ms)
+            # 16 pixels x 16 channels, gathered straight from the image (csrc/stem.hip), stored through an LDS slab as 256-byte runs
+            # per channel: 202 against 426 us for the direct kernel (tools/stem_time.py), forward -0.3 ... -0.5 ms
             sc, sh = self._bn_fold(net.bn1)
             pk = ops.pack_stem_conv_x3(self.dev_param(c1.weight), sc, sh)
             self._keep.append(pk)
