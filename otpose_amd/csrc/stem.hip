@@ -67,7 +67,7 @@ struct StArgs {
     const u32x4* packed;
     float* out;
     int B, F, H, W, Ho, Wo, HoWo, Cout, total4;      // total4: groups of 4 output pixels over all frames
-    unsigned mHoWo4, mWo4;                            // magic divisors of HoWo / 4 and Wo / 4
+    unsigned mWo4;                                    // magic divisor of Wo / 4
 };
 
 __device__ __forceinline__ uint32_t st_div(uint32_t i, uint32_t magic) { return magic ? __umulhi(i, magic) : i; }
@@ -94,13 +94,15 @@ __global__ __launch_bounds__(256) void stem_kernel(StArgs A) {
     const size_t clip = (size_t)3 * A.F * A.H * A.W;                           // floats of one clip
     const otp_rsrc rin = make_rsrc(A.in, (size_t)A.B * clip * sizeof(float));
     const long P0 = ((long)blockIdx.x * 4 + wave) * (16 * NPT);              // first output pixel of this wave (all frames, row-major)
+    // frame and 4-pixel group of the wave's first pixel (one exact division per wave); its 16 NPT pixels span at most two frames
+    const uint32_t H4 = (uint32_t)(A.HoWo >> 2), g0 = (uint32_t)(P0 >> 2), n0 = g0 / H4, rem0 = g0 - n0 * H4;
 #pragma unroll 4
     for (int p = 0; p < NPT; ++p) {
         // ---- A fragment: the 8 (tap, channel) values of pixel P0 + 16 p + i16 --------------------------------------------------
         const long px = P0 + 16 * p + i16;
         const bool pv = px < 4l * A.total4;
-        const uint32_t g = (uint32_t)((pv ? px : 0) >> 2);                       // its 4-pixel group
-        const uint32_t n = st_div(g, A.mHoWo4), r4 = g - n * (uint32_t)(A.HoWo >> 2);
+        uint32_t r4 = rem0 + (uint32_t)((16 * p + i16) >> 2), n = n0;            // its 4-pixel group inside frame n
+        if (r4 >= H4) r4 -= H4, ++n;
         const uint32_t yo = st_div(r4, A.mWo4), xo = 4 * (r4 - yo * (uint32_t)(A.Wo >> 2)) + (uint32_t)(px & 3);
         const int b = (int)(n % (uint32_t)A.B), f = (int)(n / (uint32_t)A.B);
         const int base = (b * 3 * A.F + 3 * f) * A.H * A.W;                     // channel 0 of frame f of clip b (fits 31 bits: checked on the host)
@@ -117,8 +119,9 @@ __global__ __launch_bounds__(256) void stem_kernel(StArgs A) {
         // ---- 3 split products per channel tile; D row = pixel, column = channel: register r of lane (channel i16, kq) is pixel 4 kq + r
         const long q0 = P0 + 16 * p + 4 * kq;                                    // this lane's 4 consecutive output pixels
         const bool qv = q0 < 4l * A.total4;
-        const uint32_t g2 = (uint32_t)((qv ? q0 : 0) >> 2);
-        const uint32_t n2 = st_div(g2, A.mHoWo4), pi = 4 * (g2 - n2 * (uint32_t)(A.HoWo >> 2));
+        uint32_t r2 = rem0 + (uint32_t)(4 * p + kq), n2 = n0;
+        if (r2 >= H4) r2 -= H4, ++n2;
+        const uint32_t pi = 4 * r2;
 #pragma unroll
         for (int t = 0; t < ST_CT; ++t) {
             f32x4 acc = {shv[t], shv[t], shv[t], shv[t]};
@@ -142,8 +145,9 @@ __global__ __launch_bounds__(256) void stem_kernel(StArgs A) {
         if ((p & 3) == 3) {                                                  // 64 pixels of this wave are in the slab: channel rows out
             const long r0 = P0 + 16 * (p - 3) + 4 * i16;                     // lane: pixels 4 i16 .. + 3 of the 64, channels kq + 4 j
             const bool rv = r0 < 4l * A.total4;
-            const uint32_t g3 = (uint32_t)((rv ? r0 : 0) >> 2);
-            const uint32_t n3 = st_div(g3, A.mHoWo4), pj = 4 * (g3 - n3 * (uint32_t)(A.HoWo >> 2));
+            uint32_t r3 = rem0 + (uint32_t)(4 * (p - 3) + i16), n3 = n0;
+            if (r3 >= H4) r3 -= H4, ++n3;
+            const uint32_t pj = 4 * r3;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int co = 4 * j + kq;
@@ -160,7 +164,11 @@ __global__ __launch_bounds__(256) void stem_kernel(StArgs A) {
 extern "C" int otp_stem_conv_x3_supported(int B, int F, int H, int W, int Cout) {
     if (B <= 0 || F <= 0 || H < 2 || W < 2 || Cout <= 0 || Cout > 16 * ST_CT) return 0;
     const int Wo = (W - 1) / 2 + 1;
-    if (Wo % 4 || (size_t)B * 3 * F * H * W * 4 >= (1ull << 31)) return 0;
+    const int Ho = (H - 1) / 2 + 1;
+    // a wave's 64 pixels span at most two frames; 31-bit pixel indices and input byte offsets; exact magic division by Wo / 4
+    if (Wo % 4 || Ho * Wo < 64 || (size_t)B * 3 * F * H * W * 4 >= (1ull << 31) || (size_t)B * F * Ho * Wo >= (1ull << 31) ||
+        (size_t)(Ho * Wo / 4) * (Wo / 4) >= (1ull << 32))
+        return 0;
     return 1;
 }
 
@@ -187,10 +195,8 @@ extern "C" int otp_stem_conv_x3(const void* in, const void* packed, void* out, i
     a.out = static_cast<float*>(out);
     a.B = B, a.F = F, a.H = H, a.W = W, a.Ho = (H - 1) / 2 + 1, a.Wo = (W - 1) / 2 + 1, a.HoWo = a.Ho * a.Wo, a.Cout = Cout;
     const long total = (long)B * F * a.HoWo;
-    if (total / 4 >= (1l << 30)) return OTP_ERR_UNSUPPORTED;
     a.total4 = (int)(total / 4);
-    a.mHoWo4 = st_magic((uint32_t)(a.HoWo / 4)), a.mWo4 = st_magic((uint32_t)(a.Wo / 4));
-    if ((unsigned long)(a.total4) * (unsigned long)(a.HoWo / 4) >= (1ul << 32)) return OTP_ERR_UNSUPPORTED;   // exact magic division
+    a.mWo4 = st_magic((uint32_t)(a.Wo / 4));
 #ifndef ST_NPT
 #define ST_NPT 4
 #endif

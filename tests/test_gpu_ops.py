@@ -421,7 +421,8 @@ def test_pointwise_x3_matches_fp64(cin, cout, res, relu, hw):
     _close(o1, torch.einsum("oc,bchw->bohw", wt.double(), x).float(), 2e-5)
 
 
-@pytest.mark.parametrize("b,frames,h,w,cout", [(2, 5, 32, 24, 64), (3, 5, 30, 40, 64), (1, 7, 17, 15, 40), (2, 1, 8, 8, 64)])
+@pytest.mark.parametrize("b,frames,h,w,cout", [(2, 5, 32, 24, 64), (3, 5, 30, 40, 64), (1, 7, 17, 15, 40), (2, 1, 16, 16, 64),
+                                               (16, 7, 96, 128, 64)])
 def test_stem_conv_x3_matches_fp64(b, frames, h, w, cout):
     """csrc/stem.hip (HRNet's conv1 + bn1 + relu, model/HRNet.py:33-36, on the frames of the clip, model/OTPose.py:317) against
     F.conv2d in fp64 on the re-arranged frames; odd sizes: the last row / column of taps reads the padding."""
