@@ -313,7 +313,7 @@ int otp_stem_conv_x3(const void* in, const void* packed, void* out, int B, int F
  * concatenation 128 -> 256), what nn.Conv2d(k = 1) + folded BatchNorm2d + ReLU compute there:
  *   out[b, out_coff + o, t] = act(scale[o] * sum_c w[o, c] * x[b, x_coff + c, t] + shift[o] (+ res[b, res_coff + o, t]))
  * x / res / out: (B, ctot, T) fp32, T = H * W pixels; 16 <= Cin <= 256 (held by the 64 / 128 / 256-channel instantiation, zero
- * weights past Cin), Cout <= 256 and a multiple of 4, T even;
+ * weights past Cin), Cout <= 256, T even;
  * packed: otp_pointwise_x3_weight_bytes(Cin, Cout) bytes from otp_pointwise_x3_pack (w: (Cout, Cin) fp32; scale / shift may
  * be NULL = 1 / 0); relu != 0 clamps at zero.  OTP_ERR_UNSUPPORTED for other shapes (the caller keeps otp_conv2d_x3). */
 int otp_pointwise_x3_supported(int Cin, int Cout, int T);

@@ -291,7 +291,7 @@ int px_cin_pad(int Cin) { return Cin <= 64 ? 64 : (Cin <= 128 ? 128 : 256); }   
 }  // namespace
 
 extern "C" int otp_pointwise_x3_supported(int Cin, int Cout, int T) {
-    return (px_cin_ok(Cin) && Cout > 0 && Cout <= PX_MAX_COUT && Cout % 4 == 0 && T >= 2 && T % 2 == 0 && (size_t)Cout * T * 4 < (1ull << 31)) ? 1 : 0;
+    return (px_cin_ok(Cin) && Cout > 0 && Cout <= PX_MAX_COUT && T >= 2 && T % 2 == 0 && (size_t)Cout * T * 4 < (1ull << 31)) ? 1 : 0;
 }
 
 extern "C" int otp_pointwise_x3_s8_supported(int Cin, int Cout, int T) {

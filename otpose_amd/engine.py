@@ -212,8 +212,10 @@ class InferenceEngine:
             self._emit(run_small)
             return out
         if (self.use_pointx and in2 is None and (kh, kw) == (1, 1) and stride == 1 and pad == 0 and res_up <= 1 and not frame_split
-                and act in (ACT_NONE, ACT_RELU) and inp.C == cin_w and cin_w % 16 == 0      # (the population of the x3 kernels)
-                and (cin_w in (64, 128, 256) or os.environ.get("OTPOSE_POINTX_FUSE", "1") != "0")
+                and act in (ACT_NONE, ACT_RELU) and inp.C == cin_w
+                and (cin_w in (64, 128, 256) or (os.environ.get("OTPOSE_POINTX_FUSE", "1") != "0" and cin_w % 16 == 0)
+                     or os.environ.get("OTPOSE_POINTX_ANY", "0") == "1")       # (opt-in: the RSB heads' and the final 1x1 convs too -
+                                                                              #  26.69 against 26.72 ms, and they leave exact fp32)
                 and ops.pointwise_x3_supported(cin_w, cout, inp.t.shape[2] * inp.t.shape[3])):
             # HRNet layer1's and the fuse layers' 1x1 convs (<= 256 channels in and out): register-resident pixels, streamed weights
             # (csrc/pointx.hip) - bound by their HBM streams, which the implicit-GEMM kernel ran at a third of the rate

@@ -390,7 +390,7 @@ def test_dense_and_qkv_front_x3_match_fp64(T, C):
 
 @pytest.mark.parametrize("cin,cout,res,relu", [(256, 64, False, True), (64, 256, True, True), (128, 256, False, True),
                                                 (64, 64, False, False), (256, 100, True, False), (96, 48, False, False),
-                                                (192, 96, True, True), (40, 20, False, True)])
+                                                (192, 96, True, True), (40, 20, False, True), (48, 17, False, False), (51, 80, True, True), (17, 24, False, False)])
 @pytest.mark.parametrize("hw", [(8, 8), (25, 10), (24, 18)])
 def test_pointwise_x3_matches_fp64(cin, cout, res, relu, hw):
     """csrc/pointx.hip (HRNet layer1's 1x1 convs, model/HRNet.py:551-571, with the BatchNorm folded into scale / shift) vs
@@ -399,6 +399,7 @@ def test_pointwise_x3_matches_fp64(cin, cout, res, relu, hw):
     B, (h, w) = 3, hw
     assert ops.pointwise_x3_supported(cin, cout, h * w) and not ops.pointwise_x3_supported(384, cout, h * w)
     assert not ops.pointwise_x3_supported(cin, 260, h * w) and not ops.pointwise_x3_supported(cin, cout, h * w + 1)
+    assert not ops.pointwise_x3_supported(8, cout, h * w)
     xt = seeded((B, cin + 24, h, w), 71)                   # the input is channels [16, 16 + cin) of a wider tensor
     wt, sc, sh = seeded((cout, cin), 72) / cin ** 0.5, 1.0 + 0.3 * seeded((cout,), 73), seeded((cout,), 74)
     rt = seeded((B, cout + 8, h, w), 75)                   # residual: channels [8, 8 + cout)
