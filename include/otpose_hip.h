@@ -66,6 +66,14 @@ int otp_mdcn_forward_ex(const void* x, const void* offset, const void* mask, con
  * (the reference accumulates them over the batch, cpp:638-650; the caller zeroes them, reference
  * functions/deform_conv.py:152-156).  grad_bias may be NULL.  workspace: otp_mdcn_backward_workspace bytes. */
 size_t otp_mdcn_backward_workspace(int N, int C, int H, int W, int Cout, int kh, int kw);
+/* exact workspace of one otp_mdcn_backward_ex call (otp_mdcn_backward_workspace is the upper bound over every geometry with
+ * that input size).  The backward holds NO order-dependent arithmetic (the reference's col2im scatters with float atomicAdd,
+ * deform_conv_cuda_kernel.cu:612-629): the fused fp32 3x3 form accumulates grad_x in 64-bit fixed point and adds per-workgroup
+ * partial sums of grad_x / grad_weight / grad_bias, kept in this workspace, in a fixed order - two calls on the same inputs
+ * return the same bits. */
+size_t otp_mdcn_backward_workspace_ex(int N, int C, int H, int W, int Cout, int kh, int kw, int stride_h, int stride_w, int pad_h,
+                                      int pad_w, int dil_h, int dil_w, int groups, int deformable_groups, int dtype,
+                                      int has_mask);
 int otp_mdcn_backward(const void* x, const void* offset, const void* mask, const void* weight,
                       const void* grad_out, void* grad_x, void* grad_offset, void* grad_mask,
                       void* grad_weight, void* grad_bias, void* workspace, size_t workspace_bytes,
@@ -458,10 +466,13 @@ int otp_pck_accuracy(const void* pred_coords, const void* target_coords, void* a
 
 /* ---- optimizer step of the training loop (script/Common.py:136-143: clip_grad_norm_ then optimizer.step(); AdamW built by
  * thirdparty/utils/train_utils.py:129-133) over flat, 16-byte aligned fp32 buffers ------------------------------------
- * otp_grad_sumsq: *acc_f64 += sum(grad^2) (zero it first; call once per flat gradient segment).
+ * otp_grad_sumsq: acc_f64[0] += sum(grad^2) (zero it first; call once per flat gradient segment).  acc_f64 addresses
+ * 1 + otp_grad_sumsq_scratch() doubles: the words behind the accumulator hold the per-workgroup partial sums, which a
+ * second launch adds in a fixed order (no float atomics: the clip coefficient is the same bits on every run).
  * otp_adamw_step: torch.optim.AdamW update of one hyper-parameter group, step >= 1 = the 1-based step count; the
  * gradient is first scaled by min(1, max_norm / (sqrt(*gradnorm_sq_f64) + 1e-6)) read on the device
  * (gradnorm_sq_f64 == NULL or max_norm <= 0: no clipping). */
+size_t otp_grad_sumsq_scratch(void);
 int otp_grad_sumsq(const void* grad, size_t n, void* acc_f64, void* stream);
 int otp_adamw_step(void* param, const void* grad, void* exp_avg, void* exp_avg_sq, size_t n, float lr, float beta1,
                    float beta2, float eps, float weight_decay, int step, const void* gradnorm_sq_f64, float max_norm,

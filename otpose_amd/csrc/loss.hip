@@ -41,8 +41,9 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restric
     int* fl = reinterpret_cast<int*>(sm + B * J);     // [J]
     float* acc = sm + B * J + J;      // [2]: ohkm sum, mse sum
     int* sel = reinterpret_cast<int*>(acc + 2);       // [B*J] 1 when (b,j) is in the sample's top-k
+    float* mj = reinterpret_cast<float*>(sel + B * J);      // [J] per-joint mse terms
+    float* ob = mj + J;                                     // [B] per-sample ohkm terms
     const int tid = threadIdx.x;
-    if (tid < 2) acc[tid] = 0.f;
     for (int j = tid; j < J; j += blockDim.x) {
         int f;
         if (flags_given) {
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restric
     if (tid < J) {
         float m = 0.f;
         for (int b = 0; b < B; ++b) m += stats[(b * J + tid) * 3] + (fl[tid] ? 0.f : stats[(b * J + tid) * 3 + 1]);
-        atomicAdd(&acc[1], m / ((float)B * (float)HW));
+        mj[tid] = m / ((float)B * (float)HW);
     }
     // ohkm: per sample the k largest joint losses (loss.py:13-23); ties resolved by lower joint index
     for (int b = tid; b < B; b += blockDim.x) {
@@ -82,10 +83,14 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restric
             sel[b * J + best] = 1;
             sum += bv;
         }
-        atomicAdd(&acc[0], sum / (float)topk);
+        ob[b] = sum / (float)topk;
     }
     __syncthreads();
-    if (tid == 0) {
+    if (tid == 0) {                   // sums in index order: the same bits on every run (no atomics)
+        float a0 = 0.f, a1 = 0.f;
+        for (int b = 0; b < B; ++b) a0 += ob[b];
+        for (int j = 0; j < J; ++j) a1 += mj[j];
+        acc[0] = a0; acc[1] = a1;
         const float ohkm = acc[0] / (float)B;
         result[0] = ohkm;
         result[1] = acc[1] / (float)J;
@@ -143,15 +148,16 @@ __global__ __launch_bounds__(256) void joints_finish_kernel(const float* __restr
     float* l = sm;                                    // [B*J]
     int* sel = reinterpret_cast<int*>(sm + B * J);    // [B*J]
     float* acc = sm + 2 * B * J;                      // [2]
+    float* mj = acc + 2;                              // [J] per-joint mse terms
+    float* ob = mj + J;                               // [B] per-sample ohkm terms
     const int tid = threadIdx.x;
-    if (tid < 2) acc[tid] = 0.f;
     const float inv_hw = 1.f / (float)HW;
     for (int i = tid; i < B * J; i += blockDim.x) { l[i] = 0.5f * ss[i] * inv_hw; sel[i] = 0; }
     __syncthreads();
     for (int j = tid; j < J; j += blockDim.x) {
         float m = 0.f;
         for (int b = 0; b < B; ++b) m += ss[b * J + j];
-        atomicAdd(&acc[1], m / ((float)B * (float)HW));
+        mj[j] = m / ((float)B * (float)HW);
     }
     if (ohkm)
         for (int b = tid; b < B; b += blockDim.x) {
@@ -165,10 +171,15 @@ __global__ __launch_bounds__(256) void joints_finish_kernel(const float* __restr
                 sel[b * J + best] = 1;
                 sum += bv;
             }
-            atomicAdd(&acc[0], sum / (float)topk);
+            ob[b] = sum / (float)topk;
         }
     __syncthreads();
-    if (tid == 0) {
+    if (tid == 0) {                                   // sums in index order (no atomics)
+        float a0 = 0.f, a1 = 0.f;
+        if (ohkm)
+            for (int b = 0; b < B; ++b) a0 += ob[b];
+        for (int j = 0; j < J; ++j) a1 += mj[j];
+        acc[0] = a0; acc[1] = a1;
         if (ohkm) {
             const float v = acc[0] / (float)B;
             result[0] = v; result[1] = acc[1] / eff; result[2] = v + acc[1];
@@ -204,7 +215,7 @@ extern "C" int otp_loss_st_ohkw_grads(const void* s, const void* t, const void* 
     if (!s || !t || !g || !w || !flags || !result || !workspace || B <= 0 || J <= 0 || HW <= 0 || topk <= 0 || topk > J)
         return OTP_ERR_BAD_ARG;
     if (workspace_bytes < otp_loss_workspace(B, J)) return OTP_ERR_WORKSPACE;
-    const size_t lds = ((size_t)B * J * 2 + J + 2) * sizeof(float);
+    const size_t lds = ((size_t)B * J * 2 + 2 * J + B + 2) * sizeof(float);
     if (lds > 64 * 1024) return OTP_ERR_UNSUPPORTED;
     auto st = static_cast<hipStream_t>(stream);
     auto f = [](const void* p) { return static_cast<const float*>(p); };
@@ -233,7 +244,7 @@ extern "C" int otp_loss_joints_mse(const void* o, const void* g, const void* w, 
     if (!o || !g || !result || !workspace || B <= 0 || J <= 0 || HW <= 0) return OTP_ERR_BAD_ARG;
     if (ohkm && (topk <= 0 || topk > J)) return OTP_ERR_BAD_ARG;
     if (workspace_bytes < otp_loss_workspace(B, J)) return OTP_ERR_WORKSPACE;
-    const size_t lds = ((size_t)B * J * 2 + 2) * sizeof(float);
+    const size_t lds = ((size_t)B * J * 2 + J + B + 2) * sizeof(float);
     if (lds > 64 * 1024) return OTP_ERR_UNSUPPORTED;
     auto st = static_cast<hipStream_t>(stream);
     auto f = [](const void* p) { return static_cast<const float*>(p); };

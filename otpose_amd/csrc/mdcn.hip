@@ -13,9 +13,10 @@
 //     output.zero_() and its separate bias add disappear.  alpha/beta fold the weighted sum over
 //     dilations of model/OTPose.py:387-392 into the store.
 //   * backward: a workgroup owns (image, deformable group, pixel chunk).  grad_x is accumulated in an
-//     LDS copy of the plane (ds_add_f32) instead of global float atomics; grad_offset / grad_mask are
-//     written once, coalesced; grad_weight / grad_bias partial sums live in registers and are reduced
-//     with wavefront shuffles, one atomic per (o,c,k) per workgroup.
+//     LDS copy of the plane as 64-bit fixed point (ds_add_u64: order-independent, so the backward is
+//     bit-reproducible - the reference's float atomics are not); grad_offset / grad_mask are written once,
+//     coalesced; grad_weight / grad_bias partial sums live in registers, are reduced with wavefront
+//     shuffles and leave as per-workgroup partials that a second launch adds in a fixed order.
 //
 // HBM roofline: algorithmic bytes per (image, call) = (C + 2*dg*K + dg*K + Cout) * H*W * 4
 // (13,630,464 B at C=Cout=dg=17, K=9, 96x72).
@@ -107,6 +108,11 @@ __device__ __forceinline__ void stage_plane(float* __restrict__ plane, const flo
             plane[(y + 1) * g.LW + PADL + xx] = src[i];
         }
     }
+}
+
+// nearest 64-bit integer of a fixed-point contribution; out-of-range / NaN (non-finite gradients) add nothing
+__device__ __forceinline__ long long fx_round(double v) {
+    return fabs(v) < 9.0e18 ? __double2ll_rn(v) : 0ll;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -318,28 +324,44 @@ __global__ __launch_bounds__(FWD_THREADS, 2) void mdcn_fwd_kernel(
 // ------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------
-// grid = (pixel chunks S, deformable groups, N), 256 threads.  LDS: x plane + grad_x plane (both with
-// the zero border) + [K][COP] weights of the current channel + reduction scratch.
+// grid = (pixel chunks S, deformable groups, N), 512 threads, one workgroup per CU.  LDS: grad_x accumulation plane (64-bit
+// integers) + x plane (both with the zero border) + [K][COP] weights of the current channel + reduction scratch.
 // CO_T must cover Cout (host restricts the fast path to Cout <= CO_T).
-constexpr int BWD_THREADS = 256;
+//
+// DETERMINISM (round 4).  The reference scatters grad_x with float atomicAdd (kernel.cu:612-629), whose result depends on the
+// order the adds arrive in; round 3 traced the run-to-run spread of the bf16 training backward (one step in five off by
+// 1e-3 .. 6e-3) to exactly such order noise (3e-8 here) being amplified by the 60 bf16-rounded layers behind it.  This kernel
+// has NO order-dependent arithmetic:
+//   * grad_x: every contribution v is rounded ONCE to a multiple of q = 2^(e-40), where 2^e > B >= |v| and
+//     B = max_k sum_o |W[o,c,k]| * max|grad_out| * max|mask| over the workgroup's pixels (maxima are order-independent), and
+//     added to the LDS plane as a 64-bit integer (ds_add_u64): integer addition is associative, so the plane is bit-identical
+//     whatever order the waves arrive in.  |v|/q < 2^40 and a cell receives < 2^20 contributions, so nothing overflows;
+//     the rounding error per contribution is <= 2^-41 B (a float atomic rounds the running sum to 2^-24 of itself per add).
+//   * a plane shared by S > 1 pixel chunks leaves as S partial planes (workspace) that a second launch adds in chunk order;
+//   * grad_weight / grad_bias: per-workgroup partial sums (fixed shuffle tree) into the workspace, added in workgroup order by
+//     the same second launch.
+constexpr int BWD_THREADS = 512;
+constexpr int BWD_WAVES = BWD_THREADS / 64;
+constexpr int BWD_SMAX = 8;                    // most pixel chunks per (image, deformable group)
 
 template <int CO_T>
-__global__ __launch_bounds__(BWD_THREADS, 2) void mdcn_bwd_kernel(
+__global__ __launch_bounds__(BWD_THREADS, 1) void mdcn_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ off, const float* __restrict__ msk,
-    const float* __restrict__ w, const float* __restrict__ gout, float* __restrict__ gx,
-    float* __restrict__ goff, float* __restrict__ gmsk, float* __restrict__ gw, float* __restrict__ gb,
-    Geom g, int chunk_px, int atomic_gx) {
+    const float* __restrict__ w, const float* __restrict__ gout, float* __restrict__ gxdst,
+    float* __restrict__ goff, float* __restrict__ gmsk, float* __restrict__ gwpart, float* __restrict__ gbpart,
+    Geom g, int chunk_px) {
     constexpr int COP = (CO_T + 3) & ~3;
     constexpr int K = 9;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* plane = smem;                       // x plane
-    float* gplane = smem + g.plane;            // grad_x accumulation plane
-    float* wl = gplane + g.plane;              // [K][COP] weights W[o][c][k] of channel c
-    float* red = wl + K * COP;                 // [4 waves][CO_T] reduction scratch
+    unsigned long long* gpl = reinterpret_cast<unsigned long long*>(smem);   // grad_x accumulation plane, fixed point
+    float* plane = smem + 2 * g.plane;         // x plane
+    float* wl = plane + g.plane;               // [K][COP] weights W[o][c][k] of channel c
+    float* red = wl + K * COP;                 // [BWD_WAVES][CO_T] reduction scratch (also the maxima of the bound)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int grp = blockIdx.y, n = blockIdx.z;
     const int p_begin = blockIdx.x * chunk_px;
     const int p_end = min(g.P, p_begin + chunk_px);
+    const int wslot = n * gridDim.x + blockIdx.x;          // this workgroup's row of the grad_weight / grad_bias partials
 
     zero_plane(plane, g.plane, tid, BWD_THREADS);
     const float* xn = x + (size_t)n * g.C * g.H * g.W;
@@ -350,11 +372,26 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void mdcn_bwd_kernel(
     const otp_rsrc rgmg = make_rsrc(gmsk + ((size_t)n * g.dg + grp) * K * g.P, (size_t)K * P4);
     const otp_rsrc rgon = make_rsrc(gout + (size_t)n * g.Co * g.P, (size_t)g.Co * P4);
 
+    // ---- the two data maxima of the contribution bound, over this workgroup's pixels ------------------------------
+    float gomax = 0.f, mmax = 0.f;
+    for (int p = p_begin + tid; p < p_end; p += BWD_THREADS) {
+#pragma unroll
+        for (int o = 0; o < CO_T; ++o) gomax = fmaxf(gomax, fabsf(bload(rgon, p * 4, o * P4)));   // rows >= Cout read 0
+#pragma unroll
+        for (int k = 0; k < K; ++k) mmax = fmaxf(mmax, fabsf(bload(rmg, p * 4, k * P4)));
+    }
+    gomax = wave_max(gomax);
+    mmax = wave_max(mmax);
+    if (lane == 0) { red[wave] = gomax; red[BWD_WAVES + wave] = mmax; }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < BWD_WAVES; ++i) { gomax = fmaxf(gomax, red[i]); mmax = fmaxf(mmax, red[BWD_WAVES + i]); }
+
     for (int cl = 0; cl < g.cpg_dg; ++cl) {
         const int c = grp * g.cpg_dg + cl;
         const int wgrp = c / g.cin_g;          // conv group of this input channel
         __syncthreads();
-        zero_plane(gplane, g.plane, tid, BWD_THREADS);
+        for (int i = tid; i < g.plane; i += BWD_THREADS) gpl[i] = 0ull;
         stage_plane(plane, xn + (size_t)c * g.H * g.W, g, tid, BWD_THREADS);
         for (int i = tid; i < K * COP; i += BWD_THREADS) {
             int k = i / COP, o = i - k * COP;
@@ -363,6 +400,26 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void mdcn_bwd_kernel(
             wl[i] = v;
         }
         __syncthreads();
+        if (tid < K) {
+            float s = 0.f;
+#pragma unroll
+            for (int o = 0; o < CO_T; ++o) s += fabsf(wl[tid * COP + o]);
+            red[tid] = s;
+        }
+        __syncthreads();
+        float wmax = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) wmax = fmaxf(wmax, red[k]);
+        // |gcol * mask * (bilinear weight <= 1)| <= bound (1.001: the fma chain of gcol rounds); 2^e > bound
+        const float bound = wmax * gomax * mmax * 1.001f;
+        double sc = 0.0, inv = 0.0;            // bound == 0: every contribution is 0; not finite: nothing sensible to add
+        if (bound > 0.f && bound < INFINITY) {
+            int e;
+            (void)frexpf(bound, &e);
+            sc = ldexp(1.0, 40 - e);
+            inv = ldexp(1.0, e - 40);
+        }
+        __syncthreads();                       // red is reused below
 
         float gbacc[CO_T];                     // sum_p gout[o,p] (reduced only by the channel-0 workgroups)
 #pragma unroll
@@ -411,46 +468,89 @@ __global__ __launch_bounds__(BWD_THREADS, 2) void mdcn_bwd_kernel(
                 bstore(gm, rgmg, p * 4, k * P4);
                 bstore(d_h, rgog, p * 4, (2 * k) * P4);
                 bstore(d_w, rgog, p * 4, (2 * k + 1) * P4);
-                // grad_x: scatter to the four corners of the LDS plane (border cells are dropped later)
-                atomicAdd(&gplane[t.addr], gc_m * hh * hw);
-                atomicAdd(&gplane[t.addr + 1], gc_m * hh * t.lw);
-                atomicAdd(&gplane[t.addr + g.LW], gc_m * t.lh * hw);
-                atomicAdd(&gplane[t.addr + g.LW + 1], gc_m * t.lh * t.lw);
+                // grad_x: scatter to the four corners of the LDS plane (border cells are dropped later), fixed point
+                if (gc_m != 0.f) {
+                    const double gs = (double)gc_m * sc;
+                    const double a1 = gs * (double)(hh * hw), a2 = gs * (double)(hh * t.lw);
+                    const double a3 = gs * (double)(t.lh * hw), a4 = gs * (double)(t.lh * t.lw);
+                    atomicAdd(&gpl[t.addr], (unsigned long long)fx_round(a1));
+                    atomicAdd(&gpl[t.addr + 1], (unsigned long long)fx_round(a2));
+                    atomicAdd(&gpl[t.addr + g.LW], (unsigned long long)fx_round(a3));
+                    atomicAdd(&gpl[t.addr + g.LW + 1], (unsigned long long)fx_round(a4));
+                }
                 const float col = in * bil * m;
 #pragma unroll
                 for (int o = 0; o < CO_T; ++o) gwacc[o] = fmaf(go[o], col, gwacc[o]);
             }
-            // grad_weight[:, c, k]: wave shuffle reduce, cross-wave through LDS, one atomic per output channel
+            // grad_weight[:, c, k] partial: wave shuffle reduce, cross-wave through LDS in wave order
 #pragma unroll
             for (int o = 0; o < CO_T; ++o) {
                 float sred = wave_sum(gwacc[o]);
                 if (lane == 0) red[wave * CO_T + o] = sred;
             }
             __syncthreads();
-            if (tid < CO_T && tid < g.Co && tid / g.cout_g == wgrp) {
-                float sred = red[tid] + red[CO_T + tid] + red[2 * CO_T + tid] + red[3 * CO_T + tid];
-                atomicAdd(&gw[((size_t)tid * g.cin_g + (c - wgrp * g.cin_g)) * K + k], sred);
+            if (tid < CO_T) {
+                float sred = 0.f;
+#pragma unroll
+                for (int i = 0; i < BWD_WAVES; ++i) sred += red[i * CO_T + tid];
+                gwpart[(((size_t)wslot * g.C + c) * K + k) * CO_T + tid] = sred;
             }
             __syncthreads();
         }
-        // ---- grad_x plane -> global ----------------------------------------------------------
-        float* gxc = gx + ((size_t)n * g.C + c) * g.H * g.W;
+        // ---- grad_x plane -> global (the tensor itself, or this chunk's partial plane) -----------------------
+        float* gxc = gxdst + (((size_t)blockIdx.x * g.N + n) * g.C + c) * g.H * g.W;
         for (int i = tid; i < g.H * g.W; i += BWD_THREADS) {
             int y = i / g.W, xx = i - y * g.W;
-            float v = gplane[(y + 1) * g.LW + PADL + xx];
-            if (atomic_gx) atomicAdd(&gxc[i], v); else gxc[i] = v;
+            gxc[i] = (float)((double)(long long)gpl[(y + 1) * g.LW + PADL + xx] * inv);
         }
-        // ---- grad_bias (channel-0 workgroups only) -------------------------------------------------
-        if (gb != nullptr && c == 0) {
+        // ---- grad_bias partial (channel-0 workgroups only) ---------------------------------------------------
+        if (gbpart != nullptr && c == 0) {
 #pragma unroll
             for (int o = 0; o < CO_T; ++o) {
                 float sred = wave_sum(gbacc[o]);
                 if (lane == 0) red[wave * CO_T + o] = sred;
             }
             __syncthreads();
-            if (tid < CO_T && tid < g.Co)
-                atomicAdd(&gb[tid], red[tid] + red[CO_T + tid] + red[2 * CO_T + tid] + red[3 * CO_T + tid]);
+            if (tid < CO_T) {
+                float sred = 0.f;
+#pragma unroll
+                for (int i = 0; i < BWD_WAVES; ++i) sred += red[i * CO_T + tid];
+                gbpart[(size_t)wslot * CO_T + tid] = sred;
+            }
         }
+    }
+}
+
+// gx = sum over the S partial planes, in chunk order (S > 1 only)
+__global__ __launch_bounds__(256) void mdcn_bwd_gx_reduce_kernel(const float* __restrict__ part, float* __restrict__ gx,
+                                                                  size_t total, int S) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        float s = part[i];
+        for (int j = 1; j < S; ++j) s += part[(size_t)j * total + i];
+        gx[i] = s;
+    }
+}
+
+// grad_weight[o][ci][k] += sum over the `slots` workgroup rows (row order) of the partials; same for grad_bias
+template <int CO_T>
+__global__ __launch_bounds__(256) void mdcn_bwd_param_reduce_kernel(const float* __restrict__ gwpart,
+                                                                     const float* __restrict__ gbpart, float* __restrict__ gw,
+                                                                     float* __restrict__ gb, Geom g, int slots) {
+    constexpr int K = 9;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int nw = g.Co * g.cin_g * K;
+    if (i < nw) {
+        const int k = i % K, ci = (i / K) % g.cin_g, o = i / (K * g.cin_g);
+        const int c = (o / g.cout_g) * g.cin_g + ci;
+        const float* src = gwpart + ((size_t)c * K + k) * CO_T + o;
+        float s = 0.f;
+        for (int r = 0; r < slots; ++r) s += src[(size_t)r * g.C * K * CO_T];
+        gw[i] += s;
+    } else if (gb != nullptr && i < nw + g.Co) {
+        const int o = i - nw;
+        float s = 0.f;
+        for (int r = 0; r < slots; ++r) s += gbpart[(size_t)r * CO_T + o];
+        gb[o] += s;
     }
 }
 
@@ -534,9 +634,67 @@ extern "C" int otp_mdcn_forward(const void* x, const void* offset, const void* m
                                groups, deformable_groups, alpha, beta, dtype, stream);
 }
 
+namespace {
+
+// Launch plan of the fused fp32 3x3 backward: pixel chunks per (image, deformable group) and the workspace it needs
+// ([S partial grad_x planes when S > 1][grad_weight partials per workgroup row][grad_bias partials per workgroup row]).
+constexpr int BWD_CO_T = 17;
+struct BwdPlan { int S, chunk; size_t gx_part, gw_part, gb_part; };
+
+size_t bwd_need(const Geom& g, int S) {
+    const size_t rows = (size_t)g.N * S;
+    return ((S > 1 ? (size_t)S * g.N * g.C * g.H * g.W : 0) + rows * g.C * 9 * BWD_CO_T + rows * BWD_CO_T) * sizeof(float);
+}
+
+BwdPlan bwd_plan(const Geom& g, size_t workspace_bytes) {
+    // pixel chunks: enough workgroups (one per CU) to fill 256 CUs a few times over
+    const int wgs = g.N * g.dg;
+    int S = 1;
+    while (S < BWD_SMAX && wgs * S < 1024 && g.P / (S * 2) >= BWD_THREADS) S *= 2;
+    while (S > 1 && workspace_bytes < bwd_need(g, S)) S /= 2;          // a small workspace costs parallelism, not the result
+    BwdPlan p;
+    p.chunk = otp_ceil_div(otp_ceil_div(g.P, S), 64) * 64;
+    p.S = otp_ceil_div(g.P, p.chunk);
+    p.gx_part = p.S > 1 ? (size_t)p.S * g.N * g.C * g.H * g.W : 0;
+    p.gw_part = (size_t)g.N * p.S * g.C * 9 * BWD_CO_T;
+    p.gb_part = (size_t)g.N * p.S * BWD_CO_T;
+    return p;
+}
+
+bool bwd_fast(Geom& g, int N, int C, int H, int W, int Cout, int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w,
+              int dil_h, int dil_w, int groups, int dg, int dtype, bool has_mask, size_t* lds) {
+    const bool iso = stride_h == stride_w && pad_h == pad_w && dil_h == dil_w;
+    if (!(dtype == OTP_DTYPE_F32 && iso && has_mask && kh == 3 && kw == 3 && Cout <= BWD_CO_T)) return false;
+    if (!make_geom(g, N, C, H, W, Cout, kh, kw, stride_h, pad_h, dil_h, groups, dg)) return false;
+    constexpr int COP = (BWD_CO_T + 3) & ~3;
+    *lds = ((size_t)3 * g.plane + 9 * COP + BWD_WAVES * BWD_CO_T) * sizeof(float);
+    return *lds <= OTP_LDS_LIMIT;
+}
+
+}  // namespace
+
+// exact size for one call (the fused fp32 3x3 form chooses its pixel chunks from the geometry)
+extern "C" size_t otp_mdcn_backward_workspace_ex(int N, int C, int H, int W, int Cout, int kh, int kw, int stride_h, int stride_w,
+                                                 int pad_h, int pad_w, int dil_h, int dil_w, int groups,
+                                                 int deformable_groups, int dtype, int has_mask) {
+    Geom g;
+    size_t lds = 0;
+    const size_t generic = otp_mdcn_generic_backward_workspace(C, Cout, kh, kw, groups > 0 ? groups : 1);
+    if (!bwd_fast(g, N, C, H, W, Cout, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, groups, deformable_groups, dtype,
+                  has_mask != 0, &lds))
+        return generic;
+    const BwdPlan p = bwd_plan(g, (size_t)-1);
+    const size_t need = (p.gx_part + p.gw_part + p.gb_part) * sizeof(float);
+    return need > generic ? need : generic;
+}
+
+// upper bound over every geometry with this input size (most pixel chunks, most workgroup rows)
 extern "C" size_t otp_mdcn_backward_workspace(int N, int C, int H, int W, int Cout, int kh, int kw) {
-    (void)N, (void)H, (void)W;
-    return otp_mdcn_generic_backward_workspace(C, Cout, kh, kw, 1);      // groups = 1 is the largest case
+    const size_t generic = otp_mdcn_generic_backward_workspace(C, Cout, kh, kw, 1);      // groups = 1 is the largest case
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0) return generic;
+    const size_t rows = (size_t)N * BWD_SMAX;
+    const size_t need = ((size_t)BWD_SMAX * N * C * H * W + rows * C * 9 * BWD_CO_T + rows * BWD_CO_T) * sizeof(float);
+    return need > generic ? need : generic;
 }
 
 extern "C" int otp_mdcn_backward_ex(const void* x, const void* offset, const void* mask, const void* weight,
@@ -547,37 +705,36 @@ extern "C" int otp_mdcn_backward_ex(const void* x, const void* offset, const voi
     if (!x || !offset || !weight || !grad_out || !grad_x || !grad_offset || !grad_weight) return OTP_ERR_BAD_ARG;
     if (mask && !grad_mask) return OTP_ERR_BAD_ARG;
     auto st = static_cast<hipStream_t>(stream);
-    const bool iso = stride_h == stride_w && pad_h == pad_w && dil_h == dil_w;
     Geom g;
-    bool fast = dtype == OTP_DTYPE_F32 && iso && mask && kh == 3 && kw == 3 && Cout <= 17 &&
-                make_geom(g, N, C, H, W, Cout, kh, kw, stride_h, pad_h, dil_h, groups, deformable_groups);
-    constexpr int CO_T = 17, COP = 20, K = 9;
     size_t lds = 0;
-    if (fast) {
-        lds = ((size_t)2 * g.plane + K * COP + 4 * CO_T) * sizeof(float);
-        fast = lds <= OTP_LDS_LIMIT;
-    }
-    if (!fast)
+    if (!bwd_fast(g, N, C, H, W, Cout, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, groups, deformable_groups, dtype,
+                  mask != nullptr, &lds))
         return otp_mdcn_generic_backward(x, offset, mask, weight, grad_out, grad_x, grad_offset, grad_mask, grad_weight, grad_bias,
                                          workspace, workspace_bytes, N, C, H, W, Cout, kh, kw, stride_h, stride_w, pad_h, pad_w,
                                          dil_h, dil_w, groups, deformable_groups, dtype, st);
-    // pixel chunks: enough workgroups to fill 256 CUs a few times over
-    int wgs = N * deformable_groups;
-    int S = 1;
-    while (wgs * S < 1024 && g.P / (S * 2) >= 4 * BWD_THREADS) S *= 2;
-    int chunk = otp_ceil_div(otp_ceil_div(g.P, S), BWD_THREADS) * BWD_THREADS;
-    S = otp_ceil_div(g.P, chunk);
-    int atomic_gx = S > 1;
-    if (atomic_gx)
-        if (hipMemsetAsync(grad_x, 0, (size_t)N * C * H * W * sizeof(float), st) != hipSuccess) return OTP_ERR_LAUNCH;
-    auto kern = mdcn_bwd_kernel<CO_T>;
+    const BwdPlan p = bwd_plan(g, workspace ? workspace_bytes : 0);
+    if (!workspace || workspace_bytes < (p.gx_part + p.gw_part + p.gb_part) * sizeof(float)) return OTP_ERR_WORKSPACE;
+    float* gxpart = static_cast<float*>(workspace);
+    float* gwpart = gxpart + p.gx_part;
+    float* gbpart = gwpart + p.gw_part;
+    auto kern = mdcn_bwd_kernel<BWD_CO_T>;
     OTP_ALLOW_BIG_LDS(kern, lds);
-    hipLaunchKernelGGL(kern, dim3(S, deformable_groups, N), dim3(BWD_THREADS), lds, st,
+    hipLaunchKernelGGL(kern, dim3(p.S, deformable_groups, N), dim3(BWD_THREADS), lds, st,
                        static_cast<const float*>(x), static_cast<const float*>(offset),
                        static_cast<const float*>(mask), static_cast<const float*>(weight),
-                       static_cast<const float*>(grad_out), static_cast<float*>(grad_x),
-                       static_cast<float*>(grad_offset), static_cast<float*>(grad_mask),
-                       static_cast<float*>(grad_weight), static_cast<float*>(grad_bias), g, chunk, atomic_gx);
+                       static_cast<const float*>(grad_out), p.S > 1 ? gxpart : static_cast<float*>(grad_x),
+                       static_cast<float*>(grad_offset), static_cast<float*>(grad_mask), gwpart,
+                       grad_bias ? gbpart : nullptr, g, p.chunk);
+    if (p.S > 1) {
+        const size_t total = (size_t)N * C * H * W;
+        const size_t blocks = (total + 255) / 256;
+        hipLaunchKernelGGL(mdcn_bwd_gx_reduce_kernel, dim3(blocks > 4096 ? 4096 : (unsigned)blocks), dim3(256), 0, st, gxpart,
+                           static_cast<float*>(grad_x), total, p.S);
+    }
+    const int nw = g.Co * g.cin_g * 9 + g.Co;
+    hipLaunchKernelGGL(mdcn_bwd_param_reduce_kernel<BWD_CO_T>, dim3(otp_ceil_div(nw, 256)), dim3(256), 0, st, gwpart,
+                       grad_bias ? gbpart : nullptr, static_cast<float*>(grad_weight), static_cast<float*>(grad_bias), g,
+                       N * p.S);
     return otp_launch_status();
 }
 

@@ -1,14 +1,18 @@
 // Optimizer step of the reference training loop (script/Common.py:136-143): global-norm gradient clipping
 // (torch.nn.utils.clip_grad_norm_, max_norm = TRAIN.CLIP_GRAD_L2NORM) followed by AdamW
 // (thirdparty/utils/train_utils.py:129-133, torch.optim.AdamW semantics) over FLAT parameter / gradient / moment buffers.
-// Two HBM-bound passes: sum of squares (fp64 partials, one atomic per workgroup) and the fused clip + update, which reads the
+// Two HBM-bound passes: sum of squares (fp64 partials per workgroup, added in a fixed order: no atomics, the same bits on
+// every run) and the fused clip + update, which reads the
 // clip coefficient from device memory - no host synchronisation between backward and the next forward.
 #include "common.h"
 
 namespace {
 
+constexpr int SUMSQ_PARTS = 1024;       // most workgroups of one sum-of-squares launch = scratch doubles behind the accumulator
+
+// part[block] = this workgroup's share of sum(g^2) (fp64, fixed order: strided per-thread sums, shuffle tree, waves in order)
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, size_t n4, size_t n,
-                                                     double* __restrict__ acc) {
+                                                     double* __restrict__ part) {
     __shared__ double red[4];
     double s = 0.0;
     const otp_f32x4* g4 = reinterpret_cast<const otp_f32x4*>(g);
@@ -22,7 +26,19 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(acc, red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// *acc += sum of the `parts` partials in a fixed order (one workgroup; no atomics: the same bits on every run)
+__global__ __launch_bounds__(256) void sumsq_finish_kernel(const double* __restrict__ part, int parts, double* __restrict__ acc) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < parts; i += 256) s += part[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) *acc += (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 __device__ __forceinline__ void adamw_one(float& p, float g, float& m, float& v, float clip, float lr_wd, float b1, float b2,
@@ -72,11 +88,17 @@ unsigned grid_for(size_t n4) {
 
 }  // namespace
 
+extern "C" size_t otp_grad_sumsq_scratch(void) { return SUMSQ_PARTS; }
+
 extern "C" int otp_grad_sumsq(const void* grad, size_t n, void* acc_f64, void* stream) {
     if (!grad || !acc_f64 || n == 0) return OTP_ERR_BAD_ARG;
     if (reinterpret_cast<uintptr_t>(grad) & 15) return OTP_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       static_cast<const float*>(grad), n / 4, n, static_cast<double*>(acc_f64));
+    unsigned grid = grid_for(n / 4);
+    if (grid > SUMSQ_PARTS) grid = SUMSQ_PARTS;
+    double* acc = static_cast<double*>(acc_f64);
+    auto st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, st, static_cast<const float*>(grad), n / 4, n, acc + 1);
+    hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(256), 0, st, acc + 1, (int)grid, acc);
     return otp_launch_status();
 }
 

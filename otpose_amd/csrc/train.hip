@@ -401,34 +401,60 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restr
     }
 }
 
-// dW[co][ci][tap] += sum over the gx workgroups of one (co-group, ci-group) of their partial accumulators.
-// grid (slot blocks, 8 segments of the workgroup range, co-group * ci-group); a thread owns one fragment slot.
+// dW[co][ci][tap] += sum over the gx workgroups of one (co-group, ci-group) of their partial accumulators, in a FIXED order
+// (round 4: no float atomics - the result is the same bits on every run).  grid (blocks of 32 per-wave fragment slots,
+// co-group * ci-group); 256 threads = 32 slots x 8 segments of the workgroup range; the segments meet in LDS and are added
+// in order.  A thread walks the four waves' copies of its slot: with 1x1 kernels the waves split the pixel steps of the same
+// (co, ci) tile, so their sums are added (wave order) into ONE weight; otherwise each wave's slot is a weight of its own.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int gx,
                                                             int gy, int Cout, int Cin, int KS) {
-    const int slot = blockIdx.x * 256 + threadIdx.x;                    // [wave][g][b][r][lane]
-    if (slot >= WG_SLOTS) return;
-    const int lane = slot & 63, r = (slot >> 6) & 3, gb = slot >> 8;    // gb = (wave * 7 + g) * 3 + b
-    const int b = gb % 3, wg = gb / 3, g = wg % WG_GROUPS, wave = wg / WG_GROUPS;
-    const int by = blockIdx.z % gy, bz = blockIdx.z / gy;
+    __shared__ float red[4][8][32];
+    constexpr int WSLOTS = WG_SLOTS / 4;                                // slots of one wave: [g][b][r][lane]
+    const int sl = threadIdx.x & 31, sg = threadIdx.x >> 5;
+    const int sub = blockIdx.x * 32 + sl;
+    const int seg = (gx + 7) >> 3;
+    const int w0 = sg * seg, w1 = min(gx, w0 + seg);
+#pragma unroll
+    for (int wave = 0; wave < 4; ++wave) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        if (sub < WSLOTS && w1 > w0) {
+            const float* src = part + ((size_t)blockIdx.y * gx + w0) * WG_SLOTS + wave * WSLOTS + sub;
+            int w = w0;
+            for (; w + 3 < w1; w += 4, src += 4 * (size_t)WG_SLOTS) {
+                s0 += src[0]; s1 += src[WG_SLOTS]; s2 += src[2 * (size_t)WG_SLOTS]; s3 += src[3 * (size_t)WG_SLOTS];
+            }
+            for (; w < w1; ++w, src += WG_SLOTS) s0 += src[0];
+        }
+        red[wave][sg][sl] = (s0 + s1) + (s2 + s3);
+    }
+    __syncthreads();
+    if (sg != 0 || sub >= WSLOTS) return;
+    const int lane = sub & 63, r = (sub >> 6) & 3, gb = sub >> 8;       // gb = g * 3 + b
+    const int b = gb % 3, g = gb / 3;
+    const int by = blockIdx.y % gy, bz = blockIdx.y / gy;
     const int co0 = by * WG_CO, ci0 = bz * WG_CI, KK = KS * KS;
     const int ncib = min(3, (Cin - ci0 + 15) >> 4), ncob = min(3, (Cout - co0 + 15) >> 4);
     const bool split_steps = KK == 1;
     const int ncombo = KK * ncib;
-    const int combo = split_steps ? g : wave + 4 * g;
-    if (combo >= ncombo || b >= ncob) return;
-    const int tap = combo / ncib, cib = combo - tap * ncib;
-    const int co = co0 + b * 16 + (lane >> 4) * 4 + r, ci = ci0 + cib * 16 + (lane & 15);
-    if (co >= Cout || ci >= Cin) return;
-    const int seg = (gx + gridDim.y - 1) / gridDim.y;
-    const int w0 = blockIdx.y * seg, w1 = min(gx, w0 + seg);
-    const float* src = part + ((size_t)blockIdx.z * gx + w0) * WG_SLOTS + slot;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int w = w0;
-    for (; w + 3 < w1; w += 4, src += 4 * (size_t)WG_SLOTS) {
-        s0 += src[0]; s1 += src[WG_SLOTS]; s2 += src[2 * (size_t)WG_SLOTS]; s3 += src[3 * (size_t)WG_SLOTS];
+    const int co = co0 + b * 16 + (lane >> 4) * 4 + r;
+    if (b >= ncob || co >= Cout) return;
+    float total = 0.f;
+#pragma unroll
+    for (int wave = 0; wave < 4; ++wave) {
+        float v = red[wave][0][sl];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) v += red[wave][k][sl];
+        if (split_steps) { total += v; continue; }
+        const int combo = wave + 4 * g;
+        if (combo >= ncombo) continue;
+        const int tap = combo / ncib, cib = combo - tap * ncib;
+        const int ci = ci0 + cib * 16 + (lane & 15);
+        if (ci < Cin) dw[((size_t)co * Cin + ci) * KK + tap] += v;
     }
-    for (; w < w1; ++w, src += WG_SLOTS) s0 += src[0];
-    if (w1 > w0) atomicAdd(&dw[((size_t)co * Cin + ci) * KK + tap], (s0 + s1) + (s2 + s3));
+    if (split_steps && g < ncombo) {
+        const int ci = ci0 + g * 16 + (lane & 15);                      // tap 0, ci block g
+        if (ci < Cin) dw[(size_t)co * Cin + ci] += total;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -795,20 +821,18 @@ extern "C" int otp_conv2d_wgrad(const void* x, const void* grad_out, void* grad_
     const int gy = otp_ceil_div(Cout, WG_CO), gz = otp_ceil_div(Cin, WG_CI);
     int gx = wgrad_grid_x(Cout, Cin);
     if (gx > P.ntiles) gx = P.ntiles;
-    // workspace given: per-workgroup partial sums + a reduction (no contended atomics); NULL: atomics straight into dW
+    // workspace given: per-workgroup partial sums + a fixed-order reduction (bit-reproducible); NULL: float atomics straight
+    // into dW (result depends on their order in the last bits)
     float* part = static_cast<float*>(workspace);
     if (part && workspace_bytes < (size_t)gx * gy * gz * WG_SLOTS * sizeof(float)) return OTP_ERR_WORKSPACE;
-    if (gx < 4) part = nullptr;                           // a handful of workgroups: the atomics are not contended
     auto kern = conv_wgrad_kernel;
     OTP_ALLOW_BIG_LDS(kern, lds);
     auto st = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(kern, dim3(gx, gy, gz), dim3(256), lds, st, static_cast<const float*>(x),
                        static_cast<const float*>(grad_out), static_cast<float*>(grad_weight), part, P);
-    if (part) {
-        const int segs = gx >= 64 ? 8 : (gx >= 16 ? 4 : 1);
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(WG_SLOTS / 256, segs, gy * gz), dim3(256), 0, st, part,
+    if (part)
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(otp_ceil_div(WG_SLOTS / 4, 32), gy * gz), dim3(256), 0, st, part,
                            static_cast<float*>(grad_weight), gx, gy, Cout, Cin, kh);
-    }
     return otp_launch_status();
 }
 

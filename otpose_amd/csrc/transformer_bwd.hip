@@ -277,15 +277,19 @@ __global__ void dwconv3_bwd_x_kernel(const float* __restrict__ dy, const float* 
     dx[(size_t)blockIdx.y * T + t] = s;
 }
 
-// dw[c][k] = sum_{b, to} dy[b,c,to] * x[b,c,to*s-1+k]; grid (C, splits), accumulated with atomics (dw zeroed by the caller)
-__global__ __launch_bounds__(256) void dwconv3_bwd_w_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                             float* __restrict__ dw, int B, int C, int T, int To,
-                                                             int stride) {
-    __shared__ float red[3][4];
+// dw[c][k] += sum_{b, to} dy[b,c,to] * x[b,c,to*s-1+k]; grid (C): ONE workgroup of 1024 threads per channel, so the sum has a
+// fixed order (strided per-thread sums, shuffle tree, waves in order) and the result is the same bits on every run - the
+// (C, splits) grid with one float atomic per split that this replaces was not (round 4).  A channel is 2 * B * To floats
+// (0.9 MB at 16 x 6912): C = 136 workgroups stream it at the same rate the split grid did.
+constexpr int DWW_THREADS = 1024;
+__global__ __launch_bounds__(DWW_THREADS) void dwconv3_bwd_w_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                     float* __restrict__ dw, int B, int C, int T, int To,
+                                                                     int stride) {
+    __shared__ float red[3][DWW_THREADS / 64];
     const int c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t total = (size_t)B * To;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    for (size_t i = (size_t)blockIdx.y * 256 + threadIdx.x; i < total; i += (size_t)gridDim.y * 256) {
+    for (size_t i = threadIdx.x; i < total; i += DWW_THREADS) {
         const int b = (int)(i / To), to = (int)(i - (size_t)b * To);
         const float* xr = x + ((size_t)b * C + c) * T;
         const float g = dy[((size_t)b * C + c) * To + to];
@@ -297,8 +301,12 @@ __global__ __launch_bounds__(256) void dwconv3_bwd_w_kernel(const float* __restr
     s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
     if (lane == 0) { red[0][wave] = s0; red[1][wave] = s1; red[2][wave] = s2; }
     __syncthreads();
-    if (threadIdx.x < 3)
-        atomicAdd(&dw[c * 3 + threadIdx.x], red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+    if (threadIdx.x < 3) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < DWW_THREADS / 64; ++i) s += red[threadIdx.x][i];
+        dw[c * 3 + threadIdx.x] += s;
+    }
 }
 
 // ---- GELU (exact erf) --------------------------------------------------------------------------------------
@@ -452,9 +460,7 @@ extern "C" int otp_dwconv3_backward(const void* x, const void* w, const void* gr
     hipLaunchKernelGGL(dwconv3_bwd_x_kernel, dim3(otp_ceil_div(T, 256), B * C), dim3(256), 0, st,
                        static_cast<const float*>(grad_y), static_cast<const float*>(w), static_cast<float*>(grad_x), C, T, To,
                        stride);
-    int splits = 1;
-    while (C * splits < 1024 && (size_t)B * To / (splits * 2) >= 1024) splits *= 2;
-    hipLaunchKernelGGL(dwconv3_bwd_w_kernel, dim3(C, splits), dim3(256), 0, st, static_cast<const float*>(x),
+    hipLaunchKernelGGL(dwconv3_bwd_w_kernel, dim3(C), dim3(DWW_THREADS), 0, st, static_cast<const float*>(x),
                        static_cast<const float*>(grad_y), static_cast<float*>(grad_w), B, C, T, To, stride);
     return otp_launch_status();
 }

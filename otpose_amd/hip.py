@@ -47,6 +47,7 @@ SIGNATURES = {
     "otp_mdcn_forward_ex": (c_int, [c_void_p] * 6 + [c_int] * 15 + [c_float, c_float, c_int, c_void_p]),
     "otp_mdcn_backward_ex": (c_int, [c_void_p] * 10 + [c_void_p, c_size_t] + [c_int] * 15 + [c_int, c_void_p]),
     "otp_mdcn_backward_workspace": (c_size_t, [c_int] * 7),
+    "otp_mdcn_backward_workspace_ex": (c_size_t, [c_int] * 17),
     "otp_mdcn_backward": (c_int, [c_void_p] * 10 + [c_void_p, c_size_t] + [c_int] * 12 + [c_int, c_void_p]),
     "otp_conv2d_pack_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "otp_conv2d": (c_int, [c_void_p] * 7 + [ctypes.POINTER(ConvDesc), c_void_p]),
@@ -77,6 +78,7 @@ SIGNATURES = {
     "otp_conv2d_plan": (c_int, [ctypes.POINTER(ConvDesc), ctypes.POINTER(c_int)]),
     "otp_conv2d_pack_weight_dgrad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "otp_dilate": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "otp_grad_sumsq_scratch": (c_size_t, []),
     "otp_grad_sumsq": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
     "otp_adamw_step": (c_int, [c_void_p] * 4 + [c_size_t] + [c_float] * 5 + [c_int, c_void_p, c_float, c_void_p]),
     "otp_pck_accuracy": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_float, c_void_p]),

@@ -100,7 +100,8 @@ def modulated_deform_conv_cuda_backward(input, weight, bias, ones, offset, mask,
     mask = mask.contiguous() if mask is not None else None
     grad_output = grad_output.contiguous()
     L = hip.lib()
-    ws_bytes = L.otp_mdcn_backward_workspace(n, c, h, w, cout, kernel_h, kernel_w)
+    ws_bytes = L.otp_mdcn_backward_workspace_ex(n, c, h, w, cout, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w,
+                                                dilation_h, dilation_w, group, deformable_group, dtype, int(mask is not None))
     ws = torch.empty(max(int(ws_bytes), 8) // 8, dtype=torch.float64, device=input.device)
     st = L.otp_mdcn_backward_ex(
         hip.ptr(input), hip.ptr(offset), hip.ptr(mask), hip.ptr(weight), hip.ptr(grad_output),

@@ -62,7 +62,9 @@ class FusedAdamW(torch.optim.Optimizer):
             self._flat.append({"p": fp, "g": fg, "m": fm, "v": fv, "params": ps, "step": 0,
                                "gptr": [p._otp_grad_slot.data_ptr() for p in ps]})
         devs = {f["p"].device for f in self._flat if f}
-        self._normsq = {d: torch.zeros(1, dtype=torch.float64, device=d) for d in devs}
+        # [0]: the squared norm; behind it the scratch of otp_grad_sumsq's fixed-order reduction
+        scratch = int(hip.lib().otp_grad_sumsq_scratch())
+        self._normsq = {d: torch.zeros(1 + scratch, dtype=torch.float64, device=d) for d in devs}
 
     def _rehome_grads(self):
         """``p.grad`` must stay a view of the flat gradient buffer.  ``model.zero_grad()`` (set_to_none=True by default)
@@ -112,13 +114,13 @@ class FusedAdamW(torch.optim.Optimizer):
         if not _rehomed:
             self._rehome_grads()
         for acc in self._normsq.values():
-            acc.zero_()
+            acc[:1].zero_()
         for f in self._flat:
             if f:
                 hip.check(L.otp_grad_sumsq(hip.ptr(f["g"]), f["g"].numel(), hip.ptr(self._normsq[f["g"].device]),
                                            hip.stream_of(f["g"])), "otp_grad_sumsq")
         accs = list(self._normsq.values())
-        return accs[0].sqrt() if len(accs) == 1 else torch.stack([a.cpu() for a in accs]).sum().sqrt()
+        return accs[0][:1].sqrt() if len(accs) == 1 else torch.stack([a[:1].cpu() for a in accs]).sum().sqrt()
 
     @torch.no_grad()
     def step(self, closure=None):
