@@ -376,6 +376,29 @@ def gen_e2e_seeds():
     save("e2e_seeds", **arrays)
 
 
+def gen_e2e_cfg2_seeds():
+    """the headline configuration (cfg2: 384x288, HRNet-W48) under two MORE weight draws, one clip each
+    with an input seed of its own - the split-product arithmetic's error is data dependent, so one weight draw is not a
+    distribution.  Stored per draw: output heat-maps, rough heat-maps of the current frame, context, max|.| of all seven."""
+    names = ("output", "rough", "intersection", "prev_b", "context", "squeezed", "total_b")
+    arrays = {}
+    cfg = C.cfg2()
+    with torch.no_grad():
+        for ws, xs in ((777, 31), (4242, 32)):
+            m = ref_otpose(cfg)
+            S.fill_synthetic_(m, ws, S.gains_for(cfg))
+            m.eval()
+            x, margin = S.synthetic_clip(1, cfg.MODEL.IMAGE_SIZE, seed=xs)
+            outs = m(x, margin=margin)
+            tag = f"cfg2_w{ws}_x{xs}"
+            arrays[tag + "_output"] = outs[0]
+            arrays[tag + "_rough_cur"] = outs[1][:1]
+            arrays[tag + "_context"] = outs[4]
+            arrays[tag + "_absmax"] = np.array([float(o.abs().max()) for o in outs])
+            print(f"  {tag}: " + " ".join(f"{n}={float(o.abs().max()):.3g}" for n, o in zip(names, outs)))
+    save("e2e_cfg2_seeds", **arrays)
+
+
 def _oracle_run(cfg, b, gains):
     from otpose_amd import OTPose
     m = OTPose(cfg)
@@ -415,7 +438,8 @@ def calibrate():
 
 
 GENS = {"keys": gen_state_dict_keys, "blocks": gen_blocks, "hrnet_tiny": gen_hrnet_tiny,
-        "losses": gen_losses, "decode": gen_decode, "accuracy": gen_accuracy, "e2e_tiny": gen_e2e_tiny, "e2e_cfg1": gen_e2e_cfg1, "e2e_cfg2": gen_e2e_cfg2, "train_step": gen_train_step, "e2e_seeds": gen_e2e_seeds}
+        "losses": gen_losses, "decode": gen_decode, "accuracy": gen_accuracy, "e2e_tiny": gen_e2e_tiny, "e2e_cfg1": gen_e2e_cfg1, "e2e_cfg2": gen_e2e_cfg2, "train_step": gen_train_step, "e2e_seeds": gen_e2e_seeds,
+        "e2e_cfg2_seeds": gen_e2e_cfg2_seeds}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

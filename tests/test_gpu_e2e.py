@@ -167,6 +167,66 @@ def test_headline_batch_agrees_with_the_single_clip_the_golden_pins(golden):
         assert float((a - r).abs().max()) <= 2e-5 * max(1.0, float(r.abs().max())), n
 
 
+def test_headline_batch_all_16_clips_match_the_oracle():
+    """EVERY clip of the batch bench.py times (BASELINE configs[1]: 16 clips x 5 x 384x288, HRNet-W48,
+    reference path model/OTPose.py:307-394) against the CPU oracle on the same 16 clips (four oracle forwards of four clips;
+    the oracle itself is pinned by the reference-generated goldens, tests/test_oracle_golden.py).  The default eval arithmetic
+    is split-bf16 products with fp32 accumulation, whose error is data dependent, so the bound is checked per clip and the
+    per-clip maxima are printed as a distribution: heat-maps (output, rough) <= 1e-3 ABSOLUTE on every clip."""
+    from oracle import otpose_oracle as O
+    cfg = cfg2()
+    x, margin = S.synthetic_clip(16, cfg.MODEL.IMAGE_SIZE)
+    margin[5] = torch.tensor([0.0, 1.0, 0.0, 2.0])        # sequence borders inside the batch
+    margin[11] = torch.tensor([1.0, 0.0, 2.0, 0.0])
+    m = OTPose(cfg)
+    S.fill_synthetic_(m)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.cuda().eval()
+    with torch.no_grad():
+        outs = [o.cpu() for o in m(x.cuda(), margin=margin.cuda())]
+    rows = lambda t, lo, hi: t[lo:hi] if t.shape[0] == 16 else torch.cat([t[f * 16 + lo:f * 16 + hi] for f in range(5)])   # noqa: E731
+    per_clip = {n: [] for n in NAMES}
+    for lo in range(0, 16, 4):
+        with torch.no_grad():
+            ref = O.otpose_forward(sd, cfg, x[lo:lo + 4], margin[lo:lo + 4])
+        for n, o, r in zip(NAMES, outs, ref):
+            ob = rows(o, lo, lo + 4)
+            assert ob.shape == r.shape, n
+            for k in range(4):
+                a = ob[k:k + 1] if o.shape[0] == 16 else ob[k::4]
+                b = r[k:k + 1] if o.shape[0] == 16 else r[k::4]
+                per_clip[n].append(float((a - b).abs().max()))
+                scale = max(1.0, float(b.abs().max()))
+                assert per_clip[n][-1] <= TOL * scale, (n, lo + k, per_clip[n][-1], scale)
+    for n in NAMES:
+        v = per_clip[n]
+        print("%-13s per-clip max |delta| vs oracle: min %.2e median %.2e max %.2e" % (n, min(v), sorted(v)[8], max(v)))
+    assert max(per_clip["output"]) <= TOL and max(per_clip["rough"]) <= TOL
+
+
+@pytest.mark.parametrize("ws,xs", [(777, 31), (4242, 32)])
+def test_e2e_cfg2_two_more_weight_seeds(golden, ws, xs):
+    """cfg2 under two more weight draws against reference-generated goldens
+    (tests/golden/make_golden.py::gen_e2e_cfg2_seeds): heat-maps <= 1e-3 ABSOLUTE."""
+    g = golden("e2e_cfg2_seeds")
+    cfg = cfg2()
+    m = OTPose(cfg)
+    S.fill_synthetic_(m, ws, S.gains_for(cfg))
+    m = m.cuda().eval()
+    x, margin = S.synthetic_clip(1, cfg.MODEL.IMAGE_SIZE, seed=xs)
+    with torch.no_grad():
+        outs = [o.cpu() for o in m(x.cuda(), margin=margin.cuda())]
+    tag = f"cfg2_w{ws}_x{xs}"
+    errs = {"output": float((outs[0] - g[tag + "_output"]).abs().max()),
+            "rough": float((outs[1][:1] - g[tag + "_rough_cur"]).abs().max()),
+            "context": float((outs[4] - g[tag + "_context"]).abs().max())}
+    print(tag, errs, "max |output| %.3g" % float(g[tag + "_output"].abs().max()))
+    assert errs["output"] <= TOL and errs["rough"] <= TOL, (tag, errs)
+    assert errs["context"] <= TOL * max(1.0, float(g[tag + "_context"].abs().max())), (tag, errs)
+    for o, mx in zip(outs, g[tag + "_absmax"].tolist()):
+        assert abs(float(o.abs().max()) - mx) <= TOL * max(1.0, mx)
+
+
 @pytest.mark.parametrize("ws", [S.WEIGHT_SEED, 777])
 def test_e2e_cfg1_three_input_seeds_two_weight_seeds(golden, ws):
     """The split-product eval path against reference-generated goldens of cfg1 for 3 input seeds x 2 weight seeds

@@ -209,3 +209,22 @@ def test_e2e_cfg1_other_seeds(golden, ws, xs):
     _close(outs[4], g[tag + "_context"], 5e-5)
     for o, mx in zip(outs, g[tag + "_absmax"].tolist()):
         assert abs(float(o.abs().max()) - mx) <= 1e-4 * max(1.0, mx)
+
+
+@pytest.mark.parametrize("ws,xs", [(777, 31), (4242, 32)])
+def test_e2e_cfg2_other_weight_seeds(golden, ws, xs):
+    """The headline configuration under two more weight draws (tests/golden/make_golden.py::gen_e2e_cfg2_seeds)."""
+    g = golden("e2e_cfg2_seeds")
+    cfg = cfg2()
+    m = OTPose(cfg)
+    S.fill_synthetic_(m, ws, S.gains_for(cfg))
+    sd = {k: v.detach() for k, v in m.state_dict().items()}
+    x, margin = S.synthetic_clip(1, cfg.MODEL.IMAGE_SIZE, seed=xs)
+    with torch.no_grad():
+        outs = O.otpose_forward(sd, cfg, x, margin)
+    tag = f"cfg2_w{ws}_x{xs}"
+    _close(outs[0], g[tag + "_output"], 5e-5)
+    _close(outs[1][:1], g[tag + "_rough_cur"], 5e-5)
+    _close(outs[4], g[tag + "_context"], 5e-5)
+    for o, mx in zip(outs, g[tag + "_absmax"].tolist()):
+        assert abs(float(o.abs().max()) - mx) <= 1e-4 * max(1.0, mx)
