@@ -32,6 +32,75 @@ BN_EPS = 1e-5
 
 
 # ------------------------------------------------------------------------------------------------
+# bf16 storage points: a yardstick for the bf16 TRAINING path of the product (BASELINE configs[2])
+# ------------------------------------------------------------------------------------------------
+# The reference has no bf16 mode, so a bf16 step cannot be compared with it directly: against an fp32 / fp64
+# graph the bf16 activations (2^-9 per stored value) flip ~1 % of the ReLU gates and move the whole gradient by 0.1 relative L2
+# - a bound that would not notice a wrong kernel.  Inside ``with bf16_points():`` this restatement rounds to bfloat16 exactly
+# where otpose_amd/train.py::TrainGraphBF16 stores bfloat16 - the HRNet input, every HRNet conv result (BatchNorm statistics
+# are taken from the rounded values, as csrc/nhwc.hip does), every BatchNorm (+ residual) (+ ReLU) result, every fuse-row
+# accumulation, the MLP interior of the temporal encoders, the input of the offset / mask convs, the weights of those
+# layers (fp32 masters, straight-through) - and rounds the GRADIENTS at the same tensors in the backward pass (the product's
+# input-gradient convs and BatchNorm backward kernels store bf16).  Accumulation stays in the oracle's precision, as the
+# product accumulates in fp32; everything outside those layers is untouched.  What is left between the two is summation
+# order (1e-7) and the bf16 roundings it flips.
+_BF16_POINTS = False
+
+
+class bf16_points:
+    def __enter__(self):
+        global _BF16_POINTS
+        self.prev, _BF16_POINTS = _BF16_POINTS, True
+        return self
+
+    def __exit__(self, *exc):
+        global _BF16_POINTS
+        _BF16_POINTS = self.prev
+        return False
+
+
+def _bf(x):
+    return x.to(torch.bfloat16).to(x.dtype)
+
+
+class _RoundBoth(torch.autograd.Function):
+    """value and gradient both stored as bfloat16"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return _bf(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _bf(g)
+
+
+class _RoundGrad(torch.autograd.Function):
+    """fp32 value whose gradient is converted to bfloat16 before the layer's backward kernels run"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _bf(g)
+
+
+def _rb(x):
+    return _RoundBoth.apply(x) if _BF16_POINTS else x
+
+
+def _rg(x):
+    return _RoundGrad.apply(x) if _BF16_POINTS else x
+
+
+def _rbw(w):
+    """bf16 copy of an fp32 master weight; the weight gradient (fp32 in the product) passes straight through"""
+    return w + (_bf(w) - w).detach() if _BF16_POINTS else w
+
+
+# ------------------------------------------------------------------------------------------------
 # building blocks
 # ------------------------------------------------------------------------------------------------
 def _bn(sd: SD, p: str, x, training=False):
@@ -46,13 +115,28 @@ def _conv(sd: SD, p: str, x, stride=1, pad=0, dil=1):
     return F.conv2d(x, sd[p + ".weight"], sd.get(p + ".bias"), stride, pad, dil)
 
 
-def _conv_bn(sd, conv, bn, x, stride=1, pad=0, relu=False, training=False):
+def _conv_bn(sd, conv, bn, x, stride=1, pad=0, relu=False, training=False, res=None):
+    if _BF16_POINTS:
+        # csrc/nhwc.hip: bf16 operands, fp32 accumulation, the result stored as bf16 (statistics from the stored values), then
+        # one pass y = act(c * scale + shift (+ res)) stored as bf16; ``_rb(x)`` rounds this consumer's input gradient
+        c = _rb(F.conv2d(_rb(x), _rbw(sd[conv + ".weight"]), None, stride, pad))
+        y = _bn(sd, bn, c, training)
+        if res is not None:
+            y = y + res
+        return _rb(F.relu(y) if relu else y)
+    assert res is None
     y = _bn(sd, bn, _conv(sd, conv, x, stride, pad), training)
     return F.relu(y) if relu else y
 
 
 def basic_block(sd: SD, p: str, x, training=False):
     """model/HRNet.py:514-530"""
+    if _BF16_POINTS:
+        y = _conv_bn(sd, p + ".conv1", p + ".bn1", x, 1, 1, True, training)
+        res = x
+        if (p + ".downsample.0.weight") in sd:
+            res = _conv_bn(sd, p + ".downsample.0", p + ".downsample.1", x, 1, 0, False, training)
+        return _conv_bn(sd, p + ".conv2", p + ".bn2", y, 1, 1, True, training, res=res)
     y = _conv_bn(sd, p + ".conv1", p + ".bn1", x, 1, 1, True, training)
     y = _conv_bn(sd, p + ".conv2", p + ".bn2", y, 1, 1, False, training)
     res = x
@@ -65,6 +149,11 @@ def bottleneck(sd: SD, p: str, x, training=False):
     """model/HRNet.py:551-571"""
     y = _conv_bn(sd, p + ".conv1", p + ".bn1", x, 1, 0, True, training)
     y = _conv_bn(sd, p + ".conv2", p + ".bn2", y, 1, 1, True, training)
+    if _BF16_POINTS:
+        res = x
+        if (p + ".downsample.0.weight") in sd:
+            res = _conv_bn(sd, p + ".downsample.0", p + ".downsample.1", x, 1, 0, False, training)
+        return _conv_bn(sd, p + ".conv3", p + ".bn3", y, 1, 0, True, training, res=res)
     y = _conv_bn(sd, p + ".conv3", p + ".bn3", y, 1, 0, False, training)
     res = x
     if (p + ".downsample.0.weight") in sd:
@@ -84,6 +173,27 @@ def hr_module(sd: SD, p: str, xs: List[torch.Tensor], n_out: int, training=False
     if n == 1:
         return xs
     outs = []
+    if _BF16_POINTS:
+        # the product's order and storage (otpose_amd/train.py::hr_module): the identity term seeds the sum, every other
+        # term rides on a fused add whose result is stored as bf16, the last one applies the ReLU
+        for i in range(n_out):
+            y = xs[i]
+            terms = [j for j in range(n) if j != i]
+            for idx, j in enumerate(terms):
+                last = idx == len(terms) - 1
+                q = f"{p}.fuse_layers.{i}.{j}"
+                if j > i:
+                    low = _conv_bn(sd, q + ".0", q + ".1", xs[j], 1, 0, False, training)
+                    y = y + F.interpolate(low, scale_factor=2 ** (j - i), mode="nearest")
+                    y = _rb(F.relu(y) if last else y)
+                else:
+                    t = xs[j]
+                    for k in range(i - j - 1):
+                        t = _conv_bn(sd, f"{q}.{k}.0", f"{q}.{k}.1", t, 2, 1, True, training)
+                    k = i - j - 1
+                    y = _conv_bn(sd, f"{q}.{k}.0", f"{q}.{k}.1", t, 2, 1, last, training, res=y)
+            outs.append(y)
+        return outs
     for i in range(n_out):
         y = None
         for j in range(n):
@@ -104,6 +214,7 @@ def hr_module(sd: SD, p: str, xs: List[torch.Tensor], n_out: int, training=False
 
 def hrnet_forward(sd: SD, p: str, x, stage_cfgs: Sequence[dict], training=False):
     """model/HRNet.py:116-152.  ``stage_cfgs`` = [STAGE2, STAGE3, STAGE4] dicts."""
+    x = _rb(x)                                          # bf16 mode: the frames enter as NHWC bf16
     x = _conv_bn(sd, p + ".conv1", p + ".bn1", x, 2, 1, True, training)
     x = _conv_bn(sd, p + ".conv2", p + ".bn2", x, 2, 1, True, training)
     for b in range(4):
@@ -130,6 +241,8 @@ def hrnet_forward(sd: SD, p: str, x, stage_cfgs: Sequence[dict], training=False)
         for m in range(nm):
             n_out = 1 if (s == 4 and m == nm - 1) else nb     # HRNet.py:105-106,172-175
             ys = hr_module(sd, f"{p}.stage{s}.{m}", ys, n_out, training)
+    if _BF16_POINTS:                                    # bf16 operands, fp32 NCHW heat-maps out; their gradient enters as bf16
+        return _rg(F.conv2d(_rb(ys[0]), _rbw(sd[p + ".final_layer.weight"]), sd.get(p + ".final_layer.bias")))
     return _conv(sd, p + ".final_layer", ys[0])
 
 
@@ -170,6 +283,14 @@ def transformer_block(sd: SD, p: str, x, n_head: int, stride: int):
     a = masked_mhca(sd, p + ".attn", channel_layernorm(sd, p + ".ln1", x), n_head, stride)
     skip = x if stride == 1 else F.max_pool1d(x, stride + 1, stride, (stride + 1) // 2)
     y = skip + sd[p + ".drop_path_attn.scale"] * a
+    if _BF16_POINTS and y.shape[1] % 8 == 0 and y.shape[2] % 32 == 0:
+        # otpose_amd/train.py::TrainGraphBF16.mlp: the MLP interior of the temporal encoders on bf16 (the C = 17 flow encoder
+        # and odd lengths stay fp32): LayerNorm output, hidden activation and GELU result stored as bf16, fp32 result
+        yn = _rb(channel_layernorm(sd, p + ".ln2", y))
+        h = _rb(F.conv1d(yn, _rbw(sd[p + ".mlp.0.weight"]), sd[p + ".mlp.0.bias"]))
+        h = _rb(F.gelu(h))
+        h = _rg(F.conv1d(_rb(h), _rbw(sd[p + ".mlp.3.weight"]), sd[p + ".mlp.3.bias"]))
+        return y + sd[p + ".drop_path_mlp.scale"] * h
     h = F.conv1d(channel_layernorm(sd, p + ".ln2", y), sd[p + ".mlp.0.weight"], sd[p + ".mlp.0.bias"])
     h = F.conv1d(F.gelu(h), sd[p + ".mlp.3.weight"], sd[p + ".mlp.3.bias"])
     return y + sd[p + ".drop_path_mlp.scale"] * h
@@ -414,9 +535,14 @@ def otpose_forward(sd: SD, cfg, x, margin, training_bn=False, return_intermediat
     trans = rsb_chain(sd, "offset_mask_combine_conv", torch.cat([branches, def_h], 1), training_bn)  # :378
     out = None
     inter_d = []
+    trans_b = _rb(trans)                                                      # bf16 mode: one bf16 copy feeds the ten convs
     for i, d in enumerate(dils):                                              # :381-392
-        off = F.conv2d(trans, sd[f"offsets_list.{i}.0.weight"], None, 1, d, d)
-        msk = F.conv2d(trans, sd[f"masks_list.{i}.0.weight"], None, 1, d, d)
+        if _BF16_POINTS:
+            off = _rg(F.conv2d(_rb(trans_b), _rbw(sd[f"offsets_list.{i}.0.weight"]), None, 1, d, d))
+            msk = _rg(F.conv2d(_rb(trans_b), _rbw(sd[f"masks_list.{i}.0.weight"]), None, 1, d, d))
+        else:
+            off = F.conv2d(trans, sd[f"offsets_list.{i}.0.weight"], None, 1, d, d)
+            msk = F.conv2d(trans, sd[f"masks_list.{i}.0.weight"], None, 1, d, d)
         p = f"modulated_deform_conv_list.{i}.deform_conv"
         wrp = mdcn_forward(def_h, off, msk, sd[p + ".weight"], sd[p + ".bias"], 1, d, d, 1, J)
         out = (1.0 / len(dils)) * wrp if out is None else out + (1.0 / len(dils)) * wrp

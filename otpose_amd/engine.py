@@ -908,6 +908,14 @@ class InferenceEngine:
             self.inp.copy_(x)
         if margin.data_ptr() != self.margin.data_ptr():
             self.margin.copy_(margin.to(torch.float32))
+        if self.use_graph:
+            from . import parallel
+            if not parallel.graph_replay_safe():
+                # an RCCL communicator of this process was destroyed: replaying a hipGraph after that segfaults inside the
+                # runtime (torch 2.10 / ROCm 7.2) - eager launches from here on.  A graph already captured is kept alive,
+                # never replayed (tearing it down before eager launches on its streams is the other known crash)
+                self.use_graph = False
+                self._parked_graph, self.graph = self.graph, None
         if self.use_graph and self.graph is None:
             self._launch_all()                      # warm-up (sets kernel attributes) before capture
             torch.cuda.synchronize(self.dev)

@@ -54,8 +54,41 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, torch.device
     return rank, world, device
 
 
+_GROUP_SEEN = False          # this process has used an initialised process group (it may have been destroyed since)
+
+
+def _group_alive() -> bool:
+    global _GROUP_SEEN
+    if dist.is_available() and dist.is_initialized():
+        _GROUP_SEEN = True
+        return True
+    return False
+
+
+def graph_replay_safe() -> bool:
+    """False once a process group this process worked with has been DESTROYED.  On torch 2.10 / ROCm 7.2 a hipGraph replay
+    after an RCCL communicator was torn down segfaults inside the runtime (seen in the GPU suite: an inference engine's
+    replay after a test that had destroyed its one-rank group), so :class:`otpose_amd.engine.InferenceEngine` asks here
+    before every replay and launches its kernel list eagerly from then on - slower on the host, same kernels, same bits.
+    The reference loop never gets there (train.py:74-99 validates after every epoch INSIDE the process, i.e. with the group
+    alive: replays stay on); a caller that does tear the group down mid-process (tests, notebooks) stays alive.
+    Use :func:`shutdown` to end a job: it leaves the group up until the last GPU work of the process is done."""
+    return _group_alive() or not _GROUP_SEEN
+
+
+def shutdown() -> None:
+    """End of a data-parallel job: wait for the device, then destroy the default process group (if any).  Call it LAST -
+    after the final validation pass - because graph replays are switched off for the rest of the process afterwards
+    (:func:`graph_replay_safe`)."""
+    if _group_alive():
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def world_size() -> int:
-    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    return dist.get_world_size() if _group_alive() else 1
 
 
 def collectives_on() -> bool:
@@ -63,13 +96,13 @@ def collectives_on() -> bool:
     group of ONE rank with ``OTPOSE_FORCE_COLLECTIVES=1`` - the latter sends every tensor through RCCL on a single GPU
     (sum over one rank = identity), so the device-side ordering of the exchange (side-stream gradients -> collective ->
     optimizer) runs on a 1-GPU box exactly as it does on eight."""
-    if not (dist.is_available() and dist.is_initialized()):
+    if not _group_alive():
         return False
     return dist.get_world_size() > 1 or os.environ.get("OTPOSE_FORCE_COLLECTIVES") == "1"
 
 
 def rank() -> int:
-    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    return dist.get_rank() if _group_alive() else 0
 
 
 def shard_range(n_clips: int, rank_: int, world: int) -> Tuple[int, int]:

@@ -16,6 +16,70 @@ from tests.test_gpu_train_slots import (CLIP, GRAD_TOL, LR, WD, _assert_weights_
 pytestmark = pytest.mark.gpu
 
 
+def test_train_then_validate_in_one_process_with_a_live_and_a_destroyed_group():
+    """The reference loop trains an epoch and validates in the SAME process (train.py:74-99).  Here: eval forward (hipGraph
+    captured), one data-parallel training step through a one-rank RCCL group (flags MAX, flat all-reduce, fused AdamW), eval
+    forward again WITH THE GROUP ALIVE (new weights -> the engine re-captures and replays next to a live communicator), then
+    the group is destroyed and the eval forward runs once more: graph replays are known to segfault after a communicator
+    teardown (module docstring), so the engine must switch itself to eager launches (`parallel.graph_replay_safe`) - same
+    kernels, so the same bits as the replay."""
+    import socket
+    import torch.distributed as dist
+    from otpose_amd import OTPose, tiny_cfg
+    cfg = tiny_cfg(8, (64, 96))
+    model = OTPose(cfg)
+    S.fill_synthetic_(model)
+    model = model.cuda()
+    x, margin = S.synthetic_clip(2, cfg.MODEL.IMAGE_SIZE)
+    x, margin = x.cuda(), margin.cuda()
+    J, (w, h) = cfg.MODEL.NUM_JOINTS, cfg.MODEL.HEATMAP_SIZE
+    g, wt = _targets(2, J, h, w)
+    assert PAR.graph_replay_safe()
+    model.eval()
+    with torch.no_grad():
+        before = [o.clone() for o in model(x, margin=margin)]
+    assert model._engine.graph is not None
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ["OTPOSE_FORCE_COLLECTIVES"] = "1"
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        model.train()
+        model.train_dropout, model.train_dtype = False, "bf16"
+        opt = FusedAdamW([p for p in model.parameters() if p.requires_grad], lr=LR, weight_decay=WD, max_grad_norm=CLIP)
+        loss = PAR.train_step_dp(model, opt, x, margin, g, wt)
+        assert bool(torch.isfinite(loss))
+        model.eval()
+        with torch.no_grad():
+            live1 = [o.clone() for o in model(x, margin=margin)]      # capture next to the live communicator
+            live2 = [o.clone() for o in model(x, margin=margin)]      # replay
+        assert model._engine.graph is not None and PAR.graph_replay_safe()
+        for a, b in zip(live1, live2):
+            assert torch.equal(a, b)
+        assert float((live1[0] - before[0]).abs().max()) > 0.0         # the step moved the weights
+    finally:
+        os.environ.pop("OTPOSE_FORCE_COLLECTIVES", None)
+        PAR.shutdown()
+    assert not PAR.graph_replay_safe()
+    with torch.no_grad():
+        after = [o.clone() for o in model(x, margin=margin)]          # would have been a replay: must go eager
+    torch.cuda.synchronize()
+    assert model._engine.graph is None and not model._engine.use_graph
+    for a, b in zip(live1, after):
+        assert torch.equal(a, b)
+    m2 = OTPose(cfg)                                                   # an engine built after the teardown never captures
+    S.fill_synthetic_(m2)
+    m2 = m2.cuda().eval()
+    with torch.no_grad():
+        fresh = [o.clone() for o in m2(x, margin=margin)]
+    torch.cuda.synchronize()
+    assert m2._engine.graph is None
+    for a, b in zip(before, fresh):
+        assert torch.equal(a, b)
+
+
 def test_rccl_exchange_on_one_rank_matches_no_exchange():
     """RCCL path on ONE GPU: a process group of a single rank with OTPOSE_FORCE_COLLECTIVES=1 sends the joint flags, the
     flat gradient buffers (FusedAdamW) and GradBuckets' packed buckets (hook mode, launched from inside the backward with
