@@ -523,6 +523,21 @@ class TrainGraph:
         return out, rough, inter, prev_b, ctx, squeezed, total_b
 
 
+class _LayerTap(Function):
+    """Identity node that records the gradient flowing back through THIS use of a tensor (``taps['layers']`` mode of
+    :class:`TrainGraphBF16`: the per-layer, in-context check of tests/test_gpu_train_bf16_yardstick.py)."""
+
+    @staticmethod
+    def forward(ctx, x, rec, key):
+        ctx.rec, ctx.key = rec, key
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.rec[ctx.key] = g.detach().clone()
+        return g, None, None
+
+
 class TrainGraphBF16(TrainGraph):
     """The same walk with the HRNet backbone (86 % of the FLOPs, model/HRNet.py:116-152) on the bf16 path of
     :mod:`otpose_amd.bf16_ops`: NHWC bfloat16 activations, bf16 matrix-core convolutions with fp32 accumulation, fp32
@@ -549,11 +564,25 @@ class TrainGraphBF16(TrainGraph):
         if x.dtype != B16.BF16:
             return super().conv_bn(conv, bn, x, stride, pad, relu, res)
         self.count_batch(bn)
-        return B16.conv_bn(x, self.P[conv + ".weight"], self.P[bn + ".weight"], self.P[bn + ".bias"], res,
-                           self.Bf[bn + ".running_mean"], self.Bf[bn + ".running_var"], stride, pad, relu, 0.1, 1e-5)
+        layers = self.taps.get("layers") if self.taps is not None else None
+        if layers is not None:
+            # record this layer in context: its bf16 operands, its result, and (after backward) the gradient arriving at the
+            # result and the gradients it hands to its input / residual
+            rec = dict(conv=conv, bn=bn, stride=stride, pad=pad, relu=relu, x=x.detach(), res=None if res is None else res.detach())
+            x = _LayerTap.apply(x, rec, "gx")
+            if res is not None:
+                res = _LayerTap.apply(res, rec, "gres")
+        y = B16.conv_bn(x, self.P[conv + ".weight"], self.P[bn + ".weight"], self.P[bn + ".bias"], res,
+                        self.Bf[bn + ".running_mean"], self.Bf[bn + ".running_var"], stride, pad, relu, 0.1, 1e-5)
+        if layers is not None:
+            rec["y"] = y.detach()
+            y = _LayerTap.apply(y, rec, "gy")
+            layers.append(rec)
+        return y
 
     def basic_block(self, p, x):
-        if (x.dtype != B16.BF16 or self.has(p + ".downsample.0.weight") or os.environ.get("OTPOSE_BLOCK_FUSE", "1") == "0"):
+        if (x.dtype != B16.BF16 or self.has(p + ".downsample.0.weight") or os.environ.get("OTPOSE_BLOCK_FUSE", "1") == "0"
+                or (self.taps is not None and self.taps.get("layers") is not None)):     # layer taps: two conv + BN nodes
             return super().basic_block(p, x)
         self.count_batch(p + ".bn1")
         self.count_batch(p + ".bn2")
