@@ -185,6 +185,17 @@ size_t otp_conv3x3_s8_weight_bytes(int Cout, int Cin);
 int otp_conv3x3_s8_pack_weight(const void* weight, const void* scale, void* wpacked, int Cout, int Cin, void* stream);
 int otp_conv3x3_s8(const void* in_s8, const void* wpacked, const void* shift, const void* res_c4, void* out_f32,
                    int out_f32_layout, void* out_s8, const otp_conv_desc* desc, void* stream);
+/* The STRIDE 2 form (csrc/convs2.hip): the down-sampling chains of the fuse layers (model/HRNet.py:442-470), the transition
+ * layers (:192-231) and the stem's second conv (:66-72) from an S8 image, same packed weights (otp_conv3x3_s8_pack_weight).
+ * The window is staged with its columns de-interleaved by parity, so the fragment reads of 16 consecutive output pixels stay
+ * conflict-free.  Exactly one output form per call: `out_s8` = the S8 image of act(conv + shift) (a chain's intermediate:
+ * conv + BN + ReLU, no residual), or `out_nchw` = a channel slice of an fp32 NCHW tensor (desc->out_ctot / out_coff) holding
+ * act(conv + shift + res), `res_nchw` NULL or a channel slice (desc->res_ctot / res_coff) that may be the output itself (a
+ * fuse row accumulates in place).  desc: kh = kw = 3, stride 2, pad 1, dil 1, H and W even, Cin % 16 == 0, Cout % 16 == 0,
+ * Ho*Wo % 4 == 0, act NONE / RELU. */
+int otp_conv3x3_s2_s8_supported(const otp_conv_desc* desc, int nchw_out);
+int otp_conv3x3_s2_s8(const void* in_s8, const void* wpacked, const void* shift, const void* res_nchw, void* out_nchw,
+                      void* out_s8, const otp_conv_desc* desc, void* stream);
 
 /* ---- training-step building blocks for the convolutional layers (script/Common.py:91,136-144 run the reference under
  * model.train(): BatchNorm2d uses batch statistics, every conv needs both gradients) -----------------------------

@@ -84,6 +84,38 @@ class InferenceEngine:
         with torch.no_grad():
             self._build()
 
+    @classmethod
+    def bare(cls, device, multi_stream=False):
+        """An engine with NO model behind it, for tests of one sub-module: the caller emits that module's launches with the
+        engine's own emitters (``rsb_chain``, ``tblock``, ...) on buffers from :meth:`new`, sets ``inp`` to any of them (its
+        stream is the launch stream) and runs the list with :meth:`_launch_all` - exactly the launches a full engine would
+        issue for that module, without building an OTPose around it.  Never captures a graph."""
+        self = cls.__new__(cls)
+        device = torch.device(device)
+        if device.type != "cuda" or not torch.cuda.is_available():
+            raise RuntimeError("InferenceEngine.bare needs the GPU (there is no CPU or PyTorch-op fallback)")
+        env = os.environ.get
+        self.lib, self.dev, self.model, self.B = hip.lib(), device, None, 0
+        self.ops, self._aux, self._keep, self._bufs, self._stream = [], {}, [], [], None
+        self.use_graph, self.graph = False, None
+        self.use_winograd = env("OTPOSE_WINOGRAD", "1") != "0"
+        self.use_x3 = env("OTPOSE_CONV_MATH", "x3") != "f32"
+        self.use_dcn_fused = self.use_x3 and env("OTPOSE_DCN_FUSED", "1") != "0"
+        self.use_s8 = self.use_x3 and env("OTPOSE_S8", "1") != "0"
+        self.use_flow_fused = env("OTPOSE_FLOW_FUSED", "1") != "0"
+        self.use_small_conv = env("OTPOSE_SMALL_CONV", "1") != "0"
+        self.use_fused_mlp = env("OTPOSE_FUSED_MLP", "1") != "0"
+        self.fuse_shortcut = env("OTPOSE_FUSE_SHORTCUT", "1") != "0"
+        self.fuse_upsample = env("OTPOSE_FUSE_UPSAMPLE", "1") != "0"
+        self.use_dense_cc = env("OTPOSE_DENSE_CC", "1") != "0"
+        self.use_qkv_front = env("OTPOSE_QKV_FRONT", "1") != "0"
+        self.use_pointx = self.use_x3 and env("OTPOSE_POINTX", "1") != "0"
+        self.multi_stream = bool(multi_stream)
+        self._sid = 0
+        self._side = hip.side_streams(device, 3, 0) if self.multi_stream else []
+        self.inp = None
+        return self
+
     # ---------------------------------------------------------------------------------------------
     def matches(self, x) -> bool:
         return (x.shape[0] == self.B and x.device == self.dev and tuple(x.shape[2:]) == (self.H_img, self.W_img)

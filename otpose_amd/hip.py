@@ -73,6 +73,8 @@ SIGNATURES = {
     "otp_conv3x3_s8_weight_bytes": (c_size_t, [c_int, c_int]),
     "otp_conv3x3_s8_pack_weight": (c_int, [c_void_p] * 3 + [c_int, c_int, c_void_p]),
     "otp_conv3x3_s8": (c_int, [c_void_p] * 5 + [c_int, c_void_p, ctypes.POINTER(ConvDesc), c_void_p]),
+    "otp_conv3x3_s2_s8_supported": (c_int, [ctypes.POINTER(ConvDesc), c_int]),
+    "otp_conv3x3_s2_s8": (c_int, [c_void_p] * 6 + [ctypes.POINTER(ConvDesc), c_void_p]),
     "otp_conv2d_set_tile": (c_int, [c_int] * 4),
     "otp_conv2d_last_plan": (c_int, [ctypes.POINTER(c_int)]),
     "otp_conv2d_plan": (c_int, [ctypes.POINTER(ConvDesc), ctypes.POINTER(c_int)]),

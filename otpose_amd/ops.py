@@ -462,6 +462,49 @@ def s8_conv_desc(n, cin, cout, h, w, act=ACT_NONE, out: View = None):
     return d
 
 
+def s8_s2_conv_desc(n, cin, cout, h, w, act=ACT_NONE, out: View = None, res: View = None):
+    """Descriptor of the stride-2 S8 convolution (csrc/convs2.hip): (n, cin, h, w) -> (n, cout, h / 2, w / 2)."""
+    d = hip.ConvDesc()
+    d.N, d.Cin, d.H, d.W, d.Cout = n, cin, h, w, cout
+    d.kh = d.kw = 3
+    d.stride, d.pad, d.dil = 2, 1, 1
+    d.in_ctot, d.in_coff, d.in2_ctot, d.in2_coff = cin, 0, 0, 0
+    d.out_ctot, d.out_coff = (out.ctot, out.coff) if out is not None else (cout, 0)
+    d.res_ctot, d.res_coff = (res.ctot, res.coff) if res is not None else (0, 0)
+    d.res_up = 1
+    d.act, d.Ho, d.Wo, d.frame_split = act, h // 2, w // 2, 0
+    return d
+
+
+def s8_s2_conv_supported(desc, nchw_out=True):
+    return bool(hip.lib().otp_conv3x3_s2_s8_supported(desc, int(nchw_out)))
+
+
+def conv3x3_s2_s8(x_s8, shape, weight, scale=None, shift=None, act=ACT_NONE, res=None, out="nchw"):
+    """act(conv2d(x, weight, 3x3, stride 2, pad 1) * scale + shift (+ res)) from the S8 image ``x_s8`` of logical ``shape``
+    (n, cin, h, w).  ``out = "nchw"``: fp32 (n, cout, h / 2, w / 2) tensor (``res`` an fp32 tensor of that shape or None);
+    ``out = "s8"``: the S8 image of the result (no residual)."""
+    _require_gpu(x_s8, weight)
+    n, cin, h, w = shape
+    cout = weight.shape[0]
+    wp = pack_s8_weight(weight, scale)
+    sh = shift.detach().contiguous().float() if shift is not None else None
+    L = hip.lib()
+    if out == "s8":
+        assert res is None
+        d = s8_s2_conv_desc(n, cin, cout, h, w, act)
+        o8 = s8_empty(n, cout, h // 2, w // 2, x_s8.device)
+        hip.check(L.otp_conv3x3_s2_s8(hip.ptr(x_s8), hip.ptr(wp), hip.ptr(sh), None, None, hip.ptr(o8), d, hip.stream_of(x_s8)),
+                  "otp_conv3x3_s2_s8")
+        return o8
+    o = torch.empty(n, cout, h // 2, w // 2, dtype=torch.float32, device=x_s8.device)
+    rv = View(res.contiguous()) if res is not None else None
+    d = s8_s2_conv_desc(n, cin, cout, h, w, act, View(o), rv)
+    hip.check(L.otp_conv3x3_s2_s8(hip.ptr(x_s8), hip.ptr(wp), hip.ptr(sh), hip.ptr(rv.t) if rv is not None else None, hip.ptr(o),
+                                  None, d, hip.stream_of(x_s8)), "otp_conv3x3_s2_s8")
+    return o
+
+
 def pack_s8_weight(weight, scale=None):
     """(Cout, Cin, 3, 3) fp32 (times scale[cout]) -> bf16 hi / lo MFMA fragments for :func:`conv3x3_s8_launch`."""
     _require_gpu(weight)

@@ -199,3 +199,70 @@ def test_s8_upsample_add_equals_upsample_add_multi_then_pack(factors):
                                         hip.ptr(c4), n, c, hh, wh, 1, c, 0, c, 0, hip.stream_of(res)), "s8 up")
         assert torch.equal(s8, want_s8) and torch.equal(c4, want_c4)
         assert torch.equal(out, want) if with_nchw else bool((out == 7.0).all())
+
+
+# ---- stride 2 (csrc/convs2.hip): the down-sampling chains of the fuse layers, transitions, the stem's conv2 ---------------------
+# (N, Cin, Cout, H, W, residual, relu)
+S2_CASES = [
+    (5, 48, 96, 96, 72, True, False),        # HRNet-W48 fuse 0 -> 1: two-image... 128-pixel tiles, 11 window rows of 73 records
+    (3, 48, 48, 96, 72, False, True),        # a chain's intermediate (keeps the width, ReLU)
+    (5, 96, 192, 48, 36, True, True),        # fuse 1 -> 2: tiles straddle images
+    (7, 192, 384, 24, 18, True, True),       # fuse 2 -> 3: 12 x 9 outputs, more than one image per tile
+    (3, 48, 192, 48, 36, True, False),       # last conv of a two-step chain
+    (2, 64, 64, 192, 144, False, True),      # the stem's conv2: 64-pixel tiles (145-record window rows), NTW = 2
+    (3, 256, 96, 96, 72, False, True),       # transition1's new branch
+    (2, 32, 80, 20, 12, True, True),         # Cout = 5 tiles of 16: a lone tile, tail tile
+    (1, 16, 16, 8, 8, False, False),         # one partial tile, one chunk
+    (80, 192, 384, 24, 18, True, True),      # full batch: XCD-interleaved tile ranges with ragged ends
+    (16, 48, 96, 96, 72, True, True),
+    (3, 32, 64, 64, 48, True, True),         # HRNet-W32 (cfg1)
+]
+
+
+@pytest.mark.parametrize("case", S2_CASES, ids=lambda c: "x".join(str(v) for v in c[:5]))
+def test_conv3x3_stride2_s8_matches_float64(case):
+    n, ci, co, h, w, with_res, relu = case
+    g = torch.Generator(device="cpu").manual_seed(sum(case[:5]) + 1)
+    x = torch.randn(n, ci, h, w, generator=g).cuda()
+    wt = (torch.randn(co, ci, 3, 3, generator=g) * (2.0 / (ci * 9)) ** 0.5).cuda()
+    sc = (torch.rand(co, generator=g) + 0.5).cuda()
+    sh = torch.randn(co, generator=g).cuda()
+    res = torch.randn(n, co, h // 2, w // 2, generator=g).cuda() if with_res else None
+    xs = ops.s8_pack(x)
+    xin = ops.s8_unpack(xs, n, ci, h, w).double()                       # the kernel's input IS hi + lo
+    ref = F.conv2d(xin, wt.double(), None, 2, 1, 1) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)
+    ref_nores = torch.relu(ref) if relu else ref
+    if with_res:
+        ref = ref + res.double()
+    if relu:
+        ref = torch.relu(ref)
+    act = ops.ACT_RELU if relu else ops.ACT_NONE
+    assert ops.s8_s2_conv_supported(ops.s8_s2_conv_desc(n, ci, co, h, w, act))
+    y = ops.conv3x3_s2_s8(xs, (n, ci, h, w), wt, sc, sh, act, res)
+    scale = float(ref.abs().max())
+    err = float((y.double() - ref).abs().max()) / scale
+    assert err <= 2e-5, err
+    # S8 output form (no residual): the split of the fp32 result of the same call, bit for bit
+    y0 = ops.conv3x3_s2_s8(xs, (n, ci, h, w), wt, sc, sh, act, None)
+    assert float((y0.double() - ref_nores).abs().max()) / float(ref_nores.abs().max()) <= 2e-5
+    y8 = ops.conv3x3_s2_s8(xs, (n, ci, h, w), wt, sc, sh, act, None, out="s8")
+    assert torch.equal(y8, ops.s8_pack(y0))
+
+
+def test_conv3x3_stride2_s8_accumulates_in_place_into_a_channel_slice():
+    """A fuse row adds its terms in place (model/HRNet.py:488-494): residual = output = a channel slice of a wider tensor."""
+    g = torch.Generator(device="cpu").manual_seed(19)
+    n, ci, co, h, w = 3, 32, 16, 24, 16
+    x = torch.randn(n, ci, h, w, generator=g).cuda()
+    wt = (torch.randn(co, ci, 3, 3, generator=g) * 0.1).cuda()
+    big = torch.randn(n, 40, h // 2, w // 2, generator=g).cuda()
+    before = big.clone()
+    v = ops.View(big, 8, co)
+    d = ops.s8_s2_conv_desc(n, ci, co, h, w, ops.ACT_RELU, v, v)
+    from otpose_amd import hip
+    xs, wp = ops.s8_pack(x), ops.pack_s8_weight(wt)                    # (kept alive across the launch)
+    hip.check(hip.lib().otp_conv3x3_s2_s8(hip.ptr(xs), hip.ptr(wp), None, hip.ptr(big), hip.ptr(big), None, d,
+                                          hip.stream_of(big)), "otp_conv3x3_s2_s8")
+    want = ops.conv3x3_s2_s8(xs, (n, ci, h, w), wt, None, None, ops.ACT_RELU, before[:, 8:24].contiguous())
+    assert torch.equal(big[:, 8:24], want)
+    assert torch.equal(big[:, :8], before[:, :8]) and torch.equal(big[:, 24:], before[:, 24:])
