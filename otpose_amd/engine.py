@@ -358,6 +358,77 @@ class InferenceEngine:
         self._emit(run)
         return True
 
+    def s8_image(self, v: View, want_c4=False):
+        """The S8 image (and, on request, the C4 image) of a full NCHW tensor: what its producer already wrote (``_aux``), or one
+        ``otp_s8_pack`` pass emitted here, on the current stream, and cached for later consumers.  None when the tensor is not
+        eligible (channel slice, channels % 16, pixels % 4)."""
+        n, c, h, w = v.t.shape
+        if not self.use_s8 or v.coff != 0 or v.C != c or c % 16 or (h * w) % 4:
+            return None
+        aux = self._aux.get(id(v.t))
+        if aux is not None and "s8" in aux and (not want_c4 or aux.get("c4") is not None):
+            return aux
+        self._needs_nchw(v)
+        s8 = aux["s8"] if aux is not None and "s8" in aux else self.new(n * c * h * w)
+        c4 = self.new(n * c * h * w) if want_c4 else None
+        self.call(self.lib.otp_s8_pack, "otp_s8_pack", hip.ptr(v.t), hip.ptr(s8), hip.ptr(c4), n, c, h, w, v.ctot, v.coff)
+        if aux is None:
+            aux = self._aux[id(v.t)] = {"nchw_needed": True}
+        aux["s8"] = s8
+        if c4 is not None:
+            aux["c4"] = c4
+        return aux
+
+    def s2_chain_s8(self, layers, x: View, act_last, res: View = None, out: View = None):
+        """A chain of 3x3 / stride 2 conv + BN (+ ReLU) layers (a fuse layer's down-sampling path, model/HRNet.py:442-470, or a
+        transition layer's new branch, :213-229) on S8 records (csrc/convs2.hip): every intermediate exists only as its S8 image,
+        the last layer writes act(conv + shift (+ res)) into the fp32 NCHW tensor ``out``.  ``layers`` = [(conv, bn, relu)].
+        Returns the output view, or None (nothing emitted) when a layer is not of that shape."""
+        if not (self.use_s8 and os.environ.get("OTPOSE_S8_STRIDE2", "1") != "0"):
+            return None
+        n, c, h, w = x.t.shape
+        if x.coff != 0 or x.C != c:
+            return None
+        hh, ww, cin = h, w, c
+        descs = []
+        for li, (cv, bn, relu) in enumerate(layers):
+            last = li == len(layers) - 1
+            if (cv.kernel_size != (3, 3) or cv.stride != (2, 2) or cv.padding != (1, 1) or cv.dilation != (1, 1) or cv.bias is not None
+                    or cv.groups != 1 or cv.in_channels != cin or hh % 2 or ww % 2):
+                return None
+            co = cv.out_channels
+            if last:
+                if out is None:
+                    out = View(self.new(n, co, hh // 2, ww // 2))
+                d = ops.s8_s2_conv_desc(n, cin, co, hh, ww, act_last, out, res)
+            else:
+                d = ops.s8_s2_conv_desc(n, cin, co, hh, ww, ACT_RELU if relu else ACT_NONE)
+            if not ops.s8_s2_conv_supported(d, last):
+                return None
+            descs.append(d)
+            hh, ww, cin = hh // 2, ww // 2, co
+        aux = self.s8_image(x)
+        if aux is None:
+            return None
+        self._needs_nchw(res)
+        L = self.lib
+        cur = aux["s8"]
+        hh, ww, cin = h, w, c
+        for li, ((cv, bn, relu), d) in enumerate(zip(layers, descs)):
+            last = li == len(layers) - 1
+            sc, sh = self._bn_fold(bn)
+            wp = ops.pack_s8_weight(self.dev_param(cv.weight), sc)
+            self._keep += [wp, d]
+            if last:
+                self.call(L.otp_conv3x3_s2_s8, "otp_conv3x3_s2_s8", hip.ptr(cur), hip.ptr(wp), hip.ptr(sh),
+                          hip.ptr(res.t) if res is not None else None, hip.ptr(out.t), None, d)
+            else:
+                nxt = self.new(n * cv.out_channels * (hh // 2) * (ww // 2))
+                self.call(L.otp_conv3x3_s2_s8, "otp_conv3x3_s2_s8", hip.ptr(cur), hip.ptr(wp), hip.ptr(sh), None, None, hip.ptr(nxt), d)
+                cur = nxt
+            hh, ww, cin = hh // 2, ww // 2, cv.out_channels
+        return out
+
     def _bn_fold(self, bn):
         g, b = self.dev_param(bn.weight), self.dev_param(bn.bias)
         mu, var = self.dev_param(bn.running_mean), self.dev_param(bn.running_var)
@@ -366,7 +437,7 @@ class InferenceEngine:
         self._keep += [sc, sh]
         return sc, sh
 
-    def branch_s8(self, blocks, x: View):
+    def branch_s8(self, blocks, x: View, want_s8=False):
         """A branch of a HighResolutionModule (HRNet.py:478-496: 4 BasicBlocks, :500-530) on split-record activations
         (csrc/convs.hip).  The branch input is converted once to its S8 image (the MFMA operand records: conv input) and its
         C4 image (fp32, the accumulator layout: residual); inside the branch conv1 goes S8 -> S8, conv2 S8 + C4 residual ->
@@ -385,12 +456,10 @@ class InferenceEngine:
             return None
         L = self.lib
         new_img = lambda: self.new(n * c * h * w)                          # noqa: E731  (S8 and C4 images are 4 bytes per element)
-        aux = self._aux.get(id(x.t))
-        if aux is not None:                                                # the producer (a fuse row) already wrote both images
-            xs8, xc4 = aux["s8"], aux["c4"]
-        else:
-            xs8, xc4 = new_img(), new_img()
-            self.call(L.otp_s8_pack, "otp_s8_pack", hip.ptr(x.t), hip.ptr(xs8), hip.ptr(xc4), n, c, h, w, x.ctot, x.coff)
+        aux = self.s8_image(x, want_c4=True)                               # written by the producer (a fuse row), or packed here
+        if aux is None:
+            return None
+        xs8, xc4 = aux["s8"], aux["c4"]
         out = None
         for b, blk in enumerate(blocks):
             last = b == len(blocks) - 1
@@ -408,8 +477,12 @@ class InferenceEngine:
                 out = View(self.new(n, c, h, w))
                 d2 = ops.s8_conv_desc(n, c, c, h, w, ACT_RELU, out)
                 self._keep.append(d2)
+                # a stride-2 consumer in the fuse layer (csrc/convs2.hip) reads the S8 image: written here, next to the NCHW tensor
+                o8 = new_img() if want_s8 else None
+                if o8 is not None:
+                    self._aux[id(out.t)] = {"s8": o8, "nchw_needed": True}
                 self.call(L.otp_conv3x3_s8, "otp_conv3x3_s8", hip.ptr(y8), hip.ptr(w2), hip.ptr(sh2), hip.ptr(xc4), hip.ptr(out.t),
-                          ops.S8_F32_NCHW, None, d2)
+                          ops.S8_F32_NCHW, hip.ptr(o8) if o8 is not None else None, d2)
             else:
                 oc4, o8 = new_img(), new_img()
                 d2 = ops.s8_conv_desc(n, c, c, h, w, ACT_RELU)
@@ -468,13 +541,20 @@ class InferenceEngine:
             self.join((1,))
         return self.conv_bn(y, blk.conv3, blk.bn3, ACT_RELU, res=res)
 
-    def hr_module(self, mod, xs: List[View]) -> List[View]:
+    def hr_module(self, mod, xs: List[View], fork_in=True, join_out=True) -> List[View]:
+        """One HighResolutionModule (model/HRNet.py:478-496).  ``fork_in`` / ``join_out`` = False chain consecutive modules of
+        a stage stream by stream: branch i of the next module only reads row i of this module's fuse layer, which ran on stream
+        i, so neither the join behind the rows nor the fork in front of the next branches is needed - a branch starts as soon
+        as ITS row is done instead of when the slowest row is."""
         n = mod.num_branches
         xs = list(xs)
-        self.fork(range(1, n))
+        if fork_in:
+            self.fork(range(1, n))
         for i in range(n):
             self.on_stream(i)                                     # branch i is independent of the others until the fuse
-            y = self.branch_s8(list(mod.branches[i]), xs[i]) if self.use_s8 else None
+            # branch i feeds the stride-2 chains of the fuse rows below it
+            down = i < len(mod.fuse_layers) - 1 and os.environ.get("OTPOSE_S8_STRIDE2", "1") != "0"
+            y = self.branch_s8(list(mod.branches[i]), xs[i], want_s8=down) if self.use_s8 else None
             if y is not None:
                 xs[i] = y
                 continue
@@ -485,6 +565,9 @@ class InferenceEngine:
         if n == 1:
             return xs
         outs = []
+        if self.use_s8 and os.environ.get("OTPOSE_S8_STRIDE2", "1") != "0":
+            for j in range(min(n, len(mod.fuse_layers) - 1)):     # S8 images the rows below read, made before the rows fork
+                self.s8_image(xs[j])
         self.fork(range(1, len(mod.fuse_layers)))
         for i in range(len(mod.fuse_layers)):
             self.on_stream(i)                                     # fuse row i reads every branch, writes only y_i
@@ -524,10 +607,14 @@ class InferenceEngine:
                     else:
                         y = self.conv_bn(xs[j], fl[0], fl[1], act, res=res, out=tgt, res_up=f)
                 else:
+                    tgt = y if y is not None else View(self.new(*xs[i].t.shape))
+                    chain = [(fl[k][0], fl[k][1], k < len(fl) - 1) for k in range(len(fl))]
+                    if self.s2_chain_s8(chain, xs[j], act, res=res, out=tgt) is not None:
+                        y = tgt
+                        continue
                     t = xs[j]
                     for k in range(len(fl) - 1):
                         t = self.conv_bn(t, fl[k][0], fl[k][1], ACT_RELU)
-                    tgt = y if y is not None else View(self.new(*xs[i].t.shape))
                     y = self.conv_bn(t, fl[-1][0], fl[-1][1], act, res=res, out=tgt)
             if ups:
                 res = xs[i] if y is None else y
@@ -546,7 +633,8 @@ class InferenceEngine:
                 y = tgt
             outs.append(y)
         self.on_stream(0)
-        self.join(range(1, len(mod.fuse_layers)))
+        if join_out:
+            self.join(range(1, len(mod.fuse_layers)))
         return outs
 
     def hrnet(self, net, x_in: View) -> View:
@@ -606,6 +694,10 @@ class InferenceEngine:
             trans = getattr(net, f"transition{s - 1}")
             xs = []
             live = [i for i, tr in enumerate(trans) if tr is not None]
+            if s >= 3 and self.use_s8 and os.environ.get("OTPOSE_S8_STRIDE2", "1") != "0":
+                # the lowest-resolution tensor feeds the new branch's stride-2 conv AND its own branch of the next module: one
+                # pack pass (S8 + C4) before the streams fork serves both
+                self.s8_image(ys[-1], want_c4=True)
             self.fork(range(1, len(live)))                         # the transition convs only share their inputs
             for i, tr in enumerate(trans):
                 if tr is None:
@@ -616,14 +708,24 @@ class InferenceEngine:
                     xs.append(self.conv_bn(ys[i], tr[0], tr[1], ACT_RELU))
                 else:                                              # new branch from the last tensor
                     z = ys[-1]
-                    for step in tr:
-                        z = self.conv_bn(z, step[0], step[1], ACT_RELU)
-                    xs.append(z)
+                    zs = self.s2_chain_s8([(step[0], step[1], True) for step in tr], z, ACT_RELU) if s >= 3 else None
+                    if zs is None:
+                        for step in tr:
+                            z = self.conv_bn(z, step[0], step[1], ACT_RELU)
+                        zs = z
+                    xs.append(zs)
             self.on_stream(0)
             self.join(range(1, len(live)))
             ys = xs
-            for mod in getattr(net, f"stage{s}"):
-                ys = self.hr_module(mod, ys)
+            mods = list(getattr(net, f"stage{s}"))
+            chain = os.environ.get("OTPOSE_CHAIN_MODULES", "1") != "0"
+            for mi, mod in enumerate(mods):
+                nxt = mods[mi + 1] if mi + 1 < len(mods) else None
+                # the next module's branch i continues on the stream of this module's row i (same count of rows and branches)
+                cont = chain and nxt is not None and len(mod.fuse_layers) == nxt.num_branches and mod.num_branches > 1
+                ys = self.hr_module(mod, ys, fork_in=not (mi > 0 and prev_cont), join_out=not cont) if mi > 0 else \
+                    self.hr_module(mod, ys, fork_in=True, join_out=not cont)
+                prev_cont = cont
         fl = net.final_layer
         rough = View(self.new(self.F * self.B, self.J, self.h, self.w))
         return self.conv(ys[0], fl.weight, rough, 1, fl.padding[0], 1, bias=fl.bias)

@@ -32,4 +32,24 @@ for cin, cout, h, w in ((48, 96, 96, 72), (48, 48, 96, 72), (48, 192, 48, 36), (
     t = a.elapsed_time(b) / 20 * 1e3
     flop = 2.0 * cin * cout * 9 * n * (h // 2) * (w // 2)
     byts = 4.0 * n * (cin * h * w + cout * (h // 2) * (w // 2))
-    print("%3d -> %3d s2 @%dx%d x%d: %.1f us, %.0f algorithmic TFLOP/s, %.2f TB/s" % (cin, cout, h, w, n, t, flop / t / 1e6, byts / t / 1e6))
+    line = "%3d -> %3d s2 @%dx%d x%d: convx %.1f us, %.0f algorithmic TFLOP/s, %.2f TB/s" % (cin, cout, h, w, n, t, flop / t / 1e6, byts / t / 1e6)
+    # the same layer on S8 records (csrc/convs2.hip): S8 -> NCHW (+ ReLU) and S8 -> S8
+    if ops.s8_s2_conv_supported(ops.s8_s2_conv_desc(n, cin, cout, h, w, ops.ACT_RELU)):
+        xs = ops.s8_pack(x)
+        wp = ops.pack_s8_weight(wt, sc)
+        o8 = ops.s8_empty(n, cout, h // 2, w // 2, "cuda")
+        d1 = ops.s8_s2_conv_desc(n, cin, cout, h, w, ops.ACT_RELU, ops.View(o))
+        d2 = ops.s8_s2_conv_desc(n, cin, cout, h, w, ops.ACT_RELU)
+        for name, g in (("S8->NCHW", lambda: hip.check(L.otp_conv3x3_s2_s8(hip.ptr(xs), hip.ptr(wp), hip.ptr(sh), None, hip.ptr(o), None, d1, hip.stream_of(x)), "s2")),   # noqa: E731
+                        ("S8->S8", lambda: hip.check(L.otp_conv3x3_s2_s8(hip.ptr(xs), hip.ptr(wp), hip.ptr(sh), None, None, hip.ptr(o8), d2, hip.stream_of(x)), "s2"))):   # noqa: E731
+            for _ in range(3):
+                g()
+            torch.cuda.synchronize()
+            a.record()
+            for _ in range(20):
+                g()
+            b.record()
+            torch.cuda.synchronize()
+            t2 = a.elapsed_time(b) / 20 * 1e3
+            line += " | %s %.1f us (%.0f TFLOP/s)" % (name, t2, flop / t2 / 1e6)
+    print(line, flush=True)
