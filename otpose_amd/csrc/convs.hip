@@ -83,35 +83,31 @@ __device__ __forceinline__ void ssplit8(const float (&v)[8], u32x4& hi, u32x4& l
 }
 
 // fp32 NCHW (channel-sliced view) -> S8 (+ the C4 image [N][C/4][H*W][4] of the same values, the residual layout of
-// otp_conv3x3_s8).  A thread owns 4 consecutive pixels of one channel group: 8 coalesced float4 loads, 4 + 4 record stores
-// (64 contiguous bytes per part) and 2 x 4 float4 stores.
+// otp_conv3x3_s8).  A thread owns ONE pixel of one 8-channel group: 8 dword loads (256-byte runs per channel row and wave)
+// and one 16-byte store per image and part - every store instruction of a wave writes 1 KB of consecutive records.  (Round 3's
+// form gave a thread 4 consecutive pixels: its stores were 16-byte pieces 64 bytes apart, and the pass ran at 2.4 TB/s;
+// "store-run length is worth a factor on this chip")
 __global__ __launch_bounds__(256) void s8_pack_kernel(const float* __restrict__ in, u32x4* __restrict__ out, float* __restrict__ c4,
                                                        int N, int C, int HW, int ctot, int coff) {
-    const int q4 = HW >> 2, G8 = C >> 3;
-    const size_t items = (size_t)N * G8 * q4;
+    const int G8 = C >> 3;
+    const size_t items = (size_t)N * G8 * HW;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < items; i += (size_t)gridDim.x * 256) {
-        const int q = (int)(i % q4);
-        const size_t r = i / q4;
+        const int p = (int)(i % HW);
+        const size_t r = i / HW;
         const int g = (int)(r % G8), n = (int)(r / G8);
-        const float* src = in + ((size_t)n * ctot + coff + 8 * g) * HW + 4 * q;
-        f32x4 v[8];
+        const float* src = in + ((size_t)n * ctot + coff + 8 * g) * HW + p;
+        float f[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = *reinterpret_cast<const f32x4*>(src + (size_t)e * HW);
-        u32x4* dst = out + ((size_t)(n * G8 + g) * 2) * HW + 4 * q;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float f[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] = v[e][k];
-            u32x4 hi, lo;
-            ssplit8(f, hi, lo);
-            dst[k] = hi;
-            dst[(size_t)HW + k] = lo;
-            if (c4) {
-                f32x4* d4 = reinterpret_cast<f32x4*>(c4) + ((size_t)n * (C >> 2) + 2 * g) * HW + 4 * q + k;
-                d4[0] = (f32x4){f[0], f[1], f[2], f[3]};
-                d4[HW] = (f32x4){f[4], f[5], f[6], f[7]};
-            }
+        for (int e = 0; e < 8; ++e) f[e] = src[(size_t)e * HW];
+        u32x4 hi, lo;
+        ssplit8(f, hi, lo);
+        u32x4* dst = out + ((size_t)(n * G8 + g) * 2) * HW + p;
+        dst[0] = hi;
+        dst[HW] = lo;
+        if (c4) {
+            f32x4* d4 = reinterpret_cast<f32x4*>(c4) + ((size_t)n * (C >> 2) + 2 * g) * HW + p;
+            d4[0] = (f32x4){f[0], f[1], f[2], f[3]};
+            d4[HW] = (f32x4){f[4], f[5], f[6], f[7]};
         }
     }
 }
@@ -125,7 +121,10 @@ struct S8Up {
     int f[3];
     int n;
 };
-__global__ __launch_bounds__(256) void s8_upsample_add_kernel(S8Up U, const float* __restrict__ res, float* out_nchw,
+// the round-3 form: a thread owns 4 consecutive pixels of one 8-channel group - a quarter of the low-resolution loads per pixel
+// (kept for rows with three upsampled terms, where those loads outweigh the short store runs: 117 against 138 us at 48 channels
+// @96x72 with terms at 1/2, 1/4, 1/8 resolution; with one or two terms the one-pixel form below is 25 % faster)
+__global__ __launch_bounds__(256) void s8_upsample_add4_kernel(S8Up U, const float* __restrict__ res, float* out_nchw,
                                                                u32x4* __restrict__ out_s8, float* __restrict__ out_c4, int N, int C,
                                                                int Hh, int Wh, int relu, int res_ctot, int res_coff, int out_ctot,
                                                                int out_coff) {
@@ -175,6 +174,51 @@ __global__ __launch_bounds__(256) void s8_upsample_add_kernel(S8Up U, const floa
             d4[0] = (f32x4){f[0], f[1], f[2], f[3]};
             d4[HW] = (f32x4){f[4], f[5], f[6], f[7]};
         }
+    }
+}
+
+__global__ __launch_bounds__(256) void s8_upsample_add_kernel(S8Up U, const float* __restrict__ res, float* out_nchw,
+                                                               u32x4* __restrict__ out_s8, float* __restrict__ out_c4, int N, int C,
+                                                               int Hh, int Wh, int relu, int res_ctot, int res_coff, int out_ctot,
+                                                               int out_coff) {
+    // a thread owns ONE pixel of one 8-channel group (see s8_pack_kernel: 1 KB store runs per wave instruction)
+    const int HW = Hh * Wh, G8 = C >> 3;
+    const size_t items = (size_t)N * G8 * HW;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < items; i += (size_t)gridDim.x * 256) {
+        const int p = (int)(i % HW);
+        const size_t r = i / HW;
+        const int g = (int)(r % G8), n = (int)(r / G8);
+        const int y = p / Wh, x = p - y * Wh;
+        int lo_off[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int f = k < U.n ? U.f[k] : 1;
+            lo_off[k] = (y / f) * (Wh / f) + x / f;                 // pixel of term k's low-resolution map
+        }
+        float f8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = 8 * g + e;
+            float o = res[((size_t)n * res_ctot + res_coff + c) * HW + p];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if (k < U.n) {
+                    const int f = U.f[k];
+                    o = o + U.low[k][((size_t)n * C + c) * (size_t)((Hh / f) * (Wh / f)) + lo_off[k]];
+                }
+            }
+            if (relu) o = fmaxf(o, 0.f);
+            f8[e] = o;
+            if (out_nchw) out_nchw[((size_t)n * out_ctot + out_coff + c) * HW + p] = o;
+        }
+        u32x4 hi, lo;
+        ssplit8(f8, hi, lo);
+        u32x4* dst = out_s8 + ((size_t)(n * G8 + g) * 2) * HW + p;
+        dst[0] = hi;
+        dst[HW] = lo;
+        f32x4* d4 = reinterpret_cast<f32x4*>(out_c4) + ((size_t)n * (C >> 2) + 2 * g) * HW + p;
+        d4[0] = (f32x4){f8[0], f8[1], f8[2], f8[3]};
+        d4[HW] = (f32x4){f8[4], f8[5], f8[6], f8[7]};
     }
 }
 
@@ -685,8 +729,8 @@ extern "C" int otp_s8_pack(const void* in, void* out, void* out_c4, int N, int C
     if (C % 8 || ((H * W) & 3) ||
         ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(out_c4)) & 15))
         return OTP_ERR_UNSUPPORTED;
-    const size_t items = (size_t)N * (C / 8) * (H * W / 4);
-    const int grid = (int)((items + 255) / 256 > 8192 ? 8192 : (items + 255) / 256);
+    const size_t items = (size_t)N * (C / 8) * (H * W);
+    const int grid = (int)((items + 255) / 256 > 16384 ? 16384 : (items + 255) / 256);
     hipLaunchKernelGGL(s8_pack_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const float*>(in),
                        static_cast<u32x4*>(out), static_cast<float*>(out_c4), N, C, H * W, in_ctot, in_coff);
     return otp_launch_status();
@@ -710,8 +754,16 @@ extern "C" int otp_s8_upsample_add(const void* const* lows, const int* factors, 
     if ((reinterpret_cast<uintptr_t>(res) | reinterpret_cast<uintptr_t>(out_nchw) | reinterpret_cast<uintptr_t>(out_s8) |
          reinterpret_cast<uintptr_t>(out_c4)) & 15)
         return OTP_ERR_UNSUPPORTED;
-    const size_t items = (size_t)N * (C / 8) * (Hh * Wh / 4);
-    const int grid = (int)((items + 255) / 256 > 8192 ? 8192 : (items + 255) / 256);
+    if (nlow >= 3) {
+        const size_t items4 = (size_t)N * (C / 8) * (Hh * Wh / 4);
+        const int grid4 = (int)((items4 + 255) / 256 > 8192 ? 8192 : (items4 + 255) / 256);
+        hipLaunchKernelGGL(s8_upsample_add4_kernel, dim3(grid4), dim3(256), 0, static_cast<hipStream_t>(stream), U,
+                           static_cast<const float*>(res), static_cast<float*>(out_nchw), static_cast<u32x4*>(out_s8),
+                           static_cast<float*>(out_c4), N, C, Hh, Wh, relu, res_ctot, res_coff, out_ctot, out_coff);
+        return otp_launch_status();
+    }
+    const size_t items = (size_t)N * (C / 8) * (Hh * Wh);
+    const int grid = (int)((items + 255) / 256 > 16384 ? 16384 : (items + 255) / 256);
     hipLaunchKernelGGL(s8_upsample_add_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), U,
                        static_cast<const float*>(res), static_cast<float*>(out_nchw), static_cast<u32x4*>(out_s8),
                        static_cast<float*>(out_c4), N, C, Hh, Wh, relu, res_ctot, res_coff, out_ctot, out_coff);

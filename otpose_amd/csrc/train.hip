@@ -414,10 +414,21 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     const int sub = blockIdx.x * 32 + sl;
     const int seg = (gx + 7) >> 3;
     const int w0 = sg * seg, w1 = min(gx, w0 + seg);
+    // which of the four waves' copies of this slot hold a weight at all (most of the 48 x 48 x 9 slot space is empty for the
+    // narrow layers this fp32 path serves: their partials are never read)
+    const int lane_ = sub & 63, r_ = (sub >> 6) & 3, gb_ = sub >> 8;
+    const int b_ = gb_ % 3, g_ = gb_ / 3;
+    const int by_ = blockIdx.y % gy, bz_ = blockIdx.y / gy;
+    const int ncib_ = min(3, (Cin - bz_ * WG_CI + 15) >> 4), ncob_ = min(3, (Cout - by_ * WG_CO + 15) >> 4);
+    const int KK_ = KS * KS, ncombo_ = KK_ * ncib_;
+    const bool row_ok = sub < WSLOTS && b_ < ncob_ && by_ * WG_CO + b_ * 16 + (lane_ >> 4) * 4 + r_ < Cout;
 #pragma unroll
     for (int wave = 0; wave < 4; ++wave) {
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        if (sub < WSLOTS && w1 > w0) {
+        const int combo_ = KK_ == 1 ? g_ : wave + 4 * g_;
+        const bool live = row_ok && combo_ < ncombo_ &&
+                          bz_ * WG_CI + (combo_ - (combo_ / ncib_) * ncib_) * 16 + (lane_ & 15) < Cin;
+        if (live && w1 > w0) {
             const float* src = part + ((size_t)blockIdx.y * gx + w0) * WG_SLOTS + wave * WSLOTS + sub;
             int w = w0;
             for (; w + 3 < w1; w += 4, src += 4 * (size_t)WG_SLOTS) {
