@@ -113,7 +113,7 @@ def measured_traffic(key, with_source=False):
     in separate passes and corrected as MI355X_MICROARCH.md prescribes; see profiles/r02_traffic.json for the split-bf16
     kernels and profiles/r01_traffic.json for the f32 ones).  None when the files or the key are absent: PMC counters cannot
     be read from inside this process."""
-    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 v = json.load(f).get(key, {}).get("hbm_bytes_per_launch")
@@ -223,7 +223,7 @@ def kernel_rooflines(dev, batch):
                  "conv2_form": {"what": "S8 + C4 residual -> C4 + S8 (BasicBlock conv2)", "ms_per_launch": t_conv2,
                                 "achieved": conv_flop / (t_conv2 * 1e-3) / 1e12, "frac": conv_flop / (t_conv2 * 1e-3) / peak,
                                 "mfma_pipe_frac": executed / (t_conv2 * 1e-3) / peak,
-                                "traffic": tr2, "traffic_source": "committed profile (profiles/r03_traffic.json), not collected in this run",
+                                "traffic": tr2, "traffic_source": "committed profile (profiles/r0*_traffic.json: separate --pmc passes), not collected in this run",
                                 "algorithmic_bytes_per_launch": 4.0 * 4 * 48 * 96 * 72 * n,
                                 "hbm_frac": (tr2 if tr2 is not None else 4.0 * 4 * 48 * 96 * 72 * n) / (t_conv2 * 1e-3) / PEAK_HBM}}
     elif use_x3:
