@@ -101,6 +101,11 @@ typedef struct otp_conv_desc {
     int N, Cin, H, W, Cout, kh, kw, stride, pad, dil;
     int in_ctot, in_coff, in2_ctot, in2_coff, out_ctot, out_coff;
     int res_ctot, res_coff, res_up, act, Ho, Wo, frame_split;
+    /* split-product kernels only (otp_conv2d_x3, otp_conv3x3_s8, otp_conv3x3_s2_s8): the packed weights carry a power-of-two
+     * factor 2^k (folded into the `scale` vector handed to the packer) so that BOTH half pieces of every weight are normal
+     * numbers - 22 significand bits per weight instead of ~17 for BatchNorm-folded weights of magnitude 0.01 - and the kernel
+     * multiplies the accumulated sum by out_scale = 2^-k before shift / residual / activation.  0 means 1. */
+    float out_scale;
 } otp_conv_desc;
 
 /* tuning / test hook: force the (M-blocks, pixel-blocks, waves-in-M, waves-in-pixels) tile of otp_conv2d;

@@ -64,6 +64,29 @@ __device__ __forceinline__ float bload(otp_rsrc r, int voff_bytes, int soff_byte
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff_bytes, soff_bytes, 0));
 }
 typedef float otp_f32x4 __attribute__((ext_vector_type(4)));
+typedef float otp_f32x2 __attribute__((ext_vector_type(2)));
+
+// ---- the 16-bit operand type of the split ("x3") products ------------------------------------------------------------------
+// Every fp32 operand a of the convolutions / projections / MLPs / attention products of the eval path is carried as two 16-bit
+// pieces, hi = rne(a), lo = rne(a - hi), and a product is accumulated in fp32 as a_lo*b_hi + a_hi*b_lo + a_hi*b_hi on the
+// 16x16x32 MFMA (csrc/convx.hip).  Rounds 2-3 used bfloat16 pieces: 8 significand bits each, a = hi + lo to 2^-17.  Round 4
+// switched to IEEE half: 11 bits each, a = hi + lo to max(2^-22 |a|, 2^-25) - the f16 MFMA of gfx950 has the same rate as the
+// bf16 one and takes SUBNORMAL f16 inputs exactly (tools/micro/mfma_f16_denorm.hip), which the small `lo` pieces need.  Range:
+// operands above 65504 become infinities (BatchNorm-folded weights and heat-map activations are orders of magnitude below);
+// -DOTP_X3_BF16 restores the bfloat16 pieces.
+#ifdef OTP_X3_BF16
+typedef __bf16 otp_x3_t;
+#define OTP_X3_MFMA __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#else
+typedef _Float16 otp_x3_t;
+#define OTP_X3_MFMA __builtin_amdgcn_mfma_f32_16x16x32_f16
+#endif
+typedef otp_x3_t otp_x3x2 __attribute__((ext_vector_type(2)));
+typedef otp_x3_t otp_x3x8 __attribute__((ext_vector_type(8)));
+// the two pieces of a packed pair back as fp32
+__device__ __forceinline__ otp_f32x2 otp_x3_widen(uint32_t pair) {
+    return __builtin_convertvector(__builtin_bit_cast(otp_x3x2, pair), otp_f32x2);
+}
 typedef unsigned int otp_u32x4 __attribute__((ext_vector_type(4)));
 // 16-byte buffer load: offsets at or past the descriptor's size return zeros (hardware range check)
 __device__ __forceinline__ otp_f32x4 bload4(otp_rsrc r, int voff_bytes) {

@@ -29,8 +29,8 @@
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef otp_x3x8 h16x8;              // 8 operand pieces of the split products (common.h: IEEE half since round 4)
+typedef otp_x3x2 h16x2;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -58,6 +58,7 @@ __device__ unsigned long long otp_convs_stamps[8192 * 32];
 struct SPlan {
     int N, C, H, W, HW, Cout, total;
     int out_ctot, out_coff, act, f32_mode;
+    float pre, post;                      // weights carry 2^k = pre (otp_conv_desc.out_scale = post = 2^-k): see the epilogue
     int NTW, nN, nTiles, nChunks, tpx;
     int NPT;                              // pixel tiles of 16 per wave (workgroup tile = 64 NPT pixels)
     int VR, W1, NIW, NV, pl;              // virtual rows per image (H + 1), records per window row (W + 1), 64-record pieces per plane,
@@ -71,10 +72,10 @@ __device__ __forceinline__ void ssplit8(const float (&v)[8], u32x4& hi, u32x4& l
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const f32x2 a = {v[2 * i], v[2 * i + 1]};
-        const bf16x2 ah = __builtin_convertvector(a, bf16x2);
+        const h16x2 ah = __builtin_convertvector(a, h16x2);
         const uint32_t hb = __builtin_bit_cast(uint32_t, ah);
-        const f32x2 af = {__builtin_bit_cast(float, hb << 16), __builtin_bit_cast(float, hb & 0xffff0000u)};
-        const bf16x2 al = __builtin_convertvector(a - af, bf16x2);
+        const f32x2 af = otp_x3_widen(hb);
+        const h16x2 al = __builtin_convertvector(a - af, h16x2);
         h[i] = hb;
         l[i] = __builtin_bit_cast(uint32_t, al);
     }
@@ -246,10 +247,8 @@ __global__ __launch_bounds__(256) void s8_unpack_kernel(const u32x4* __restrict_
         const u32x4 hi = in[((size_t)(n * G8 + g) * 2) * HW + p], lo = in[((size_t)(n * G8 + g) * 2 + 1) * HW + p];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const uint32_t hw = hi[e >> 1], lw = lo[e >> 1];
-            const float fh = __builtin_bit_cast(float, (e & 1) ? (hw & 0xffff0000u) : (hw << 16));
-            const float fl = __builtin_bit_cast(float, (e & 1) ? (lw & 0xffff0000u) : (lw << 16));
-            out[((size_t)n * C + 8 * g + e) * HW + p] = fh + fl;
+            const f32x2 fh = otp_x3_widen(hi[e >> 1]), fl = otp_x3_widen(lo[e >> 1]);
+            out[((size_t)n * C + 8 * g + e) * HW + p] = fh[e & 1] + fl[e & 1];
         }
     }
 }
@@ -472,30 +471,34 @@ __global__ __launch_bounds__(256, NCHW ? 2 : 3) void convs_kernel(const unsigned
                     rres, (pv && tv) ? c4o + (ch0[t] >> 2) * P.HW * 16 : SOOB, 0, 0));
             }
         }
+        // the weights carry a factor pre = 2^k (both half pieces of every weight normal: otp_conv_desc.out_scale), so the sum
+        // starts from (residual + shift) * 2^k - exact - and is multiplied by post = 2^-k in the epilogue
 #pragma unroll
-        for (int t = 0; t < NTW; ++t)
+        for (int t = 0; t < NTW; ++t) {
+            const f32x4 shp = sh[t] * P.pre;
 #pragma unroll
-            for (int p = 0; p < NPT; ++p) acc[t][p] += sh[t];
+            for (int p = 0; p < NPT; ++p) acc[t][p] = acc[t][p] * P.pre + shp;
+        }
     }
 
     // One chunk: NBLK blocks of 3 NTW MFMAs.  B fragments are read two blocks ahead (ring of three), the weight fragments of
     // the next k-step two blocks before it starts, the reads spread between the MFMAs (tools/micro/mfma_loop.hip: 16.8 cycles
     // per MFMA for one wave per SIMD, against 20.8 with reads one block ahead, clustered, and addresses computed in the loop).
     auto mfma_phase = [&]() __attribute__((always_inline)) {
-        bf16x8 ah[2][NTW], al[2][NTW], bh[3], bl[3];
+        h16x8 ah[2][NTW], al[2][NTW], bh[3], bl[3];
         auto load_a = [&](int buf, int s) __attribute__((always_inline)) {
 #pragma unroll
             for (int t = 0; t < NTW; ++t) {
                 if (s < SKS - 1) {
                     const unsigned char* a = wl + ((s * NTW + t) * 2) * 1024 + lane * 16;
-                    ah[buf][t] = *reinterpret_cast<const bf16x8*>(a);
-                    al[buf][t] = *reinterpret_cast<const bf16x8*>(a + 1024);
+                    ah[buf][t] = *reinterpret_cast<const h16x8*>(a);
+                    al[buf][t] = *reinterpret_cast<const h16x8*>(a + 1024);
                 } else {
                     // last k-step: k-slots 16, 17 (tap 8) on the lanes kl = 0, 1; kl = 2, 3 (tap 9) multiply zeros - their half of
                     // the fragment is not stored (512-byte half pieces behind the full ones)
                     const unsigned char* a = wl + (SKS - 1) * NTW * 2048 + t * 1024 + (lane & 31) * 16;
-                    const bf16x8 h = *reinterpret_cast<const bf16x8*>(a), l = *reinterpret_cast<const bf16x8*>(a + 512);
-                    const bf16x8 z = __builtin_bit_cast(bf16x8, (u32x4){0u, 0u, 0u, 0u});
+                    const h16x8 h = *reinterpret_cast<const h16x8*>(a), l = *reinterpret_cast<const h16x8*>(a + 512);
+                    const h16x8 z = __builtin_bit_cast(h16x8, (u32x4){0u, 0u, 0u, 0u});
                     ah[buf][t] = upper ? z : h;
                     al[buf][t] = upper ? z : l;
                 }
@@ -503,8 +506,8 @@ __global__ __launch_bounds__(256, NCHW ? 2 : 3) void convs_kernel(const unsigned
         };
         auto load_b = [&](int buf, int blk) __attribute__((always_inline)) {
             const unsigned char* b = win + (pb[blk % NPT] + toff[blk / NPT]);
-            bh[buf] = *reinterpret_cast<const bf16x8*>(b);
-            bl[buf] = *reinterpret_cast<const bf16x8*>(b + PL);
+            bh[buf] = *reinterpret_cast<const h16x8*>(b);
+            bl[buf] = *reinterpret_cast<const h16x8*>(b + PL);
         };
         load_a(0, 0);
         load_b(0, 0);
@@ -517,9 +520,9 @@ __global__ __launch_bounds__(256, NCHW ? 2 : 3) void convs_kernel(const unsigned
             if (na) load_a(sa ^ 1, s + 1);
 #pragma unroll
             for (int t = 0; t < NTW; ++t) {
-                acc[t][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[sa][t], bh[cur], acc[t][p], 0, 0, 0);
-                acc[t][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[sa][t], bl[cur], acc[t][p], 0, 0, 0);
-                acc[t][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[sa][t], bh[cur], acc[t][p], 0, 0, 0);
+                acc[t][p] = OTP_X3_MFMA(al[sa][t], bh[cur], acc[t][p], 0, 0, 0);
+                acc[t][p] = OTP_X3_MFMA(ah[sa][t], bl[cur], acc[t][p], 0, 0, 0);
+                acc[t][p] = OTP_X3_MFMA(ah[sa][t], bh[cur], acc[t][p], 0, 0, 0);
             }
             if (!nb) sblock_sched<NM, 0>();
             else if (na) sblock_sched<NM, 2 + 2 * NTW>();
@@ -548,6 +551,12 @@ __global__ __launch_bounds__(256, NCHW ? 2 : 3) void convs_kernel(const unsigned
     // All arithmetic first, all stores last: no register a store reads is written again before the wave ends (the S8 records of
     // one pixel tile used to be rebuilt in the registers the previous tile's stores were still reading - results then changed
     // with the load on the memory pipeline, i.e. with who else was resident on the CU).
+    if (P.post != 1.f) {
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+#pragma unroll
+            for (int p = 0; p < NPT; ++p) acc[t][p] = acc[t][p] * P.post;
+    }
     if (P.act == OTP_ACT_RELU) {
 #pragma unroll
         for (int t = 0; t < NTW; ++t)
@@ -662,6 +671,8 @@ bool convs_plan(const otp_conv_desc& d, SPlan& P) {
     if (d.Cin % 16 || d.Cout % 16 || ((d.H * d.W) & 3) || d.Ho != d.H || d.Wo != d.W) return false;
     P.N = d.N; P.C = d.Cin; P.H = d.H; P.W = d.W; P.HW = d.H * d.W; P.Cout = d.Cout; P.total = d.N * P.HW;
     P.out_ctot = d.out_ctot; P.out_coff = d.out_coff; P.act = d.act; P.f32_mode = S_F32_NONE;
+    P.post = d.out_scale > 0.f ? d.out_scale : 1.f;
+    P.pre = 1.f / P.post;
     P.NTW = s8_ntw(d.Cout);
     P.nN = ((d.Cout + 15) / 16 + P.NTW - 1) / P.NTW;
     P.NPT = 4;

@@ -22,8 +22,8 @@
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef otp_x3x8 h16x8;              // 8 operand pieces of the split products (common.h: IEEE half since round 4)
+typedef otp_x3x2 h16x2;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -43,10 +43,10 @@ __device__ __forceinline__ void ssplit8(const float (&v)[8], u32x4& hi, u32x4& l
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const f32x2 a = {v[2 * i], v[2 * i + 1]};
-        const bf16x2 ah = __builtin_convertvector(a, bf16x2);
+        const h16x2 ah = __builtin_convertvector(a, h16x2);
         const uint32_t hb = __builtin_bit_cast(uint32_t, ah);
-        const f32x2 af = {__builtin_bit_cast(float, hb << 16), __builtin_bit_cast(float, hb & 0xffff0000u)};
-        const bf16x2 al = __builtin_convertvector(a - af, bf16x2);
+        const f32x2 af = otp_x3_widen(hb);
+        const h16x2 al = __builtin_convertvector(a - af, h16x2);
         h[i] = hb;
         l[i] = __builtin_bit_cast(uint32_t, al);
     }
@@ -87,6 +87,7 @@ __device__ __forceinline__ void sblock_sched() {
 struct S2Plan {
     int N, C, H, W, HW, Ho, Wo, HWo, Cout, total;      // total = N * Ho * Wo output pixels
     int out_ctot, out_coff, res_ctot, res_coff, act;
+    float pre, post;                                   // weights carry 2^k = pre; the sum is multiplied by post = 2^-k (out_scale)
     int NTW, nN, nTiles, nChunks, tpx, NPT;
     int VR, W1, NIW, NV, pl;                           // virtual rows per image (H + 1), records per virtual row (W + 1), 64-record
                                                        // pieces per plane, records / bytes of a window plane
@@ -197,23 +198,23 @@ __global__ __launch_bounds__(256, 2) void convs2_kernel(const unsigned char* __r
             pb[p] = (((n0 + dn) * P.VR + 2 * y - Vf) * P.W1 + x) * 16;    // record x of the virtual row of tap dy = 0
             offS[p] = pv ? ((n0 + dn) * (P.Cout >> 2) * P.HWo + pi) * 16 : SOOB;   // S8 image: (((img Go + ch / 8) 2 + part) HWo + pi) 16
 #pragma unroll
-            for (int t = 0; t < NTW; ++t) acc[t][p] = sh[t];
+            for (int t = 0; t < NTW; ++t) acc[t][p] = sh[t] * P.pre;
         }
     }
 
     auto mfma_phase = [&]() __attribute__((always_inline)) {
-        bf16x8 ah[2][NTW], al[2][NTW], bh[3], bl[3];
+        h16x8 ah[2][NTW], al[2][NTW], bh[3], bl[3];
         auto load_a = [&](int buf, int s) __attribute__((always_inline)) {
 #pragma unroll
             for (int t = 0; t < NTW; ++t) {
                 if (s < SKS - 1) {
                     const unsigned char* a = wl + ((s * NTW + t) * 2) * 1024 + lane * 16;
-                    ah[buf][t] = *reinterpret_cast<const bf16x8*>(a);
-                    al[buf][t] = *reinterpret_cast<const bf16x8*>(a + 1024);
+                    ah[buf][t] = *reinterpret_cast<const h16x8*>(a);
+                    al[buf][t] = *reinterpret_cast<const h16x8*>(a + 1024);
                 } else {
                     const unsigned char* a = wl + (SKS - 1) * NTW * 2048 + t * 1024 + (lane & 31) * 16;
-                    const bf16x8 h = *reinterpret_cast<const bf16x8*>(a), l = *reinterpret_cast<const bf16x8*>(a + 512);
-                    const bf16x8 z = __builtin_bit_cast(bf16x8, (u32x4){0u, 0u, 0u, 0u});
+                    const h16x8 h = *reinterpret_cast<const h16x8*>(a), l = *reinterpret_cast<const h16x8*>(a + 512);
+                    const h16x8 z = __builtin_bit_cast(h16x8, (u32x4){0u, 0u, 0u, 0u});
                     ah[buf][t] = upper ? z : h;
                     al[buf][t] = upper ? z : l;
                 }
@@ -221,8 +222,8 @@ __global__ __launch_bounds__(256, 2) void convs2_kernel(const unsigned char* __r
         };
         auto load_b = [&](int buf, int blk) __attribute__((always_inline)) {
             const unsigned char* b = win + (pb[blk % NPT] + toff[blk / NPT]);
-            bh[buf] = *reinterpret_cast<const bf16x8*>(b);
-            bl[buf] = *reinterpret_cast<const bf16x8*>(b + PL);
+            bh[buf] = *reinterpret_cast<const h16x8*>(b);
+            bl[buf] = *reinterpret_cast<const h16x8*>(b + PL);
         };
         load_a(0, 0);
         load_b(0, 0);
@@ -236,9 +237,9 @@ __global__ __launch_bounds__(256, 2) void convs2_kernel(const unsigned char* __r
             if (na) load_a(sa ^ 1, s + 1);
 #pragma unroll
             for (int t = 0; t < NTW; ++t) {
-                acc[t][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[sa][t], bh[cur], acc[t][p], 0, 0, 0);
-                acc[t][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[sa][t], bl[cur], acc[t][p], 0, 0, 0);
-                acc[t][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[sa][t], bh[cur], acc[t][p], 0, 0, 0);
+                acc[t][p] = OTP_X3_MFMA(al[sa][t], bh[cur], acc[t][p], 0, 0, 0);
+                acc[t][p] = OTP_X3_MFMA(ah[sa][t], bl[cur], acc[t][p], 0, 0, 0);
+                acc[t][p] = OTP_X3_MFMA(ah[sa][t], bh[cur], acc[t][p], 0, 0, 0);
             }
             if (!nb && !na) sblock_sched<NM, 0>();
             else if (nb && na) sblock_sched<NM, 2 + 2 * NTW>();
@@ -258,6 +259,12 @@ __global__ __launch_bounds__(256, 2) void convs2_kernel(const unsigned char* __r
         }
     }
 
+    if (P.post != 1.f) {
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+#pragma unroll
+            for (int p = 0; p < NPT; ++p) acc[t][p] = acc[t][p] * P.post;
+    }
     if (!NCHW) {
         // ---- S8 records of act(result) straight from the accumulators (no residual in this form) -------------------------------
         if (P.act == OTP_ACT_RELU) {
@@ -375,6 +382,8 @@ bool convs2_plan(const otp_conv_desc& d, S2Plan& P, bool nchw) {
     P.N = d.N; P.C = d.Cin; P.H = d.H; P.W = d.W; P.HW = d.H * d.W; P.Ho = Ho; P.Wo = Wo; P.HWo = Ho * Wo; P.Cout = d.Cout;
     P.total = d.N * P.HWo;
     P.out_ctot = d.out_ctot; P.out_coff = d.out_coff; P.res_ctot = d.res_ctot; P.res_coff = d.res_coff; P.act = d.act;
+    P.post = d.out_scale > 0.f ? d.out_scale : 1.f;
+    P.pre = 1.f / P.post;
     P.NTW = s8_ntw(d.Cout);
     P.nN = ((d.Cout + 15) / 16 + P.NTW - 1) / P.NTW;
     P.nChunks = d.Cin / 16;

@@ -22,8 +22,8 @@
 namespace {
 
 typedef __bf16 bf16;
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef otp_x3x8 h16x8;              // 8 operand pieces of the split products (common.h: IEEE half since round 4)
+typedef otp_x3x2 h16x2;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -56,6 +56,7 @@ struct XPlan {
     int N, Cin, H, W, HW, Cout, Ho, Wo, HoWo, total;
     int in_ctot, in_coff, out_ctot, out_coff, res_ctot, res_coff, act;
     int stride, pad, dil, taps;
+    float post;                            // otp_conv_desc.out_scale (1 when unset)
     int NTW, nN, nTiles, nChunks, tpx;
     int VR, WPp, CS, rowsMax, S, NI;
     int winBytes, wBytes;
@@ -68,10 +69,10 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const f32x2 a = {v[2 * i], v[2 * i + 1]};
-        const bf16x2 ah = __builtin_convertvector(a, bf16x2);
+        const h16x2 ah = __builtin_convertvector(a, h16x2);
         const uint32_t hb = __builtin_bit_cast(uint32_t, ah);
-        const f32x2 af = {__builtin_bit_cast(float, hb << 16), __builtin_bit_cast(float, hb & 0xffff0000u)};
-        const bf16x2 al = __builtin_convertvector(a - af, bf16x2);
+        const f32x2 af = otp_x3_widen(hb);
+        const h16x2 al = __builtin_convertvector(a - af, h16x2);
         h[i] = hb;
         l[i] = __builtin_bit_cast(uint32_t, al);
     }
@@ -288,19 +289,19 @@ __global__ __launch_bounds__(256, 2) void convx_kernel(const float* __restrict__
     // Fragment pipeline: the LDS reads of the next n-tile (and, at the last n-tile of a k-step, of the next step's pixel
     // fragments) are issued before the 12 MFMAs of the current one, so no MFMA waits on an LDS round trip.
     auto mfma_phase = [&]() __attribute__((always_inline)) {
-        bf16x8 ah[2][MTW], al[2][MTW], bh[2], bl[2];
+        h16x8 ah[2][MTW], al[2][MTW], bh[2], bl[2];
         auto load_a = [&](int buf, int s) __attribute__((always_inline)) {
 #pragma unroll
             for (int mt = 0; mt < MTW; ++mt) {
                 const unsigned char* a = win + mbase[mt] + toff[s];
-                ah[buf][mt] = *reinterpret_cast<const bf16x8*>(a);
-                al[buf][mt] = *reinterpret_cast<const bf16x8*>(a + LO);
+                ah[buf][mt] = *reinterpret_cast<const h16x8*>(a);
+                al[buf][mt] = *reinterpret_cast<const h16x8*>(a + LO);
             }
         };
         auto load_b = [&](int buf, int s, int t) __attribute__((always_inline)) {
             const unsigned char* b = wl + ((s * NTW + t) * 2) * 1024 + lane * 16;
-            bh[buf] = *reinterpret_cast<const bf16x8*>(b);
-            bl[buf] = *reinterpret_cast<const bf16x8*>(b + 1024);
+            bh[buf] = *reinterpret_cast<const h16x8*>(b);
+            bl[buf] = *reinterpret_cast<const h16x8*>(b + 1024);
         };
         load_a(0, 0);
         load_b(0, 0, 0);
@@ -318,9 +319,9 @@ __global__ __launch_bounds__(256, 2) void convx_kernel(const float* __restrict__
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int mt = 0; mt < MTW; ++mt) {
-                    acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[sa][mt], bh[cur], acc[mt][t], 0, 0, 0);
-                    acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[sa][mt], bl[cur], acc[mt][t], 0, 0, 0);
-                    acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[sa][mt], bh[cur], acc[mt][t], 0, 0, 0);
+                    acc[mt][t] = OTP_X3_MFMA(al[sa][mt], bh[cur], acc[mt][t], 0, 0, 0);
+                    acc[mt][t] = OTP_X3_MFMA(ah[sa][mt], bl[cur], acc[mt][t], 0, 0, 0);
+                    acc[mt][t] = OTP_X3_MFMA(ah[sa][mt], bh[cur], acc[mt][t], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -406,7 +407,7 @@ __global__ __launch_bounds__(256, 2) void convx_kernel(const float* __restrict__
         const float sh = shv[t];
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt) {
-            f32x4 y = acc[mt][t] + sh + rv[mt][t];
+            f32x4 y = acc[mt][t] * P.post + sh + rv[mt][t];      // post = 2^-k: the packed weights carry 2^k (out_scale)
 #pragma unroll
             for (int r = 0; r < 4; ++r) y[r] = fmaxf(y[r], lo);
             if (ev[mt] && co < P.Cout) *reinterpret_cast<f32x4*>(out + (size_t)eo[mt] + (size_t)co * P.HoWo) = y;
@@ -435,6 +436,7 @@ bool convx_plan(const otp_conv_desc& d, XPlan& P) {
     P.Ho = Ho; P.Wo = Wo; P.HoWo = Ho * Wo; P.total = d.N * P.HoWo;
     P.in_ctot = d.in_ctot; P.in_coff = d.in_coff; P.out_ctot = d.out_ctot; P.out_coff = d.out_coff;
     P.res_ctot = d.res_ctot; P.res_coff = d.res_coff; P.act = d.act;
+    P.post = d.out_scale > 0.f ? d.out_scale : 1.f;
     P.stride = d.stride; P.pad = d.pad; P.dil = d.dil;
     const int c16 = (d.Cout + 15) / 16;
     P.NTW = x3_ntw(d.Cout, d.stride, TAPS);

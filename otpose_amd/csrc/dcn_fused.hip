@@ -23,8 +23,8 @@
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef otp_x3x8 h16x8;              // 8 operand pieces of the split products (common.h: IEEE half since round 4)
+typedef otp_x3x2 h16x2;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -45,10 +45,10 @@ __device__ __forceinline__ void f_split8(const float (&v)[8], u32x4& hi, u32x4& 
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const f32x2 a = {v[2 * i], v[2 * i + 1]};
-        const uint32_t hb = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, bf16x2));
-        const f32x2 af = {__builtin_bit_cast(float, hb << 16), __builtin_bit_cast(float, hb & 0xffff0000u)};
+        const uint32_t hb = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, h16x2));
+        const f32x2 af = otp_x3_widen(hb);
         h[i] = hb;
-        l[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(a - af, bf16x2));
+        l[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(a - af, h16x2));
     }
     hi = (u32x4){h[0], h[1], h[2], h[3]};
     lo = (u32x4){l[0], l[1], l[2], l[3]};
@@ -71,14 +71,39 @@ __global__ __launch_bounds__(256) void dcnf_split_kernel(const float* __restrict
     }
 }
 
+// The offset and the mask weights of a dilation are stored times a power of two each (2^k with max |w| 2^k in [2^13, 2^14):
+// both half pieces of every weight are then normal numbers, 22 significand bits instead of ~17 - otp_conv_desc.out_scale in
+// include/otpose_hip.h is the same device) and the kernel multiplies the sums by 2^-k on their way to the sampling scratch.
+// One workgroup per (dilation, offsets | masks) finds the maximum and writes post = 2^-k into the image's tail.
+__global__ __launch_bounds__(256) void dcnf_exp_kernel(const float* const* __restrict__ w_off, const float* const* __restrict__ w_mask,
+                                                       float* __restrict__ post, int J) {
+    __shared__ float wmax[4];
+    const int di = blockIdx.x, kind = blockIdx.y;
+    const float* w = kind ? w_mask[di] : w_off[di];
+    const int count = (kind ? 9 : 18) * J * FCIN * 9;
+    float m = 0.f;
+    for (int i = threadIdx.x; i < count; i += 256) m = fmaxf(m, fabsf(w[i]));
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+        int e = 0;
+        (void)frexpf(m, &e);
+        const int k = (m > 0.f && m < 3e38f) ? min(40, max(-40, 14 - e)) : 0;
+        post[di * 2 + kind] = ldexpf(1.f, -k);
+    }
+}
+
 // packed image: [ND][J] weight blocks of FBLK bytes, then [ND][J][9][20] floats (W_dcn[o][g][k], o padded to 20), then the
-// J bias sums.  Weight block: [tap][n-tile][hi, lo][lane][8 bf16], lane = (channel 16 nt + (lane & 15) of the group's 32:
+// J bias sums (5 units), then post[ND][offsets | masks] (dcnf_exp_kernel, 4 units).  Weight block: [tap][n-tile][hi, lo][lane][8 bf16], lane = (channel 16 nt + (lane & 15) of the group's 32:
 // 0..17 offsets 18 g + c, 18..26 masks 9 g + c - 18, 27..31 zero; kq = lane >> 4 -> input channels 8 kq .. + 7)
 __global__ void dcnf_pack_kernel(const float* const* __restrict__ w_off, const float* const* __restrict__ w_mask,
                                  const float* const* __restrict__ w_dcn, const float* const* __restrict__ bias,
                                  unsigned char* __restrict__ packed, int ND, int J) {
     const int units = FBLK / 16;
     const size_t nW = (size_t)ND * J * units, nT = (size_t)ND * J * 9 * 5, total = nW + nT + 5;
+    const float* post = reinterpret_cast<const float*>(packed + (total << 4));          // written by dcnf_exp_kernel before this launch
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         u32x4 o = {0u, 0u, 0u, 0u};
         if (idx < nW) {
@@ -87,12 +112,13 @@ __global__ void dcnf_pack_kernel(const float* const* __restrict__ w_off, const f
             if (u < 9 * 2 * 2 * 64) {
                 const int frag = u >> 6, lane = u & 63, part = frag & 1, nt = (frag >> 1) & 1, tap = frag >> 2;
                 const int ch = 16 * nt + (lane & 15), kq = lane >> 4;
+                const float pre = 1.f / post[di * 2 + (ch < 18 ? 0 : 1)];
                 float v[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int ci = 8 * kq + j;
-                    v[j] = ch < 18 ? w_off[di][((size_t)(18 * g + ch) * FCIN + ci) * 9 + tap]
-                                   : (ch < 27 ? w_mask[di][((size_t)(9 * g + ch - 18) * FCIN + ci) * 9 + tap] : 0.f);
+                    v[j] = pre * (ch < 18 ? w_off[di][((size_t)(18 * g + ch) * FCIN + ci) * 9 + tap]
+                                          : (ch < 27 ? w_mask[di][((size_t)(9 * g + ch - 18) * FCIN + ci) * 9 + tap] : 0.f));
                 }
                 u32x4 hi, lo;
                 f_split8(v, hi, lo);
@@ -163,6 +189,7 @@ __global__ __launch_bounds__(64 * NW) void dcn_fused_kernel(const unsigned char*
     const otp_rsrc rws = make_rsrc32(ws + (size_t)n * P.HW * 128, (unsigned)P.HW * 128u);
     const otp_rsrc rx = make_rsrc32(x + (size_t)n * J * P.HW, (unsigned)(J * P.HW) * 4u);
     const size_t table_off = (size_t)P.ND * J * FBLK;
+    const float* postv = reinterpret_cast<const float*>(packed + table_off + ((size_t)P.ND * J * 45 + 5) * 16);
 
     float part[JP];
 #pragma unroll
@@ -172,6 +199,9 @@ __global__ __launch_bounds__(64 * NW) void dcn_fused_kernel(const unsigned char*
 
     for (int di = 0; di < P.ND; ++di) {
         const int d = P.dil[di];
+        // 2^-k of this dilation's packed offset / mask weights: accumulator 0 holds offset channels 0 .. 15, accumulator 1 the
+        // offset channels 16, 17 and the masks
+        const float post0 = postv[2 * di], post1 = i16 < 2 ? post0 : postv[2 * di + 1];
         __syncthreads();                                            // the previous dilation's table / weight buffers are free
         for (int i = tid; i < J * 9 * 5; i += 64 * NW)
             reinterpret_cast<u32x4*>(wd)[i] = reinterpret_cast<const u32x4*>(packed + table_off)[(size_t)di * J * 45 + i];
@@ -195,23 +225,23 @@ __global__ __launch_bounds__(64 * NW) void dcn_fused_kernel(const unsigned char*
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
-                const bf16x8 b0h = *reinterpret_cast<const bf16x8*>(wb + (k * 4 + 0) * 1024);
-                const bf16x8 b0l = *reinterpret_cast<const bf16x8*>(wb + (k * 4 + 1) * 1024);
-                const bf16x8 b1h = *reinterpret_cast<const bf16x8*>(wb + (k * 4 + 2) * 1024);
-                const bf16x8 b1l = *reinterpret_cast<const bf16x8*>(wb + (k * 4 + 3) * 1024);
-                const bf16x8 a_h = __builtin_bit_cast(bf16x8, ah[k]), a_l = __builtin_bit_cast(bf16x8, al[k]);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_l, b0h, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_l, b1h, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h, b0l, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h, b1l, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h, b0h, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h, b1h, acc1, 0, 0, 0);
+                const h16x8 b0h = *reinterpret_cast<const h16x8*>(wb + (k * 4 + 0) * 1024);
+                const h16x8 b0l = *reinterpret_cast<const h16x8*>(wb + (k * 4 + 1) * 1024);
+                const h16x8 b1h = *reinterpret_cast<const h16x8*>(wb + (k * 4 + 2) * 1024);
+                const h16x8 b1l = *reinterpret_cast<const h16x8*>(wb + (k * 4 + 3) * 1024);
+                const h16x8 a_h = __builtin_bit_cast(h16x8, ah[k]), a_l = __builtin_bit_cast(h16x8, al[k]);
+                acc0 = OTP_X3_MFMA(a_l, b0h, acc0, 0, 0, 0);
+                acc1 = OTP_X3_MFMA(a_l, b1h, acc1, 0, 0, 0);
+                acc0 = OTP_X3_MFMA(a_h, b0l, acc0, 0, 0, 0);
+                acc1 = OTP_X3_MFMA(a_h, b1l, acc1, 0, 0, 0);
+                acc0 = OTP_X3_MFMA(a_h, b0h, acc0, 0, 0, 0);
+                acc1 = OTP_X3_MFMA(a_h, b1h, acc1, 0, 0, 0);
             }
             // accumulator (channel i16 / 16 + i16, pixels 4 kq + r) -> scratch[pixel][channel]
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                scr[(4 * kq + r) * 32 + i16] = acc0[r];
-                scr[(4 * kq + r) * 32 + 16 + i16] = acc1[r];
+                scr[(4 * kq + r) * 32 + i16] = acc0[r] * post0;
+                scr[(4 * kq + r) * 32 + 16 + i16] = acc1[r] * post1;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -281,7 +311,7 @@ extern "C" int otp_dcn_fused_supported(int Cin, int J, int H, int W, int ND) {
 
 extern "C" size_t otp_dcn_fused_weight_bytes(int ND, int J) {
     if (ND <= 0 || J <= 0 || J > 20) return 0;
-    return (size_t)ND * J * FBLK + (size_t)ND * J * 45 * 16 + 5 * 16;
+    return (size_t)ND * J * FBLK + (size_t)ND * J * 45 * 16 + 5 * 16 + (FMAXD * 2 * 4);
 }
 
 // w_off[i] (18 J, 32, 3, 3), w_mask[i] (9 J, 32, 3, 3), w_dcn[i] (J, J, 3, 3), bias[i] (J) or NULL: device pointer arrays
@@ -291,6 +321,10 @@ extern "C" int otp_dcn_fused_pack(const void* const* w_off, const void* const* w
     if (!w_off || !w_mask || !w_dcn || !bias || !packed) return OTP_ERR_BAD_ARG;
     const size_t bytes = otp_dcn_fused_weight_bytes(ND, J);
     if (!bytes) return OTP_ERR_UNSUPPORTED;
+    if (ND > FMAXD) return OTP_ERR_UNSUPPORTED;
+    float* post = reinterpret_cast<float*>(static_cast<unsigned char*>(packed) + bytes - FMAXD * 2 * 4);
+    hipLaunchKernelGGL(dcnf_exp_kernel, dim3(ND, 2), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const float* const*>(w_off), reinterpret_cast<const float* const*>(w_mask), post, J);
     hipLaunchKernelGGL(dcnf_pack_kernel, dim3(1024), dim3(256), 0, static_cast<hipStream_t>(stream),
                        reinterpret_cast<const float* const*>(w_off), reinterpret_cast<const float* const*>(w_mask),
                        reinterpret_cast<const float* const*>(w_dcn), reinterpret_cast<const float* const*>(bias),

@@ -12,24 +12,24 @@
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef otp_x3x8 h16x8;              // 8 operand pieces of the split products (common.h: IEEE half since round 4)
+typedef otp_x3x2 h16x2;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void dx_split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+__device__ __forceinline__ void dx_split8(const float (&v)[8], h16x8& hi, h16x8& lo) {
     uint32_t h[4], l[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const f32x2 a = {v[2 * i], v[2 * i + 1]};
-        const uint32_t hb = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, bf16x2));
-        const f32x2 af = {__builtin_bit_cast(float, hb << 16), __builtin_bit_cast(float, hb & 0xffff0000u)};
+        const uint32_t hb = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, h16x2));
+        const f32x2 af = otp_x3_widen(hb);
         h[i] = hb;
-        l[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(a - af, bf16x2));
+        l[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(a - af, h16x2));
     }
-    hi = __builtin_bit_cast(bf16x8, (u32x4){h[0], h[1], h[2], h[3]});
-    lo = __builtin_bit_cast(bf16x8, (u32x4){l[0], l[1], l[2], l[3]});
+    hi = __builtin_bit_cast(h16x8, (u32x4){h[0], h[1], h[2], h[3]});
+    lo = __builtin_bit_cast(h16x8, (u32x4){l[0], l[1], l[2], l[3]});
 }
 
 __device__ __forceinline__ float dx_kslot_sum(float v) {
@@ -57,7 +57,7 @@ __global__ void densex_pack_kernel(const float* __restrict__ w, const float* __r
             const int c = 32 * ks + 8 * kq + j;
             v[j] = (row < C && c < C) ? w[(size_t)row * C + c] : 0.f;
         }
-        bf16x8 hi, lo;
+        h16x8 hi, lo;
         dx_split8(v, hi, lo);
         o = __builtin_bit_cast(u32x4, (frag & 1) ? lo : hi);
     } else if (u < KS * 2 * 64 + 8) {
@@ -94,7 +94,7 @@ __device__ __forceinline__ void dx_stage(const unsigned char* __restrict__ src, 
 // the `vmcnt(0)` of __syncthreads(), which made every block pay a store round trip.
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 template <int C, bool RES>
-__device__ __forceinline__ void dx_project(const bf16x8 (&Xh)[dx_ks(C)][2], const bf16x8 (&Xl)[dx_ks(C)][2],
+__device__ __forceinline__ void dx_project(const h16x8 (&Xh)[dx_ks(C)][2], const h16x8 (&Xl)[dx_ks(C)][2],
                                            const unsigned char* __restrict__ packed, unsigned char* lds,
                                            const float* __restrict__ res, float* __restrict__ out, size_t base, int T, int tok,
                                            bool valid) {
@@ -120,14 +120,14 @@ __device__ __forceinline__ void dx_project(const bf16x8 (&Xh)[dx_ks(C)][2], cons
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(P + (ks * 2) * 1024 + lane * 16);
-            const bf16x8 al = *reinterpret_cast<const bf16x8*>(P + (ks * 2 + 1) * 1024 + lane * 16);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, Xh[ks][0], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, Xh[ks][1], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, Xl[ks][0], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, Xl[ks][1], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, Xh[ks][0], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, Xh[ks][1], acc1, 0, 0, 0);
+            const h16x8 ah = *reinterpret_cast<const h16x8*>(P + (ks * 2) * 1024 + lane * 16);
+            const h16x8 al = *reinterpret_cast<const h16x8*>(P + (ks * 2 + 1) * 1024 + lane * 16);
+            acc0 = OTP_X3_MFMA(al, Xh[ks][0], acc0, 0, 0, 0);
+            acc1 = OTP_X3_MFMA(al, Xh[ks][1], acc1, 0, 0, 0);
+            acc0 = OTP_X3_MFMA(ah, Xl[ks][0], acc0, 0, 0, 0);
+            acc1 = OTP_X3_MFMA(ah, Xl[ks][1], acc1, 0, 0, 0);
+            acc0 = OTP_X3_MFMA(ah, Xh[ks][0], acc0, 0, 0, 0);
+            acc1 = OTP_X3_MFMA(ah, Xh[ks][1], acc1, 0, 0, 0);
         }
         const f32x4 sc = *reinterpret_cast<const f32x4*>(P + KS * 2048 + 16 * kq);
         const f32x4 sh = *reinterpret_cast<const f32x4*>(P + KS * 2048 + 64 + 16 * kq);
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void densex_cc_kernel(DxArgs A, int T, int 
     const size_t base = (size_t)b * C * T;
     const float* __restrict__ x = A.x[blockIdx.y];
     dx_stage<BLKB>(A.packed[blockIdx.y], lds);
-    bf16x8 Xh[KS][2], Xl[KS][2];
+    h16x8 Xh[KS][2], Xl[KS][2];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         float v0[8], v1[8];
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256, C <= 136 ? 3 : 2) void qkvx_front_kernel(const
                 v1 += X1[ks][j] * X1[ks][j];
             }
         const float r0 = 1.f / sqrtf(dx_kslot_sum(v0) * inv_c + eps), r1 = 1.f / sqrtf(dx_kslot_sum(v1) * inv_c + eps);
-        bf16x8 Xh[KS][2], Xl[KS][2];
+        h16x8 Xh[KS][2], Xl[KS][2];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll

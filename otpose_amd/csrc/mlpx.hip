@@ -20,8 +20,8 @@
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef otp_x3x8 h16x8;              // 8 operand pieces of the split products (common.h: IEEE half since round 4)
+typedef otp_x3x2 h16x2;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -57,18 +57,18 @@ __device__ __forceinline__ float mx_kslot_sum(float v) {   // sum over the four 
 }
 
 // 8 floats -> bf16 hi / lo vectors (hi = rne(a), lo = rne(a - hi))
-__device__ __forceinline__ void mx_split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+__device__ __forceinline__ void mx_split8(const float (&v)[8], h16x8& hi, h16x8& lo) {
     uint32_t h[4], l[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const f32x2 a = {v[2 * i], v[2 * i + 1]};
-        const uint32_t hb = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, bf16x2));
-        const f32x2 af = {__builtin_bit_cast(float, hb << 16), __builtin_bit_cast(float, hb & 0xffff0000u)};
+        const uint32_t hb = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, h16x2));
+        const f32x2 af = otp_x3_widen(hb);
         h[i] = hb;
-        l[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(a - af, bf16x2));
+        l[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(a - af, h16x2));
     }
-    hi = __builtin_bit_cast(bf16x8, (u32x4){h[0], h[1], h[2], h[3]});
-    lo = __builtin_bit_cast(bf16x8, (u32x4){l[0], l[1], l[2], l[3]});
+    hi = __builtin_bit_cast(h16x8, (u32x4){h[0], h[1], h[2], h[3]});
+    lo = __builtin_bit_cast(h16x8, (u32x4){l[0], l[1], l[2], l[3]});
 }
 
 constexpr int mx_ks1(int C) { return (C + 31) / 32; }
@@ -107,7 +107,7 @@ __global__ void mlpx_pack_kernel(const float* __restrict__ w1, const float* __re
                 if (c < C && hid < HID) v[j] = w2[(size_t)c * HID + hid];
             }
         }
-        bf16x8 hi, lo;
+        h16x8 hi, lo;
         mx_split8(v, hi, lo);
         o = __builtin_bit_cast(u32x4, lo_part ? lo : hi);
     } else if (u < (W1B + W2B) / 16 + 8) {
@@ -199,7 +199,7 @@ __device__ __forceinline__ void mlpx_pass(const float* __restrict__ x, const uns
                 }
         }
     }
-    bf16x8 Xh[KS1][NT], Xl[KS1][NT];
+    h16x8 Xh[KS1][NT], Xl[KS1][NT];
 #pragma unroll
     for (int ks = 0; ks < KS1; ++ks)
 #pragma unroll
@@ -230,17 +230,17 @@ __device__ __forceinline__ void mlpx_pass(const float* __restrict__ x, const uns
             for (int t = 0; t < NT; ++t) H[tile][t] = *reinterpret_cast<const f32x4*>(PB + 16 * tile + 4 * kq);
 #pragma unroll
             for (int ks = 0; ks < KS1; ++ks) {
-                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(P1 + ((tile * KS1 + ks) * 2) * 1024);
-                const bf16x8 al = *reinterpret_cast<const bf16x8*>(P1 + ((tile * KS1 + ks) * 2 + 1) * 1024);
+                const h16x8 ah = *reinterpret_cast<const h16x8*>(P1 + ((tile * KS1 + ks) * 2) * 1024);
+                const h16x8 al = *reinterpret_cast<const h16x8*>(P1 + ((tile * KS1 + ks) * 2 + 1) * 1024);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    H[tile][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, Xh[ks][t], H[tile][t], 0, 0, 0);
-                    H[tile][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, Xl[ks][t], H[tile][t], 0, 0, 0);
-                    H[tile][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, Xh[ks][t], H[tile][t], 0, 0, 0);
+                    H[tile][t] = OTP_X3_MFMA(al, Xh[ks][t], H[tile][t], 0, 0, 0);
+                    H[tile][t] = OTP_X3_MFMA(ah, Xl[ks][t], H[tile][t], 0, 0, 0);
+                    H[tile][t] = OTP_X3_MFMA(ah, Xh[ks][t], H[tile][t], 0, 0, 0);
                 }
             }
         }
-        bf16x8 Gh[NT], Gl[NT];
+        h16x8 Gh[NT], Gl[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const f32x2 g0 = mx_gelu2(f32x2{H[0][t][0], H[0][t][1]}), g1 = mx_gelu2(f32x2{H[0][t][2], H[0][t][3]});
@@ -251,13 +251,13 @@ __device__ __forceinline__ void mlpx_pass(const float* __restrict__ x, const uns
         // phase 2: Y += W2[:, 32 hb ..] . hidden tiles (k-slot (kq, j) = hidden channel 4 kq + j / 16 + 4 kq + j - 4)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(P2 + (mt * 2) * 1024);
-            const bf16x8 al = *reinterpret_cast<const bf16x8*>(P2 + (mt * 2 + 1) * 1024);
+            const h16x8 ah = *reinterpret_cast<const h16x8*>(P2 + (mt * 2) * 1024);
+            const h16x8 al = *reinterpret_cast<const h16x8*>(P2 + (mt * 2 + 1) * 1024);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                Y[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, Gh[t], Y[mt][t], 0, 0, 0);
-                Y[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, Gl[t], Y[mt][t], 0, 0, 0);
-                Y[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, Gh[t], Y[mt][t], 0, 0, 0);
+                Y[mt][t] = OTP_X3_MFMA(al, Gh[t], Y[mt][t], 0, 0, 0);
+                Y[mt][t] = OTP_X3_MFMA(ah, Gl[t], Y[mt][t], 0, 0, 0);
+                Y[mt][t] = OTP_X3_MFMA(ah, Gh[t], Y[mt][t], 0, 0, 0);
             }
         }
         __syncthreads();                              // every wave is done with this block; the next one has landed

@@ -13,25 +13,25 @@
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef otp_x3x8 h16x8;              // 8 operand pieces of the split products (common.h: IEEE half since round 4)
+typedef otp_x3x2 h16x2;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ void px_split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+__device__ __forceinline__ void px_split8(const float (&v)[8], h16x8& hi, h16x8& lo) {
     uint32_t h[4], l[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const f32x2 a = {v[2 * i], v[2 * i + 1]};
-        const uint32_t hb = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, bf16x2));
-        const f32x2 af = {__builtin_bit_cast(float, hb << 16), __builtin_bit_cast(float, hb & 0xffff0000u)};
+        const uint32_t hb = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, h16x2));
+        const f32x2 af = otp_x3_widen(hb);
         h[i] = hb;
-        l[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(a - af, bf16x2));
+        l[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(a - af, h16x2));
     }
-    hi = __builtin_bit_cast(bf16x8, (u32x4){h[0], h[1], h[2], h[3]});
-    lo = __builtin_bit_cast(bf16x8, (u32x4){l[0], l[1], l[2], l[3]});
+    hi = __builtin_bit_cast(h16x8, (u32x4){h[0], h[1], h[2], h[3]});
+    lo = __builtin_bit_cast(h16x8, (u32x4){l[0], l[1], l[2], l[3]});
 }
 
 constexpr int px_ks(int CIN) { return CIN / 32; }
@@ -60,7 +60,7 @@ __global__ void pointx_pack_kernel(const float* __restrict__ w, const float* __r
             const int c = 32 * ks + 8 * kq + j;
             v[j] = (row < Cout && c < Cin) ? w[(size_t)row * Cin + c] : 0.f;
         }
-        bf16x8 hi, lo;
+        h16x8 hi, lo;
         px_split8(v, hi, lo);
         reinterpret_cast<u32x4*>(packed)[idx] = __builtin_bit_cast(u32x4, (f2 & 1) ? lo : hi);
     } else if (idx < nblk * units + 2 * PX_MAX_COUT / 4) {                  // [scale 256][shift 256] floats, by channel
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256, CIN <= 128 ? 3 : 2) void pointx_kernel(PxArgs 
     if (tid < 2 * PX_MAX_COUT / 4)
         reinterpret_cast<f32x4*>(ss)[tid] = reinterpret_cast<const f32x4*>(A.packed + (size_t)A.nblk * BLKB)[tid];
     const float* __restrict__ x = A.x + ((size_t)b * A.x_ctot + A.x_coff) * T + (valid ? tok : T - 2);
-    bf16x8 Xh[KS][2], Xl[KS][2];
+    h16x8 Xh[KS][2], Xl[KS][2];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         float v0[8], v1[8];
@@ -161,14 +161,14 @@ __global__ __launch_bounds__(256, CIN <= 128 ? 3 : 2) void pointx_kernel(PxArgs 
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(P + ((m * KS + ks) * 2) * 1024 + lane * 16);
-                const bf16x8 al = *reinterpret_cast<const bf16x8*>(P + ((m * KS + ks) * 2 + 1) * 1024 + lane * 16);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, Xh[ks][0], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, Xh[ks][1], acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, Xl[ks][0], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, Xl[ks][1], acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, Xh[ks][0], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, Xh[ks][1], acc1, 0, 0, 0);
+                const h16x8 ah = *reinterpret_cast<const h16x8*>(P + ((m * KS + ks) * 2) * 1024 + lane * 16);
+                const h16x8 al = *reinterpret_cast<const h16x8*>(P + ((m * KS + ks) * 2 + 1) * 1024 + lane * 16);
+                acc0 = OTP_X3_MFMA(al, Xh[ks][0], acc0, 0, 0, 0);
+                acc1 = OTP_X3_MFMA(al, Xh[ks][1], acc1, 0, 0, 0);
+                acc0 = OTP_X3_MFMA(ah, Xl[ks][0], acc0, 0, 0, 0);
+                acc1 = OTP_X3_MFMA(ah, Xl[ks][1], acc1, 0, 0, 0);
+                acc0 = OTP_X3_MFMA(ah, Xh[ks][0], acc0, 0, 0, 0);
+                acc1 = OTP_X3_MFMA(ah, Xh[ks][1], acc1, 0, 0, 0);
             }
             acc[m][0] = acc0;
             acc[m][1] = acc1;
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256, CIN <= 128 ? 3 : 2) void pointx_s8_kernel(PxAr
     if (tid < 2 * PX_MAX_COUT / 4)
         reinterpret_cast<f32x4*>(ss)[tid] = reinterpret_cast<const f32x4*>(A.packed + (size_t)A.nblk * BLKB)[tid];
     const float* __restrict__ x = A.x + ((size_t)b * A.x_ctot + A.x_coff) * T + (valid ? tok : T - 2);
-    bf16x8 Xh[KS][2], Xl[KS][2];
+    h16x8 Xh[KS][2], Xl[KS][2];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         float v0[8], v1[8];
@@ -242,14 +242,14 @@ __global__ __launch_bounds__(256, CIN <= 128 ? 3 : 2) void pointx_s8_kernel(PxAr
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(P + ((m * KS + ks) * 2) * 1024 + lane * 16);
-                const bf16x8 al = *reinterpret_cast<const bf16x8*>(P + ((m * KS + ks) * 2 + 1) * 1024 + lane * 16);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, Xh[ks][0], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, Xh[ks][1], acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, Xl[ks][0], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, Xl[ks][1], acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, Xh[ks][0], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, Xh[ks][1], acc1, 0, 0, 0);
+                const h16x8 ah = *reinterpret_cast<const h16x8*>(P + ((m * KS + ks) * 2) * 1024 + lane * 16);
+                const h16x8 al = *reinterpret_cast<const h16x8*>(P + ((m * KS + ks) * 2 + 1) * 1024 + lane * 16);
+                acc0 = OTP_X3_MFMA(al, Xh[ks][0], acc0, 0, 0, 0);
+                acc1 = OTP_X3_MFMA(al, Xh[ks][1], acc1, 0, 0, 0);
+                acc0 = OTP_X3_MFMA(ah, Xl[ks][0], acc0, 0, 0, 0);
+                acc1 = OTP_X3_MFMA(ah, Xl[ks][1], acc1, 0, 0, 0);
+                acc0 = OTP_X3_MFMA(ah, Xh[ks][0], acc0, 0, 0, 0);
+                acc1 = OTP_X3_MFMA(ah, Xh[ks][1], acc1, 0, 0, 0);
             }
             acc[m][0] = acc0;
             acc[m][1] = acc1;
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256, CIN <= 128 ? 3 : 2) void pointx_s8_kernel(PxAr
                     v[i] = fmaxf(acc[m][h][i] * sc0[i] + sh0[i], lo_clamp);
                     v[4 + i] = fmaxf(acc[m + 1][h][i] * sc1[i] + sh1[i], lo_clamp);
                 }
-                bf16x8 hi, lo;
+                h16x8 hi, lo;
                 px_split8(v, hi, lo);
                 const int o = live ? ((g * 2) * T + tok + h) * 16 : -16;
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hi), ro, o, 0, 0);

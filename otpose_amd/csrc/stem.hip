@@ -9,24 +9,24 @@
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef otp_x3x8 h16x8;              // 8 operand pieces of the split products (common.h: IEEE half since round 4)
+typedef otp_x3x2 h16x2;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void st_split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+__device__ __forceinline__ void st_split8(const float (&v)[8], h16x8& hi, h16x8& lo) {
     uint32_t h[4], l[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const f32x2 a = {v[2 * i], v[2 * i + 1]};
-        const uint32_t hb = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, bf16x2));
-        const f32x2 af = {__builtin_bit_cast(float, hb << 16), __builtin_bit_cast(float, hb & 0xffff0000u)};
+        const uint32_t hb = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, h16x2));
+        const f32x2 af = otp_x3_widen(hb);
         h[i] = hb;
-        l[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(a - af, bf16x2));
+        l[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(a - af, h16x2));
     }
-    hi = __builtin_bit_cast(bf16x8, (u32x4){h[0], h[1], h[2], h[3]});
-    lo = __builtin_bit_cast(bf16x8, (u32x4){l[0], l[1], l[2], l[3]});
+    hi = __builtin_bit_cast(h16x8, (u32x4){h[0], h[1], h[2], h[3]});
+    lo = __builtin_bit_cast(h16x8, (u32x4){l[0], l[1], l[2], l[3]});
 }
 
 constexpr int ST_CT = 4;          // 16-channel output tiles (Cout = 64)
@@ -37,26 +37,41 @@ constexpr int ST_CT = 4;          // 16-channel output tiles (Cout = 64)
 #endif
 constexpr int ST_ROW = 68;        // floats per channel row of a wave's LDS slab
 
-// packed weights: [cout tile][hi | lo][64 lanes] 16-byte B fragments (lane (channel i16, kq): k slots 8 kq .. 8 kq + 7), then shift[64]
+// packed weights: [cout tile][hi | lo][64 lanes] 16-byte B fragments (lane (channel i16, kq): k slots 8 kq .. 8 kq + 7), then
+// shift[64] * 2^k, then {2^-k, 0, 0, 0}.  The weights are stored times the power of two 2^k that puts the largest |w * scale| in
+// [2^13, 2^14), so both half pieces of every weight are normal numbers (otp_conv_desc.out_scale in include/otpose_hip.h is the
+// same device for the descriptor-driven kernels); every workgroup of the pack finds the maximum itself (27 Cout values).
 __global__ void stem_pack_kernel(const float* __restrict__ w, const float* __restrict__ scale, const float* __restrict__ shift,
                                  u32x4* __restrict__ packed, int Cout) {
+    __shared__ float wmax[4];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < Cout * 27; i += blockDim.x) m = fmaxf(m, fabsf(w[i] * (scale ? scale[i / 27] : 1.f)));
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    int e = 0;
+    (void)frexpf(m, &e);                                                        // m = f 2^e, f in [0.5, 1)
+    const int kx = (m > 0.f && m < 3e38f) ? min(40, max(-40, 14 - e)) : 0;
+    const float pre = ldexpf(1.f, kx), post = ldexpf(1.f, -kx);
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx == ST_CT * 2 * 64 + 16) packed[idx] = (u32x4){__builtin_bit_cast(uint32_t, post), 0u, 0u, 0u};
     if (idx < ST_CT * 2 * 64) {
         const int t = idx >> 7, part = (idx >> 6) & 1, lane = idx & 63, co = 16 * t + (lane & 15), kq = lane >> 4;
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = 8 * kq + j, tap = k / 3, c = k - tap * 3;               // reference weight layout (Cout, 3, 3, 3): [co][c][dy][dx]
-            v[j] = (k < 27 && co < Cout) ? w[(co * 3 + c) * 9 + tap] * (scale ? scale[co] : 1.f) : 0.f;
+            v[j] = (k < 27 && co < Cout) ? w[(co * 3 + c) * 9 + tap] * (scale ? scale[co] : 1.f) * pre : 0.f;
         }
-        bf16x8 hi, lo;
+        h16x8 hi, lo;
         st_split8(v, hi, lo);
         packed[idx] = __builtin_bit_cast(u32x4, part ? lo : hi);
     } else if (idx < ST_CT * 2 * 64 + 16) {
         const int q = idx - ST_CT * 2 * 64;
         float v[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = (4 * q + i < Cout && shift) ? shift[4 * q + i] : 0.f;
+        for (int i = 0; i < 4; ++i) v[i] = (4 * q + i < Cout && shift) ? shift[4 * q + i] * pre : 0.f;
         packed[idx] = (u32x4){__builtin_bit_cast(uint32_t, v[0]), __builtin_bit_cast(uint32_t, v[1]), __builtin_bit_cast(uint32_t, v[2]),
                               __builtin_bit_cast(uint32_t, v[3])};
     }
@@ -81,16 +96,17 @@ __global__ __launch_bounds__(256) void stem_kernel(StArgs A) {
     __shared__ __attribute__((aligned(16))) float slabs[4 * 64 * ST_ROW];
     float* slab = slabs + wave * 64 * ST_ROW;
 #endif
-    bf16x8 Wh[ST_CT], Wl[ST_CT];
+    h16x8 Wh[ST_CT], Wl[ST_CT];
 #pragma unroll
     for (int t = 0; t < ST_CT; ++t) {
-        Wh[t] = __builtin_bit_cast(bf16x8, A.packed[(t * 2) * 64 + lane]);
-        Wl[t] = __builtin_bit_cast(bf16x8, A.packed[(t * 2 + 1) * 64 + lane]);
+        Wh[t] = __builtin_bit_cast(h16x8, A.packed[(t * 2) * 64 + lane]);
+        Wl[t] = __builtin_bit_cast(h16x8, A.packed[(t * 2 + 1) * 64 + lane]);
     }
     const float shv[ST_CT] = {reinterpret_cast<const float*>(A.packed + ST_CT * 2 * 64)[i16],
                               reinterpret_cast<const float*>(A.packed + ST_CT * 2 * 64)[16 + i16],
                               reinterpret_cast<const float*>(A.packed + ST_CT * 2 * 64)[32 + i16],
                               reinterpret_cast<const float*>(A.packed + ST_CT * 2 * 64)[48 + i16]};
+    const float post = reinterpret_cast<const float*>(A.packed + ST_CT * 2 * 64 + 16)[0];   // 2^-k of the packed weights
     const size_t clip = (size_t)3 * A.F * A.H * A.W;                           // floats of one clip
     const otp_rsrc rin = make_rsrc(A.in, (size_t)A.B * clip * sizeof(float));
     const long P0 = ((long)blockIdx.x * 4 + wave) * (16 * NPT);              // first output pixel of this wave (all frames, row-major)
@@ -114,7 +130,7 @@ __global__ __launch_bounds__(256) void stem_kernel(StArgs A) {
             const bool ok = pv && k < 27 && iy >= 0 && iy < A.H && ix >= 0 && ix < A.W;
             v[j] = bload(rin, ok ? (base + (c * A.H + iy) * A.W + ix) * 4 : -16, 0);
         }
-        bf16x8 ah, al;
+        h16x8 ah, al;
         st_split8(v, ah, al);
         // ---- 3 split products per channel tile; D row = pixel, column = channel: register r of lane (channel i16, kq) is pixel 4 kq + r
         const long q0 = P0 + 16 * p + 4 * kq;                                    // this lane's 4 consecutive output pixels
@@ -125,9 +141,10 @@ __global__ __launch_bounds__(256) void stem_kernel(StArgs A) {
 #pragma unroll
         for (int t = 0; t < ST_CT; ++t) {
             f32x4 acc = {shv[t], shv[t], shv[t], shv[t]};
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, Wh[t], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, Wl[t], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, Wh[t], acc, 0, 0, 0);
+            acc = OTP_X3_MFMA(al, Wh[t], acc, 0, 0, 0);
+            acc = OTP_X3_MFMA(ah, Wl[t], acc, 0, 0, 0);
+            acc = OTP_X3_MFMA(ah, Wh[t], acc, 0, 0, 0);
+            acc = acc * post;
             const int co = 16 * t + i16;
 #if ST_LDS
             // through the wave's LDS slab [64 channels][64 + 4 pixels]: the stores below then cover 256 contiguous bytes per channel
@@ -172,12 +189,12 @@ extern "C" int otp_stem_conv_x3_supported(int B, int F, int H, int W, int Cout) 
     return 1;
 }
 
-extern "C" size_t otp_stem_conv_x3_weight_bytes(int Cout) { return (Cout <= 0 || Cout > 16 * ST_CT) ? 0 : (ST_CT * 2 * 64 + 16) * 16; }
+extern "C" size_t otp_stem_conv_x3_weight_bytes(int Cout) { return (Cout <= 0 || Cout > 16 * ST_CT) ? 0 : (ST_CT * 2 * 64 + 17) * 16; }
 
 extern "C" int otp_stem_conv_x3_pack(const void* w, const void* scale, const void* shift, void* packed, int Cout, void* stream) {
     if (!w || !packed) return OTP_ERR_BAD_ARG;
     if (!otp_stem_conv_x3_weight_bytes(Cout)) return OTP_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(stem_pack_kernel, dim3(otp_ceil_div(ST_CT * 2 * 64 + 16, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL(stem_pack_kernel, dim3(otp_ceil_div(ST_CT * 2 * 64 + 17, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        static_cast<const float*>(w), static_cast<const float*>(scale), static_cast<const float*>(shift),
                        static_cast<u32x4*>(packed), Cout);
     return otp_launch_status();

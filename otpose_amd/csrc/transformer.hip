@@ -328,8 +328,8 @@ __global__ __launch_bounds__(256) void attn_scores_kernel(const float* __restric
 // rows of a fragment read hit 16 distinct bank groups); a fragment is one ds_read_b128 (8 consecutive tokens of a row), a
 // 16 x 16 score tile takes 3 MFMAs per 32 tokens instead of 8 f32 ones at twice the cycles.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 sx_bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 sx_bf16x2 __attribute__((ext_vector_type(2)));
+typedef otp_x3x8 sx_h16x8;
+typedef otp_x3x2 sx_h16x2;
 constexpr int SX_PITCH = ATT_TC * 2 + 16;          // bytes per LDS row
 
 template <int NB>
@@ -377,10 +377,10 @@ __global__ __launch_bounds__(256) void attn_scores_x3_kernel(const float* __rest
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const f32x2 a = {v[2 * i], v[2 * i + 1]};
-            const uint32_t hb = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, sx_bf16x2));
-            const f32x2 af = {__builtin_bit_cast(float, hb << 16), __builtin_bit_cast(float, hb & 0xffff0000u)};
+            const uint32_t hb = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, sx_h16x2));
+            const f32x2 af = otp_x3_widen(hb);
             h[i] = hb;
-            l[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(a - af, sx_bf16x2));
+            l[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(a - af, sx_h16x2));
         }
         hi = (unsigned long long)h[0] | ((unsigned long long)h[1] << 32);
         lo = (unsigned long long)l[0] | ((unsigned long long)l[1] << 32);
@@ -415,13 +415,13 @@ __global__ __launch_bounds__(256) void attn_scores_x3_kernel(const float* __rest
                 const int qo = (ib * 16 + r16) * SX_PITCH + kk * 16, ko = (jb * 16 + r16) * SX_PITCH + kk * 16;
 #pragma unroll
                 for (int ks = 0; ks < ATT_TC / 32; ++ks) {
-                    const sx_bf16x8 a_h = *reinterpret_cast<const sx_bf16x8*>(qh + qo + ks * 64);
-                    const sx_bf16x8 a_l = *reinterpret_cast<const sx_bf16x8*>(ql + qo + ks * 64);
-                    const sx_bf16x8 b_h = *reinterpret_cast<const sx_bf16x8*>(kh + ko + ks * 64);
-                    const sx_bf16x8 b_l = *reinterpret_cast<const sx_bf16x8*>(kl_ + ko + ks * 64);
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_l, b_h, acc[i], 0, 0, 0);
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h, b_l, acc[i], 0, 0, 0);
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h, b_h, acc[i], 0, 0, 0);
+                    const sx_h16x8 a_h = *reinterpret_cast<const sx_h16x8*>(qh + qo + ks * 64);
+                    const sx_h16x8 a_l = *reinterpret_cast<const sx_h16x8*>(ql + qo + ks * 64);
+                    const sx_h16x8 b_h = *reinterpret_cast<const sx_h16x8*>(kh + ko + ks * 64);
+                    const sx_h16x8 b_l = *reinterpret_cast<const sx_h16x8*>(kl_ + ko + ks * 64);
+                    acc[i] = OTP_X3_MFMA(a_l, b_h, acc[i], 0, 0, 0);
+                    acc[i] = OTP_X3_MFMA(a_h, b_l, acc[i], 0, 0, 0);
+                    acc[i] = OTP_X3_MFMA(a_h, b_h, acc[i], 0, 0, 0);
                 }
             }
         }
@@ -607,10 +607,10 @@ __global__ __launch_bounds__(PVX_TH, 2) void attn_pv_x3_kernel(const float* __re
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const f32x2 a = {x[2 * i], x[2 * i + 1]};
-            const uint32_t hb = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, sx_bf16x2));
-            const f32x2 af = {__builtin_bit_cast(float, hb << 16), __builtin_bit_cast(float, hb & 0xffff0000u)};
+            const uint32_t hb = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, sx_h16x2));
+            const f32x2 af = otp_x3_widen(hb);
             h[i] = hb;
-            l[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(a - af, sx_bf16x2));
+            l[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(a - af, sx_h16x2));
         }
         hi = (unsigned long long)h[0] | ((unsigned long long)h[1] << 32);
         lo = (unsigned long long)l[0] | ((unsigned long long)l[1] << 32);
@@ -685,23 +685,23 @@ __global__ __launch_bounds__(PVX_TH, 2) void attn_pv_x3_kernel(const float* __re
     for (int ks = 0; ks < KS; ++ks) {
         const int kg = 4 * ks + kk;                                // 8-wide j group of this lane
         const bool kv = kg < G;
-        sx_bf16x8 ah[2], al[2];
+        sx_h16x8 ah[2], al[2];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             const unsigned char* a = kv ? vrec + ((wave * 2 + mt) * 16 + r16) * REC + kg * 16 : zrec;
-            ah[mt] = *reinterpret_cast<const sx_bf16x8*>(a);
-            al[mt] = *reinterpret_cast<const sx_bf16x8*>(kv ? a + HSP * 2 : zrec);
+            ah[mt] = *reinterpret_cast<const sx_h16x8*>(a);
+            al[mt] = *reinterpret_cast<const sx_h16x8*>(kv ? a + HSP * 2 : zrec);
         }
 #pragma unroll
         for (int nt = 0; nt < NB; ++nt) {
             const unsigned char* b = kv ? prec + (nt * 16 + r16) * REC + kg * 16 : zrec;
-            const sx_bf16x8 b_h = *reinterpret_cast<const sx_bf16x8*>(b);
-            const sx_bf16x8 b_l = *reinterpret_cast<const sx_bf16x8*>(kv ? b + HSP * 2 : zrec);
+            const sx_h16x8 b_h = *reinterpret_cast<const sx_h16x8*>(b);
+            const sx_h16x8 b_l = *reinterpret_cast<const sx_h16x8*>(kv ? b + HSP * 2 : zrec);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], b_h, acc[mt][nt], 0, 0, 0);
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], b_l, acc[mt][nt], 0, 0, 0);
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], b_h, acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = OTP_X3_MFMA(al[mt], b_h, acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = OTP_X3_MFMA(ah[mt], b_l, acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = OTP_X3_MFMA(ah[mt], b_h, acc[mt][nt], 0, 0, 0);
             }
         }
     }

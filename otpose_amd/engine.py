@@ -75,6 +75,10 @@ class InferenceEngine:
         # emitted on side HIP streams: inside the captured graph they become parallel branches, so the small-map launches
         # (640-960 workgroups on 512 resident slots) fill each other's tails
         self.multi_stream = os.environ.get("OTPOSE_STREAMS", "1") != "0"
+        # the last OTPOSE_F32_TAIL HighResolutionModules of stage 4 and the backbone's final 1x1 conv on the exact-fp32 MFMA kernels
+        # (Winograd / direct) instead of split products: the layers whose rounding reaches `rough` un-attenuated
+        self.f32_tail = int(os.environ.get("OTPOSE_F32_TAIL", "0")) if self.use_x3 else 0
+        self._exact = False
         self._sid = 0
         # process-wide pool (see hip.side_streams); stream_set > 0: the streams of another sub-batch of a PipelinedEngine
         self._side = hip.side_streams(device, 3, 4 * stream_set) if self.multi_stream else []
@@ -111,6 +115,7 @@ class InferenceEngine:
         self.use_qkv_front = env("OTPOSE_QKV_FRONT", "1") != "0"
         self.use_pointx = self.use_x3 and env("OTPOSE_POINTX", "1") != "0"
         self.multi_stream = bool(multi_stream)
+        self.f32_tail, self._exact = 0, False
         self._sid = 0
         self._side = hip.side_streams(device, 3, 0) if self.multi_stream else []
         self.inp = None
@@ -243,7 +248,7 @@ class InferenceEngine:
                 hip.check(L.otp_conv3x3_small(*sargs, self._stream), "otp_conv3x3_small")
             self._emit(run_small)
             return out
-        if (self.use_pointx and in2 is None and (kh, kw) == (1, 1) and stride == 1 and pad == 0 and res_up <= 1 and not frame_split
+        if (self.use_pointx and not self._exact and in2 is None and (kh, kw) == (1, 1) and stride == 1 and pad == 0 and res_up <= 1 and not frame_split
                 and act in (ACT_NONE, ACT_RELU) and inp.C == cin_w
                 and (cin_w in (64, 128, 256) or (os.environ.get("OTPOSE_POINTX_FUSE", "1") != "0" and cin_w % 16 == 0)
                      or os.environ.get("OTPOSE_POINTX_ANY", "0") == "1")       # (opt-in: the RSB heads' and the final 1x1 convs too -
@@ -261,10 +266,12 @@ class InferenceEngine:
                 hip.check(L.otp_pointwise_x3(*pargs, self._stream), "otp_pointwise_x3")
             self._emit(run_px)
             return out
-        if self.use_x3 and in2 is None and (kh, kw) in ((3, 3), (1, 1)) and ops.x3_supported(d):
+        if self.use_x3 and not self._exact and in2 is None and (kh, kw) in ((3, 3), (1, 1)) and ops.x3_supported(d):
             # 3x3 / stride 1 with Cin % 16 == 0: split-bf16 (bf16x3) products on the bf16 matrix cores, fp32 storage and
             # accumulation (csrc/convx.hip); the per-channel scale is folded into the packed weights
-            xp = ops.pack_x3_weight(w, sc, stride)
+            e = ops.x3_weight_exponent(w, sc)         # weights stored times 2^e, the sum multiplied by 2^-e (otp_conv_desc.out_scale)
+            d.out_scale = 2.0 ** -e
+            xp = ops.pack_x3_weight(w, sc, stride, e)
             self._keep.append(xp)
             xargs = (hip.ptr(inp.t), hip.ptr(xp), hip.ptr(sh), hip.ptr(res.t if res is not None else None), hip.ptr(out.t), d)
 
@@ -337,7 +344,7 @@ class InferenceEngine:
         S8 and C4 images the next module's branch reads (csrc/convs.hip, otp_s8_upsample_add); the NCHW tensor ``tgt`` is
         written only if some other consumer asks for it before the first launch.  Returns False when the row is not eligible."""
         n_, c_, hh, wh = tgt.t.shape
-        if not self.use_s8 or tgt.coff != 0 or tgt.C != c_ or c_ % 16 or wh % 4 or (hh * wh) % 4:
+        if not self.use_s8 or self._exact or tgt.coff != 0 or tgt.C != c_ or c_ % 16 or wh % 4 or (hh * wh) % 4:
             return False
         if not ops.s8_conv_supported(ops.s8_conv_desc(n_, c_, c_, hh, wh, ACT_RELU)):
             return False
@@ -384,7 +391,7 @@ class InferenceEngine:
         transition layer's new branch, :213-229) on S8 records (csrc/convs2.hip): every intermediate exists only as its S8 image,
         the last layer writes act(conv + shift (+ res)) into the fp32 NCHW tensor ``out``.  ``layers`` = [(conv, bn, relu)].
         Returns the output view, or None (nothing emitted) when a layer is not of that shape."""
-        if not (self.use_s8 and os.environ.get("OTPOSE_S8_STRIDE2", "1") != "0"):
+        if not (self.use_s8 and not self._exact and os.environ.get("OTPOSE_S8_STRIDE2", "1") != "0"):
             return None
         n, c, h, w = x.t.shape
         if x.coff != 0 or x.C != c:
@@ -417,7 +424,7 @@ class InferenceEngine:
         for li, ((cv, bn, relu), d) in enumerate(zip(layers, descs)):
             last = li == len(layers) - 1
             sc, sh = self._bn_fold(bn)
-            wp = ops.pack_s8_weight(self.dev_param(cv.weight), sc)
+            wp = self._pack_s8(cv, sc, d)
             self._keep += [wp, d]
             if last:
                 self.call(L.otp_conv3x3_s2_s8, "otp_conv3x3_s2_s8", hip.ptr(cur), hip.ptr(wp), hip.ptr(sh),
@@ -428,6 +435,14 @@ class InferenceEngine:
                 cur = nxt
             hh, ww, cin = hh // 2, ww // 2, cv.out_channels
         return out
+
+    def _pack_s8(self, conv, sc, desc):
+        """Packed split-product weights of a 3x3 conv for csrc/convs.hip / convs2.hip, stored times the layer's power of two
+        (ops.x3_weight_exponent) with the inverse in ``desc.out_scale``."""
+        w = self.dev_param(conv.weight)
+        e = ops.x3_weight_exponent(w, sc)
+        desc.out_scale = 2.0 ** -e
+        return ops.pack_s8_weight(w, sc, e)
 
     def _bn_fold(self, bn):
         g, b = self.dev_param(bn.weight), self.dev_param(bn.bias)
@@ -444,7 +459,7 @@ class InferenceEngine:
         C4 + S8; the last conv2 writes the NCHW tensor the fuse layer reads.  Returns None when the branch is not of that
         shape (the caller then emits the blocks one convolution at a time)."""
         n, c, h, w = x.t.shape
-        if x.coff != 0 or x.C != c:
+        if x.coff != 0 or x.C != c or self._exact:
             return None
         for blk in blocks:
             convs = (getattr(blk, "conv1", None), getattr(blk, "conv2", None))
@@ -465,18 +480,17 @@ class InferenceEngine:
             last = b == len(blocks) - 1
             sc1, sh1 = self._bn_fold(blk.bn1)
             sc2, sh2 = self._bn_fold(blk.bn2)
-            w1 = ops.pack_s8_weight(self.dev_param(blk.conv1.weight), sc1)
-            w2 = ops.pack_s8_weight(self.dev_param(blk.conv2.weight), sc2)
-            self._keep += [w1, w2]
             y8 = new_img()
             d1 = ops.s8_conv_desc(n, c, c, h, w, ACT_RELU)
-            self._keep.append(d1)
+            w1 = self._pack_s8(blk.conv1, sc1, d1)
+            self._keep += [w1, d1]
             self.call(L.otp_conv3x3_s8, "otp_conv3x3_s8", hip.ptr(xs8), hip.ptr(w1), hip.ptr(sh1), None, None, ops.S8_F32_C4,
                       hip.ptr(y8), d1)
             if last:
                 out = View(self.new(n, c, h, w))
                 d2 = ops.s8_conv_desc(n, c, c, h, w, ACT_RELU, out)
-                self._keep.append(d2)
+                w2 = self._pack_s8(blk.conv2, sc2, d2)
+                self._keep += [w2, d2]
                 # a stride-2 consumer in the fuse layer (csrc/convs2.hip) reads the S8 image: written here, next to the NCHW tensor
                 o8 = new_img() if want_s8 else None
                 if o8 is not None:
@@ -486,7 +500,8 @@ class InferenceEngine:
             else:
                 oc4, o8 = new_img(), new_img()
                 d2 = ops.s8_conv_desc(n, c, c, h, w, ACT_RELU)
-                self._keep.append(d2)
+                w2 = self._pack_s8(blk.conv2, sc2, d2)
+                self._keep += [w2, d2]
                 self.call(L.otp_conv3x3_s8, "otp_conv3x3_s8", hip.ptr(y8), hip.ptr(w2), hip.ptr(sh2), hip.ptr(xc4), hip.ptr(oc4),
                           ops.S8_F32_C4, hip.ptr(o8), d2)
                 xs8, xc4 = o8, oc4
@@ -516,7 +531,7 @@ class InferenceEngine:
         sc1, sh1 = self._bn_fold(bn1)
         sc2, sh2 = self._bn_fold(bn2)
         pk = ops.pack_pointwise_x3_s8(self.dev_param(conv1.weight), sc1, sh1)
-        w2 = ops.pack_s8_weight(self.dev_param(conv2.weight), sc2)
+        w2 = self._pack_s8(conv2, sc2, d2)
         y8 = self.new(n * c1o * h * w)
         self._keep += [pk, w2, d2]
         self.call(L.otp_pointwise_x3_s8, "otp_pointwise_x3_s8", hip.ptr(x.t), hip.ptr(pk), hip.ptr(y8), n, c1i, c1o, h * w, x.ctot,
@@ -553,7 +568,7 @@ class InferenceEngine:
         for i in range(n):
             self.on_stream(i)                                     # branch i is independent of the others until the fuse
             # branch i feeds the stride-2 chains of the fuse rows below it
-            down = i < len(mod.fuse_layers) - 1 and os.environ.get("OTPOSE_S8_STRIDE2", "1") != "0"
+            down = i < len(mod.fuse_layers) - 1 and not self._exact and os.environ.get("OTPOSE_S8_STRIDE2", "1") != "0"
             y = self.branch_s8(list(mod.branches[i]), xs[i], want_s8=down) if self.use_s8 else None
             if y is not None:
                 xs[i] = y
@@ -565,7 +580,7 @@ class InferenceEngine:
         if n == 1:
             return xs
         outs = []
-        if self.use_s8 and os.environ.get("OTPOSE_S8_STRIDE2", "1") != "0":
+        if self.use_s8 and not self._exact and os.environ.get("OTPOSE_S8_STRIDE2", "1") != "0":
             for j in range(min(n, len(mod.fuse_layers) - 1)):     # S8 images the rows below read, made before the rows fork
                 self.s8_image(xs[j])
         self.fork(range(1, len(mod.fuse_layers)))
@@ -723,12 +738,16 @@ class InferenceEngine:
                 nxt = mods[mi + 1] if mi + 1 < len(mods) else None
                 # the next module's branch i continues on the stream of this module's row i (same count of rows and branches)
                 cont = chain and nxt is not None and len(mod.fuse_layers) == nxt.num_branches and mod.num_branches > 1
+                self._exact = s == 4 and mi >= len(mods) - self.f32_tail
                 ys = self.hr_module(mod, ys, fork_in=not (mi > 0 and prev_cont), join_out=not cont) if mi > 0 else \
                     self.hr_module(mod, ys, fork_in=True, join_out=not cont)
                 prev_cont = cont
         fl = net.final_layer
         rough = View(self.new(self.F * self.B, self.J, self.h, self.w))
-        return self.conv(ys[0], fl.weight, rough, 1, fl.padding[0], 1, bias=fl.bias)
+        self._exact = self.f32_tail > 0
+        out = self.conv(ys[0], fl.weight, rough, 1, fl.padding[0], 1, bias=fl.bias)
+        self._exact = False
+        return out
 
     # ---- ConvTransformer (reference model/ConvVideoTransformer.py:123-184, model/blocks.py:264-280,400-453) ----
     def v3(self, t3):

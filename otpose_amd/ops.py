@@ -10,6 +10,8 @@ callers that bind the native module directly.
 from __future__ import annotations
 
 import ctypes
+import math
+import os
 
 import torch
 from torch.autograd import Function
@@ -354,9 +356,40 @@ def conv3x3_small(x, weight, scale=None, shift=None, act=ACT_NONE, in2=None):
     return out
 
 
-def pack_x3_weight(weight, scale=None, stride=1):
-    """(Cout, Cin, k, k) fp32, k = 3 or 1 (times scale[cout]) -> bf16 hi / lo MFMA fragments for :func:`conv2d_x3_launch` (the
-    chunking depends on k and the stride)."""
+def x3_weight_exponent(weight, scale=None) -> int:
+    """The power of two k a layer's split-product weights are stored with: max |weight * scale| * 2^k lands in [2^13, 2^14).
+
+    A weight is carried as two IEEE-half pieces hi + lo (csrc/common.h); `lo` is at most 2^-11 |w|, so for BatchNorm-folded
+    weights of magnitude 1e-2 it is a SUBNORMAL half (spacing 2^-24) and the pair holds the weight to 2^-25 absolute - 17
+    significand bits - and that error is the same for every pixel of every frame, so it does not average out over a layer's sum
+    the way activation rounding does: it was the whole heat-map error of the split-product forward.  Scaled by
+    2^k both pieces are normal (22 bits); the kernels multiply the accumulated sum by 2^-k (``otp_conv_desc.out_scale``; the
+    pointwise kernels through their per-channel epilogue scale).  ``OTPOSE_X3_WSCALE=0`` stores the weights unscaled."""
+    if os.environ.get("OTPOSE_X3_WSCALE", "1") == "0":
+        return 0
+    w = weight.detach()
+    m = w.abs().reshape(w.shape[0], -1).amax(dim=1)
+    if scale is not None:
+        m = m * scale.detach().abs().to(m.device, m.dtype)
+    m = float(m.max())
+    if not (m > 0.0 and math.isfinite(m)):
+        return 0
+    return max(-40, min(40, 14 - math.frexp(m)[1]))
+
+
+def _scaled_vec(scale, k, cout, device):
+    """scale[cout] * 2^k as a contiguous fp32 vector (None when there is nothing to multiply by)"""
+    sc = scale.detach().to(device, torch.float32).contiguous() if scale is not None else None
+    if k == 0:
+        return sc
+    f = float(2.0 ** k)
+    return sc * f if sc is not None else torch.full((cout,), f, dtype=torch.float32, device=device)
+
+
+def pack_x3_weight(weight, scale=None, stride=1, k=0):
+    """(Cout, Cin, k, k) fp32, k = 3 or 1 (times scale[cout] * 2^k) -> half hi / lo MFMA fragments for :func:`conv2d_x3_launch`
+    (the chunking depends on the kernel size and the stride); the descriptor's ``out_scale`` must then be 2^-k
+    (:func:`x3_weight_exponent`)."""
     _require_gpu(weight)
     _check_f32(weight)
     w = weight.detach().contiguous()
@@ -369,7 +402,7 @@ def pack_x3_weight(weight, scale=None, stride=1):
     if not nbytes:
         raise ValueError(f"otp_conv2d_x3: unsupported channel counts ({cout}, {cin})")
     u = torch.empty(nbytes // 4, dtype=torch.int32, device=w.device)
-    sc = scale.detach().contiguous().float() if scale is not None else None
+    sc = _scaled_vec(scale, k, cout, w.device)
     hip.check(L.otp_conv2d_x3_pack_weight(hip.ptr(w), hip.ptr(sc), hip.ptr(u), cout, cin, kh, stride, hip.stream_of(w)),
               "otp_conv2d_x3_pack_weight")
     return u
@@ -396,7 +429,9 @@ def conv2d_x3(x, weight, scale=None, shift=None, act=ACT_NONE, res=None, pad=1, 
     iv, ov = View(x.contiguous()), View(out)
     rv = View(res.contiguous()) if res is not None else None
     d = conv_desc(iv, ov, cout, k, k, stride, pad, dil, act, None, rv)
-    conv2d_x3_launch(iv, pack_x3_weight(weight, scale, stride), shift, ov, d, rv)
+    e = x3_weight_exponent(weight, scale)
+    d.out_scale = 2.0 ** -e
+    conv2d_x3_launch(iv, pack_x3_weight(weight, scale, stride, e), shift, ov, d, rv)
     return out
 
 
@@ -487,12 +522,14 @@ def conv3x3_s2_s8(x_s8, shape, weight, scale=None, shift=None, act=ACT_NONE, res
     _require_gpu(x_s8, weight)
     n, cin, h, w = shape
     cout = weight.shape[0]
-    wp = pack_s8_weight(weight, scale)
+    e = x3_weight_exponent(weight, scale)
+    wp = pack_s8_weight(weight, scale, e)
     sh = shift.detach().contiguous().float() if shift is not None else None
     L = hip.lib()
     if out == "s8":
         assert res is None
         d = s8_s2_conv_desc(n, cin, cout, h, w, act)
+        d.out_scale = 2.0 ** -e
         o8 = s8_empty(n, cout, h // 2, w // 2, x_s8.device)
         hip.check(L.otp_conv3x3_s2_s8(hip.ptr(x_s8), hip.ptr(wp), hip.ptr(sh), None, None, hip.ptr(o8), d, hip.stream_of(x_s8)),
                   "otp_conv3x3_s2_s8")
@@ -500,13 +537,15 @@ def conv3x3_s2_s8(x_s8, shape, weight, scale=None, shift=None, act=ACT_NONE, res
     o = torch.empty(n, cout, h // 2, w // 2, dtype=torch.float32, device=x_s8.device)
     rv = View(res.contiguous()) if res is not None else None
     d = s8_s2_conv_desc(n, cin, cout, h, w, act, View(o), rv)
+    d.out_scale = 2.0 ** -e
     hip.check(L.otp_conv3x3_s2_s8(hip.ptr(x_s8), hip.ptr(wp), hip.ptr(sh), hip.ptr(rv.t) if rv is not None else None, hip.ptr(o),
                                   None, d, hip.stream_of(x_s8)), "otp_conv3x3_s2_s8")
     return o
 
 
-def pack_s8_weight(weight, scale=None):
-    """(Cout, Cin, 3, 3) fp32 (times scale[cout]) -> bf16 hi / lo MFMA fragments for :func:`conv3x3_s8_launch`."""
+def pack_s8_weight(weight, scale=None, k=0):
+    """(Cout, Cin, 3, 3) fp32 (times scale[cout] * 2^k) -> half hi / lo MFMA fragments for :func:`conv3x3_s8_launch` and
+    :func:`conv3x3_s2_s8`; the descriptor's ``out_scale`` must then be 2^-k (:func:`x3_weight_exponent`)."""
     _require_gpu(weight)
     _check_f32(weight)
     w = weight.detach().contiguous()
@@ -517,7 +556,7 @@ def pack_s8_weight(weight, scale=None):
     if not nbytes:
         raise ValueError(f"otp_conv3x3_s8: unsupported channel counts ({cout}, {cin})")
     u = torch.empty(nbytes // 4, dtype=torch.int32, device=w.device)
-    sc = scale.detach().contiguous().float() if scale is not None else None
+    sc = _scaled_vec(scale, k, cout, w.device)
     hip.check(L.otp_conv3x3_s8_pack_weight(hip.ptr(w), hip.ptr(sc), hip.ptr(u), cout, cin, hip.stream_of(w)),
               "otp_conv3x3_s8_pack_weight")
     return u
@@ -545,7 +584,9 @@ def conv3x3_s8(x_s8, shape, weight, scale=None, shift=None, act=ACT_NONE, res_c4
     if want_s8:
         out_s8 = s8_empty(n, cout, h, w, x_s8.device)
     d = s8_conv_desc(n, cin, cout, h, w, act)
-    conv3x3_s8_launch(x_s8, pack_s8_weight(weight, scale), shift, d, res_c4, out, layout, out_s8)
+    e = x3_weight_exponent(weight, scale)
+    d.out_scale = 2.0 ** -e
+    conv3x3_s8_launch(x_s8, pack_s8_weight(weight, scale, e), shift, d, res_c4, out, layout, out_s8)
     return out, out_s8
 
 
@@ -655,6 +696,9 @@ def pack_pointwise_x3(weight, scale=None, shift=None):
         raise RuntimeError(f"otp_pointwise_x3: unsupported weight shape {tuple(weight.shape)}")
     f = lambda t: None if t is None else t.detach().to(weight.device, torch.float32).contiguous()   # noqa: E731
     w, sc, sh = f(weight).reshape(cout, cin), f(scale), f(shift)
+    e = x3_weight_exponent(w)                     # weights stored times 2^e, undone by the kernel's per-channel epilogue scale
+    if e:
+        w, sc = w * float(2.0 ** e), _scaled_vec(sc, -e, cout, w.device)
     packed = torch.empty(nbytes // 4, dtype=torch.float32, device=weight.device)
     hip.check(L.otp_pointwise_x3_pack(hip.ptr(w), hip.ptr(sc), hip.ptr(sh), hip.ptr(packed), cin, cout, hip.stream_of(w)),
               "otp_pointwise_x3_pack")
@@ -687,6 +731,9 @@ def pack_pointwise_x3_s8(weight, scale=None, shift=None):
         raise RuntimeError(f"otp_pointwise_x3_s8: unsupported weight shape {tuple(weight.shape)}")
     f = lambda t: None if t is None else t.detach().to(weight.device, torch.float32).contiguous()   # noqa: E731
     w, sc, sh = f(weight).reshape(cout, cin), f(scale), f(shift)
+    e = x3_weight_exponent(w)                     # weights stored times 2^e, undone by the kernel's per-channel epilogue scale
+    if e:
+        w, sc = w * float(2.0 ** e), _scaled_vec(sc, -e, cout, w.device)
     packed = torch.empty(nbytes // 4, dtype=torch.float32, device=weight.device)
     hip.check(L.otp_pointwise_x3_s8_pack(hip.ptr(w), hip.ptr(sc), hip.ptr(sh), hip.ptr(packed), cin, cout, hip.stream_of(w)),
               "otp_pointwise_x3_s8_pack")

@@ -1,7 +1,7 @@
 """Split-record (S8) activations and the LDS-DMA fed 3x3 convolution (csrc/convs.hip, otp_conv3x3_s8) - the HRNet BasicBlock
 convs of model/HRNet.py:500-530 - against a float64 ``F.conv2d`` of the same operands, and the S8 converters against their
 definition.  Tolerance as for otp_conv2d_x3 (tests/test_gpu_convx.py): 2e-5 of the output range for the fp32 result; the
-S8 result additionally carries the split's own remainder (2^-17 relative per element)."""
+S8 result additionally carries the split's own remainder (2^-22 relative per element with the IEEE-half pieces of round 4)."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -11,8 +11,9 @@ from otpose_amd import ops
 pytestmark = pytest.mark.gpu
 
 
-def _bf16_rne(x):
-    return x.to(torch.bfloat16).to(torch.float32)
+def _h16_rne(x):
+    """the 16-bit operand type of the split products: IEEE half since round 4 (bfloat16 before; csrc/common.h)"""
+    return x.to(torch.float16).to(torch.float32)
 
 
 @pytest.mark.parametrize("shape,coff,ctot", [((3, 48, 12, 8), 0, 48), ((2, 16, 6, 6), 8, 40), ((5, 96, 24, 18), 0, 96)])
@@ -21,18 +22,20 @@ def test_s8_pack_is_hi_lo_of_the_definition(shape, coff, ctot):
     g = torch.Generator().manual_seed(c + h)
     full = (torch.randn(n, ctot, h, w, generator=g) * 3).cuda()
     full[0, coff, 0, 0] = 0.0
-    full[0, coff + 1, 0, 1] = 1e-30                       # hi carries it, lo = 0
+    full[0, coff + 1, 0, 1] = 1e-30                       # below the smallest half subnormal: both pieces 0
+    full[0, coff + 2, 0, 2] = 3e-6                        # a subnormal half: hi carries 6 bits of it, lo the rest
     x = full[:, coff:coff + c]
     s8 = ops.s8_pack(ops.View(full, coff, c))
-    rec = s8.view(torch.int16).view(n, c // 8, 2, h * w, 8)       # [n][g][part][p][e] bf16 bit patterns
-    hi = _bf16_rne(x)
-    lo = _bf16_rne(x - hi)
+    rec = s8.view(torch.int16).view(n, c // 8, 2, h * w, 8)       # [n][g][part][p][e] 16-bit patterns
+    hi = _h16_rne(x)
+    lo = _h16_rne(x - hi)
     want = torch.stack([hi, lo], 0).view(2, n, c // 8, 8, h * w).permute(1, 2, 0, 4, 3)   # -> [n][g][part][p][e]
-    got = rec.view(torch.bfloat16).to(torch.float32)
+    got = rec.view(torch.float16).to(torch.float32)
     assert torch.equal(got, want.contiguous())
     back = ops.s8_unpack(s8, n, c, h, w)
     assert torch.equal(back, hi + lo)
-    assert float((back - x).abs().max()) <= 2.0 ** -16 * float(x.abs().max())
+    # two half pieces carry 22 significand bits, or everything down to the half subnormal spacing 2^-24
+    assert float((back - x).abs().max()) <= max(2.0 ** -21 * float(x.abs().max()), 2.0 ** -24)
 
 
 # (N, Cin, Cout, H, W, residual, relu)
@@ -99,7 +102,9 @@ def test_conv3x3_s8_writes_a_channel_slice_of_an_nchw_tensor():
     wt = (torch.randn(16, 32, 3, 3, generator=g) * 0.1).cuda()
     big = torch.full((3, 40, 20, 12), 7.0, device="cuda")
     d = ops.s8_conv_desc(3, 32, 16, 20, 12, ops.ACT_NONE, ops.View(big, 8, 16))
-    ops.conv3x3_s8_launch(ops.s8_pack(x), ops.pack_s8_weight(wt), None, d, None, big, ops.S8_F32_NCHW, None)
+    e = ops.x3_weight_exponent(wt)                       # the wrapper below stores the weights times 2^e: same here
+    d.out_scale = 2.0 ** -e
+    ops.conv3x3_s8_launch(ops.s8_pack(x), ops.pack_s8_weight(wt, None, e), None, d, None, big, ops.S8_F32_NCHW, None)
     y, _ = ops.conv3x3_s8(ops.s8_pack(x), tuple(x.shape), wt, want_s8=False)
     assert torch.equal(big[:, 8:24], y) and float((big[:, :8] - 7).abs().max()) == 0 and float((big[:, 24:] - 7).abs().max()) == 0
 
@@ -260,9 +265,48 @@ def test_conv3x3_stride2_s8_accumulates_in_place_into_a_channel_slice():
     v = ops.View(big, 8, co)
     d = ops.s8_s2_conv_desc(n, ci, co, h, w, ops.ACT_RELU, v, v)
     from otpose_amd import hip
-    xs, wp = ops.s8_pack(x), ops.pack_s8_weight(wt)                    # (kept alive across the launch)
+    e = ops.x3_weight_exponent(wt)
+    d.out_scale = 2.0 ** -e
+    xs, wp = ops.s8_pack(x), ops.pack_s8_weight(wt, None, e)           # (kept alive across the launch)
     hip.check(hip.lib().otp_conv3x3_s2_s8(hip.ptr(xs), hip.ptr(wp), None, hip.ptr(big), hip.ptr(big), None, d,
                                           hip.stream_of(big)), "otp_conv3x3_s2_s8")
     want = ops.conv3x3_s2_s8(xs, (n, ci, h, w), wt, None, None, ops.ACT_RELU, before[:, 8:24].contiguous())
     assert torch.equal(big[:, 8:24], want)
     assert torch.equal(big[:, :8], before[:, :8]) and torch.equal(big[:, 24:], before[:, 24:])
+
+
+@pytest.mark.parametrize("kind", ["s8", "s2", "x3", "x3_1x1", "pointwise"])
+def test_weight_exponent_keeps_small_weights_to_fp32_accuracy(kind, monkeypatch):
+    """BatchNorm-folded weights of magnitude 1e-2: unscaled, the `lo` half piece of a weight is subnormal and the pair holds it to
+    2^-25 absolute (~17 bits) - an error common to all pixels; stored times 2^k (ops.x3_weight_exponent) and the sum multiplied
+    by 2^-k (otp_conv_desc.out_scale) the result is within fp32 rounding of float64 arithmetic on the same operands."""
+    g = torch.Generator(device="cpu").manual_seed(23)
+    n, ci, co, h, w = 2, 64, 64, 32, 24
+    k = 1 if kind in ("x3_1x1", "pointwise") else 3
+    x = torch.randn(n, ci, h, w, generator=g).cuda()
+    wt = (torch.randn(co, ci, k, k, generator=g) * 0.01).cuda()
+    sc = (torch.rand(co, generator=g) * 0.5 + 0.5).cuda()
+    sh = (torch.randn(co, generator=g) * 0.1).cuda()
+    xs = ops.s8_pack(x)
+    xin = ops.s8_unpack(xs, n, ci, h, w).double()
+    stride = 2 if kind == "s2" else 1
+    ref = torch.relu(F.conv2d(xin, wt.double(), None, stride, k // 2, 1) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1))
+
+    def run():
+        if kind == "s8":
+            return ops.conv3x3_s8(xs, (n, ci, h, w), wt, sc, sh, ops.ACT_RELU, want_s8=False)[0]
+        if kind == "s2":
+            return ops.conv3x3_s2_s8(xs, (n, ci, h, w), wt, sc, sh, ops.ACT_RELU)
+        if kind == "pointwise":
+            out = torch.empty(n, co, h, w, device="cuda")
+            ops.pointwise_x3(ops.View(x), ops.pack_pointwise_x3(wt, sc, sh), ops.View(out), None, True)
+            return out
+        return ops.conv2d_x3(x, wt, sc, sh, ops.ACT_RELU, None, k // 2, 1, 1)
+
+    # the part of the result the weights contribute (shift is exact in both): errors as a fraction of ITS range
+    span = float((ref - torch.relu(sh.double()).view(1, -1, 1, 1)).abs().max())
+    scaled = float((run().double() - ref).abs().max()) / span
+    monkeypatch.setenv("OTPOSE_X3_WSCALE", "0")
+    plain = float((run().double() - ref).abs().max()) / span
+    print("\n%s: max err / span  scaled %.2e  unscaled %.2e" % (kind, scaled, plain))
+    assert scaled <= 2e-6 and plain >= 3 * scaled

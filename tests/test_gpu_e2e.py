@@ -171,14 +171,14 @@ def test_headline_batch_all_16_clips_match_the_oracle():
     """EVERY clip of the batch bench.py times (BASELINE configs[1]: 16 clips x 5 x 384x288, HRNet-W48,
     reference path model/OTPose.py:307-394) against the CPU oracle on the same 16 clips (four oracle forwards of four clips;
     the oracle itself is pinned by the reference-generated goldens, tests/test_oracle_golden.py).  The default eval arithmetic
-    is split-bf16 products with fp32 accumulation, whose error is data dependent, so the bound is checked per clip and the
-    per-clip maxima are printed as a distribution: heat-maps (output, rough) <= 1e-3 ABSOLUTE on every clip - the contract of
-    BASELINE.json.  The other five outputs are held to 1e-3 of max(1, range), except `context`: tools/headline_parity_probe.py
-    (profiles/r04_headline_parity_probe.txt) shows the 17-channel flow encoder (model/OTPose.py:331-335) to be
-    ill-conditioned on some clips - on clip 7 of this batch the ORACLE in fp32 differs from the oracle in fp64 by 1e-4 on
-    `context` (25x its usual 4e-6) and the exact-fp32 HIP engine by 1.5e-4; the split-product engine, whose `total_b` input to
-    that encoder carries 6e-5 instead of 3e-6, lands at 2.1e-2 there (2.8e-3 of the range; 1e-3 .. 3e-3 on three more clips,
-    1e-4 on the rest).  `context` is therefore bounded at 5e-3 of its range and its distribution is printed."""
+    is split-half products with fp32 accumulation (csrc/common.h), whose error is data dependent, so the bound is checked per
+    clip and the per-clip maxima are printed as a distribution.  The contract of BASELINE.json is 1e-3 ABSOLUTE on the heat-maps;
+    what the build delivers since the weights are stored with their power of two (ops.x3_weight_exponent; rounds 2-3 and the
+    first half of round 4 carried 5e-4 on `output` and, through the ill-conditioned 17-channel flow encoder of
+    model/OTPose.py:331-335, 2.1e-2 on `context` of clip 7) is within 5x of what the fp32 ORACLE itself differs from its fp64 run
+    (profiles/r04_headline_parity_probe.txt: output 4.5e-5 against 9.3e-6, rough 5.8e-6 against 1.1e-6, context 8.8e-4 against
+    9.9e-5 on clip 7), so the test holds it to ~3x those measurements: output <= 1.5e-4, rough <= 3e-5, every other output <=
+    3e-4 of max(1, range)."""
     from oracle import otpose_oracle as O
     cfg = cfg2()
     x, margin = S.synthetic_clip(16, cfg.MODEL.IMAGE_SIZE)
@@ -203,11 +203,11 @@ def test_headline_batch_all_16_clips_match_the_oracle():
                 b = r[k:k + 1] if o.shape[0] == 16 else r[k::4]
                 per_clip[n].append(float((a - b).abs().max()))
                 scale = max(1.0, float(b.abs().max()))
-                assert per_clip[n][-1] <= (5.0 if n == "context" else 1.0) * TOL * scale, (n, lo + k, per_clip[n][-1], scale)
+                assert per_clip[n][-1] <= 3e-4 * scale, (n, lo + k, per_clip[n][-1], scale)
     for n in NAMES:
         v = per_clip[n]
         print("%-13s per-clip max |delta| vs oracle: min %.2e median %.2e max %.2e" % (n, min(v), sorted(v)[8], max(v)))
-    assert max(per_clip["output"]) <= TOL and max(per_clip["rough"]) <= TOL
+    assert max(per_clip["output"]) <= 1.5e-4 and max(per_clip["rough"]) <= 3e-5
 
 
 @pytest.mark.parametrize("ws,xs", [(777, 31), (4242, 32)])
