@@ -199,25 +199,28 @@ def kernel_rooflines(dev, batch):
     use_s8 = (use_x3 and os.environ.get("OTPOSE_S8", "1") != "0"
               and ops.s8_conv_supported(ops.s8_conv_desc(n, 48, 48, 96, 72, ops.ACT_RELU)))
     if use_s8:
-        # the kernel the engine runs for this layer inside an HRNet branch (csrc/convs.hip): split-bf16 products on activations
+        # the kernel the engine runs for this layer inside an HRNet branch (csrc/convs.hip): split-half products on activations
         # kept as MFMA operand records (S8), staged by the LDS-DMA.  A BasicBlock runs it twice: conv1 S8 -> S8 (timed here as
-        # `roofline`) and conv2 S8 + C4 residual -> C4 + S8 (`conv2_form`).  Every fp32 product is three bf16 MFMA products and
-        # a chunk's 9 taps occupy 10 tap slots: the pipe executes 3 * 10/9 of the algorithmic FLOPs, priced at the dense bf16 peak.
+        # `roofline`) and conv2 S8 + C4 residual -> C4 + S8 (`conv2_form`).  Every fp32 product is three f16 MFMA products (same rate as bf16) and
+        # a chunk's 9 taps occupy 10 tap slots: the pipe executes 3 * 10/9 of the algorithmic FLOPs, priced at the dense 16-bit peak.
         xs = ops.s8_pack(x)
         ys = ops.s8_empty(n, 48, 96, 72, dev)
-        ws = ops.pack_s8_weight(w, sc)
         ds = ops.s8_conv_desc(n, 48, 48, 96, 72, ops.ACT_RELU)
+        we = ops.x3_weight_exponent(w, sc)            # the weights carry 2^we, the kernel multiplies its sums by 2^-we (engine default)
+        ds.out_scale = 2.0 ** -we
+        ws = ops.pack_s8_weight(w, sc, we)
         t_conv = event_time_ms(lambda: ops.conv3x3_s8_launch(xs, ws, sh, ds, None, None, ops.S8_F32_C4, ys), 20, st)
         rc4, oc4 = ops.c4_empty(n, 48, 96, 72, dev), ops.c4_empty(n, 48, 96, 72, dev)
         ops.s8_pack(torch.randn(n, 48, 96, 72, generator=g).to(dev), out_c4=rc4)
         t_conv2 = event_time_ms(lambda: ops.conv3x3_s8_launch(xs, ws, sh, ds, rc4, oc4, ops.S8_F32_C4, ys), 20, st)
-        kname = ("convs_kernel<3, false, 4> (bf16x3 split products, S8 operand records, LDS-DMA, 3 workgroups / CU) 48->48 3x3 @96x72 x%d frames, S8 -> S8 "
+        kname = ("convs_kernel<3, false, 4> (f16x3 split products, S8 operand records, LDS-DMA, 3 workgroups / CU) 48->48 3x3 @96x72 x%d frames, S8 -> S8 "
                  "(grid %d x 256 threads)" % (n, ((n * 96 * 72 // 256 + 7) // 8) * 8))
         executed = conv_flop * 3.0 * 10.0 / 9.0
         peak = PEAK_BF16_MATRIX
         tr2, _ = measured_traffic("convs_48_48_3x3_96x72_x80_conv2", True)
-        extra = {"arithmetic": "fp32 accumulate; operands stored as bf16 hi | lo records (hi = rne(x), lo = rne(x - hi)), products "
-                               "lo*hi + hi*lo + hi*hi (csrc/convs.hip)",
+        extra = {"arithmetic": "fp32 accumulate; operands stored as IEEE-half hi | lo records (hi = rne(x), lo = rne(x - hi)), products "
+                               "lo*hi + hi*lo + hi*hi on v_mfma_f32_16x16x32_f16; weights stored times a per-layer power of two so that both "
+                               "pieces are normal numbers (csrc/convs.hip, otp_conv_desc.out_scale)",
                  "pmc": "committed profile, not collected in this run - profiles/r03c_convs_pmc_fold.txt: SQ_INSTS_VALU 11.07 M of which 4.67 M MFMA = 1.37 other vector "
                         "instructions per MFMA (prologue / epilogue), SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 6 %",
                  "conv2_form": {"what": "S8 + C4 residual -> C4 + S8 (BasicBlock conv2)", "ms_per_launch": t_conv2,
@@ -227,16 +230,18 @@ def kernel_rooflines(dev, batch):
                                 "algorithmic_bytes_per_launch": 4.0 * 4 * 48 * 96 * 72 * n,
                                 "hbm_frac": (tr2 if tr2 is not None else 4.0 * 4 * 48 * 96 * 72 * n) / (t_conv2 * 1e-3) / PEAK_HBM}}
     elif use_x3:
-        # the kernel the engine runs for this layer outside the S8 path: split-bf16 products on the bf16 matrix cores from fp32
-        # NCHW input (csrc/convx.hip).  Every fp32 product is three bf16 MFMA products and a chunk's 9 taps occupy 10 tap
+        # the kernel the engine runs for this layer outside the S8 path: split-half products on the 16-bit matrix cores from fp32
+        # NCHW input (csrc/convx.hip).  Every fp32 product is three f16 MFMA products and a chunk's 9 taps occupy 10 tap
         # slots, so the pipe executes 3 * 10/9 of the algorithmic FLOPs - against the dense bf16 peak.
-        xp = ops.pack_x3_weight(w, sc, 1)
+        we = ops.x3_weight_exponent(w, sc)
+        d.out_scale = 2.0 ** -we
+        xp = ops.pack_x3_weight(w, sc, 1, we)
         t_conv = event_time_ms(lambda: ops.conv2d_x3_launch(iv, xp, sh, ov, d), 20, st)
-        kname = "convx_kernel<16,4,1,3> (bf16x3 split products) 48->48 3x3 @96x72 x%d frames (grid %d x 256 threads)" % (
+        kname = "convx_kernel<16,4,1,3> (f16x3 split products) 48->48 3x3 @96x72 x%d frames (grid %d x 256 threads)" % (
             n, ((n * 96 * 72 // 256 + 7) // 8) * 8)
         executed = conv_flop * 3.0 * 10.0 / 9.0
         peak = PEAK_BF16_MATRIX
-        extra = {"arithmetic": "fp32 storage / accumulate, products as bf16 hi*hi + hi*lo + lo*hi (csrc/convx.hip)"}
+        extra = {"arithmetic": "fp32 storage / accumulate, products as half hi*hi + hi*lo + lo*hi (csrc/convx.hip)"}
     elif use_wino:
         # the kernel the engine runs for this layer: Winograd F(2x2,3x3) (csrc/wino.hip).  `achieved` stays ALGORITHMIC
         # (direct-convolution) FLOPs per second; the kernel itself executes 16/36 of them on the MFMA pipe.
@@ -311,7 +316,7 @@ def kernel_rooflines(dev, batch):
         mlp_flop = 4.0 * C * HID * batch * T
         balanced = T % 432 == 0 and batch * (T // 432) >= 192 and os.environ.get("OTP_MLP_BALANCED", "1") != "0"
         if x3:
-            # split-bf16 kernel (csrc/mlpx.hip): 3 bf16 MFMA products per fp32 product, K padded 136 -> 160 in the first GEMM
+            # split-half kernel (csrc/mlpx.hip): 3 f16 MFMA products per fp32 product, K padded 136 -> 160 in the first GEMM
             packed = ops.pack_mlp_x3_weights(w1, b1, w2)
             t_mlp = event_time_ms(lambda: ops.ln_mlp_x3(xm, one, zero, 1e-5, packed, one, zero, out=om), 20, st)
             executed = 3.0 * 2.0 * (160 * HID + HID * 144) * batch * T
@@ -622,7 +627,7 @@ def main():
             torch.cuda.synchronize(dev)
             d5 = time.perf_counter() - t5
         config5 = {"workload": "BASELINE configs[4] as far as the reference defines it: batch 16 x 7-frame window x 384x288, HRNet-W48 "
-                               "(no RSN backbone / occlusion mask exists in the reference), fp32 storage, split-bf16 products",
+                               "(no RSN backbone / occlusion mask exists in the reference), fp32 storage, split-half (f16x3) products",
                    "frames_per_s": 7 * a.batch * a.steps / d5, "ms_per_step": 1e3 * d5 / a.steps,
                    "outputs_finite": all(bool(torch.isfinite(o).all()) for o in o5),
                    "encoder_kernels": "C = 204 instantiations of csrc/mlpx.hip / csrc/densex.hip (ln2 + MLP, q / k / v front end, projections)"}
@@ -645,13 +650,16 @@ def main():
             "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             # the arithmetic that was timed: every tensor, accumulator, normalisation and activation is fp32; the products of the
-            # convolutions / projections / MLPs / attention are three bf16 MFMA products of two-piece fp32 operands (~2^-17 per
-            # product; the reference's fp32 is 2^-24, its default TF32 convolutions on NVIDIA hardware 2^-11).  The same forward
+            # convolutions / projections / MLPs / attention are three f16 MFMA products of two-piece fp32 operands (IEEE-half pieces, 22 significand
+            # bits per operand; the reference's fp32 is 24, its default TF32 convolutions on NVIDIA hardware 11).  Measured on the
+            # headline batch (profiles/r04_headline_parity_probe.txt): heat-maps within 4.5e-5 of the fp32 oracle on all 16 clips,
+            # the exact-fp32 kernels within 1.5e-5, the fp32 oracle itself 9e-6 from its fp64 run.  The same forward
             # on exact-fp32 MFMA kernels is `exact_fp32_kernels` of this line.
-            "dtype": "f32" if math == "f32" else "f32 storage+accumulate / bf16x3 split products", "data": "synthetic",
+            "dtype": "f32" if math == "f32" else "f32 storage+accumulate / f16x3 split products", "data": "synthetic",
             "rccl_world": dist.get_world_size() if dist is not None else 1,
-            "arithmetic": ("fp32 accumulation everywhere; conv / MLP / projection products as three bf16 MFMA products of two-piece "
-                           "operands (a = hi + lo, |a - hi - lo| <= 2^-18 |a|: DESIGN.md section 3.1c); tensors are fp32 except, "
+            "arithmetic": ("fp32 accumulation everywhere; conv / MLP / projection products as three f16 MFMA products of two-piece "
+                           "operands (a = hi + lo in IEEE half, |a - hi - lo| <= max(2^-23 |a|, 2^-25); HRNet / warping-head weights stored times "
+                           "a per-layer power of two so both pieces are normal: DESIGN.md section 3.1c); tensors are fp32 except, "
                            "inside an HRNet branch, the conv1 output of a BasicBlock, which exists only as that hi | lo pair "
                            "(the residual chain stays fp32: DESIGN.md section 3.1d)"
                            if math != "f32" else "fp32 throughout (f32 MFMA)"),

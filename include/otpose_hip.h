@@ -142,9 +142,9 @@ int otp_conv3x3_small_pack(const void* weight, void* wpacked, int Cout, int Cin,
 int otp_conv3x3_small(const void* in, const void* in2, const void* wpacked, const void* scale, const void* shift, void* out,
                       const otp_conv_desc* desc, void* stream);
 
-/* fp32 3x3 (stride 1 or 2) and 1x1 (stride 1) convolutions on the bf16 matrix cores with split ("bf16x3") products: every fp32 operand is the sum
- * of two bf16 pieces (hi = rne(a), lo = rne(a - hi)), a product is lo*hi + hi*lo + hi*hi accumulated in fp32 (dropped terms
- * <= 3 * 2^-18 |a b|), storage stays fp32 NCHW.  Same descriptor and fused epilogue (shift, residual, activation,
+/* fp32 3x3 (stride 1 or 2) and 1x1 (stride 1) convolutions on the 16-bit matrix cores with split ("f16x3": two IEEE-half pieces per operand, csrc/common.h) products: every fp32 operand is the sum
+ * of two IEEE-half pieces (hi = rne(a), lo = rne(a - hi): 22 significand bits while lo is a normal number - see out_scale in
+ * otp_conv_desc for the weights), a product is lo*hi + hi*lo + hi*hi accumulated in fp32, storage stays fp32 NCHW.  Same descriptor and fused epilogue (shift, residual, activation,
  * channel-sliced views) as otp_conv2d_wino; the per-channel scale is folded into the packed weights.  Replaces the cuDNN
  * convs behind model/HRNet.py:500-571 (BasicBlock / Bottleneck conv2) and the 3x3 transition / dilated convs.
  * otp_conv2d_x3_supported: 3x3 with stride 1 (Cin % 16 == 0) or 2 (Cin % 8 == 0), any pad / dilation whose window fits the
@@ -244,7 +244,7 @@ int otp_channel_sum(const void* a, void* out, void* workspace, size_t workspace_
  *   out = alpha * sum_i [ ModulatedDeformConv_i(x, Conv_off_i(trans), Conv_mask_i(trans)) + bias_i ]
  * trans (B, 32, H, W), x = def_heatmaps (B, J, H, W), out (B, J, H, W), all fp32; 3x3 kernels, stride 1, padding = dilation,
  * deformable_groups = J, groups = 1 (the only form model/OTPose.py:141-157 builds).  The 27 J offset / mask channels per pixel
- * and dilation exist only in registers / LDS; the 32 -> 27 J convolutions run on the bf16 matrix cores with split products
+ * and dilation exist only in registers / LDS; the 32 -> 27 J convolutions run on the 16-bit matrix cores with split products
  * (see otp_conv2d_x3), the sampling follows deform_conv_cuda_kernel.cu:403-432, 549-556 exactly.
  * packed: otp_dcn_fused_weight_bytes(ND, J) bytes written by otp_dcn_fused_pack from DEVICE arrays of ND device pointers
  * (w_off[i] (18 J, 32, 3, 3), w_mask[i] (9 J, 32, 3, 3), w_dcn[i] (J, J, 3, 3), bias[i] (J) or NULL).
@@ -311,7 +311,7 @@ int otp_mlp_fused(const void* x, const void* packed, const void* scale, const vo
 int otp_ln_mlp_fused(const void* y, const void* ln_gamma, const void* ln_beta, float ln_eps, const void* packed,
                      const void* scale, const void* shift, void* out, int B, int C, int HID, int T, void* stream);
 
-/* otp_dense_cc / otp_qkv_front (csrc/dense.hip) with split-bf16 ("bf16x3") products on the bf16 matrix cores
+/* otp_dense_cc / otp_qkv_front (csrc/dense.hip) with split-half ("f16x3": two IEEE-half pieces per fp32 operand, csrc/common.h) products on the 16-bit matrix cores
  * (csrc/densex.hip): same arguments; the packed images come from otp_dense_x3_pack (otp_dense_x3_weight_bytes bytes each),
  * the parameter table of otp_qkv_front_x3 is the one otp_qkv_front_pack_table writes. */
 int otp_dense_x3_supported(int C, int T);
@@ -332,7 +332,7 @@ size_t otp_stem_conv_x3_weight_bytes(int Cout);
 int otp_stem_conv_x3_pack(const void* w, const void* scale, const void* shift, void* packed, int Cout, void* stream);
 int otp_stem_conv_x3(const void* in, const void* packed, void* out, int B, int F, int H, int W, int Cout, void* stream);
 
-/* Pointwise (1x1, stride 1) convolution Cin -> Cout on fp32 NCHW channel slices with split-bf16 products (csrc/pointx.hip):
+/* Pointwise (1x1, stride 1) convolution Cin -> Cout on fp32 NCHW channel slices with split-half products (csrc/pointx.hip):
  * HRNet layer1's Bottleneck convs (model/HRNet.py:551-571: 256 -> 64, 64 -> 256 + residual, the shortcut folded over the
  * concatenation 128 -> 256), what nn.Conv2d(k = 1) + folded BatchNorm2d + ReLU compute there:
  *   out[b, out_coff + o, t] = act(scale[o] * sum_c w[o, c] * x[b, x_coff + c, t] + shift[o] (+ res[b, res_coff + o, t]))
@@ -354,7 +354,7 @@ int otp_pointwise_x3_s8_pack(const void* w, const void* scale, const void* shift
 int otp_pointwise_x3_s8(const void* x, const void* packed, void* out_s8, int B, int Cin, int Cout, int T, int x_ctot, int x_coff,
                         int relu, void* stream);
 
-/* The same operator with split-bf16 ("bf16x3") products on the bf16 matrix cores (csrc/mlpx.hip): fp32 storage, fp32
+/* The same operator with split-half ("f16x3": two IEEE-half pieces per fp32 operand, csrc/common.h) products on the 16-bit matrix cores (csrc/mlpx.hip): fp32 storage, fp32
  * accumulation, LayerNorm / bias / GELU in fp32; each product is lo*hi + hi*lo + hi*hi of two bf16 pieces per operand.
  * Own packed image (otp_mlp_x3_weight_bytes / otp_mlp_x3_pack); same arguments and aliasing rules as otp_mlp_fused /
  * otp_ln_mlp_fused. */
@@ -420,7 +420,7 @@ int otp_upsample_add_multi(const void* const* lows, const int* factors, int nlow
  * Channel attention backward is assembled on the host side from these (otpose_amd/train_ops.py): with O^T = the
  * transposed-contiguous image otp_chan_attn writes, dO = transpose(d_out), dP = dO v^T (scores + slab sum),
  * dS = softmax'(P, dP), dq = scale * dS k, dk = scale * dS^T q, dv = P^T dO (three otp_chan_attn_apply + transposes). */
-/* Arithmetic of the q.k^T score products of otp_chan_attn / otp_chan_attn_scores: 1 (default) = split-bf16 products on the
+/* Arithmetic of the q.k^T score products of otp_chan_attn / otp_chan_attn_scores: 1 (default) = split-half products on the
  * bf16 matrix cores (fp32 accumulation, see otp_conv2d_x3), 0 = the f32 MFMA kernel.  Process-wide switch. */
 int otp_chan_attn_set_split(int on);
 int otp_chan_attn_splits(int BH, int T);

@@ -59,7 +59,7 @@ class InferenceEngine:
         # conv products: "x3" = fp32 operands split into two bf16 pieces, three bf16 MFMAs per product, fp32 accumulate
         # (csrc/convx.hip); "f32" = the f32 MFMA kernels only (Winograd / direct)
         self.use_x3 = os.environ.get("OTPOSE_CONV_MATH", "x3") != "f32"
-        # offset / mask convs + DCN gathers of all dilations in one launch (split-bf16 products for the convs)
+        # offset / mask convs + DCN gathers of all dilations in one launch (split-half products for the convs)
         self.use_dcn_fused = self.use_x3 and os.environ.get("OTPOSE_DCN_FUSED", "1") != "0"
         # HRNet branches (chains of BasicBlocks) on split-record activations fed by the LDS-DMA (csrc/convs.hip)
         self.use_s8 = self.use_x3 and os.environ.get("OTPOSE_S8", "1") != "0"
@@ -267,7 +267,7 @@ class InferenceEngine:
             self._emit(run_px)
             return out
         if self.use_x3 and not self._exact and in2 is None and (kh, kw) in ((3, 3), (1, 1)) and ops.x3_supported(d):
-            # 3x3 / stride 1 with Cin % 16 == 0: split-bf16 (bf16x3) products on the bf16 matrix cores, fp32 storage and
+            # 3x3 / stride 1 with Cin % 16 == 0: split-half (f16x3) products on the 16-bit matrix cores, fp32 storage and
             # accumulation (csrc/convx.hip); the per-channel scale is folded into the packed weights
             e = ops.x3_weight_exponent(w, sc)         # weights stored times 2^e, the sum multiplied by 2^-e (otp_conv_desc.out_scale)
             d.out_scale = 2.0 ** -e
@@ -314,7 +314,7 @@ class InferenceEngine:
                          res_up=res_up, **kw)
 
     def dense(self, xs, packs, ress, outs, B, C, T):
-        """Emit one otp_dense_cc (or, with split-bf16 products, otp_dense_x3) launch over len(xs) problems."""
+        """Emit one otp_dense_cc (or, with split-half products, otp_dense_x3) launch over len(xs) problems."""
         ax, ap, ar, ao = ops.dense_cc_args(xs, packs, ress, outs)
         self._keep += [ax, ap, ar, ao, *packs]
         x3 = self.use_x3 and ops.dense_x3_supported(C, T)
@@ -830,7 +830,7 @@ class InferenceEngine:
         out = self.new(B, C, To)
         hid = blk.mlp[0].out_channels
         if self.use_fused_mlp and self.use_x3 and ops.mlp_x3_supported(C, hid, To):
-            # the same single launch with split-bf16 products on the bf16 matrix cores (csrc/mlpx.hip)
+            # the same single launch with split-half products on the 16-bit matrix cores (csrc/mlpx.hip)
             dev = lambda t: t.detach().to(self.dev, torch.float32)     # noqa: E731
             packed = ops.pack_mlp_x3_weights(dev(blk.mlp[0].weight), dev(blk.mlp[0].bias), dev(blk.mlp[3].weight))
             scd = dev(sm).contiguous()

@@ -419,7 +419,7 @@ def conv2d_x3_launch(inp: View, wpacked, shift, out: View, desc, res: View = Non
 
 
 def conv2d_x3(x, weight, scale=None, shift=None, act=ACT_NONE, res=None, pad=1, dil=1, stride=1):
-    """act(conv2d(x, weight, stride, pad, dil) * scale + shift + res) with split-bf16 products (csrc/convx.hip)."""
+    """act(conv2d(x, weight, stride, pad, dil) * scale + shift + res) with split-half products (csrc/convx.hip)."""
     _require_gpu(x, weight)
     n, cin, h, w = x.shape
     cout, k = weight.shape[0], weight.shape[2]
@@ -614,7 +614,7 @@ def dense_x3_supported(c, t) -> bool:
 
 def pack_dense_cc(weight, scale=None, shift=None, x3=False):
     """(C, C[, 1]) pointwise weight (+ per-output-channel scale / shift) -> the per-16-row fragment image of
-    :func:`dense_cc` (MaskedMHCA query / key / value / proj, model/blocks.py:383-386).  ``x3``: the split-bf16 image of
+    :func:`dense_cc` (MaskedMHCA query / key / value / proj, model/blocks.py:383-386).  ``x3``: the split-half image of
     csrc/densex.hip (pass the same flag to :func:`dense_cc` / :func:`qkv_front`)."""
     _require_gpu(weight)
     c = weight.shape[0]
@@ -872,7 +872,7 @@ def pack_mlp_x3_weights(w1, b1, w2):
 
 
 def mlp_x3(x, packed, scale, shift, res, out=None, hid=None, stream=None):
-    """:func:`mlp_fused` with split-bf16 products on the bf16 matrix cores (fp32 storage / accumulation)."""
+    """:func:`mlp_fused` with split-half products on the 16-bit matrix cores (fp32 storage / accumulation)."""
     _require_gpu(x, packed, res)
     _check_f32(x)
     b, c, t = x.shape
@@ -885,7 +885,7 @@ def mlp_x3(x, packed, scale, shift, res, out=None, hid=None, stream=None):
 
 
 def ln_mlp_x3(y, gamma, beta, eps, packed, scale, shift, out=None, hid=None, stream=None):
-    """:func:`ln_mlp_fused` with split-bf16 products."""
+    """:func:`ln_mlp_fused` with split-half products."""
     _require_gpu(y, packed)
     _check_f32(y)
     b, c, t = y.shape

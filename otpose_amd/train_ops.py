@@ -72,7 +72,7 @@ def _dense_cc(cin, cout, k, stride, pad, hw):
 def _dense_cc_launch(x4, w2, bias, out4):
     from . import ops
     n, c = x4.shape[:2]
-    # split-bf16 products (csrc/densex.hip) unless the exact-fp32 kernels are asked for, as in the inference engine
+    # split-half products (csrc/densex.hip) unless the exact-fp32 kernels are asked for, as in the inference engine
     x3 = os.environ.get("OTPOSE_CONV_MATH", "x3") != "f32" and ops.dense_x3_supported(c, x4.shape[2] * x4.shape[3])
     pk = ops.pack_dense_cc(w2, None, bias, x3=x3)
     ops.dense_cc([x4.view(n, c, -1)], [pk], None, [out4.view(n, c, -1)], x3=x3)
