@@ -319,6 +319,12 @@ size_t otp_dense_x3_weight_bytes(int C);
 int otp_dense_x3_pack(const void* w, const void* scale, const void* shift, void* packed, int C, void* stream);
 int otp_dense_x3(const void* const* x, const void* const* packed, const void* const* res, void* const* out, int nprob, int B,
                  int C, int T, void* stream);
+/* The same projection with BFLOAT16 operand pieces (csrc/densex_grad.hip), for operands of unknown magnitude: the training
+ * backward's input gradient dx = W^T dy (otpose_amd/train_ops.py).  An IEEE-half piece flushes 1e-8 to zero and holds 1e-5 to
+ * 8 bits; a bfloat16 pair keeps 16-17 bits at any magnitude.  Same arguments; images from otp_dense_x3_pack_bf16p. */
+int otp_dense_x3_pack_bf16p(const void* w, const void* scale, const void* shift, void* packed, int C, void* stream);
+int otp_dense_x3_bf16p(const void* const* x, const void* const* packed, const void* const* res, void* const* out, int nprob, int B,
+                 int C, int T, void* stream);
 int otp_qkv_front_x3(const void* x, const void* table, const void* packed_q, const void* packed_k, const void* packed_v,
                      void* q, void* k, void* v, int B, int C, int T, float eps, void* stream);
 
@@ -426,6 +432,10 @@ int otp_chan_attn_set_split(int on);
 int otp_chan_attn_splits(int BH, int T);
 int otp_chan_attn_scores(const void* a, const void* b, void* slabs, int BH, int hs, int T, void* stream);
 int otp_chan_attn_apply(const void* v, const void* M, void* out, int BH, int hs, int T, void* stream);
+/* The two products with bfloat16 operand pieces (csrc/transformer_grad.hip) for the attention backward, whose operands are
+ * gradients (dS = dO v^T; dq, dk, dv): same arguments, same otp_chan_attn_set_split switch. */
+int otp_chan_attn_scores_bf16p(const void* a, const void* b, void* slabs, int BH, int hs, int T, void* stream);
+int otp_chan_attn_apply_bf16p(const void* v, const void* M, void* out, int BH, int hs, int T, void* stream);
 /* per batch: in (R, Cc) row-major -> out (Cc, R) row-major times scale */
 int otp_transpose_scale(const void* in, void* out, int batches, int R, int Cc, float scale, void* stream);
 /* slabs (BH, NS, HSP, HSP) partial dP, P (BH, HSP, HSP) -> dS, dS^T, P^T (BH, HSP, HSP), HSP = hs rounded up to 16 */

@@ -8,7 +8,15 @@
 // fragments (lane (token pair n, kq): channels 32 ks + 8 kq .. + 7); the weights stream through the LDS one 16-row output
 // block at a time (LDS-DMA, double buffered, one barrier per block); a block's 16 x 32 result is scaled, shifted, added to
 // the residual and stored as soon as its 30 MFMAs are done.
+//
+// This file is compiled twice.  densex.o: IEEE-half pieces (csrc/common.h) for the forward's O(1) activations.  densex_grad.o
+// (densex_grad.hip: -DOTP_X3_BF16, entry points suffixed _bf16p): bfloat16 pieces for operands whose magnitude is not known -
+// the GRADIENTS the training backward sends through the same projection (dx = W^T dy, otpose_amd/train_ops.py): a half piece
+// flushes 1e-8 to zero and holds 1e-5 to 8 bits, a bfloat16 pair keeps 16-17 bits at any magnitude.
 #include "common.h"
+#ifndef OTP_ENTRY
+#define OTP_ENTRY(name) name
+#endif
 
 namespace {
 
@@ -270,14 +278,16 @@ __global__ __launch_bounds__(256, C <= 136 ? 3 : 2) void qkvx_front_kernel(const
 }  // namespace
 
 // C = 136: 8 stacked maps x 17 joints (5-frame window); C = 204: 12 x 17 (the 7-frame window of BASELINE configs[4])
+#ifndef OTP_X3_GRAD_COPY
 extern "C" int otp_dense_x3_supported(int C, int T) { return ((C == 136 || C == 204) && T > 0 && T % 2 == 0) ? 1 : 0; }
 
 extern "C" size_t otp_dense_x3_weight_bytes(int C) {
     if (C <= 0 || C % 4) return 0;
     return (size_t)((C + 15) / 16) * dx_block_bytes(C);
 }
+#endif
 
-extern "C" int otp_dense_x3_pack(const void* w, const void* scale, const void* shift, void* packed, int C, void* stream) {
+extern "C" int OTP_ENTRY(otp_dense_x3_pack)(const void* w, const void* scale, const void* shift, void* packed, int C, void* stream) {
     if (!w || !packed) return OTP_ERR_BAD_ARG;
     const size_t bytes = otp_dense_x3_weight_bytes(C);
     if (!bytes) return OTP_ERR_UNSUPPORTED;
@@ -288,7 +298,7 @@ extern "C" int otp_dense_x3_pack(const void* w, const void* scale, const void* s
     return otp_launch_status();
 }
 
-extern "C" int otp_dense_x3(const void* const* x, const void* const* packed, const void* const* res, void* const* out,
+extern "C" int OTP_ENTRY(otp_dense_x3)(const void* const* x, const void* const* packed, const void* const* res, void* const* out,
                             int nprob, int B, int C, int T, void* stream) {
     if (!x || !packed || !out || nprob < 1 || nprob > 3 || B <= 0) return OTP_ERR_BAD_ARG;
     if (!otp_dense_x3_supported(C, T)) return OTP_ERR_UNSUPPORTED;
@@ -313,6 +323,7 @@ extern "C" int otp_dense_x3(const void* const* x, const void* const* packed, con
     return otp_launch_status();
 }
 
+#ifndef OTP_X3_GRAD_COPY
 extern "C" int otp_qkv_front_x3(const void* x, const void* table, const void* packed_q, const void* packed_k,
                                 const void* packed_v, void* q, void* k, void* v, int B, int C, int T, float eps, void* stream) {
     if (!x || !table || !packed_q || !packed_k || !packed_v || !q || !k || !v || B <= 0) return OTP_ERR_BAD_ARG;
@@ -336,3 +347,4 @@ extern "C" int otp_qkv_front_x3(const void* x, const void* table, const void* pa
                            static_cast<const float*>(x), static_cast<const float*>(table), a, T, tiles, eps);
     return otp_launch_status();
 }
+#endif  // OTP_X3_GRAD_COPY

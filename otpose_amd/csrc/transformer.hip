@@ -5,8 +5,16 @@
 //
 // All tensors are (B, C, T) with T contiguous, so a thread owns one time step t and walks the C
 // channels: every global access of a wave is a coalesced 256-byte run along T.
+//
+// This file is compiled twice.  transformer.o: everything, split products on IEEE-half pieces (csrc/common.h).
+// transformer_grad.o (transformer_grad.hip: -DOTP_X3_BF16 -DOTP_X3_GRAD_COPY): only otp_chan_attn_scores_bf16p /
+// otp_chan_attn_apply_bf16p, the two attention products with bfloat16 pieces, for the training backward, whose operands are
+// GRADIENTS of unknown magnitude (a half piece flushes 1e-8 to zero; a bfloat16 pair keeps 16-17 bits at any magnitude).
 #include "common.h"
 #include <cstdlib>
+#ifndef OTP_ENTRY
+#define OTP_ENTRY(name) name
+#endif
 
 namespace {
 
@@ -772,6 +780,7 @@ __global__ void upsample_linear4_kernel(const float* __restrict__ x, float* __re
 
 }  // namespace
 
+#ifndef OTP_X3_GRAD_COPY
 extern "C" int otp_ln_channel(const void* x, const void* gamma, const void* beta, void* y, void* pool, int B,
                               int C, int T, float eps, void* stream) {
     if (!x || !gamma || !beta || !y || B <= 0 || C <= 0 || T <= 0) return OTP_ERR_BAD_ARG;
@@ -812,9 +821,17 @@ extern "C" int otp_dwconv_ln3(const void* x, const void* dwq, const void* dwk, c
 #undef OTP_DW_ARGS
     return otp_launch_status();
 }
+#endif  // OTP_X3_GRAD_COPY
+
+// 1: score products as split products (default), 0: f32 MFMA (otp_chan_attn_set_split); one flag for both copies of this file
+#ifndef OTP_X3_GRAD_COPY
+std::atomic<int> otp_g_attn_split{1};
+#else
+extern std::atomic<int> otp_g_attn_split;
+#endif
+#define g_attn_split otp_g_attn_split
 
 namespace {
-std::atomic<int> g_attn_split{1};       // 1: score products as split bf16 (default), 0: f32 MFMA (otp_chan_attn_set_split)
 int attn_splits(int BH, int T) {
     int ns = 1;
     while (BH * ns < 768 && T / (ns * 2) >= 2 * ATT_TC) ns *= 2;
@@ -822,6 +839,7 @@ int attn_splits(int BH, int T) {
 }
 }  // namespace
 
+#ifndef OTP_X3_GRAD_COPY
 extern "C" size_t otp_chan_attn_workspace(int B, int C, int T, int n_head) {
     if (B <= 0 || C <= 0 || T <= 0 || n_head <= 0 || C % n_head) return 0;
     const int hs = C / n_head, HSP = (hs + 15) & ~15;
@@ -892,9 +910,10 @@ extern "C" int otp_chan_attn_set_split(int on) {
 }
 
 extern "C" int otp_chan_attn_splits(int BH, int T) { return (BH > 0 && T > 0) ? attn_splits(BH, T) : 0; }
+#endif  // OTP_X3_GRAD_COPY
 
 // slabs[bh][s] (HSP x HSP, zero padded) = partial a . b^T over the s-th slice of T, no scale: sum the slabs for a . b^T
-extern "C" int otp_chan_attn_scores(const void* a, const void* b, void* slabs, int BH, int hs, int T, void* stream) {
+extern "C" int OTP_ENTRY(otp_chan_attn_scores)(const void* a, const void* b, void* slabs, int BH, int hs, int T, void* stream) {
     if (!a || !b || !slabs || BH <= 0 || hs <= 0 || T <= 0) return OTP_ERR_BAD_ARG;
     const int HSP = (hs + 15) & ~15, NB = HSP / 16;
     if (NB > 7) return OTP_ERR_UNSUPPORTED;
@@ -930,7 +949,7 @@ extern "C" int otp_chan_attn_scores(const void* a, const void* b, void* slabs, i
 }
 
 // out[bh][t][i] = sum_j M[bh][i][j] * v[bh][j][t]   (M: HSP x HSP zero padded; the transposed-contiguous output image)
-extern "C" int otp_chan_attn_apply(const void* v, const void* M, void* out, int BH, int hs, int T, void* stream) {
+extern "C" int OTP_ENTRY(otp_chan_attn_apply)(const void* v, const void* M, void* out, int BH, int hs, int T, void* stream) {
     if (!v || !M || !out || BH <= 0 || hs <= 0 || T <= 0) return OTP_ERR_BAD_ARG;
     const int HSP = (hs + 15) & ~15, NB = HSP / 16;
     if (NB > 7) return OTP_ERR_UNSUPPORTED;
@@ -972,6 +991,7 @@ extern "C" int otp_chan_attn_apply(const void* v, const void* M, void* out, int 
     return otp_launch_status();
 }
 
+#ifndef OTP_X3_GRAD_COPY
 extern "C" int otp_maxpool3s2_forward(const void* x, void* y, int rows, int T, void* stream) {
     if (!x || !y || rows <= 0 || T <= 0) return OTP_ERR_BAD_ARG;
     const int To = (T + 2 - 3) / 2 + 1;
@@ -995,3 +1015,4 @@ extern "C" int otp_upsample_linear(const void* x, void* out, int B, int C, int T
                            f, out_ctot, out_coff);
     return otp_launch_status();
 }
+#endif  // OTP_X3_GRAD_COPY

@@ -120,6 +120,8 @@ SIGNATURES = {
     "otp_dense_x3_weight_bytes": (c_size_t, [c_int]),
     "otp_dense_x3_pack": (c_int, [c_void_p] * 4 + [c_int, c_void_p]),
     "otp_dense_x3": (c_int, [ctypes.POINTER(c_void_p)] * 4 + [c_int] * 4 + [c_void_p]),
+    "otp_dense_x3_pack_bf16p": (c_int, [c_void_p] * 4 + [c_int, c_void_p]),
+    "otp_dense_x3_bf16p": (c_int, [ctypes.POINTER(c_void_p)] * 4 + [c_int] * 4 + [c_void_p]),
     "otp_stem_conv_x3_supported": (c_int, [c_int] * 5),
     "otp_stem_conv_x3_weight_bytes": (c_size_t, [c_int]),
     "otp_stem_conv_x3_pack": (c_int, [c_void_p] * 4 + [c_int, c_void_p]),
@@ -148,6 +150,8 @@ SIGNATURES = {
     "otp_chan_attn_scores": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p]),
     "otp_chan_attn_set_split": (c_int, [c_int]),
     "otp_chan_attn_apply": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p]),
+    "otp_chan_attn_scores_bf16p": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p]),
+    "otp_chan_attn_apply_bf16p": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p]),
     "otp_transpose_scale": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "otp_softmax_backward": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_void_p]),
     "otp_ln_channel_backward": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_float, c_void_p]),

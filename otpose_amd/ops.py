@@ -612,10 +612,11 @@ def dense_x3_supported(c, t) -> bool:
     return bool(hip.lib().otp_dense_x3_supported(int(c), int(t)))
 
 
-def pack_dense_cc(weight, scale=None, shift=None, x3=False):
+def pack_dense_cc(weight, scale=None, shift=None, x3=False, grad=False):
     """(C, C[, 1]) pointwise weight (+ per-output-channel scale / shift) -> the per-16-row fragment image of
     :func:`dense_cc` (MaskedMHCA query / key / value / proj, model/blocks.py:383-386).  ``x3``: the split-half image of
-    csrc/densex.hip (pass the same flag to :func:`dense_cc` / :func:`qkv_front`)."""
+    csrc/densex.hip (pass the same flag to :func:`dense_cc` / :func:`qkv_front`); ``grad`` (with ``x3``): the image with
+    bfloat16 pieces for :func:`dense_cc` on operands of unknown magnitude - gradients (csrc/densex_grad.hip)."""
     _require_gpu(weight)
     c = weight.shape[0]
     L = hip.lib()
@@ -625,8 +626,8 @@ def pack_dense_cc(weight, scale=None, shift=None, x3=False):
     f = lambda t: None if t is None else t.detach().to(weight.device, torch.float32).contiguous()   # noqa: E731
     w, sc, sh = f(weight), f(scale), f(shift)
     packed = torch.empty(nbytes // 4, dtype=torch.float32, device=weight.device)
-    hip.check((L.otp_dense_x3_pack if x3 else L.otp_dense_cc_pack)(hip.ptr(w), hip.ptr(sc), hip.ptr(sh), hip.ptr(packed), c,
-                                                                    hip.stream_of(w)), "otp_dense_cc_pack")
+    pack = (L.otp_dense_x3_pack_bf16p if grad else L.otp_dense_x3_pack) if x3 else L.otp_dense_cc_pack
+    hip.check(pack(hip.ptr(w), hip.ptr(sc), hip.ptr(sh), hip.ptr(packed), c, hip.stream_of(w)), "otp_dense_cc_pack")
     return packed
 
 
@@ -637,13 +638,14 @@ def dense_cc_args(xs, packs, ress, outs):
     return arr(xs), arr(packs), arr(ress if ress is not None else [None] * n), arr(outs)
 
 
-def dense_cc(xs, packs, ress=None, outs=None, stream=None, x3=False):
-    """out[p] = scale[p] * (W[p] . x[p]) + shift[p] (+ res[p]) for up to three (B, C, T) problems in one launch."""
+def dense_cc(xs, packs, ress=None, outs=None, stream=None, x3=False, grad=False):
+    """out[p] = scale[p] * (W[p] . x[p]) + shift[p] (+ res[p]) for up to three (B, C, T) problems in one launch (``grad``: see
+    :func:`pack_dense_cc`)."""
     _require_gpu(*xs)
     b, c, t = xs[0].shape
     outs = [torch.empty_like(x) for x in xs] if outs is None else outs
     ax, ap, ar, ao = dense_cc_args(xs, packs, ress, outs)
-    fn = hip.lib().otp_dense_x3 if x3 else hip.lib().otp_dense_cc
+    fn = (hip.lib().otp_dense_x3_bf16p if grad else hip.lib().otp_dense_x3) if x3 else hip.lib().otp_dense_cc
     hip.check(fn(ax, ap, ar, ao, len(xs), b, c, t, stream if stream is not None else hip.stream_of(xs[0])), "otp_dense_cc")
     return outs
 

@@ -69,13 +69,14 @@ def _dense_cc(cin, cout, k, stride, pad, hw):
             and ops.dense_cc_supported(cin, hw))
 
 
-def _dense_cc_launch(x4, w2, bias, out4):
+def _dense_cc_launch(x4, w2, bias, out4, grad=False):
     from . import ops
     n, c = x4.shape[:2]
-    # split-half products (csrc/densex.hip) unless the exact-fp32 kernels are asked for, as in the inference engine
+    # split products (csrc/densex.hip) unless the exact-fp32 kernels are asked for, as in the inference engine; ``grad``: x4 is a
+    # gradient - bfloat16 pieces (csrc/densex_grad.hip), an IEEE-half piece would flush the small ones to zero
     x3 = os.environ.get("OTPOSE_CONV_MATH", "x3") != "f32" and ops.dense_x3_supported(c, x4.shape[2] * x4.shape[3])
-    pk = ops.pack_dense_cc(w2, None, bias, x3=x3)
-    ops.dense_cc([x4.view(n, c, -1)], [pk], None, [out4.view(n, c, -1)], x3=x3)
+    pk = ops.pack_dense_cc(w2, None, bias, x3=x3, grad=grad)
+    ops.dense_cc([x4.view(n, c, -1)], [pk], None, [out4.view(n, c, -1)], x3=x3, grad=grad)
 
 
 def _winograd(cin, cout, d):
@@ -101,7 +102,7 @@ def conv2d_grad_input(grad_out, weight, in_shape, stride, pad, dil):
         g = gd
     gx = torch.empty(in_shape, dtype=torch.float32, device=g.device)
     if _dense_cc(cin, cout, kh, stride, pad, h * w):
-        _dense_cc_launch(g, weight.reshape(cout, cin).t(), None, gx)         # dx = W^T . dy
+        _dense_cc_launch(g, weight.reshape(cout, cin).t(), None, gx, grad=True)         # dx = W^T . dy
         return gx
     iv, ov = View(g), View(gx)
     d = conv_desc(iv, ov, cin, kh, kw, 1, dil * (kh - 1) - pad, dil, ACT_NONE)
@@ -526,14 +527,15 @@ class ChanAttnFunction(Function):
         hip.check(L.otp_transpose_scale(hip.ptr(gout), hip.ptr(d_o), bh, t, hs, 1.0, st), "otp_transpose_scale")
         ns = L.otp_chan_attn_splits(bh, t)
         slabs = new(bh * ns * hsp * hsp)
-        hip.check(L.otp_chan_attn_scores(hip.ptr(d_o), hip.ptr(v), hip.ptr(slabs), bh, hs, t, st), "otp_chan_attn_scores")
+        # (every product of the backward has a gradient operand: bfloat16 pieces - csrc/transformer_grad.hip)
+        hip.check(L.otp_chan_attn_scores_bf16p(hip.ptr(d_o), hip.ptr(v), hip.ptr(slabs), bh, hs, t, st), "otp_chan_attn_scores")
         d_s, d_st, p_t = new(bh, hsp, hsp), new(bh, hsp, hsp), new(bh, hsp, hsp)
         hip.check(L.otp_softmax_backward(hip.ptr(slabs), hip.ptr(p), hip.ptr(d_s), hip.ptr(d_st), hip.ptr(p_t), bh, hs, ns,
                                          st), "otp_softmax_backward")
         tmp = new(bh, t, hs)
         grads = []
         for src, mat, sc in ((k, d_s, scale), (q, d_st, scale), (d_o, p_t, 1.0)):
-            hip.check(L.otp_chan_attn_apply(hip.ptr(src), hip.ptr(mat), hip.ptr(tmp), bh, hs, t, st), "otp_chan_attn_apply")
+            hip.check(L.otp_chan_attn_apply_bf16p(hip.ptr(src), hip.ptr(mat), hip.ptr(tmp), bh, hs, t, st), "otp_chan_attn_apply")
             g = new(b, c, t)
             hip.check(L.otp_transpose_scale(hip.ptr(tmp), hip.ptr(g), bh, t, hs, sc, st), "otp_transpose_scale")
             grads.append(g)
