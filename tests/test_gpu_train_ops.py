@@ -257,3 +257,37 @@ def test_scale_residual_matches_autograd(b, c, t, masked):
     _close(xd.grad, xr.grad)
     _close(ad.grad, ar.grad)
     _close(sd.grad, sr.grad, 1e-4)
+
+
+@pytest.mark.parametrize("mag", [1.0, 1e-5, 1e-8])
+def test_gradient_operands_of_any_magnitude_keep_their_precision(mag):
+    """The backward sends GRADIENTS through the projection and the attention products.  Their magnitude is whatever the loss
+    makes it; the split products of those calls therefore use bfloat16 pieces (csrc/densex_grad.hip, transformer_grad.hip:
+    16-17 bits at any magnitude), not the IEEE-half pieces of the forward, which flush 1e-8 to zero and hold 1e-5 to 8 bits."""
+    from otpose_amd import ops
+    from otpose_amd import train_ops as T
+    c, t = 136, 520
+    w = seeded((c, c, 1, 1), 5) / math.sqrt(c)
+    gy = (seeded((2, c, 1, t), 6) * mag).cuda()
+    gx = T.conv2d_grad_input(gy, w.cuda(), (2, c, 1, t), 1, 0, 1)
+    ref = torch.einsum("oi,nohw->nihw", w.view(c, c).double(), gy.cpu().double())
+    err = float((gx.cpu().double() - ref).abs().max()) / float(ref.abs().max())
+    assert err <= 3e-5, err
+    # what the forward's half pieces would make of the same operand (why the second copy of the kernels exists)
+    pk = ops.pack_dense_cc(w.view(c, c).t().contiguous().cuda(), x3=True)
+    half = ops.dense_cc([gy.view(2, c, t)], [pk], x3=True)[0]
+    err_half = float((half.cpu().double().view_as(ref) - ref).abs().max()) / float(ref.abs().max())
+    assert (err_half > 10 * err) == (mag < 1e-3), (err, err_half)
+    # attention backward: dS = dO v^T and the three applies all carry a gradient operand
+    hs, nh = 68, 2
+    q, k, v = (seeded((2, c, t), s_) * 0.3 for s_ in (1, 2, 3))
+    go = seeded((2, c, t), 4) * mag
+    leaves = [z.clone().cuda().requires_grad_() for z in (q, k, v)]
+    T.chan_attn(*leaves, nh, 1.0 / math.sqrt(hs)).backward(go.cuda())
+    refs = [z.clone().double().requires_grad_() for z in (q, k, v)]
+    qq, kk, vv = (z.view(2, nh, hs, -1) for z in refs)
+    att = F.softmax((qq / math.sqrt(hs)) @ kk.transpose(-2, -1), dim=-1)
+    (att @ vv).transpose(2, 3).contiguous().view(2, c, -1).backward(go.double())
+    for a, b in zip(leaves, refs):
+        e = float((a.grad.cpu().double() - b.grad).abs().max()) / float(b.grad.abs().max())
+        assert e <= 2e-4, e
