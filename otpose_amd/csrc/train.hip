@@ -403,14 +403,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restr
 
 // dW[co][ci][tap] += sum over the gx workgroups of one (co-group, ci-group) of their partial accumulators, in a FIXED order
 // (round 4: no float atomics - the result is the same bits on every run).  grid (blocks of 32 per-wave fragment slots,
-// co-group * ci-group); 256 threads = 32 slots x 8 segments of the workgroup range; the segments meet in LDS and are added
-// in order.  A thread walks the four waves' copies of its slot: with 1x1 kernels the waves split the pixel steps of the same
-// (co, ci) tile, so their sums are added (wave order) into ONE weight; otherwise each wave's slot is a weight of its own.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int gx,
-                                                            int gy, int Cout, int Cin, int KS) {
+// co-group * ci-group); 1024 threads = 32 slots x 8 segments of the workgroup range x the four waves' copies of a slot; the
+// segments meet in LDS and are added in order.  With 1x1 kernels the waves split the pixel steps of the same (co, ci) tile, so
+// their sums are added (wave order) into ONE weight; otherwise each wave's slot is a weight of its own.
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int gx,
+                                                             int gy, int Cout, int Cin, int KS) {
     __shared__ float red[4][8][32];
     constexpr int WSLOTS = WG_SLOTS / 4;                                // slots of one wave: [g][b][r][lane]
-    const int sl = threadIdx.x & 31, sg = threadIdx.x >> 5;
+    // 1024 threads = 32 slots x 8 segments x the 4 waves' copies (256 threads walking the four copies one after the other were a
+    // latency chain: 35 us per launch beside the backward's other kernels)
+    const int sl = threadIdx.x & 31, sg = (threadIdx.x >> 5) & 7, wave = threadIdx.x >> 8;
     const int sub = blockIdx.x * 32 + sl;
     const int seg = (gx + 7) >> 3;
     const int w0 = sg * seg, w1 = min(gx, w0 + seg);
@@ -422,8 +424,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     const int ncib_ = min(3, (Cin - bz_ * WG_CI + 15) >> 4), ncob_ = min(3, (Cout - by_ * WG_CO + 15) >> 4);
     const int KK_ = KS * KS, ncombo_ = KK_ * ncib_;
     const bool row_ok = sub < WSLOTS && b_ < ncob_ && by_ * WG_CO + b_ * 16 + (lane_ >> 4) * 4 + r_ < Cout;
-#pragma unroll
-    for (int wave = 0; wave < 4; ++wave) {
+    {
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         const int combo_ = KK_ == 1 ? g_ : wave + 4 * g_;
         const bool live = row_ok && combo_ < ncombo_ &&
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         red[wave][sg][sl] = (s0 + s1) + (s2 + s3);
     }
     __syncthreads();
-    if (sg != 0 || sub >= WSLOTS) return;
+    if (threadIdx.x >= 32 || sub >= WSLOTS) return;
     const int lane = sub & 63, r = (sub >> 6) & 3, gb = sub >> 8;       // gb = g * 3 + b
     const int b = gb % 3, g = gb / 3;
     const int by = blockIdx.y % gy, bz = blockIdx.y / gy;
@@ -451,12 +452,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     if (b >= ncob || co >= Cout) return;
     float total = 0.f;
 #pragma unroll
-    for (int wave = 0; wave < 4; ++wave) {
-        float v = red[wave][0][sl];
+    for (int wv = 0; wv < 4; ++wv) {
+        float v = red[wv][0][sl];
 #pragma unroll
-        for (int k = 1; k < 8; ++k) v += red[wave][k][sl];
+        for (int k = 1; k < 8; ++k) v += red[wv][k][sl];
         if (split_steps) { total += v; continue; }
-        const int combo = wave + 4 * g;
+        const int combo = wv + 4 * g;
         if (combo >= ncombo) continue;
         const int tap = combo / ncib, cib = combo - tap * ncib;
         const int ci = ci0 + cib * 16 + (lane & 15);
@@ -842,7 +843,7 @@ extern "C" int otp_conv2d_wgrad(const void* x, const void* grad_out, void* grad_
     hipLaunchKernelGGL(kern, dim3(gx, gy, gz), dim3(256), lds, st, static_cast<const float*>(x),
                        static_cast<const float*>(grad_out), static_cast<float*>(grad_weight), part, P);
     if (part)
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(otp_ceil_div(WG_SLOTS / 4, 32), gy * gz), dim3(256), 0, st, part,
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(otp_ceil_div(WG_SLOTS / 4, 32), gy * gz), dim3(1024), 0, st, part,
                            static_cast<float*>(grad_weight), gx, gy, Cout, Cin, kh);
     return otp_launch_status();
 }

@@ -287,16 +287,39 @@ __global__ __launch_bounds__(DWW_THREADS) void dwconv3_bwd_w_kernel(const float*
                                                                      int stride) {
     __shared__ float red[3][DWW_THREADS / 64];
     const int c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const size_t total = (size_t)B * To;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    for (size_t i = threadIdx.x; i < total; i += DWW_THREADS) {
-        const int b = (int)(i / To), to = (int)(i - (size_t)b * To);
-        const float* xr = x + ((size_t)b * C + c) * T;
-        const float g = dy[((size_t)b * C + c) * To + to];
-        const int t0 = to * stride - 1;
-        if (t0 >= 0) s0 += g * xr[t0];
-        s1 += g * xr[t0 + 1];
-        if (t0 + 2 < T) s2 += g * xr[t0 + 2];
+    if (stride == 1 && (T & 3) == 0) {
+        // rows of T = To floats, 16-byte aligned: a thread takes four consecutive time steps per pass (one float4 of dy, one of x
+        // and the two neighbours), two passes in flight - the one-element loop below ran at 1.3 TB/s (91 us at 16 x 136 x 6912)
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const int q4 = T >> 2, groups = B * q4;
+        auto one = [&](int i) __attribute__((always_inline)) {
+            const int b = i / q4, t = (i - b * q4) << 2;
+            const float* xr = x + ((size_t)b * C + c) * T + t;
+            const f32x4 g = *reinterpret_cast<const f32x4*>(dy + ((size_t)b * C + c) * T + t);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(xr);
+            const float left = t > 0 ? xr[-1] : 0.f, right = t + 4 < T ? xr[4] : 0.f;
+            s0 += g[0] * left + g[1] * v[0] + g[2] * v[1] + g[3] * v[2];
+            s1 += g[0] * v[0] + g[1] * v[1] + g[2] * v[2] + g[3] * v[3];
+            s2 += g[0] * v[1] + g[1] * v[2] + g[2] * v[3] + g[3] * right;
+        };
+        int i = threadIdx.x;
+        for (; i + DWW_THREADS < groups; i += 2 * DWW_THREADS) {
+            one(i);
+            one(i + DWW_THREADS);
+        }
+        if (i < groups) one(i);
+    } else {
+        const size_t total = (size_t)B * To;
+        for (size_t i = threadIdx.x; i < total; i += DWW_THREADS) {
+            const int b = (int)(i / To), to = (int)(i - (size_t)b * To);
+            const float* xr = x + ((size_t)b * C + c) * T;
+            const float g = dy[((size_t)b * C + c) * To + to];
+            const int t0 = to * stride - 1;
+            if (t0 >= 0) s0 += g * xr[t0];
+            s1 += g * xr[t0 + 1];
+            if (t0 + 2 < T) s2 += g * xr[t0 + 2];
+        }
     }
     s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
     if (lane == 0) { red[0][wave] = s0; red[1][wave] = s1; red[2][wave] = s2; }
