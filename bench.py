@@ -113,7 +113,7 @@ def measured_traffic(key, with_source=False):
     in separate passes and corrected as MI355X_MICROARCH.md prescribes; see profiles/r02_traffic.json for the split-bf16
     kernels and profiles/r01_traffic.json for the f32 ones).  None when the files or the key are absent: PMC counters cannot
     be read from inside this process."""
-    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in ("r04c_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 v = json.load(f).get(key, {}).get("hbm_bytes_per_launch")

@@ -807,37 +807,43 @@ bool make_wgrad_plan(const otp_nhwc_conv_desc* d, WgradPlan* p) {
 // BatchNorm (batch statistics) on NHWC bf16, fp32 arithmetic
 // ---------------------------------------------------------------------------------------------------------------------
 // partial sums [rows][2][C] -> mean / rstd, scale = gamma*rstd, shift = beta - mean*scale, running statistics update
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int rows, int C, int Ctrue, float count,
+constexpr int BNF_RL = 128;                 // row lanes of the two finalize kernels (8 channels x BNF_RL rows = 1024 threads)
+__global__ __launch_bounds__(8 * BNF_RL) void bn_finalize_kernel(const float* __restrict__ part, int rows, int C, int Ctrue, float count,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            float* __restrict__ mean_o, float* __restrict__ rstd_o,
                                                            float* __restrict__ scale_o, float* __restrict__ shift_o,
                                                            float* __restrict__ run_mean, float* __restrict__ run_var, float eps,
                                                            float momentum) {
-    // 8 channels x 32 row lanes per workgroup: the partial rows (up to N * tiles of the conv) are the long axis
-    __shared__ double red[2][32][8];
+    // 8 channels x 128 row lanes per workgroup: the partial rows (up to N * tiles of the conv) are the long axis
+    __shared__ double red[2][BNF_RL][8];
     const int cl = threadIdx.x & 7, rq = threadIdx.x >> 3, c = blockIdx.x * 8 + cl;
     double s1 = 0.0, s2 = 0.0;
     if (c < C) {
         int r = rq;
-        for (; r + 96 < rows; r += 128) {
+        for (; r + 3 * BNF_RL < rows; r += 4 * BNF_RL) {
             float a[4], b[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                a[j] = part[((size_t)(r + 32 * j) * 2) * C + c];
-                b[j] = part[((size_t)(r + 32 * j) * 2 + 1) * C + c];
+                a[j] = part[((size_t)(r + BNF_RL * j) * 2) * C + c];
+                b[j] = part[((size_t)(r + BNF_RL * j) * 2 + 1) * C + c];
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) s1 += (double)a[j], s2 += (double)b[j];
         }
-        for (; r < rows; r += 32) {
+        for (; r < rows; r += BNF_RL) {
             s1 += (double)part[((size_t)r * 2) * C + c];
             s2 += (double)part[((size_t)r * 2 + 1) * C + c];
         }
     }
     red[0][rq][cl] = s1, red[1][rq][cl] = s2;
     __syncthreads();
+    if (rq < 16) {                                  // fixed-order fold: 128 -> 16 row lanes, then one thread per channel
+        for (int k = rq + 16; k < BNF_RL; k += 16) s1 += red[0][k][cl], s2 += red[1][k][cl];
+        red[0][rq][cl] = s1, red[1][rq][cl] = s2;
+    }
+    __syncthreads();
     if (rq == 0 && c < C) {
-        for (int k = 1; k < 32; ++k) s1 += red[0][k][cl], s2 += red[1][k][cl];
+        for (int k = 1; k < 16; ++k) s1 += red[0][k][cl], s2 += red[1][k][cl];
         const double m = s1 / count;
         double var = s2 / count - m * m;
         if (var < 0.0) var = 0.0;
@@ -940,35 +946,42 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16* __restri
 }
 
 // partials -> dgamma, dbeta, and the three per-channel coefficients of pass 2
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int rows, int C, int Ctrue,
-                                                               float count, const float* __restrict__ gamma,
-                                                               const float* __restrict__ rstd, float* __restrict__ dgamma,
-                                                               float* __restrict__ dbeta, float* __restrict__ coef) {
-    // 8 channels x 32 row lanes per workgroup: the partial rows (up to N * tiles of the conv) are the long axis
-    __shared__ double red[2][32][8];
+__global__ __launch_bounds__(8 * BNF_RL) void bn_bwd_finalize_kernel(const float* __restrict__ part, int rows, int C, int Ctrue,
+                                                                      float count, const float* __restrict__ gamma,
+                                                                      const float* __restrict__ rstd, float* __restrict__ dgamma,
+                                                                      float* __restrict__ dbeta, float* __restrict__ coef) {
+    // 8 channels x 128 row lanes per workgroup: the partial rows (up to N * tiles of the conv, 2160 at 96x72 x 80) are the long
+    // axis - with 32 row lanes this launch, between the two HBM passes of every layer's BatchNorm backward, was a 15 us chain
+    __shared__ double red[2][BNF_RL][8];
     const int cl = threadIdx.x & 7, rq = threadIdx.x >> 3, c = blockIdx.x * 8 + cl;
     double s1 = 0.0, s2 = 0.0;
     if (c < C) {
         int r = rq;
-        for (; r + 96 < rows; r += 128) {
+        for (; r + 3 * BNF_RL < rows; r += 4 * BNF_RL) {
             float a[4], b[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                a[j] = part[((size_t)(r + 32 * j) * 2) * C + c];
-                b[j] = part[((size_t)(r + 32 * j) * 2 + 1) * C + c];
+                a[j] = part[((size_t)(r + BNF_RL * j) * 2) * C + c];
+                b[j] = part[((size_t)(r + BNF_RL * j) * 2 + 1) * C + c];
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) s1 += (double)a[j], s2 += (double)b[j];
         }
-        for (; r < rows; r += 32) {
+        for (; r < rows; r += BNF_RL) {
             s1 += (double)part[((size_t)r * 2) * C + c];
             s2 += (double)part[((size_t)r * 2 + 1) * C + c];
         }
     }
     red[0][rq][cl] = s1, red[1][rq][cl] = s2;
     __syncthreads();
+    // fold the row lanes in a fixed order: 128 -> 16 on the first 16 row lanes, then one thread per channel
+    if (rq < 16) {
+        for (int k = rq + 16; k < BNF_RL; k += 16) s1 += red[0][k][cl], s2 += red[1][k][cl];
+        red[0][rq][cl] = s1, red[1][rq][cl] = s2;
+    }
+    __syncthreads();
     if (rq == 0 && c < C) {
-        for (int k = 1; k < 32; ++k) s1 += red[0][k][cl], s2 += red[1][k][cl];
+        for (int k = 1; k < 16; ++k) s1 += red[0][k][cl], s2 += red[1][k][cl];
         const bool live = c < Ctrue;
         if (live) dbeta[c] = (float)s1, dgamma[c] = (float)s2;
         const float k1 = live ? gamma[c] * rstd[c] : 0.f;
@@ -1347,7 +1360,7 @@ extern "C" int otp_nhwc_bn_finalize(const void* partials, int rows, int C, int C
                                     void* running_var, float eps, float momentum, void* stream) {
     if (!partials || !gamma || !beta || !mean || !rstd || !scale || !shift || rows <= 0 || C <= 0 || CS < C)
         return OTP_ERR_BAD_ARG;
-    bn_finalize_kernel<<<(CS + 7) / 8, 256, 0, static_cast<hipStream_t>(stream)>>>(
+    bn_finalize_kernel<<<(CS + 7) / 8, 8 * BNF_RL, 0, static_cast<hipStream_t>(stream)>>>(
         static_cast<const float*>(partials), rows, CS, C, count, static_cast<const float*>(gamma), static_cast<const float*>(beta),
         static_cast<float*>(mean), static_cast<float*>(rstd), static_cast<float*>(scale), static_cast<float*>(shift),
         static_cast<float*>(running_mean), static_cast<float*>(running_var), eps, momentum);
@@ -1405,7 +1418,7 @@ extern "C" int otp_nhwc_bn_backward(const void* gy, const void* y, const void* x
         bn_bwd_reduce_kernel<R><<<rows, 256, lds, st>>>(static_cast<const bf16*>(gy), static_cast<const bf16*>(y),    \
                                                         static_cast<const bf16*>(x), static_cast<const float*>(mean), \
                                                         static_cast<const float*>(rstd), part, pixels, C8, ppw, relu); \
-        bn_bwd_finalize_kernel<<<(CS + 7) / 8, 256, 0, st>>>(part, rows, CS, C, (float)pixels,                         \
+        bn_bwd_finalize_kernel<<<(CS + 7) / 8, 8 * BNF_RL, 0, st>>>(part, rows, CS, C, (float)pixels,                         \
                                                              static_cast<const float*>(gamma),                        \
                                                              static_cast<const float*>(rstd), static_cast<float*>(dgamma), \
                                                              static_cast<float*>(dbeta), coef);                       \
