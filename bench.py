@@ -221,7 +221,7 @@ def kernel_rooflines(dev, batch):
         extra = {"arithmetic": "fp32 accumulate; operands stored as IEEE-half hi | lo records (hi = rne(x), lo = rne(x - hi)), products "
                                "lo*hi + hi*lo + hi*hi on v_mfma_f32_16x16x32_f16; weights stored times a per-layer power of two so that both "
                                "pieces are normal numbers (csrc/convs.hip, otp_conv_desc.out_scale)",
-                 "pmc": "committed profile, not collected in this run - profiles/r03c_convs_pmc_fold.txt: SQ_INSTS_VALU 11.07 M of which 4.67 M MFMA = 1.37 other vector "
+                 "pmc": "committed profile, not collected in this run - profiles/r04c_convs_pmc_fold.txt: SQ_INSTS_VALU 11.18 M of which 4.67 M MFMA = 1.40 other vector "
                         "instructions per MFMA (prologue / epilogue), SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 6 %",
                  "conv2_form": {"what": "S8 + C4 residual -> C4 + S8 (BasicBlock conv2)", "ms_per_launch": t_conv2,
                                 "achieved": conv_flop / (t_conv2 * 1e-3) / 1e12, "frac": conv_flop / (t_conv2 * 1e-3) / peak,
