@@ -1,7 +1,9 @@
-"""Development tool (GPU box): nhwc_conv_kernel with one against two pixel tiles per workgroup (OTP_NHWC_NT, read once per
-process - the tool starts itself once per setting BEFORE anything touches the GPU), forward conv of the HRNet branch shapes and
-a few others, 80 frames, microseconds per launch (HIP events, 30 launches) and agreement of the two results.
-usage: python tools/nhwc_nt_ab.py"""
+"""Development tool (GPU box): A / B of two builds of the library on nhwc_conv_kernel - forward conv of the HRNet branch shapes
+and a few others, 80 frames, microseconds per launch (HIP events, 30 launches) and agreement of the two results.  The tool starts
+itself once per build (OTPOSE_HIP_LIB) BEFORE anything touches the GPU.  Round 4 used it for two experiments:
+profiles/r04_nhwc_two_tiles_ab.txt (two pixel tiles per workgroup, a build switch that is no longer in the tree) and
+profiles/r04_nhwc_minwg_ab.txt (-DOTP_NHWC_MINWG=3: register budget for three workgroups per CU).
+usage: python tools/nhwc_nt_ab.py <libA.so> <libB.so>"""
 import os
 import subprocess
 import sys
@@ -33,13 +35,15 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.exit(0)
 
 res = {}
+libs = {"1": os.path.abspath(sys.argv[1]), "2": os.path.abspath(sys.argv[2])}
 for nt in ("1", "2"):
-    env = dict(os.environ, OTP_NHWC_NT=nt)
+    env = dict(os.environ, OTPOSE_HIP_LIB=libs[nt])
     r = subprocess.run([sys.executable, __file__, "child"], env=env, capture_output=True, text=True, timeout=600)
     if r.returncode:
         print(r.stderr[-2000:])
         sys.exit(1)
     res[nt] = [ln.split() for ln in r.stdout.splitlines() if ln and ln[0].isdigit()]
-print("%-28s %10s %10s   %s" % ("shape (80 frames, forward)", "NT=1 us", "NT=2 us", "same result"))
+print("A = %s\nB = %s" % (sys.argv[1], sys.argv[2]))
+print("%-28s %10s %10s   %s" % ("shape (80 frames, forward)", "A us", "B us", "same result"))
 for a, b in zip(res["1"], res["2"]):
     print("%-28s %10s %10s   %s" % ("%s->%s k%s @%sx%s" % (a[0], a[1], a[4], a[2], a[3]), a[5], b[5], a[6:] == b[6:]))
