@@ -58,6 +58,7 @@ struct ConvPlan {
     int MB, NB, BM, nM, P, tilesPerImg;
     int RW, rowsMax;
     int ldsW, ldsX, ldsTab, lds;
+    int pipe;                                 // the chunk pipeline of nhwc_conv_kernel applies (see there)
     size_t wbytes;
 };
 
@@ -102,6 +103,14 @@ bool size_plan(const otp_nhwc_conv_desc* d, ConvPlan* p, int ck, int nb) {
     p->ldsTab = round_up(p->KS * 4 * 4, 16);
     p->lds = p->ldsW + p->ldsX + p->ldsTab + 4 * 2 * p->BM * 4;
     p->wbytes = (size_t)p->nChunks * p->nM * p->ldsW;
+    {
+        // chunk pipeline: 256 threads hold one chunk's window (one (column, channel group) unit x 8 rows per thread, 256 / units-per-
+        // row row groups) and weight slab (PIPE_WU(MB) 16-byte units per thread) in registers
+        const int rowUnits = p->RW * p->CK8;
+        static const int min_chunks = getenv("OTP_NHWC_PIPE_MIN_CHUNKS") ? atoi(getenv("OTP_NHWC_PIPE_MIN_CHUNKS")) : 3;
+        p->pipe = p->KS == 7 && p->nChunks >= min_chunks && rowUnits <= 256 && p->rowsMax <= 8 * (256 / rowUnits) &&
+                  p->ldsW / 16 <= 256 * ((448 * (p->BM / 16) + 255) / 256);
+    }
     return p->lds <= OTP_LDS_LIMIT;
 }
 
@@ -311,7 +320,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[MB][NB], const bool (
     }
 }
 
-template <int MB, int NB, bool K7>
+template <int MB, int NB, bool K7, bool PIPE>
 __global__ __launch_bounds__(256) void nhwc_conv_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wpk,
                                                          const float* __restrict__ bias, const bf16* __restrict__ res,
                                                          bf16* __restrict__ out, float* __restrict__ out_f32,
@@ -364,6 +373,71 @@ __global__ __launch_bounds__(256) void nhwc_conv_kernel(const bf16* __restrict__
     const int rowUnits = p.RW * p.CK8;
     const otp_rsrc xres = make_rsrc(x, (size_t)p.N * p.H * p.W * p.CinS * 2);
     OTP_STAMP(1);
+    if constexpr (K7 && PIPE) {
+        {
+            // ---- chunk pipeline (3x3 taps x 24-channel chunks, more than one chunk): the window and the weight slab of chunk c + 1
+            // are loaded into REGISTERS while chunk c is multiplied, and go to the LDS between two barriers.  Without it a
+            // workgroup's life at 48 -> 48 @96x72 is 29 k cycles for 6 k of MFMA work - load -> LDS store -> barrier -> multiply
+            // with nothing in flight, hidden only by the other workgroups of the CU.  No branch around
+            // the loads (hipcc would wait for every outstanding load at the join): a load that is not wanted points past its
+            // descriptor and returns zeros.
+            constexpr int WU = (448 * MB + 255) / 256;                 // 16-byte weight units per thread: 7 k-steps x 4 x BM x 16 B
+            const int G = 256 / rowUnits, grp = tid / rowUnits, cu = tid - grp * rowUnits;
+            const int col = cu / p.CK8, cgi = cu - col * p.CK8, ix = col - p.pad;
+            const bool colIn = grp < G && ix >= 0 && ix < p.W;
+            const int ldst = col * p.CKp + cgi * 8;
+            const otp_rsrc wres = make_rsrc(wpk, p.wbytes);
+            u32x4 xv[8], wv[WU];
+            auto issue = [&](int ch) __attribute__((always_inline)) {
+                const int c = ch * p.CK + cgi * 8;
+                const bool colOK = colIn && ch < p.nChunks && c < p.CinS;
+                const int gcol = (ix * p.CinS + c) * 2;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int r = grp * 8 + j, iy = rowLo + r;
+                    const bool ok = colOK && r < nrows && iy >= 0 && iy < p.H;
+                    xv[j] = bload16(xres, ok ? (n * p.H + iy) * (p.W * p.CinS * 2) + gcol : OOB);
+                }
+                const int wbase = (ch * p.nM + mt) * wunits * 16;
+#pragma unroll
+                for (int i = 0; i < WU; ++i) {
+                    const int u = tid + 256 * i;
+                    wv[i] = bload16(wres, (u < wunits && ch < p.nChunks) ? wbase + u * 16 : OOB);
+                }
+            };
+            issue(0);
+            for (int ch = 0; ch < p.nChunks; ++ch) {
+                if (ch) __syncthreads();                                  // every wave has left the previous chunk's images
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (grp < G && grp * 8 + j < nrows) *reinterpret_cast<u32x4*>(sX + (grp * 8 + j) * (p.RW * p.CKp) + ldst) = xv[j];
+#pragma unroll
+                for (int i = 0; i < WU; ++i)
+                    if (tid + 256 * i < wunits) *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(sW) + (tid + 256 * i) * 16) = wv[i];
+                __syncthreads();
+                if (ch == 0) OTP_STAMP(2);
+                issue(ch + 1);                                            // in flight under this chunk's MFMAs
+#pragma unroll
+                for (int ks = 0; ks < 7; ++ks) {
+                    const int koff = sTab[ks * 4 + lg];
+                    bf16x8 a[MB];
+#pragma unroll
+                    for (int m = 0; m < MB; ++m) a[m] = *reinterpret_cast<const bf16x8*>(sW + ((ks * 4 + lg) * BM + m * 16 + l15) * 8);
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const bf16x8 b = *reinterpret_cast<const bf16x8*>(sX + boff[nb] + koff);
+#pragma unroll
+                        for (int m = 0; m < MB; ++m) acc[m][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], b, acc[m][nb], 0, 0, 0);
+                    }
+                }
+                if (ch == 0) OTP_STAMP(3);
+            }
+            OTP_STAMP(4);
+            conv_epilogue<MB, NB>(acc, valid, p, bias, res, out, out_f32, stats, smem, sRed, n, tile, mt, p0, npx);
+            OTP_STAMP(5);
+            return;
+        }
+    }
     for (int ch = 0; ch < p.nChunks; ++ch) {
         if (ch) __syncthreads();
         // One L2 round trip per chunk: the first 8 weight units AND the first 8 window rows of this thread are all in
@@ -442,10 +516,10 @@ __global__ __launch_bounds__(256) void nhwc_conv_kernel(const bf16* __restrict__
     OTP_STAMP(5);
 }
 
-template <int MB, int NB, bool K7>
+template <int MB, int NB, bool K7, bool PIPE>
 int launch_conv_k(const ConvPlan& p, const void* x, const void* wpk, const void* bias, const void* res, void* out, void* stats,
                   hipStream_t st) {
-    auto kern = nhwc_conv_kernel<MB, NB, K7>;
+    auto kern = nhwc_conv_kernel<MB, NB, K7, PIPE>;
     OTP_ALLOW_BIG_LDS(kern, p.lds);
     const int grid = p.N * p.tilesPerImg * p.nM;
     kern<<<grid, 256, p.lds, st>>>(static_cast<const bf16*>(x), static_cast<const bf16*>(wpk), static_cast<const float*>(bias),
@@ -457,8 +531,10 @@ int launch_conv_k(const ConvPlan& p, const void* x, const void* wpk, const void*
 template <int MB, int NB>
 int launch_conv(const ConvPlan& p, const void* x, const void* wpk, const void* bias, const void* res, void* out, void* stats,
                 hipStream_t st) {
-    return p.KS == 7 ? launch_conv_k<MB, NB, true>(p, x, wpk, bias, res, out, stats, st)
-                     : launch_conv_k<MB, NB, false>(p, x, wpk, bias, res, out, stats, st);
+    if (p.KS == 7)
+        return p.pipe ? launch_conv_k<MB, NB, true, true>(p, x, wpk, bias, res, out, stats, st)
+                      : launch_conv_k<MB, NB, true, false>(p, x, wpk, bias, res, out, stats, st);
+    return launch_conv_k<MB, NB, false, false>(p, x, wpk, bias, res, out, stats, st);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
