@@ -33,6 +33,13 @@ constexpr int FCIN = 32;                      // channels of `trans`
 constexpr int FBLK = 40960;                   // bytes of one (dilation, group) weight block: 9 taps x 2 n-tiles x (hi, lo) x 1 KB, padded
 constexpr int FPIX = 128;                     // pixels per workgroup (8 waves); the 9-wave form owns 144
 constexpr int FMAXD = 8;                      // dilations per launch
+#ifndef FSCR
+#define FSCR 36
+#endif
+constexpr int FSCR_ = FSCR;                   // floats per pixel row of a wave's sampling scratch (32 channels + padding): with 32 the
+                                              // 16 pixels of a read sat on two banks (50 % of the LDS-active cycles were conflicts,
+                                              // profiles/r04_dcnf_pmc_fold.txt); 36 puts the 16 pixels 4 banks apart and the four
+                                              // row groups of a write 16 banks apart
 
 struct FusedPlan {
     int B, J, H, W, HW, ND, tilesPerImg;
@@ -177,14 +184,14 @@ __global__ __launch_bounds__(64 * NW) void dcn_fused_kernel(const unsigned char*
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* wbuf = smem;                                     // 2 x FBLK
     float* scratch = reinterpret_cast<float*>(smem + 2 * FBLK);     // [8 waves][16 pixels][32 channels]
-    float* wd = scratch + NW * 16 * 32;                             // [J][9][20]
+    float* wd = scratch + NW * 16 * FSCR_;                          // [J][9][20]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i16 = lane & 15, kq = lane >> 4;
     const int n = (int)blockIdx.x / P.tilesPerImg, p0 = ((int)blockIdx.x - n * P.tilesPerImg) * (16 * NW);
     const int p = p0 + wave * 16 + i16;                             // the lane's pixel (both as fragment row and as sampling pixel)
     const int y = p / P.W, xx0 = p - y * P.W;
-    float* scr = scratch + wave * (16 * 32);
+    float* scr = scratch + wave * (16 * FSCR_);
 
     const otp_rsrc rws = make_rsrc32(ws + (size_t)n * P.HW * 128, (unsigned)P.HW * 128u);
     const otp_rsrc rx = make_rsrc32(x + (size_t)n * J * P.HW, (unsigned)(J * P.HW) * 4u);
@@ -240,8 +247,8 @@ __global__ __launch_bounds__(64 * NW) void dcn_fused_kernel(const unsigned char*
             // accumulator (channel i16 / 16 + i16, pixels 4 kq + r) -> scratch[pixel][channel]
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                scr[(4 * kq + r) * 32 + i16] = acc0[r] * post0;
-                scr[(4 * kq + r) * 32 + 16 + i16] = acc1[r] * post1;
+                scr[(4 * kq + r) * FSCR_ + i16] = acc0[r] * post0;
+                scr[(4 * kq + r) * FSCR_ + 16 + i16] = acc1[r] * post1;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -251,7 +258,7 @@ __global__ __launch_bounds__(64 * NW) void dcn_fused_kernel(const unsigned char*
             for (int it = 0; it < 3; ++it) {
                 const bool live = it < kcnt;
                 const int k = live ? kbase + it : kbase;
-                const float oh = scr[i16 * 32 + 2 * k], ow = scr[i16 * 32 + 2 * k + 1], m = scr[i16 * 32 + 18 + k];
+                const float oh = scr[i16 * FSCR_ + 2 * k], ow = scr[i16 * FSCR_ + 2 * k + 1], m = scr[i16 * FSCR_ + 18 + k];
                 const int ky = k / 3, kx = k - 3 * ky;
                 const float h = (float)(y + (ky - 1) * d) + oh, w = (float)(xx0 + (kx - 1) * d) + ow;
                 const bool inside = h > -1.f && w > -1.f && h < (float)P.H && w < (float)P.W;
@@ -356,7 +363,7 @@ extern "C" int otp_dcn_fused_forward(const void* trans, const void* x, const voi
     const size_t nsplit = (size_t)B * P.HW * 4;
     hipLaunchKernelGGL(dcnf_split_kernel, dim3((unsigned)((nsplit + 255) / 256 > 4096 ? 4096 : (nsplit + 255) / 256)), dim3(256), 0,
                        st, static_cast<const float*>(trans), static_cast<u32x4*>(workspace), B, P.HW);
-    const size_t lds = 2 * (size_t)FBLK + (size_t)(px / 16) * 16 * 32 * 4 + (size_t)17 * 9 * 20 * 4 + 64;
+    const size_t lds = 2 * (size_t)FBLK + (size_t)(px / 16) * 16 * FSCR_ * 4 + (size_t)17 * 9 * 20 * 4 + 64;
     if (nine) {
         auto kern = dcn_fused_kernel<17, 9>;
         OTP_ALLOW_BIG_LDS(kern, lds);
