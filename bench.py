@@ -470,8 +470,10 @@ def train_step_probe(cfg, dev, batch, dtype="bf16", steps=3, dist=None):
                         "peak": (PEAK_BF16_MATRIX if dtype == "bf16" else PEAK_F32_MATRIX) / 1e12, "unit": "TFLOP/s per GPU",
                         "frac": flop / t / world / (PEAK_BF16_MATRIX if dtype == "bf16" else PEAK_F32_MATRIX),
                         "traffic": None,
-                        "note": "algorithmic 3 x 409 GFLOP per clip; at bf16 the step is bound by HBM / L2 traffic and launch "
-                                "latency of ~9000 kernels, not by the matrix pipe (see DESIGN.md section 5)"}}
+                        "note": "algorithmic 3 x 409 GFLOP per clip; the step is GPU-bound (host side 85-100 ms, hidden; a one-stream "
+                                "hipGraph replays no faster than the one-stream eager step: profiles/r04_train_graph_probe.txt) - "
+                                "~200 ms of kernel time on four streams, the bf16 conv kernel bound by the latency of its "
+                                "staging, not by the matrix pipe (DESIGN.md sections 3.6 and 5)"}}
     del model, opt, loss
     torch.cuda.empty_cache()
     return res
