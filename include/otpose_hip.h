@@ -106,6 +106,10 @@ typedef struct otp_conv_desc {
      * numbers - 22 significand bits per weight instead of ~17 for BatchNorm-folded weights of magnitude 0.01 - and the kernel
      * multiplies the accumulated sum by out_scale = 2^-k before shift / residual / activation.  0 means 1. */
     float out_scale;
+    /* otp_conv3x3_s8 only: layout of the residual image.  0: C4 fp32 image [N][Cout / 4][H * W][4] (the default);
+     * 1: S8 records [N][Cout / 8][hi | lo][H * W] - a block's input image serves as its residual (hi + lo holds it to 2^-22),
+     * so a chain of BasicBlocks needs no fp32 image between its blocks. */
+    int res_layout;
 } otp_conv_desc;
 
 /* tuning / test hook: force the (M-blocks, pixel-blocks, waves-in-M, waves-in-pixels) tile of otp_conv2d;
@@ -178,8 +182,9 @@ int otp_conv2d_x3(const void* in, const void* wpacked, const void* shift, const 
 #define OTP_S8_F32_NCHW 2
 size_t otp_s8_bytes(int N, int C, int H, int W);
 int otp_s8_pack(const void* in_f32, void* out_s8, void* out_c4, int N, int C, int H, int W, int in_ctot, int in_coff, void* stream);
-/* otp_upsample_add_multi (a fuse row's upsampled terms, model/HRNet.py:487-494) writing the S8 and C4 images of its result -
- * what the next module's branch reads - and the NCHW tensor only when out_nchw != NULL; same additions in the same order */
+/* otp_upsample_add_multi (a fuse row's upsampled terms, model/HRNet.py:487-494) writing the S8 image of its result - what the
+ * next module's branch reads - the C4 image when out_c4 != NULL (a branch that takes its residual from an fp32 image:
+ * otp_conv_desc.res_layout = 0) and the NCHW tensor only when out_nchw != NULL; same additions in the same order */
 int otp_s8_upsample_add(const void* const* lows, const int* factors, int nlow, const void* res, void* out_nchw, void* out_s8,
                         void* out_c4, int N, int C, int Hh, int Wh, int relu, int res_ctot, int res_coff, int out_ctot,
                         int out_coff, void* stream);

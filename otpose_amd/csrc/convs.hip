@@ -57,7 +57,7 @@ __device__ unsigned long long otp_convs_stamps[8192 * 32];
 
 struct SPlan {
     int N, C, H, W, HW, Cout, total;
-    int out_ctot, out_coff, act, f32_mode;
+    int out_ctot, out_coff, act, f32_mode, res_s8;
     float pre, post;                      // weights carry 2^k = pre (otp_conv_desc.out_scale = post = 2^-k): see the epilogue
     int NTW, nN, nTiles, nChunks, tpx;
     int NPT;                              // pixel tiles of 16 per wave (workgroup tile = 64 NPT pixels)
@@ -171,9 +171,11 @@ __global__ __launch_bounds__(256) void s8_upsample_add4_kernel(S8Up U, const flo
             ssplit8(f, hi, lo);
             dst[k] = hi;
             dst[(size_t)HW + k] = lo;
-            f32x4* d4 = reinterpret_cast<f32x4*>(out_c4) + ((size_t)n * (C >> 2) + 2 * g) * HW + 4 * q + k;
-            d4[0] = (f32x4){f[0], f[1], f[2], f[3]};
-            d4[HW] = (f32x4){f[4], f[5], f[6], f[7]};
+            if (out_c4) {
+                f32x4* d4 = reinterpret_cast<f32x4*>(out_c4) + ((size_t)n * (C >> 2) + 2 * g) * HW + 4 * q + k;
+                d4[0] = (f32x4){f[0], f[1], f[2], f[3]};
+                d4[HW] = (f32x4){f[4], f[5], f[6], f[7]};
+            }
         }
     }
 }
@@ -217,9 +219,11 @@ __global__ __launch_bounds__(256) void s8_upsample_add_kernel(S8Up U, const floa
         u32x4* dst = out_s8 + ((size_t)(n * G8 + g) * 2) * HW + p;
         dst[0] = hi;
         dst[HW] = lo;
-        f32x4* d4 = reinterpret_cast<f32x4*>(out_c4) + ((size_t)n * (C >> 2) + 2 * g) * HW + p;
-        d4[0] = (f32x4){f8[0], f8[1], f8[2], f8[3]};
-        d4[HW] = (f32x4){f8[4], f8[5], f8[6], f8[7]};
+        if (out_c4) {                                               // (uniform; NULL when the consumer reads its residual as S8)
+            f32x4* d4 = reinterpret_cast<f32x4*>(out_c4) + ((size_t)n * (C >> 2) + 2 * g) * HW + p;
+            d4[0] = (f32x4){f8[0], f8[1], f8[2], f8[3]};
+            d4[HW] = (f32x4){f8[4], f8[5], f8[6], f8[7]};
+        }
     }
 }
 
@@ -464,11 +468,46 @@ __global__ __launch_bounds__(256, NCHW ? 2 : 3) void convs_kernel(const unsigned
             if (NCHW) offN[NCHW ? p : 0] = pv ? ((img * P.out_ctot + P.out_coff) * P.HW + pi) * 4 : SOOB;
             offS[p] = pv ? c4o : SOOB;
             // residual (C4 image; out-of-range offsets read zeros) + shift
+            if (!P.res_s8) {
 #pragma unroll
-            for (int t = 0; t < NTW; ++t) {
-                const bool tv = co_blk + 16 * t < P.Cout;
-                acc[t][p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                    rres, (pv && tv) ? c4o + (ch0[t] >> 2) * P.HW * 16 : SOOB, 0, 0));
+                for (int t = 0; t < NTW; ++t) {
+                    const bool tv = co_blk + 16 * t < P.Cout;
+                    acc[t][p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                        rres, (pv && tv) ? c4o + (ch0[t] >> 2) * P.HW * 16 : SOOB, 0, 0));
+                }
+            }
+        }
+        if (P.res_s8) {
+            // residual as S8 records (otp_conv_desc.res_layout = 1): the block input's operand image IS the residual - hi + lo holds
+            // it to 2^-22 - so no fp32 (C4) image of it has to exist.  The records are read the way the epilogue writes them: a
+            // lane's registers of a tile pair are the 8 channels of one record group (srow2ch), a tile without a partner takes
+            // the lower or upper half of one.
+#pragma unroll
+            for (int t = 0; t < NTW; t += 2) {
+                const bool tav = co_blk + 16 * t < P.Cout;
+                const int so = (ch0[t] >> 3) * 2 * P.HW * 16;
+                if (stile_paired(co_blk, t, NTW, P.Cout)) {          // (uniform)
+#pragma unroll
+                    for (int p = 0; p < NPT; ++p) {
+                        const int o = (tav && offS[p] != SOOB) ? offS[p] + so : SOOB;
+                        const u32x4 h = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, o, 0, 0));
+                        const u32x4 l = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, o, P.HW * 16, 0));
+                        const otp_f32x2 a0 = otp_x3_widen(h[0]) + otp_x3_widen(l[0]), a1 = otp_x3_widen(h[1]) + otp_x3_widen(l[1]);
+                        const otp_f32x2 a2 = otp_x3_widen(h[2]) + otp_x3_widen(l[2]), a3 = otp_x3_widen(h[3]) + otp_x3_widen(l[3]);
+                        acc[t][p] = f32x4{a0.x, a0.y, a1.x, a1.y};
+                        acc[t + 1 < NTW ? t + 1 : t][p] = f32x4{a2.x, a2.y, a3.x, a3.y};
+                    }
+                } else {
+                    const int half = (ch0[t] >> 2) & 1;
+#pragma unroll
+                    for (int p = 0; p < NPT; ++p) {
+                        const int o = (tav && offS[p] != SOOB) ? offS[p] + so + 8 * half : SOOB;
+                        const u32x2 h = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rres, o, 0, 0));
+                        const u32x2 l = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rres, o, P.HW * 16, 0));
+                        const otp_f32x2 a0 = otp_x3_widen(h[0]) + otp_x3_widen(l[0]), a1 = otp_x3_widen(h[1]) + otp_x3_widen(l[1]);
+                        acc[t][p] = f32x4{a0.x, a0.y, a1.x, a1.y};
+                    }
+                }
             }
         }
         // the weights carry a factor pre = 2^k (both half pieces of every weight normal: otp_conv_desc.out_scale), so the sum
@@ -673,6 +712,7 @@ bool convs_plan(const otp_conv_desc& d, SPlan& P) {
     P.out_ctot = d.out_ctot; P.out_coff = d.out_coff; P.act = d.act; P.f32_mode = S_F32_NONE;
     P.post = d.out_scale > 0.f ? d.out_scale : 1.f;
     P.pre = 1.f / P.post;
+    P.res_s8 = d.res_layout == 1;
     P.NTW = s8_ntw(d.Cout);
     P.nN = ((d.Cout + 15) / 16 + P.NTW - 1) / P.NTW;
     P.NPT = 4;
@@ -750,8 +790,8 @@ extern "C" int otp_s8_pack(const void* in, void* out, void* out_c4, int N, int C
 extern "C" int otp_s8_upsample_add(const void* const* lows, const int* factors, int nlow, const void* res, void* out_nchw,
                                    void* out_s8, void* out_c4, int N, int C, int Hh, int Wh, int relu, int res_ctot, int res_coff,
                                    int out_ctot, int out_coff, void* stream) {
-    if (!lows || !factors || !res || !out_s8 || !out_c4 || nlow < 1 || nlow > 3 || N <= 0 || C <= 0 || Hh <= 0 || Wh <= 0)
-        return OTP_ERR_BAD_ARG;
+    if (!lows || !factors || !res || !out_s8 || nlow < 1 || nlow > 3 || N <= 0 || C <= 0 || Hh <= 0 || Wh <= 0)
+        return OTP_ERR_BAD_ARG;                         // (out_c4 may be NULL: a consumer that reads its residual as S8 records)
     if (Wh % 4 || C % 8 || res_ctot < res_coff + C || (out_nchw && out_ctot < out_coff + C)) return OTP_ERR_UNSUPPORTED;
     S8Up U{};
     U.n = nlow;

@@ -349,7 +349,9 @@ class InferenceEngine:
         if not ops.s8_conv_supported(ops.s8_conv_desc(n_, c_, c_, hh, wh, ACT_RELU)):
             return False
         self._needs_nchw(res)
-        s8, c4 = self.new(n_ * c_ * hh * wh), self.new(n_ * c_ * hh * wh)
+        # (the C4 fp32 image only when the next module's branch reads its residual from it: OTPOSE_S8_RESIDUAL=0)
+        s8 = self.new(n_ * c_ * hh * wh)
+        c4 = self.new(n_ * c_ * hh * wh) if os.environ.get("OTPOSE_S8_RESIDUAL", "1") == "0" else None
         aux = {"s8": s8, "c4": c4, "nchw_needed": False}
         self._aux[id(tgt.t)] = aux
         lp = (ctypes.c_void_p * len(lows))(*[hip.ptr(v.t) for v in lows])
@@ -454,9 +456,9 @@ class InferenceEngine:
 
     def branch_s8(self, blocks, x: View, want_s8=False):
         """A branch of a HighResolutionModule (HRNet.py:478-496: 4 BasicBlocks, :500-530) on split-record activations
-        (csrc/convs.hip).  The branch input is converted once to its S8 image (the MFMA operand records: conv input) and its
-        C4 image (fp32, the accumulator layout: residual); inside the branch conv1 goes S8 -> S8, conv2 S8 + C4 residual ->
-        C4 + S8; the last conv2 writes the NCHW tensor the fuse layer reads.  Returns None when the branch is not of that
+        (csrc/convs.hip).  The branch input is converted once to its S8 image (the MFMA operand records): conv input AND
+        residual (round 4; before: a C4 fp32 image next to it); inside the branch conv1 goes S8 -> S8, conv2 S8 + S8 residual ->
+        S8; the last conv2 writes the NCHW tensor the fuse layer reads.  Returns None when the branch is not of that
         shape (the caller then emits the blocks one convolution at a time)."""
         n, c, h, w = x.t.shape
         if x.coff != 0 or x.C != c or self._exact:
@@ -471,10 +473,13 @@ class InferenceEngine:
             return None
         L = self.lib
         new_img = lambda: self.new(n * c * h * w)                          # noqa: E731  (S8 and C4 images are 4 bytes per element)
-        aux = self.s8_image(x, want_c4=True)                               # written by the producer (a fuse row), or packed here
+        # residual of a block: its input's S8 records (hi + lo holds the value to 2^-22: otp_conv_desc.res_layout = 1) - no fp32 (C4)
+        # image exists between the blocks of a branch; OTPOSE_S8_RESIDUAL=0: the exact fp32 residual chain of round 3
+        res_s8 = os.environ.get("OTPOSE_S8_RESIDUAL", "1") != "0"
+        aux = self.s8_image(x, want_c4=not res_s8)                         # written by the producer (a fuse row), or packed here
         if aux is None:
             return None
-        xs8, xc4 = aux["s8"], aux["c4"]
+        xs8, xc4 = aux["s8"], (None if res_s8 else aux["c4"])
         out = None
         for b, blk in enumerate(blocks):
             last = b == len(blocks) - 1
@@ -489,21 +494,23 @@ class InferenceEngine:
             if last:
                 out = View(self.new(n, c, h, w))
                 d2 = ops.s8_conv_desc(n, c, c, h, w, ACT_RELU, out)
+                d2.res_layout = int(res_s8)
                 w2 = self._pack_s8(blk.conv2, sc2, d2)
                 self._keep += [w2, d2]
                 # a stride-2 consumer in the fuse layer (csrc/convs2.hip) reads the S8 image: written here, next to the NCHW tensor
                 o8 = new_img() if want_s8 else None
                 if o8 is not None:
                     self._aux[id(out.t)] = {"s8": o8, "nchw_needed": True}
-                self.call(L.otp_conv3x3_s8, "otp_conv3x3_s8", hip.ptr(y8), hip.ptr(w2), hip.ptr(sh2), hip.ptr(xc4), hip.ptr(out.t),
-                          ops.S8_F32_NCHW, hip.ptr(o8) if o8 is not None else None, d2)
+                self.call(L.otp_conv3x3_s8, "otp_conv3x3_s8", hip.ptr(y8), hip.ptr(w2), hip.ptr(sh2),
+                          hip.ptr(xs8 if res_s8 else xc4), hip.ptr(out.t), ops.S8_F32_NCHW, hip.ptr(o8) if o8 is not None else None, d2)
             else:
-                oc4, o8 = new_img(), new_img()
+                oc4, o8 = (None if res_s8 else new_img()), new_img()
                 d2 = ops.s8_conv_desc(n, c, c, h, w, ACT_RELU)
+                d2.res_layout = int(res_s8)
                 w2 = self._pack_s8(blk.conv2, sc2, d2)
                 self._keep += [w2, d2]
-                self.call(L.otp_conv3x3_s8, "otp_conv3x3_s8", hip.ptr(y8), hip.ptr(w2), hip.ptr(sh2), hip.ptr(xc4), hip.ptr(oc4),
-                          ops.S8_F32_C4, hip.ptr(o8), d2)
+                self.call(L.otp_conv3x3_s8, "otp_conv3x3_s8", hip.ptr(y8), hip.ptr(w2), hip.ptr(sh2),
+                          hip.ptr(xs8 if res_s8 else xc4), hip.ptr(oc4) if oc4 is not None else None, ops.S8_F32_C4, hip.ptr(o8), d2)
                 xs8, xc4 = o8, oc4
         return out
 
@@ -712,7 +719,7 @@ class InferenceEngine:
             if s >= 3 and self.use_s8 and os.environ.get("OTPOSE_S8_STRIDE2", "1") != "0":
                 # the lowest-resolution tensor feeds the new branch's stride-2 conv AND its own branch of the next module: one
                 # pack pass (S8 + C4) before the streams fork serves both
-                self.s8_image(ys[-1], want_c4=True)
+                self.s8_image(ys[-1], want_c4=os.environ.get("OTPOSE_S8_RESIDUAL", "1") == "0")
             self.fork(range(1, len(live)))                         # the transition convs only share their inputs
             for i, tr in enumerate(trans):
                 if tr is None:

@@ -30,7 +30,7 @@ class ConvDesc(ctypes.Structure):
     _fields_ = [(n, c_int) for n in (
         "N", "Cin", "H", "W", "Cout", "kh", "kw", "stride", "pad", "dil",
         "in_ctot", "in_coff", "in2_ctot", "in2_coff", "out_ctot", "out_coff",
-        "res_ctot", "res_coff", "res_up", "act", "Ho", "Wo", "frame_split")] + [("out_scale", ctypes.c_float)]
+        "res_ctot", "res_coff", "res_up", "act", "Ho", "Wo", "frame_split")] + [("out_scale", ctypes.c_float), ("res_layout", ctypes.c_int)]
 
 
 class NhwcConvDesc(ctypes.Structure):

@@ -568,7 +568,7 @@ def conv3x3_s8_launch(in_s8, wpacked, shift, desc, res_c4=None, out_f32=None, f3
     hip.check(st, "otp_conv3x3_s8")
 
 
-def conv3x3_s8(x_s8, shape, weight, scale=None, shift=None, act=ACT_NONE, res_c4=None, f32="nchw", want_s8=True):
+def conv3x3_s8(x_s8, shape, weight, scale=None, shift=None, act=ACT_NONE, res_c4=None, f32="nchw", want_s8=True, res_s8=None):
     """act(conv2d(x, weight, 3x3, stride 1, pad 1) * scale + shift + res) from an S8 image ``x_s8`` of logical ``shape``
     (n, cin, h, w); ``res_c4`` a C4 image of the residual.  Returns (fp32 result - an NCHW tensor for f32 = "nchw", a C4 image
     for "c4", None for None -, S8 image of the result or None)."""
@@ -586,7 +586,11 @@ def conv3x3_s8(x_s8, shape, weight, scale=None, shift=None, act=ACT_NONE, res_c4
     d = s8_conv_desc(n, cin, cout, h, w, act)
     e = x3_weight_exponent(weight, scale)
     d.out_scale = 2.0 ** -e
-    conv3x3_s8_launch(x_s8, pack_s8_weight(weight, scale, e), shift, d, res_c4, out, layout, out_s8)
+    if res_s8 is not None:                           # the residual as S8 records (its hi + lo) instead of a C4 fp32 image
+        assert res_c4 is None
+        d.res_layout = 1
+    conv3x3_s8_launch(x_s8, pack_s8_weight(weight, scale, e), shift, d, res_s8 if res_s8 is not None else res_c4, out, layout,
+                      out_s8)
     return out, out_s8
 
 

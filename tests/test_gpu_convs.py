@@ -94,6 +94,17 @@ def test_conv3x3_s8_matches_float64(case):
     assert none_s8 is None and torch.equal(ops.c4_unpack(yc, n, co, h, w), y)
     none_f, ys2 = ops.conv3x3_s8(xs, (n, ci, h, w), wt, sc, sh, act, res_c4, f32=None)
     assert none_f is None and torch.equal(ys2, ys)
+    if with_res:
+        # the residual as S8 records (otp_conv_desc.res_layout = 1: a BasicBlock's input image serves as its residual): the same
+        # bits as the C4 form fed with hi + lo of those records, and within 2^-22 of the residual's magnitude of the fp32 form
+        rs8 = ops.s8_pack(res)
+        r_hl = ops.s8_unpack(rs8, n, co, h, w)
+        rc4 = ops.c4_empty(n, co, h, w, "cuda")
+        ops.s8_pack(r_hl, out_c4=rc4)
+        y_s, ys_s = ops.conv3x3_s8(xs, (n, ci, h, w), wt, sc, sh, act, res_s8=rs8)
+        y_c, ys_c = ops.conv3x3_s8(xs, (n, ci, h, w), wt, sc, sh, act, rc4)
+        assert torch.equal(y_s, y_c) and torch.equal(ys_s, ys_c)
+        assert float((y_s - y).abs().max()) <= 2.0 ** -21 * float(res.abs().max())
 
 
 def test_conv3x3_s8_writes_a_channel_slice_of_an_nchw_tensor():
