@@ -663,8 +663,8 @@ def main():
             "arithmetic": ("fp32 accumulation everywhere; conv / MLP / projection products as three f16 MFMA products of two-piece "
                            "operands (a = hi + lo in IEEE half, |a - hi - lo| <= max(2^-23 |a|, 2^-25); HRNet / warping-head weights stored times "
                            "a per-layer power of two so both pieces are normal: DESIGN.md section 3.1c); tensors are fp32 except, "
-                           "inside an HRNet branch, the conv1 output of a BasicBlock, which exists only as that hi | lo pair "
-                           "(the residual chain stays fp32: DESIGN.md section 3.1d)"
+                           "inside an HRNet branch, the tensors between the convolutions of its BasicBlocks, which exist only as that hi | lo "
+                           "pair - conv inputs and, since round 4, the residual too (22 significand bits: DESIGN.md section 3.1d)"
                            if math != "f32" else "fp32 throughout (f32 MFMA)"),
             "config": {"workload": "BASELINE configs[1]: batch %d x 5-frame x 384x288, HRNet-W48 + DCN warp + "
                                    "ConvVideoTransformer, fp32 forward (eval), seeded synthetic weights" % a.batch,
