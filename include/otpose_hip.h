@@ -188,6 +188,11 @@ int otp_s8_pack(const void* in_f32, void* out_s8, void* out_c4, int N, int C, in
 int otp_s8_upsample_add(const void* const* lows, const int* factors, int nlow, const void* res, void* out_nchw, void* out_s8,
                         void* out_c4, int N, int C, int Hh, int Wh, int relu, int res_ctot, int res_coff, int out_ctot,
                         int out_coff, void* stream);
+/* the same with the residual given as fp32 NCHW (res_layout 0) or as its S8 image (res_layout 1: hi + lo of the records; the
+ * res_ctot / res_coff arguments are then unused) - a branch output that every consumer reads as S8 needs no NCHW tensor */
+int otp_s8_upsample_add_ex(const void* const* lows, const int* factors, int nlow, const void* res, int res_layout, void* out_nchw,
+                           void* out_s8, void* out_c4, int N, int C, int Hh, int Wh, int relu, int res_ctot, int res_coff,
+                           int out_ctot, int out_coff, void* stream);
 int otp_s8_unpack(const void* in_s8, void* out_f32, int N, int C, int H, int W, void* stream);
 int otp_c4_unpack(const void* in_c4, void* out_f32, int N, int C, int H, int W, void* stream);
 int otp_conv3x3_s8_supported(const otp_conv_desc* desc);

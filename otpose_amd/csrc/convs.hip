@@ -125,10 +125,11 @@ struct S8Up {
 // the round-3 form: a thread owns 4 consecutive pixels of one 8-channel group - a quarter of the low-resolution loads per pixel
 // (kept for rows with three upsampled terms, where those loads outweigh the short store runs: 117 against 138 us at 48 channels
 // @96x72 with terms at 1/2, 1/4, 1/8 resolution; with one or two terms the one-pixel form below is 25 % faster)
+// `res`: the fp32 NCHW residual, or (res_s8 != 0) its S8 image - hi + lo of the records, the same 4 bytes per element
 __global__ __launch_bounds__(256) void s8_upsample_add4_kernel(S8Up U, const float* __restrict__ res, float* out_nchw,
                                                                u32x4* __restrict__ out_s8, float* __restrict__ out_c4, int N, int C,
                                                                int Hh, int Wh, int relu, int res_ctot, int res_coff, int out_ctot,
-                                                               int out_coff) {
+                                                               int out_coff, int res_s8) {
     const int HW = Hh * Wh, q4 = HW >> 2, G8 = C >> 3, Wh4 = Wh >> 2;
     const size_t items = (size_t)N * G8 * q4;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < items; i += (size_t)gridDim.x * 256) {
@@ -137,10 +138,23 @@ __global__ __launch_bounds__(256) void s8_upsample_add4_kernel(S8Up U, const flo
         const int g = (int)(r % G8), n = (int)(r / G8);
         const int y = q / Wh4, x4 = q - y * Wh4;
         f32x4 v[8];
+        if (res_s8) {                                               // (uniform) records of the four pixels -> v[channel][pixel]
+            const u32x4* rs = reinterpret_cast<const u32x4*>(res) + ((size_t)(n * G8 + g) * 2) * HW + 4 * q;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const u32x4 h = rs[k], l = rs[(size_t)HW + k];
+#pragma unroll
+                for (int e2 = 0; e2 < 4; ++e2) {
+                    const otp_f32x2 a = otp_x3_widen(h[e2]) + otp_x3_widen(l[e2]);
+                    v[2 * e2][k] = a.x;
+                    v[2 * e2 + 1][k] = a.y;
+                }
+            }
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int c = 8 * g + e;
-            f32x4 o = *reinterpret_cast<const f32x4*>(res + ((size_t)n * res_ctot + res_coff + c) * HW + 4 * q);
+            f32x4 o = res_s8 ? v[e] : *reinterpret_cast<const f32x4*>(res + ((size_t)n * res_ctot + res_coff + c) * HW + 4 * q);
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 if (k < U.n) {
@@ -183,7 +197,7 @@ __global__ __launch_bounds__(256) void s8_upsample_add4_kernel(S8Up U, const flo
 __global__ __launch_bounds__(256) void s8_upsample_add_kernel(S8Up U, const float* __restrict__ res, float* out_nchw,
                                                                u32x4* __restrict__ out_s8, float* __restrict__ out_c4, int N, int C,
                                                                int Hh, int Wh, int relu, int res_ctot, int res_coff, int out_ctot,
-                                                               int out_coff) {
+                                                               int out_coff, int res_s8) {
     // a thread owns ONE pixel of one 8-channel group (see s8_pack_kernel: 1 KB store runs per wave instruction)
     const int HW = Hh * Wh, G8 = C >> 3;
     const size_t items = (size_t)N * G8 * HW;
@@ -199,10 +213,20 @@ __global__ __launch_bounds__(256) void s8_upsample_add_kernel(S8Up U, const floa
             lo_off[k] = (y / f) * (Wh / f) + x / f;                 // pixel of term k's low-resolution map
         }
         float f8[8];
+        if (res_s8) {                                               // (uniform) the pixel's record pair of this channel group
+            const u32x4* rs = reinterpret_cast<const u32x4*>(res) + ((size_t)(n * G8 + g) * 2) * HW + p;
+            const u32x4 h = rs[0], l = rs[HW];
+#pragma unroll
+            for (int e2 = 0; e2 < 4; ++e2) {
+                const otp_f32x2 a = otp_x3_widen(h[e2]) + otp_x3_widen(l[e2]);
+                f8[2 * e2] = a.x;
+                f8[2 * e2 + 1] = a.y;
+            }
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int c = 8 * g + e;
-            float o = res[((size_t)n * res_ctot + res_coff + c) * HW + p];
+            float o = res_s8 ? f8[e] : res[((size_t)n * res_ctot + res_coff + c) * HW + p];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 if (k < U.n) {
@@ -790,9 +814,18 @@ extern "C" int otp_s8_pack(const void* in, void* out, void* out_c4, int N, int C
 extern "C" int otp_s8_upsample_add(const void* const* lows, const int* factors, int nlow, const void* res, void* out_nchw,
                                    void* out_s8, void* out_c4, int N, int C, int Hh, int Wh, int relu, int res_ctot, int res_coff,
                                    int out_ctot, int out_coff, void* stream) {
+    return otp_s8_upsample_add_ex(lows, factors, nlow, res, 0, out_nchw, out_s8, out_c4, N, C, Hh, Wh, relu, res_ctot, res_coff,
+                                  out_ctot, out_coff, stream);
+}
+
+extern "C" int otp_s8_upsample_add_ex(const void* const* lows, const int* factors, int nlow, const void* res, int res_layout,
+                                      void* out_nchw, void* out_s8, void* out_c4, int N, int C, int Hh, int Wh, int relu,
+                                      int res_ctot, int res_coff, int out_ctot, int out_coff, void* stream) {
     if (!lows || !factors || !res || !out_s8 || nlow < 1 || nlow > 3 || N <= 0 || C <= 0 || Hh <= 0 || Wh <= 0)
         return OTP_ERR_BAD_ARG;                         // (out_c4 may be NULL: a consumer that reads its residual as S8 records)
-    if (Wh % 4 || C % 8 || res_ctot < res_coff + C || (out_nchw && out_ctot < out_coff + C)) return OTP_ERR_UNSUPPORTED;
+    if (res_layout != 0 && res_layout != 1) return OTP_ERR_BAD_ARG;
+    const int res_s8 = res_layout;                      // 1: `res` is the S8 image of the (N, C, Hh, Wh) residual
+    if (Wh % 4 || C % 8 || (!res_s8 && res_ctot < res_coff + C) || (out_nchw && out_ctot < out_coff + C)) return OTP_ERR_UNSUPPORTED;
     S8Up U{};
     U.n = nlow;
     for (int k = 0; k < nlow; ++k) {
@@ -810,14 +843,14 @@ extern "C" int otp_s8_upsample_add(const void* const* lows, const int* factors, 
         const int grid4 = (int)((items4 + 255) / 256 > 8192 ? 8192 : (items4 + 255) / 256);
         hipLaunchKernelGGL(s8_upsample_add4_kernel, dim3(grid4), dim3(256), 0, static_cast<hipStream_t>(stream), U,
                            static_cast<const float*>(res), static_cast<float*>(out_nchw), static_cast<u32x4*>(out_s8),
-                           static_cast<float*>(out_c4), N, C, Hh, Wh, relu, res_ctot, res_coff, out_ctot, out_coff);
+                           static_cast<float*>(out_c4), N, C, Hh, Wh, relu, res_ctot, res_coff, out_ctot, out_coff, res_s8);
         return otp_launch_status();
     }
     const size_t items = (size_t)N * (C / 8) * (Hh * Wh);
     const int grid = (int)((items + 255) / 256 > 16384 ? 16384 : (items + 255) / 256);
     hipLaunchKernelGGL(s8_upsample_add_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), U,
                        static_cast<const float*>(res), static_cast<float*>(out_nchw), static_cast<u32x4*>(out_s8),
-                       static_cast<float*>(out_c4), N, C, Hh, Wh, relu, res_ctot, res_coff, out_ctot, out_coff);
+                       static_cast<float*>(out_c4), N, C, Hh, Wh, relu, res_ctot, res_coff, out_ctot, out_coff, res_s8);
     return otp_launch_status();
 }
 

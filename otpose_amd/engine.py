@@ -348,21 +348,28 @@ class InferenceEngine:
             return False
         if not ops.s8_conv_supported(ops.s8_conv_desc(n_, c_, c_, hh, wh, ACT_RELU)):
             return False
-        self._needs_nchw(res)
+        s8_res = os.environ.get("OTPOSE_S8_RESIDUAL", "1") != "0"
+        lazy = s8_res and os.environ.get("OTPOSE_S8_LAZY_NCHW", "1") != "0"
+        # the identity term: the S8 image of `res` when its producer wrote one (a branch output: hi + lo of the records, 2^-22) -
+        # `res` then needs no NCHW tensor on this account - else the fp32 NCHW tensor
+        raux = self._aux.get(id(res.t)) if (lazy and res.coff == 0 and res.C == c_ and res.ctot == c_) else None
+        res_img = raux.get("s8") if raux is not None else None
+        if res_img is None:
+            self._needs_nchw(res)
         # (the C4 fp32 image only when the next module's branch reads its residual from it: OTPOSE_S8_RESIDUAL=0)
         s8 = self.new(n_ * c_ * hh * wh)
-        c4 = self.new(n_ * c_ * hh * wh) if os.environ.get("OTPOSE_S8_RESIDUAL", "1") == "0" else None
+        c4 = None if s8_res else self.new(n_ * c_ * hh * wh)
         aux = {"s8": s8, "c4": c4, "nchw_needed": False}
         self._aux[id(tgt.t)] = aux
         lp = (ctypes.c_void_p * len(lows))(*[hip.ptr(v.t) for v in lows])
         fp = (ctypes.c_int * len(lows))(*factors)
         self._keep += [lp, fp]
         L = self.lib
-        args = (lp, fp, len(lows), hip.ptr(res.t))
+        args = (lp, fp, len(lows), hip.ptr(res_img if res_img is not None else res.t), int(res_img is not None))
         tail = (hip.ptr(s8), hip.ptr(c4), n_, c_, hh, wh, 1, res.ctot, res.coff, tgt.ctot, tgt.coff)
 
         def run():
-            hip.check(L.otp_s8_upsample_add(*args, hip.ptr(tgt.t) if aux["nchw_needed"] else None, *tail, self._stream),
+            hip.check(L.otp_s8_upsample_add_ex(*args, hip.ptr(tgt.t) if aux["nchw_needed"] else None, *tail, self._stream),
                       "otp_s8_upsample_add")
         self._emit(run)
         return True
@@ -499,10 +506,19 @@ class InferenceEngine:
                 self._keep += [w2, d2]
                 # a stride-2 consumer in the fuse layer (csrc/convs2.hip) reads the S8 image: written here, next to the NCHW tensor
                 o8 = new_img() if want_s8 else None
+                lazy = res_s8 and os.environ.get("OTPOSE_S8_LAZY_NCHW", "1") != "0"
+                oaux = {"s8": o8, "nchw_needed": not lazy} if o8 is not None else {"nchw_needed": True}
                 if o8 is not None:
-                    self._aux[id(out.t)] = {"s8": o8, "nchw_needed": True}
-                self.call(L.otp_conv3x3_s8, "otp_conv3x3_s8", hip.ptr(y8), hip.ptr(w2), hip.ptr(sh2),
-                          hip.ptr(xs8 if res_s8 else xc4), hip.ptr(out.t), ops.S8_F32_NCHW, hip.ptr(o8) if o8 is not None else None, d2)
+                    # consumers that can read the S8 image (stride-2 chains, the fuse row's identity term) do; the NCHW tensor is
+                    # written only if some consumer asks for it before the first launch (_needs_nchw)
+                    self._aux[id(out.t)] = oaux
+                largs = (hip.ptr(y8), hip.ptr(w2), hip.ptr(sh2), hip.ptr(xs8 if res_s8 else xc4))
+                optr, o8ptr = hip.ptr(out.t), (hip.ptr(o8) if o8 is not None else None)
+
+                def run_last(largs=largs, optr=optr, o8ptr=o8ptr, d2=d2, oaux=oaux):
+                    hip.check(L.otp_conv3x3_s8(*largs, optr if oaux["nchw_needed"] else None, ops.S8_F32_NCHW, o8ptr, d2, self._stream),
+                              "otp_conv3x3_s8")
+                self._emit(run_last)
             else:
                 oc4, o8 = (None if res_s8 else new_img()), new_img()
                 d2 = ops.s8_conv_desc(n, c, c, h, w, ACT_RELU)

@@ -67,6 +67,8 @@ SIGNATURES = {
     "otp_s8_bytes": (c_size_t, [c_int] * 4),
     "otp_s8_pack": (c_int, [c_void_p] * 3 + [c_int] * 6 + [c_void_p]),
     "otp_s8_upsample_add": (c_int, [ctypes.POINTER(c_void_p), ctypes.POINTER(c_int), c_int] + [c_void_p] * 4 + [c_int] * 9 + [c_void_p]),
+    "otp_s8_upsample_add_ex": (c_int, [ctypes.POINTER(c_void_p), ctypes.POINTER(c_int), c_int, c_void_p, c_int] + [c_void_p] * 3
+                               + [c_int] * 9 + [c_void_p]),
     "otp_s8_unpack": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
     "otp_c4_unpack": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
     "otp_conv3x3_s8_supported": (c_int, [ctypes.POINTER(ConvDesc)]),
