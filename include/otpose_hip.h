@@ -369,6 +369,10 @@ size_t otp_pointwise_x3_s8_weight_bytes(int Cin, int Cout);
 int otp_pointwise_x3_s8_pack(const void* w, const void* scale, const void* shift, void* packed, int Cin, int Cout, void* stream);
 int otp_pointwise_x3_s8(const void* x, const void* packed, void* out_s8, int B, int Cin, int Cout, int T, int x_ctot, int x_coff,
                         int relu, void* stream);
+/* + an fp32 NCHW residual (channel slice r_coff .. r_coff + Cout of r_ctot) added before the activation: a Bottleneck's conv3
+ * (model/HRNet.py:566-571) whose result is read as S8 records only */
+int otp_pointwise_x3_s8_res(const void* x, const void* packed, const void* res, void* out_s8, int B, int Cin, int Cout, int T,
+                            int x_ctot, int x_coff, int r_ctot, int r_coff, int relu, void* stream);
 
 /* The same operator with split-half ("f16x3": two IEEE-half pieces per fp32 operand, csrc/common.h) products on the 16-bit matrix cores (csrc/mlpx.hip): fp32 storage, fp32
  * accumulation, LayerNorm / bias / GELU in fp32; each product is lo*hi + hi*lo + hi*hi of two bf16 pieces per operand.

@@ -201,7 +201,9 @@ __global__ __launch_bounds__(256, CIN <= 128 ? 3 : 2) void pointx_kernel(PxArgs 
 // records of csrc/convs.hip) instead of fp32 NCHW: a Bottleneck's conv1 feeding its 3x3 conv2 (model/HRNet.py:551-571).  Tiles
 // are processed in pairs whose packed rows are permuted (pointx_pack_kernel, s8 = 1) so that lane (pixel pair n, kq) ends up with
 // channels 32 p + 8 kq .. + 7 of its two pixels: one hi and one lo record per pixel, 16 lanes = 512 contiguous bytes per store.
-template <int CIN>
+// RES: + an fp32 NCHW residual before the activation (a Bottleneck's conv3, HRNet.py:566-571, whose consumers read S8 records:
+// layer1's last block in front of transition1)
+template <int CIN, bool RES = false>
 __global__ __launch_bounds__(256, CIN <= 128 ? 3 : 2) void pointx_s8_kernel(PxArgs A) {
     constexpr int KS = px_ks(CIN), MPB = px_mpb_s8(CIN), BLKB = MPB * KS * 2048;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BLKB + 2 * PX_MAX_COUT * 4];
@@ -229,6 +231,7 @@ __global__ __launch_bounds__(256, CIN <= 128 ? 3 : 2) void pointx_s8_kernel(PxAr
     }
     const unsigned plane = (unsigned)((size_t)A.Cout * T * sizeof(float));         // an S8 image is 4 bytes per element too
     const otp_rsrc ro = make_rsrc32(A.out + (size_t)b * A.Cout * T, plane);
+    const otp_rsrc rr = make_rsrc32(RES ? A.res + ((size_t)b * A.r_ctot + A.r_coff) * T : A.out, RES ? plane : 0u);
     const float lo_clamp = A.relu ? 0.f : -__builtin_inff();
     __syncthreads();
 #pragma unroll 1
@@ -237,6 +240,18 @@ __global__ __launch_bounds__(256, CIN <= 128 ? 3 : 2) void pointx_s8_kernel(PxAr
         asm volatile("" ::: "memory");
         const unsigned char* P = lds + (blk & 1) * BLKB;
         f32x4 acc[MPB][2];
+        // residual of the lane's two pixels, 8 channels per tile pair: in flight under the MFMAs of the block
+        f32x2 rv[RES ? MPB / 2 : 1][8];
+        if constexpr (RES) {
+#pragma unroll
+            for (int m = 0; m < MPB; m += 2) {
+                const int pr = (blk * MPB + m) >> 1, c8 = 32 * pr + 8 * kq;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    rv[m >> 1][e] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(
+                        rr, (valid && c8 < A.Cout) ? ((c8 + e) * T + tok) * 4 : -16, 0, 0));
+            }
+        }
 #pragma unroll
         for (int m = 0; m < MPB; ++m) {
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -267,8 +282,9 @@ __global__ __launch_bounds__(256, CIN <= 128 ? 3 : 2) void pointx_s8_kernel(PxAr
                 float v[8];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    v[i] = fmaxf(acc[m][h][i] * sc0[i] + sh0[i], lo_clamp);
-                    v[4 + i] = fmaxf(acc[m + 1][h][i] * sc1[i] + sh1[i], lo_clamp);
+                    const float r0 = RES ? rv[RES ? m >> 1 : 0][i][h] : 0.f, r1 = RES ? rv[RES ? m >> 1 : 0][4 + i][h] : 0.f;
+                    v[i] = fmaxf(acc[m][h][i] * sc0[i] + sh0[i] + r0, lo_clamp);
+                    v[4 + i] = fmaxf(acc[m + 1][h][i] * sc1[i] + sh1[i] + r1, lo_clamp);
                 }
                 h16x8 hi, lo;
                 px_split8(v, hi, lo);
@@ -370,7 +386,13 @@ extern "C" int otp_pointwise_x3(const void* x, const void* packed, const void* r
 
 extern "C" int otp_pointwise_x3_s8(const void* x, const void* packed, void* out_s8, int B, int Cin, int Cout, int T, int x_ctot,
                                    int x_coff, int relu, void* stream) {
+    return otp_pointwise_x3_s8_res(x, packed, nullptr, out_s8, B, Cin, Cout, T, x_ctot, x_coff, 0, 0, relu, stream);
+}
+
+extern "C" int otp_pointwise_x3_s8_res(const void* x, const void* packed, const void* res, void* out_s8, int B, int Cin, int Cout,
+                                       int T, int x_ctot, int x_coff, int r_ctot, int r_coff, int relu, void* stream) {
     if (!x || !packed || !out_s8 || B <= 0) return OTP_ERR_BAD_ARG;
+    if (res && (r_coff < 0 || r_coff + Cout > r_ctot || (reinterpret_cast<uintptr_t>(res) & 7))) return OTP_ERR_BAD_ARG;
     if (!otp_pointwise_x3_s8_supported(Cin, Cout, T)) return OTP_ERR_UNSUPPORTED;
     if (x_coff < 0 || x_coff + Cin > x_ctot) return OTP_ERR_BAD_ARG;
     if (reinterpret_cast<uintptr_t>(x) & 7 || (reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(out_s8)) & 15)
@@ -379,13 +401,18 @@ extern "C" int otp_pointwise_x3_s8(const void* x, const void* packed, void* out_
     PxArgs a;
     a.x = static_cast<const float*>(x);
     a.packed = static_cast<const unsigned char*>(packed);
-    a.res = nullptr;
+    a.res = static_cast<const float*>(res);
     a.out = static_cast<float*>(out_s8);
     a.T = T, a.tiles_per_b = otp_ceil_div(T, 128), a.Cin = Cin, a.Cout = Cout, a.nblk = (MT + MPB - 1) / MPB, a.relu = relu ? 1 : 0;
-    a.x_ctot = x_ctot, a.x_coff = x_coff, a.r_ctot = 0, a.r_coff = 0, a.o_ctot = Cout, a.o_coff = 0;
+    a.x_ctot = x_ctot, a.x_coff = x_coff, a.r_ctot = r_ctot, a.r_coff = r_coff, a.o_ctot = Cout, a.o_coff = 0;
     const dim3 grid((unsigned)(B * a.tiles_per_b));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (Cin == 64) hipLaunchKernelGGL(pointx_s8_kernel<64>, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(pointx_s8_kernel<256>, grid, dim3(256), 0, st, a);
+    if (res) {
+        if (Cin == 64) hipLaunchKernelGGL((pointx_s8_kernel<64, true>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((pointx_s8_kernel<256, true>), grid, dim3(256), 0, st, a);
+    } else {
+        if (Cin == 64) hipLaunchKernelGGL((pointx_s8_kernel<64, false>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((pointx_s8_kernel<256, false>), grid, dim3(256), 0, st, a);
+    }
     return otp_launch_status();
 }

@@ -530,6 +530,40 @@ class InferenceEngine:
                 xs8, xc4 = o8, oc4
         return out
 
+    def conv_bn_s8(self, x: View, conv, bn, act=ACT_RELU):
+        """act(bn(conv3x3 stride 1 pad 1 (x))) on csrc/convs.hip from the S8 image of ``x`` (packed here unless its producer wrote
+        one), result as S8 records for the branch that follows and as the NCHW tensor only if another consumer asks for it.
+        Returns None (nothing emitted) when the layer is not of that shape."""
+        n, c, h, w = x.t.shape
+        if (not self.use_s8 or self._exact or conv.kernel_size != (3, 3) or conv.stride != (1, 1) or conv.padding != (1, 1)
+                or conv.dilation != (1, 1) or conv.bias is not None or conv.groups != 1 or conv.in_channels != c
+                or x.coff != 0 or x.C != c or conv.out_channels % 16):
+            return None
+        co = conv.out_channels
+        out = View(self.new(n, co, h, w))
+        d = ops.s8_conv_desc(n, c, co, h, w, act, out)
+        if not ops.s8_conv_supported(d):
+            return None
+        aux = self.s8_image(x)
+        if aux is None:
+            return None
+        sc, sh = self._bn_fold(bn)
+        wp = self._pack_s8(conv, sc, d)
+        o8 = self.new(n * co * h * w)
+        lazy = os.environ.get("OTPOSE_S8_RESIDUAL", "1") != "0" and os.environ.get("OTPOSE_S8_LAZY_NCHW", "1") != "0"
+        oaux = {"s8": o8, "nchw_needed": not lazy}
+        self._aux[id(out.t)] = oaux
+        self._keep += [wp, d]
+        L = self.lib
+        largs = (hip.ptr(aux["s8"]), hip.ptr(wp), hip.ptr(sh), None)
+        optr, o8ptr = hip.ptr(out.t), hip.ptr(o8)
+
+        def run():
+            hip.check(L.otp_conv3x3_s8(*largs, optr if oaux["nchw_needed"] else None, ops.S8_F32_NCHW, o8ptr, d, self._stream),
+                      "otp_conv3x3_s8")
+        self._emit(run)
+        return out
+
     def conv1_conv2_s8(self, x: View, conv1, bn1, conv2, bn2, out: View = None):
         """relu(bn2(conv2(relu(bn1(conv1(x)))))) of a Bottleneck (HRNet.py:551-571: 1x1 then 3x3) with the intermediate kept as S8
         records: conv1 on csrc/pointx.hip writes the operand records of csrc/convs.hip, conv2 reads them and writes fp32 NCHW -
@@ -563,7 +597,10 @@ class InferenceEngine:
                   None, d2)
         return out
 
-    def bottleneck(self, blk, x: View) -> View:
+    def bottleneck(self, blk, x: View, s8_only=False) -> View:
+        """One Bottleneck (model/HRNet.py:551-571).  ``s8_only``: the result is wanted as S8 records (transition1's convs read
+        them) - conv3 writes them straight from its accumulators (csrc/pointx.hip) and the NCHW tensor of the returned view is
+        filled, by a conversion pass, only if some consumer asks for it."""
         res = x
         if blk.downsample is not None:
             # the 1x1 shortcut only needs x: a side stream next to conv1 / conv2
@@ -577,6 +614,30 @@ class InferenceEngine:
             y = self.conv_bn(y, blk.conv2, blk.bn2, ACT_RELU)
         if blk.downsample is not None:
             self.join((1,))
+        n, _, h, w = y.t.shape
+        c3 = blk.conv3
+        if (s8_only and self.use_s8 and self.use_pointx and not self._exact and c3.kernel_size == (1, 1) and c3.bias is None
+                and c3.stride == (1, 1) and y.C == c3.in_channels and res.C == c3.out_channels
+                and ops.pointwise_x3_s8_supported(c3.in_channels, c3.out_channels, h * w)):
+            for v_ in (y, res):
+                self._needs_nchw(v_)
+            co = c3.out_channels
+            sc, sh = self._bn_fold(blk.bn3)
+            pk = ops.pack_pointwise_x3_s8(self.dev_param(c3.weight), sc, sh)
+            out = View(self.new(n, co, h, w))
+            o8 = self.new(n * co * h * w)
+            oaux = {"s8": o8, "nchw_needed": False}
+            self._aux[id(out.t)] = oaux
+            self._keep.append(pk)
+            L = self.lib
+            args = (hip.ptr(y.t), hip.ptr(pk), hip.ptr(res.t), hip.ptr(o8), n, y.C, co, h * w, y.ctot, y.coff, res.ctot, res.coff, 1)
+
+            def run():
+                hip.check(L.otp_pointwise_x3_s8_res(*args, self._stream), "otp_pointwise_x3_s8_res")
+                if oaux["nchw_needed"]:                         # (a consumer without an S8 path: hi + lo back to fp32 NCHW)
+                    hip.check(L.otp_s8_unpack(hip.ptr(o8), hip.ptr(out.t), n, co, h, w, self._stream), "otp_s8_unpack")
+            self._emit(run)
+            return out
         return self.conv_bn(y, blk.conv3, blk.bn3, ACT_RELU, res=res)
 
     def hr_module(self, mod, xs: List[View], fork_in=True, join_out=True) -> List[View]:
@@ -725,17 +786,21 @@ class InferenceEngine:
             blocks = blocks[1:]
         else:
             x = self.conv_bn(x, net.conv2, net.bn2, ACT_RELU)
-        for blk in blocks:
-            x = self.bottleneck(blk, x)
+        t1_s8 = self.use_s8 and not self._exact and os.environ.get("OTPOSE_T1_S8", "1") != "0" \
+            and os.environ.get("OTPOSE_S8_STRIDE2", "1") != "0"
+        for bi, blk in enumerate(blocks):
+            x = self.bottleneck(blk, x, s8_only=t1_s8 and bi == len(blocks) - 1)
         ys = [x]
         for s in (2, 3, 4):
             trans = getattr(net, f"transition{s - 1}")
             xs = []
             live = [i for i, tr in enumerate(trans) if tr is not None]
-            if s >= 3 and self.use_s8 and os.environ.get("OTPOSE_S8_STRIDE2", "1") != "0":
-                # the lowest-resolution tensor feeds the new branch's stride-2 conv AND its own branch of the next module: one
-                # pack pass (S8 + C4) before the streams fork serves both
-                self.s8_image(ys[-1], want_c4=os.environ.get("OTPOSE_S8_RESIDUAL", "1") == "0")
+            t1_s8 = s == 2 and self.use_s8 and not self._exact and os.environ.get("OTPOSE_T1_S8", "1") != "0"
+            if (s >= 3 or t1_s8) and self.use_s8 and os.environ.get("OTPOSE_S8_STRIDE2", "1") != "0":
+                # the lowest-resolution tensor feeds the new branch's stride-2 conv AND its own branch of the next module (s >= 3) /
+                # the width-change conv of transition1 (s = 2: 256 -> 48 and 256 -> 96 stride 2 ran at 100-160 TFLOP/s on the
+                # fp32-input kernel): one pack pass before the streams fork serves both
+                self.s8_image(ys[-1], want_c4=s >= 3 and os.environ.get("OTPOSE_S8_RESIDUAL", "1") == "0")
             self.fork(range(1, len(live)))                         # the transition convs only share their inputs
             for i, tr in enumerate(trans):
                 if tr is None:
@@ -743,10 +808,11 @@ class InferenceEngine:
                     continue
                 self.on_stream(live.index(i))
                 if isinstance(tr[0], torch.nn.Conv2d):            # same-resolution width change
-                    xs.append(self.conv_bn(ys[i], tr[0], tr[1], ACT_RELU))
+                    y_ = self.conv_bn_s8(ys[i], tr[0], tr[1], ACT_RELU) if t1_s8 else None
+                    xs.append(y_ if y_ is not None else self.conv_bn(ys[i], tr[0], tr[1], ACT_RELU))
                 else:                                              # new branch from the last tensor
                     z = ys[-1]
-                    zs = self.s2_chain_s8([(step[0], step[1], True) for step in tr], z, ACT_RELU) if s >= 3 else None
+                    zs = self.s2_chain_s8([(step[0], step[1], True) for step in tr], z, ACT_RELU) if (s >= 3 or t1_s8) else None
                     if zs is None:
                         for step in tr:
                             z = self.conv_bn(z, step[0], step[1], ACT_RELU)

@@ -136,6 +136,7 @@ SIGNATURES = {
     "otp_pointwise_x3_s8_weight_bytes": (c_size_t, [c_int] * 2),
     "otp_pointwise_x3_s8_pack": (c_int, [c_void_p] * 4 + [c_int, c_int, c_void_p]),
     "otp_pointwise_x3_s8": (c_int, [c_void_p] * 3 + [c_int] * 7 + [c_void_p]),
+    "otp_pointwise_x3_s8_res": (c_int, [c_void_p] * 4 + [c_int] * 9 + [c_void_p]),
     "otp_qkv_front_x3": (c_int, [c_void_p] * 8 + [c_int] * 3 + [c_float, c_void_p]),
     "otp_mlp_x3_supported": (c_int, [c_int] * 3),
     "otp_mlp_x3_weight_bytes": (c_size_t, [c_int] * 2),

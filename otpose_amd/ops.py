@@ -746,13 +746,16 @@ def pack_pointwise_x3_s8(weight, scale=None, shift=None):
     return packed
 
 
-def pointwise_x3_s8(x: View, packed, cout, out_s8=None, relu=False, stream=None):
-    """S8 image of act(scale * (W . x) + shift): a 1x1 conv feeding :func:`conv3x3_s8_launch` without an fp32 round trip."""
+def pointwise_x3_s8(x: View, packed, cout, out_s8=None, relu=False, stream=None, res: View = None):
+    """S8 image of act(scale * (W . x) + shift (+ res)): a 1x1 conv feeding :func:`conv3x3_s8_launch` without an fp32 round trip
+    (``res``: an fp32 NCHW channel-slice view, a Bottleneck's conv3)."""
     _require_gpu(x.t)
     b, _, h, w = x.t.shape
     out_s8 = s8_empty(b, cout, h, w, x.t.device) if out_s8 is None else out_s8
-    hip.check(hip.lib().otp_pointwise_x3_s8(hip.ptr(x.t), hip.ptr(packed), hip.ptr(out_s8), b, x.C, cout, h * w, x.ctot, x.coff,
-                                            int(bool(relu)), stream if stream is not None else hip.stream_of(x.t)),
+    hip.check(hip.lib().otp_pointwise_x3_s8_res(hip.ptr(x.t), hip.ptr(packed), hip.ptr(res.t if res is not None else None),
+                                                hip.ptr(out_s8), b, x.C, cout, h * w, x.ctot, x.coff,
+                                                res.ctot if res is not None else 0, res.coff if res is not None else 0,
+                                                int(bool(relu)), stream if stream is not None else hip.stream_of(x.t)),
               "otp_pointwise_x3_s8")
     return out_s8
 
