@@ -485,6 +485,17 @@ def test_pointwise_x3_s8_matches_fp64_and_feeds_the_s8_conv(cin, cout, hw):
     o = torch.empty(B, cout, h, w, device="cuda")
     ops.pointwise_x3(xv, ops.pack_pointwise_x3(wt.cuda(), sc.cuda(), sh.cuda()), ops.View(o), None, True)
     assert torch.equal(s8, ops.s8_pack(o))
+    # + an fp32 NCHW residual (a channel slice) before the ReLU: a Bottleneck's conv3 read as S8 only (layer1 -> transition1);
+    # the same bits as the fp32 route with the residual, packed
+    rt = seeded((B, cout + 4, h, w), 85).cuda()
+    rv = ops.View(rt, 4, cout)
+    s8r = ops.pointwise_x3_s8(xv, ops.pack_pointwise_x3_s8(wt.cuda(), sc.cuda(), sh.cuda()), cout, relu=True, res=rv)
+    o2 = torch.empty(B, cout, h, w, device="cuda")
+    ops.pointwise_x3(xv, ops.pack_pointwise_x3(wt.cuda(), sc.cuda(), sh.cuda()), ops.View(o2), rv, True)
+    assert torch.equal(s8r, ops.s8_pack(o2))
+    refr = (torch.einsum("oc,bchw->bohw", wt.double(), x) * sc.double()[None, :, None, None] + sh.double()[None, :, None, None]
+            + rt[:, 4:4 + cout].cpu().double()).clamp_min(0)
+    _close(ops.s8_unpack(s8r, B, cout, h, w), refr.float(), 2e-5)
 
 
 @pytest.mark.parametrize("T", [32, 250, 1152])
