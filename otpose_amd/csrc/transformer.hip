@@ -793,6 +793,8 @@ extern "C" int otp_ln_channel(const void* x, const void* gamma, const void* beta
     if (C <= 17) hipLaunchKernelGGL(ln_channel_kernel<17>, grid, dim3(256), 0, st, xf, gf, bf, yf, C, T, eps);
     else if (C <= 136)
         hipLaunchKernelGGL(ln_channel_split_kernel<34>, dim3(otp_ceil_div(T, 64), B), dim3(256), 0, st, xf, gf, bf, yf, C, T, eps);
+    else if (C <= 204)                                   // 12 x 17 stacked maps: the 7-frame window of BASELINE configs[4]
+        hipLaunchKernelGGL(ln_channel_split_kernel<51>, dim3(otp_ceil_div(T, 64), B), dim3(256), 0, st, xf, gf, bf, yf, C, T, eps);
     else hipLaunchKernelGGL(ln_channel_kernel<0>, grid, dim3(256), 0, st, xf, gf, bf, yf, C, T, eps);
     if (pool) {
         int To = (T + 2 - 3) / 2 + 1;

@@ -870,8 +870,11 @@ class InferenceEngine:
         self.call(L.otp_ln_channel, "otp_ln_channel", hip.ptr(x), hip.ptr(p(blk.ln1.weight)), hip.ptr(p(blk.ln1.bias)),
                   hip.ptr(ln1), hip.ptr(skip), B, C, T, blk.ln1.eps)
         q, k, v = self.new(B, C, To), self.new(B, C, To), self.new(B, C, To)
-        dense = self.use_dense_cc and ops.dense_cc_supported(C, To)
-        dx3 = dense and self.use_x3 and ops.dense_x3_supported(C, To)
+        # (the split-product kernels of csrc/densex.hip also hold C = 204, the 7-frame window of BASELINE configs[4]; the exact-fp32
+        #  ones of csrc/dense.hip only C = 136 - until round 4 this line asked the fp32 predicate first and cfg5 ran its
+        #  projections and the q / k / v front end on the generic kernels: 23 ms of kernel time per forward)
+        dx3 = self.use_dense_cc and self.use_x3 and ops.dense_x3_supported(C, To)
+        dense = dx3 or (self.use_dense_cc and ops.dense_cc_supported(C, To))
         if dense:
             packs = [ops.pack_dense_cc(m.weight.to(self.dev), None, m.bias.to(self.dev), x3=dx3)
                      for m in (a.query, a.key, a.value)]
