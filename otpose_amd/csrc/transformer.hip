@@ -345,8 +345,9 @@ __global__ __launch_bounds__(256) void attn_scores_x3_kernel(const float* __rest
                                                               float* __restrict__ slabs, int hs, int T, int chunk) {
     constexpr int HSP = NB * 16, NT = NB * NB, TPW = (NT + 3) / 4;
     constexpr int NQ = (HSP * (ATT_TC / 4) + 255) / 256;
-    __shared__ __attribute__((aligned(16))) unsigned char qh[HSP * SX_PITCH], ql[HSP * SX_PITCH];
-    __shared__ __attribute__((aligned(16))) unsigned char kh[HSP * SX_PITCH], kl_[HSP * SX_PITCH];
+    // (dynamic: 4 HSP SX_PITCH bytes - 64.5 KB at HSP = 112, the 102-wide heads of the 7-frame window, past the static limit)
+    extern __shared__ __attribute__((aligned(16))) unsigned char sxs[];
+    unsigned char *qh = sxs, *ql = sxs + HSP * SX_PITCH, *kh = sxs + 2 * HSP * SX_PITCH, *kl_ = sxs + 3 * HSP * SX_PITCH;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bh = blockIdx.x, s = blockIdx.y;
     const float* qb = q + (size_t)bh * hs * T;
@@ -593,11 +594,16 @@ __global__ __launch_bounds__(256) void attn_pv_kernel(const float* __restrict__ 
 // accumulator row of one 16-token tile, a few times per launch, only while the two temporal encoders ran side by side - found
 // as replay-to-replay differences of the batch-16 forward, tools/dbg notes in DESIGN.md section 4); with the CU to itself
 // neither kernel's results depend on what else is running.
-constexpr int PVX_WAVES = 8, PVX_TH = 64 * PVX_WAVES, PVX_TT = 32 * PVX_WAVES;
+// PVX_WAVES: 8 up to HSP = 80; 4 for the 96 / 112-wide heads of the 7-frame window (the records of 256 tokens would not fit)
 constexpr size_t PVX_LDS = 138 * 1024;
+constexpr int pvx_waves(int NB) { return NB <= 5 ? 8 : 4; }
+constexpr size_t pvx_lds(int NB) {
+    return NB <= 5 ? PVX_LDS : (size_t)(32 * pvx_waves(NB) + NB * 16) * (NB * 16 * 4 + 16) + 16;
+}
 template <int NB>
-__global__ __launch_bounds__(PVX_TH, 2) void attn_pv_x3_kernel(const float* __restrict__ v, const float* __restrict__ P,
-                                                          float* __restrict__ out, int hs, int T) {
+__global__ __launch_bounds__(64 * pvx_waves(NB), 2) void attn_pv_x3_kernel(const float* __restrict__ v, const float* __restrict__ P,
+                                                                      float* __restrict__ out, int hs, int T) {
+    constexpr int PVX_WAVES = pvx_waves(NB), PVX_TH = 64 * PVX_WAVES, PVX_TT = 32 * PVX_WAVES;
     constexpr int HSP = NB * 16, KS = (HSP + 31) / 32, G = HSP / 8;
     constexpr int REC = HSP * 4 + 16;                              // bytes of a token (v) / row (P) record
     constexpr int NVI = (G * (PVX_TT / 4) + PVX_TH - 1) / PVX_TH;            // v items (8 rows x 4 tokens) per thread
@@ -871,19 +877,20 @@ extern "C" int otp_chan_attn(const void* q, const void* k, const void* v, void* 
 #define OTP_ATT(NB_)                                                                                           \
     {                                                                                                          \
         bool split_ = false;                                                                                   \
-        if constexpr (NB_ <= 5) {                                                                              \
-            if (g_attn_split.load(std::memory_order_relaxed)) {                                                \
-                split_ = true;                                                                                 \
-                hipLaunchKernelGGL(attn_scores_x3_kernel<NB_>, g1, dim3(256), 0, st, qf, kf, slabs, hs, T, chunk); \
-            }                                                                                                  \
+        if (g_attn_split.load(std::memory_order_relaxed)) {                                                    \
+            split_ = true;                                                                                     \
+            auto ks_ = attn_scores_x3_kernel<NB_>;                                                             \
+            const size_t ls_ = (size_t)4 * NB_ * 16 * SX_PITCH;                                                \
+            OTP_ALLOW_BIG_LDS(ks_, ls_);                                                                       \
+            hipLaunchKernelGGL(ks_, g1, dim3(256), ls_, st, qf, kf, slabs, hs, T, chunk);                      \
         }                                                                                                      \
         if (!split_) hipLaunchKernelGGL(attn_scores_kernel<NB_>, g1, dim3(256), 0, st, qf, kf, slabs, hs, T, chunk); \
         hipLaunchKernelGGL(attn_softmax_kernel, dim3(BH, otp_ceil_div(HSP, 4)), dim3(256), 0, st, slabs, P, hs, HSP, NS, scale);      \
         if (split_) {                                                                                          \
             auto kx = attn_pv_x3_kernel<NB_>;                                                                  \
-            const size_t lx = PVX_LDS;                      /* >= (PVX_TT + HSP) * (HSP * 4 + 16) + 16 for HSP <= 80 */                                     \
+            const size_t lx = pvx_lds(NB_);                 /* >= (tokens + HSP) * (HSP * 4 + 16) + 16 */                                                   \
             OTP_ALLOW_BIG_LDS(kx, lx);                                                                         \
-            hipLaunchKernelGGL(kx, dim3(BH, otp_ceil_div(T, PVX_TT)), dim3(PVX_TH), lx, st, vf, P, of, hs, T);    \
+            hipLaunchKernelGGL(kx, dim3(BH, otp_ceil_div(T, 32 * pvx_waves(NB_))), dim3(64 * pvx_waves(NB_)), lx, st, vf, P, of, hs, T); \
         } else {                                                                                               \
             auto kern = attn_pv_kernel<NB_>;                                                                   \
             OTP_ALLOW_BIG_LDS(kern, pv_lds);                                                                   \
@@ -929,11 +936,12 @@ extern "C" int OTP_ENTRY(otp_chan_attn_scores)(const void* a, const void* b, voi
 #define OTP_SC(NB_)                                                                                       \
     {                                                                                                     \
         bool split_ = false;                                                                              \
-        if constexpr (NB_ <= 5) {                                                                         \
-            if (g_attn_split.load(std::memory_order_relaxed)) {                                           \
-                split_ = true;                                                                            \
-                hipLaunchKernelGGL(attn_scores_x3_kernel<NB_>, g1, dim3(256), 0, st, af, bf, sf, hs, T, chunk); \
-            }                                                                                             \
+        if (g_attn_split.load(std::memory_order_relaxed)) {                                               \
+            split_ = true;                                                                                \
+            auto ks_ = attn_scores_x3_kernel<NB_>;                                                        \
+            const size_t ls_ = (size_t)4 * NB_ * 16 * SX_PITCH;                                           \
+            OTP_ALLOW_BIG_LDS(ks_, ls_);                                                                  \
+            hipLaunchKernelGGL(ks_, g1, dim3(256), ls_, st, af, bf, sf, hs, T, chunk);                    \
         }                                                                                                 \
         if (!split_) hipLaunchKernelGGL(attn_scores_kernel<NB_>, g1, dim3(256), 0, st, af, bf, sf, hs, T, chunk); \
     }
@@ -965,14 +973,12 @@ extern "C" int OTP_ENTRY(otp_chan_attn_apply)(const void* v, const void* M, void
 #define OTP_APPLY(NB_)                                                                                      \
     {                                                                                                       \
         bool split_ = false;                                                                                \
-        if constexpr (NB_ <= 5) {                                                                           \
-            if (g_attn_split.load(std::memory_order_relaxed)) {                                             \
-                split_ = true;                                                                              \
-                auto kx = attn_pv_x3_kernel<NB_>;                                                           \
-                const size_t lx = PVX_LDS;                      /* >= (PVX_TT + HSP) * (HSP * 4 + 16) + 16 for HSP <= 80 */                              \
-                OTP_ALLOW_BIG_LDS(kx, lx);                                                                  \
-                hipLaunchKernelGGL(kx, dim3(BH, otp_ceil_div(T, PVX_TT)), dim3(PVX_TH), lx, st, vf, mf, of, hs, T); \
-            }                                                                                               \
+        if (g_attn_split.load(std::memory_order_relaxed)) {                                                 \
+            split_ = true;                                                                                  \
+            auto kx = attn_pv_x3_kernel<NB_>;                                                               \
+            const size_t lx = pvx_lds(NB_);                                                                 \
+            OTP_ALLOW_BIG_LDS(kx, lx);                                                                      \
+            hipLaunchKernelGGL(kx, dim3(BH, otp_ceil_div(T, 32 * pvx_waves(NB_))), dim3(64 * pvx_waves(NB_)), lx, st, vf, mf, of, hs, T); \
         }                                                                                                   \
         if (!split_) {                                                                                      \
             auto kern = attn_pv_kernel<NB_>;                                                                \

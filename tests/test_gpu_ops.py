@@ -270,6 +270,20 @@ def test_chan_attn_full_size_vs_oracle_slice():
     _close(out, ref, 1e-4)
 
 
+@pytest.mark.parametrize("c,nh,t", [(204, 2, 1728), (192, 2, 500), (204, 2, 6912)])
+def test_chan_attn_wide_heads_vs_fp64(c, nh, t):
+    """Head sizes 96 / 102 (the 12 x 17 stacked maps of the 7-frame window, BASELINE configs[4]): the split-product score and
+    P . v kernels with their LDS images sized at run time (round 4; before, heads wider than 80 ran on the f32-MFMA kernels)
+    against float64, ragged and full lengths."""
+    b = 2
+    q, k, v = seeded((b, c, t), 1, 0.3), seeded((b, c, t), 2, 0.3), seeded((b, c, t), 3)
+    hs = c // nh
+    att = (q.double().view(b, nh, hs, t) * (1 / math.sqrt(hs))) @ k.double().view(b, nh, hs, t).transpose(-2, -1)
+    ref = (F.softmax(att, -1) @ v.double().view(b, nh, hs, t)).transpose(2, 3).contiguous().view(b, c, t)
+    out = ops.chan_attn(q.cuda(), k.cuda(), v.cuda(), nh, 1 / math.sqrt(hs))
+    _close(out, ref.float(), 1e-4)
+
+
 @pytest.mark.parametrize("f", [1, 2, 4])
 def test_upsample_linear(f):
     x = seeded((2, 5, 27), 1)
