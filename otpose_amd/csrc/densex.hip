@@ -198,7 +198,7 @@ struct QxArgs {
 // q, k, v = W_p . LN_p(dwconv3_p(x)) + b_p in one launch (stride 1); table[p][c] = {dw0, dw1, dw2, gamma, beta, 0, 0, 0}
 // (three waves per SIMD: 168 VGPRs with 21 spilled measured 119 us at cfg2 against 127 at two waves / 183 VGPRs and 133 at four)
 template <int C>
-__global__ __launch_bounds__(256, C <= 136 ? 3 : 2) void qkvx_front_kernel(const float* __restrict__ x, const float* __restrict__ table,
+__global__ __launch_bounds__(256, C <= 136 ? 3 : 1) void qkvx_front_kernel(const float* __restrict__ x, const float* __restrict__ table,
                                                             QxArgs A, int T, int tiles_per_b, float eps) {
     constexpr int KS = dx_ks(C), BLKB = dx_block_bytes(C), TAB = 3 * C * 8;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BLKB];
