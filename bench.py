@@ -113,7 +113,7 @@ def measured_traffic(key, with_source=False):
     in separate passes and corrected as MI355X_MICROARCH.md prescribes; see profiles/r02_traffic.json for the split-bf16
     kernels and profiles/r01_traffic.json for the f32 ones).  None when the files or the key are absent: PMC counters cannot
     be read from inside this process."""
-    for name in ("r04c_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in ("r04f_traffic.json", "r04c_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 v = json.load(f).get(key, {}).get("hbm_bytes_per_launch")
@@ -215,6 +215,7 @@ def kernel_rooflines(dev, batch):
         ds2 = ops.s8_conv_desc(n, 48, 48, 96, 72, ops.ACT_RELU)
         ds2.out_scale, ds2.res_layout = ds.out_scale, 1
         t_conv2 = event_time_ms(lambda: ops.conv3x3_s8_launch(xs, ws, sh, ds2, rs8, None, ops.S8_F32_C4, ys), 20, st)
+        tr2, _ = measured_traffic("convs_48_48_3x3_96x72_x80_conv2", True)
         kname = ("convs_kernel<3, false, 4> (f16x3 split products, S8 operand records, LDS-DMA, 3 workgroups / CU) 48->48 3x3 @96x72 x%d frames, S8 -> S8 "
                  "(grid %d x 256 threads)" % (n, ((n * 96 * 72 // 256 + 7) // 8) * 8))
         executed = conv_flop * 3.0 * 10.0 / 9.0
@@ -222,14 +223,14 @@ def kernel_rooflines(dev, batch):
         extra = {"arithmetic": "fp32 accumulate; operands stored as IEEE-half hi | lo records (hi = rne(x), lo = rne(x - hi)), products "
                                "lo*hi + hi*lo + hi*hi on v_mfma_f32_16x16x32_f16; weights stored times a per-layer power of two so that both "
                                "pieces are normal numbers (csrc/convs.hip, otp_conv_desc.out_scale)",
-                 "pmc": "committed profile, not collected in this run - profiles/r04c_convs_pmc_fold.txt: SQ_INSTS_VALU 11.18 M of which 4.67 M MFMA = 1.40 other vector "
+                 "pmc": "committed profile, not collected in this run - profiles/r04f_convs_pmc_fold.txt: SQ_INSTS_VALU 11.18 M of which 4.67 M MFMA = 1.40 other vector "
                         "instructions per MFMA (prologue / epilogue), SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 6 %",
                  "conv2_form": {"what": "S8 + S8 residual -> S8 (BasicBlock conv2; round 3: + C4 residual -> C4 + S8, 428 MB)", "ms_per_launch": t_conv2,
                                 "achieved": conv_flop / (t_conv2 * 1e-3) / 1e12, "frac": conv_flop / (t_conv2 * 1e-3) / peak,
                                 "mfma_pipe_frac": executed / (t_conv2 * 1e-3) / peak,
-                                "traffic": None, "traffic_source": "not collected for this form (the committed counters are of the round-3 form)",
+                                "traffic": tr2, "traffic_source": "committed profile (profiles/r04f_traffic.json: separate --pmc passes of tools/convs_one.py ... conv2s), not collected in this run",
                                 "algorithmic_bytes_per_launch": 3.0 * 4 * 48 * 96 * 72 * n,
-                                "hbm_frac": 3.0 * 4 * 48 * 96 * 72 * n / (t_conv2 * 1e-3) / PEAK_HBM}}
+                                "hbm_frac": (tr2 if tr2 is not None else 3.0 * 4 * 48 * 96 * 72 * n) / (t_conv2 * 1e-3) / PEAK_HBM}}
     elif use_x3:
         # the kernel the engine runs for this layer outside the S8 path: split-half products on the 16-bit matrix cores from fp32
         # NCHW input (csrc/convx.hip).  Every fp32 product is three f16 MFMA products and a chunk's 9 taps occupy 10 tap

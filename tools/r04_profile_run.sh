@@ -8,7 +8,7 @@ mkdir -p gpurun_out
 SQ1="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES"
 SQ2="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES"
 bash tools/pmc.sh ${TAG}_convs "$SQ1" "$SQ2" "FETCH_SIZE" "WRITE_SIZE" -- tools/convs_one.py 80 48 48 96 72
-bash tools/pmc.sh ${TAG}_convs_conv2 "FETCH_SIZE" "WRITE_SIZE" -- tools/convs_one.py 80 48 48 96 72 conv2
+bash tools/pmc.sh ${TAG}_convs_conv2 "FETCH_SIZE" "WRITE_SIZE" -- tools/convs_one.py 80 48 48 96 72 conv2s
 bash tools/pmc.sh ${TAG}_convs2 "$SQ1" "$SQ2" "FETCH_SIZE" "WRITE_SIZE" -- tools/convs2_one.py 80 48 96 96 72
 python tools/pmc_fold.py convs_kernel gpurun_out/${TAG}_convs_pmc1.csv gpurun_out/${TAG}_convs_pmc2.csv gpurun_out/${TAG}_convs_pmc3.csv gpurun_out/${TAG}_convs_pmc4.csv > gpurun_out/${TAG}_convs_pmc_fold.txt
 python tools/pmc_fold.py convs_kernel gpurun_out/${TAG}_convs_conv2_pmc1.csv gpurun_out/${TAG}_convs_conv2_pmc2.csv >> gpurun_out/${TAG}_convs_pmc_fold.txt
@@ -25,7 +25,7 @@ def mean(path, sub, counter):
 out = {}
 for key, stem, kern, alg, what in (
         ("convs_48_48_3x3_96x72_x80", "convs", "convs_kernel", 212336640, "convs_kernel<3, false, 4> S8 -> S8, ReLU (a BasicBlock's conv1; tools/convs_one.py 80 48 48 96 72)"),
-        ("convs_48_48_3x3_96x72_x80_conv2", "convs_conv2", "convs_kernel", 424673280, "convs_kernel<3, false, 4> S8 + C4 residual -> C4 + S8 (a BasicBlock's conv2)"),
+        ("convs_48_48_3x3_96x72_x80_conv2", "convs_conv2", "convs_kernel", 318504960, "convs_kernel<3, false, 4> S8 + S8 residual -> S8 (a BasicBlock's conv2 since round 4; tools/convs_one.py ... conv2s)"),
         ("convs2_48_96_3x3s2_96x72_x80", "convs2", "convs2_kernel", 4 * 80 * (48 * 96 * 72 + 96 * 48 * 36), "convs2_kernel<3, true, 2> S8 -> fp32 NCHW, ReLU (fuse layer 48 -> 96 stride 2; tools/convs2_one.py 80 48 96 96 72)")):
     fi = 3 if stem != "convs_conv2" else 1
     f = mean("gpurun_out/%s_%s_pmc%d.csv" % (tag, stem, fi), kern, "FETCH_SIZE")
