@@ -37,10 +37,20 @@ for c, h, w in ((48, 96, 72), (96, 48, 36), (192, 24, 18), (384, 12, 9)):
         hh, ww, f = hh // 2, ww // 2, f * 2
         lows.append(torch.randn(n, c, hh, ww, device="cuda"))
         fs.append(f)
-    if not lows:
+    if not lows or w % 4:                 # (otp_s8_upsample_add wants rows of whole float4s)
         continue
     lp = (ctypes.c_void_p * len(lows))(*[hip.ptr(v) for v in lows])
     fp = (ctypes.c_int * len(lows))(*fs)
+    # the forms the engine launches since round 4: no C4 image; the row's own term as fp32 NCHW or as its S8 image
+    xs8 = ops.s8_pack(x)
+    for lay, what in ((0, "NCHW"), (1, "S8")):
+        src = xs8 if lay else x
+        g2 = lambda: hip.check(L.otp_s8_upsample_add_ex(lp, fp, len(lows), hip.ptr(src), lay, None, hip.ptr(s8), None,   # noqa: E731
+                                                       n, c, h, w, 1, c, 0, c, 0, hip.stream_of(x)), "up")
+        t = timeit(g2)
+        byts = 4.0 * (x.numel() * 2 + sum(v.numel() for v in lows))
+        print("s8_upsample_add_ex %3d ch @%dx%d x%d, %d low terms, %s residual -> S8 only: %.1f us, %.2f TB/s"
+              % (c, h, w, n, len(lows), what, t, byts / t / 1e6), flush=True)
     for nchw in (False, True):
         o = torch.empty_like(x)
         g = lambda: hip.check(L.otp_s8_upsample_add(lp, fp, len(lows), hip.ptr(x), hip.ptr(o) if nchw else None, hip.ptr(s8),   # noqa: E731
