@@ -71,6 +71,18 @@ def test_e2e_cfg2_clip_matches_reference_golden(golden):
     print(_check(outs, golden("e2e_cfg2_b1")))
 
 
+@pytest.mark.parametrize("switch", ["OTPOSE_S8_STRIDE2", "OTPOSE_FUSE_UPSAMPLE", "OTPOSE_POINTX", "OTPOSE_S8_RESIDUAL",
+                                    "OTPOSE_S8_LAZY_NCHW", "OTPOSE_T1_S8", "OTPOSE_CHAIN_MODULES", "OTPOSE_STEM_X3", "OTPOSE_L1_S8",
+                                    "OTPOSE_X3_WSCALE", "OTPOSE_S8"])
+def test_e2e_cfg1_with_each_engine_switch_off(golden, monkeypatch, switch):
+    """Every kernel-family switch of the engine, one at a time, against the reference-generated golden.  Since round 4 a branch
+    output's NCHW tensor is written only when a consumer asks for it (engine._needs_nchw): each switch moves some consumer from
+    the S8 records back to the fp32 tensor, and a consumer that forgot to ask would read an unwritten buffer here."""
+    monkeypatch.setenv(switch, "0")
+    _, outs = _run(cfg1(), 1)
+    _check(outs, golden("e2e_cfg1"))
+
+
 def test_graph_replay_and_eager_agree_and_batch_rows_are_independent(monkeypatch):
     cfg = tiny_cfg(8, (64, 96))
     m, outs = _run(cfg, 2)
