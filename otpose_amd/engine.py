@@ -690,7 +690,9 @@ class InferenceEngine:
                 if j > i:
                     f = 2 ** (j - i)
                     tgt = y if y is not None else View(self.new(*xs[i].t.shape))
-                    if f >= 2 and (xs[j].t.shape[3] * f) % 4 == 0:
+                    if f >= 2 and ((xs[j].t.shape[3] * f) % 4 == 0 or os.environ.get("OTPOSE_UP_ANY_WIDTH", "1") != "0"):
+                        # (any width: otp_upsample_add has a one-element form - rows of 18 at 384x288 used to send the 384 -> 192
+                        #  term of stage 4's row 2 to the generic conv kernel's upsample epilogue, 195 us on the row's critical path)
                         # the upsampled tensor is f*f x the conv result: conv at low resolution, then one streaming
                         # accumulate kernel (measured faster than the conv kernel's element-wise upsample epilogue)
                         low = self.conv_bn(xs[j], fl[0], fl[1], ACT_NONE)
