@@ -83,7 +83,10 @@ def shutdown() -> None:
     if _group_alive():
         if torch.cuda.is_available():
             torch.cuda.synchronize()
-        dist.barrier()
+        if dist.get_world_size() > 1:                    # (a one-rank group has nobody to wait for: no collective on the way out)
+            dist.barrier()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
         dist.destroy_process_group()
 
 
