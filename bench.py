@@ -368,7 +368,7 @@ def kernel_rooflines(dev, batch):
         w_msk = [(torch.randn(153, 32, 3, 3, generator=g) / 17.0).to(dev) for _ in dils]
         w_dcn = [(torch.randn(17, 17, 3, 3, generator=g) * 0.2).to(dev) for _ in dils]
         packed = ops.pack_dcn_fused(w_off, w_msk, w_dcn, [None] * 5)
-        ws = torch.empty(batch * 96 * 72 * 32, dtype=torch.int32, device=dev)
+        ws = torch.empty(hip.lib().otp_dcn_fused_workspace(batch, 96, 72) // 4, dtype=torch.int32, device=dev)
         t_head = event_time_ms(lambda: ops.dcn_fused(tr, xd, packed, dils, 0.2, out=od, workspace=ws), 10, st)
         conv_fl = 2.0 * 459 * 32 * 9 * 96 * 72 * batch * 5                     # the ten 32 -> 306 / 153 convs
         unfused_bytes = (DCN_BYTES_PER_CLIP_DIL + 2 * 459 * 6912 * 4.0) * batch * 5   # DCN streams + conv outputs written

@@ -78,6 +78,24 @@ __global__ __launch_bounds__(256) void dcnf_split_kernel(const float* __restrict
     }
 }
 
+// def_heatmaps (B, J, H, W) -> planes with a one-pixel ZERO border, (H + 2) x (W + 2): a bilinear corner of a sample inside the
+// open interval (-1, H) x (-1, W) is then always a valid element (row floor(h) + 1 in [0, H], + 1 in [1, H + 1]), so the gather
+// needs no per-corner bounds logic - ~13 of the ~55 vector instructions per sample of a kernel that is bound by their issue
+// (profiles/r04_dcnf_pmc_fold.txt: 140 M non-MFMA vector instructions per launch) - and the four corners share one address
+// register (immediate offsets 4, Wp 4, Wp 4 + 4).  8.4 MB at cfg2, L2 resident like the planes it replaces.
+__global__ __launch_bounds__(256) void dcnf_pad_kernel(const float* __restrict__ x, float* __restrict__ xp, int planes, int H, int W) {
+    const int Hp = H + 2, Wp = W + 2;
+    const size_t total = (size_t)planes * Hp * Wp;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Wp);
+        const size_t r = i / Wp;
+        const int y = (int)(r % Hp);
+        const size_t pl = r / Hp;
+        const bool in = y >= 1 && y <= H && c >= 1 && c <= W;
+        xp[i] = in ? x[(pl * H + (y - 1)) * W + (c - 1)] : 0.f;
+    }
+}
+
 // The offset and the mask weights of a dilation are stored times a power of two each (2^k with max |w| 2^k in [2^13, 2^14):
 // both half pieces of every weight are then normal numbers, 22 significand bits instead of ~17 - otp_conv_desc.out_scale in
 // include/otpose_hip.h is the same device) and the kernel multiplies the sums by 2^-k on their way to the sampling scratch.
@@ -194,7 +212,8 @@ __global__ __launch_bounds__(64 * NW) void dcn_fused_kernel(const unsigned char*
     float* scr = scratch + wave * (16 * FSCR_);
 
     const otp_rsrc rws = make_rsrc32(ws + (size_t)n * P.HW * 128, (unsigned)P.HW * 128u);
-    const otp_rsrc rx = make_rsrc32(x + (size_t)n * J * P.HW, (unsigned)(J * P.HW) * 4u);
+    const int Wp = P.W + 2, HWp = (P.H + 2) * Wp;              // x: the zero-bordered planes of dcnf_pad_kernel
+    const otp_rsrc rx = make_rsrc32(x + (size_t)n * J * HWp, (unsigned)(J * HWp) * 4u);
     const size_t table_off = (size_t)P.ND * J * FBLK;
     const float* postv = reinterpret_cast<const float*>(packed + table_off + ((size_t)P.ND * J * 45 + 5) * 16);
 
@@ -266,12 +285,12 @@ __global__ __launch_bounds__(64 * NW) void dcn_fused_kernel(const unsigned char*
                 const float hf = floorf(hc), wf = floorf(wc);
                 const int hl = (int)hf, wl = (int)wf;
                 const float lh = hc - hf, lw = wc - wf, hh = 1.f - lh, hw = 1.f - lw;
-                const int base = (g * P.H + hl) * P.W + wl;
-                const bool t_ok = hl >= 0, b_ok = hl + 1 < P.H, l_ok = wl >= 0, r_ok = wl + 1 < P.W;
-                const float v1 = bload(rx, (t_ok && l_ok) ? base * 4 : -16, 0);
-                const float v2 = bload(rx, (t_ok && r_ok) ? (base + 1) * 4 : -16, 0);
-                const float v3 = bload(rx, (b_ok && l_ok) ? (base + P.W) * 4 : -16, 0);
-                const float v4 = bload(rx, (b_ok && r_ok) ? (base + P.W + 1) * 4 : -16, 0);
+                // (hl, wl) in [-1, H - 1] x [-1, W - 1]: element (hl + 1, wl + 1) of the bordered plane and its three neighbours exist
+                const int base = (g * HWp + (hl + 1) * Wp + wl + 1) * 4;
+                const float v1 = bload(rx, base, 0);
+                const float v2 = bload(rx, base + 4, 0);
+                const float v3 = bload(rx, base + Wp * 4, 0);
+                const float v4 = bload(rx, base + Wp * 4 + 4, 0);
                 const float smp = hh * hw * v1 + hh * lw * v2 + lh * hw * v3 + lh * lw * v4;
                 const float val = (live && inside) ? smp * m : 0.f;
                 const float* wrow = wd + (g * 9 + k) * 20;
@@ -339,8 +358,10 @@ extern "C" int otp_dcn_fused_pack(const void* const* w_off, const void* const* w
     return otp_launch_status();
 }
 
+// the split copy of `trans` ((B, H, W, [32 hi | 32 lo]) halves) + the zero-bordered copy of the J = 17 heat-map planes
+static size_t dcnf_split_bytes(int B, int H, int W) { return (size_t)B * H * W * 128; }
 extern "C" size_t otp_dcn_fused_workspace(int B, int H, int W) {
-    return (B > 0 && H > 0 && W > 0) ? (size_t)B * H * W * 128 : 0;
+    return (B > 0 && H > 0 && W > 0) ? dcnf_split_bytes(B, H, W) + (size_t)B * 17 * (H + 2) * (W + 2) * sizeof(float) : 0;
 }
 
 extern "C" int otp_dcn_fused_forward(const void* trans, const void* x, const void* packed, void* out, void* workspace,
@@ -363,17 +384,23 @@ extern "C" int otp_dcn_fused_forward(const void* trans, const void* x, const voi
     const size_t nsplit = (size_t)B * P.HW * 4;
     hipLaunchKernelGGL(dcnf_split_kernel, dim3((unsigned)((nsplit + 255) / 256 > 4096 ? 4096 : (nsplit + 255) / 256)), dim3(256), 0,
                        st, static_cast<const float*>(trans), static_cast<u32x4*>(workspace), B, P.HW);
+    float* xp = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + dcnf_split_bytes(B, H, W));
+    {
+        const size_t npad = (size_t)B * J * (H + 2) * (W + 2);
+        hipLaunchKernelGGL(dcnf_pad_kernel, dim3((unsigned)((npad + 255) / 256 > 4096 ? 4096 : (npad + 255) / 256)), dim3(256), 0, st,
+                           static_cast<const float*>(x), xp, B * J, H, W);
+    }
     const size_t lds = 2 * (size_t)FBLK + (size_t)(px / 16) * 16 * FSCR_ * 4 + (size_t)17 * 9 * 20 * 4 + 64;
     if (nine) {
         auto kern = dcn_fused_kernel<17, 9>;
         OTP_ALLOW_BIG_LDS(kern, lds);
         hipLaunchKernelGGL(kern, dim3((unsigned)(B * P.tilesPerImg)), dim3(576), lds, st, static_cast<const unsigned char*>(workspace),
-                           static_cast<const float*>(x), static_cast<const unsigned char*>(packed), static_cast<float*>(out), P);
+                           static_cast<const float*>(xp), static_cast<const unsigned char*>(packed), static_cast<float*>(out), P);
     } else {
         auto kern = dcn_fused_kernel<17, 8>;
         OTP_ALLOW_BIG_LDS(kern, lds);
         hipLaunchKernelGGL(kern, dim3((unsigned)(B * P.tilesPerImg)), dim3(512), lds, st, static_cast<const unsigned char*>(workspace),
-                           static_cast<const float*>(x), static_cast<const unsigned char*>(packed), static_cast<float*>(out), P);
+                           static_cast<const float*>(xp), static_cast<const unsigned char*>(packed), static_cast<float*>(out), P);
     }
     return otp_launch_status();
 }

@@ -1098,7 +1098,8 @@ class InferenceEngine:
                                         [self.dev_param(c[0].weight) for c in m.masks_list],
                                         [self.dev_param(dc.weight) for dc in dcs],
                                         [None if dc.bias is None else self.dev_param(dc.bias) for dc in dcs])
-            ws = self.new(B, 32, h, w)                               # bf16 hi / lo NHWC copy of trans: 128 bytes per pixel
+            # the split NHWC copy of trans (128 bytes per pixel) + the zero-bordered copy of the heat-map planes
+            ws = self.new(int(L.otp_dcn_fused_workspace(B, h, w)) // 4)
             dl = (ctypes.c_int * nd)(*dils)
             self._keep += [packed, dl]
             self.call(L.otp_dcn_fused_forward, "otp_dcn_fused_forward", hip.ptr(trans.t), hip.ptr(def_h.t), hip.ptr(packed),

@@ -14,7 +14,8 @@ w_dcn = [(torch.randn(J, J, 3, 3, generator=g) * 0.2).cuda() for _ in dils]
 bias = [torch.randn(J, generator=g).cuda() for _ in dils]
 packed = ops.pack_dcn_fused(w_off, w_msk, w_dcn, bias)
 out = torch.empty_like(x)
-ws = torch.empty(B * H * W * 32, dtype=torch.int32, device="cuda")
+from otpose_amd import hip  # noqa: E402
+ws = torch.empty(hip.lib().otp_dcn_fused_workspace(B, H, W) // 4, dtype=torch.int32, device="cuda")
 
 
 def timed(fn, reps=10):
