@@ -41,6 +41,65 @@ extern "C" {
 
 int otp_version(void);
 
+/* ---- range guard of the 16-bit-operand kernels (csrc/range.hip) -------------------------------------------------------------
+ * The split-product ("x3") kernels below carry every fp32 operand as two IEEE-half pieces, and the fp16 engine (otp_h16_*)
+ * stores activations as halves: both have fp32's significand budget or less and HALF'S EXPONENT RANGE - |a| >= 65504 becomes
+ * inf, its products NaN, and a ReLU or the DCN's bounds test would swallow the NaN.  The reference computes these layers in
+ * fp32 (model/HRNet.py:500-530, model/blocks.py:248-254, 400-453) and has no such limit, so it is never crossed silently:
+ * every such kernel tests its results before the activation and records a violation in one process-wide sticky word.
+ *   otp_range_flag_read(reset): 0 = clean, else the code of a kernel family that saw a non-finite sum or a result >= 65504
+ *     since the last reset (1 convx, 2 convs, 3 convs2, 4 pointx, 5 stem, 6 S8 passes, 7 mlpx, 8 densex, 9 attention,
+ *     10 dcn_fused, 11 fp16 engine).  Host function; definitive once the launches in question have completed.
+ *   otp_range_poison(out, n, stream): launch that fills out[0 .. n) (fp32) with NaN if the word is set - the last launch of a
+ *     forward, so that a caller who never asks cannot consume finite-looking heat-maps computed from an overflowed operand. */
+int otp_range_flag_read(int reset);
+int otp_range_poison(void* out, size_t n, void* stream);
+
+/* ---- fp16-storage eval kernels of the HRNet backbone (csrc/h16.hip; cfg.MODEL.DTYPE = "fp16", BASELINE.json configs[4]) --------
+ * The reference's native op dispatches half (deform_conv_cuda_kernel.cu:719) but its model never runs below fp32; this is the
+ * documented fp16 extension.  Operands are IEEE half - activations as stored, weights rounded once times a per-layer power of two
+ * `pre` (the launch multiplies its sums by out_scale = 1 / pre) - one f16 MFMA per product, fp32 accumulation / shift / residual /
+ * ReLU, one rounding to half per stored value.
+ * H8 image of a logical (N, C, H, W) tensor, C % 8 == 0: [N][C / 8][H * W] records of 16 bytes = the 8 halves of channels
+ * 8 g .. 8 g + 7 at pixel p (otp_h8_bytes = 2 bytes per element).  (gtot, goff) address a range of channel groups of a wider H8
+ * tensor (gtot = 0: dense), so channel concatenations cost nothing.
+ *   otp_h8_pack / otp_h8_unpack       fp32 NCHW channel slice <-> H8 (round to nearest even / exact widening)
+ *   otp_h16_conv3x3                   out = act(conv3x3 pad 1 stride 1|2 (in) + shift (+ res)), H8 -> H8: model/HRNet.py:500-530
+ *                                     (BasicBlock), :551-571 (Bottleneck conv2), :213-229 / :442-470 (stride-2 chains), :66-72
+ *   otp_h16_pointwise                 out = act(W x + shift (+ res)): H8 -> H8, or -> a channel slice of an fp32 NCHW tensor
+ *                                     (out_f32_nchw = 1; out_tot / out_off then count channels): :551-571 conv1 / conv3, :426-439
+ *                                     (fuse 1x1), :108-114 (final_layer)
+ *   otp_h16_stem                      relu(conv3x3 s2 p1 (frames of the fp32 clip (B, 3 F, H, W)) + shift) -> H8 (F B, Cout, ..): :118-120
+ *   otp_h16_upsample_add              out = act(res + sum_k nearest_up_fk(low_k)), all H8: a fuse row's tail, :487-494
+ * Every launch feeds the range guard (otp_range_flag_read, code 11).  Never allocates, never synchronises. */
+typedef struct otp_h16_conv_desc {
+    int N, Cin, H, W, Cout, stride, act;                               /* 3x3, pad 1, dilation 1; Cin % 16 == 0, Cout % 8 == 0 */
+    int in_gtot, in_goff, out_gtot, out_goff, res_gtot, res_goff;      /* channel-group slices (gtot = 0: the dense tensor) */
+    float out_scale;                                                   /* 1 / pre of otp_h16_conv3x3_pack_weight (0 = 1) */
+} otp_h16_conv_desc;
+size_t otp_h8_bytes(int N, int C, int H, int W);
+int otp_h8_pack(const void* in_f32, void* out_h8, int N, int C, int H, int W, int in_ctot, int in_coff, int out_gtot, int out_goff,
+                void* stream);
+int otp_h8_unpack(const void* in_h8, void* out_f32, int N, int C, int H, int W, int in_gtot, int in_goff, void* stream);
+int otp_h16_conv3x3_supported(const otp_h16_conv_desc* desc);
+size_t otp_h16_conv3x3_weight_bytes(int Cout, int Cin);
+int otp_h16_conv3x3_pack_weight(const void* weight, const void* scale, void* wpacked, int Cout, int Cin, float pre, void* stream);
+int otp_h16_conv3x3(const void* in_h8, const void* wpacked, const void* shift, const void* res_h8, void* out_h8,
+                    const otp_h16_conv_desc* desc, void* stream);
+int otp_h16_pointwise_supported(int Cin, int Cout);
+size_t otp_h16_pointwise_weight_bytes(int Cin, int Cout);
+int otp_h16_pointwise_pack(const void* w, const void* scale, const void* shift, void* packed, int Cin, int Cout, float pre,
+                           void* stream);
+int otp_h16_pointwise(const void* in_h8, const void* packed, const void* res_h8, void* out, int out_f32_nchw, int N, int Cin, int Cout,
+                      int HW, int in_gtot, int in_goff, int res_gtot, int res_goff, int out_tot, int out_off, int relu,
+                      float out_scale, void* stream);
+int otp_h16_stem_supported(int B, int F, int H, int W, int Cout);
+size_t otp_h16_stem_weight_bytes(int Cout);
+int otp_h16_stem_pack(const void* w, const void* scale, const void* shift, void* packed, int Cout, void* stream);
+int otp_h16_stem(const void* in, const void* packed, void* out_h8, int B, int F, int H, int W, int Cout, void* stream);
+int otp_h16_upsample_add(const void* const* lows_h8, const int* factors, int nlow, const void* res_h8, void* out_h8, int N, int C,
+                         int Hh, int Wh, int relu, void* stream);
+
 /* ---- modulated deformable convolution ------------------------------------------------------
  * out[n,o,p] = beta*out[n,o,p] + alpha*( bias[o] + sum_{c,k} W[o,c,k] * mask[n,g(c)*K+k,p] *
  *              bilinear(x[n,c], p*stride - pad + tap_k*dil + offset[n,g(c)*2K+2k(+1),p]) ),

@@ -86,11 +86,14 @@ def _stage(modules: int, channels: Iterable[int]) -> Dict[str, Any]:
 
 
 def make_cfg(width: int = 48, image_size: Tuple[int, int] = (288, 384),
-             dilations: Iterable[int] = (3, 6, 9, 12, 15), frames: int = 5) -> CfgNode:
+             dilations: Iterable[int] = (3, 6, 9, 12, 15), frames: int = 5, dtype: str = "fp32") -> CfgNode:
     """Built-in OTPose configuration.
 
     ``frames`` = frames per clip window: 5 is the reference (hard-coded at model/OTPose.py:309,320-321); 7 is this build's
     extension for BASELINE configs[4] (``MODEL.WINDOW_FRAMES``, 12 stacked maps per joint: oracle ``window_maps``).
+
+    ``dtype`` = ``MODEL.DTYPE`` of the EVAL forward: "fp32" (the reference's arithmetic) or "fp16" (BASELINE configs[4]: backbone
+    activations stored as IEEE half, one f16 MFMA per product - otpose_amd/engine_h16.py; an extension, never a default).
 
     ``width`` is the HRNet branch-0 width (48 = the reference's W48 yaml, 32 = HRNet-W32 used by
     BASELINE.json configs[0]); ``image_size`` is (W, H) as in the reference yaml.
@@ -103,6 +106,7 @@ def make_cfg(width: int = 48, image_size: Tuple[int, int] = (288, 384),
             "NAME": "OTPose",
             "NUM_JOINTS": 17,
             "WINDOW_FRAMES": int(frames),
+            "DTYPE": str(dtype),
             "IMAGE_SIZE": [w, h],
             "HEATMAP_SIZE": [w // 4, h // 4],
             "PRETRAINED": "",
@@ -133,11 +137,12 @@ def cfg2() -> CfgNode:
     return make_cfg(48, (288, 384))
 
 
-def tiny_cfg(width: int = 8, image_size: Tuple[int, int] = (64, 96), frames: int = 5) -> CfgNode:
+def tiny_cfg(width: int = 8, image_size: Tuple[int, int] = (64, 96), frames: int = 5, dtype: str = "fp32") -> CfgNode:
     """A reduced-width, reduced-resolution model with the full OTPose topology (test sizes)."""
-    return make_cfg(width, image_size, frames=frames)
+    return make_cfg(width, image_size, frames=frames, dtype=dtype)
 
 
-def cfg5() -> CfgNode:
-    """BASELINE.json configs[4]: 7-frame window at 384x288 (extension; the reference has no such model)."""
-    return make_cfg(48, (288, 384), frames=7)
+def cfg5(dtype: str = "fp32") -> CfgNode:
+    """BASELINE.json configs[4]: 7-frame window at 384x288 (extension; the reference has no such model); ``dtype="fp16"`` is the
+    configuration as BASELINE.json states it."""
+    return make_cfg(48, (288, 384), frames=7, dtype=dtype)

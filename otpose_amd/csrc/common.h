@@ -88,6 +88,28 @@ __device__ __forceinline__ otp_f32x2 otp_x3_widen(uint32_t pair) {
     return __builtin_convertvector(__builtin_bit_cast(otp_x3x2, pair), otp_f32x2);
 }
 typedef unsigned int otp_u32x4 __attribute__((ext_vector_type(4)));
+
+// ---- range guard of the 16-bit-operand kernels (csrc/range.hip) ----------------------------------------------------------------
+// A half piece overflows at 65504: hi = rne(a) = inf, lo = rne(a - hi) = -inf, every product with it NaN - and a ReLU (v_max_f32
+// drops a quiet NaN) or the DCN's open-interval test can swallow that NaN silently.  Every kernel that forms such pieces
+// therefore tests ITS RESULTS before the activation - a NaN accumulator is an operand that overflowed, |v| >= 65504 is a value
+// the next consumer could not split - and stores a code word through `otp_range_word()` (one word of pinned host memory, visible
+// to every device of the process; written only on a violation, so the guard costs a compare per result and no memory traffic).
+// include/otpose_hip.h: otp_range_flag_read / otp_range_poison.
+#ifdef OTP_X3_BF16
+#define OTP_RANGE_LIMIT 3.0e38f                                    /* bfloat16 pieces (the gradient builds): fp32's own range */
+#else
+#define OTP_RANGE_LIMIT 65504.f
+#endif
+enum {
+    OTP_RANGE_CONVX = 1, OTP_RANGE_CONVS = 2, OTP_RANGE_CONVS2 = 3, OTP_RANGE_POINTX = 4, OTP_RANGE_STEM = 5, OTP_RANGE_S8PASS = 6,
+    OTP_RANGE_MLPX = 7, OTP_RANGE_DENSEX = 8, OTP_RANGE_ATTN = 9, OTP_RANGE_DCNF = 10, OTP_RANGE_H16 = 11
+};
+unsigned* otp_range_word();                                        // host side: the word's address (NULL without a GPU)
+__device__ __forceinline__ bool otp_out_of_range(float v) { return !(__builtin_fabsf(v) < OTP_RANGE_LIMIT); }   // true for NaN too
+__device__ __forceinline__ void otp_range_report(unsigned* word, bool bad, unsigned code) {
+    if (bad && word) __hip_atomic_store(word, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 // 16-byte buffer load: offsets at or past the descriptor's size return zeros (hardware range check)
 __device__ __forceinline__ otp_f32x4 bload4(otp_rsrc r, int voff_bytes) {
     return __builtin_bit_cast(otp_f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff_bytes, 0, 0));

@@ -64,6 +64,7 @@ struct SPlan {
     int VR, W1, NIW, NV, pl;              // virtual rows per image (H + 1), records per window row (W + 1), 64-record pieces per plane,
                                           // records / bytes of a window plane
     uint32_t mHW, mW, mW1, mVR;
+    unsigned* rflag;                      // range-guard word (common.h)
 };
 
 // 8 floats -> bf16 hi / lo records
@@ -89,9 +90,10 @@ __device__ __forceinline__ void ssplit8(const float (&v)[8], u32x4& hi, u32x4& l
 // form gave a thread 4 consecutive pixels: its stores were 16-byte pieces 64 bytes apart, and the pass ran at 2.4 TB/s;
 // "store-run length is worth a factor on this chip")
 __global__ __launch_bounds__(256) void s8_pack_kernel(const float* __restrict__ in, u32x4* __restrict__ out, float* __restrict__ c4,
-                                                       int N, int C, int HW, int ctot, int coff) {
+                                                       int N, int C, int HW, int ctot, int coff, unsigned* rflag) {
     const int G8 = C >> 3;
     const size_t items = (size_t)N * G8 * HW;
+    bool bad = false;                                               // range guard (common.h): a value its half pieces cannot hold
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < items; i += (size_t)gridDim.x * 256) {
         const int p = (int)(i % HW);
         const size_t r = i / HW;
@@ -100,6 +102,8 @@ __global__ __launch_bounds__(256) void s8_pack_kernel(const float* __restrict__ 
         float f[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) f[e] = src[(size_t)e * HW];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bad |= otp_out_of_range(f[e]);
         u32x4 hi, lo;
         ssplit8(f, hi, lo);
         u32x4* dst = out + ((size_t)(n * G8 + g) * 2) * HW + p;
@@ -111,6 +115,7 @@ __global__ __launch_bounds__(256) void s8_pack_kernel(const float* __restrict__ 
             d4[HW] = (f32x4){f[4], f[5], f[6], f[7]};
         }
     }
+    otp_range_report(rflag, bad, OTP_RANGE_S8PASS);
 }
 
 // A fuse row's upsampled terms (HRNet.py:487-494; otp_upsample_add_multi: out = act(res + up_f0(low0) + up_f1(low1) + ...), added
@@ -129,9 +134,10 @@ struct S8Up {
 __global__ __launch_bounds__(256) void s8_upsample_add4_kernel(S8Up U, const float* __restrict__ res, float* out_nchw,
                                                                u32x4* __restrict__ out_s8, float* __restrict__ out_c4, int N, int C,
                                                                int Hh, int Wh, int relu, int res_ctot, int res_coff, int out_ctot,
-                                                               int out_coff, int res_s8) {
+                                                               int out_coff, int res_s8, unsigned* rflag) {
     const int HW = Hh * Wh, q4 = HW >> 2, G8 = C >> 3, Wh4 = Wh >> 2;
     const size_t items = (size_t)N * G8 * q4;
+    bool bad = false;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < items; i += (size_t)gridDim.x * 256) {
         const int q = (int)(i % q4);
         const size_t r = i / q4;
@@ -168,6 +174,8 @@ __global__ __launch_bounds__(256) void s8_upsample_add4_kernel(S8Up U, const flo
                     }
                 }
             }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bad |= otp_out_of_range(o[j]);
             if (relu) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.f);
@@ -192,15 +200,17 @@ __global__ __launch_bounds__(256) void s8_upsample_add4_kernel(S8Up U, const flo
             }
         }
     }
+    otp_range_report(rflag, bad, OTP_RANGE_S8PASS);
 }
 
 __global__ __launch_bounds__(256) void s8_upsample_add_kernel(S8Up U, const float* __restrict__ res, float* out_nchw,
                                                                u32x4* __restrict__ out_s8, float* __restrict__ out_c4, int N, int C,
                                                                int Hh, int Wh, int relu, int res_ctot, int res_coff, int out_ctot,
-                                                               int out_coff, int res_s8) {
+                                                               int out_coff, int res_s8, unsigned* rflag) {
     // a thread owns ONE pixel of one 8-channel group (see s8_pack_kernel: 1 KB store runs per wave instruction)
     const int HW = Hh * Wh, G8 = C >> 3;
     const size_t items = (size_t)N * G8 * HW;
+    bool bad = false;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < items; i += (size_t)gridDim.x * 256) {
         const int p = (int)(i % HW);
         const size_t r = i / HW;
@@ -234,6 +244,7 @@ __global__ __launch_bounds__(256) void s8_upsample_add_kernel(S8Up U, const floa
                     o = o + U.low[k][((size_t)n * C + c) * (size_t)((Hh / f) * (Wh / f)) + lo_off[k]];
                 }
             }
+            bad |= otp_out_of_range(o);
             if (relu) o = fmaxf(o, 0.f);
             f8[e] = o;
             if (out_nchw) out_nchw[((size_t)n * out_ctot + out_coff + c) * HW + p] = o;
@@ -249,6 +260,7 @@ __global__ __launch_bounds__(256) void s8_upsample_add_kernel(S8Up U, const floa
             d4[HW] = (f32x4){f8[4], f8[5], f8[6], f8[7]};
         }
     }
+    otp_range_report(rflag, bad, OTP_RANGE_S8PASS);
 }
 
 // C4 -> fp32 NCHW: test / debugging aid
@@ -502,6 +514,12 @@ __global__ __launch_bounds__(256, NCHW ? 2 : 3) void convs_kernel(const unsigned
             }
         }
         if (P.res_s8) {
+            // (a tile past Cout behind an unpaired one gets no residual below: zero, not whatever the registers held - nothing
+            //  stores it, but the range guard of the epilogue reads every accumulator)
+#pragma unroll
+            for (int t = 1; t < NTW; t += 2)
+#pragma unroll
+                for (int p = 0; p < NPT; ++p) acc[t][p] = f32x4{0.f, 0.f, 0.f, 0.f};
             // residual as S8 records (otp_conv_desc.res_layout = 1): the block input's operand image IS the residual - hi + lo holds
             // it to 2^-22 - so no fp32 (C4) image of it has to exist.  The records are read the way the epilogue writes them: a
             // lane's registers of a tile pair are the 8 channels of one record group (srow2ch), a tile without a partner takes
@@ -619,6 +637,17 @@ __global__ __launch_bounds__(256, NCHW ? 2 : 3) void convs_kernel(const unsigned
         for (int t = 0; t < NTW; ++t)
 #pragma unroll
             for (int p = 0; p < NPT; ++p) acc[t][p] = acc[t][p] * P.post;
+    }
+    {   // range guard (common.h): NaN = an operand piece overflowed, |v| >= 65504 = the next consumer could not split it - before
+        // the ReLU, which would swallow the NaN
+        bool bad = false;
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+#pragma unroll
+            for (int p = 0; p < NPT; ++p)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bad |= otp_out_of_range(acc[t][p][r]);
+        otp_range_report(P.rflag, bad, OTP_RANGE_CONVS);
     }
     if (P.act == OTP_ACT_RELU) {
 #pragma unroll
@@ -807,7 +836,7 @@ extern "C" int otp_s8_pack(const void* in, void* out, void* out_c4, int N, int C
     const size_t items = (size_t)N * (C / 8) * (H * W);
     const int grid = (int)((items + 255) / 256 > 16384 ? 16384 : (items + 255) / 256);
     hipLaunchKernelGGL(s8_pack_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const float*>(in),
-                       static_cast<u32x4*>(out), static_cast<float*>(out_c4), N, C, H * W, in_ctot, in_coff);
+                       static_cast<u32x4*>(out), static_cast<float*>(out_c4), N, C, H * W, in_ctot, in_coff, otp_range_word());
     return otp_launch_status();
 }
 
@@ -843,14 +872,14 @@ extern "C" int otp_s8_upsample_add_ex(const void* const* lows, const int* factor
         const int grid4 = (int)((items4 + 255) / 256 > 8192 ? 8192 : (items4 + 255) / 256);
         hipLaunchKernelGGL(s8_upsample_add4_kernel, dim3(grid4), dim3(256), 0, static_cast<hipStream_t>(stream), U,
                            static_cast<const float*>(res), static_cast<float*>(out_nchw), static_cast<u32x4*>(out_s8),
-                           static_cast<float*>(out_c4), N, C, Hh, Wh, relu, res_ctot, res_coff, out_ctot, out_coff, res_s8);
+                           static_cast<float*>(out_c4), N, C, Hh, Wh, relu, res_ctot, res_coff, out_ctot, out_coff, res_s8, otp_range_word());
         return otp_launch_status();
     }
     const size_t items = (size_t)N * (C / 8) * (Hh * Wh);
     const int grid = (int)((items + 255) / 256 > 16384 ? 16384 : (items + 255) / 256);
     hipLaunchKernelGGL(s8_upsample_add_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), U,
                        static_cast<const float*>(res), static_cast<float*>(out_nchw), static_cast<u32x4*>(out_s8),
-                       static_cast<float*>(out_c4), N, C, Hh, Wh, relu, res_ctot, res_coff, out_ctot, out_coff, res_s8);
+                       static_cast<float*>(out_c4), N, C, Hh, Wh, relu, res_ctot, res_coff, out_ctot, out_coff, res_s8, otp_range_word());
     return otp_launch_status();
 }
 
@@ -909,6 +938,7 @@ extern "C" int otp_conv3x3_s8(const void* in_s8, const void* wpacked, const void
         return OTP_ERR_UNSUPPORTED;
     SPlan P{};
     if (!convs_plan(d, P)) return OTP_ERR_UNSUPPORTED;
+    P.rflag = otp_range_word();
     P.f32_mode = out_f32 ? (out_f32_layout == OTP_S8_F32_C4 ? S_F32_C4 : S_F32_NCHW) : S_F32_NONE;
     auto st = static_cast<hipStream_t>(stream);
     auto fs = static_cast<const float*>(shift);

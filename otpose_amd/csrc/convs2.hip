@@ -92,6 +92,7 @@ struct S2Plan {
     int VR, W1, NIW, NV, pl;                           // virtual rows per image (H + 1), records per virtual row (W + 1), 64-record
                                                        // pieces per plane, records / bytes of a window plane
     uint32_t mHWo, mWo, mW1, mVR;
+    unsigned* rflag;                                   // range-guard word (common.h)
 };
 
 // NCHW: fp32 result (+ residual) into a channel slice of an NCHW tensor; otherwise the S8 image of the result only
@@ -267,6 +268,16 @@ __global__ __launch_bounds__(256, 2) void convs2_kernel(const unsigned char* __r
     }
     if (!NCHW) {
         // ---- S8 records of act(result) straight from the accumulators (no residual in this form) -------------------------------
+        {   // range guard (common.h), before the ReLU that would swallow a NaN
+            bool bad = false;
+#pragma unroll
+            for (int t = 0; t < NTW; ++t)
+#pragma unroll
+                for (int p = 0; p < NPT; ++p)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) bad |= otp_out_of_range(acc[t][p][r]);
+            otp_range_report(P.rflag, bad, OTP_RANGE_CONVS2);
+        }
         if (P.act == OTP_ACT_RELU) {
 #pragma unroll
             for (int t = 0; t < NTW; ++t)
@@ -342,10 +353,13 @@ __global__ __launch_bounds__(256, 2) void convs2_kernel(const unsigned char* __r
         rv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
             rres, (rb != SOOB && co_blk + ch < P.Cout) ? rb + ch * P.HWo * 4 : SOOB, 0, 0));
     }
+    bool bad = false;                                                // range guard (common.h), before the ReLU
 #pragma unroll
     for (int k = 0; k < NTW * 16 / CPI; ++k) {
         const int ch = c0 + CPI * k;
         f32x4 v = *reinterpret_cast<const f32x4*>(tl + ch * RS + 4 * g) + rv[k];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bad |= otp_out_of_range(v[e]);
         if (relu) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -353,6 +367,7 @@ __global__ __launch_bounds__(256, 2) void convs2_kernel(const unsigned char* __r
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rof,
                                                (ob != SOOB && co_blk + ch < P.Cout) ? ob + ch * P.HWo * 4 : SOOB, 0, 0);
     }
+    otp_range_report(P.rflag, bad, OTP_RANGE_CONVS2);
 }
 
 int s8_ntw(int Cout) {
@@ -460,6 +475,7 @@ extern "C" int otp_conv3x3_s2_s8(const void* in_s8, const void* wpacked, const v
     S2Plan P{};
     const bool nchw = out_nchw != nullptr;
     if (!convs2_plan(d, P, nchw)) return OTP_ERR_UNSUPPORTED;
+    P.rflag = otp_range_word();
     auto st = static_cast<hipStream_t>(stream);
     auto fs = static_cast<const float*>(shift);
     auto fr = static_cast<const float*>(res_nchw);

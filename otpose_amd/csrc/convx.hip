@@ -57,6 +57,7 @@ struct XPlan {
     int in_ctot, in_coff, out_ctot, out_coff, res_ctot, res_coff, act;
     int stride, pad, dil, taps;
     float post;                            // otp_conv_desc.out_scale (1 when unset)
+    unsigned* rflag;                       // range-guard word (common.h)
     int NTW, nN, nTiles, nChunks, tpx;
     int VR, WPp, CS, rowsMax, S, NI;
     int winBytes, wBytes;
@@ -401,6 +402,7 @@ __global__ __launch_bounds__(256, 2) void convx_kernel(const float* __restrict__
     XSTAMP(7);
 
     const float lo = P.act == OTP_ACT_RELU ? 0.f : -INFINITY;
+    bool bad = false;                                            // range guard (common.h): tested before the ReLU swallows a NaN
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
         const int co = co0 + 16 * t;
@@ -409,10 +411,14 @@ __global__ __launch_bounds__(256, 2) void convx_kernel(const float* __restrict__
         for (int mt = 0; mt < MTW; ++mt) {
             f32x4 y = acc[mt][t] * P.post + sh + rv[mt][t];      // post = 2^-k: the packed weights carry 2^k (out_scale)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) y[r] = fmaxf(y[r], lo);
+            for (int r = 0; r < 4; ++r) {
+                bad |= otp_out_of_range(y[r]);
+                y[r] = fmaxf(y[r], lo);
+            }
             if (ev[mt] && co < P.Cout) *reinterpret_cast<f32x4*>(out + (size_t)eo[mt] + (size_t)co * P.HoWo) = y;
         }
     }
+    otp_range_report(P.rflag, bad, OTP_RANGE_CONVX);
     XSTAMP(8);
 #ifdef OTP_CONVX_TIMING
     if (threadIdx.x == 0 && blockIdx.x < 8192) otp_convx_stamps[blockIdx.x * 16 + 10] = __builtin_amdgcn_s_memrealtime();
@@ -562,6 +568,7 @@ extern "C" int otp_conv2d_x3(const void* in, const void* wpacked, const void* sh
         return OTP_ERR_UNSUPPORTED;
     XPlan P{};
     if (!convx_plan(d, P)) return OTP_ERR_UNSUPPORTED;
+    P.rflag = otp_range_word();
     auto st = static_cast<hipStream_t>(stream);
     auto fi = static_cast<const float*>(in);
     auto fw = static_cast<const u32x4*>(wpacked);

@@ -45,6 +45,7 @@ struct FusedPlan {
     int B, J, H, W, HW, ND, tilesPerImg;
     int dil[FMAXD];
     float alpha;
+    unsigned* rflag;                                                // range-guard word (common.h)
 };
 
 __device__ __forceinline__ void f_split8(const float (&v)[8], u32x4& hi, u32x4& lo) {
@@ -220,6 +221,9 @@ __global__ __launch_bounds__(64 * NW) void dcn_fused_kernel(const unsigned char*
     float part[JP];
 #pragma unroll
     for (int o = 0; o < JP; ++o) part[o] = 0.f;
+    // range guard (common.h): a `trans` value beyond a half's range makes the offset / mask sums NaN, and the open-interval test
+    // below would then DROP the sample silently (every comparison with a NaN is false) - so the sums are tested
+    bool bad = false;
     // the lane's taps in the sampling phase: sub 0 -> taps 0, 1, 2; sub s > 0 -> taps 2 s + 1, 2 s + 2
     const int kbase = kq == 0 ? 0 : 2 * kq + 1, kcnt = kq == 0 ? 3 : 2;
 
@@ -266,8 +270,11 @@ __global__ __launch_bounds__(64 * NW) void dcn_fused_kernel(const unsigned char*
             // accumulator (channel i16 / 16 + i16, pixels 4 kq + r) -> scratch[pixel][channel]
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                scr[(4 * kq + r) * FSCR_ + i16] = acc0[r] * post0;
-                scr[(4 * kq + r) * FSCR_ + 16 + i16] = acc1[r] * post1;
+                const float o0 = acc0[r] * post0, o1 = acc1[r] * post1;
+                bad |= otp_out_of_range(o0);
+                bad |= otp_out_of_range(o1);
+                scr[(4 * kq + r) * FSCR_ + i16] = o0;
+                scr[(4 * kq + r) * FSCR_ + 16 + i16] = o1;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -304,6 +311,7 @@ __global__ __launch_bounds__(64 * NW) void dcn_fused_kernel(const unsigned char*
             __syncthreads();                                        // weight buffer swap; the wave's scratch is free again
         }
     }
+    otp_range_report(P.rflag, bad, OTP_RANGE_DCNF);
     // the four subs of a pixel hold partial sums over their taps
 #pragma unroll
     for (int o = 0; o < JP; ++o) {
@@ -331,7 +339,7 @@ bool P_nine(int B, int HW) {
 
 extern "C" int otp_dcn_fused_supported(int Cin, int J, int H, int W, int ND) {
     return (Cin == FCIN && J == 17 && H > 0 && W > 0 && (H * W) % FPIX == 0 && ND >= 1 && ND <= FMAXD &&
-            (long)H * W * 128 < (1l << 31) && (long)J * H * W * 4 < (1l << 31))
+            (long)H * W * 128 < (1l << 31) && (long)J * (H + 2) * (W + 2) * 4 < (1l << 31))   // (the gather reads the bordered planes)
                ? 1 : 0;
 }
 
@@ -361,7 +369,8 @@ extern "C" int otp_dcn_fused_pack(const void* const* w_off, const void* const* w
 // the split copy of `trans` ((B, H, W, [32 hi | 32 lo]) halves) + the zero-bordered copy of the J = 17 heat-map planes
 static size_t dcnf_split_bytes(int B, int H, int W) { return (size_t)B * H * W * 128; }
 extern "C" size_t otp_dcn_fused_workspace(int B, int H, int W) {
-    return (B > 0 && H > 0 && W > 0) ? dcnf_split_bytes(B, H, W) + (size_t)B * 17 * (H + 2) * (W + 2) * sizeof(float) : 0;
+    constexpr int J = 17;                                           // the one instantiation (otp_dcn_fused_supported)
+    return (B > 0 && H > 0 && W > 0) ? dcnf_split_bytes(B, H, W) + (size_t)B * J * (H + 2) * (W + 2) * sizeof(float) : 0;
 }
 
 extern "C" int otp_dcn_fused_forward(const void* trans, const void* x, const void* packed, void* out, void* workspace,
@@ -377,6 +386,7 @@ extern "C" int otp_dcn_fused_forward(const void* trans, const void* x, const voi
     const bool nine = P_nine(B, H * W);
     const int px = nine ? 144 : FPIX;
     P.B = B; P.J = J; P.H = H; P.W = W; P.HW = H * W; P.ND = ND; P.tilesPerImg = P.HW / px; P.alpha = alpha;
+    P.rflag = otp_range_word();
     for (int i = 0; i < ND; ++i) {
         if (dilations[i] <= 0) return OTP_ERR_BAD_ARG;
         P.dil[i] = dilations[i];

@@ -105,8 +105,9 @@ template <int C, bool RES>
 __device__ __forceinline__ void dx_project(const h16x8 (&Xh)[dx_ks(C)][2], const h16x8 (&Xl)[dx_ks(C)][2],
                                            const unsigned char* __restrict__ packed, unsigned char* lds,
                                            const float* __restrict__ res, float* __restrict__ out, size_t base, int T, int tok,
-                                           bool valid) {
+                                           bool valid, unsigned* rflag) {
     constexpr int KS = dx_ks(C), MT = (C + 15) / 16, BLKB = dx_block_bytes(C);
+    bool bad = false;                                 // range guard (common.h): a NaN sum = an operand beyond a half's range
     const int lane = threadIdx.x & 63, kq = lane >> 4;
     const unsigned plane = (unsigned)((size_t)C * T * sizeof(float));
     const otp_rsrc ro = make_rsrc32(out + base, plane);
@@ -143,6 +144,8 @@ __device__ __forceinline__ void dx_project(const h16x8 (&Xh)[dx_ks(C)][2], const
         for (int i = 0; i < 4; ++i) {
             f32x2 v = {acc0[i] * sc[i] + sh[i], acc1[i] * sc[i] + sh[i]};
             if (RES) v += r[i];
+            bad |= otp_out_of_range(v.x);
+                bad |= otp_out_of_range(v.y);
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), ro, voff[i], 0, 0);
         }
         if (mt + 1 < MT) {
@@ -151,6 +154,7 @@ __device__ __forceinline__ void dx_project(const h16x8 (&Xh)[dx_ks(C)][2], const
             asm volatile("" ::: "memory");
         }
     }
+    otp_range_report(rflag, bad, OTP_RANGE_DENSEX);
 }
 
 struct DxArgs {
@@ -161,7 +165,7 @@ struct DxArgs {
 };
 
 template <int C>
-__global__ __launch_bounds__(256, 2) void densex_cc_kernel(DxArgs A, int T, int tiles_per_b) {
+__global__ __launch_bounds__(256, 2) void densex_cc_kernel(DxArgs A, int T, int tiles_per_b, unsigned* rflag) {
     constexpr int KS = dx_ks(C), BLKB = dx_block_bytes(C);
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BLKB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kq = lane >> 4, n = lane & 15;
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void densex_cc_kernel(DxArgs A, int T, int 
         dx_split8(v1, Xh[ks][1], Xl[ks][1]);
     }
     __syncthreads();
-    dx_project<C, true>(Xh, Xl, A.packed[blockIdx.y], lds, A.res[blockIdx.y], A.out[blockIdx.y], base, T, tok, valid);
+    dx_project<C, true>(Xh, Xl, A.packed[blockIdx.y], lds, A.res[blockIdx.y], A.out[blockIdx.y], base, T, tok, valid, rflag);
 }
 
 struct QxArgs {
@@ -199,7 +203,7 @@ struct QxArgs {
 // (three waves per SIMD: 168 VGPRs with 21 spilled measured 119 us at cfg2 against 127 at two waves / 183 VGPRs and 133 at four)
 template <int C>
 __global__ __launch_bounds__(256, C <= 136 ? 3 : 1) void qkvx_front_kernel(const float* __restrict__ x, const float* __restrict__ table,
-                                                            QxArgs A, int T, int tiles_per_b, float eps) {
+                                                            QxArgs A, int T, int tiles_per_b, float eps, unsigned* rflag) {
     constexpr int KS = dx_ks(C), BLKB = dx_block_bytes(C), TAB = 3 * C * 8;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BLKB];
     __shared__ __attribute__((aligned(16))) float tab[TAB];
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(256, C <= 136 ? 3 : 1) void qkvx_front_kernel(const
             dx_split8(X1[ks], Xh[ks][1], Xl[ks][1]);
         }
         __syncthreads();                              // weight block 0 of this problem landed
-        dx_project<C, false>(Xh, Xl, A.packed[p], lds, nullptr, A.out[p], base, T, tok, valid);
+        dx_project<C, false>(Xh, Xl, A.packed[p], lds, nullptr, A.out[p], base, T, tok, valid, rflag);
     }
 }
 
@@ -316,10 +320,10 @@ extern "C" int OTP_ENTRY(otp_dense_x3)(const void* const* x, const void* const* 
     const int tiles = otp_ceil_div(T, 128);
     if (C == 204)
         hipLaunchKernelGGL(densex_cc_kernel<204>, dim3((unsigned)(B * tiles), (unsigned)nprob), dim3(256), 0,
-                           static_cast<hipStream_t>(stream), a, T, tiles);
+                           static_cast<hipStream_t>(stream), a, T, tiles, otp_range_word());
     else
         hipLaunchKernelGGL(densex_cc_kernel<136>, dim3((unsigned)(B * tiles), (unsigned)nprob), dim3(256), 0,
-                           static_cast<hipStream_t>(stream), a, T, tiles);
+                           static_cast<hipStream_t>(stream), a, T, tiles, otp_range_word());
     return otp_launch_status();
 }
 
@@ -341,10 +345,10 @@ extern "C" int otp_qkv_front_x3(const void* x, const void* table, const void* pa
     const int tiles = otp_ceil_div(T, 128);
     if (C == 204)
         hipLaunchKernelGGL(qkvx_front_kernel<204>, dim3((unsigned)(B * tiles), 3u), dim3(256), 0, static_cast<hipStream_t>(stream),
-                           static_cast<const float*>(x), static_cast<const float*>(table), a, T, tiles, eps);
+                           static_cast<const float*>(x), static_cast<const float*>(table), a, T, tiles, eps, otp_range_word());
     else
         hipLaunchKernelGGL(qkvx_front_kernel<136>, dim3((unsigned)(B * tiles), 3u), dim3(256), 0, static_cast<hipStream_t>(stream),
-                           static_cast<const float*>(x), static_cast<const float*>(table), a, T, tiles, eps);
+                           static_cast<const float*>(x), static_cast<const float*>(table), a, T, tiles, eps, otp_range_word());
     return otp_launch_status();
 }
 #endif  // OTP_X3_GRAD_COPY

@@ -142,7 +142,7 @@ __device__ __forceinline__ void mlpx_pass(const float* __restrict__ x, const uns
                                           const float* __restrict__ scale, const float* __restrict__ shift,
                                           const float* __restrict__ res, float* __restrict__ out, int T, size_t base, int tok0,
                                           unsigned char* lds, const float* __restrict__ ln_gamma,
-                                          const float* __restrict__ ln_beta, float ln_eps) {
+                                          const float* __restrict__ ln_beta, float ln_eps, unsigned* rflag) {
     constexpr int KS1 = mx_ks1(C), MT = mx_mt(C), HB = (HID + 31) / 32;
     constexpr int W1B = mx_w1_bytes(C), W2B = mx_w2_bytes(C), BLKB = mx_block_bytes(C);
     const int lane = threadIdx.x & 63, kq = lane >> 4, n = lane & 15;
@@ -263,6 +263,16 @@ __device__ __forceinline__ void mlpx_pass(const float* __restrict__ x, const uns
         __syncthreads();                              // every wave is done with this block; the next one has landed
     }
 
+    {   // range guard (common.h): an input or hidden value beyond a half's range has made these sums NaN
+        bool bad = false;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bad |= otp_out_of_range(Y[mt][t][i]);
+        otp_range_report(rflag, bad, OTP_RANGE_MLPX);
+    }
     if (!valid) return;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -291,12 +301,12 @@ template <int C, int HID, int WAVES, bool LN, int NT>
 __global__ __launch_bounds__(WAVES * 64, (NT == 1 && C <= 136) ? 4 : 2) void mlpx_kernel(
     const float* __restrict__ x, const unsigned char* __restrict__ packed, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ out, int T, int tiles_per_b,
-    const float* __restrict__ ln_gamma, const float* __restrict__ ln_beta, float ln_eps) {
+    const float* __restrict__ ln_gamma, const float* __restrict__ ln_beta, float ln_eps, unsigned* rflag) {
     extern __shared__ __attribute__((aligned(16))) unsigned char mx_lds[];
     const int wave = threadIdx.x >> 6;
     const int b = blockIdx.x / tiles_per_b, tile = blockIdx.x - b * tiles_per_b;
     mlpx_pass<C, HID, WAVES * 64, LN, NT>(x, packed, scale, shift, res, out, T, (size_t)b * C * T,
-                                          tile * (WAVES * 16 * NT) + wave * 16 * NT, mx_lds, ln_gamma, ln_beta, ln_eps);
+                                          tile * (WAVES * 16 * NT) + wave * 16 * NT, mx_lds, ln_gamma, ln_beta, ln_eps, rflag);
 }
 
 // Balanced form for token counts that are multiples of 27 column tiles per workgroup (T = 6912 = 16 x 27 x 16), as
@@ -305,21 +315,21 @@ template <int C, int HID, bool LN>
 __global__ __launch_bounds__(512, 2) void mlpx_balanced_kernel(
     const float* __restrict__ x, const unsigned char* __restrict__ packed, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ out, int T, int wgs_per_b,
-    const float* __restrict__ ln_gamma, const float* __restrict__ ln_beta, float ln_eps) {
+    const float* __restrict__ ln_gamma, const float* __restrict__ ln_beta, float ln_eps, unsigned* rflag) {
     extern __shared__ __attribute__((aligned(16))) unsigned char mx_lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.x / wgs_per_b, part = blockIdx.x - b * wgs_per_b;
     const size_t base = (size_t)b * C * T;
     const int t0 = part * (27 * 16);
-    mlpx_pass<C, HID, 512, LN, 2>(x, packed, scale, shift, res, out, T, base, t0 + wave * 32, mx_lds, ln_gamma, ln_beta, ln_eps);
+    mlpx_pass<C, HID, 512, LN, 2>(x, packed, scale, shift, res, out, T, base, t0 + wave * 32, mx_lds, ln_gamma, ln_beta, ln_eps, rflag);
     if (wave < 3) {
         mlpx_pass<C, HID, 512, LN, 2>(x, packed, scale, shift, res, out, T, base, t0 + (16 + 2 * wave) * 16, mx_lds, ln_gamma,
-                                      ln_beta, ln_eps);
+                                      ln_beta, ln_eps, rflag);
     } else {
         // waves 4, 5, 6 -> tiles 22, 23, 24; wave 3 -> 25; wave 7 -> 26
         const int tile = wave == 3 ? 25 : (wave == 7 ? 26 : 18 + wave);
         mlpx_pass<C, HID, 512, LN, 1>(x, packed, scale, shift, res, out, T, base, t0 + tile * 16, mx_lds, ln_gamma, ln_beta,
-                                      ln_eps);
+                                      ln_eps, rflag);
     }
 }
 
@@ -362,7 +372,7 @@ int mlpx_launch(const void* x, const void* packed, const void* scale, const void
         auto kern = ln_gamma ? mlpx_kernel<204, 816, WAVES, true, 1> : mlpx_kernel<204, 816, WAVES, false, 1>;
         OTP_ALLOW_BIG_LDS(kern, lds204);
         hipLaunchKernelGGL(kern, dim3((unsigned)(B * tiles)), dim3(WAVES * 64), lds204, static_cast<hipStream_t>(stream), f(x), pk,
-                           f(scale), f(shift), f(res), static_cast<float*>(out), T, tiles, f(ln_gamma), f(ln_beta), ln_eps);
+                           f(scale), f(shift), f(res), static_cast<float*>(out), T, tiles, f(ln_gamma), f(ln_beta), ln_eps, otp_range_word());
         return otp_launch_status();
     }
     const size_t lds = 2 * (size_t)mx_block_bytes(136);
@@ -381,7 +391,7 @@ int mlpx_launch(const void* x, const void* packed, const void* scale, const void
         auto kern = ln_gamma ? mlpx_kernel<136, 544, WAVES, true, 1> : mlpx_kernel<136, 544, WAVES, false, 1>;
         OTP_ALLOW_BIG_LDS(kern, lds);
         hipLaunchKernelGGL(kern, dim3((unsigned)(B * tiles)), dim3(WAVES * 64), lds, static_cast<hipStream_t>(stream), f(x), pk,
-                           f(scale), f(shift), f(res), static_cast<float*>(out), T, tiles, f(ln_gamma), f(ln_beta), ln_eps);
+                           f(scale), f(shift), f(res), static_cast<float*>(out), T, tiles, f(ln_gamma), f(ln_beta), ln_eps, otp_range_word());
         return otp_launch_status();
     }
     if (!bal_off && T % (27 * 16) == 0 && (bal_force || (long)B * (T / (27 * 16)) >= 192)) {
@@ -389,7 +399,7 @@ int mlpx_launch(const void* x, const void* packed, const void* scale, const void
         OTP_ALLOW_BIG_LDS(bk, lds);
         const int per_b = T / (27 * 16);
         hipLaunchKernelGGL(bk, dim3((unsigned)(B * per_b)), dim3(512), lds, static_cast<hipStream_t>(stream), f(x), pk,
-                           f(scale), f(shift), f(res), static_cast<float*>(out), T, per_b, f(ln_gamma), f(ln_beta), ln_eps);
+                           f(scale), f(shift), f(res), static_cast<float*>(out), T, per_b, f(ln_gamma), f(ln_beta), ln_eps, otp_range_word());
         return otp_launch_status();
     }
     constexpr int WAVES = 8;
@@ -397,7 +407,7 @@ int mlpx_launch(const void* x, const void* packed, const void* scale, const void
     auto kern = ln_gamma ? mlpx_kernel<136, 544, WAVES, true, 2> : mlpx_kernel<136, 544, WAVES, false, 2>;
     OTP_ALLOW_BIG_LDS(kern, lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)(B * tiles)), dim3(WAVES * 64), lds, static_cast<hipStream_t>(stream), f(x), pk,
-                       f(scale), f(shift), f(res), static_cast<float*>(out), T, tiles, f(ln_gamma), f(ln_beta), ln_eps);
+                       f(scale), f(shift), f(res), static_cast<float*>(out), T, tiles, f(ln_gamma), f(ln_beta), ln_eps, otp_range_word());
     return otp_launch_status();
 }
 }  // namespace

@@ -97,6 +97,7 @@ struct PxArgs {
     float* out;
     int T, tiles_per_b, Cin, Cout, nblk, relu;
     int x_ctot, x_coff, r_ctot, r_coff, o_ctot, o_coff;
+    unsigned* rflag;                                                         // range-guard word (common.h)
 };
 
 template <int CIN, bool RES>
@@ -133,6 +134,7 @@ __global__ __launch_bounds__(256, CIN <= 128 ? 3 : 2) void pointx_kernel(PxArgs 
     const otp_rsrc ro = make_rsrc32(A.out + ((size_t)b * A.o_ctot + A.o_coff) * T, plane);
     const otp_rsrc rr = make_rsrc32(RES ? A.res + ((size_t)b * A.r_ctot + A.r_coff) * T : A.out, RES ? plane : 0u);
     const float lo_clamp = A.relu ? 0.f : -__builtin_inff();
+    bool bad = false;                                  // range guard (common.h): results tested before the clamp swallows a NaN
     __syncthreads();                                   // weight block 0 and scale / shift landed
     // Every wave issues the SAME vector-memory instructions per block - residual loads, the DMA of the next block, 4 MPB stores,
     // lanes without a pixel or channel masked by an out-of-range offset - so the barrier can wait for the DMA alone
@@ -183,6 +185,8 @@ __global__ __launch_bounds__(256, CIN <= 128 ? 3 : 2) void pointx_kernel(PxArgs 
             for (int i = 0; i < 4; ++i) {
                 f32x2 v = {acc[m][0][i] * sc[i] + sh[i], acc[m][1][i] * sc[i] + sh[i]};
                 if (RES) v += r[m][i];
+                bad |= otp_out_of_range(v.x);
+                bad |= otp_out_of_range(v.y);
                 v.x = fmaxf(v.x, lo_clamp);
                 v.y = fmaxf(v.y, lo_clamp);
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), ro, voff[m][i], 0, 0);
@@ -195,6 +199,7 @@ __global__ __launch_bounds__(256, CIN <= 128 ? 3 : 2) void pointx_kernel(PxArgs 
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
+    otp_range_report(A.rflag, bad, OTP_RANGE_POINTX);
 }
 
 // The same convolution writing the S8 image of its result ([B][Cout / 8][hi | lo][T] 16-byte records of 8 bf16: the operand
@@ -233,6 +238,7 @@ __global__ __launch_bounds__(256, CIN <= 128 ? 3 : 2) void pointx_s8_kernel(PxAr
     const otp_rsrc ro = make_rsrc32(A.out + (size_t)b * A.Cout * T, plane);
     const otp_rsrc rr = make_rsrc32(RES ? A.res + ((size_t)b * A.r_ctot + A.r_coff) * T : A.out, RES ? plane : 0u);
     const float lo_clamp = A.relu ? 0.f : -__builtin_inff();
+    bool bad = false;                                  // range guard (common.h)
     __syncthreads();
 #pragma unroll 1
     for (int blk = 0; blk < A.nblk; ++blk) {
@@ -283,8 +289,11 @@ __global__ __launch_bounds__(256, CIN <= 128 ? 3 : 2) void pointx_s8_kernel(PxAr
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float r0 = RES ? rv[RES ? m >> 1 : 0][i][h] : 0.f, r1 = RES ? rv[RES ? m >> 1 : 0][4 + i][h] : 0.f;
-                    v[i] = fmaxf(acc[m][h][i] * sc0[i] + sh0[i] + r0, lo_clamp);
-                    v[4 + i] = fmaxf(acc[m + 1][h][i] * sc1[i] + sh1[i] + r1, lo_clamp);
+                    const float u0 = acc[m][h][i] * sc0[i] + sh0[i] + r0, u1 = acc[m + 1][h][i] * sc1[i] + sh1[i] + r1;
+                    bad |= otp_out_of_range(u0);
+                bad |= otp_out_of_range(u1);
+                    v[i] = fmaxf(u0, lo_clamp);
+                    v[4 + i] = fmaxf(u1, lo_clamp);
                 }
                 h16x8 hi, lo;
                 px_split8(v, hi, lo);
@@ -299,6 +308,7 @@ __global__ __launch_bounds__(256, CIN <= 128 ? 3 : 2) void pointx_s8_kernel(PxAr
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
+    otp_range_report(A.rflag, bad, OTP_RANGE_POINTX);
 }
 
 bool px_cin_ok(int Cin) { return Cin >= 16 && Cin <= 256; }
@@ -370,6 +380,7 @@ extern "C" int otp_pointwise_x3(const void* x, const void* packed, const void* r
     a.out = static_cast<float*>(out);
     a.T = T, a.tiles_per_b = otp_ceil_div(T, 128), a.Cin = Cin, a.Cout = Cout, a.nblk = (MT + MPB - 1) / MPB, a.relu = relu ? 1 : 0;
     a.x_ctot = x_ctot, a.x_coff = x_coff, a.r_ctot = res_ctot, a.r_coff = res_coff, a.o_ctot = out_ctot, a.o_coff = out_coff;
+    a.rflag = otp_range_word();
     const dim3 grid((unsigned)(B * a.tiles_per_b));
     hipStream_t st = static_cast<hipStream_t>(stream);
 #define OTP_PX_GO(CIN_)                                                                                      \
@@ -405,6 +416,7 @@ extern "C" int otp_pointwise_x3_s8_res(const void* x, const void* packed, const 
     a.out = static_cast<float*>(out_s8);
     a.T = T, a.tiles_per_b = otp_ceil_div(T, 128), a.Cin = Cin, a.Cout = Cout, a.nblk = (MT + MPB - 1) / MPB, a.relu = relu ? 1 : 0;
     a.x_ctot = x_ctot, a.x_coff = x_coff, a.r_ctot = r_ctot, a.r_coff = r_coff, a.o_ctot = Cout, a.o_coff = 0;
+    a.rflag = otp_range_word();
     const dim3 grid((unsigned)(B * a.tiles_per_b));
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (res) {

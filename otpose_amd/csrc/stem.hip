@@ -83,6 +83,7 @@ struct StArgs {
     float* out;
     int B, F, H, W, Ho, Wo, HoWo, Cout, total4;      // total4: groups of 4 output pixels over all frames
     unsigned mWo4;                                    // magic divisor of Wo / 4
+    unsigned* rflag;                                  // range-guard word (common.h)
 };
 
 __device__ __forceinline__ uint32_t st_div(uint32_t i, uint32_t magic) { return magic ? __umulhi(i, magic) : i; }
@@ -112,6 +113,7 @@ __global__ __launch_bounds__(256) void stem_kernel(StArgs A) {
     const long P0 = ((long)blockIdx.x * 4 + wave) * (16 * NPT);              // first output pixel of this wave (all frames, row-major)
     // frame and 4-pixel group of the wave's first pixel (one exact division per wave); its 16 NPT pixels span at most two frames
     const uint32_t H4 = (uint32_t)(A.HoWo >> 2), g0 = (uint32_t)(P0 >> 2), n0 = g0 / H4, rem0 = g0 - n0 * H4;
+    bool bad = false;                                 // range guard (common.h): an image value beyond a half's range gives NaN sums
 #pragma unroll 4
     for (int p = 0; p < NPT; ++p) {
         // ---- A fragment: the 8 (tap, channel) values of pixel P0 + 16 p + i16 --------------------------------------------------
@@ -145,6 +147,8 @@ __global__ __launch_bounds__(256) void stem_kernel(StArgs A) {
             acc = OTP_X3_MFMA(ah, Wl[t], acc, 0, 0, 0);
             acc = OTP_X3_MFMA(ah, Wh[t], acc, 0, 0, 0);
             acc = acc * post;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bad |= otp_out_of_range(acc[r]);
             const int co = 16 * t + i16;
 #if ST_LDS
             // through the wave's LDS slab [64 channels][64 + 4 pixels]: the stores below then cover 256 contiguous bytes per channel
@@ -174,6 +178,7 @@ __global__ __launch_bounds__(256) void stem_kernel(StArgs A) {
         }
 #endif
     }
+    otp_range_report(A.rflag, bad, OTP_RANGE_STEM);
 }
 
 }  // namespace
@@ -214,6 +219,7 @@ extern "C" int otp_stem_conv_x3(const void* in, const void* packed, void* out, i
     const long total = (long)B * F * a.HoWo;
     a.total4 = (int)(total / 4);
     a.mWo4 = st_magic((uint32_t)(a.Wo / 4));
+    a.rflag = otp_range_word();
 #ifndef ST_NPT
 #define ST_NPT 4
 #endif

@@ -602,7 +602,7 @@ constexpr size_t pvx_lds(int NB) {
 }
 template <int NB>
 __global__ __launch_bounds__(64 * pvx_waves(NB), 2) void attn_pv_x3_kernel(const float* __restrict__ v, const float* __restrict__ P,
-                                                                      float* __restrict__ out, int hs, int T) {
+                                                                      float* __restrict__ out, int hs, int T, unsigned* rflag) {
     constexpr int PVX_WAVES = pvx_waves(NB), PVX_TH = 64 * PVX_WAVES, PVX_TT = 32 * PVX_WAVES;
     constexpr int HSP = NB * 16, KS = (HSP + 31) / 32, G = HSP / 8;
     constexpr int REC = HSP * 4 + 16;                              // bytes of a token (v) / row (P) record
@@ -718,6 +718,16 @@ __global__ __launch_bounds__(64 * pvx_waves(NB), 2) void attn_pv_x3_kernel(const
                 acc[mt][nt] = OTP_X3_MFMA(ah[mt], b_h, acc[mt][nt], 0, 0, 0);
             }
         }
+    }
+    {   // range guard (common.h): q, k or v beyond a half's range has made these sums NaN (through the scores and the softmax)
+        bool bad = false;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NB; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bad |= otp_out_of_range(acc[mt][nt][r]);
+        otp_range_report(rflag, bad, OTP_RANGE_ATTN);
     }
     float* ob = out + (size_t)bh * T * hs;
 #pragma unroll
@@ -890,7 +900,7 @@ extern "C" int otp_chan_attn(const void* q, const void* k, const void* v, void* 
             auto kx = attn_pv_x3_kernel<NB_>;                                                                  \
             const size_t lx = pvx_lds(NB_);                 /* >= (tokens + HSP) * (HSP * 4 + 16) + 16 */                                                   \
             OTP_ALLOW_BIG_LDS(kx, lx);                                                                         \
-            hipLaunchKernelGGL(kx, dim3(BH, otp_ceil_div(T, 32 * pvx_waves(NB_))), dim3(64 * pvx_waves(NB_)), lx, st, vf, P, of, hs, T); \
+            hipLaunchKernelGGL(kx, dim3(BH, otp_ceil_div(T, 32 * pvx_waves(NB_))), dim3(64 * pvx_waves(NB_)), lx, st, vf, P, of, hs, T, otp_range_word()); \
         } else {                                                                                               \
             auto kern = attn_pv_kernel<NB_>;                                                                   \
             OTP_ALLOW_BIG_LDS(kern, pv_lds);                                                                   \
@@ -978,7 +988,7 @@ extern "C" int OTP_ENTRY(otp_chan_attn_apply)(const void* v, const void* M, void
             auto kx = attn_pv_x3_kernel<NB_>;                                                               \
             const size_t lx = pvx_lds(NB_);                                                                 \
             OTP_ALLOW_BIG_LDS(kx, lx);                                                                      \
-            hipLaunchKernelGGL(kx, dim3(BH, otp_ceil_div(T, 32 * pvx_waves(NB_))), dim3(64 * pvx_waves(NB_)), lx, st, vf, mf, of, hs, T); \
+            hipLaunchKernelGGL(kx, dim3(BH, otp_ceil_div(T, 32 * pvx_waves(NB_))), dim3(64 * pvx_waves(NB_)), lx, st, vf, mf, of, hs, T, otp_range_word()); \
         }                                                                                                   \
         if (!split_) {                                                                                      \
             auto kern = attn_pv_kernel<NB_>;                                                                \

@@ -80,6 +80,10 @@ class InferenceEngine:
         self.f32_tail = int(os.environ.get("OTPOSE_F32_TAIL", "0")) if self.use_x3 else 0
         self._exact = False
         self._sid = 0
+        # range guard of the half-piece arithmetic (csrc/range.hip, csrc/common.h:75): "defer" (default) raises at the NEXT
+        # forward / at check_range() and NaN-fills this forward's heat-maps on the device; "sync" synchronises and raises in the
+        # forward that overflowed; "off" only keeps the device-side NaN fill
+        self.range_check = os.environ.get("OTPOSE_RANGE_CHECK", "defer")
         # process-wide pool (see hip.side_streams); stream_set > 0: the streams of another sub-batch of a PipelinedEngine
         self._side = hip.side_streams(device, 3, 4 * stream_set) if self.multi_stream else []
         self._given = (inp, margin)
@@ -117,6 +121,7 @@ class InferenceEngine:
         self.multi_stream = bool(multi_stream)
         self.f32_tail, self._exact = 0, False
         self._sid = 0
+        self.range_check = env("OTPOSE_RANGE_CHECK", "defer")
         self._side = hip.side_streams(device, 3, 0) if self.multi_stream else []
         self.inp = None
         return self
@@ -1104,8 +1109,7 @@ class InferenceEngine:
             self._keep += [packed, dl]
             self.call(L.otp_dcn_fused_forward, "otp_dcn_fused_forward", hip.ptr(trans.t), hip.ptr(def_h.t), hip.ptr(packed),
                       hip.ptr(out), hip.ptr(ws), ws.numel() * 4, B, cin_t, J, h, w, dl, nd, 1.0 / nd)
-            self.outputs = (out, rough, inter, prev_b, ctx.view(B, J, h, w), squeezed, total)
-            torch.cuda.synchronize(self.dev)
+            self._finish(out, rough, inter, prev_b, ctx, squeezed, total)
             return
         off_buf, msk_buf = self.new(B, J * 18, h, w), self.new(B, J * 9, h, w)
         for i, d in enumerate(m.deformable_conv_dilations):
@@ -1116,8 +1120,36 @@ class InferenceEngine:
             self.call(L.otp_mdcn_forward, "otp_mdcn_forward", hip.ptr(def_h.t), hip.ptr(off_buf), hip.ptr(msk_buf),
                       hip.ptr(wt), hip.ptr(bs), hip.ptr(out), B, J, h, w, J, 3, 3, 1, d, d, 1, J,
                       1.0 / nd, 0.0 if i == 0 else 1.0, 0)
+        self._finish(out, rough, inter, prev_b, ctx, squeezed, total)
+
+    def _finish(self, out, rough, inter, prev_b, ctx, squeezed, total):
+        """Last launch of the forward: the range guard's device side (csrc/range.hip) - if any 16-bit-operand kernel of this
+        process saw a value beyond a half's range, the heat-maps leave as NaN instead of as finite numbers computed from an
+        overflowed operand (the host side raises: :meth:`run`, :meth:`check_range`)."""
+        B, J, h, w = self.B, self.J, self.h, self.w
+        if self.use_x3 or getattr(self, "h16", False):
+            self.call(self.lib.otp_range_poison, "otp_range_poison", hip.ptr(out), out.numel())
         self.outputs = (out, rough, inter, prev_b, ctx.view(B, J, h, w), squeezed, total)
         torch.cuda.synchronize(self.dev)
+
+    _RANGE_KERNELS = {1: "convx (3x3 / 1x1 convolutions from fp32 NCHW)", 2: "convs (BasicBlock convolutions on S8 records)",
+                      3: "convs2 (stride-2 convolutions on S8 records)", 4: "pointx (1x1 convolutions)", 5: "stem convolution",
+                      6: "S8 conversion / fuse passes", 7: "mlpx (TransformerBlock MLP)", 8: "densex (q / k / v / proj projections)",
+                      9: "channel attention", 10: "dcn_fused (warping head)", 11: "fp16 engine kernels"}
+
+    def _raise_range(self, code):
+        raise FloatingPointError(
+            "otpose_amd: a value left the range of the half-precision operand pieces (|x| >= 65504, or a non-finite sum) in the "
+            f"{self._RANGE_KERNELS.get(code, 'kernel family %d' % code)} of an eval forward; the heat-maps of that forward were "
+            "NaN-filled on the device.  The reference computes these layers in fp32: rescale the input / check the checkpoint's "
+            "BatchNorm statistics, or run the exact-fp32 kernels (OTPOSE_CONV_MATH=f32).")
+
+    def check_range(self):
+        """Synchronise and raise FloatingPointError if a forward since the last check overflowed the half-piece arithmetic."""
+        torch.cuda.synchronize(self.dev)
+        code = self.lib.otp_range_flag_read(1)
+        if code:
+            self._raise_range(code)
 
     def __del__(self):
         try:
@@ -1149,6 +1181,11 @@ class InferenceEngine:
         buffers instead, which the NEXT ``run`` overwrites (benchmark loops, callers that consume at once)."""
         if not x.is_cuda:
             raise RuntimeError("OTPose.forward expects CUDA (HIP) tensors; there is no CPU path")
+        if self.range_check != "off":
+            # deferred half of the range guard: a violation recorded by any forward that has completed by now (no synchronisation)
+            code = self.lib.otp_range_flag_read(1)
+            if code:
+                self._raise_range(code)
         if x.dtype == torch.uint8:
             # (B, 5, H, W, 3) uint8 frames: normalise + concatenate straight into the stem conv's input buffer
             ops.frames_to_clip(x, out=self.inp)
@@ -1180,6 +1217,8 @@ class InferenceEngine:
             self.graph.replay()
         else:
             self._launch_all()
+        if self.range_check == "sync":
+            self.check_range()
         if alias_outputs:
             return self.outputs
         return tuple(o.clone() for o in self.outputs)

@@ -40,9 +40,36 @@ class NhwcConvDesc(ctypes.Structure):
 
 _ND = ctypes.POINTER(NhwcConvDesc)
 
+
+class H16ConvDesc(ctypes.Structure):
+    """Mirror of ``otp_h16_conv_desc`` (include/otpose_hip.h)."""
+    _fields_ = [(n, c_int) for n in ("N", "Cin", "H", "W", "Cout", "stride", "act", "in_gtot", "in_goff", "out_gtot", "out_goff",
+                                     "res_gtot", "res_goff")] + [("out_scale", ctypes.c_float)]
+
+
+_HD = ctypes.POINTER(H16ConvDesc)
+
 # name -> (restype, argtypes); kept in one table so tests can check every symbol is exported
 SIGNATURES = {
     "otp_version": (c_int, []),
+    "otp_range_flag_read": (c_int, [c_int]),
+    "otp_range_poison": (c_int, [c_void_p, c_size_t, c_void_p]),
+    "otp_h8_bytes": (c_size_t, [c_int] * 4),
+    "otp_h8_pack": (c_int, [c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
+    "otp_h8_unpack": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "otp_h16_conv3x3_supported": (c_int, [_HD]),
+    "otp_h16_conv3x3_weight_bytes": (c_size_t, [c_int, c_int]),
+    "otp_h16_conv3x3_pack_weight": (c_int, [c_void_p] * 3 + [c_int, c_int, c_float, c_void_p]),
+    "otp_h16_conv3x3": (c_int, [c_void_p] * 5 + [_HD, c_void_p]),
+    "otp_h16_pointwise_supported": (c_int, [c_int, c_int]),
+    "otp_h16_pointwise_weight_bytes": (c_size_t, [c_int, c_int]),
+    "otp_h16_pointwise_pack": (c_int, [c_void_p] * 4 + [c_int, c_int, c_float, c_void_p]),
+    "otp_h16_pointwise": (c_int, [c_void_p] * 4 + [c_int] * 12 + [c_float, c_void_p]),
+    "otp_h16_stem_supported": (c_int, [c_int] * 5),
+    "otp_h16_stem_weight_bytes": (c_size_t, [c_int]),
+    "otp_h16_stem_pack": (c_int, [c_void_p] * 4 + [c_int, c_void_p]),
+    "otp_h16_stem": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p]),
+    "otp_h16_upsample_add": (c_int, [ctypes.POINTER(c_void_p), ctypes.POINTER(c_int), c_int, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
     "otp_mdcn_forward": (c_int, [c_void_p] * 6 + [c_int] * 12 + [c_float, c_float, c_int, c_void_p]),
     "otp_mdcn_forward_ex": (c_int, [c_void_p] * 6 + [c_int] * 15 + [c_float, c_float, c_int, c_void_p]),
     "otp_mdcn_backward_ex": (c_int, [c_void_p] * 10 + [c_void_p, c_size_t] + [c_int] * 15 + [c_int, c_void_p]),
@@ -222,6 +249,9 @@ def lib():
             fn.argtypes = args
         # one arithmetic switch for the whole library: OTPOSE_CONV_MATH=f32 keeps every product on the f32 MFMA
         cdll.otp_chan_attn_set_split(0 if os.environ.get("OTPOSE_CONV_MATH", "x3") == "f32" else 1)
+        import torch
+        if torch.cuda.is_available():
+            cdll.otp_range_flag_read(0)       # allocates the range guard's pinned word now, outside any stream capture
         _lib = _DeviceGuarded(cdll)
     return _lib
 

@@ -192,7 +192,6 @@ class OTPose(nn.Module):
     def forward(self, x, **kwargs):
         assert "margin" in kwargs
         margin = kwargs["margin"]
-        from .engine import InferenceEngine
         if self.training:
             # model.train(): BatchNorm batch statistics + an autograd tape over HIP kernels (otpose_amd/train.py);
             # self.train_dropout = False switches Dropout / drop-path off (deterministic comparison with the oracle)
@@ -200,7 +199,7 @@ class OTPose(nn.Module):
             self._engine = None
             return forward_train(self, x, margin)
         if self._engine is None or not self._engine.matches(x):
-            self._engine = InferenceEngine(self, x.shape[0], x.device)
+            self._engine = self._engine_class()(self, x.shape[0], x.device)
         return self._engine.run(x, margin, self.alias_outputs)
 
     def forward_frames(self, frames_u8, margin):
@@ -210,23 +209,46 @@ class OTPose(nn.Module):
         if self.training:
             from . import ops
             return self.forward(ops.frames_to_clip(frames_u8), margin=margin)
-        from .engine import InferenceEngine
         b, f, h, w, _ = frames_u8.shape
         if self._engine is None or not self._engine.matches_shape(b, 3 * f, h, w, frames_u8.device):
-            self._engine = InferenceEngine(self, b, frames_u8.device)
+            self._engine = self._engine_class()(self, b, frames_u8.device)
         return self._engine.run(frames_u8, margin, self.alias_outputs)
 
     def input_buffers(self, batch, device):
         """The eval engine's own input tensors for ``batch`` clips on ``device``: ``(x (B, 3 F, H, W) fp32, margin (B, F - 1)
         fp32)``.  A data loader that writes the next batch straight into them and passes them to ``forward`` saves the
         per-call device-to-device copy (106 MB at cfg2) - ``forward`` recognises its own buffers by address."""
-        from .engine import InferenceEngine
         device = torch.device(device)
         w_img, h_img = self.cfg.MODEL.IMAGE_SIZE
         f = getattr(self, "window_frames", 5)
         if self._engine is None or not self._engine.matches_shape(batch, 3 * f, h_img, w_img, device):
-            self._engine = InferenceEngine(self, batch, device)
+            self._engine = self._engine_class()(self, batch, device)
         return self._engine.inp, self._engine.margin
+
+    def eval_dtype(self) -> str:
+        """``cfg.MODEL.DTYPE`` of the eval forward: "fp32" (default: fp32 tensors, the reference's arithmetic contract) or "fp16"
+        (BASELINE configs[4]: the backbone on half activations, csrc/h16.hip - an extension, the reference never runs below fp32)."""
+        m = self.cfg.MODEL
+        dt = str(m.get("DTYPE", "fp32") if hasattr(m, "get") else getattr(m, "DTYPE", "fp32")).lower()
+        if dt in ("fp32", "float32", "f32"):
+            return "fp32"
+        if dt in ("fp16", "float16", "half", "f16"):
+            return "fp16"
+        raise ValueError(f"MODEL.DTYPE must be 'fp32' or 'fp16', got {dt!r}")
+
+    def _engine_class(self):
+        if self.eval_dtype() == "fp16":
+            from .engine_h16 import InferenceEngineH16
+            return InferenceEngineH16
+        from .engine import InferenceEngine
+        return InferenceEngine
+
+    def check_range(self):
+        """Synchronise and raise ``FloatingPointError`` if an eval forward since the last check drove a value beyond the range of
+        the half-precision operand pieces (|x| >= 65504: csrc/common.h, csrc/range.hip).  The engine also checks, without
+        synchronising, at the start of every forward (``OTPOSE_RANGE_CHECK=sync``: at the end of the forward itself)."""
+        if self._engine is not None:
+            self._engine.check_range()
 
     def invalidate_engine(self):
         """Drop packed weights (call after changing parameters, e.g. load_state_dict)."""

@@ -1211,3 +1211,174 @@ def flow_back(x, att, prm, hidden, eps=1e-5):
     hip.check(hip.lib().otp_flow_back(hip.ptr(x), hip.ptr(att), hip.ptr(prm), hip.ptr(out), b, c, int(hidden), t, float(eps),
                                       hip.stream_of(x)), "otp_flow_back")
     return out
+
+
+# ---- fp16-storage eval kernels of the backbone (csrc/h16.hip; cfg.MODEL.DTYPE = "fp16") ------------------------------------
+class H8:
+    """An H8 image: ``t`` = int32 storage of [N][gtot][H * W] 16-byte records (8 halves = channels 8 g .. 8 g + 7 of a pixel),
+    of which this tensor is the channel groups [goff, goff + C / 8) - the fp16 engine's activation format (include/otpose_hip.h)."""
+
+    __slots__ = ("t", "N", "C", "H", "W", "gtot", "goff")
+
+    def __init__(self, t, n, c, h, w, gtot=None, goff=0):
+        assert c % 8 == 0
+        self.t, self.N, self.C, self.H, self.W = t, n, c, h, w
+        self.gtot, self.goff = (c // 8 if gtot is None else gtot), goff
+        assert 0 <= self.goff and self.goff + c // 8 <= self.gtot
+
+    def slice(self, coff, c):
+        assert coff % 8 == 0 and c % 8 == 0 and coff + c <= self.C
+        return H8(self.t, self.N, c, self.H, self.W, self.gtot, self.goff + coff // 8)
+
+
+def h8_empty(n, c, h, w, device):
+    nbytes = hip.lib().otp_h8_bytes(n, c, h, w)
+    if not nbytes:
+        raise ValueError(f"H8 images need a channel count that is a multiple of 8, got {c}")
+    return H8(torch.empty(nbytes // 4, dtype=torch.int32, device=device), n, c, h, w)
+
+
+def h8_pack(x, out: H8 = None, stream=None):
+    """fp32 NCHW tensor or channel-slice :class:`View` -> H8 (one rounding to half per element)."""
+    iv = x if isinstance(x, View) else View(x.contiguous())
+    _require_gpu(iv.t)
+    n, _, h, w = iv.t.shape
+    out = h8_empty(n, iv.C, h, w, iv.t.device) if out is None else out
+    hip.check(hip.lib().otp_h8_pack(hip.ptr(iv.t), hip.ptr(out.t), n, iv.C, h, w, iv.ctot, iv.coff, out.gtot, out.goff,
+                                    stream if stream is not None else hip.stream_of(iv.t)), "otp_h8_pack")
+    return out
+
+
+def h8_unpack(img: H8, stream=None):
+    """H8 image -> fp32 (N, C, H, W), exact."""
+    out = torch.empty(img.N, img.C, img.H, img.W, dtype=torch.float32, device=img.t.device)
+    hip.check(hip.lib().otp_h8_unpack(hip.ptr(img.t), hip.ptr(out), img.N, img.C, img.H, img.W, img.gtot, img.goff,
+                                      stream if stream is not None else hip.stream_of(img.t)), "otp_h8_unpack")
+    return out
+
+
+def h16_weight_exponent(weight, scale=None) -> int:
+    """Power of two k the fp16 engine stores a layer's (BatchNorm-folded) weights with: max |w * scale| * 2^k in [2^13, 2^14), so
+    weights down to 2^-27 of the largest stay normal halves; the launch multiplies its fp32 sums by 2^-k (exact)."""
+    w = weight.detach()
+    m = w.abs().reshape(w.shape[0], -1).amax(dim=1)
+    if scale is not None:
+        m = m * scale.detach().abs().to(m.device, m.dtype)
+    m = float(m.max())
+    if not (m > 0.0 and math.isfinite(m)):
+        return 0
+    return max(-40, min(40, 14 - math.frexp(m)[1]))
+
+
+def h16_conv_desc(x: H8, cout, stride, act=ACT_NONE, out: H8 = None, res: H8 = None, k=0):
+    d = hip.H16ConvDesc()
+    d.N, d.Cin, d.H, d.W, d.Cout, d.stride, d.act = x.N, x.C, x.H, x.W, cout, stride, act
+    d.in_gtot, d.in_goff = x.gtot, x.goff
+    d.out_gtot, d.out_goff = (out.gtot, out.goff) if out is not None else (0, 0)
+    d.res_gtot, d.res_goff = (res.gtot, res.goff) if res is not None else (0, 0)
+    d.out_scale = 2.0 ** -k
+    return d
+
+
+def h16_conv_supported(desc) -> bool:
+    return bool(hip.lib().otp_h16_conv3x3_supported(desc))
+
+
+def pack_h16_conv_weight(weight, scale=None, k=0):
+    """(Cout, Cin, 3, 3) fp32 (x scale[cout] x 2^k) -> the half A-fragment image of csrc/h16.hip."""
+    _require_gpu(weight)
+    w = weight.detach().contiguous().float()
+    cout, cin, kh, kw = w.shape
+    assert (kh, kw) == (3, 3)
+    L = hip.lib()
+    nbytes = L.otp_h16_conv3x3_weight_bytes(cout, cin)
+    if not nbytes:
+        raise RuntimeError(f"otp_h16_conv3x3: unsupported widths {cin} -> {cout}")
+    packed = torch.zeros(nbytes // 4, dtype=torch.int32, device=w.device)
+    sc = scale.detach().to(w.device, torch.float32).contiguous() if scale is not None else None
+    hip.check(L.otp_h16_conv3x3_pack_weight(hip.ptr(w), hip.ptr(sc), hip.ptr(packed), cout, cin, float(2.0 ** k), hip.stream_of(w)),
+              "otp_h16_conv3x3_pack_weight")
+    return packed
+
+
+def h16_conv3x3(x: H8, wpacked, shift, cout, stride=1, act=ACT_NONE, res: H8 = None, out: H8 = None, k=0, stream=None, desc=None):
+    """out = act(conv3x3 pad 1 (x) + shift (+ res)) on H8 images (csrc/h16.hip)."""
+    ho, wo = x.H // stride, x.W // stride
+    out = h8_empty(x.N, cout, ho, wo, x.t.device) if out is None else out
+    d = desc if desc is not None else h16_conv_desc(x, cout, stride, act, out, res, k)
+    hip.check(hip.lib().otp_h16_conv3x3(hip.ptr(x.t), hip.ptr(wpacked), hip.ptr(shift), hip.ptr(res.t if res is not None else None),
+                                        hip.ptr(out.t), d, stream if stream is not None else hip.stream_of(x.t)), "otp_h16_conv3x3")
+    return out
+
+
+def h16_pointwise_supported(cin, cout) -> bool:
+    return bool(hip.lib().otp_h16_pointwise_supported(int(cin), int(cout)))
+
+
+def pack_h16_pointwise(weight, scale=None, shift=None, k=0):
+    """(Cout, Cin[, 1, 1]) fp32 (x scale x 2^k) + shift -> the packed image of otp_h16_pointwise."""
+    _require_gpu(weight)
+    w = weight.detach().reshape(weight.shape[0], -1).contiguous().float()
+    cout, cin = w.shape
+    L = hip.lib()
+    nbytes = L.otp_h16_pointwise_weight_bytes(cin, cout)
+    if not nbytes:
+        raise RuntimeError(f"otp_h16_pointwise: unsupported widths {cin} -> {cout}")
+    packed = torch.zeros(nbytes // 4, dtype=torch.int32, device=w.device)
+    sc = scale.detach().to(w.device, torch.float32).contiguous() if scale is not None else None
+    sh = shift.detach().to(w.device, torch.float32).contiguous() if shift is not None else None
+    hip.check(L.otp_h16_pointwise_pack(hip.ptr(w), hip.ptr(sc), hip.ptr(sh), hip.ptr(packed), cin, cout, float(2.0 ** k),
+                                       hip.stream_of(w)), "otp_h16_pointwise_pack")
+    return packed
+
+
+def h16_pointwise(x: H8, packed, cout, relu=False, res: H8 = None, out=None, k=0, stream=None):
+    """out = act(W x + shift (+ res)): ``out`` an :class:`H8` (default: fresh) or a :class:`View` of an fp32 NCHW tensor."""
+    f32 = isinstance(out, View)
+    if out is None:
+        out = h8_empty(x.N, cout, x.H, x.W, x.t.device)
+    otot, ooff = (out.ctot, out.coff) if f32 else (out.gtot, out.goff)
+    hip.check(hip.lib().otp_h16_pointwise(hip.ptr(x.t), hip.ptr(packed), hip.ptr(res.t if res is not None else None), hip.ptr(out.t),
+                                          int(f32), x.N, x.C, cout, x.H * x.W, x.gtot, x.goff,
+                                          res.gtot if res is not None else 0, res.goff if res is not None else 0, otot, ooff,
+                                          int(relu), float(2.0 ** -k), stream if stream is not None else hip.stream_of(x.t)),
+              "otp_h16_pointwise")
+    return out
+
+
+def pack_h16_stem(weight, scale=None, shift=None):
+    _require_gpu(weight)
+    w = weight.detach().contiguous().float()
+    cout = w.shape[0]
+    L = hip.lib()
+    nbytes = L.otp_h16_stem_weight_bytes(cout)
+    if not nbytes:
+        raise RuntimeError(f"otp_h16_stem: unsupported width {cout}")
+    packed = torch.zeros(nbytes // 4, dtype=torch.int32, device=w.device)
+    sc = scale.detach().to(w.device, torch.float32).contiguous() if scale is not None else None
+    sh = shift.detach().to(w.device, torch.float32).contiguous() if shift is not None else None
+    hip.check(L.otp_h16_stem_pack(hip.ptr(w), hip.ptr(sc), hip.ptr(sh), hip.ptr(packed), cout, hip.stream_of(w)), "otp_h16_stem_pack")
+    return packed
+
+
+def h16_stem(clip, packed, cout, frames, out: H8 = None, stream=None):
+    """relu(conv3x3 s2 p1 of the frames of the fp32 clip (B, 3 F, H, W) + shift) as the H8 image of (F B, cout, Ho, Wo)."""
+    _require_gpu(clip)
+    b, c, h, w = clip.shape
+    assert c == 3 * frames and clip.is_contiguous()
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    out = h8_empty(frames * b, cout, ho, wo, clip.device) if out is None else out
+    hip.check(hip.lib().otp_h16_stem(hip.ptr(clip), hip.ptr(packed), hip.ptr(out.t), b, frames, h, w, cout,
+                                     stream if stream is not None else hip.stream_of(clip)), "otp_h16_stem")
+    return out
+
+
+def h16_upsample_add(lows, factors, res: H8, relu=True, out: H8 = None, stream=None):
+    """out = act(res + sum_k nearest_up(lows[k], factors[k])) on dense H8 images."""
+    assert res.gtot * 8 == res.C and all(l.gtot * 8 == l.C for l in lows)
+    out = h8_empty(res.N, res.C, res.H, res.W, res.t.device) if out is None else out
+    lp = (ctypes.c_void_p * len(lows))(*[hip.ptr(l.t) for l in lows])
+    fp = (ctypes.c_int * len(lows))(*[int(f) for f in factors])
+    hip.check(hip.lib().otp_h16_upsample_add(lp, fp, len(lows), hip.ptr(res.t), hip.ptr(out.t), res.N, res.C, res.H, res.W, int(relu),
+                                             stream if stream is not None else hip.stream_of(res.t)), "otp_h16_upsample_add")
+    return out

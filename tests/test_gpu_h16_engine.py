@@ -1,0 +1,125 @@
+"""The fp16-storage eval engine (cfg.MODEL.DTYPE = "fp16", otpose_amd/engine_h16.py; BASELINE.json configs[4]) against the fp32
+engine, the oracle and the reference-generated goldens.
+
+The reference has no fp16 forward (no AMP; only its native DCN op dispatches half, deform_conv_cuda_kernel.cu:719),
+so the bar is SURVEY section 7's "documented extension ... self-consistency: fp32 HIP vs fp16 HIP vs the CPU restatement" with a
+stated, measured tolerance per output.  Measured on MI355X (this file prints the figures): every backbone activation is rounded to
+half (2^-11 relative) once per layer, ~60 layers deep; the heat-maps come out within a few 1e-3 of their range."""
+import pytest
+import torch
+
+from otpose_amd import OTPose, cfg1, cfg2, tiny_cfg
+from otpose_amd import synthetic as S
+from otpose_amd.config import cfg5
+
+pytestmark = pytest.mark.gpu
+NAMES = ("output", "rough", "intersection", "prev_b", "context", "squeezed", "total_b")
+# max |fp16 engine - fp32 reference| as a fraction of max(1, max |reference|), per output (measured: see the prints)
+TOL = {"output": 2e-2, "rough": 1e-2, "intersection": 2e-2, "prev_b": 1e-2, "context": 5e-2, "squeezed": 1e-2, "total_b": 1e-2}
+
+
+def _model(cfg):
+    m = OTPose(cfg)
+    S.fill_synthetic_(m)
+    return m.cuda().eval()
+
+
+def _errs(outs, ref):
+    e = {}
+    for n, o, r in zip(NAMES, outs, ref):
+        o, r = o.detach().cpu().float(), r.detach().cpu().float()
+        assert bool(torch.isfinite(o).all()), n
+        e[n] = float((o - r).abs().max()) / max(1.0, float(r.abs().max()))
+    return e
+
+
+def _check(e, scale=1.0):
+    for n, v in e.items():
+        assert v <= TOL[n] * scale, f"{n}: {v:.3e} > {TOL[n] * scale:.1e}"
+
+
+def test_fp16_engine_is_selected_by_the_config_and_never_by_default():
+    from otpose_amd.engine import InferenceEngine
+    from otpose_amd.engine_h16 import InferenceEngineH16
+    cfg = tiny_cfg(16, (128, 192))
+    assert cfg.MODEL.DTYPE == "fp32"
+    m = _model(cfg)
+    x, g = S.synthetic_clip(1, cfg.MODEL.IMAGE_SIZE)
+    with torch.no_grad():
+        m(x.cuda(), margin=g.cuda())
+    assert type(m._engine) is InferenceEngine
+    m16 = _model(tiny_cfg(16, (128, 192), dtype="fp16"))
+    with torch.no_grad():
+        m16(x.cuda(), margin=g.cuda())
+    assert type(m16._engine) is InferenceEngineH16
+    with pytest.raises(ValueError):
+        _model(tiny_cfg(16, (128, 192), dtype="int8"))(x.cuda(), margin=g.cuda())
+
+
+def test_fp16_tiny_vs_fp32_engine_and_oracle():
+    from oracle import otpose_oracle as O
+    cfg32, cfg16 = tiny_cfg(16, (128, 192)), tiny_cfg(16, (128, 192), dtype="fp16")
+    m32, m16 = _model(cfg32), _model(cfg16)
+    sd = {k: v.detach().cpu().clone() for k, v in m32.state_dict().items()}
+    x, g = S.synthetic_clip(2, cfg32.MODEL.IMAGE_SIZE)
+    with torch.no_grad():
+        o32 = [o.clone() for o in m32(x.cuda(), margin=g.cuda())]
+        o16 = [o.clone() for o in m16(x.cuda(), margin=g.cuda())]
+        again = m16(x.cuda(), margin=g.cuda())
+        ref = O.otpose_forward(sd, cfg32, x, g)
+    for a, b in zip(o16, again):
+        assert torch.equal(a, b), "graph replay of the fp16 engine is not deterministic"
+    e_hip, e_orc = _errs(o16, o32), _errs(o16, ref)
+    print("fp16 vs fp32 HIP:", {k: f"{v:.2e}" for k, v in e_hip.items()})
+    print("fp16 vs oracle  :", {k: f"{v:.2e}" for k, v in e_orc.items()})
+    _check(e_hip)
+    _check(e_orc)
+
+
+def test_fp16_cfg1_and_cfg2_clip_vs_reference_goldens(golden):
+    """The same engine on the reference-generated goldens of the fp32 configurations: its max-abs reported honestly (VERDICT r04
+    item 1a) - fp16 storage does NOT meet the 1e-3 of the fp32 contract and does not claim to."""
+    for name, mk, gname in (("cfg1", cfg1, "e2e_cfg1"), ("cfg2", cfg2, "e2e_cfg2_b1")):
+        cfg = mk()
+        cfg.MODEL.DTYPE = "fp16"
+        m = _model(cfg)
+        x, g = S.synthetic_clip(1, cfg.MODEL.IMAGE_SIZE)
+        with torch.no_grad():
+            outs = m(x.cuda(), margin=g.cuda())
+        gold = golden(gname)
+        e = _errs(outs, [gold[n] for n in NAMES])
+        absd = {n: float((o.cpu() - gold[n]).abs().max()) for n, o in zip(NAMES, outs)}
+        print(name, "fp16 vs golden, fraction of range:", {k: f"{v:.2e}" for k, v in e.items()})
+        print(name, "fp16 vs golden, max abs:", {k: f"{v:.2e}" for k, v in absd.items()})
+        _check(e)
+        del m
+
+
+def test_fp16_config5_full_size_vs_fp32_engine():
+    """BASELINE configs[4] as stated: batch 16 x 7-frame window x 384 x 288, fp16 - against the fp32 engine on the same clips
+    (no oracle at this size / window: self-consistency), plus the size-independent properties: finite, replay-deterministic, a
+    clip alone == its row of the batch."""
+    c32, c16 = cfg5(), cfg5("fp16")
+    x, g = S.synthetic_clip(16, c32.MODEL.IMAGE_SIZE, frames=7)
+    x, g = x.cuda(), g.cuda()
+    m32 = _model(c32)
+    with torch.no_grad():
+        o32 = [o.clone().cpu() for o in m32(x, margin=g)]
+    del m32
+    torch.cuda.empty_cache()
+    m16 = _model(c16)
+    with torch.no_grad():
+        o16 = [o.clone() for o in m16(x, margin=g)]
+        again = m16(x, margin=g)
+        for a, b in zip(o16, again):
+            assert torch.equal(a, b)
+        solo = [o.clone() for o in m16(x[5:6].contiguous(), margin=g[5:6].contiguous())]
+    e = _errs(o16, o32)
+    print("config5 fp16 vs fp32 HIP, fraction of range:", {k: f"{v:.2e}" for k, v in e.items()})
+    _check(e)
+    # per-clip independence: rows of `rough` are stacked frame-major (n = f B + b), the other outputs per clip
+    for n, a, b in zip(NAMES, solo, o16):
+        if n == "rough":
+            continue
+        d = float((a[0] - b[5]).abs().max())
+        assert d <= 1e-3 * max(1.0, float(b[5].abs().max())), (n, d)
