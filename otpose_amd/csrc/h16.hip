@@ -31,6 +31,17 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #define H_MFMA __builtin_amdgcn_mfma_f32_16x16x32_f16
 
+#ifdef OTP_H16_TIMING
+// development build only (tools/h16_timing.sh): per-workgroup phase stamps, never in libotpose_hip.so
+__device__ unsigned long long otp_h16_stamps[8192 * 32];
+#define HSTAMP(slot)                                                                                                       \
+    do {                                                                                                                   \
+        if (threadIdx.x == 0 && blockIdx.x < 8192) otp_h16_stamps[blockIdx.x * 32 + (slot)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define HSTAMP(slot)
+#endif
+
 constexpr int HKS = 5;                    // k-steps per 16-channel chunk: 18 (tap, group) slots of 8 channels in 5 x 4 (2 empty)
 constexpr int HOOB = -16;                 // buffer offset outside every descriptor: loads return / the LDS-DMA writes zeros
 // packed weights of a (cout block, 16-channel chunk): 4 full k-steps x NTW tiles x 1 KB, then the half-filled fifth (k-slots 16, 17
@@ -59,21 +70,6 @@ __host__ __device__ inline bool hpaired(int co_blk, int t, int ntw, int Cout) {
 __host__ __device__ inline int hrow2ch(int co_blk, int t, int row, int ntw, int Cout) {
     return hpaired(co_blk, t, ntw, Cout) ? co_blk + 32 * (t >> 1) + 8 * (row >> 2) + 4 * (t & 1) + (row & 3) : co_blk + 16 * t + row;
 }
-
-#define H_WAITVM(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
-// wait until at most n (wave-uniform) vector-memory operations of this wave are outstanding; the counter has 6 bits: counts
-// past 40 wait for everything (only more conservative)
-__device__ __forceinline__ void hwait_vm(int n) {
-    switch (n) {
-        H_WAITVM(1) H_WAITVM(2) H_WAITVM(3) H_WAITVM(4) H_WAITVM(5) H_WAITVM(6) H_WAITVM(7) H_WAITVM(8) H_WAITVM(9) H_WAITVM(10)
-        H_WAITVM(11) H_WAITVM(12) H_WAITVM(13) H_WAITVM(14) H_WAITVM(15) H_WAITVM(16) H_WAITVM(17) H_WAITVM(18) H_WAITVM(19)
-        H_WAITVM(20) H_WAITVM(21) H_WAITVM(22) H_WAITVM(23) H_WAITVM(24) H_WAITVM(25) H_WAITVM(26) H_WAITVM(27) H_WAITVM(28)
-        H_WAITVM(29) H_WAITVM(30) H_WAITVM(31) H_WAITVM(32) H_WAITVM(33) H_WAITVM(34) H_WAITVM(35) H_WAITVM(36) H_WAITVM(37)
-        H_WAITVM(38) H_WAITVM(39) H_WAITVM(40)
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-}
-#undef H_WAITVM
 
 // instruction order of one (k-step, pixel tile) block: NM MFMAs and NR LDS reads interleaved (csrc/convs.hip: sblock_sched)
 template <int NM, int NR>
@@ -106,30 +102,34 @@ struct HPlan {
     int N, C, H, W, HW, Ho, Wo, HWo, Cout, total;      // total = N * Ho * Wo output pixels
     int in_gtot, in_goff, out_gtot, out_goff, res_gtot, res_goff, act;
     float pre, post;                                   // weights carry 2^k = pre; the sum is multiplied by post = 2^-k
-    int NTW, nN, nTiles, nChunks, tpx, NPT, depth;     // depth: stages of the chunk ring (1 .. 4)
+    int NTW, nN, nTiles, nChunks, tpx, NPT;
+    int CK;                                            // input channels per WINDOW stage (a multiple of 16 that divides Cin)
     int VR, W1, NIW, NV, pl;                           // virtual rows per image (H + 1), records per virtual row (W + 1), 64-record
                                                        // pieces / records / bytes of a window plane
     uint32_t mHWo, mWo, mW1, mVR;
     unsigned* rflag;
 };
 
-// Workgroup = 64 NPT flattened output pixels x 16 NTW output channels, 4 waves; K = chunks of 16 input channels x 9 taps.
-// LDS: `depth` stages of [2 window planes | weight chunk].  Window (stride 1, csrc/convs.hip): record index = (virtual row) *
+// Workgroup = 64 NPT flattened output pixels x 16 NTW output channels, 4 waves; K = input channels x 9 taps.
+// LDS: [CK / 8 window planes | one 16-channel weight chunk].  Window (stride 1, csrc/convs.hip): record index = (virtual row) *
 // (W + 1) + 1 + x from the first record a tap of the tile reads, one zero record between rows, one zero row above every image;
 // (stride 2, csrc/convs2.hip): a virtual row is [0 | odd columns | even columns] so that consecutive output pixels read consecutive
-// records.  Everything arrives by LDS-DMA; padding = lanes whose source offset is outside the descriptor.
-// Chunk ring: chunk c + depth is issued as soon as chunk c has been multiplied, and the wait in front of chunk c is COUNTED
-// (`s_waitcnt vmcnt(n)`, n = the DMA instructions this wave issued after chunk c's) - with one product per multiply a chunk's MFMAs
-// (~1 k cycles) are far shorter than a DMA round trip (~2-3 k), so the next chunk must already be in flight while one waits.
+// records.  The window arrives by LDS-DMA; padding = lanes whose source offset is outside the descriptor.
+// With ONE product per multiply a 16-channel chunk is ~1 k cycles of MFMA against a ~4 k cycle HBM round trip, and a ring of
+// 16-channel stages measured no better than no ring at all (profiles/r05_h16_ring_sweep.txt: what hides latency is other
+// workgroups, and every stage costs them LDS).  So the WINDOW of CK = 48 .. 96 channels is staged at once - one round trip per CK
+// channels instead of one per 16 - and only the weights (L2-resident, 13.5 KB per 16 channels) stream: the next chunk's
+// weights are loaded into registers under the current chunk's MFMAs and written to the LDS behind them.
 template <int NTW, int NPT, int STRIDE>
 __global__ __launch_bounds__(256, STRIDE == 1 ? 3 : 2) void h16_conv3x3_kernel(const unsigned char* __restrict__ xs,
                                                                                 const unsigned char* __restrict__ wpk,
                                                                                 const float* __restrict__ shift,
                                                                                 const unsigned char* res, unsigned char* out,
                                                                                 const HPlan P) {
-    constexpr int BM = 64 * NPT, WB = hwb(NTW), WCH = hwp(NTW), NBLK = HKS * NPT, MAXJ = STRIDE == 1 ? 2 : 4;
+    constexpr int BM = 64 * NPT, WB = hwb(NTW), WU = WB / 16, NWJ = (WU + 255) / 256, NBLK = HKS * NPT, MAXJ = STRIDE == 1 ? 2 : 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int PL = P.pl, SB = 2 * PL + WB;                         // bytes of a window plane / of a stage
+    const int PL = P.pl, NPL = P.CK >> 3, SUB = P.CK >> 4;          // bytes of a window plane, planes / weight chunks per stage
+    unsigned char* const wl = smem + NPL * PL;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i16 = lane & 15, kl = lane >> 4;
@@ -140,6 +140,10 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? 3 : 2) void h16_conv3x3_kernel(c
     const int tl = jb / P.nN, cb = jb - tl * P.nN;
     const int tile = xcd * P.tpx + tl;
     if (tile >= P.nTiles) return;
+    HSTAMP(0);
+#ifdef OTP_H16_TIMING
+    if (threadIdx.x == 0 && blockIdx.x < 8192) otp_h16_stamps[blockIdx.x * 32 + 30] = __builtin_amdgcn_s_memrealtime();
+#endif
     const int P0 = tile * BM;
     const int n0 = P0 / P.HWo, p0 = P0 - n0 * P.HWo;               // (uniform, once per workgroup)
     const int y0 = (int)hdiv((uint32_t)p0, P.mWo);
@@ -148,7 +152,7 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? 3 : 2) void h16_conv3x3_kernel(c
     const int imgB = P.in_gtot * P.HW * 16;                        // bytes of one image of the input tensor
     const int co_blk = cb * NTW * 16;
 
-    // ---- window pieces of this wave: piece k = wave + 4 j covers window records 64 k .. 64 k + 63 of both planes ---------------
+    // ---- window pieces of this wave: piece k = wave + 4 j covers window records 64 k .. 64 k + 63 of every plane ----------------
     // (arrays of a fixed bound: with a template-dependent bound captured by the lambda below hipcc 7.2's host pass emits no kernel stub)
     int voff[4];
     bool vlive[4];
@@ -168,37 +172,37 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? 3 : 2) void h16_conv3x3_kernel(c
     const otp_rsrc rin = make_rsrc32(xs + (size_t)n0 * imgB + (size_t)P.in_goff * P.HW * 16,
                                      left > 0x7fffff00ull ? 0x7fffff00u : (unsigned)left);
     const otp_rsrc rw = make_rsrc32(wpk, (unsigned)((size_t)P.nN * P.nChunks * WB));
-    const int woff = lane * 16;
-    int npw = 0;                                                   // DMA instructions this wave issues per stage
-#pragma unroll
-    for (int j = 0; j < MAXJ; ++j) npw += (wave + 4 * j < P.NIW) ? 2 : 0;
-#pragma unroll
-    for (int j = 0; j < (WCH + 3) / 4; ++j) npw += (wave + 4 * j < WCH) ? 1 : 0;
 
-    auto stage = [&](int c, int buf) __attribute__((always_inline)) {
-        unsigned char* sb = smem + buf * SB;
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) {
-            const int so = (2 * c + pl) * P.HW * 16;
+    // the window of window-stage sc: planes of channels CK sc .. CK sc + CK - 1
+    auto stage_window = [&](int sc) __attribute__((always_inline)) {
+        for (int pl = 0; pl < NPL; ++pl) {
+            const int so = (sc * NPL + pl) * P.HW * 16;
 #pragma unroll
             for (int j = 0; j < MAXJ; ++j) {
                 const int k = wave + 4 * j;
                 if (k < P.NIW && vlive[j])                           // (a plane's last piece is partial: lanes past it write nothing)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(sb + pl * PL + k * 1024), 16,
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(smem + pl * PL + k * 1024), 16,
                                                              voff[j], so, 0, 0);
             }
         }
+    };
+    // the weights of 16-channel chunk c: global -> registers (under the previous chunk's MFMAs) -> LDS; unit u = tid + 256 j
+    u32x4 wr[4];                                                   // (fixed bound, NWJ <= 4: see voff above)
+    static_assert(NWJ <= 4, "weight units per thread");
+    auto wload = [&](int c) __attribute__((always_inline)) {
         const int wb = (cb * P.nChunks + c) * WB;
 #pragma unroll
-        for (int j = 0; j < (WCH + 3) / 4; ++j) {
-            const int k = wave + 4 * j;
-            if (k < WCH && (k * 1024 + 1024 <= WB || lane < 32))     // (odd NTW: the image ends with a 512-byte half piece)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(sb + 2 * PL + k * 1024), 16, woff,
-                                                         wb + k * 1024, 0, 0);
-        }
+        for (int j = 0; j < NWJ; ++j)
+            wr[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, tid + 256 * j < WU ? (tid + 256 * j) * 16 : HOOB, wb, 0));
     };
-    stage(0, 0);
-    for (int c = 1; c < P.depth && c < P.nChunks; ++c) stage(c, c);
+    auto wstore = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NWJ; ++j)
+            if (tid + 256 * j < WU) *reinterpret_cast<u32x4*>(wl + (tid + 256 * j) * 16) = wr[j];
+    };
+    stage_window(0);
+    wload(0);
+    HSTAMP(1);
 
     // ---- per pixel tile: fragment address, lane offsets into the output / residual images --------------------------------------
     const unsigned obytes = (unsigned)((size_t)P.N * P.out_gtot * P.HWo * 16 - (size_t)P.out_goff * P.HWo * 16);
@@ -208,7 +212,6 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? 3 : 2) void h16_conv3x3_kernel(c
     const otp_rsrc rsh = make_rsrc32(shift ? shift : reinterpret_cast<const float*>(xs), shift ? (unsigned)(P.Cout * 4) : 0u);
     int pb[NPT], toff[HKS], offO[NPT], offR[NPT], ch0[NTW];
     f32x4 acc[NTW][NPT];
-    u32x4 rres[(NTW + 1) / 2][NPT];
     {
 #pragma unroll
         for (int s = 0; s < HKS; ++s) {
@@ -240,33 +243,12 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? 3 : 2) void h16_conv3x3_kernel(c
 #pragma unroll
             for (int t = 0; t < NTW; ++t) acc[t][p] = sh[t] * P.pre;
         }
-        // residual records (the lane's 8 channels of a tile pair, or the half record of a lone tile): in flight under the chunk loop
-#pragma unroll
-        for (int t = 0; t < NTW; t += 2) {
-            const bool tav = ch0[t] < P.Cout;                      // (per lane: Cout % 8 == 0, a lane's record exists or does not)
-            const int go = (ch0[t] >> 3) * P.HWo * 16;
-            if (hpaired(co_blk, t, NTW, P.Cout)) {
-#pragma unroll
-                for (int p = 0; p < NPT; ++p)
-                    rres[t >> 1][p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                        rr, (tav && offR[p] != HOOB) ? offR[p] + go : HOOB, 0, 0));
-            } else {
-                const int half = (ch0[t] >> 2) & 1;
-#pragma unroll
-                for (int p = 0; p < NPT; ++p) {
-                    const u32x2 h = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(
-                        rr, (tav && offR[p] != HOOB) ? offR[p] + go + 8 * half : HOOB, 0, 0));
-                    rres[t >> 1][p] = (u32x4){h[0], h[1], 0u, 0u};
-                }
-            }
-        }
     }
 
-    // One chunk: NBLK (k-step, pixel tile) blocks of NTW MFMAs; B fragments are read two blocks ahead (ring of three), the weight
-    // fragments of the next k-step two blocks before it starts (csrc/convs.hip)
-    auto mfma_phase = [&](int buf) __attribute__((always_inline)) {
-        const unsigned char* win = smem + buf * SB;
-        const unsigned char* wl = win + 2 * PL;
+    // One 16-channel chunk: NBLK (k-step, pixel tile) blocks of NTW MFMAs; B fragments are read two blocks ahead (ring of three),
+    // the weight fragments of the next k-step two blocks before it starts (csrc/convs.hip)
+    auto mfma_phase = [&](int sub) __attribute__((always_inline)) {
+        const unsigned char* win = smem + sub * 2 * PL;            // the two planes of this chunk
         h16x8 a[2][NTW], b[3];
         auto load_a = [&](int ab, int s) __attribute__((always_inline)) {
 #pragma unroll
@@ -304,26 +286,62 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? 3 : 2) void h16_conv3x3_kernel(c
         }
     };
 
-    const int D = P.depth;
-    int buf = 0;                                                   // stage of chunk c: c mod D
-    for (int c = 0; c < P.nChunks; ++c) {
-        // this wave's pieces of chunk c have landed: all but the DMA instructions it issued after them (the stages in front)
-        int ahead = P.nChunks - 1 - c;
-        if (ahead > D - 1) ahead = D - 1;
-        hwait_vm(ahead * npw);
-        __builtin_amdgcn_s_barrier();                              // ... and everybody else's
-        asm volatile("" ::: "memory");
-        mfma_phase(buf);
-        if (c + D < P.nChunks) {
+    HSTAMP(2);
+    const int nStages = P.C / P.CK;
+    for (int sc = 0; sc < nStages; ++sc) {
+        if (sc > 0) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                          // every wave is done with the LDS image of chunk c
+            __builtin_amdgcn_s_barrier();                          // every wave is done with the previous window (and weight chunk)
             asm volatile("" ::: "memory");
-            stage(c + D, buf);
+            stage_window(sc);
+            wload(sc * SUB);
         }
-        buf = buf + 1 == D ? 0 : buf + 1;
+        for (int sub = 0; sub < SUB; ++sub) {
+            if (sub > 0) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                      // every wave is done with the previous chunk's weight image
+                asm volatile("" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the window (and its weight units) have landed
+            }
+            if (sc == 0 && sub < 3) HSTAMP(3 + 4 * sub);
+            wstore();
+            asm volatile("" ::: "memory");
+            if (sub + 1 < SUB) wload(sc * SUB + sub + 1);          // the next chunk's weights fly under this chunk's MFMAs
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                          // the weight image (and everybody's window pieces) are in the LDS
+            asm volatile("" ::: "memory");
+            if (sc == 0 && sub < 3) HSTAMP(4 + 4 * sub);
+            mfma_phase(sub);
+            if (sc == 0 && sub < 3) HSTAMP(5 + 4 * sub);
+        }
     }
+    HSTAMP(16);
 
     // ---- epilogue: post scale, residual, range guard, ReLU, one rounding to half, 16-byte record stores ------------------------
+    // (the residual records are loaded here, not held across the chunk loop: 24 registers less is a fourth workgroup per CU, and
+    //  another workgroup's MFMAs cover the round trip)
+    u32x4 rres[(NTW + 1) / 2][NPT];
+#pragma unroll
+    for (int t = 0; t < NTW; t += 2) {
+        const bool tav = ch0[t] < P.Cout;                          // (per lane: Cout % 8 == 0, a lane's record exists or does not)
+        const int go = (ch0[t] >> 3) * P.HWo * 16;
+        if (hpaired(co_blk, t, NTW, P.Cout)) {
+#pragma unroll
+            for (int p = 0; p < NPT; ++p)
+                rres[t >> 1][p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    rr, (tav && offR[p] != HOOB) ? offR[p] + go : HOOB, 0, 0));
+        } else {
+            const int half = (ch0[t] >> 2) & 1;
+#pragma unroll
+            for (int p = 0; p < NPT; ++p) {
+                const u32x2 h = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(
+                    rr, (tav && offR[p] != HOOB) ? offR[p] + go + 8 * half : HOOB, 0, 0));
+                rres[t >> 1][p] = (u32x4){h[0], h[1], 0u, 0u};
+            }
+        }
+    }
+    HSTAMP(17);
     bool bad = false;
 #pragma unroll
     for (int t = 0; t < NTW; t += 2) {
@@ -356,6 +374,10 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? 3 : 2) void h16_conv3x3_kernel(c
         }
     }
     otp_range_report(P.rflag, bad, OTP_RANGE_H16);
+    HSTAMP(19);
+#ifdef OTP_H16_TIMING
+    if (threadIdx.x == 0 && blockIdx.x < 8192) otp_h16_stamps[blockIdx.x * 32 + 31] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 int h16_ntw(int Cout) {
@@ -406,15 +428,20 @@ bool h16_conv_plan(const otp_h16_conv_desc& d, HPlan& P) {
     P.W1 = d.W + 1;
     const int maxrec = S == 1 ? 512 : 1024;                        // 2 / 4 pieces of 64 records per wave and plane
     // the pixel tile: 256 pixels, or 128 for launches that would leave the CUs with fewer than three workgroups each; smaller while
-    // the window planes do not fit.  Ring depth 2 whenever two stages still let two workgroups share a CU.
+    // the window planes do not fit.
     bool found = false;
-    for (int npt = 4; npt >= 1; npt >>= 1) {
+    int npt0 = 4;
+    if (const char* e = getenv("OTPOSE_H16_NPT")) {                // development override of the largest pixel tile (1 / 2 / 4)
+        const int v = atoi(e);
+        if (v == 1 || v == 2 || v == 4) npt0 = v;
+    }
+    for (int npt = npt0; npt >= 1; npt >>= 1) {
         const int bm = 64 * npt;
         P.NPT = npt;
         P.nTiles = (P.total + bm - 1) / bm;
         const int NV = h16_window_records(P, bm, S);
         if (NV > maxrec) continue;
-        const size_t st = (size_t)2 * NV * 16 + hwb(P.NTW);
+        const size_t st = (size_t)2 * NV * 16 + hwb(P.NTW);          // the smallest stage: 16 channels
         if (st > 80 * 1024) continue;
         P.NV = NV;
         found = true;
@@ -428,17 +455,22 @@ bool h16_conv_plan(const otp_h16_conv_desc& d, HPlan& P) {
         if (P.NV > maxrec) return false;
     }
     P.pl = P.NV * 16;
-    // ring depth: as many stages as the chunks need, while (a) three workgroups still share a CU's 160 KB when the launch has that
-    // many per CU, else two; one product per multiply makes a chunk's MFMAs (0.5 - 1 k cycles) much shorter than a DMA round trip
-    // (~4 k cycles under load), so what counts is bytes in flight
-    const size_t st = (size_t)2 * P.pl + hwb(P.NTW);
-    const long wgs = (long)P.nTiles * P.nN;
-    const size_t budget = wgs >= 3 * 256 ? (160 * 1024) / 3 : (wgs > 256 ? 80 * 1024 : 160 * 1024);
-    P.depth = 1;
-    for (int dd = 2; dd <= 4 && dd <= P.nChunks && dd * st <= budget; ++dd) P.depth = dd;
-    if (const char* e = getenv("OTPOSE_H16_DEPTH")) {              // development override (1 .. 4)
-        const int v = atoi(e);
-        if (v >= 1 && v <= 4 && v <= P.nChunks && (size_t)v * st <= 160 * 1024) P.depth = v;
+    // channels per window stage: the largest multiple of 16 dividing Cin whose planes + one weight chunk let three workgroups share a
+    // CU's 160 KB (two when nothing else fits) - one HBM round trip per CK channels
+    {
+        const size_t wbytes = hwb(P.NTW);
+        int best = 0;
+        for (size_t budget : {(size_t)(160 * 1024) / 3, (size_t)80 * 1024, (size_t)160 * 1024}) {
+            for (int ck = 96; ck >= 16 && !best; ck -= 16)
+                if (d.Cin % ck == 0 && (size_t)(ck / 8) * P.pl + wbytes <= budget) best = ck;
+            if (best) break;
+        }
+        if (!best) return false;
+        P.CK = best;
+        if (const char* e = getenv("OTPOSE_H16_CK")) {             // development override
+            const int v = atoi(e);
+            if (v >= 16 && v <= 96 && v % 16 == 0 && d.Cin % v == 0 && (size_t)(v / 8) * P.pl + wbytes <= 160 * 1024) P.CK = v;
+        }
     }
     P.tpx = (P.nTiles + 7) / 8;
     P.NIW = (P.NV + 63) / 64;
@@ -461,7 +493,7 @@ bool h16_conv_plan(const otp_h16_conv_desc& d, HPlan& P) {
 template <int NTW, int NPT, int STRIDE>
 int h16_conv_launch(const void* xs, const void* wpk, const float* shift, const void* res, void* out, const HPlan& P, hipStream_t st) {
     auto kern = h16_conv3x3_kernel<NTW, NPT, STRIDE>;
-    const size_t need = (size_t)P.depth * (2 * P.pl + hwb(NTW));
+    const size_t need = (size_t)(P.CK / 8) * P.pl + hwb(NTW);
     OTP_ALLOW_BIG_LDS(kern, need);
     hipLaunchKernelGGL(kern, dim3(8 * P.tpx * P.nN), dim3(256), need, st, static_cast<const unsigned char*>(xs),
                        static_cast<const unsigned char*>(wpk), shift, static_cast<const unsigned char*>(res),
@@ -868,6 +900,11 @@ __global__ __launch_bounds__(256) void h8_upsample_add_kernel(H8Up U, const u32x
 }  // namespace
 
 // ---- C ABI ---------------------------------------------------------------------------------------------------------------------
+#ifdef OTP_H16_TIMING
+extern "C" int otp_h16_read_stamps(void* host_out, size_t bytes) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(otp_h16_stamps), bytes) == hipSuccess ? OTP_OK : OTP_ERR_LAUNCH;
+}
+#endif
 extern "C" size_t otp_h8_bytes(int N, int C, int H, int W) {
     if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || C % 8) return 0;
     return (size_t)N * C * H * W * 2;

@@ -83,21 +83,22 @@ def test_h16_conv3x3_matches_float64_on_the_same_halves(n, cin, cout, h, w, stri
     _check_half(ops.h8_unpack(out), ref, f"conv {cin}->{cout} s{stride}")
 
 
-def test_h16_conv3x3_ring_depth_and_group_slices_change_nothing(monkeypatch):
-    """The two-stage chunk ring against the one-stage loop (OTPOSE_H16_DEPTH), and input / output / residual as channel-group
-    slices of wider tensors: the same bits."""
+def test_h16_conv3x3_window_width_and_group_slices_change_nothing(monkeypatch):
+    """The window staged 48 channels at a time against 16 at a time (OTPOSE_H16_CK) and smaller pixel tiles (OTPOSE_H16_NPT), and
+    input / output / residual as channel-group slices of wider tensors: the same bits."""
     n, cin, cout, h, w = 3, 48, 48, 24, 18
     x, res = _rand((n, cin, h, w), 7).cuda(), _rand((n, cout, h, w), 8).cuda()
     wt, sh = _rand((cout, cin, 3, 3), 9, 0.05).cuda(), _rand((cout,), 10, 0.2).cuda()
     wp = ops.pack_h16_conv_weight(wt, None, 0)
     xi, ri = ops.h8_pack(x), ops.h8_pack(res)
-    monkeypatch.setenv("OTPOSE_H16_DEPTH", "2")
     a = ops.h8_unpack(ops.h16_conv3x3(xi, wp, sh, cout, 1, ACT_RELU, ri))
-    for depth in ("1", "3"):
-        monkeypatch.setenv("OTPOSE_H16_DEPTH", depth)
+    for ck, npt in (("16", "4"), ("48", "2"), ("16", "1")):
+        monkeypatch.setenv("OTPOSE_H16_CK", ck)
+        monkeypatch.setenv("OTPOSE_H16_NPT", npt)
         b = ops.h8_unpack(ops.h16_conv3x3(xi, wp, sh, cout, 1, ACT_RELU, ri))
-        assert torch.equal(a, b)
-    monkeypatch.delenv("OTPOSE_H16_DEPTH")
+        assert torch.equal(a, b), (ck, npt)
+    monkeypatch.delenv("OTPOSE_H16_CK")
+    monkeypatch.delenv("OTPOSE_H16_NPT")
     wide_in, wide_out, wide_res = (ops.h8_empty(n, c, h, w, x.device) for c in (64, 96, 80))
     for t in (wide_in, wide_out, wide_res):
         t.t.zero_()

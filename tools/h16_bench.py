@@ -94,6 +94,14 @@ if __name__ == "__main__":
         out = ops.h8_empty(80, 64, 192, 144, "cuda")
         t = ev(lambda: ops.h16_stem(clip, pk, 64, 5, out=out))
         print(f"stem 3->64 s2 @384x288 x80: {t:7.1f} us  {(clip.numel() * 4 + 80 * 64 * 192 * 144 * 2) / t / 1e6:5.2f} TB/s", flush=True)
+    if what == "fwd16":                              # one model only (profiling): cfg2 or cfg5 in fp16
+        which = sys.argv[2] if len(sys.argv) > 2 else "cfg2"
+        if which == "cfg5":
+            forward(cfg5("fp16"), 7, "cfg5 fp16", steps=10)
+        else:
+            c = cfg2()
+            c.MODEL.DTYPE = "fp16"
+            forward(c, 5, "cfg2 fp16", steps=10)
     if what in ("all", "forward"):
         c = cfg2()
         c.MODEL.DTYPE = "fp16"
