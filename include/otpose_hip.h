@@ -99,6 +99,15 @@ int otp_h16_stem_pack(const void* w, const void* scale, const void* shift, void*
 int otp_h16_stem(const void* in, const void* packed, void* out_h8, int B, int F, int H, int W, int Cout, void* stream);
 int otp_h16_upsample_add(const void* const* lows_h8, const int* factors, int nlow, const void* res_h8, void* out_h8, int N, int C,
                          int Hh, int Wh, int relu, void* stream);
+/* The temporal encoders' matrix kernels with the same arithmetic (model/blocks.py:248-254, 400-419): fp32 (B, C, T) tensors as in
+ * otp_ln_mlp_x3 / otp_dense_x3 / otp_qkv_front_x3 - same arguments, same packed weights - but every operand rounded to half ONCE
+ * (the hi piece), one MFMA per product, the MLP's hidden layer rounded to half behind a 6e-5 GELU; LayerNorm and accumulation fp32. */
+int otp_ln_mlp_h1(const void* y, const void* ln_gamma, const void* ln_beta, float ln_eps, const void* packed, const void* scale,
+                  const void* shift, void* out, int B, int C, int HID, int T, void* stream);
+int otp_dense_h1(const void* const* x, const void* const* packed, const void* const* res, void* const* out, int nprob, int B, int C,
+                 int T, void* stream);
+int otp_qkv_front_h1(const void* x, const void* table, const void* packed_q, const void* packed_k, const void* packed_v, void* q,
+                     void* k, void* v, int B, int C, int T, float eps, void* stream);
 
 /* ---- modulated deformable convolution ------------------------------------------------------
  * out[n,o,p] = beta*out[n,o,p] + alpha*( bias[o] + sum_{c,k} W[o,c,k] * mask[n,g(c)*K+k,p] *

@@ -101,7 +101,8 @@ __device__ __forceinline__ void dx_stage(const unsigned char* __restrict__ src, 
 // the DMA alone (`s_waitcnt vmcnt(4)`: all but the four stores, which stay in flight under the next block's MFMAs) instead of
 // the `vmcnt(0)` of __syncthreads(), which made every block pay a store round trip.
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-template <int C, bool RES>
+// H1: the fp16 engine's arithmetic - the hi pieces only (operands rounded to half once), one MFMA per product
+template <int C, bool RES, bool H1 = false>
 __device__ __forceinline__ void dx_project(const h16x8 (&Xh)[dx_ks(C)][2], const h16x8 (&Xl)[dx_ks(C)][2],
                                            const unsigned char* __restrict__ packed, unsigned char* lds,
                                            const float* __restrict__ res, float* __restrict__ out, size_t base, int T, int tok,
@@ -130,11 +131,13 @@ __device__ __forceinline__ void dx_project(const h16x8 (&Xh)[dx_ks(C)][2], const
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const h16x8 ah = *reinterpret_cast<const h16x8*>(P + (ks * 2) * 1024 + lane * 16);
-            const h16x8 al = *reinterpret_cast<const h16x8*>(P + (ks * 2 + 1) * 1024 + lane * 16);
-            acc0 = OTP_X3_MFMA(al, Xh[ks][0], acc0, 0, 0, 0);
-            acc1 = OTP_X3_MFMA(al, Xh[ks][1], acc1, 0, 0, 0);
-            acc0 = OTP_X3_MFMA(ah, Xl[ks][0], acc0, 0, 0, 0);
-            acc1 = OTP_X3_MFMA(ah, Xl[ks][1], acc1, 0, 0, 0);
+            if constexpr (!H1) {
+                const h16x8 al = *reinterpret_cast<const h16x8*>(P + (ks * 2 + 1) * 1024 + lane * 16);
+                acc0 = OTP_X3_MFMA(al, Xh[ks][0], acc0, 0, 0, 0);
+                acc1 = OTP_X3_MFMA(al, Xh[ks][1], acc1, 0, 0, 0);
+                acc0 = OTP_X3_MFMA(ah, Xl[ks][0], acc0, 0, 0, 0);
+                acc1 = OTP_X3_MFMA(ah, Xl[ks][1], acc1, 0, 0, 0);
+            }
             acc0 = OTP_X3_MFMA(ah, Xh[ks][0], acc0, 0, 0, 0);
             acc1 = OTP_X3_MFMA(ah, Xh[ks][1], acc1, 0, 0, 0);
         }
@@ -164,7 +167,7 @@ struct DxArgs {
     float* out[3];
 };
 
-template <int C>
+template <int C, bool H1 = false>
 __global__ __launch_bounds__(256, 2) void densex_cc_kernel(DxArgs A, int T, int tiles_per_b, unsigned* rflag) {
     constexpr int KS = dx_ks(C), BLKB = dx_block_bytes(C);
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BLKB];
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void densex_cc_kernel(DxArgs A, int T, int 
         dx_split8(v1, Xh[ks][1], Xl[ks][1]);
     }
     __syncthreads();
-    dx_project<C, true>(Xh, Xl, A.packed[blockIdx.y], lds, A.res[blockIdx.y], A.out[blockIdx.y], base, T, tok, valid, rflag);
+    dx_project<C, true, H1>(Xh, Xl, A.packed[blockIdx.y], lds, A.res[blockIdx.y], A.out[blockIdx.y], base, T, tok, valid, rflag);
 }
 
 struct QxArgs {
@@ -201,7 +204,7 @@ struct QxArgs {
 
 // q, k, v = W_p . LN_p(dwconv3_p(x)) + b_p in one launch (stride 1); table[p][c] = {dw0, dw1, dw2, gamma, beta, 0, 0, 0}
 // (three waves per SIMD: 168 VGPRs with 21 spilled measured 119 us at cfg2 against 127 at two waves / 183 VGPRs and 133 at four)
-template <int C>
+template <int C, bool H1 = false>
 __global__ __launch_bounds__(256, C <= 136 ? 3 : 1) void qkvx_front_kernel(const float* __restrict__ x, const float* __restrict__ table,
                                                             QxArgs A, int T, int tiles_per_b, float eps, unsigned* rflag) {
     constexpr int KS = dx_ks(C), BLKB = dx_block_bytes(C), TAB = 3 * C * 8;
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(256, C <= 136 ? 3 : 1) void qkvx_front_kernel(const
             dx_split8(X1[ks], Xh[ks][1], Xl[ks][1]);
         }
         __syncthreads();                              // weight block 0 of this problem landed
-        dx_project<C, false>(Xh, Xl, A.packed[p], lds, nullptr, A.out[p], base, T, tok, valid, rflag);
+        dx_project<C, false, H1>(Xh, Xl, A.packed[p], lds, nullptr, A.out[p], base, T, tok, valid, rflag);
     }
 }
 
@@ -302,8 +305,9 @@ extern "C" int OTP_ENTRY(otp_dense_x3_pack)(const void* w, const void* scale, co
     return otp_launch_status();
 }
 
-extern "C" int OTP_ENTRY(otp_dense_x3)(const void* const* x, const void* const* packed, const void* const* res, void* const* out,
-                            int nprob, int B, int C, int T, void* stream) {
+namespace {
+int dx_dense_launch(const void* const* x, const void* const* packed, const void* const* res, void* const* out, int nprob, int B, int C,
+                    int T, void* stream, bool h1) {
     if (!x || !packed || !out || nprob < 1 || nprob > 3 || B <= 0) return OTP_ERR_BAD_ARG;
     if (!otp_dense_x3_supported(C, T)) return OTP_ERR_UNSUPPORTED;
     DxArgs a = {};
@@ -318,18 +322,37 @@ extern "C" int OTP_ENTRY(otp_dense_x3)(const void* const* x, const void* const* 
             return OTP_ERR_BAD_ARG;
     }
     const int tiles = otp_ceil_div(T, 128);
-    if (C == 204)
-        hipLaunchKernelGGL(densex_cc_kernel<204>, dim3((unsigned)(B * tiles), (unsigned)nprob), dim3(256), 0,
-                           static_cast<hipStream_t>(stream), a, T, tiles, otp_range_word());
-    else
-        hipLaunchKernelGGL(densex_cc_kernel<136>, dim3((unsigned)(B * tiles), (unsigned)nprob), dim3(256), 0,
-                           static_cast<hipStream_t>(stream), a, T, tiles, otp_range_word());
+    const dim3 grid((unsigned)(B * tiles), (unsigned)nprob);
+    auto st = static_cast<hipStream_t>(stream);
+    if (C == 204) {
+        if (h1) hipLaunchKernelGGL((densex_cc_kernel<204, true>), grid, dim3(256), 0, st, a, T, tiles, otp_range_word());
+        else hipLaunchKernelGGL((densex_cc_kernel<204, false>), grid, dim3(256), 0, st, a, T, tiles, otp_range_word());
+    } else {
+        if (h1) hipLaunchKernelGGL((densex_cc_kernel<136, true>), grid, dim3(256), 0, st, a, T, tiles, otp_range_word());
+        else hipLaunchKernelGGL((densex_cc_kernel<136, false>), grid, dim3(256), 0, st, a, T, tiles, otp_range_word());
+    }
     return otp_launch_status();
+}
+}  // namespace
+
+extern "C" int OTP_ENTRY(otp_dense_x3)(const void* const* x, const void* const* packed, const void* const* res, void* const* out,
+                            int nprob, int B, int C, int T, void* stream) {
+    return dx_dense_launch(x, packed, res, out, nprob, B, C, T, stream, false);
 }
 
 #ifndef OTP_X3_GRAD_COPY
-extern "C" int otp_qkv_front_x3(const void* x, const void* table, const void* packed_q, const void* packed_k,
-                                const void* packed_v, void* q, void* k, void* v, int B, int C, int T, float eps, void* stream) {
+/* otp_dense_x3 with the fp16 engine's arithmetic: operands rounded to half once (the hi pieces of the same packed image), one MFMA
+ * per product; fp32 tensors and accumulation */
+extern "C" int otp_dense_h1(const void* const* x, const void* const* packed, const void* const* res, void* const* out, int nprob, int B,
+                            int C, int T, void* stream) {
+    return dx_dense_launch(x, packed, res, out, nprob, B, C, T, stream, true);
+}
+#endif
+
+#ifndef OTP_X3_GRAD_COPY
+namespace {
+int dx_qkv_launch(const void* x, const void* table, const void* packed_q, const void* packed_k, const void* packed_v, void* q, void* k,
+                  void* v, int B, int C, int T, float eps, void* stream, bool h1) {
     if (!x || !table || !packed_q || !packed_k || !packed_v || !q || !k || !v || B <= 0) return OTP_ERR_BAD_ARG;
     if (!otp_dense_x3_supported(C, T)) return OTP_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) |
@@ -343,12 +366,28 @@ extern "C" int otp_qkv_front_x3(const void* x, const void* table, const void* pa
     a.packed[2] = static_cast<const unsigned char*>(packed_v);
     a.out[0] = static_cast<float*>(q); a.out[1] = static_cast<float*>(k); a.out[2] = static_cast<float*>(v);
     const int tiles = otp_ceil_div(T, 128);
-    if (C == 204)
-        hipLaunchKernelGGL(qkvx_front_kernel<204>, dim3((unsigned)(B * tiles), 3u), dim3(256), 0, static_cast<hipStream_t>(stream),
-                           static_cast<const float*>(x), static_cast<const float*>(table), a, T, tiles, eps, otp_range_word());
-    else
-        hipLaunchKernelGGL(qkvx_front_kernel<136>, dim3((unsigned)(B * tiles), 3u), dim3(256), 0, static_cast<hipStream_t>(stream),
-                           static_cast<const float*>(x), static_cast<const float*>(table), a, T, tiles, eps, otp_range_word());
+    const dim3 grid((unsigned)(B * tiles), 3u);
+    auto st = static_cast<hipStream_t>(stream);
+    auto xf = static_cast<const float*>(x), tf = static_cast<const float*>(table);
+    if (C == 204) {
+        if (h1) hipLaunchKernelGGL((qkvx_front_kernel<204, true>), grid, dim3(256), 0, st, xf, tf, a, T, tiles, eps, otp_range_word());
+        else hipLaunchKernelGGL((qkvx_front_kernel<204, false>), grid, dim3(256), 0, st, xf, tf, a, T, tiles, eps, otp_range_word());
+    } else {
+        if (h1) hipLaunchKernelGGL((qkvx_front_kernel<136, true>), grid, dim3(256), 0, st, xf, tf, a, T, tiles, eps, otp_range_word());
+        else hipLaunchKernelGGL((qkvx_front_kernel<136, false>), grid, dim3(256), 0, st, xf, tf, a, T, tiles, eps, otp_range_word());
+    }
     return otp_launch_status();
+}
+}  // namespace
+
+extern "C" int otp_qkv_front_x3(const void* x, const void* table, const void* packed_q, const void* packed_k,
+                                const void* packed_v, void* q, void* k, void* v, int B, int C, int T, float eps, void* stream) {
+    return dx_qkv_launch(x, table, packed_q, packed_k, packed_v, q, k, v, B, C, T, eps, stream, false);
+}
+
+/* otp_qkv_front_x3 with the fp16 engine's arithmetic (operands rounded to half once, one MFMA per product) */
+extern "C" int otp_qkv_front_h1(const void* x, const void* table, const void* packed_q, const void* packed_k,
+                                const void* packed_v, void* q, void* k, void* v, int B, int C, int T, float eps, void* stream) {
+    return dx_qkv_launch(x, table, packed_q, packed_k, packed_v, q, k, v, B, C, T, eps, stream, true);
 }
 #endif  // OTP_X3_GRAD_COPY

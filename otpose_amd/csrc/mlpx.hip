@@ -50,6 +50,23 @@ __device__ __forceinline__ f32x2 mx_gelu2(f32x2 x) {
     return hx * e + hx;
 }
 
+// erf-GELU for the HALF-operand form (H1 below): the result is rounded to half (2^-11 relative) on its way into the second GEMM,
+// so 6e-5 absolute is enough: x * (0.5 + xc R(xc^2)), xc = clamp(x, +-4.2), R = a degree-8 fit of erf(sqrt(s / 2)) / (2 sqrt(s)) -
+// 12 plain vector instructions, no reciprocal (the fp32 form above: 18 + v_rcp_f32)
+__device__ __forceinline__ float mx_gelu_h(float x) {
+    const float xc = __builtin_amdgcn_fmed3f(x, -4.2f, 4.2f), s2 = xc * xc;
+    float r = 4.711542158e-11f;
+    r = r * s2 + -4.627826316e-09f;
+    r = r * s2 + 2.017249231e-07f;
+    r = r * s2 + -5.191738396e-06f;
+    r = r * s2 + 8.882890530e-05f;
+    r = r * s2 + -1.080400373e-03f;
+    r = r * s2 + 9.720675326e-03f;
+    r = r * s2 + -6.618899545e-02f;
+    r = r * s2 + 3.988157481e-01f;
+    return x * (xc * r + 0.5f);
+}
+
 __device__ __forceinline__ float mx_kslot_sum(float v) {   // sum over the four k-slot lane groups (lanes n, n+16, n+32, n+48)
     v += __shfl_xor(v, 16, 64);
     v += __shfl_xor(v, 32, 64);
@@ -69,6 +86,13 @@ __device__ __forceinline__ void mx_split8(const float (&v)[8], h16x8& hi, h16x8&
     }
     hi = __builtin_bit_cast(h16x8, (u32x4){h[0], h[1], h[2], h[3]});
     lo = __builtin_bit_cast(h16x8, (u32x4){l[0], l[1], l[2], l[3]});
+}
+// 8 floats -> halves, rounded once (the fp16 engine's operands)
+__device__ __forceinline__ h16x8 mx_half8(const float (&v)[8]) {
+    uint32_t h[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) h[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){v[2 * i], v[2 * i + 1]}, h16x2));
+    return __builtin_bit_cast(h16x8, (u32x4){h[0], h[1], h[2], h[3]});
 }
 
 constexpr int mx_ks1(int C) { return (C + 31) / 32; }
@@ -137,7 +161,9 @@ __device__ __forceinline__ void mx_stage(const unsigned char* __restrict__ src, 
 // One pass of a wave over NT (1 or 2) column tiles of 16 tokens starting at token tok0, all HID / 32 hidden blocks; every wave
 // of the workgroup calls it together (the weight blocks go through LDS behind one barrier per block).
 // NT == 2: column n of tile j is token tok0 + 2n + j (8-byte accesses); NT == 1: token tok0 + n.
-template <int C, int HID, int NTHR, bool LN, int NT>
+// H1: the fp16 engine's arithmetic (cfg.MODEL.DTYPE = "fp16") - every operand a half, rounded ONCE (the hi pieces of the same packed
+// weight image; activations and the hidden layer rounded to half), one MFMA per product, fp32 accumulation, LayerNorm / bias in fp32
+template <int C, int HID, int NTHR, bool LN, int NT, bool H1 = false>
 __device__ __forceinline__ void mlpx_pass(const float* __restrict__ x, const unsigned char* __restrict__ packed,
                                           const float* __restrict__ scale, const float* __restrict__ shift,
                                           const float* __restrict__ res, float* __restrict__ out, int T, size_t base, int tok0,
@@ -199,7 +225,7 @@ __device__ __forceinline__ void mlpx_pass(const float* __restrict__ x, const uns
                 }
         }
     }
-    h16x8 Xh[KS1][NT], Xl[KS1][NT];
+    h16x8 Xh[KS1][NT], Xl[H1 ? 1 : KS1][NT];
 #pragma unroll
     for (int ks = 0; ks < KS1; ++ks)
 #pragma unroll
@@ -207,7 +233,8 @@ __device__ __forceinline__ void mlpx_pass(const float* __restrict__ x, const uns
             float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = X[ks][j][t];
-            mx_split8(v, Xh[ks][t], Xl[ks][t]);
+            if constexpr (H1) Xh[ks][t] = mx_half8(v);
+            else mx_split8(v, Xh[ks][t], Xl[H1 ? 0 : ks][t]);
         }
     f32x4 Y[MT][NT];
 #pragma unroll
@@ -231,33 +258,49 @@ __device__ __forceinline__ void mlpx_pass(const float* __restrict__ x, const uns
 #pragma unroll
             for (int ks = 0; ks < KS1; ++ks) {
                 const h16x8 ah = *reinterpret_cast<const h16x8*>(P1 + ((tile * KS1 + ks) * 2) * 1024);
-                const h16x8 al = *reinterpret_cast<const h16x8*>(P1 + ((tile * KS1 + ks) * 2 + 1) * 1024);
+                if constexpr (H1) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    H[tile][t] = OTP_X3_MFMA(al, Xh[ks][t], H[tile][t], 0, 0, 0);
-                    H[tile][t] = OTP_X3_MFMA(ah, Xl[ks][t], H[tile][t], 0, 0, 0);
-                    H[tile][t] = OTP_X3_MFMA(ah, Xh[ks][t], H[tile][t], 0, 0, 0);
+                    for (int t = 0; t < NT; ++t) H[tile][t] = OTP_X3_MFMA(ah, Xh[ks][t], H[tile][t], 0, 0, 0);
+                } else {
+                    const h16x8 al = *reinterpret_cast<const h16x8*>(P1 + ((tile * KS1 + ks) * 2 + 1) * 1024);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        H[tile][t] = OTP_X3_MFMA(al, Xh[ks][t], H[tile][t], 0, 0, 0);
+                        H[tile][t] = OTP_X3_MFMA(ah, Xl[H1 ? 0 : ks][t], H[tile][t], 0, 0, 0);
+                        H[tile][t] = OTP_X3_MFMA(ah, Xh[ks][t], H[tile][t], 0, 0, 0);
+                    }
                 }
             }
         }
         h16x8 Gh[NT], Gl[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const f32x2 g0 = mx_gelu2(f32x2{H[0][t][0], H[0][t][1]}), g1 = mx_gelu2(f32x2{H[0][t][2], H[0][t][3]});
-            const f32x2 g2 = mx_gelu2(f32x2{H[1][t][0], H[1][t][1]}), g3 = mx_gelu2(f32x2{H[1][t][2], H[1][t][3]});
-            const float v[8] = {g0.x, g0.y, g1.x, g1.y, g2.x, g2.y, g3.x, g3.y};
-            mx_split8(v, Gh[t], Gl[t]);
+            if constexpr (H1) {
+                const float v[8] = {mx_gelu_h(H[0][t][0]), mx_gelu_h(H[0][t][1]), mx_gelu_h(H[0][t][2]), mx_gelu_h(H[0][t][3]),
+                                    mx_gelu_h(H[1][t][0]), mx_gelu_h(H[1][t][1]), mx_gelu_h(H[1][t][2]), mx_gelu_h(H[1][t][3])};
+                Gh[t] = mx_half8(v);
+            } else {
+                const f32x2 g0 = mx_gelu2(f32x2{H[0][t][0], H[0][t][1]}), g1 = mx_gelu2(f32x2{H[0][t][2], H[0][t][3]});
+                const f32x2 g2 = mx_gelu2(f32x2{H[1][t][0], H[1][t][1]}), g3 = mx_gelu2(f32x2{H[1][t][2], H[1][t][3]});
+                const float v[8] = {g0.x, g0.y, g1.x, g1.y, g2.x, g2.y, g3.x, g3.y};
+                mx_split8(v, Gh[t], Gl[t]);
+            }
         }
         // phase 2: Y += W2[:, 32 hb ..] . hidden tiles (k-slot (kq, j) = hidden channel 4 kq + j / 16 + 4 kq + j - 4)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const h16x8 ah = *reinterpret_cast<const h16x8*>(P2 + (mt * 2) * 1024);
-            const h16x8 al = *reinterpret_cast<const h16x8*>(P2 + (mt * 2 + 1) * 1024);
+            if constexpr (H1) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                Y[mt][t] = OTP_X3_MFMA(al, Gh[t], Y[mt][t], 0, 0, 0);
-                Y[mt][t] = OTP_X3_MFMA(ah, Gl[t], Y[mt][t], 0, 0, 0);
-                Y[mt][t] = OTP_X3_MFMA(ah, Gh[t], Y[mt][t], 0, 0, 0);
+                for (int t = 0; t < NT; ++t) Y[mt][t] = OTP_X3_MFMA(ah, Gh[t], Y[mt][t], 0, 0, 0);
+            } else {
+                const h16x8 al = *reinterpret_cast<const h16x8*>(P2 + (mt * 2 + 1) * 1024);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    Y[mt][t] = OTP_X3_MFMA(al, Gh[t], Y[mt][t], 0, 0, 0);
+                    Y[mt][t] = OTP_X3_MFMA(ah, Gl[t], Y[mt][t], 0, 0, 0);
+                    Y[mt][t] = OTP_X3_MFMA(ah, Gh[t], Y[mt][t], 0, 0, 0);
+                }
             }
         }
         __syncthreads();                              // every wave is done with this block; the next one has landed
@@ -297,7 +340,7 @@ __device__ __forceinline__ void mlpx_pass(const float* __restrict__ x, const uns
 }
 
 // NT token tiles of 16 per wave: 2 at C = 136; 1 at C = 204 (7 + 7 input fragments and 13 accumulator tiles per token tile)
-template <int C, int HID, int WAVES, bool LN, int NT>
+template <int C, int HID, int WAVES, bool LN, int NT, bool H1 = false>
 __global__ __launch_bounds__(WAVES * 64, (NT == 1 && C <= 136) ? 4 : 2) void mlpx_kernel(
     const float* __restrict__ x, const unsigned char* __restrict__ packed, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ out, int T, int tiles_per_b,
@@ -305,7 +348,7 @@ __global__ __launch_bounds__(WAVES * 64, (NT == 1 && C <= 136) ? 4 : 2) void mlp
     extern __shared__ __attribute__((aligned(16))) unsigned char mx_lds[];
     const int wave = threadIdx.x >> 6;
     const int b = blockIdx.x / tiles_per_b, tile = blockIdx.x - b * tiles_per_b;
-    mlpx_pass<C, HID, WAVES * 64, LN, NT>(x, packed, scale, shift, res, out, T, (size_t)b * C * T,
+    mlpx_pass<C, HID, WAVES * 64, LN, NT, H1>(x, packed, scale, shift, res, out, T, (size_t)b * C * T,
                                           tile * (WAVES * 16 * NT) + wave * 16 * NT, mx_lds, ln_gamma, ln_beta, ln_eps, rflag);
 }
 
@@ -357,8 +400,9 @@ extern "C" int otp_mlp_x3_pack(const void* w1, const void* b1, const void* w2, v
 
 namespace {
 int mlpx_launch(const void* x, const void* packed, const void* scale, const void* shift, const void* res, void* out,
-                const void* ln_gamma, const void* ln_beta, float ln_eps, int B, int C, int HID, int T, void* stream) {
+                const void* ln_gamma, const void* ln_beta, float ln_eps, int B, int C, int HID, int T, void* stream, bool h1 = false) {
     if (!x || !packed || !scale || !shift || !res || !out || B <= 0) return OTP_ERR_BAD_ARG;
+    if (h1 && !ln_gamma) return OTP_ERR_UNSUPPORTED;              // (the half-operand form exists with the fused LayerNorm only)
     if (!otp_mlp_x3_supported(C, HID, T)) return OTP_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(res) | reinterpret_cast<uintptr_t>(out)) & 7 ||
         reinterpret_cast<uintptr_t>(packed) & 15)
@@ -369,7 +413,8 @@ int mlpx_launch(const void* x, const void* packed, const void* scale, const void
         constexpr int WAVES = 8;
         const size_t lds204 = 2 * (size_t)mx_block_bytes(204);
         const int tiles = otp_ceil_div(T, WAVES * 16);
-        auto kern = ln_gamma ? mlpx_kernel<204, 816, WAVES, true, 1> : mlpx_kernel<204, 816, WAVES, false, 1>;
+        auto kern = h1 ? mlpx_kernel<204, 816, WAVES, true, 1, true>
+                       : (ln_gamma ? mlpx_kernel<204, 816, WAVES, true, 1> : mlpx_kernel<204, 816, WAVES, false, 1>);
         OTP_ALLOW_BIG_LDS(kern, lds204);
         hipLaunchKernelGGL(kern, dim3((unsigned)(B * tiles)), dim3(WAVES * 64), lds204, static_cast<hipStream_t>(stream), f(x), pk,
                            f(scale), f(shift), f(res), static_cast<float*>(out), T, tiles, f(ln_gamma), f(ln_beta), ln_eps, otp_range_word());
@@ -385,10 +430,11 @@ int mlpx_launch(const void* x, const void* packed, const void* scale, const void
     const bool bal_off = bal && bal[0] == '0', bal_force = bal && bal[0] == '2';
     const char* e1 = getenv("OTP_MLP_NT1");
     const bool nt1 = !(e1 && e1[0] == '0');
-    if (nt1 && !bal_force) {
+    if (h1 || (nt1 && !bal_force)) {
         constexpr int WAVES = 8;
         const int tiles = otp_ceil_div(T, WAVES * 16);
-        auto kern = ln_gamma ? mlpx_kernel<136, 544, WAVES, true, 1> : mlpx_kernel<136, 544, WAVES, false, 1>;
+        auto kern = h1 ? mlpx_kernel<136, 544, WAVES, true, 1, true>
+                       : (ln_gamma ? mlpx_kernel<136, 544, WAVES, true, 1> : mlpx_kernel<136, 544, WAVES, false, 1>);
         OTP_ALLOW_BIG_LDS(kern, lds);
         hipLaunchKernelGGL(kern, dim3((unsigned)(B * tiles)), dim3(WAVES * 64), lds, static_cast<hipStream_t>(stream), f(x), pk,
                            f(scale), f(shift), f(res), static_cast<float*>(out), T, tiles, f(ln_gamma), f(ln_beta), ln_eps, otp_range_word());
@@ -421,4 +467,12 @@ extern "C" int otp_ln_mlp_x3(const void* y, const void* ln_gamma, const void* ln
                              const void* scale, const void* shift, void* out, int B, int C, int HID, int T, void* stream) {
     if (!ln_gamma || !ln_beta) return OTP_ERR_BAD_ARG;
     return mlpx_launch(y, packed, scale, shift, y, out, ln_gamma, ln_beta, ln_eps, B, C, HID, T, stream);
+}
+
+/* the same launch with the fp16 engine's arithmetic: half operands rounded once (the hi pieces of the same packed image), one MFMA
+ * per product, the hidden layer rounded to half behind a 6e-5 GELU; fp32 tensors, LayerNorm and accumulation */
+extern "C" int otp_ln_mlp_h1(const void* y, const void* ln_gamma, const void* ln_beta, float ln_eps, const void* packed,
+                             const void* scale, const void* shift, void* out, int B, int C, int HID, int T, void* stream) {
+    if (!ln_gamma || !ln_beta) return OTP_ERR_BAD_ARG;
+    return mlpx_launch(y, packed, scale, shift, y, out, ln_gamma, ln_beta, ln_eps, B, C, HID, T, stream, true);
 }

@@ -80,6 +80,9 @@ class InferenceEngine:
         self.f32_tail = int(os.environ.get("OTPOSE_F32_TAIL", "0")) if self.use_x3 else 0
         self._exact = False
         self._sid = 0
+        # fp16 engine (engine_h16.py): the encoders' matrix kernels also take their operands as halves rounded once (csrc/mlpx.hip,
+        # csrc/densex.hip: the *_h1 entry points); OTPOSE_H16_TAIL=0 keeps their split products
+        self.half_products = bool(getattr(self, "h16", False)) and self.use_x3 and os.environ.get("OTPOSE_H16_TAIL", "1") != "0"
         # range guard of the half-piece arithmetic (csrc/range.hip, csrc/common.h:75): "defer" (default) raises at the NEXT
         # forward / at check_range() and NaN-fills this forward's heat-maps on the device; "sync" synchronises and raises in the
         # forward that overflowed; "off" only keeps the device-side NaN fill
@@ -121,6 +124,7 @@ class InferenceEngine:
         self.multi_stream = bool(multi_stream)
         self.f32_tail, self._exact = 0, False
         self._sid = 0
+        self.half_products = False
         self.range_check = env("OTPOSE_RANGE_CHECK", "defer")
         self._side = hip.side_streams(device, 3, 0) if self.multi_stream else []
         self.inp = None
@@ -323,7 +327,8 @@ class InferenceEngine:
         ax, ap, ar, ao = ops.dense_cc_args(xs, packs, ress, outs)
         self._keep += [ax, ap, ar, ao, *packs]
         x3 = self.use_x3 and ops.dense_x3_supported(C, T)
-        self.call(self.lib.otp_dense_x3 if x3 else self.lib.otp_dense_cc, "otp_dense_cc", ax, ap, ar, ao, len(xs), B, C, T)
+        fn = (self.lib.otp_dense_h1 if self.half_products else self.lib.otp_dense_x3) if x3 else self.lib.otp_dense_cc
+        self.call(fn, "otp_dense_cc", ax, ap, ar, ao, len(xs), B, C, T)
 
     def call(self, fn, name, *args):
         def run():
@@ -891,7 +896,8 @@ class InferenceEngine:
                                                          a.query_norm.weight, a.query_norm.bias, a.key_norm.weight,
                                                          a.key_norm.bias, a.value_norm.weight, a.value_norm.bias)])
             self._keep += [table, *packs]
-            self.call(L.otp_qkv_front_x3 if dx3 else L.otp_qkv_front, "otp_qkv_front", hip.ptr(ln1), hip.ptr(table),
+            self.call((L.otp_qkv_front_h1 if self.half_products else L.otp_qkv_front_x3) if dx3 else L.otp_qkv_front, "otp_qkv_front",
+                      hip.ptr(ln1), hip.ptr(table),
                       *[hip.ptr(t) for t in packs],
                       hip.ptr(q), hip.ptr(k), hip.ptr(v), B, C, T, a.query_norm.eps)
         else:
@@ -935,7 +941,8 @@ class InferenceEngine:
             scd = dev(sm).contiguous()
             shd = (dev(blk.mlp[3].bias) * scd).contiguous()
             self._keep += [packed, scd, shd]
-            self.call(L.otp_ln_mlp_x3, "otp_ln_mlp_x3", hip.ptr(y), hip.ptr(p(blk.ln2.weight)), hip.ptr(p(blk.ln2.bias)),
+            self.call(L.otp_ln_mlp_h1 if self.half_products else L.otp_ln_mlp_x3, "otp_ln_mlp_x3", hip.ptr(y), hip.ptr(p(blk.ln2.weight)),
+                      hip.ptr(p(blk.ln2.bias)),
                       blk.ln2.eps, hip.ptr(packed), hip.ptr(scd), hip.ptr(shd), hip.ptr(out), B, C, hid, To)
             return out
         if self.use_fused_mlp and ops.mlp_fused_supported(C, hid, To):

@@ -642,14 +642,15 @@ def dense_cc_args(xs, packs, ress, outs):
     return arr(xs), arr(packs), arr(ress if ress is not None else [None] * n), arr(outs)
 
 
-def dense_cc(xs, packs, ress=None, outs=None, stream=None, x3=False, grad=False):
+def dense_cc(xs, packs, ress=None, outs=None, stream=None, x3=False, grad=False, half=False):
     """out[p] = scale[p] * (W[p] . x[p]) + shift[p] (+ res[p]) for up to three (B, C, T) problems in one launch (``grad``: see
-    :func:`pack_dense_cc`)."""
+    :func:`pack_dense_cc`; ``half`` with ``x3``: the fp16 engine's arithmetic - operands rounded to half once, otp_dense_h1)."""
     _require_gpu(*xs)
     b, c, t = xs[0].shape
     outs = [torch.empty_like(x) for x in xs] if outs is None else outs
     ax, ap, ar, ao = dense_cc_args(xs, packs, ress, outs)
-    fn = (hip.lib().otp_dense_x3_bf16p if grad else hip.lib().otp_dense_x3) if x3 else hip.lib().otp_dense_cc
+    fn = (hip.lib().otp_dense_x3_bf16p if grad else (hip.lib().otp_dense_h1 if half else hip.lib().otp_dense_x3)) if x3 \
+        else hip.lib().otp_dense_cc
     hip.check(fn(ax, ap, ar, ao, len(xs), b, c, t, stream if stream is not None else hip.stream_of(xs[0])), "otp_dense_cc")
     return outs
 
@@ -773,12 +774,13 @@ def pack_qkv_table(dwq, dwk, dwv, gq, bq, gk, bk, gv, bv):
     return table
 
 
-def qkv_front(x, table, packs, eps=1e-5, outs=None, stream=None, x3=False):
-    """q, k, v = W_p . LN_p(dwconv3_p(x)) + b_p (stride 1) in one launch; ``packs`` = three :func:`pack_dense_cc` images."""
+def qkv_front(x, table, packs, eps=1e-5, outs=None, stream=None, x3=False, half=False):
+    """q, k, v = W_p . LN_p(dwconv3_p(x)) + b_p (stride 1) in one launch; ``packs`` = three :func:`pack_dense_cc` images
+    (``half`` with ``x3``: operands rounded to half once, otp_qkv_front_h1)."""
     _require_gpu(x, table)
     b, c, t = x.shape
     outs = [torch.empty_like(x) for _ in range(3)] if outs is None else outs
-    fn = hip.lib().otp_qkv_front_x3 if x3 else hip.lib().otp_qkv_front
+    fn = (hip.lib().otp_qkv_front_h1 if half else hip.lib().otp_qkv_front_x3) if x3 else hip.lib().otp_qkv_front
     hip.check(fn(hip.ptr(x), hip.ptr(table), *[hip.ptr(p) for p in packs], *[hip.ptr(o) for o in outs],
                  b, c, t, eps, stream if stream is not None else hip.stream_of(x)), "otp_qkv_front")
     return outs
@@ -893,14 +895,15 @@ def mlp_x3(x, packed, scale, shift, res, out=None, hid=None, stream=None):
     return out
 
 
-def ln_mlp_x3(y, gamma, beta, eps, packed, scale, shift, out=None, hid=None, stream=None):
-    """:func:`ln_mlp_fused` with split-half products."""
+def ln_mlp_x3(y, gamma, beta, eps, packed, scale, shift, out=None, hid=None, stream=None, half=False):
+    """:func:`ln_mlp_fused` with split-half products (``half``: operands and the hidden layer rounded to half once, otp_ln_mlp_h1)."""
     _require_gpu(y, packed)
     _check_f32(y)
     b, c, t = y.shape
     hid = 4 * c if hid is None else hid
     out = torch.empty_like(y) if out is None else out
-    hip.check(hip.lib().otp_ln_mlp_x3(hip.ptr(y), hip.ptr(gamma), hip.ptr(beta), eps, hip.ptr(packed), hip.ptr(scale),
+    fn = hip.lib().otp_ln_mlp_h1 if half else hip.lib().otp_ln_mlp_x3
+    hip.check(fn(hip.ptr(y), hip.ptr(gamma), hip.ptr(beta), eps, hip.ptr(packed), hip.ptr(scale),
                                       hip.ptr(shift), hip.ptr(out), b, c, hid, t,
                                       stream if stream is not None else hip.stream_of(y)), "otp_ln_mlp_x3")
     return out

@@ -177,3 +177,44 @@ def test_h16_upsample_add_is_the_fuse_row_tail(nlow):
     for l, f in zip(lows, (2, 4, 8)):
         ref = ref + F.interpolate(_h(l), scale_factor=f, mode="nearest")
     _check_half(ops.h8_unpack(out), ref.clamp_min(0), "upsample_add")
+
+
+# ---- the temporal encoders' matrix kernels with half operands (otp_*_h1; model/blocks.py:248-254, 400-419) ---------------------------
+@pytest.mark.parametrize("C,T", [(136, 256), (136, 6912), (204, 512)])
+def test_encoder_kernels_with_half_operands_stay_within_half_rounding_of_the_split_products(C, T):
+    """otp_ln_mlp_h1 / otp_dense_h1 / otp_qkv_front_h1 against their split-product (fp32-grade) twins on the same packed weights:
+    what separates them is one rounding to half per operand (2^-11 relative, averaged over K = 136 .. 816 products) and the 6e-5
+    GELU - a few 1e-3 of the output range at most."""
+    B, HID = 2, 4 * C
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(B, C, T, generator=g).cuda()
+    w1, w2 = (torch.randn(HID, C, 1, generator=g) / C ** 0.5).cuda(), (torch.randn(C, HID, 1, generator=g) / HID ** 0.5).cuda()
+    b1 = (torch.randn(HID, generator=g) * 0.1).cuda()
+    gam, bet = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.1).cuda()
+    sc, sh = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.1).cuda()
+    packed = ops.pack_mlp_x3_weights(w1, b1, w2)
+    ref = ops.ln_mlp_x3(x, gam, bet, 1e-5, packed, sc, sh)
+    got = ops.ln_mlp_x3(x, gam, bet, 1e-5, packed, sc, sh, half=True)
+    e_mlp = float((got - ref).abs().max()) / float(ref.abs().max())
+    # projections (+ residual)
+    wq = (torch.randn(C, C, generator=g) / C ** 0.5).cuda()
+    pk = ops.pack_dense_cc(wq, sc, sh, x3=True)
+    r = torch.randn(B, C, T, generator=g).cuda()
+    d_ref = ops.dense_cc([x], [pk], [r], x3=True)[0]
+    d_got = ops.dense_cc([x], [pk], [r], x3=True, half=True)[0]
+    # float64 on the same half-rounded operands: exact up to fp32 accumulation
+    d64 = (torch.einsum("oc,bct->bot", wq.half().double().cpu(), x.half().double().cpu()) * sc.double().cpu()[None, :, None]
+           + sh.double().cpu()[None, :, None] + r.double().cpu())
+    assert float((d_got.double().cpu() - d64).abs().max()) <= 3e-6 * float(d64.abs().max())
+    e_dense = float((d_got - d_ref).abs().max()) / float(d_ref.abs().max())
+    # q / k / v front end
+    dws = [(torch.randn(C, 1, 3, generator=g) * 0.5).cuda() for _ in range(3)]
+    lns = [((torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.1).cuda()) for _ in range(3)]
+    table = ops.pack_qkv_table(dws[0], dws[1], dws[2], lns[0][0], lns[0][1], lns[1][0], lns[1][1], lns[2][0], lns[2][1])
+    packs = [ops.pack_dense_cc((torch.randn(C, C, generator=g) / C ** 0.5).cuda(), None, (torch.randn(C, generator=g) * 0.1).cuda(), x3=True)
+             for _ in range(3)]
+    q_ref = ops.qkv_front(x, table, packs, x3=True)
+    q_got = ops.qkv_front(x, table, packs, x3=True, half=True)
+    e_qkv = max(float((a - b).abs().max()) / float(b.abs().max()) for a, b in zip(q_got, q_ref))
+    print(f"C={C} T={T}: half operands vs split products, fraction of range: mlp {e_mlp:.2e}  dense {e_dense:.2e}  qkv {e_qkv:.2e}")
+    assert e_mlp <= 4e-3 and e_dense <= 2e-3 and e_qkv <= 2e-3

@@ -14,8 +14,10 @@ from otpose_amd.config import cfg5
 
 pytestmark = pytest.mark.gpu
 NAMES = ("output", "rough", "intersection", "prev_b", "context", "squeezed", "total_b")
-# max |fp16 engine - fp32 reference| as a fraction of max(1, max |reference|), per output (measured: see the prints)
-TOL = {"output": 2e-2, "rough": 1e-2, "intersection": 2e-2, "prev_b": 1e-2, "context": 5e-2, "squeezed": 1e-2, "total_b": 1e-2}
+# max |fp16 engine - fp32 reference| as a fraction of max(1, max |reference|), per output.  Measured on MI355X in round 5 (the prints
+# of this file): tiny 1.7e-3 .. 2.9e-3, cfg1 vs the reference golden 0.8e-3 .. 3.2e-3 (`context`), cfg2 clip 1.1e-3 .. 3.3e-3
+# (`output`: 4.8e-3 absolute on heat-maps of range 1.46), config5 at full size 0.8e-3 .. 2.7e-3 - the bound is 2.5x the worst figure
+TOL = {n: 8e-3 for n in NAMES}
 
 
 def _model(cfg):
