@@ -113,7 +113,7 @@ def measured_traffic(key, with_source=False):
     in separate passes and corrected as MI355X_MICROARCH.md prescribes; see profiles/r02_traffic.json for the split-bf16
     kernels and profiles/r01_traffic.json for the f32 ones).  None when the files or the key are absent: PMC counters cannot
     be read from inside this process."""
-    for name in ("r04f_traffic.json", "r04c_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in ("r05_traffic.json", "r05_dcn_traffic.json", "r04f_traffic.json", "r04c_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 v = json.load(f).get(key, {}).get("hbm_bytes_per_launch")
@@ -299,12 +299,18 @@ def kernel_rooflines(dev, batch):
                                      batch, 17, 96, 72, 17, 3, 3, 1, 6, 6, 1, 17, 0.2, 0.0, 0, hip.stream_of(xd)), "dcn")
     t_dcn = event_time_ms(dcn, 20, st)
     dcn_bytes = DCN_BYTES_PER_CLIP_DIL * batch
+    # rocprofv3 FETCH_SIZE / WRITE_SIZE of this launch, CALIBRATED for its access width: tools/micro/fetch_calib.hip reads a known
+    # byte count as 27 coalesced dword streams per thread (the operator's pattern) - FETCH_SIZE reports half of it, like the 16-byte
+    # streams of the guide, WRITE_SIZE all of it (tools/r05_dcn_traffic.sh, profiles/r05_dcn_traffic.json).  Batch 16 only.
+    dcn_traffic, dcn_tsrc = measured_traffic("mdcn_fwd_17x96x72_x16", True) if batch == 16 else (None, None)
     dcn_r = {"kernel": "mdcn_fwd_kernel<17,1,true> 17x96x72 x%d clips, one dilation" % batch, "bound": "hbm",
              "achieved": dcn_bytes / (t_dcn * 1e-3) / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
              "frac": dcn_bytes / (t_dcn * 1e-3) / PEAK_HBM,
-             # FETCH_SIZE is uncalibrated for this kernel's 4-byte-per-lane streams (the committed passes read 140 MB, BELOW the
-             # 218 MB the launch must move), so no counter figure is reported
-             "traffic": None,
+             "traffic": dcn_traffic,
+             "traffic_source": ("committed profile (%s): separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this launch, FETCH_SIZE "
+                                "x 2.0 as calibrated on a copy kernel with the operator's own access pattern (27 coalesced dword streams per "
+                                "thread); not collected in this run" % dcn_tsrc) if dcn_traffic is not None else None,
+             "hbm_frac_by_traffic": (dcn_traffic / (t_dcn * 1e-3) / PEAK_HBM) if dcn_traffic is not None else None,
              "ms_per_launch": t_dcn, "algorithmic_bytes_per_launch": dcn_bytes}
     # one TransformerBlock ln2 + MLP launch of a temporal encoder (C = 136, hidden 544, T = 96*72) over the batch
     C, HID, T = 136, 544, 96 * 72
@@ -481,10 +487,10 @@ def train_step_probe(cfg, dev, batch, dtype="bf16", steps=3, dist=None):
     return res
 
 
-def cpu_baseline():
-    """The oracle (CPU restatement of the reference graph) timed on the host cores on a bounded sample of the same
-    workload: a 1-clip warm-up sizes the sample so that the three timed forwards take ~12 s together (1-8 clips of
-    5 frames, 384x288, W48); the median is reported."""
+def cpu_baseline(batch=16):
+    """The oracle (CPU restatement of the reference graph) timed on the host cores on the metric's own workload: after a 1-clip
+    warm-up, ONE forward over the whole batch (16 clips x 5 frames, 384x288, W48: ~20-30 s on 16 cores) - baseline and metric share a
+    workload.  A box on which the warm-up predicts more than ~60 s for the batch gets a proportionally smaller batch (stated)."""
     from oracle import otpose_oracle as O
     cfg = cfg2()
     m = OTPose(cfg)
@@ -498,21 +504,95 @@ def cpu_baseline():
         O.otpose_forward(sd, cfg, x, margin)
         t1 = time.perf_counter() - t0
         log("cpu_baseline: 1-clip warm-up %.2f s (%d threads)" % (t1, cores))
-        clips = max(1, min(8, int(round(4.0 / max(t1, 1e-3)))))
+        # (a batch forward costs less per clip than the warm-up clip did: ~1.3 s per clip on 16 cores)
+        clips = batch if t1 * batch * 0.6 <= 60.0 else max(1, int(60.0 / (t1 * 0.6)))
         x, margin = S.synthetic_clip(clips, cfg.MODEL.IMAGE_SIZE)
-        times = []
-        t_all = time.perf_counter()
-        for i in range(3):
-            t0 = time.perf_counter()
-            O.otpose_forward(sd, cfg, x, margin)
-            times.append(time.perf_counter() - t0)
-            log("cpu_baseline: oracle forward %d over %d clip(s) took %.2f s" % (i, clips, times[-1]))
-            if time.perf_counter() - t_all > 40.0:          # bounded: never more than ~40 s of CPU work
-                break
-    t = sorted(times)[len(times) // 2]
+        t0 = time.perf_counter()
+        O.otpose_forward(sd, cfg, x, margin)
+        t = time.perf_counter() - t0
+        log("cpu_baseline: oracle forward over %d clip(s) took %.2f s" % (clips, t))
     return {"value": 5.0 * clips / t, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "%d clip(s) (%d frames) 384x288 HRNet-W48 per forward, oracle (torch-CPU restatement), median of %d "
-                      "forwards after a 1-clip warm-up, %.2f s each" % (clips, 5 * clips, len(times), t)}
+            "sample": "%s: %d clip(s) (%d frames) 384x288 HRNet-W48 in one forward of the oracle (torch-CPU restatement) after a 1-clip "
+                      "warm-up, %.2f s" % ("the whole batch of the metric" if clips == batch else "a bounded part of the batch", clips,
+                                           5 * clips, t)}
+
+
+def config5_probe(dev, batch, steps):
+    """BASELINE configs[4] (extension: the reference has no 7-frame model, no RSN backbone, no fp16 forward): batch 16 x 7-frame
+    window x 384x288 in the dtype BASELINE.json states - fp16 (cfg.MODEL.DTYPE = "fp16": the backbone on half activations, csrc/h16.hip,
+    the encoders' matrix kernels on half operands) - with the fp32 engine on the same clips beside it: its time, and the max
+    difference of the 7 outputs (the self-consistency SURVEY section 7 prescribes for a configuration without an oracle).  The
+    dominant launch of the fp16 backbone gets its own roofline point.  1 GPU only, never part of `value`."""
+    from otpose_amd.config import cfg5
+    names = ("output", "rough", "intersection", "prev_b", "context", "squeezed", "total_b")
+    x5, g5 = S.synthetic_clip(batch, cfg5().MODEL.IMAGE_SIZE, frames=7)
+    x5, g5 = x5.to(dev), g5.to(dev)
+    res = {}
+    outs = {}
+    for dt in ("fp32", "fp16"):
+        m5 = OTPose(cfg5(dt))
+        S.fill_synthetic_(m5)
+        m5 = m5.to(dev).eval()
+        m5.alias_outputs = True
+        with torch.no_grad():
+            for _ in range(3):
+                o5 = m5(x5, margin=g5)
+            torch.cuda.synchronize(dev)
+            t5 = time.perf_counter()
+            for _ in range(steps):
+                o5 = m5(x5, margin=g5)
+            torch.cuda.synchronize(dev)
+            d5 = time.perf_counter() - t5
+        res[dt] = {"frames_per_s": 7 * batch * steps / d5, "ms_per_step": 1e3 * d5 / steps,
+                   "outputs_finite": all(bool(torch.isfinite(o).all()) for o in o5)}
+        outs[dt] = [o.clone() for o in o5]
+        m5.check_range()
+        del m5, o5
+        torch.cuda.empty_cache()
+    delta = {n: {"max_abs_delta": float((a - b).abs().max()), "max_abs_fp32": float(b.abs().max())}
+             for n, a, b in zip(names, outs["fp16"], outs["fp32"])}
+    # dominant launch of the fp16 backbone: 48 -> 48 3x3 @96x72 over the 112 frames of the batch (BasicBlock conv2: + residual + ReLU)
+    n = 7 * batch
+    g = torch.Generator().manual_seed(9)
+    xi = ops.h8_pack(torch.randn(n, 48, 96, 72, generator=g).to(dev))
+    ri = ops.h8_pack(torch.randn(n, 48, 96, 72, generator=g).to(dev))
+    wt = (torch.randn(48, 48, 3, 3, generator=g) * 0.05).to(dev)
+    k = ops.h16_weight_exponent(wt)
+    wp = ops.pack_h16_conv_weight(wt, None, k)
+    sh = torch.zeros(48, device=dev)
+    yo = ops.h8_empty(n, 48, 96, 72, dev)
+    d1 = ops.h16_conv_desc(xi, 48, 1, ops.ACT_RELU, yo, None, k)
+    d2 = ops.h16_conv_desc(xi, 48, 1, ops.ACT_RELU, yo, ri, k)
+    st = torch.cuda.current_stream(dev)
+    t1 = event_time_ms(lambda: ops.h16_conv3x3(xi, wp, sh, 48, 1, ops.ACT_RELU, None, out=yo, k=k, desc=d1), 20, st)
+    t2 = event_time_ms(lambda: ops.h16_conv3x3(xi, wp, sh, 48, 1, ops.ACT_RELU, ri, out=yo, k=k, desc=d2), 20, st)
+    flop = 2.0 * 48 * 48 * 9 * 96 * 72 * n
+    b1, b2 = 2.0 * 2 * 48 * 96 * 72 * n, 3.0 * 2 * 48 * 96 * 72 * n
+    roof = {"kernel": "h16_conv3x3_kernel<3, 4, 1> (half operands, one f16 MFMA per product, H8 records, window of 48 channels per HBM round "
+                      "trip by LDS-DMA, weights streamed through registers, 3 workgroups / CU) 48->48 3x3 @96x72 x%d frames, H8 -> H8" % n,
+            "bound": "mfma", "achieved": flop / (t1 * 1e-3) / 1e12, "peak": PEAK_BF16_MATRIX / 1e12, "unit": "TFLOP/s",
+            "frac": flop / (t1 * 1e-3) / PEAK_BF16_MATRIX,
+            "mfma_pipe_frac": flop * 10.0 / 9.0 / (t1 * 1e-3) / PEAK_BF16_MATRIX,
+            "hbm_frac": b1 / (t1 * 1e-3) / PEAK_HBM, "hbm_frac_basis": "algorithmic bytes (half in, half out)", "traffic": None,
+            "ms_per_launch": t1, "algorithmic_flop_per_launch": flop, "algorithmic_bytes_per_launch": b1,
+            "conv2_form": {"what": "+ H8 residual + ReLU (a BasicBlock's conv2)", "ms_per_launch": t2, "achieved": flop / (t2 * 1e-3) / 1e12,
+                           "frac": flop / (t2 * 1e-3) / PEAK_BF16_MATRIX, "hbm_frac": b2 / (t2 * 1e-3) / PEAK_HBM,
+                           "algorithmic_bytes_per_launch": b2},
+            "note": "one product per multiply leaves 2.9 k MFMA cycles per 256-pixel tile against ~2 k cycles of vector set-up / epilogue "
+                    "work and an HBM floor of the same order: the launch is bound by instruction issue, not by one pipe "
+                    "(profiles/r05_h16_conv_phase_stamps.txt)"}
+    return {"workload": "BASELINE configs[4] as far as the reference defines it: batch %d x 7-frame window x 384x288, HRNet-W48 (no RSN "
+                        "backbone / occlusion mask exists in the reference: model/OTPose.py:200, model/blocks.py:399-453), fp16" % batch,
+            "dtype": "fp16", "frames_per_s": res["fp16"]["frames_per_s"], "ms_per_step": res["fp16"]["ms_per_step"],
+            "outputs_finite": res["fp16"]["outputs_finite"],
+            "arithmetic": "backbone activations stored as IEEE half (H8 records), weights rounded to half once (times a per-layer power of "
+                          "two), one v_mfma_f32_16x16x32_f16 per product, fp32 accumulation / shift / residual; encoder MLP / projections / "
+                          "q-k-v front end on half operands with fp32 LayerNorm, softmax and accumulation; fp32 tensors behind the backbone",
+            "fp32_engine_same_clips": dict(res["fp32"], dtype="f32 storage+accumulate / f16x3 split products"),
+            "speedup_vs_fp32_engine": res["fp32"]["ms_per_step"] / res["fp16"]["ms_per_step"],
+            "self_consistency_fp16_vs_fp32_engine": delta,
+            "tolerance": "8e-3 of max(1, range) per output (tests/test_gpu_h16_engine.py; measured 0.8e-3 .. 2.7e-3)",
+            "roofline": roof}
 
 
 def main():
@@ -568,6 +648,14 @@ def main():
             outs = model(xb, margin=mb)
         barrier()
         dt = time.perf_counter() - t0
+        # the same loop fed from a tensor of the CALLER's (what script/Common.py:116-118 does every iteration): the engine copies the
+        # 106 MB clip tensor into its input buffer first - a device-to-device copy that `ms_per_step` (inputs resident in the
+        # engine's own buffers, OTPose.input_buffers) does not contain; reported beside it, never part of `value`
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            outs = model(x, margin=margin)
+        torch.cuda.synchronize(dev)
+        dt_copy = time.perf_counter() - t1
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -613,30 +701,7 @@ def main():
     # 384 x 288 - 12 x 17 = 204 stacked maps per temporal encoder; 1 GPU only, never part of `value`
     config5 = None
     if world == 1 and not a.no_config5 and a.batch == 16:
-        from otpose_amd.config import cfg5
-        c5 = cfg5()
-        m5 = OTPose(c5)
-        S.fill_synthetic_(m5)
-        m5 = m5.to(dev).eval()
-        m5.alias_outputs = True
-        x5, g5 = S.synthetic_clip(a.batch, c5.MODEL.IMAGE_SIZE, frames=7)
-        x5, g5 = x5.to(dev), g5.to(dev)
-        with torch.no_grad():
-            for _ in range(3):
-                o5 = m5(x5, margin=g5)
-            torch.cuda.synchronize(dev)
-            t5 = time.perf_counter()
-            for _ in range(a.steps):
-                o5 = m5(x5, margin=g5)
-            torch.cuda.synchronize(dev)
-            d5 = time.perf_counter() - t5
-        config5 = {"workload": "BASELINE configs[4] as far as the reference defines it: batch 16 x 7-frame window x 384x288, HRNet-W48 "
-                               "(no RSN backbone / occlusion mask exists in the reference), fp32 storage, split-half (f16x3) products",
-                   "frames_per_s": 7 * a.batch * a.steps / d5, "ms_per_step": 1e3 * d5 / a.steps,
-                   "outputs_finite": all(bool(torch.isfinite(o).all()) for o in o5),
-                   "encoder_kernels": "C = 204 instantiations of csrc/mlpx.hip / csrc/densex.hip (ln2 + MLP, q / k / v front end, projections)"}
-        del m5, o5, x5, g5
-        torch.cuda.empty_cache()
+        config5 = config5_probe(dev, a.batch, a.steps)
     train = None
     if not a.no_train_step:
         del outs
@@ -653,6 +718,7 @@ def main():
             "metric": "frames/sec at 384x288, 5-frame window, batch 16; heatmap max-abs delta vs ref",
             "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step_incl_input_copy": 1e3 * dt_copy / a.steps,
             # the arithmetic that was timed: every tensor, accumulator, normalisation and activation is fp32; the products of the
             # convolutions / projections / MLPs / attention are three f16 MFMA products of two-piece fp32 operands (IEEE-half pieces, 22 significand
             # bits per operand; the reference's fp32 is 24, its default TF32 convolutions on NVIDIA hardware 11).  Measured on the
@@ -705,7 +771,7 @@ def main():
         if world == 1 and a.train_f32:
             line["train_step_f32"] = train_step_probe(cfg, dev, a.batch, "f32")
         if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+            line["cpu_baseline"] = cpu_baseline(a.batch)
         print(json.dumps(line), file=json_out, flush=True)
     if dist is not None:
         dist.barrier()

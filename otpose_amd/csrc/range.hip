@@ -21,10 +21,15 @@ namespace {
 unsigned* g_word = nullptr;
 std::once_flag g_once;
 
-__global__ __launch_bounds__(256) void range_poison_kernel(const unsigned* __restrict__ word, float* __restrict__ out, size_t n) {
-    if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u) return;
+// ONE workgroup, ONE read of the word: it lives in host memory, and every wave that asks pays a PCIe round trip (the first form - 256
+// workgroups each reading it - took 130-170 us at the end of every forward; this one ~5 us).  The fill is the error path.
+__global__ __launch_bounds__(1024) void range_poison_kernel(const unsigned* __restrict__ word, float* __restrict__ out, size_t n) {
+    __shared__ unsigned flag;
+    if (threadIdx.x == 0) flag = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __syncthreads();
+    if (flag == 0u) return;
     const float nan = __builtin_nanf("");
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = nan;
+    for (size_t i = threadIdx.x; i < n; i += 1024) out[i] = nan;
 }
 
 }  // namespace
@@ -55,8 +60,6 @@ extern "C" int otp_range_poison(void* out, size_t n, void* stream) {
     if (!out || n == 0) return OTP_ERR_BAD_ARG;
     const unsigned* w = otp_range_word();
     if (!w) return OTP_ERR_LAUNCH;
-    const size_t blocks = (n + 255) / 256;
-    hipLaunchKernelGGL(range_poison_kernel, dim3((unsigned)(blocks > 256 ? 256 : blocks)), dim3(256), 0, static_cast<hipStream_t>(stream), w,
-                       static_cast<float*>(out), n);
+    hipLaunchKernelGGL(range_poison_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), w, static_cast<float*>(out), n);
     return otp_launch_status();
 }
