@@ -8,6 +8,7 @@ Public surface (mirrors the reference's module / operator API for the path in SU
 from .config import CfgNode, cfg1, cfg2, make_cfg, tiny_cfg, load_yaml  # noqa: F401
 from .model import OTPose, ModulatedDeformConv, DeformableCONV  # noqa: F401
 from .ops import modulated_deform_conv  # noqa: F401
+from . import parallel  # noqa: F401  (installs the process-group hooks: parallel.graph_replay_safe)
 
 __all__ = ["OTPose", "ModulatedDeformConv", "DeformableCONV", "modulated_deform_conv",
            "CfgNode", "make_cfg", "cfg1", "cfg2", "tiny_cfg", "load_yaml"]

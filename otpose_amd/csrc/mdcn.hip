@@ -110,7 +110,9 @@ __device__ __forceinline__ void stage_plane(float* __restrict__ plane, const flo
     }
 }
 
-// nearest 64-bit integer of a fixed-point contribution; out-of-range / NaN (non-finite gradients) add nothing
+// nearest 64-bit integer of a fixed-point contribution; out-of-range / NaN contributions add nothing HERE - a workgroup that met a
+// non-finite grad_out / mask / weight writes NaN planes instead (mdcn_bwd_kernel), as the reference's float atomicAdd would have
+// carried the NaN / Inf into grad_x (deform_conv_cuda_kernel.cu:612-629)
 __device__ __forceinline__ long long fx_round(double v) {
     return fabs(v) < 9.0e18 ? __double2ll_rn(v) : 0ll;
 }
@@ -374,16 +376,25 @@ __global__ __launch_bounds__(BWD_THREADS, 1) void mdcn_bwd_kernel(
 
     // ---- the two data maxima of the contribution bound, over this workgroup's pixels ------------------------------
     float gomax = 0.f, mmax = 0.f;
+    int nfl = 0;                               // a non-finite grad_out / mask value among this workgroup's pixels (fmaxf drops NaN)
     for (int p = p_begin + tid; p < p_end; p += BWD_THREADS) {
 #pragma unroll
-        for (int o = 0; o < CO_T; ++o) gomax = fmaxf(gomax, fabsf(bload(rgon, p * 4, o * P4)));   // rows >= Cout read 0
+        for (int o = 0; o < CO_T; ++o) {
+            const float v = fabsf(bload(rgon, p * 4, o * P4));                                     // rows >= Cout read 0
+            nfl |= !(v < INFINITY);
+            gomax = fmaxf(gomax, v);
+        }
 #pragma unroll
-        for (int k = 0; k < K; ++k) mmax = fmaxf(mmax, fabsf(bload(rmg, p * 4, k * P4)));
+        for (int k = 0; k < K; ++k) {
+            const float v = fabsf(bload(rmg, p * 4, k * P4));
+            nfl |= !(v < INFINITY);
+            mmax = fmaxf(mmax, v);
+        }
     }
     gomax = wave_max(gomax);
     mmax = wave_max(mmax);
     if (lane == 0) { red[wave] = gomax; red[BWD_WAVES + wave] = mmax; }
-    __syncthreads();
+    const int nonfinite = __syncthreads_or(nfl);     // (uniform; also the barrier in front of the reads of `red`)
 #pragma unroll
     for (int i = 0; i < BWD_WAVES; ++i) { gomax = fmaxf(gomax, red[i]); mmax = fmaxf(mmax, red[BWD_WAVES + i]); }
 
@@ -408,8 +419,12 @@ __global__ __launch_bounds__(BWD_THREADS, 1) void mdcn_bwd_kernel(
         }
         __syncthreads();
         float wmax = 0.f;
+        bool wnf = false;                      // a non-finite weight of this channel (its |w| sums are then Inf / NaN)
 #pragma unroll
-        for (int k = 0; k < K; ++k) wmax = fmaxf(wmax, red[k]);
+        for (int k = 0; k < K; ++k) {
+            wnf |= !(red[k] < INFINITY);
+            wmax = fmaxf(wmax, red[k]);
+        }
         // |gcol * mask * (bilinear weight <= 1)| <= bound (1.001: the fma chain of gcol rounds); 2^e > bound
         const float bound = wmax * gomax * mmax * 1.001f;
         double sc = 0.0, inv = 0.0;            // bound == 0: every contribution is 0; not finite: nothing sensible to add
@@ -499,9 +514,10 @@ __global__ __launch_bounds__(BWD_THREADS, 1) void mdcn_bwd_kernel(
         }
         // ---- grad_x plane -> global (the tensor itself, or this chunk's partial plane) -----------------------
         float* gxc = gxdst + (((size_t)blockIdx.x * g.N + n) * g.C + c) * g.H * g.W;
+        const bool poison = nonfinite || wnf;  // (uniform) non-finite operands: the fixed-point plane cannot carry them - NaN, loudly
         for (int i = tid; i < g.H * g.W; i += BWD_THREADS) {
             int y = i / g.W, xx = i - y * g.W;
-            gxc[i] = (float)((double)(long long)gpl[(y + 1) * g.LW + PADL + xx] * inv);
+            gxc[i] = poison ? __builtin_nanf("") : (float)((double)(long long)gpl[(y + 1) * g.LW + PADL + xx] * inv);
         }
         // ---- grad_bias partial (channel-0 workgroups only) ---------------------------------------------------
         if (gbpart != nullptr && c == 0) {

@@ -55,6 +55,38 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, torch.device
 
 
 _GROUP_SEEN = False          # this process has used an initialised process group (it may have been destroyed since)
+_GROUP_DESTROYED = False     # ... and one was torn down (latched by the hook below, whoever called torch.distributed)
+
+
+def _install_group_hooks() -> None:
+    """Latch process-group creation / destruction at the source: ``torch.distributed.init_process_group`` and
+    ``destroy_process_group`` are wrapped once, so a group that the CALLER (or another library) creates and destroys with plain
+    torch.distributed calls - no otpose_amd.parallel helper and no engine forward in between - is still seen by
+    :func:`graph_replay_safe` (the flag used to be set only when one of this module's helpers ran while the group
+    was alive).  Installed at ``import otpose_amd``; a ``from torch.distributed import destroy_process_group`` taken before that
+    import bypasses it."""
+    if getattr(dist, "_otpose_group_hooks", False) or not dist.is_available():
+        return
+    orig_init, orig_destroy = dist.init_process_group, dist.destroy_process_group
+
+    def init_process_group(*a, **k):
+        global _GROUP_SEEN
+        r = orig_init(*a, **k)
+        _GROUP_SEEN = True
+        return r
+
+    def destroy_process_group(*a, **k):
+        global _GROUP_SEEN, _GROUP_DESTROYED
+        if dist.is_initialized():
+            _GROUP_SEEN = _GROUP_DESTROYED = True
+        return orig_destroy(*a, **k)
+
+    init_process_group.__doc__, destroy_process_group.__doc__ = orig_init.__doc__, orig_destroy.__doc__
+    dist.init_process_group, dist.destroy_process_group = init_process_group, destroy_process_group
+    dist._otpose_group_hooks = True
+
+
+_install_group_hooks()
 
 
 def _group_alive() -> bool:
@@ -305,7 +337,7 @@ def joint_flags(target: torch.Tensor) -> torch.Tensor:
     return (target.amax(dim=(0, 2, 3)) == 1).to(torch.int32)
 
 
-def train_step_dp(model, optimizer, x, margin, target, target_weight, forward=None, criterion=None):
+def train_step_dp(model, optimizer, x, margin, target, target_weight, forward=None, criterion=None, stats=None):
     """One data-parallel training step on this rank's clips - the reference's ``nn.DataParallel`` iteration
     (train.py:78-79, script/Common.py:118-144) as one process per GPU:
 
@@ -315,7 +347,12 @@ def train_step_dp(model, optimizer, x, margin, target, target_weight, forward=No
     -> ``optimizer.step()`` (global-norm clip on the already-reduced gradients, identical on every rank).
 
     ``forward(model, x, margin)`` and ``criterion(outputs, target, target_weight, flags)`` default to the HIP training
-    graph (:mod:`otpose_amd.train`); the CPU tests pass their own.  Returns the rank-mean loss (detached)."""
+    graph (:mod:`otpose_amd.train`); the CPU tests pass their own.  Returns the rank-mean loss (detached).
+
+    ``stats`` (a dict, optional): filled with ``comm_ms`` - the wall time of the gradient exchange, bracketed by device
+    synchronisations, i.e. the time between the last backward kernel and the optimizer that a scaling run loses to the collective -
+    its payload ``comm_bytes`` and ``overlap`` (what of the exchange runs under the backward pass: nothing in the flat-buffer form).
+    Asking for it serialises the step; bench.py measures it in an extra, untimed step."""
     if forward is None or criterion is None:
         from . import train as _train
         forward = forward or _train.forward_train
@@ -325,13 +362,27 @@ def train_step_dp(model, optimizer, x, margin, target, target_weight, forward=No
     flags = allreduce_joint_flags(joint_flags(target))
     loss = criterion(outputs, target, target_weight, flags)
     loss.backward()
+    if stats is not None:
+        import time
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
     if hasattr(optimizer, "flat_grads"):
         allreduce_flat_grads(optimizer)
+        nbytes = sum(int(g.numel()) * g.element_size() for g in optimizer.flat_grads()) if stats is not None else 0
     elif collectives_on():
         bk = getattr(optimizer, "_otp_buckets", None)
         if bk is None:
             bk = GradBuckets([p for g in optimizer.param_groups for p in g["params"]])
             optimizer._otp_buckets = bk
         bk.reduce()
+        nbytes = sum(int(p.numel()) * p.element_size() for g in optimizer.param_groups for p in g["params"]) if stats is not None else 0
+    else:
+        nbytes = 0
+    if stats is not None:
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        stats.update(comm_ms=1e3 * (time.perf_counter() - t0), comm_bytes=nbytes if collectives_on() else 0, world=world_size(),
+                     overlap="none: the gradients are reduced after the backward pass (flat fp32 buffers / buckets in one go)")
     optimizer.step()
     return allreduce_mean_(loss.detach().clone())

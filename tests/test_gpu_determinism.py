@@ -64,6 +64,30 @@ def test_dcn_backward_fixed_point_is_as_accurate_as_fp64_needs():
     assert err <= 2e-6, err
 
 
+def test_dcn_backward_carries_non_finite_gradients_into_grad_x():
+    """The reference scatters with float atomicAdd (deform_conv_cuda_kernel.cu:612-629): an Inf / NaN in grad_out (or in the mask,
+    or in a weight) reaches grad_x.  The fixed-point planes cannot hold it, so the workgroups that meet one write NaN planes - a
+    diverged step must not hand the optimizer a finite-looking grad_x."""
+    n, h, w_, dil = 2, 24, 20, 3
+    x = seeded((n, 17, h, w_), 1).cuda()
+    off = (seeded((n, 306, h, w_), 2) * 3.0).cuda()
+    msk = seeded((n, 153, h, w_), 3).cuda()
+    w = (seeded((17, 17, 3, 3), 4) * 0.2).cuda()
+    b = seeded((17,), 5).cuda()
+    gout = seeded((n, 17, h, w_), 6).cuda()
+    assert all(bool(torch.isfinite(t).all()) for t in _dcn_backward(x, off, msk, w, b, gout, dil))
+    for poison in (float("inf"), float("nan")):
+        bad = gout.clone()
+        bad[1, 3, 7, 9] = poison
+        gx = _dcn_backward(x, off, msk, w, b, bad, dil)[0]
+        assert not bool(torch.isfinite(gx[1]).all()), "a non-finite grad_out vanished from grad_x"
+        assert bool(torch.isfinite(gx[0]).all()), "the other image has nothing to do with it"
+    wbad = w.clone()
+    wbad[2, 5, 1, 1] = float("nan")
+    gx = _dcn_backward(x, off, msk, wbad, b, gout, dil)[0]
+    assert not bool(torch.isfinite(gx[:, 5]).all())
+
+
 def _step_grads(model, x, margin, g, wt, opt=None):
     if opt is not None:
         opt.zero_grad()

@@ -73,13 +73,18 @@ def test_e2e_cfg2_clip_matches_reference_golden(golden):
 
 @pytest.mark.parametrize("switch", ["OTPOSE_S8_STRIDE2", "OTPOSE_FUSE_UPSAMPLE", "OTPOSE_POINTX", "OTPOSE_S8_RESIDUAL",
                                     "OTPOSE_S8_LAZY_NCHW", "OTPOSE_T1_S8", "OTPOSE_CHAIN_MODULES", "OTPOSE_STEM_X3", "OTPOSE_L1_S8",
-                                    "OTPOSE_X3_WSCALE", "OTPOSE_S8"])
+                                    "OTPOSE_X3_WSCALE", "OTPOSE_S8", "OTPOSE_UP_ANY_WIDTH", "OTPOSE_F32_TAIL=1", "OTPOSE_F32_TAIL=2"])
 def test_e2e_cfg1_with_each_engine_switch_off(golden, monkeypatch, switch):
     """Every kernel-family switch of the engine, one at a time, against the reference-generated golden.  Since round 4 a branch
     output's NCHW tensor is written only when a consumer asks for it (engine._needs_nchw): each switch moves some consumer from
-    the S8 records back to the fp32 tensor, and a consumer that forgot to ask would read an unwritten buffer here."""
-    monkeypatch.setenv(switch, "0")
-    _, outs = _run(cfg1(), 1)
+    the S8 records back to the fp32 tensor, and a consumer that forgot to ask would read an unwritten buffer here.
+    OTPOSE_F32_TAIL=n switches the S8 / pointx / split-product routes OFF for the last n modules of stage 4 and the
+    final layer, in the middle of modules chained stream by stream: the same lazily written tensors, from the other side."""
+    name, _, value = switch.partition("=")
+    monkeypatch.setenv(name, value or "0")
+    m, outs = _run(cfg1(), 1)
+    if name == "OTPOSE_F32_TAIL":
+        assert m._engine.f32_tail == int(value)
     _check(outs, golden("e2e_cfg1"))
 
 

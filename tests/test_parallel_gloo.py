@@ -281,3 +281,107 @@ def test_train_step_dp_matches_the_global_batch_loss():
         # divides by world, so the update equals the global-batch update
         assert torch.allclose(out["s"], model.s - 0.5 * model.s.grad, atol=1e-6)
         assert torch.allclose(out["t"], model.t - 0.5 * model.t.grad, atol=1e-6)
+
+
+# ---- worlds of 4 and 8 ranks: what the first `bench.py --gpus 8` will exercise --------------------------------
+def _loss_case_n(B):
+    g = torch.Generator().manual_seed(23)
+    J, h, w = 17, 6, 5
+    s = torch.randn(B, J, h, w, generator=g) * 0.3
+    t = torch.randn(B, J, h, w, generator=g) * 0.3
+    tgt = torch.rand(B, J, h, w, generator=g) * 0.9
+    for b in range(B):                                   # joint b (mod 13) has its exact-1 peak ONLY in clip b: every rank's local
+        tgt[b, b % 13, b % h, b % w] = 1.0               # flags differ from the global ones; joints 13-16 have none anywhere
+    wgt = (torch.rand(B, J, 1, generator=g) > 0.15).float()
+    return s, t, tgt, wgt
+
+
+def _dp_world_worker(rank, world, port, out_path, B, steps):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    P.init_from_env("gloo")
+    from oracle import otpose_oracle as O
+    s, t, tgt, wgt = _loss_case_n(B)
+    b, e = P.shard_range(B, rank, world)
+    model = _Heads(s, t)
+    opt = torch.optim.SGD(model.parameters(), lr=0.5)
+    ids = torch.arange(b, e)
+
+    def forward(m, x, margin):
+        return m.s[x], m.t[x]
+
+    def criterion(outs, target, target_weight, flags):
+        return O.st_ohkw_mse_loss(outs[0], outs[1], target, target_weight, 8, global_flags=flags)["final_loss"]
+
+    losses, stats = [], {}
+    for it in range(steps):                              # the second step reuses the gradient buckets of the first
+        losses.append(float(P.train_step_dp(model, opt, ids, None, tgt[b:e], wgt[b:e], forward=forward, criterion=criterion,
+                                            stats=stats if it == steps - 1 else None)))
+    assert stats["world"] == world and stats["comm_ms"] >= 0.0 and stats["comm_bytes"] > 0
+    # every replica must hold the same parameters after the exchange: compare checksums across ranks
+    chk = torch.stack([model.s.detach().double().sum(), model.t.detach().double().sum(), model.s.detach().double().abs().sum()])
+    allc = [torch.empty_like(chk) for _ in range(world)]
+    dist.all_gather(allc, chk)
+    same = all(torch.equal(c, allc[0]) for c in allc)
+    flags = P.allreduce_joint_flags(P.joint_flags(tgt[b:e])).tolist()
+    if rank == 0:
+        torch.save({"losses": losses, "s": model.s.detach().clone(), "t": model.t.detach().clone(), "same": same, "flags": flags,
+                    "shard": (b, e)}, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_train_step_dp_on_four_and_eight_ranks_equals_the_global_batch(world):
+    """Equal shards (8 clips): two steps on `world` ranks == two steps of the global-batch loss (flags MAX-reduced, gradients
+    averaged, buckets reused by the second step), and every replica ends with identical parameters."""
+    from oracle import otpose_oracle as O
+    B, steps = 8, 2
+    out = _spawn(_dp_world_worker, world, B, steps)
+    assert out["same"] and out["flags"] == [1] * 8 + [0] * 9
+    s, t, tgt, wgt = _loss_case_n(B)
+    model = _Heads(s, t)
+    opt = torch.optim.SGD(model.parameters(), lr=0.5)
+    ref_losses = []
+    for _ in range(steps):
+        opt.zero_grad()
+        loss = O.st_ohkw_mse_loss(model.s, model.t, tgt, wgt, 8)["final_loss"]
+        loss.backward()
+        opt.step()
+        ref_losses.append(float(loss.detach()))
+    for a, b in zip(out["losses"], ref_losses):
+        assert abs(a - b) < 1e-6 * max(1.0, abs(b)), (out["losses"], ref_losses)      # (fp32 sums in another order)
+    assert torch.allclose(out["s"], model.s.detach(), atol=2e-6) and torch.allclose(out["t"], model.t.detach(), atol=2e-6)
+
+
+@pytest.mark.parametrize("world,B", [(4, 10), (8, 11)])
+def test_train_step_dp_with_ragged_shards_keeps_replicas_identical(world, B):
+    """Ragged shards (10 clips on 4 ranks: 3, 3, 2, 2; 11 on 8): the control flow of the step - flag MAX, bucket reuse across
+    steps, exchange, optimizer - runs to the end on every rank, the flags are the global ones and the replicas stay identical
+    (the mean over ranks then weights clips unequally: the reference's DataLoader drops the last batch for the same reason)."""
+    out = _spawn(_dp_world_worker, world, B, 3)
+    assert out["same"]
+    assert out["flags"] == [1] * min(B, 13) + [0] * (17 - min(B, 13))
+    assert all(l == l and abs(l) < 1e6 for l in out["losses"])
+    assert out["shard"] == P.shard_range(B, 0, world)
+
+
+def test_a_group_created_and_destroyed_with_plain_torch_distributed_calls_is_seen():
+    """graph_replay_safe() used to depend on a parallel.* helper having run while the group was alive.  The hooks
+    installed at import latch creation / destruction whoever calls torch.distributed."""
+    import subprocess
+    import sys
+    code = (
+        "import os, torch.distributed as dist\n"
+        "import otpose_amd\n"
+        "from otpose_amd import parallel as P\n"
+        "assert P.graph_replay_safe()\n"
+        "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='%d')\n"
+        "dist.init_process_group('gloo', rank=0, world_size=1)\n"
+        "dist.destroy_process_group()\n"
+        "assert not P.graph_replay_safe(), 'a torn-down group went unnoticed'\n"
+        "print('ok')\n" % _free_port())
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
