@@ -100,8 +100,11 @@ int otp_h16_stem(const void* in, const void* packed, void* out_h8, int B, int F,
 int otp_h16_upsample_add(const void* const* lows_h8, const int* factors, int nlow, const void* res_h8, void* out_h8, int N, int C,
                          int Hh, int Wh, int relu, void* stream);
 /* The temporal encoders' matrix kernels with the same arithmetic (model/blocks.py:248-254, 400-419): fp32 (B, C, T) tensors as in
- * otp_ln_mlp_x3 / otp_dense_x3 / otp_qkv_front_x3 - same arguments, same packed weights - but every operand rounded to half ONCE
- * (the hi piece), one MFMA per product, the MLP's hidden layer rounded to half behind a 6e-5 GELU; LayerNorm and accumulation fp32. */
+ * otp_ln_mlp_x3 / otp_dense_x3 / otp_qkv_front_x3 - same arguments; otp_dense_h1 / otp_qkv_front_h1 read the hi pieces of the SAME packed
+ * weights, otp_ln_mlp_h1 a hi-only image of its own (otp_mlp_h1_pack: half the LDS, two workgroups per CU at C = 204) - but every operand
+ * is rounded to half ONCE, one MFMA per product, the MLP's hidden layer rounded to half behind a 6e-5 GELU; LayerNorm and accumulation fp32. */
+size_t otp_mlp_h1_weight_bytes(int C, int HID);                    /* the hi-only image: half of otp_mlp_x3_weight_bytes */
+int otp_mlp_h1_pack(const void* w1, const void* b1, const void* w2, void* packed, int C, int HID, void* stream);
 int otp_ln_mlp_h1(const void* y, const void* ln_gamma, const void* ln_beta, float ln_eps, const void* packed, const void* scale,
                   const void* shift, void* out, int B, int C, int HID, int T, void* stream);
 int otp_dense_h1(const void* const* x, const void* const* packed, const void* const* res, void* const* out, int nprob, int B, int C,

@@ -106,7 +106,11 @@ enum {
     OTP_RANGE_MLPX = 7, OTP_RANGE_DENSEX = 8, OTP_RANGE_ATTN = 9, OTP_RANGE_DCNF = 10, OTP_RANGE_H16 = 11
 };
 unsigned* otp_range_word();                                        // host side: the word's address (NULL without a GPU)
+#ifdef OTP_NO_RANGE_GUARD                                          /* development A/B only (tools/lib_variant.sh): what the guard costs */
+__device__ __forceinline__ bool otp_out_of_range(float) { return false; }
+#else
 __device__ __forceinline__ bool otp_out_of_range(float v) { return !(__builtin_fabsf(v) < OTP_RANGE_LIMIT); }   // true for NaN too
+#endif
 __device__ __forceinline__ void otp_range_report(unsigned* word, bool bad, unsigned code) {
     if (bad && word) __hip_atomic_store(word, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }

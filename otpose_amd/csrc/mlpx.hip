@@ -99,13 +99,15 @@ constexpr int mx_ks1(int C) { return (C + 31) / 32; }
 constexpr int mx_mt(int C) { return (C + 15) / 16; }
 // bytes of one 32-hidden-channel block: W1 fragments [2 tiles][ks][hi, lo][1 KB], W2 fragments [mt][hi, lo][1 KB], b1[32],
 // rounded up to whole KB (one LDS-DMA instruction of a wave); the last copy pass of a workgroup may be partial
-constexpr int mx_w1_bytes(int C) { return 2 * mx_ks1(C) * 2 * 1024; }
-constexpr int mx_w2_bytes(int C) { return mx_mt(C) * 2 * 1024; }
-constexpr int mx_block_bytes(int C) { return (mx_w1_bytes(C) + mx_w2_bytes(C) + 128 + 1023) / 1024 * 1024; }
+// (PS = pieces per fragment: 2 = hi | lo, the split products; 1 = hi only, the half-operand form H1 - half the image, so that two
+//  workgroups of the C = 204 instantiation share a CU's LDS)
+constexpr int mx_w1_bytes(int C, int PS = 2) { return 2 * mx_ks1(C) * PS * 1024; }
+constexpr int mx_w2_bytes(int C, int PS = 2) { return mx_mt(C) * PS * 1024; }
+constexpr int mx_block_bytes(int C, int PS = 2) { return (mx_w1_bytes(C, PS) + mx_w2_bytes(C, PS) + 128 + 1023) / 1024 * 1024; }
 
 __global__ void mlpx_pack_kernel(const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
-                                 unsigned char* __restrict__ packed, int C, int HID) {
-    const int KS1 = mx_ks1(C), W1B = mx_w1_bytes(C), W2B = mx_w2_bytes(C), BLKB = mx_block_bytes(C);
+                                 unsigned char* __restrict__ packed, int C, int HID, int PS) {
+    const int KS1 = mx_ks1(C), W1B = mx_w1_bytes(C, PS), W2B = mx_w2_bytes(C, PS), BLKB = mx_block_bytes(C, PS);
     const int units = BLKB / 16;                                   // 16-byte units per block
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= ((HID + 31) / 32) * units) return;                  // (a ragged last block - HID = 816 - is padded with zero weights)
@@ -114,9 +116,9 @@ __global__ void mlpx_pack_kernel(const float* __restrict__ w1, const float* __re
     float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (u < (W1B + W2B) / 16) {
         const int frag = u >> 6, lane = u & 63, row = lane & 15, kq = lane >> 4;
-        const bool lo_part = frag & 1;
+        const bool lo_part = PS == 2 && (frag & 1);
         if (u < W1B / 16) {
-            const int f2 = frag >> 1, tile = f2 / KS1, ks = f2 - tile * KS1;
+            const int f2 = frag / PS, tile = f2 / KS1, ks = f2 - tile * KS1;
             const int hid = 32 * hb + 16 * tile + row;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -124,7 +126,7 @@ __global__ void mlpx_pack_kernel(const float* __restrict__ w1, const float* __re
                 if (c < C && hid < HID) v[j] = w1[(size_t)hid * C + c];
             }
         } else {
-            const int mt = (frag - W1B / 1024) >> 1, c = 16 * mt + row;
+            const int mt = (frag - W1B / 1024) / PS, c = 16 * mt + row;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int hid = 32 * hb + (j < 4 ? 4 * kq + j : 16 + 4 * kq + j - 4);
@@ -169,8 +171,8 @@ __device__ __forceinline__ void mlpx_pass(const float* __restrict__ x, const uns
                                           const float* __restrict__ res, float* __restrict__ out, int T, size_t base, int tok0,
                                           unsigned char* lds, const float* __restrict__ ln_gamma,
                                           const float* __restrict__ ln_beta, float ln_eps, unsigned* rflag) {
-    constexpr int KS1 = mx_ks1(C), MT = mx_mt(C), HB = (HID + 31) / 32;
-    constexpr int W1B = mx_w1_bytes(C), W2B = mx_w2_bytes(C), BLKB = mx_block_bytes(C);
+    constexpr int KS1 = mx_ks1(C), MT = mx_mt(C), HB = (HID + 31) / 32, PS = H1 ? 1 : 2;
+    constexpr int W1B = mx_w1_bytes(C, PS), W2B = mx_w2_bytes(C, PS), BLKB = mx_block_bytes(C, PS);
     const int lane = threadIdx.x & 63, kq = lane >> 4, n = lane & 15;
     const int tok = tok0 + NT * n;
     const bool valid = tok < T;                       // NT == 2: T is even, a token pair is inside or outside together
@@ -257,7 +259,7 @@ __device__ __forceinline__ void mlpx_pass(const float* __restrict__ x, const uns
             for (int t = 0; t < NT; ++t) H[tile][t] = *reinterpret_cast<const f32x4*>(PB + 16 * tile + 4 * kq);
 #pragma unroll
             for (int ks = 0; ks < KS1; ++ks) {
-                const h16x8 ah = *reinterpret_cast<const h16x8*>(P1 + ((tile * KS1 + ks) * 2) * 1024);
+                const h16x8 ah = *reinterpret_cast<const h16x8*>(P1 + ((tile * KS1 + ks) * PS) * 1024);
                 if constexpr (H1) {
 #pragma unroll
                     for (int t = 0; t < NT; ++t) H[tile][t] = OTP_X3_MFMA(ah, Xh[ks][t], H[tile][t], 0, 0, 0);
@@ -289,7 +291,7 @@ __device__ __forceinline__ void mlpx_pass(const float* __restrict__ x, const uns
         // phase 2: Y += W2[:, 32 hb ..] . hidden tiles (k-slot (kq, j) = hidden channel 4 kq + j / 16 + 4 kq + j - 4)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const h16x8 ah = *reinterpret_cast<const h16x8*>(P2 + (mt * 2) * 1024);
+            const h16x8 ah = *reinterpret_cast<const h16x8*>(P2 + (mt * PS) * 1024);
             if constexpr (H1) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) Y[mt][t] = OTP_X3_MFMA(ah, Gh[t], Y[mt][t], 0, 0, 0);
@@ -341,7 +343,7 @@ __device__ __forceinline__ void mlpx_pass(const float* __restrict__ x, const uns
 
 // NT token tiles of 16 per wave: 2 at C = 136; 1 at C = 204 (7 + 7 input fragments and 13 accumulator tiles per token tile)
 template <int C, int HID, int WAVES, bool LN, int NT, bool H1 = false>
-__global__ __launch_bounds__(WAVES * 64, (NT == 1 && C <= 136) ? 4 : 2) void mlpx_kernel(
+__global__ __launch_bounds__(WAVES * 64, (NT == 1 && (C <= 136 || H1)) ? 4 : 2) void mlpx_kernel(
     const float* __restrict__ x, const unsigned char* __restrict__ packed, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ out, int T, int tiles_per_b,
     const float* __restrict__ ln_gamma, const float* __restrict__ ln_beta, float ln_eps, unsigned* rflag) {
@@ -387,6 +389,12 @@ extern "C" size_t otp_mlp_x3_weight_bytes(int C, int HID) {
     return (size_t)((HID + 31) / 32) * mx_block_bytes(C);
 }
 
+/* the image of otp_ln_mlp_h1: the hi pieces only (weights rounded to half once), half the bytes */
+extern "C" size_t otp_mlp_h1_weight_bytes(int C, int HID) {
+    if (C <= 0 || C % 4 || HID <= 0 || HID % 16) return 0;
+    return (size_t)((HID + 31) / 32) * mx_block_bytes(C, 1);
+}
+
 extern "C" int otp_mlp_x3_pack(const void* w1, const void* b1, const void* w2, void* packed, int C, int HID, void* stream) {
     if (!w1 || !b1 || !w2 || !packed) return OTP_ERR_BAD_ARG;
     const size_t bytes = otp_mlp_x3_weight_bytes(C, HID);
@@ -394,7 +402,18 @@ extern "C" int otp_mlp_x3_pack(const void* w1, const void* b1, const void* w2, v
     const int total = (int)(bytes / 16);
     hipLaunchKernelGGL(mlpx_pack_kernel, dim3(otp_ceil_div(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        static_cast<const float*>(w1), static_cast<const float*>(b1), static_cast<const float*>(w2),
-                       static_cast<unsigned char*>(packed), C, HID);
+                       static_cast<unsigned char*>(packed), C, HID, 2);
+    return otp_launch_status();
+}
+
+extern "C" int otp_mlp_h1_pack(const void* w1, const void* b1, const void* w2, void* packed, int C, int HID, void* stream) {
+    if (!w1 || !b1 || !w2 || !packed) return OTP_ERR_BAD_ARG;
+    const size_t bytes = otp_mlp_h1_weight_bytes(C, HID);
+    if (!bytes) return OTP_ERR_UNSUPPORTED;
+    const int total = (int)(bytes / 16);
+    hipLaunchKernelGGL(mlpx_pack_kernel, dim3(otp_ceil_div(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const float*>(w1), static_cast<const float*>(b1), static_cast<const float*>(w2),
+                       static_cast<unsigned char*>(packed), C, HID, 1);
     return otp_launch_status();
 }
 
@@ -411,7 +430,7 @@ int mlpx_launch(const void* x, const void* packed, const void* scale, const void
     auto pk = static_cast<const unsigned char*>(packed);
     if (C == 204) {                                              // 7-frame window: one token tile per wave, 128 tokens per workgroup
         constexpr int WAVES = 8;
-        const size_t lds204 = 2 * (size_t)mx_block_bytes(204);
+        const size_t lds204 = 2 * (size_t)mx_block_bytes(204, h1 ? 1 : 2);
         const int tiles = otp_ceil_div(T, WAVES * 16);
         auto kern = h1 ? mlpx_kernel<204, 816, WAVES, true, 1, true>
                        : (ln_gamma ? mlpx_kernel<204, 816, WAVES, true, 1> : mlpx_kernel<204, 816, WAVES, false, 1>);
@@ -420,7 +439,7 @@ int mlpx_launch(const void* x, const void* packed, const void* scale, const void
                            f(scale), f(shift), f(res), static_cast<float*>(out), T, tiles, f(ln_gamma), f(ln_beta), ln_eps, otp_range_word());
         return otp_launch_status();
     }
-    const size_t lds = 2 * (size_t)mx_block_bytes(136);
+    const size_t lds = 2 * (size_t)mx_block_bytes(136, h1 ? 1 : 2);
     // Default: one token tile per wave (NT = 1), 128 tokens per 8-wave workgroup, <= 128 VGPRs, i.e. TWO 80 KB workgroups per CU
     // - 132 us at cfg2 against 149 for the balanced form.  (Opt-in until the packed-fp32 op_sel hazard of DESIGN.md section 3.1d
     // was found: the forward's replays differed with it - through the kernels of csrc/densex.hip next to it, not through this
@@ -469,8 +488,8 @@ extern "C" int otp_ln_mlp_x3(const void* y, const void* ln_gamma, const void* ln
     return mlpx_launch(y, packed, scale, shift, y, out, ln_gamma, ln_beta, ln_eps, B, C, HID, T, stream);
 }
 
-/* the same launch with the fp16 engine's arithmetic: half operands rounded once (the hi pieces of the same packed image), one MFMA
- * per product, the hidden layer rounded to half behind a 6e-5 GELU; fp32 tensors, LayerNorm and accumulation */
+/* the same launch with the fp16 engine's arithmetic: half operands rounded once, one MFMA per product, the hidden layer rounded to
+ * half behind a 6e-5 GELU; fp32 tensors, LayerNorm and accumulation.  `packed`: the hi-only image of otp_mlp_h1_pack */
 extern "C" int otp_ln_mlp_h1(const void* y, const void* ln_gamma, const void* ln_beta, float ln_eps, const void* packed,
                              const void* scale, const void* shift, void* out, int B, int C, int HID, int T, void* stream) {
     if (!ln_gamma || !ln_beta) return OTP_ERR_BAD_ARG;

@@ -937,7 +937,7 @@ class InferenceEngine:
         if self.use_fused_mlp and self.use_x3 and ops.mlp_x3_supported(C, hid, To):
             # the same single launch with split-half products on the 16-bit matrix cores (csrc/mlpx.hip)
             dev = lambda t: t.detach().to(self.dev, torch.float32)     # noqa: E731
-            packed = ops.pack_mlp_x3_weights(dev(blk.mlp[0].weight), dev(blk.mlp[0].bias), dev(blk.mlp[3].weight))
+            packed = ops.pack_mlp_x3_weights(dev(blk.mlp[0].weight), dev(blk.mlp[0].bias), dev(blk.mlp[3].weight), half=self.half_products)
             scd = dev(sm).contiguous()
             shd = (dev(blk.mlp[3].bias) * scd).contiguous()
             self._keep += [packed, scd, shd]

@@ -69,6 +69,8 @@ SIGNATURES = {
     "otp_h16_stem_weight_bytes": (c_size_t, [c_int]),
     "otp_h16_stem_pack": (c_int, [c_void_p] * 4 + [c_int, c_void_p]),
     "otp_h16_stem": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p]),
+    "otp_mlp_h1_weight_bytes": (c_size_t, [c_int] * 2),
+    "otp_mlp_h1_pack": (c_int, [c_void_p] * 4 + [c_int] * 2 + [c_void_p]),
     "otp_ln_mlp_h1": (c_int, [c_void_p] * 3 + [c_float] + [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
     "otp_dense_h1": (c_int, [ctypes.POINTER(c_void_p)] * 4 + [c_int] * 4 + [c_void_p]),
     "otp_qkv_front_h1": (c_int, [c_void_p] * 8 + [c_int] * 3 + [c_float, c_void_p]),

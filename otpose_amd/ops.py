@@ -866,19 +866,19 @@ def mlp_x3_supported(c, hid, t) -> bool:
     return bool(hip.lib().otp_mlp_x3_supported(int(c), int(hid), int(t)))
 
 
-def pack_mlp_x3_weights(w1, b1, w2):
-    """The same MLP weights as :func:`pack_mlp_weights`, split into bf16 hi / lo MFMA fragments per 32 hidden channels
-    (csrc/mlpx.hip)."""
+def pack_mlp_x3_weights(w1, b1, w2, half=False):
+    """The same MLP weights as :func:`pack_mlp_weights`, split into half hi / lo MFMA fragments per 32 hidden channels
+    (csrc/mlpx.hip); ``half``: the hi-only image of the fp16 engine's form (``ln_mlp_x3(..., half=True)``)."""
     _require_gpu(w1, b1, w2)
     hid, c = w1.shape[:2]
     L = hip.lib()
-    nbytes = L.otp_mlp_x3_weight_bytes(c, hid)
+    nbytes = (L.otp_mlp_h1_weight_bytes if half else L.otp_mlp_x3_weight_bytes)(c, hid)
     if not nbytes:
         raise RuntimeError(f"otp_mlp_x3: unsupported widths C={c}, HID={hid}")
     packed = torch.empty(nbytes // 4, dtype=torch.int32, device=w1.device)
     w1c, w2c, b1c = (t.detach().contiguous().float() for t in (w1, w2, b1))
-    hip.check(L.otp_mlp_x3_pack(hip.ptr(w1c), hip.ptr(b1c), hip.ptr(w2c), hip.ptr(packed), c, hid, hip.stream_of(w1c)),
-              "otp_mlp_x3_pack")
+    hip.check((L.otp_mlp_h1_pack if half else L.otp_mlp_x3_pack)(hip.ptr(w1c), hip.ptr(b1c), hip.ptr(w2c), hip.ptr(packed), c, hid,
+                                                                 hip.stream_of(w1c)), "otp_mlp_x3_pack")
     return packed
 
 

@@ -194,7 +194,7 @@ def test_encoder_kernels_with_half_operands_stay_within_half_rounding_of_the_spl
     sc, sh = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.1).cuda()
     packed = ops.pack_mlp_x3_weights(w1, b1, w2)
     ref = ops.ln_mlp_x3(x, gam, bet, 1e-5, packed, sc, sh)
-    got = ops.ln_mlp_x3(x, gam, bet, 1e-5, packed, sc, sh, half=True)
+    got = ops.ln_mlp_x3(x, gam, bet, 1e-5, ops.pack_mlp_x3_weights(w1, b1, w2, half=True), sc, sh, half=True)
     e_mlp = float((got - ref).abs().max()) / float(ref.abs().max())
     # projections (+ residual)
     wq = (torch.randn(C, C, generator=g) / C ** 0.5).cuda()

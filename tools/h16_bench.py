@@ -94,6 +94,29 @@ if __name__ == "__main__":
         out = ops.h8_empty(80, 64, 192, 144, "cuda")
         t = ev(lambda: ops.h16_stem(clip, pk, 64, 5, out=out))
         print(f"stem 3->64 s2 @384x288 x80: {t:7.1f} us  {(clip.numel() * 4 + 80 * 64 * 192 * 144 * 2) / t / 1e6:5.2f} TB/s", flush=True)
+    if what == "enc":                                # the encoders' matrix kernels: split products against half operands
+        for C, T in ((136, 6912), (204, 6912)):
+            B, HID = 16, 4 * C
+            g = torch.Generator().manual_seed(5)
+            x = torch.randn(B, C, T, generator=g).cuda()
+            w1, w2 = (torch.randn(HID, C, 1, generator=g) / C ** 0.5).cuda(), (torch.randn(C, HID, 1, generator=g) / HID ** 0.5).cuda()
+            b1, one, zero = torch.zeros(HID, device="cuda"), torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
+            out = torch.empty_like(x)
+            for half in (False, True):
+                pk = ops.pack_mlp_x3_weights(w1, b1, w2, half=half)
+                t = ev(lambda: ops.ln_mlp_x3(x, one, zero, 1e-5, pk, one, zero, out=out, half=half))
+                print(f"ln_mlp C={C} half={int(half)}: {t:7.1f} us", flush=True)
+            wq = (torch.randn(C, C, generator=g) / C ** 0.5).cuda()
+            pkd = ops.pack_dense_cc(wq, one, zero, x3=True)
+            for half in (False, True):
+                t = ev(lambda: ops.dense_cc([x], [pkd], [x], outs=[out], x3=True, half=half))
+                print(f"dense  C={C} half={int(half)}: {t:7.1f} us", flush=True)
+            dws = [(torch.randn(C, 1, 3, generator=g) * 0.5).cuda() for _ in range(3)]
+            table = ops.pack_qkv_table(dws[0], dws[1], dws[2], one, zero, one, zero, one, zero)
+            outs = [torch.empty_like(x) for _ in range(3)]
+            for half in (False, True):
+                t = ev(lambda: ops.qkv_front(x, table, [pkd, pkd, pkd], outs=outs, x3=True, half=half))
+                print(f"qkv    C={C} half={int(half)}: {t:7.1f} us", flush=True)
     if what == "fwd16":                              # one model only (profiling): cfg2 or cfg5 in fp16
         which = sys.argv[2] if len(sys.argv) > 2 else "cfg2"
         if which == "cfg5":
