@@ -482,8 +482,38 @@ def train_step_probe(cfg, dev, batch, dtype="bf16", steps=3, dist=None):
                                 "hipGraph replays no faster than the one-stream eager step: profiles/r04_train_graph_probe.txt) - "
                                 "~200 ms of kernel time on four streams, the bf16 conv kernel bound by the latency of its "
                                 "staging, not by the matrix pipe (DESIGN.md sections 3.6 and 5)"}}
+    # the exchange's own wall time (an extra, untimed step with the collective bracketed by device synchronisations): what a scaling
+    # run loses between the last backward kernel and the optimizer - so that a SCALE line can attribute its lost efficiency
+    stats = {}
+    PAR.train_step_dp(model, opt, x, margin, g, wt, stats=stats)
+    res["comm_ms"], res["comm_bytes"], res["comm_overlap"] = stats.get("comm_ms"), stats.get("comm_bytes"), stats.get("overlap")
     del model, opt, loss
     torch.cuda.empty_cache()
+    if world == 1 and dtype == "bf16" and os.environ.get("OTPOSE_BENCH_TRAIN_CHECKS", "1") != "0":
+        # cfg3 at FULL size is more than `loss_finite`: the step from seeded weights twice - same loss and same
+        # updated weights to the last bit (every order-dependent sum of the step is fixed-order or integer: DESIGN.md section 4) -
+        # and once in fp32 on the same clips and dropout masks: the bf16 loss against the fp32 loss of the same HIP graph
+        def one_step(dt):
+            m = OTPose(cfg)
+            S.fill_synthetic_(m)
+            m = m.to(dev).train()
+            m.train_dtype = dt
+            o = FusedAdamW([p for p in m.parameters() if p.requires_grad], lr=1e-4, weight_decay=0.01, max_grad_norm=1.0)
+            torch.manual_seed(4242)
+            torch.cuda.manual_seed(4242)                        # the dropout / drop-path masks of the step
+            l = float(PAR.train_step_dp(m, o, x, margin, g, wt))
+            torch.cuda.synchronize(dev)
+            wsum = float(sum(p.detach().double().sum() for p in m.parameters()))
+            wabs = float(sum(p.detach().double().abs().sum() for p in m.parameters()))
+            del m, o
+            torch.cuda.empty_cache()
+            return l, wsum, wabs
+        a1, b1, c1 = one_step("bf16")
+        a2, b2, c2 = one_step("bf16")
+        a3, _, _ = one_step("f32")
+        res["full_size_checks"] = {"what": "batch %d x 5 x 384x288, one step from the seeded weights, dropout seeds fixed" % batch,
+                                   "loss_bf16": a1, "loss_bf16_again": a2, "bit_reproducible": a1 == a2 and b1 == b2 and c1 == c2,
+                                   "loss_fp32_same_graph": a3, "loss_rel_diff_bf16_vs_fp32": abs(a1 - a3) / max(abs(a3), 1e-30)}
     return res
 
 

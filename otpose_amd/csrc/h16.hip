@@ -58,6 +58,12 @@ __device__ __forceinline__ u32x4 hpack8(const float (&v)[8]) {
     for (int i = 0; i < 4; ++i) h[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){v[2 * i], v[2 * i + 1]}, h16x2));
     return (u32x4){h[0], h[1], h[2], h[3]};
 }
+// max(x, 0) as ONE instruction: fmaxf / fmed3f lower to v_max_f32 x, x (the IEEE quieting of a signalling NaN) + v_max_f32 x, 0
+__device__ __forceinline__ float hrelu(float x) {
+    float y;
+    asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
+    return y;
+}
 __device__ __forceinline__ f32x2 hwiden(uint32_t pair) { return __builtin_convertvector(__builtin_bit_cast(h16x2, pair), f32x2); }
 
 // Output-channel row of an MFMA tile <-> channel (the convention of csrc/convs.hip): cout tiles go in pairs (2 tp, 2 tp + 1) whose
@@ -120,8 +126,11 @@ struct HPlan {
 // workgroups, and every stage costs them LDS).  So the WINDOW of CK = 48 .. 96 channels is staged at once - one round trip per CK
 // channels instead of one per 16 - and only the weights (L2-resident, 13.5 KB per 16 channels) stream: the next chunk's
 // weights are loaded into registers under the current chunk's MFMAs and written to the LDS behind them.
+#ifndef OTP_H16_MINWG
+#define OTP_H16_MINWG 3                   /* development A/B (tools/lib_variant.sh): waves per SIMD the register budget is cut for */
+#endif
 template <int NTW, int NPT, int STRIDE>
-__global__ __launch_bounds__(256, STRIDE == 1 ? 3 : 2) void h16_conv3x3_kernel(const unsigned char* __restrict__ xs,
+__global__ __launch_bounds__(256, STRIDE == 1 ? OTP_H16_MINWG : 2) void h16_conv3x3_kernel(const unsigned char* __restrict__ xs,
                                                                                 const unsigned char* __restrict__ wpk,
                                                                                 const float* __restrict__ shift,
                                                                                 const unsigned char* res, unsigned char* out,
@@ -175,14 +184,16 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? 3 : 2) void h16_conv3x3_kernel(c
 
     // the window of window-stage sc: planes of channels CK sc .. CK sc + CK - 1
     auto stage_window = [&](int sc) __attribute__((always_inline)) {
-        for (int pl = 0; pl < NPL; ++pl) {
-            const int so = (sc * NPL + pl) * P.HW * 16;
+        const int so0 = sc * NPL * P.HW * 16, dso = P.HW * 16;
 #pragma unroll
-            for (int j = 0; j < MAXJ; ++j) {
-                const int k = wave + 4 * j;
-                if (k < P.NIW && vlive[j])                           // (a plane's last piece is partial: lanes past it write nothing)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(smem + pl * PL + k * 1024), 16,
-                                                             voff[j], so, 0, 0);
+        for (int j = 0; j < MAXJ; ++j) {
+            const int k = wave + 4 * j;
+            // (piece outermost: its lane mask - a plane's last piece is partial, lanes past it write nothing - is set once for all the
+            //  planes; inside, a plane costs two scalar adds and the DMA instruction)
+            if (k < P.NIW && vlive[j]) {
+                int so = so0, ld = k * 1024;
+                for (int pl = 0; pl < NPL; ++pl, so += dso, ld += PL)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(smem + ld), 16, voff[j], so, 0, 0);
             }
         }
     };
@@ -361,7 +372,7 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? 3 : 2) void h16_conv3x3_kernel(c
             for (int e = 0; e < 8; ++e) bad |= otp_out_of_range(f[e]);
             if (P.act == OTP_ACT_RELU) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
+                for (int e = 0; e < 8; ++e) f[e] = hrelu(f[e]);
             }
             const u32x4 rec = hpack8(f);
             if (paired) {

@@ -834,6 +834,8 @@ extern "C" int otp_dwconv_ln3(const void* x, const void* dwq, const void* dwk, c
         hipLaunchKernelGGL(dwconv_ln3_kernel<5>, dim3(otp_ceil_div(To, 64), B), dim3(256), 0, st, OTP_DW_ARGS);
     else if (C <= 4 * 34)
         hipLaunchKernelGGL(dwconv_ln3_kernel<34>, dim3(otp_ceil_div(To, 64), B), dim3(256), 0, st, OTP_DW_ARGS);
+    else if (C <= 4 * 51)                                          // C = 204: the 7-frame window (the generic kernel took 370-450 us)
+        hipLaunchKernelGGL(dwconv_ln3_kernel<51>, dim3(otp_ceil_div(To, 64), B), dim3(256), 0, st, OTP_DW_ARGS);
     else
         hipLaunchKernelGGL(dwconv_ln3_generic_kernel, dim3(otp_ceil_div(To, 256), B), dim3(256), 0, st, OTP_DW_ARGS);
 #undef OTP_DW_ARGS

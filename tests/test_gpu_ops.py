@@ -634,3 +634,20 @@ def test_conv2d_winograd_matches_conv2d(case):
     ops.conv2d_wino_launch(iv, ops.pack_wino_weight(wt.cuda()), sc.cuda(), sh.cuda(), ov, d, rv)
     _close(bo[:, 1:1 + cout], ref + res)
     assert float((bo[:, 0] - 7).abs().max()) == 0 and float((bo[:, 1 + cout:] - 7).abs().max()) == 0
+
+
+@pytest.mark.parametrize("C,stride", [(204, 2), (204, 1), (136, 2), (17, 2)])
+def test_dwconv_ln3_every_width_and_stride_matches_float64(C, stride):
+    """Depthwise k = 3 convs + channel LayerNorms of MaskedMHCA (model/blocks.py:359-381, 406-416) at the widths the engine launches
+    them with: C = 204 (the 7-frame window's stride-2 blocks) runs on the wave-split kernel since round 5, not the generic one."""
+    B, T, eps = 2, 250, 1e-5
+    x = seeded((B, C, T), 91)
+    dws = [seeded((C, 1, 3), 92 + i) * 0.6 for i in range(3)]
+    gs = [1.0 + 0.3 * seeded((C,), 95 + i) for i in range(3)]
+    bs = [0.2 * seeded((C,), 98 + i) for i in range(3)]
+    outs = ops.dwconv_ln3(x.cuda(), [t.cuda().contiguous() for t in dws], [t.cuda() for t in gs], [t.cuda() for t in bs], stride, eps)
+    for i in range(3):
+        d = F.conv1d(x.double(), dws[i].double(), None, stride, 1, 1, C)
+        r = d - d.mean(1, keepdim=True)
+        ref = r / torch.sqrt((r * r).mean(1, keepdim=True) + eps) * gs[i].double()[None, :, None] + bs[i].double()[None, :, None]
+        _close(outs[i], ref.float(), 3e-6)
