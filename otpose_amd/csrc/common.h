@@ -114,6 +114,13 @@ __device__ __forceinline__ bool otp_out_of_range(float v) { return !(__builtin_f
 __device__ __forceinline__ void otp_range_report(unsigned* word, bool bad, unsigned code) {
     if (bad && word) __hip_atomic_store(word, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// max(x, 0) as ONE instruction.  fmaxf lowers to v_max_f32 x, x (the IEEE quieting of a signalling NaN) + v_max_f32 x, 0: two vector
+// instructions per value in epilogues that are bound by vector issue (48 values per lane and tile in the conv kernels).
+__device__ __forceinline__ float otp_relu(float x) {
+    float y;
+    asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
+    return y;
+}
 // 16-byte buffer load: offsets at or past the descriptor's size return zeros (hardware range check)
 __device__ __forceinline__ otp_f32x4 bload4(otp_rsrc r, int voff_bytes) {
     return __builtin_bit_cast(otp_f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff_bytes, 0, 0));

@@ -655,7 +655,7 @@ __global__ __launch_bounds__(256, NCHW ? 2 : 3) void convs_kernel(const unsigned
 #pragma unroll
             for (int p = 0; p < NPT; ++p)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[t][p][r] = fmaxf(acc[t][p][r], 0.f);
+                for (int r = 0; r < 4; ++r) acc[t][p][r] = otp_relu(acc[t][p][r]);
     }
     // S8 records straight from the accumulators: a lane's registers of a tile PAIR are 8 consecutive channels of its pixel
     // (srow2ch) - split, one hi and one lo record per (pair, pixel tile); a tile without a partner gives 4 consecutive channels

@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void convs2_kernel(const unsigned char* __r
 #pragma unroll
                 for (int p = 0; p < NPT; ++p)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[t][p][r] = fmaxf(acc[t][p][r], 0.f);
+                    for (int r = 0; r < 4; ++r) acc[t][p][r] = otp_relu(acc[t][p][r]);
         }
         u32x4 rec[(NTW + 1) / 2][NPT][2];
 #pragma unroll

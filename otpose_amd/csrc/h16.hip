@@ -58,12 +58,6 @@ __device__ __forceinline__ u32x4 hpack8(const float (&v)[8]) {
     for (int i = 0; i < 4; ++i) h[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){v[2 * i], v[2 * i + 1]}, h16x2));
     return (u32x4){h[0], h[1], h[2], h[3]};
 }
-// max(x, 0) as ONE instruction: fmaxf / fmed3f lower to v_max_f32 x, x (the IEEE quieting of a signalling NaN) + v_max_f32 x, 0
-__device__ __forceinline__ float hrelu(float x) {
-    float y;
-    asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
-    return y;
-}
 __device__ __forceinline__ f32x2 hwiden(uint32_t pair) { return __builtin_convertvector(__builtin_bit_cast(h16x2, pair), f32x2); }
 
 // Output-channel row of an MFMA tile <-> channel (the convention of csrc/convs.hip): cout tiles go in pairs (2 tp, 2 tp + 1) whose
@@ -372,7 +366,7 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? OTP_H16_MINWG : 2) void h16_conv
             for (int e = 0; e < 8; ++e) bad |= otp_out_of_range(f[e]);
             if (P.act == OTP_ACT_RELU) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) f[e] = hrelu(f[e]);
+                for (int e = 0; e < 8; ++e) f[e] = otp_relu(f[e]);
             }
             const u32x4 rec = hpack8(f);
             if (paired) {
