@@ -393,8 +393,12 @@ __global__ __launch_bounds__(BWD_THREADS, 1) void mdcn_bwd_kernel(
     }
     gomax = wave_max(gomax);
     mmax = wave_max(mmax);
-    if (lane == 0) { red[wave] = gomax; red[BWD_WAVES + wave] = mmax; }
-    const int nonfinite = __syncthreads_or(nfl);     // (uniform; also the barrier in front of the reads of `red`)
+    nfl = __any(nfl);                                                          // (per wave)
+    if (lane == 0) { red[wave] = gomax; red[BWD_WAVES + wave] = mmax; red[2 * BWD_WAVES + wave] = nfl ? 1.f : 0.f; }
+    __syncthreads();
+    bool nonfinite = false;                          // (uniform)
+#pragma unroll
+    for (int i = 0; i < BWD_WAVES; ++i) nonfinite |= red[2 * BWD_WAVES + i] != 0.f;
 #pragma unroll
     for (int i = 0; i < BWD_WAVES; ++i) { gomax = fmaxf(gomax, red[i]); mmax = fmaxf(mmax, red[BWD_WAVES + i]); }
 
