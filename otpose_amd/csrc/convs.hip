@@ -42,6 +42,9 @@ constexpr int SKS = 5;                    // k-steps per chunk: 18 (tap, group) 
 constexpr int SOOB = -16;                 // buffer offset outside every descriptor: the load returns / writes zeros
 
 __device__ __forceinline__ uint32_t sdiv(uint32_t i, uint32_t magic) { return magic ? __umulhi(i, magic) : i; }
+// a * b of the per-lane index arithmetic, both operands below 2^24 (convs_plan checks): v_mul_u32_u24 issues at full rate,
+// v_mul_lo_u32 at a quarter of it
+__device__ __forceinline__ int smul(int a, int b) { return (int)__umul24((unsigned)a, (unsigned)b); }
 uint32_t smagic(uint32_t d) { return d <= 1 ? 0u : (uint32_t)((1ull << 32) / d) + 1u; }   // exact while i * d < 2^32
 
 #ifdef OTP_CONVS_TIMING
@@ -425,11 +428,11 @@ __global__ __launch_bounds__(256, NCHW ? 2 : 3) void convs_kernel(const unsigned
     for (int j = 0; j < 2; ++j) {
         vlive[j] = 64 * (wave + 4 * j) + lane < P.NV;
         const int v = 64 * (wave + 4 * j) + lane + x0;
-        const int r = (int)sdiv((uint32_t)v, P.mW1), cp = v - r * P.W1;
+        const int r = (int)sdiv((uint32_t)v, P.mW1), cp = v - smul(r, P.W1);
         const int V = Vf + r;
-        const int n = (int)sdiv((uint32_t)V, P.mVR), yy = V - n * P.VR;
+        const int n = (int)sdiv((uint32_t)V, P.mVR), yy = V - smul(n, P.VR);
         const bool ok = cp >= 1 && yy >= 1 && n < P.N;
-        voff[j] = ok ? (n - n0) * imgB + ((yy - 1) * P.W + cp - 1) * 16 : SOOB;
+        voff[j] = ok ? (n - n0) * imgB + (smul(yy - 1, P.W) + cp - 1) * 16 : SOOB;
     }
     const size_t left = (size_t)(P.N - n0) * imgB;
     const otp_rsrc rin = make_rsrc32(xs + (size_t)n0 * imgB, left > 0x7fffff00ull ? 0x7fffff00u : (unsigned)left);
@@ -493,15 +496,15 @@ __global__ __launch_bounds__(256, NCHW ? 2 : 3) void convs_kernel(const unsigned
             const bool pv = P0 + m < P.total;
             if (!pv) m = P.total - 1 - P0;                         // tail tile: a finite address, the result is dropped
             const int q = p0 + m;
-            const int dn = (int)sdiv((uint32_t)q, P.mHW), pi = q - dn * P.HW;
-            const int y = (int)sdiv((uint32_t)pi, P.mW), x = pi - y * P.W;
-            pb[p] = (((n0 + dn) * P.VR + y - Vf) * P.W1 + x) * 16;   // record of tap (0, 0): one row up, one column left (+ x0)
+            const int dn = (int)sdiv((uint32_t)q, P.mHW), pi = q - smul(dn, P.HW);
+            const int y = (int)sdiv((uint32_t)pi, P.mW), x = pi - smul(y, P.W);
+            pb[p] = (smul(smul(n0 + dn, P.VR) + y - Vf, P.W1) + x) * 16;   // record of tap (0, 0): one row up, one column left (+ x0)
             const int img = n0 + dn;
             // pixel part of the byte offsets; the channel part (ch0[t]) is added where it is used
             //   C4 image   ((img C4o + ch / 4) HW + pi) 16          NCHW slice ((img ctot + coff + ch) HW + pi) 4
             //   S8 image   (((img Go + ch / 8) 2 + part) HW + pi) 16
-            const int c4o = (img * C4o * P.HW + pi) * 16;
-            if (NCHW) offN[NCHW ? p : 0] = pv ? ((img * P.out_ctot + P.out_coff) * P.HW + pi) * 4 : SOOB;
+            const int c4o = (smul(smul(img, C4o), P.HW) + pi) * 16;
+            if (NCHW) offN[NCHW ? p : 0] = pv ? (smul(smul(img, P.out_ctot) + P.out_coff, P.HW) + pi) * 4 : SOOB;
             offS[p] = pv ? c4o : SOOB;
             // residual (C4 image; out-of-range offsets read zeros) + shift
             if (!P.res_s8) {
@@ -509,7 +512,7 @@ __global__ __launch_bounds__(256, NCHW ? 2 : 3) void convs_kernel(const unsigned
                 for (int t = 0; t < NTW; ++t) {
                     const bool tv = co_blk + 16 * t < P.Cout;
                     acc[t][p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                        rres, (pv && tv) ? c4o + (ch0[t] >> 2) * P.HW * 16 : SOOB, 0, 0));
+                        rres, (pv && tv) ? c4o + smul(ch0[t] >> 2, P.HW) * 16 : SOOB, 0, 0));
                 }
             }
         }
@@ -527,7 +530,7 @@ __global__ __launch_bounds__(256, NCHW ? 2 : 3) void convs_kernel(const unsigned
 #pragma unroll
             for (int t = 0; t < NTW; t += 2) {
                 const bool tav = co_blk + 16 * t < P.Cout;
-                const int so = (ch0[t] >> 3) * 2 * P.HW * 16;
+                const int so = smul(ch0[t] >> 3, P.HW) * 32;
                 if (stile_paired(co_blk, t, NTW, P.Cout)) {          // (uniform)
 #pragma unroll
                     for (int p = 0; p < NPT; ++p) {
@@ -683,7 +686,7 @@ __global__ __launch_bounds__(256, NCHW ? 2 : 3) void convs_kernel(const unsigned
 #pragma unroll
             for (int p = 0; p < NPT; ++p)
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[t][p]), rof,
-                                                       (co_blk + 16 * t < P.Cout && offS[p] != SOOB) ? offS[p] + (ch0[t] >> 2) * P.HW * 16 : SOOB,
+                                                       (co_blk + 16 * t < P.Cout && offS[p] != SOOB) ? offS[p] + smul(ch0[t] >> 2, P.HW) * 16 : SOOB,
                                                        0, 0);
     } else if (NCHW) {
         // channel slice of an NCHW tensor (the tensor a fuse layer / another kernel family reads).  Straight from the accumulators
@@ -705,20 +708,20 @@ __global__ __launch_bounds__(256, NCHW ? 2 : 3) void convs_kernel(const unsigned
         const int g = tid % G, c0 = tid / G;
         const bool gv = P0 + 4 * g < P.total;                        // (a group of 4 stays inside one image: H W % 4 == 0)
         const int q = gv ? p0 + 4 * g : p0;                          // relative to image n0, like the pixel tiles above
-        const int qn = (int)sdiv((uint32_t)q, P.mHW), qi = q - qn * P.HW;
-        const int ob = gv ? (((n0 + qn) * P.out_ctot + P.out_coff + co_blk) * P.HW + qi) * 4 : SOOB;
+        const int qn = (int)sdiv((uint32_t)q, P.mHW), qi = q - smul(qn, P.HW);
+        const int ob = gv ? (smul(smul(n0 + qn, P.out_ctot) + P.out_coff + co_blk, P.HW) + qi) * 4 : SOOB;
 #pragma unroll
         for (int k = 0; k < NTW * 16 / CPI; ++k) {
             const int ch = c0 + CPI * k;
             const u32x4 v = *reinterpret_cast<const u32x4*>(tl + ch * RS + 4 * g);
-            __builtin_amdgcn_raw_buffer_store_b128(v, rof, (ob != SOOB && co_blk + ch < P.Cout) ? ob + ch * P.HW * 4 : SOOB, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rof, (ob != SOOB && co_blk + ch < P.Cout) ? ob + smul(ch, P.HW) * 4 : SOOB, 0, 0);
         }
     }
     if (outs) {
 #pragma unroll
         for (int t = 0; t < NTW; t += 2) {
             const bool tav = co_blk + 16 * t < P.Cout;
-            const int so = (ch0[t] >> 3) * 2 * P.HW * 16;           // record group of the lane's channels, part 0
+            const int so = smul(ch0[t] >> 3, P.HW) * 32;           // record group of the lane's channels, part 0
             if (stile_paired(co_blk, t, NTW, P.Cout)) {
 #pragma unroll
                 for (int p = 0; p < NPT; ++p) {
@@ -798,6 +801,8 @@ bool convs_plan(const otp_conv_desc& d, SPlan& P) {
     if ((long)(d.N + 1) * P.VR * P.VR >= (1l << 32)) return false;
     if ((long)d.Cin * P.HW * 4 * 8 >= (1l << 31)) return false;    // a tile spans < 8 images: per-lane offsets stay 31-bit
     if (P.HW < 32) return false;
+    // operands of the kernel's 24-bit index multiplies (smul)
+    if (P.HW >= (1 << 24) || (long)(d.N + 8) * P.VR >= (1l << 24) || (long)(d.N + 8) * (d.Cout / 4 + d.out_ctot) + d.out_coff >= (1l << 24)) return false;
     if ((size_t)P.nN * P.nChunks * swch(P.NTW) * 1024 >= (1ull << 31)) return false;
     return true;
 }

@@ -18,18 +18,30 @@
 // a 1x1 conv loads its operand fragments straight from global memory.  (gtot, goff): a tensor may be a range of channel groups
 // of a wider H8 tensor - channel concatenations cost nothing.
 #include "common.h"
+#include "hb.h"
 #include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
 
 namespace {
 
+// csrc/hb.hip compiles this file a second time with OTP_H16_BF16: the 3x3 kernel on bfloat16 NHWC tensors for the training step's
+// forward / input-gradient convolutions (csrc/nhwc.hip dispatches to it) - same window, weight stream and MFMA schedule, the
+// records' addresses generalised to (pixel stride, group stride), per-tile channel statistics instead of the folded BatchNorm.
+#ifdef OTP_H16_BF16
+typedef __bf16 h16;
+#define H_MFMA __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#else
 typedef _Float16 h16;
+#define H_MFMA __builtin_amdgcn_mfma_f32_16x16x32_f16
+#endif
 typedef h16 h16x8 __attribute__((ext_vector_type(8)));
 typedef h16 h16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-#define H_MFMA __builtin_amdgcn_mfma_f32_16x16x32_f16
 
 #ifdef OTP_H16_TIMING
 // development build only (tools/h16_timing.sh): per-workgroup phase stamps, never in libotpose_hip.so
@@ -42,34 +54,58 @@ __device__ unsigned long long otp_h16_stamps[8192 * 32];
 #define HSTAMP(slot)
 #endif
 
-constexpr int HKS = 5;                    // k-steps per 16-channel chunk: 18 (tap, group) slots of 8 channels in 5 x 4 (2 empty)
+constexpr int HKS = OTP_HB_KS;            // k-steps per 16-channel chunk: 18 (tap, group) slots of 8 channels in 5 x 4 (2 empty)
 constexpr int HOOB = -16;                 // buffer offset outside every descriptor: loads return / the LDS-DMA writes zeros
 // packed weights of a (cout block, 16-channel chunk): 4 full k-steps x NTW tiles x 1 KB, then the half-filled fifth (k-slots 16, 17
 // on lanes 0 .. 31: 512 bytes per tile)
-__host__ __device__ constexpr int hwb(int ntw) { return ntw * 4608; }
+__host__ __device__ constexpr int hwb(int ntw) { return otp_hb_wb(ntw); }
 __host__ __device__ constexpr int hwp(int ntw) { return (hwb(ntw) + 1023) / 1024; }     // 1 KB pieces (the last may be half)
+// bf16 (training) build: the four waves' partial channel sums behind the weight image
+#ifdef OTP_H16_BF16
+__host__ __device__ constexpr int hsred(int ntw) { return 4 * 2 * ntw * 16 * 4; }
+#else
+__host__ __device__ constexpr int hsred(int) { return 0; }
+#endif
 
 __device__ __forceinline__ uint32_t hdiv(uint32_t i, uint32_t magic) { return magic ? __umulhi(i, magic) : i; }
+// a * b for per-lane index arithmetic whose operands stay below 2^24 (checked by the plan): v_mul_u32_u24 runs at full rate,
+// v_mul_lo_u32 at a quarter - 40 of them sat in the set-up of every tile
+__device__ __forceinline__ int hmul(int a, int b) { return (int)__umul24((unsigned)a, (unsigned)b); }
 uint32_t hmagic(uint32_t d) { return d <= 1 ? 0u : (uint32_t)((1ull << 32) / d) + 1u; }   // exact while i * d < 2^32
 
 __device__ __forceinline__ u32x4 hpack8(const float (&v)[8]) {
     uint32_t h[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) h[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){v[2 * i], v[2 * i + 1]}, h16x2));
+    for (int i = 0; i < 4; ++i) h[i] = __builtin_bit_cast(uint32_t, (h16x2){(h16)v[2 * i], (h16)v[2 * i + 1]});
     return (u32x4){h[0], h[1], h[2], h[3]};
 }
+#ifdef OTP_H16_BF16
+__device__ __forceinline__ f32x2 hwiden(uint32_t pair) {
+    return (f32x2){__builtin_bit_cast(float, pair << 16), __builtin_bit_cast(float, pair & 0xffff0000u)};
+}
+#else
 __device__ __forceinline__ f32x2 hwiden(uint32_t pair) { return __builtin_convertvector(__builtin_bit_cast(h16x2, pair), f32x2); }
+#endif
+
+// sum over the 16 lanes of a DPP row (one MFMA pixel column group), every lane ends with the total (csrc/nhwc.hip: row16_sum)
+template <int CTRL>
+__device__ __forceinline__ float hdpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float hrow16_sum(float v) {
+    v += hdpp<0xB1>(v);           // quad_perm [1,0,3,2]
+    v += hdpp<0x4E>(v);           // quad_perm [2,3,0,1]
+    v += hdpp<0x124>(v);          // row_ror:4
+    v += hdpp<0x128>(v);          // row_ror:8
+    return v;
+}
 
 // Output-channel row of an MFMA tile <-> channel (the convention of csrc/convs.hip): cout tiles go in pairs (2 tp, 2 tp + 1) whose
 // rows are permuted so that lane (pixel, kl) ends up with 8 CONSECUTIVE channels 32 tp + 8 kl .. + 7 of its pixel = one H8 record;
 // a tile without a partner keeps the identity (4 consecutive channels per lane = half a record).
-__host__ __device__ inline bool hpaired(int co_blk, int t, int ntw, int Cout) {
-    const int tb = t | 1;
-    return tb < ntw && co_blk + 16 * tb < Cout;
-}
-__host__ __device__ inline int hrow2ch(int co_blk, int t, int row, int ntw, int Cout) {
-    return hpaired(co_blk, t, ntw, Cout) ? co_blk + 32 * (t >> 1) + 8 * (row >> 2) + 4 * (t & 1) + (row & 3) : co_blk + 16 * t + row;
-}
+// (the definitions live in csrc/hb.h: the bf16 build's weight packer is csrc/nhwc.hip's)
+__host__ __device__ inline bool hpaired(int co_blk, int t, int ntw, int Cout) { return otp_hb_paired(co_blk, t, ntw, Cout); }
+__host__ __device__ inline int hrow2ch(int co_blk, int t, int row, int ntw, int Cout) { return otp_hb_row2ch(co_blk, t, row, ntw, Cout); }
 
 // instruction order of one (k-step, pixel tile) block: NM MFMAs and NR LDS reads interleaved (csrc/convs.hip: sblock_sched)
 template <int NM, int NR>
@@ -100,7 +136,12 @@ __device__ __forceinline__ void hblock_sched() {
 // ================================================================================================================================
 struct HPlan {
     int N, C, H, W, HW, Ho, Wo, HWo, Cout, total;      // total = N * Ho * Wo output pixels
-    int in_gtot, in_goff, out_gtot, out_goff, res_gtot, res_goff, act;
+    int act;
+    // where records live, in bytes: record (image n, channel group g, pixel p) of a tensor is at base + n imgB + g gS + p pS.
+    // H8: pS = 16, gS = 16 HW, imgB = 16 gtot HW, base = 16 goff HW.  NHWC with CS channels: pS = 2 CS, gS = 16, imgB = 2 CS HW
+    int in_pS, in_gS, in_imgB, out_pS, out_gS, out_imgB, res_pS, res_gS, res_imgB;
+    size_t in_base, out_base, res_base;
+    float* stats;                                      // bf16 build: per-tile channel sums [nTiles][2][Cout] of the stored values, or NULL
     float pre, post;                                   // weights carry 2^k = pre; the sum is multiplied by post = 2^-k
     int NTW, nN, nTiles, nChunks, tpx, NPT;
     int CK;                                            // input channels per WINDOW stage (a multiple of 16 that divides Cin)
@@ -152,7 +193,7 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? OTP_H16_MINWG : 2) void h16_conv
     const int y0 = (int)hdiv((uint32_t)p0, P.mWo);
     const int x0 = STRIDE == 1 ? p0 - y0 * P.Wo : 0;               // stride 1: the window starts at record x0 of its first row
     const int Vf = n0 * P.VR + STRIDE * y0;                        // first virtual row of the window
-    const int imgB = P.in_gtot * P.HW * 16;                        // bytes of one image of the input tensor
+    const int imgB = P.in_imgB;                                    // bytes of one image of the input tensor
     const int co_blk = cb * NTW * 16;
 
     // ---- window pieces of this wave: piece k = wave + 4 j covers window records 64 k .. 64 k + 63 of every plane ----------------
@@ -164,21 +205,20 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? OTP_H16_MINWG : 2) void h16_conv
         const int v = 64 * (wave + 4 * j) + lane;
         vlive[j] = v < P.NV;
         const int vv = v + x0;
-        const int r = (int)hdiv((uint32_t)vv, P.mW1), i = vv - r * P.W1;
+        const int r = (int)hdiv((uint32_t)vv, P.mW1), i = vv - hmul(r, P.W1);
         const int V = Vf + r;
-        const int n = (int)hdiv((uint32_t)V, P.mVR), yy = V - n * P.VR;
+        const int n = (int)hdiv((uint32_t)V, P.mVR), yy = V - hmul(n, P.VR);
         const int col = STRIDE == 1 ? i - 1 : (i <= P.Wo ? 2 * (i - 1) + 1 : 2 * (i - P.Wo - 1));   // stride 2: odd columns, then even
         const bool ok = i >= 1 && yy >= 1 && n < P.N;
-        voff[j] = ok ? (n - n0) * imgB + ((yy - 1) * P.W + col) * 16 : HOOB;
+        voff[j] = ok ? (n - n0) * imgB + hmul(hmul(yy - 1, P.W) + col, P.in_pS) : HOOB;    // (imgB may pass 2^24: a full multiply)
     }
-    const size_t left = (size_t)(P.N - n0) * imgB - (size_t)P.in_goff * P.HW * 16;
-    const otp_rsrc rin = make_rsrc32(xs + (size_t)n0 * imgB + (size_t)P.in_goff * P.HW * 16,
-                                     left > 0x7fffff00ull ? 0x7fffff00u : (unsigned)left);
+    const size_t left = (size_t)(P.N - n0) * imgB - P.in_base;
+    const otp_rsrc rin = make_rsrc32(xs + (size_t)n0 * imgB + P.in_base, left > 0x7fffff00ull ? 0x7fffff00u : (unsigned)left);
     const otp_rsrc rw = make_rsrc32(wpk, (unsigned)((size_t)P.nN * P.nChunks * WB));
 
     // the window of window-stage sc: planes of channels CK sc .. CK sc + CK - 1
     auto stage_window = [&](int sc) __attribute__((always_inline)) {
-        const int so0 = sc * NPL * P.HW * 16, dso = P.HW * 16;
+        const int so0 = sc * NPL * P.in_gS, dso = P.in_gS;
 #pragma unroll
         for (int j = 0; j < MAXJ; ++j) {
             const int k = wave + 4 * j;
@@ -210,10 +250,9 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? OTP_H16_MINWG : 2) void h16_conv
     HSTAMP(1);
 
     // ---- per pixel tile: fragment address, lane offsets into the output / residual images --------------------------------------
-    const unsigned obytes = (unsigned)((size_t)P.N * P.out_gtot * P.HWo * 16 - (size_t)P.out_goff * P.HWo * 16);
-    const otp_rsrc ro = make_rsrc32(out + (size_t)P.out_goff * P.HWo * 16, obytes);
-    const otp_rsrc rr = make_rsrc32(res ? res + (size_t)P.res_goff * P.HWo * 16 : xs,
-                                    res ? (unsigned)((size_t)P.N * P.res_gtot * P.HWo * 16 - (size_t)P.res_goff * P.HWo * 16) : 0u);
+    const unsigned obytes = (unsigned)((size_t)P.N * P.out_imgB - P.out_base);
+    const otp_rsrc ro = make_rsrc32(out + P.out_base, obytes);
+    const otp_rsrc rr = make_rsrc32(res ? res + P.res_base : xs, res ? (unsigned)((size_t)P.N * P.res_imgB - P.res_base) : 0u);
     const otp_rsrc rsh = make_rsrc32(shift ? shift : reinterpret_cast<const float*>(xs), shift ? (unsigned)(P.Cout * 4) : 0u);
     int pb[NPT], toff[HKS], offO[NPT], offR[NPT], ch0[NTW];
     f32x4 acc[NTW][NPT];
@@ -226,7 +265,7 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? OTP_H16_MINWG : 2) void h16_conv
             const int dy = tap / 3, dx = tap - dy * 3;
             // record of the tap relative to the pixel's record of tap row dy = 0 (stride 2: parity de-interleaved virtual rows)
             const int rx = STRIDE == 1 ? dx - x0 : (dx == 0 ? 0 : (dx == 1 ? P.Wo + 1 : 1));
-            toff[s] = (dy * P.W1 + rx) * 16 + (q & 1) * PL;
+            toff[s] = (hmul(dy, P.W1) + rx) * 16 + (q & 1) * PL;
         }
         f32x4 sh[NTW];
 #pragma unroll
@@ -240,11 +279,11 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? OTP_H16_MINWG : 2) void h16_conv
             const bool pv = P0 + m < P.total;
             if (!pv) m = P.total - 1 - P0;                         // tail tile: a finite address, the result is dropped
             const int q = p0 + m;
-            const int dn = (int)hdiv((uint32_t)q, P.mHWo), pi = q - dn * P.HWo;
-            const int y = (int)hdiv((uint32_t)pi, P.mWo), x = pi - y * P.Wo;
-            pb[p] = (((n0 + dn) * P.VR + STRIDE * y - Vf) * P.W1 + x) * 16;
-            offO[p] = pv ? ((n0 + dn) * P.out_gtot * P.HWo + pi) * 16 : HOOB;
-            offR[p] = (pv && res) ? ((n0 + dn) * P.res_gtot * P.HWo + pi) * 16 : HOOB;
+            const int dn = (int)hdiv((uint32_t)q, P.mHWo), pi = q - hmul(dn, P.HWo);
+            const int y = (int)hdiv((uint32_t)pi, P.mWo), x = pi - hmul(y, P.Wo);
+            pb[p] = (hmul(hmul(n0 + dn, P.VR) + STRIDE * y - Vf, P.W1) + x) * 16;
+            offO[p] = pv ? (n0 + dn) * P.out_imgB + hmul(pi, P.out_pS) : HOOB;
+            offR[p] = (pv && res) ? (n0 + dn) * P.res_imgB + hmul(pi, P.res_pS) : HOOB;
 #pragma unroll
             for (int t = 0; t < NTW; ++t) acc[t][p] = sh[t] * P.pre;
         }
@@ -330,7 +369,7 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? OTP_H16_MINWG : 2) void h16_conv
 #pragma unroll
     for (int t = 0; t < NTW; t += 2) {
         const bool tav = ch0[t] < P.Cout;                          // (per lane: Cout % 8 == 0, a lane's record exists or does not)
-        const int go = (ch0[t] >> 3) * P.HWo * 16;
+        const int go = hmul(ch0[t] >> 3, P.res_gS);
         if (hpaired(co_blk, t, NTW, P.Cout)) {
 #pragma unroll
             for (int p = 0; p < NPT; ++p)
@@ -347,13 +386,83 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? OTP_H16_MINWG : 2) void h16_conv
         }
     }
     HSTAMP(17);
+#ifdef OTP_H16_BF16
+    // training form (csrc/nhwc.hip's contract): out = bf16(conv + bias); the per-tile channel sums / sums of squares are those of
+    // the ROUNDED values (what BatchNorm will normalise); a residual is added to the rounded result and the sum rounded again -
+    // bit for bit a separate bf16 add.  Sums: 16 lanes of a DPP row hold the 16 pixels of a tile -> row sum -> the four waves'
+    // partials through the LDS behind the weight image, added in a fixed order.
+    constexpr int CB = NTW * 16;
+    float* sred = reinterpret_cast<float*>(wl + WB);               // [4 waves][2][CB]
+#pragma unroll
+    for (int t = 0; t < NTW; t += 2) {
+        const bool paired = hpaired(co_blk, t, NTW, P.Cout);       // (uniform)
+        const int t1 = t + 1 < NTW ? t + 1 : t;
+        const bool tav = ch0[t] < P.Cout;                          // (per lane)
+        const int go = hmul(ch0[t] >> 3, P.out_gS);
+        float s1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, s2[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int p = 0; p < NPT; ++p) {
+            float f[8] = {acc[t][p][0], acc[t][p][1], acc[t][p][2], acc[t][p][3], paired ? acc[t1][p][0] : 0.f,
+                          paired ? acc[t1][p][1] : 0.f, paired ? acc[t1][p][2] : 0.f, paired ? acc[t1][p][3] : 0.f};
+            u32x4 rec = hpack8(f);
+            const bool pv = offO[p] != HOOB;
+            if (P.stats || res) {
+                const f32x2 w0 = hwiden(rec[0]), w1 = hwiden(rec[1]), w2 = hwiden(rec[2]), w3 = hwiden(rec[3]);
+                float fr[8] = {w0.x, w0.y, w1.x, w1.y, w2.x, w2.y, w3.x, w3.y};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float v = pv ? fr[e] : 0.f;
+                    s1[e] += v;
+                    s2[e] += v * v;
+                }
+                if (res) {
+                    const u32x4 rq = rres[t >> 1][p];
+                    const f32x2 r0 = hwiden(rq[0]), r1 = hwiden(rq[1]), r2 = hwiden(rq[2]), r3 = hwiden(rq[3]);
+                    float g[8] = {fr[0] + r0.x, fr[1] + r0.y, fr[2] + r1.x, fr[3] + r1.y, fr[4] + r2.x, fr[5] + r2.y, fr[6] + r3.x, fr[7] + r3.y};
+                    rec = hpack8(g);
+                }
+            }
+            if (paired) {
+                __builtin_amdgcn_raw_buffer_store_b128(rec, ro, (tav && pv) ? offO[p] + go : HOOB, 0, 0);
+            } else {
+                const int half = (ch0[t] >> 2) & 1;
+                __builtin_amdgcn_raw_buffer_store_b64((u32x2){rec[0], rec[1]}, ro, (tav && pv) ? offO[p] + go + 8 * half : HOOB, 0, 0);
+            }
+        }
+        if (P.stats) {
+            const int cl = ch0[t] - co_blk;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (e < 4 || paired) {
+                    const float a = hrow16_sum(s1[e]), b = hrow16_sum(s2[e]);
+                    if (i16 == 0) {
+                        sred[(wave * 2 + 0) * CB + cl + e] = a;
+                        sred[(wave * 2 + 1) * CB + cl + e] = b;
+                    }
+                }
+            }
+        }
+    }
+    if (P.stats) {
+        __syncthreads();
+        for (int i = tid; i < 2 * CB; i += 256) {
+            const int which = i / CB, c = i - which * CB, co = co_blk + c;
+            if (co < P.Cout) {
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) v += sred[(w * 2 + which) * CB + c];
+                P.stats[((size_t)tile * 2 + which) * P.Cout + co] = v;
+            }
+        }
+    }
+#else
     bool bad = false;
 #pragma unroll
     for (int t = 0; t < NTW; t += 2) {
         const bool paired = hpaired(co_blk, t, NTW, P.Cout);       // (uniform)
         const int t1 = t + 1 < NTW ? t + 1 : t;
         const bool tav = ch0[t] < P.Cout;                          // (per lane)
-        const int go = (ch0[t] >> 3) * P.HWo * 16;
+        const int go = hmul(ch0[t] >> 3, P.out_gS);
 #pragma unroll
         for (int p = 0; p < NPT; ++p) {
             const u32x4 rq = rres[t >> 1][p];
@@ -379,16 +488,14 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? OTP_H16_MINWG : 2) void h16_conv
         }
     }
     otp_range_report(P.rflag, bad, OTP_RANGE_H16);
+#endif
     HSTAMP(19);
 #ifdef OTP_H16_TIMING
     if (threadIdx.x == 0 && blockIdx.x < 8192) otp_h16_stamps[blockIdx.x * 32 + 31] = __builtin_amdgcn_s_memrealtime();
 #endif
 }
 
-int h16_ntw(int Cout) {
-    const int c16 = (Cout + 15) / 16;
-    return (c16 % 3 == 0) ? 3 : (c16 % 2 == 0 || c16 <= 2 ? 2 : 3);
-}
+int h16_ntw(int Cout) { return otp_hb_ntw(Cout); }
 
 int h16_window_records(const HPlan& P, int bm, int stride) {
     int NV = 0;
@@ -409,7 +516,9 @@ int h16_window_records(const HPlan& P, int bm, int stride) {
     return NV;
 }
 
-bool h16_conv_plan(const otp_h16_conv_desc& d, HPlan& P) {
+// nhwc: the tensors are NHWC with exactly Cin / Cout channels (csrc/hb.hip: HPlan's strides are those of 2-byte NHWC elements);
+// otherwise H8 images, channel-group slices from the descriptor
+bool h16_conv_plan(const otp_h16_conv_desc& d, HPlan& P, bool nhwc = false) {
     if (d.stride != 1 && d.stride != 2) return false;
     if (d.N <= 0 || d.Cin <= 0 || d.Cout <= 0 || d.H <= 0 || d.W <= 0) return false;
     if (d.Cin % 16 || d.Cout % 8 || (d.act != OTP_ACT_NONE && d.act != OTP_ACT_RELU)) return false;
@@ -417,12 +526,25 @@ bool h16_conv_plan(const otp_h16_conv_desc& d, HPlan& P) {
     const int S = d.stride, Ho = d.H / S, Wo = d.W / S;
     P.N = d.N; P.C = d.Cin; P.H = d.H; P.W = d.W; P.HW = d.H * d.W; P.Ho = Ho; P.Wo = Wo; P.HWo = Ho * Wo; P.Cout = d.Cout;
     P.total = d.N * P.HWo;
-    P.in_gtot = d.in_gtot > 0 ? d.in_gtot : d.Cin / 8; P.in_goff = d.in_gtot > 0 ? d.in_goff : 0;
-    P.out_gtot = d.out_gtot > 0 ? d.out_gtot : d.Cout / 8; P.out_goff = d.out_gtot > 0 ? d.out_goff : 0;
-    P.res_gtot = d.res_gtot > 0 ? d.res_gtot : d.Cout / 8; P.res_goff = d.res_gtot > 0 ? d.res_goff : 0;
-    if (P.in_goff < 0 || P.in_goff + d.Cin / 8 > P.in_gtot || P.out_goff < 0 || P.out_goff + d.Cout / 8 > P.out_gtot ||
-        P.res_goff < 0 || P.res_goff + d.Cout / 8 > P.res_gtot)
+    const int in_gtot = d.in_gtot > 0 ? d.in_gtot : d.Cin / 8, in_goff = d.in_gtot > 0 ? d.in_goff : 0;
+    const int out_gtot = d.out_gtot > 0 ? d.out_gtot : d.Cout / 8, out_goff = d.out_gtot > 0 ? d.out_goff : 0;
+    const int res_gtot = d.res_gtot > 0 ? d.res_gtot : d.Cout / 8, res_goff = d.res_gtot > 0 ? d.res_goff : 0;
+    if (in_goff < 0 || in_goff + d.Cin / 8 > in_gtot || out_goff < 0 || out_goff + d.Cout / 8 > out_gtot || res_goff < 0 ||
+        res_goff + d.Cout / 8 > res_gtot)
         return false;
+    if ((size_t)in_gtot * P.HW * 16 >= (1ull << 31) || (size_t)out_gtot * P.HWo * 16 >= (1ull << 31) || (size_t)res_gtot * P.HWo * 16 >= (1ull << 31))
+        return false;
+    if (nhwc) {
+        if (d.in_gtot > 0 || d.out_gtot > 0 || d.res_gtot > 0) return false;
+        P.in_pS = d.Cin * 2; P.in_gS = 16; P.in_imgB = P.HW * d.Cin * 2; P.in_base = 0;
+        P.out_pS = P.res_pS = d.Cout * 2; P.out_gS = P.res_gS = 16; P.out_imgB = P.res_imgB = P.HWo * d.Cout * 2;
+        P.out_base = P.res_base = 0;
+    } else {
+        P.in_pS = 16; P.in_gS = P.HW * 16; P.in_imgB = in_gtot * P.HW * 16; P.in_base = (size_t)in_goff * P.HW * 16;
+        P.out_pS = 16; P.out_gS = P.HWo * 16; P.out_imgB = out_gtot * P.HWo * 16; P.out_base = (size_t)out_goff * P.HWo * 16;
+        P.res_pS = 16; P.res_gS = P.HWo * 16; P.res_imgB = res_gtot * P.HWo * 16; P.res_base = (size_t)res_goff * P.HWo * 16;
+    }
+    P.stats = nullptr;
     P.act = d.act;
     P.post = d.out_scale > 0.f ? d.out_scale : 1.f;
     P.pre = 1.f / P.post;
@@ -446,7 +568,7 @@ bool h16_conv_plan(const otp_h16_conv_desc& d, HPlan& P) {
         P.nTiles = (P.total + bm - 1) / bm;
         const int NV = h16_window_records(P, bm, S);
         if (NV > maxrec) continue;
-        const size_t st = (size_t)2 * NV * 16 + hwb(P.NTW);          // the smallest stage: 16 channels
+        const size_t st = (size_t)2 * NV * 16 + hwb(P.NTW) + hsred(P.NTW);   // the smallest stage: 16 channels
         if (st > 80 * 1024) continue;
         P.NV = NV;
         found = true;
@@ -463,7 +585,7 @@ bool h16_conv_plan(const otp_h16_conv_desc& d, HPlan& P) {
     // channels per window stage: the largest multiple of 16 dividing Cin whose planes + one weight chunk let three workgroups share a
     // CU's 160 KB (two when nothing else fits) - one HBM round trip per CK channels
     {
-        const size_t wbytes = hwb(P.NTW);
+        const size_t wbytes = hwb(P.NTW) + hsred(P.NTW);
         int best = 0;
         for (size_t budget : {(size_t)(160 * 1024) / 3, (size_t)80 * 1024, (size_t)160 * 1024}) {
             for (int ck = 96; ck >= 16 && !best; ck -= 16)
@@ -483,14 +605,19 @@ bool h16_conv_plan(const otp_h16_conv_desc& d, HPlan& P) {
     // exactness of the magic divisions (numerator * divisor < 2^32) and 31-bit byte offsets
     if ((long)(P.HWo + 256) * P.HWo >= (1l << 32) || (long)P.HWo * Wo >= (1l << 32)) return false;
     if ((long)(d.N + 2) * P.VR * P.VR >= (1l << 32) || (long)(maxrec + d.W + 2) * P.W1 >= (1l << 32)) return false;
-    if ((long)P.in_gtot * P.HW * 16 * 20 >= (1l << 31)) return false;     // a tile spans few images: per-lane offsets stay 31-bit
-    if ((size_t)d.N * P.out_gtot * P.HWo * 16 >= (1ull << 31) || (size_t)d.N * P.res_gtot * P.HWo * 16 >= (1ull << 31)) return false;
+    if ((long)P.in_imgB * 20 >= (1l << 31)) return false;                 // a tile spans few images: per-lane offsets stay 31-bit
+    if ((size_t)d.N * P.out_imgB >= (1ull << 31) || (size_t)d.N * P.res_imgB >= (1ull << 31)) return false;
     if ((size_t)P.nN * P.nChunks * hwb(P.NTW) >= (1ull << 31)) return false;
     if (P.HWo < 16) return false;
+    // operands of the 24-bit multiplies of the kernel's index arithmetic (hmul)
+    if (P.HW >= (1 << 24) || (long)(d.N + 2) * P.VR >= (1l << 24) || (long)(maxrec + 2 * d.W + 8) >= (1l << 24) ||
+        (long)(d.N + 2) * P.VR * 2 + 2 * d.H >= (1l << 24) || P.in_pS >= (1 << 24) || P.out_pS >= (1 << 24) || P.in_gS >= (1 << 24) ||
+        P.out_gS >= (1 << 24) || d.Cout / 8 >= (1 << 24))
+        return false;
     // images a tile's window may touch: (n - n0) * imgB must stay below 2^31
     {
         const long span = (long)(64 * P.NPT) / P.HWo + 2;
-        if (span * P.in_gtot * P.HW * 16 >= (1l << 31)) return false;
+        if (span * P.in_imgB >= (1l << 31)) return false;
     }
     return true;
 }
@@ -498,7 +625,7 @@ bool h16_conv_plan(const otp_h16_conv_desc& d, HPlan& P) {
 template <int NTW, int NPT, int STRIDE>
 int h16_conv_launch(const void* xs, const void* wpk, const float* shift, const void* res, void* out, const HPlan& P, hipStream_t st) {
     auto kern = h16_conv3x3_kernel<NTW, NPT, STRIDE>;
-    const size_t need = (size_t)(P.CK / 8) * P.pl + hwb(NTW);
+    const size_t need = (size_t)(P.CK / 8) * P.pl + hwb(NTW) + hsred(NTW);
     OTP_ALLOW_BIG_LDS(kern, need);
     hipLaunchKernelGGL(kern, dim3(8 * P.tpx * P.nN), dim3(256), need, st, static_cast<const unsigned char*>(xs),
                        static_cast<const unsigned char*>(wpk), shift, static_cast<const unsigned char*>(res),
@@ -506,6 +633,29 @@ int h16_conv_launch(const void* xs, const void* wpk, const float* shift, const v
     return otp_launch_status();
 }
 
+int h16_conv_dispatch(const void* xs, const void* wpk, const float* fs, const void* res, void* out, const HPlan& P, int stride,
+                      hipStream_t st) {
+#define OTP_H16_GO(NTW_, NPT_, S_) return h16_conv_launch<NTW_, NPT_, S_>(xs, wpk, fs, res, out, P, st)
+#define OTP_H16_NPT(NPT_, S_)                                  \
+    if (P.NPT == NPT_) {                                       \
+        if (P.NTW == 2) OTP_H16_GO(2, NPT_, S_);               \
+        OTP_H16_GO(3, NPT_, S_);                               \
+    }
+    if (stride == 1) {
+        OTP_H16_NPT(4, 1)
+        OTP_H16_NPT(2, 1)
+        OTP_H16_NPT(1, 1)
+    } else {
+        OTP_H16_NPT(4, 2)
+        OTP_H16_NPT(2, 2)
+        OTP_H16_NPT(1, 2)
+    }
+#undef OTP_H16_NPT
+#undef OTP_H16_GO
+    return OTP_ERR_UNSUPPORTED;
+}
+
+#ifndef OTP_H16_BF16
 // packed weights: [cout block][chunk][k-step][cout tile][lane] 16-byte A fragments, lane (i16, kl): row i16 of the tile = channel
 // hrow2ch(block, tile, i16), k-slot q = 4 s + kl -> tap q / 2, input channels 16 chunk + 8 (q % 2) .. + 7; the fifth k-step holds
 // k-slots 16, 17 only (32 lanes per tile)
@@ -534,6 +684,8 @@ __global__ void h16_wpack_kernel(const float* __restrict__ w, const float* __res
     }
 }
 
+#endif  // !OTP_H16_BF16
+
 // ================================================================================================================================
 // 1x1 convolution on H8 records: out = act(W . x + shift (+ res)), H8 (+ H8 residual) -> H8, or -> a channel slice of fp32 NCHW
 // ================================================================================================================================
@@ -541,13 +693,18 @@ __global__ void h16_wpack_kernel(const float* __restrict__ w, const float* __res
 // channels as B-operand fragments - lane (pixel i16 of tile h, kq) loads record (group 4 ks + kq, pixel) straight from global
 // memory, 16 bytes, no conversion; the weights stream through the LDS in blocks of one cout-tile pair (32 output channels: 2 KS
 // KB, LDS-DMA, double buffered); a pair's two 16 x 16 results per pixel tile are 8 consecutive channels per lane = one record.
+// (csrc/hb.hip: the same kernel on bfloat16 NHWC tensors - the TransformerBlock MLP's two projections and their input gradients in
+//  the training step, reached through csrc/nhwc.hip's otp_nhwc_conv_* - with the bias as a separate fp32 vector.)
 struct HPw {
     const unsigned char* x;
     const unsigned char* packed;
     const unsigned char* res;
     unsigned char* out;
+    const float* shift;                                           // Cout floats or NULL
     int total, HW, Cin, Cout, nblk, relu, f32out;
-    int x_gtot, x_goff, r_gtot, r_goff, o_tot, o_off;             // o_tot / o_off: groups (H8 output) or channels (fp32 NCHW output)
+    // record (image n, channel group g, pixel p) of a tensor: base + n imgB + g gS + p pS bytes (see HPlan)
+    size_t x_imgB, x_gS, x_pS, x_base, r_imgB, r_gS, r_pS, r_base, o_imgB, o_gS, o_pS, o_base;
+    int o_tot, o_off;                                             // fp32 NCHW output: channels of the tensor / first channel
     float post;
     unsigned* rflag;
 };
@@ -565,20 +722,19 @@ __device__ __forceinline__ void hpw_stage(const unsigned char* __restrict__ src,
     }
 }
 
-constexpr int HPW_MAXC = 512;             // shift table: output channels
+constexpr int HPW_MAXC = 1024;            // shift table: output channels
 // KS k-steps of 32 input channels (Cin padded with zero weights and masked loads); a weight block = one tile pair x KS x 1 KB each
 // = 2 KS KB, rounded up to whole 4 KB passes of the 256 threads
-__host__ __device__ constexpr int hpw_blkb(int KS) { return ((2 * KS * 1024) + 4095) / 4096 * 4096; }
+__host__ __device__ constexpr int hpw_blkb(int KS) { return otp_hbpw_blkb(KS); }
 
 template <int KS>
 __global__ __launch_bounds__(256, KS <= 4 ? 4 : (KS <= 8 ? 3 : 2)) void h16_pointwise_kernel(HPw A) {
     constexpr int BLKB = hpw_blkb(KS);
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BLKB + HPW_MAXC * 4];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];     // 2 BLKB + HPW_MAXC * 4
     float* shl = reinterpret_cast<float*>(lds + 2 * BLKB);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kq = lane >> 4, n16 = lane & 15;
     hpw_stage<BLKB>(A.packed, lds);
-    for (int i = tid; i < HPW_MAXC / 4; i += 256)
-        reinterpret_cast<f32x4*>(shl)[i] = reinterpret_cast<const f32x4*>(A.packed + (size_t)A.nblk * BLKB)[i];
+    for (int i = tid; i < HPW_MAXC; i += 256) shl[i] = (A.shift && i < A.Cout) ? A.shift[i] : 0.f;
     // the lane's two pixels (tile h: flattened pixel base + 16 h + n16), their image and in-image index
     int img[2], pix[2];
     bool pv[2];
@@ -598,7 +754,7 @@ __global__ __launch_bounds__(256, KS <= 4 ? 4 : (KS <= 8 ? 3 : 2)) void h16_poin
         for (int h = 0; h < 2; ++h) {
             const int g = 4 * ks + kq;
             const bool live = g < Gin;                                         // groups past Cin: zero operands (and zero weights)
-            const u32x4* src = reinterpret_cast<const u32x4*>(A.x) + ((size_t)img[h] * A.x_gtot + A.x_goff + (live ? g : 0)) * A.HW + pix[h];
+            const u32x4* src = reinterpret_cast<const u32x4*>(A.x + A.x_base + img[h] * A.x_imgB + (live ? g : 0) * A.x_gS + pix[h] * A.x_pS);
             const u32x4 v = *src;
             X[ks][h] = live ? v : (u32x4){0u, 0u, 0u, 0u};
         }
@@ -618,7 +774,7 @@ __global__ __launch_bounds__(256, KS <= 4 ? 4 : (KS <= 8 ? 3 : 2)) void h16_poin
         for (int h = 0; h < 2; ++h) {
             rq[h] = (u32x4){0u, 0u, 0u, 0u};
             if (A.res && cl && pv[h])
-                rq[h] = reinterpret_cast<const u32x4*>(A.res)[((size_t)img[h] * A.r_gtot + A.r_goff + (c8 >> 3)) * A.HW + pix[h]];
+                rq[h] = *reinterpret_cast<const u32x4*>(A.res + A.r_base + img[h] * A.r_imgB + (c8 >> 3) * A.r_gS + pix[h] * A.r_pS);
         }
         f32x4 acc[2][2];                                                       // [tile of the pair][pixel tile]
 #pragma unroll
@@ -638,10 +794,26 @@ __global__ __launch_bounds__(256, KS <= 4 ? 4 : (KS <= 8 ? 3 : 2)) void h16_poin
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const f32x2 r0 = hwiden(rq[h][0]), r1 = hwiden(rq[h][1]), r2 = hwiden(rq[h][2]), r3 = hwiden(rq[h][3]);
+#ifdef OTP_H16_BF16
+            float f[8] = {acc[0][h][0] + sh0[0], acc[0][h][1] + sh0[1], acc[0][h][2] + sh0[2], acc[0][h][3] + sh0[3],
+                          acc[1][h][0] + sh1[0], acc[1][h][1] + sh1[1], acc[1][h][2] + sh1[2], acc[1][h][3] + sh1[3]};
+#else
             float f[8] = {acc[0][h][0] * A.post + sh0[0] + r0.x, acc[0][h][1] * A.post + sh0[1] + r0.y,
                           acc[0][h][2] * A.post + sh0[2] + r1.x, acc[0][h][3] * A.post + sh0[3] + r1.y,
                           acc[1][h][0] * A.post + sh1[0] + r2.x, acc[1][h][1] * A.post + sh1[1] + r2.y,
                           acc[1][h][2] * A.post + sh1[2] + r3.x, acc[1][h][3] * A.post + sh1[3] + r3.y};
+#endif
+#ifdef OTP_H16_BF16
+            if (A.res) {
+                // csrc/nhwc.hip's contract: the residual is added to the ROUNDED result and the sum rounded again (a separate bf16 add)
+                const u32x4 q = hpack8((const float(&)[8])f);
+                const f32x2 w0 = hwiden(q[0]), w1 = hwiden(q[1]), w2 = hwiden(q[2]), w3 = hwiden(q[3]);
+                const float g[8] = {w0.x, w0.y, w1.x, w1.y, w2.x, w2.y, w3.x, w3.y};
+                const float rr[8] = {r0.x, r0.y, r1.x, r1.y, r2.x, r2.y, r3.x, r3.y};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = g[e] + rr[e];
+            }
+#endif
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 bad |= otp_out_of_range(f[e]);
@@ -654,7 +826,7 @@ __global__ __launch_bounds__(256, KS <= 4 ? 4 : (KS <= 8 ? 3 : 2)) void h16_poin
                     for (int e = 0; e < 8; ++e)
                         if (c8 + e < A.Cout) o[(size_t)e * A.HW] = f[e];
                 } else {
-                    reinterpret_cast<u32x4*>(A.out)[((size_t)img[h] * A.o_tot + A.o_off + (c8 >> 3)) * A.HW + pix[h]] = hpack8(f);
+                    *reinterpret_cast<u32x4*>(A.out + A.o_base + img[h] * A.o_imgB + (c8 >> 3) * A.o_gS + pix[h] * A.o_pS) = hpack8(f);
                 }
             }
         }
@@ -662,9 +834,23 @@ __global__ __launch_bounds__(256, KS <= 4 ? 4 : (KS <= 8 ? 3 : 2)) void h16_poin
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
+#ifndef OTP_H16_BF16
     otp_range_report(A.rflag, bad, OTP_RANGE_H16);
+#else
+    (void)bad;
+#endif
 }
 
+template <int KS>
+int hpw_launch(const HPw& a, hipStream_t st) {
+    auto kern = h16_pointwise_kernel<KS>;
+    const size_t need = 2 * (size_t)hpw_blkb(KS) + HPW_MAXC * 4;
+    OTP_ALLOW_BIG_LDS(kern, need);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((a.total + 127) / 128)), dim3(256), need, st, a);
+    return otp_launch_status();
+}
+
+#ifndef OTP_H16_BF16
 // packed: nblk blocks of [tile of the pair][ks][lane] 16-byte A fragments (rows permuted: row r16 of tile m of pair p = channel
 // 32 p + 8 (r16 >> 2) + 4 m + (r16 & 3)), padded to hpw_blkb(KS), then shift[HPW_MAXC] floats, then {post, 0, 0, 0}
 __global__ void h16_pw_pack_kernel(const float* __restrict__ w, const float* __restrict__ scale, const float* __restrict__ shift,
@@ -995,26 +1181,7 @@ extern "C" int otp_h16_conv3x3(const void* in_h8, const void* wpacked, const voi
     HPlan P{};
     if (!h16_conv_plan(*desc, P)) return OTP_ERR_UNSUPPORTED;
     P.rflag = otp_range_word();
-    auto st = static_cast<hipStream_t>(stream);
-    auto fs = static_cast<const float*>(shift);
-#define OTP_H16_GO(NTW_, NPT_, S_) return h16_conv_launch<NTW_, NPT_, S_>(in_h8, wpacked, fs, res_h8, out_h8, P, st)
-#define OTP_H16_NPT(NPT_, S_)                                  \
-    if (P.NPT == NPT_) {                                       \
-        if (P.NTW == 2) OTP_H16_GO(2, NPT_, S_);               \
-        OTP_H16_GO(3, NPT_, S_);                               \
-    }
-    if (desc->stride == 1) {
-        OTP_H16_NPT(4, 1)
-        OTP_H16_NPT(2, 1)
-        OTP_H16_NPT(1, 1)
-    } else {
-        OTP_H16_NPT(4, 2)
-        OTP_H16_NPT(2, 2)
-        OTP_H16_NPT(1, 2)
-    }
-#undef OTP_H16_NPT
-#undef OTP_H16_GO
-    return OTP_ERR_UNSUPPORTED;
+    return h16_conv_dispatch(in_h8, wpacked, static_cast<const float*>(shift), res_h8, out_h8, P, desc->stride, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int otp_h16_pointwise_supported(int Cin, int Cout) {
@@ -1061,18 +1228,22 @@ extern "C" int otp_h16_pointwise(const void* in_h8, const void* packed, const vo
     a.res = static_cast<const unsigned char*>(res_h8);
     a.out = static_cast<unsigned char*>(out);
     a.total = N * HW, a.HW = HW, a.Cin = Cin, a.Cout = Cout, a.nblk = (Cout + 31) / 32, a.relu = relu ? 1 : 0, a.f32out = out_f32_nchw ? 1 : 0;
-    a.x_gtot = in_gtot, a.x_goff = in_goff, a.r_gtot = res_gtot, a.r_goff = res_goff, a.o_tot = out_tot, a.o_off = out_off;
+    const size_t hw16 = (size_t)HW * 16;
+    a.x_imgB = in_gtot * hw16, a.x_gS = hw16, a.x_pS = 16, a.x_base = in_goff * hw16;
+    a.r_imgB = res_gtot * hw16, a.r_gS = hw16, a.r_pS = 16, a.r_base = res_goff * hw16;
+    a.o_imgB = out_tot * hw16, a.o_gS = hw16, a.o_pS = 16, a.o_base = out_off * hw16;
+    a.o_tot = out_tot, a.o_off = out_off;
     a.post = out_scale > 0.f ? out_scale : 1.f;
     a.rflag = otp_range_word();
-    const dim3 grid((unsigned)((a.total + 127) / 128));
+    const int KS = hpw_ks(Cin);
+    a.shift = reinterpret_cast<const float*>(a.packed + (size_t)a.nblk * hpw_blkb(KS));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    switch (hpw_ks(Cin)) {
-        case 2: hipLaunchKernelGGL(h16_pointwise_kernel<2>, grid, dim3(256), 0, st, a); break;
-        case 4: hipLaunchKernelGGL(h16_pointwise_kernel<4>, grid, dim3(256), 0, st, a); break;
-        case 8: hipLaunchKernelGGL(h16_pointwise_kernel<8>, grid, dim3(256), 0, st, a); break;
-        default: hipLaunchKernelGGL(h16_pointwise_kernel<12>, grid, dim3(256), 0, st, a); break;
+    switch (KS) {
+        case 2: return hpw_launch<2>(a, st);
+        case 4: return hpw_launch<4>(a, st);
+        case 8: return hpw_launch<8>(a, st);
+        default: return hpw_launch<12>(a, st);
     }
-    return otp_launch_status();
 }
 
 extern "C" int otp_h16_stem_supported(int B, int F, int H, int W, int Cout) {
@@ -1114,3 +1285,101 @@ extern "C" int otp_h16_stem(const void* in, const void* packed, void* out_h8, in
                        static_cast<hipStream_t>(stream), a);
     return otp_launch_status();
 }
+
+#else  // OTP_H16_BF16: csrc/hb.hip
+}  // namespace
+
+namespace {
+// The plan walks every pixel tile of the launch (h16_window_records) - fine once per layer when a forward is captured into a graph, not
+// per launch of an eager training step (~700 convolutions, each asking three or four times): plans are kept per shape.
+struct HbKey {
+    int v[6];
+    bool operator<(const HbKey& o) const { return memcmp(v, o.v, sizeof(v)) < 0; }
+};
+std::mutex g_hb_mutex;
+std::map<HbKey, std::pair<bool, HPlan>> g_hb_plans;
+
+bool hb_plan(const otp_nhwc_conv_desc* d, HPlan& P) {
+    if (!d || d->kh != 3 || d->kw != 3 || d->pad != 1 || d->dil != 1 || (d->stride != 1 && d->stride != 2) || d->out_mode != 0) return false;
+    const HbKey key{{d->N, d->Cin, d->H, d->W, d->Cout, d->stride}};
+    std::lock_guard<std::mutex> lock(g_hb_mutex);
+    auto it = g_hb_plans.find(key);
+    if (it == g_hb_plans.end()) {
+        otp_h16_conv_desc h{};
+        h.N = d->N, h.Cin = d->Cin, h.H = d->H, h.W = d->W, h.Cout = d->Cout, h.stride = d->stride, h.act = OTP_ACT_NONE;
+        h.out_scale = 1.f;
+        HPlan Q{};
+        const bool ok = h16_conv_plan(h, Q, true);
+        if (g_hb_plans.size() > 4096) g_hb_plans.clear();
+        it = g_hb_plans.emplace(key, std::make_pair(ok, Q)).first;
+    }
+    P = it->second.second;
+    return it->second.first;
+}
+}  // namespace
+
+// ---- 1x1 convolutions of (N, 1, T, C) sequences: the TransformerBlock MLP's projections and their input gradients ----------------
+bool otp_hbpw_supported(const otp_nhwc_conv_desc* d) {
+    if (!d || d->kh != 1 || d->kw != 1 || d->stride != 1 || d->pad != 0 || d->N <= 0 || d->H <= 0 || d->W <= 0) return false;
+    if (d->Cin % 8 || d->Cout % 8 || d->Cout > HPW_MAXC || otp_hbpw_ks(d->Cin) == 0) return false;
+    if (d->out_mode != 0 && d->out_mode != 1) return false;
+    return (size_t)d->N * d->H * d->W < (1ull << 31);
+}
+
+int otp_hbpw_conv(const void* x, const void* wpacked, const void* bias, const void* res, void* out, const otp_nhwc_conv_desc* d,
+                  hipStream_t stream) {
+    if (!otp_hbpw_supported(d)) return OTP_ERR_UNSUPPORTED;
+    if (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(wpacked) | reinterpret_cast<uintptr_t>(res)) & 15) ||
+        (reinterpret_cast<uintptr_t>(out) & (d->out_mode ? 3 : 15)) || (reinterpret_cast<uintptr_t>(bias) & 3))
+        return OTP_ERR_UNSUPPORTED;
+    HPw a{};
+    a.x = static_cast<const unsigned char*>(x);
+    a.packed = static_cast<const unsigned char*>(wpacked);
+    a.res = static_cast<const unsigned char*>(res);
+    a.out = static_cast<unsigned char*>(out);
+    a.shift = static_cast<const float*>(bias);
+    const int HW = d->H * d->W;
+    a.total = d->N * HW, a.HW = HW, a.Cin = d->Cin, a.Cout = d->Cout, a.nblk = (d->Cout + 31) / 32, a.relu = 0, a.f32out = d->out_mode ? 1 : 0;
+    a.x_pS = (size_t)d->Cin * 2, a.x_gS = 16, a.x_imgB = HW * a.x_pS, a.x_base = 0;
+    a.r_pS = a.o_pS = (size_t)d->Cout * 2, a.r_gS = a.o_gS = 16, a.r_imgB = a.o_imgB = HW * a.o_pS, a.r_base = a.o_base = 0;
+    a.o_tot = d->Cout, a.o_off = 0;
+    a.post = 1.f;
+    a.rflag = nullptr;
+    switch (otp_hbpw_ks(d->Cin)) {
+        case 2: return hpw_launch<2>(a, stream);
+        case 4: return hpw_launch<4>(a, stream);
+        case 5: return hpw_launch<5>(a, stream);
+        case 8: return hpw_launch<8>(a, stream);
+        case 12: return hpw_launch<12>(a, stream);
+        case 17: return hpw_launch<17>(a, stream);
+    }
+    return OTP_ERR_UNSUPPORTED;
+}
+
+bool otp_hb_supported(const otp_nhwc_conv_desc* d) {
+    HPlan P{};
+    return hb_plan(d, P);
+}
+
+// Where the window kernel pays (MI355X, 80 frames, tools/bf16_conv_bench.py with and without OTPOSE_NHWC_HB=0): not on the wide maps -
+// rows of more than 96 pixels leave 128- or 64-pixel tiles - and not below 64 input channels at stride 1, where the 16-byte pieces of
+// an NHWC pixel make the window's LDS-DMA gather six cache lines per instruction where the H8 engine reads one.
+bool otp_hb_pays(const otp_nhwc_conv_desc* d) { return d && d->W <= 96 && (d->stride == 2 || d->Cin >= 64); }
+
+int otp_hb_stats_rows(const otp_nhwc_conv_desc* d) {
+    HPlan P{};
+    return hb_plan(d, P) ? P.nTiles : 0;
+}
+
+int otp_hb_conv(const void* x, const void* wpacked, const void* bias, const void* res, void* out, void* stats,
+                const otp_nhwc_conv_desc* d, hipStream_t stream) {
+    HPlan P{};
+    if (!hb_plan(d, P)) return OTP_ERR_UNSUPPORTED;
+    if (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(wpacked) | reinterpret_cast<uintptr_t>(out) |
+          reinterpret_cast<uintptr_t>(res)) & 15) || (reinterpret_cast<uintptr_t>(bias) & 3))
+        return OTP_ERR_UNSUPPORTED;
+    P.stats = static_cast<float*>(stats);
+    P.rflag = nullptr;
+    return h16_conv_dispatch(x, wpacked, static_cast<const float*>(bias), res, out, P, d->stride, stream);
+}
+#endif

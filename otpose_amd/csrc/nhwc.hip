@@ -17,6 +17,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "hb.h"
 #include <cstring>
 
 namespace {
@@ -170,7 +171,54 @@ struct PackJob {                       // one weight re-layout: everything nhwc_
     long so, si, sdy, sdx, base;
     size_t total;
     ConvPlan p;
+    int hb, hbNTW, hbChunks;           // hb = 1: the operator of csrc/hb.hip's 3x3 kernel (layout: csrc/hb.h), p only carries Cin / Cout
+    int hbKS;                          // hb = 2: of its 1x1 kernel, hbKS k-steps
 };
+
+// 3x3 / pad 1 / stride 1 or 2 convolutions with Cin % 16 == 0 run on csrc/hb.hip's kernel (the fp16 engine's conv for bfloat16
+// NHWC tensors: whole-Cin window by LDS-DMA, weights streamed through registers, three workgroups per CU) where that is faster
+// than nhwc_conv_kernel (otp_hb_pays: 96 / 192-channel branches, the stride-2 fuse convs).  OTPOSE_NHWC_HB=0 keeps every layer on nhwc_conv_kernel, =2 sends every
+// shape the window kernel covers to it, whether it pays or not (A/B, tests).
+bool use_hb(const otp_nhwc_conv_desc* d) {
+    const char* e = getenv("OTPOSE_NHWC_HB");                      // (read per call: the tests switch it inside one process)
+    const int mode = e ? atoi(e) : 1;
+    return mode != 0 && d && (mode == 2 || otp_hb_pays(d)) && otp_hb_supported(d);
+}
+
+// 1x1 convolutions of (N, 1, T, C) sequences - the two projections of a TransformerBlock's MLP and their input gradients - run on
+// csrc/hb.hip's pointwise kernel (the input register-resident, the weights streamed through the LDS): nhwc_conv_kernel re-stages
+// 46 KB of weights per 128-token tile and 136-channel chunk with one workgroup per CU (134 / 214 us per projection at cfg2).
+bool use_hbpw(const otp_nhwc_conv_desc* d) {
+    const char* e = getenv("OTPOSE_NHWC_HB");
+    return !(e && atoi(e) == 0) && d && d->H == 1 && otp_hbpw_supported(d);
+}
+
+__device__ __forceinline__ float pack_hbpw_value(const float* __restrict__ w, const PackJob& jb, size_t i) {
+    const int j = (int)(i & 7);
+    const size_t r = i >> 3;
+    const int units = otp_hbpw_blkb(jb.hbKS) / 16;
+    const int blk = (int)(r / units), u = (int)(r % units);
+    if (u >= 2 * jb.hbKS * 64) return 0.f;
+    const int frag = u >> 6, lane = u & 63, m = frag / jb.hbKS, ks = frag - m * jb.hbKS, r16 = lane & 15, kq = lane >> 4;
+    const int o = 32 * blk + 8 * (r16 >> 2) + 4 * m + (r16 & 3), ci = 32 * ks + 8 * kq + j;
+    if (o >= jb.p.Cout || ci >= jb.p.Cin) return 0.f;
+    return w[jb.base + o * jb.so + ci * jb.si];
+}
+
+// element i of the packed operator of csrc/hb.hip's kernel: [cout block][16-channel chunk][16-byte unit (csrc/hb.h)][8 channels]
+__device__ __forceinline__ float pack_hb_value(const float* __restrict__ w, const PackJob& jb, size_t i) {
+    const int j = (int)(i & 7);
+    size_t r = i >> 3;
+    const int WU = otp_hb_wb(jb.hbNTW) / 16;
+    const int u = (int)(r % WU); r /= WU;
+    const int chunk = (int)(r % jb.hbChunks), cb = (int)(r / jb.hbChunks);
+    int s, t, lane;
+    otp_hb_unit(u, jb.hbNTW, &s, &t, &lane);
+    const int o = otp_hb_row2ch(cb * jb.hbNTW * 16, t, lane & 15, jb.hbNTW, jb.p.Cout);
+    const int q = 4 * s + (lane >> 4), tap = q >> 1, ci = chunk * 16 + 8 * (q & 1) + j;
+    if (tap > 8 || o >= jb.p.Cout || ci >= jb.p.Cin) return 0.f;
+    return w[jb.base + o * jb.so + ci * jb.si + (tap / 3) * jb.sdy + (tap % 3) * jb.sdx];
+}
 
 __device__ __forceinline__ void pack_range(const float* __restrict__ w, bf16* __restrict__ out, const ConvPlan& p, long so, long si,
                                            long sdy, long sdx, long base, size_t total, size_t first, size_t step) {
@@ -197,10 +245,20 @@ __global__ void nhwc_pack_kernel(const float* __restrict__ w, bf16* __restrict__
                (size_t)gridDim.x * blockDim.x);
 }
 
+__global__ void nhwc_pack_hb_kernel(PackJob jb) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < jb.total; i += (size_t)gridDim.x * blockDim.x)
+        jb.out[i] = (bf16)(jb.hb == 2 ? pack_hbpw_value(jb.w, jb, i) : pack_hb_value(jb.w, jb, i));
+}
+
 // every weight of a training step in one launch: blockIdx.y = job (the table lives in device memory, its fields arrive
 // through the scalar cache), blockIdx.x strides over the job's elements
 __global__ void nhwc_pack_batch_kernel(const PackJob* __restrict__ jobs) {
     const PackJob& jb = jobs[blockIdx.y];
+    if (jb.hb) {
+        for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < jb.total; i += (size_t)gridDim.x * blockDim.x)
+            jb.out[i] = (bf16)(jb.hb == 2 ? pack_hbpw_value(jb.w, jb, i) : pack_hb_value(jb.w, jb, i));
+        return;
+    }
     pack_range(jb.w, jb.out, jb.p, jb.so, jb.si, jb.sdy, jb.sdx, jb.base, jb.total,
                blockIdx.x * (size_t)blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
 }
@@ -1311,13 +1369,24 @@ int grid_for(size_t units) {
 // =====================================================================================================================
 // C ABI
 // =====================================================================================================================
+namespace {
+size_t hb_weight_bytes(const otp_nhwc_conv_desc* d) {
+    const int ntw = otp_hb_ntw(d->Cout), nN = ((d->Cout + 15) / 16 + ntw - 1) / ntw;
+    return (size_t)nN * (d->Cin / 16) * otp_hb_wb(ntw);
+}
+size_t hbpw_weight_bytes(const otp_nhwc_conv_desc* d) { return (size_t)((d->Cout + 31) / 32) * otp_hbpw_blkb(otp_hbpw_ks(d->Cin)); }
+}  // namespace
+
 extern "C" size_t otp_nhwc_conv_weight_bytes(const otp_nhwc_conv_desc* d) {
     ConvPlan p;
+    if (use_hb(d)) return hb_weight_bytes(d);
+    if (use_hbpw(d)) return hbpw_weight_bytes(d);
     return make_plan(d, &p) ? p.wbytes : 0;
 }
 
 extern "C" int otp_nhwc_conv_stats_rows(const otp_nhwc_conv_desc* d) {
     ConvPlan p;
+    if (use_hb(d)) return otp_hb_stats_rows(d);
     return make_plan(d, &p) ? p.N * p.tilesPerImg : 0;
 }
 
@@ -1335,12 +1404,14 @@ bool make_pack_job(const void* weight, void* wpacked, const otp_nhwc_conv_desc* 
     if (!make_plan(d, &jb->p)) return false;
     const ConvPlan& p = jb->p;
     const long taps = (long)p.kh * p.kw;
+    jb->hb = use_hb(d) ? 1 : (use_hbpw(d) ? 2 : 0);
+    jb->hbNTW = otp_hb_ntw(d->Cout), jb->hbChunks = d->Cin / 16, jb->hbKS = otp_hbpw_ks(d->Cin);
     if (!dgrad) {
         jb->so = p.Cin * taps, jb->si = taps, jb->sdy = p.kw, jb->sdx = 1, jb->base = 0;
     } else {      // original weight is (O = d->Cin, I = d->Cout, kh, kw); this conv maps O -> I with flipped taps
         jb->so = taps, jb->si = (long)p.Cout * taps, jb->sdy = -p.kw, jb->sdx = -1, jb->base = taps - 1;
     }
-    jb->total = p.wbytes / 2;
+    jb->total = (jb->hb == 1 ? hb_weight_bytes(d) : (jb->hb == 2 ? hbpw_weight_bytes(d) : p.wbytes)) / 2;
     jb->w = static_cast<const float*>(weight);
     jb->out = static_cast<bf16*>(wpacked);
     return true;
@@ -1351,6 +1422,10 @@ extern "C" int otp_nhwc_conv_pack(const void* weight, void* wpacked, const otp_n
     PackJob jb;
     if (!weight || !wpacked) return OTP_ERR_BAD_ARG;
     if (!make_pack_job(weight, wpacked, d, dgrad, &jb)) return OTP_ERR_UNSUPPORTED;
+    if (jb.hb) {
+        nhwc_pack_hb_kernel<<<grid_for(jb.total), 256, 0, static_cast<hipStream_t>(stream)>>>(jb);
+        return otp_launch_status();
+    }
     nhwc_pack_kernel<<<grid_for(jb.total), 256, 0, static_cast<hipStream_t>(stream)>>>(jb.w, jb.out, jb.p, jb.so, jb.si, jb.sdy,
                                                                                       jb.sdx, jb.base, jb.total);
     return otp_launch_status();
@@ -1384,6 +1459,8 @@ extern "C" int otp_nhwc_conv_bf16_res(const void* x, const void* wpacked, const 
     if (!make_plan(d, &p)) return OTP_ERR_UNSUPPORTED;
     if (res && (p.out_mode != 0 || stats)) return OTP_ERR_BAD_ARG;   // the sum is an NHWC bf16 tensor; statistics are of conv(x)
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (use_hb(d)) return otp_hb_conv(x, wpacked, bias, res, out, stats, d, st);
+    if (use_hbpw(d)) return stats ? OTP_ERR_UNSUPPORTED : otp_hbpw_conv(x, wpacked, bias, res, out, d, st);
 #define OTP_NHWC_CASE(mb, nb) \
     if (p.MB == mb && p.NB == nb) return launch_conv<mb, nb>(p, x, wpacked, bias, res, out, stats, st)
     OTP_NHWC_CASE(1, 2); OTP_NHWC_CASE(2, 2); OTP_NHWC_CASE(3, 2); OTP_NHWC_CASE(4, 2); OTP_NHWC_CASE(5, 2); OTP_NHWC_CASE(6, 2);

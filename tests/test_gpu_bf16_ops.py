@@ -91,6 +91,81 @@ def test_conv_forward_stats_dgrad_wgrad(case):
     assert float((gw - gwr).abs().max()) <= 2e-5 * max(1.0, float(gwr.abs().max())), float((gw - gwr).abs().max())
 
 
+@pytest.mark.parametrize("case", [(48, 48, 1, 5, 96, 72), (96, 96, 1, 3, 48, 36), (192, 192, 1, 3, 24, 18), (384, 384, 1, 5, 12, 9),
+                                  (64, 64, 2, 2, 192, 144), (48, 96, 2, 3, 96, 72), (96, 40, 1, 2, 20, 14), (32, 56, 2, 3, 16, 12)])
+def test_window_kernel_matches_the_chunked_kernel(case, monkeypatch):
+    """3x3 / pad 1 convolutions with Cin % 16 == 0 run on csrc/hb.hip (the fp16 engine's window + weight-stream kernel compiled for
+    bfloat16 NHWC tensors); OTPOSE_NHWC_HB=0 keeps nhwc_conv_kernel.  Same operands, same products, fp32 sums in another order:
+    the bf16 results may differ by one rounding step, the per-tile statistics must add up to the same channel sums, and both sit
+    within the rounding of a float64 convolution."""
+    from otpose_amd import bf16_ops as B
+    from otpose_amd import hip
+    cin, cout, stride, n, h, w = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = _rb(torch.randn(n, cin, h, w, generator=g))
+    wt = _rb(torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5)
+    bias = torch.randn(cout, generator=g).to(_dev())
+    ref = (F.conv2d(x.double(), wt.double(), None, stride, 1, 1) + bias.cpu().double().view(1, -1, 1, 1)).float()
+    xd, wd = _nhwc(x), wt.to(_dev())
+    d = B._desc(n, h, w, cin, cout, 3, 3, stride, 1, 1, 0)
+    import ctypes
+    res = {}
+    for hb in ("1", "0"):
+        monkeypatch.setenv("OTPOSE_NHWC_HB", "2" if hb == "1" else "0")       # 2: also the shapes where it does not pay
+        rows = hip.lib().otp_nhwc_conv_stats_rows(ctypes.byref(d))
+        out, stats, r2 = B.conv_forward(xd, wd, bias, stride, 1, 1)
+        torch.cuda.synchronize()
+        assert rows == r2 == stats.shape[0]
+        res[hb] = (out.float().cpu(), stats.sum(0).cpu())
+    monkeypatch.delenv("OTPOSE_NHWC_HB")
+    a, b = res["1"][0], res["0"][0]
+    assert res["1"][0].shape == res["0"][0].shape
+    got = a.permute(0, 3, 1, 2)
+    tol = 2.0 ** -8 * float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= tol
+    assert float((a - b).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
+    assert float((a != b).float().mean()) < 0.05                 # (rounding flips only)
+    o = a.reshape(-1, a.shape[-1])
+    assert torch.allclose(res["1"][1][0], o.sum(0), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(res["1"][1][1], (o * o).sum(0), rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize("case", [(136, 544, 2, 6912), (544, 136, 2, 6912), (136, 136, 3, 200), (40, 24, 1, 77), (204, 816, 1, 1000),
+                                  (816, 204, 1, 1000)])
+def test_sequence_pointwise_convs_forward_and_input_gradient(case, monkeypatch):
+    """The two projections of a TransformerBlock MLP (model/blocks.py:248-254) on the (B, 1, T, C) view of a sequence: csrc/hb.hip's
+    pointwise kernel (register-resident input, streamed weights) behind otp_nhwc_conv_* - bf16 NHWC and fp32 NCHW results, bias,
+    the input gradient with and without a skip gradient - against float64 and against nhwc_conv_kernel (OTPOSE_NHWC_HB=0)."""
+    from otpose_amd import bf16_ops as B
+    cin, cout, n, t = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = _rb(torch.randn(n, cin, 1, t, generator=g))
+    wt = _rb(torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5)
+    bias = torch.randn(cout, generator=g)
+    ref = F.conv2d(x.double(), wt.double(), bias.double()).float()
+    gy = _rb(torch.randn(n, cout, 1, t, generator=g))
+    res = _rb(torch.randn(n, cin, 1, t, generator=g))
+    gref = torch.nn.grad.conv2d_input(x.shape, wt.double(), gy.double()).float()
+    xd, wd, bd, gyd, resd = _nhwc(x), wt.to(_dev()), bias.to(_dev()), _nhwc(gy), _nhwc(res)
+    got = {}
+    for hb in ("1", "0"):
+        monkeypatch.setenv("OTPOSE_NHWC_HB", hb)
+        o16, _, _ = B.conv_forward(xd, wd, bd, 1, 0, 1, out_mode=0, want_stats=False)
+        o32, _, _ = B.conv_forward(xd, wd, bd, 1, 0, 1, out_mode=1)
+        gx = B.conv_dgrad(gyd, wd, (1, t), 1, 0, 1)
+        gxr = B.conv_dgrad(gyd, wd, (1, t), 1, 0, 1, res=resd)
+        torch.cuda.synchronize()
+        assert torch.equal(gxr, gx + resd)
+        got[hb] = (_nchw(o16, cout), o32.cpu(), _nchw(gx, cin))
+    monkeypatch.delenv("OTPOSE_NHWC_HB")
+    for hb in ("1", "0"):
+        o16, o32, gx = got[hb]
+        assert float((o16 - ref).abs().max()) <= 2.0 ** -8 * float(ref.abs().max()), hb
+        assert float((o32 - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max())), hb
+        assert float((gx - gref).abs().max()) <= 2.0 ** -8 * float(gref.abs().max()), hb
+    assert float((got["1"][1] - got["0"][1]).abs().max()) <= 2e-4 * max(1.0, float(ref.abs().max()))
+
+
 @pytest.mark.parametrize("c,relu,with_res", [(48, True, True), (96, True, False), (17, False, False), (256, False, True)])
 def test_conv_bn_function_matches_torch_autograd(c, relu, with_res):
     """ConvBnFunction forward / backward vs conv2d + batch_norm(training) + residual + relu on fp64 autograd."""

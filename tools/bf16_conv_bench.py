@@ -59,6 +59,23 @@ def main():
         print("%3d->%3d k%d s%d %3dx%-3d x%-3d %9.1f %9.1f %9.1f   %6.0f %6.0f %6.0f   MB%d NB%d CK%d ch%d nM%d grid%d lds%d"
               % (cin, cout, k, s, h, w, n, t_f, t_d, t_w, flop / t_f / 1e6, flop / t_d / 1e6, flop / t_w / 1e6,
                  plan[0], plan[1], plan[2], plan[3], plan[4], plan[5], plan[6]), flush=True)
+    # the TransformerBlock MLP's projections on (B, 1, T, C) sequences (16 clips x 96 x 72 tokens)
+    for cin, cout in ((136, 544), (544, 136)):
+        nb, t = n // 5, 6912
+        x = torch.randn(nb, 1, t, B.cs(cin), device=dev).to(B.BF16)
+        wt = torch.randn(cout, cin, 1, 1, device=dev) * 0.05
+        gy = torch.randn(nb, 1, t, B.cs(cout), device=dev).to(B.BF16)
+        bias = torch.zeros(cout, device=dev)
+        t_f = timeit(lambda: B.conv_forward(x, wt, bias, 1, 0, 1, out_mode=0, want_stats=False))
+        t_o = timeit(lambda: B.conv_forward(x, wt, bias, 1, 0, 1, out_mode=1))
+        t_d = timeit(lambda: B.conv_dgrad(gy, wt, (1, t), 1, 0, 1))
+        t_w = timeit(lambda: B.conv_wgrad(x, gy, tuple(wt.shape), 1, 0, 1))
+        print("seq %3d->%3d x%d x%d: fwd bf16 %.1f us, fwd fp32 NCHW %.1f us, dgrad %.1f us, wgrad %.1f us (with per-call packs)"
+              % (cin, cout, nb, t, t_f, t_o, t_d, t_w), flush=True)
+    yn = torch.randn(n // 5, 136, 1, 6912, device=dev)
+    print("to_nhwc 136 x 6912 x%d: %.1f us;" % (n // 5, timeit(lambda: B.to_nhwc(yn))), end=" ")
+    yb = B.to_nhwc(yn)
+    print("to_nchw: %.1f us" % timeit(lambda: B.to_nchw(yb, 136)))
     # BatchNorm passes at the widest map
     c = 48
     xx = torch.randn(n, 96, 72, c, device=dev).to(B.BF16)
