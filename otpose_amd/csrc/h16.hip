@@ -1361,10 +1361,13 @@ bool otp_hb_supported(const otp_nhwc_conv_desc* d) {
     return hb_plan(d, P);
 }
 
-// Where the window kernel pays (MI355X, 80 frames, tools/bf16_conv_bench.py with and without OTPOSE_NHWC_HB=0): not on the wide maps -
-// rows of more than 96 pixels leave 128- or 64-pixel tiles - and not below 64 input channels at stride 1, where the 16-byte pieces of
-// an NHWC pixel make the window's LDS-DMA gather six cache lines per instruction where the H8 engine reads one.
-bool otp_hb_pays(const otp_nhwc_conv_desc* d) { return d && d->W <= 96 && (d->stride == 2 || d->Cin >= 64); }
+// Where the window kernel pays (MI355X, 80 frames, tools/bf16_conv_bench.py with OTPOSE_NHWC_HB=2 and =0; forward / input gradient us):
+// 48 -> 48 @96x72 47.8 / 46.5 against 50.3 / 49.6, 96 -> 96 @48x36 42.1 / 43.9 against 52.4 / 49.7, 192 -> 192 @24x18 41.7 / 48.4 against
+// 49.8 / 52.8, 64 -> 64 @96x72 70.7 / 70.8 against 78.2 / 75.3, 48 -> 96 stride 2 38.3 / 97.3 against 64.1 / 105.0; not at 384 channels
+// (54.2 / 62.9 against 53.5 / 60.5) and not on the wide maps (64 -> 64 stride 2 @192x144: 241 / 469 against 234 / 421 - rows of more
+// than 96 pixels leave 128- or 64-pixel tiles).  The 16-byte pieces of an NHWC pixel make the window's LDS-DMA gather up to six cache
+// lines per instruction where the H8 engine reads one: the gain is a third of what the fp16 engine's layout gives the same kernel.
+bool otp_hb_pays(const otp_nhwc_conv_desc* d) { return d && d->W <= 96 && d->Cin <= 192 && d->Cout <= 192; }
 
 int otp_hb_stats_rows(const otp_nhwc_conv_desc* d) {
     HPlan P{};

@@ -190,7 +190,8 @@ bool use_hb(const otp_nhwc_conv_desc* d) {
 // 46 KB of weights per 128-token tile and 136-channel chunk with one workgroup per CU (134 / 214 us per projection at cfg2).
 bool use_hbpw(const otp_nhwc_conv_desc* d) {
     const char* e = getenv("OTPOSE_NHWC_HB");
-    return !(e && atoi(e) == 0) && d && d->H == 1 && otp_hbpw_supported(d);
+    const char* e2 = getenv("OTPOSE_NHWC_HBPW");                   // (=0: only the 1x1 kernel off)
+    return !(e && atoi(e) == 0) && !(e2 && atoi(e2) == 0) && d && d->H == 1 && otp_hbpw_supported(d);
 }
 
 __device__ __forceinline__ float pack_hbpw_value(const float* __restrict__ w, const PackJob& jb, size_t i) {
@@ -1243,6 +1244,36 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
     }
 }
 
+// The same conversion for tensors with many channels (the (B, C, T) sequences of the temporal encoders: C = 136): a workgroup moves
+// 64 pixels x all channels through the LDS - reads are 256-byte runs of one channel plane, writes 16-byte units of the tile's
+// CONTIGUOUS 64 x CS x 2 bytes (the kernel above scatters a 16-byte piece per thread at the pixel stride: 46 us for 16 x 136 x 6912
+// against 16 us for the opposite direction).  LDS rows of CS / 2 | 1 dwords (channel pairs): an odd stride, no bank conflicts.
+__global__ __launch_bounds__(256) void nchw_to_nhwc_tile_kernel(const float* __restrict__ in, bf16* __restrict__ out, int C, int HW,
+                                                                 int CS) {
+    extern __shared__ unsigned int ttile[];
+    const int tilesPerImg = (HW + 63) / 64;
+    const int n = blockIdx.x / tilesPerImg, p0 = (blockIdx.x - n * tilesPerImg) * 64;
+    const int RS = (CS / 2) | 1;
+    const int px = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const bool pv = p0 + px < HW;
+    const float* src = in + (size_t)n * C * HW + p0 + (pv ? px : 0);
+#pragma unroll 4
+    for (int cp = g; cp < CS / 2; cp += 4) {
+        const int c = 2 * cp;
+        const float a = (pv && c < C) ? src[(size_t)c * HW] : 0.f, b = (pv && c + 1 < C) ? src[(size_t)(c + 1) * HW] : 0.f;
+        typedef bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+        ttile[px * RS + cp] = __builtin_bit_cast(unsigned int, (bf16x2_t){(bf16)a, (bf16)b});
+    }
+    __syncthreads();
+    const int U = CS / 8, npx = HW - p0 < 64 ? HW - p0 : 64;
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    for (int u = threadIdx.x; u < npx * U; u += 256) {
+        const int q = u / U, k = u - q * U;
+        const unsigned int* r = ttile + q * RS + 4 * k;
+        *reinterpret_cast<u32x4_t*>(out + ((size_t)n * HW + p0 + q) * CS + 8 * k) = (u32x4_t){r[0], r[1], r[2], r[3]};
+    }
+}
+
 // (N, H, W, CS) bf16 -> (N, C, H, W) fp32: a workgroup moves 64 pixels x all channels through LDS, so that the reads are
 // 16-byte units of whole pixel rows and the writes 256-byte runs of one channel plane
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const bf16* __restrict__ in, float* __restrict__ out, int N, int C,
@@ -1608,6 +1639,11 @@ extern "C" int otp_nhwc_upsample_add_backward(const void* gy, const void* out, v
 extern "C" int otp_nchw_f32_to_nhwc_bf16(const void* in, void* out, int N, int C, int H, int W, int frame_split, void* stream) {
     if (!in || !out || N <= 0 || C <= 0 || (frame_split > 0 && N % frame_split)) return OTP_ERR_BAD_ARG;
     const int CS = (C + 7) / 8 * 8;
+    if (frame_split <= 0 && CS >= 32 && CS <= 4096 && (size_t)N * ((H * W + 63) / 64) < (1ull << 31)) {
+        nchw_to_nhwc_tile_kernel<<<N * ((H * W + 63) / 64), 256, (size_t)64 * ((CS / 2) | 1) * 4, static_cast<hipStream_t>(stream)>>>(
+            static_cast<const float*>(in), static_cast<bf16*>(out), C, H * W, CS);
+        return otp_launch_status();
+    }
     nchw_to_nhwc_kernel<<<grid_for((size_t)N * H * W), 256, 0, static_cast<hipStream_t>(stream)>>>(
         static_cast<const float*>(in), static_cast<bf16*>(out), N, C, H * W, CS, frame_split);
     return otp_launch_status();

@@ -464,10 +464,8 @@ class TrainGraph:
         st = self.branch_streams(total_b, 3)
         main, par = st[0], st[1] is not st[0]
         if par:
-            st[2].wait_stream(main)
+            st[2].wait_stream(main)                    # def_fuse's stream starts from here (its launches are enqueued further down)
             total_b.record_stream(st[2])
-        with torch.cuda.stream(st[2]):
-            def_h = self.rsb_chain("def_fuse", total_b)
         ctx = self.conv_transformer("flow_encoder", total_b, 1, (0, 6, 0))[0].reshape(B, J, pe_h, pe_w)
         mg = margin.to(x.dtype)
         div = lambda t, k: t / (mg[:, k] + 1)[:, None, None, None]           # noqa: E731
@@ -496,6 +494,11 @@ class TrainGraph:
             t1 = self.conv_transformer("temporal_encoder1", x1, 2, (0, 6, 2))
             s1 = torch.stack(t1, 1).contiguous().view(B, -1, pe_h, pe_w)
             f1 = self.conv("final_layer1", s1, 1, fk // 2)
+        # def_fuse is enqueued BETWEEN the two encoders: autograd runs a backward's ready nodes latest-first, so its backward (a chain
+        # of small fp32 launches, ~7 ms alone at a third of the chip) comes between encoder 2's and encoder 1's and overlaps with
+        # encoder 1's on the other stream - emitted first it came last, alone, in front of the backbone's backward
+        with torch.cuda.stream(st[2]):
+            def_h = self.rsb_chain("def_fuse", total_b)
         t2 = self.conv_transformer("temporal_encoder2", x2, 2, (0, 6, 2))
         s2 = torch.stack(t2, 1).contiguous().view(B, -1, pe_h, pe_w)
         f2 = self.conv("final_layer2", s2, 1, fk // 2)

@@ -96,6 +96,7 @@ def test_every_bf16_backbone_layer_matches_fp64_on_its_own_operands():
     assert len(layers) > 100
     worst = dict(y=0.0, ymax=0.0, gx=0.0, gres=0.0, gw=0.0, gg=0.0, gb=0.0)
     where = dict(worst)
+    flips = decisions = 0
     for rec in layers:
         conv, bn = rec["conv"], rec["bn"]
         w = P[conv + ".weight"]
@@ -104,10 +105,23 @@ def test_every_bf16_backbone_layer_matches_fp64_on_its_own_operands():
               "b.bias": P[bn + ".bias"].detach().cpu().double().requires_grad_()}
         xin = _nchw(rec["x"], cin).requires_grad_()
         res = _nchw(rec["res"], cout).requires_grad_() if rec["res"] is not None else None
-        with O.bf16_points():
-            y = O._conv_bn(sd, "c", "b", xin, rec["stride"], rec["pad"], rec["relu"], True, res=res)
-            y.backward(_nchw(rec["gy"], cout))
         yh = _nchw(rec["y"], cout)
+        with O.bf16_points():
+            # the layer without its ReLU, then the ReLU with the DECISIONS the kernel took (yh > 0): a pre-activation within one
+            # rounding step of zero may fall on either side - the synthetic frames have flat regions, so one such value repeats over
+            # many pixels (round 5: 18 of 122 880 decisions of one layer differed, all in one channel, and carried 1.8 % of the
+            # gradient arriving there) - and a gradient taken through the other branch says nothing about the arithmetic.  The
+            # number of differing decisions is bounded below instead.
+            pre = O._conv_bn(sd, "c", "b", xin, rec["stride"], rec["pad"], False, True, res=res)
+            if rec["relu"]:
+                keep = (yh > 0).to(pre.dtype)
+                y = pre * keep
+                flips += int(((pre.detach() > 0) != (yh > 0)).sum())
+                decisions += yh.numel()
+            else:
+                y = pre
+            y.backward(_nchw(rec["gy"], cout))
+            y = torch.relu(pre.detach()) if rec["relu"] else pre.detach()
         errs = dict(y=_rel(yh, y.detach()),
                     ymax=float((yh - y.detach()).abs().max()) / float(y.detach().abs().max()),
                     gw=_rel(w.grad.cpu().double(), sd["c.weight"].grad),
@@ -124,6 +138,8 @@ def test_every_bf16_backbone_layer_matches_fp64_on_its_own_operands():
           % len(layers))
     for k in ("y", "ymax", "gx", "gres", "gw", "gg", "gb"):
         print("   %-5s %.3e   (%s)" % (k, worst[k], where[k]))
+    print("   ReLU decisions that differ from float64's: %d of %d" % (flips, decisions))
+    assert flips <= 2e-4 * decisions
     # y / gx / gres: stored bf16 - a share of elements rounds the other way (relative L2); ymax: the largest single difference
     # as a fraction of the layer's range (one bf16 ulp of the largest value is 2^-8 = 3.9e-3); gw / gg / gb: fp32 sums
     assert worst["y"] <= TOL["y"] and worst["ymax"] <= TOL["ymax"]
