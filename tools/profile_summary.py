@@ -45,7 +45,8 @@ def timeline(src, dst, marker, bin_us=1000.0):
     if len(marks) < 4:
         return
     gaps = sorted((marks[i + 1] - marks[i], i) for i in range(len(marks) - 1))
-    gaps = [g for g in gaps if g[0] >= 0.2 * gaps[-1][0]]          # (a marker launched twice in a row: not a period)
+    ref = gaps[len(gaps) // 2 + len(gaps) // 4][0]                  # median of the longer half (a marker launched twice in a row
+    gaps = [g for g in gaps if 0.5 * ref <= g[0] <= 1.5 * ref]     #  leaves short gaps, a pause between bench phases a long one)
     _, i = gaps[len(gaps) // 2]                                   # a median-length period
     t0, t1 = marks[i], marks[i + 1]
     nb = int((t1 - t0) / 1e3 / bin_us) + 1
