@@ -700,6 +700,13 @@ int otp_nhwc_channel_sum(const void* g, void* out, void* workspace, size_t works
                          void* stream);
 int otp_gelu_bf16_forward(const void* x, void* y, size_t n, void* stream);
 int otp_gelu_bf16_backward(const void* x, const void* grad_y, void* grad_x, size_t n, void* stream);
+/* nn.GELU followed by nn.Dropout(p) of the same MLP (model/blocks.py:250-251; training mode) as one pass over n bf16 elements
+ * (n % 8 == 0): y = keep ? gelu(x) / (1 - p') : 0 with p' = round(65536 p) / 65536, rounded once; keep_bits (n / 8 bytes) receives
+ * the decisions, bit j of byte u = element 8 u + j.  The draws are a counter-based hash of (element index, seed): the same seed
+ * repeats them.  The backward takes the bits: grad_x = keep ? grad_y * gelu'(x) / (1 - p') : 0. */
+int otp_gelu_dropout_bf16_forward(const void* x, void* y, void* keep_bits, size_t n, float p, unsigned long long seed, void* stream);
+int otp_gelu_dropout_bf16_backward(const void* x, const void* grad_y, const void* keep_bits, void* grad_x, size_t n, float p,
+                                   void* stream);
 
 #ifdef __cplusplus
 }

@@ -538,6 +538,47 @@ class GeluFunction(Function):
 gelu = GeluFunction.apply
 
 
+def _draw_seed(device):
+    """A 64-bit seed for a counter-based draw from PyTorch's CUDA generator state (seed, Philox offset), advancing the offset like a
+    random op does: ``torch.manual_seed`` makes the step's draws repeat, consecutive calls differ.  Host side only."""
+    gen = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()]
+    off = gen.get_offset()
+    gen.set_offset(off + 4)
+    return (gen.initial_seed() * 0x9E3779B97F4A7C15 + (off + 1) * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+
+
+class GeluDropoutFunction(Function):
+    """``dropout(gelu(x), p)`` of the TransformerBlock MLP (model/blocks.py:250-251, training mode) on bf16 as ONE pass each way
+    (``otp_gelu_dropout_bf16_*``): the separate GELU + ``F.dropout`` launches cost a 240 MB pass forward and a 360 MB one backward more."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        _require_gpu(x)
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        keep = torch.empty(x.numel() // 8, dtype=torch.uint8, device=x.device)
+        hip.check(hip.lib().otp_gelu_dropout_bf16_forward(hip.ptr(x), hip.ptr(y), hip.ptr(keep), x.numel(), float(p), int(seed),
+                                                          hip.stream_of(x)), "otp_gelu_dropout_bf16_forward")
+        ctx.save_for_backward(x, keep)
+        ctx.p = float(p)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, keep = ctx.saved_tensors
+        gx = torch.empty_like(x)
+        hip.check(hip.lib().otp_gelu_dropout_bf16_backward(hip.ptr(x), hip.ptr(gy.contiguous()), hip.ptr(keep), hip.ptr(gx), x.numel(),
+                                                           ctx.p, hip.stream_of(x)), "otp_gelu_dropout_bf16_backward")
+        return gx, None, None
+
+
+def gelu_dropout(x, p, seed=None):
+    """``F.dropout(gelu(x), p, training=True)`` on a bf16 tensor (numel % 8 == 0); ``seed``: None draws one from the CUDA generator."""
+    if not p > 0.0:
+        return gelu(x)
+    return GeluDropoutFunction.apply(x, p, _draw_seed(x.device) if seed is None else seed)
+
+
 class ToNhwcFunction(Function):
     """(N, C, H, W) fp32 -> (N, H, W, CS) bf16 with the matching gradient conversion (the precision / layout hand-over
     in front of a bf16 sub-graph)."""

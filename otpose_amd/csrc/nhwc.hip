@@ -1388,6 +1388,62 @@ __global__ __launch_bounds__(256) void gelu_bf16_bwd_kernel(const bf16* __restri
     }
 }
 
+// GELU followed by Dropout(p) (model/blocks.py:250-251) as one pass: y = keep ? gelu(x) / (1 - p) : 0, one rounding, plus the keep
+// decisions as one bit per element (a byte per 8-element unit) for the backward - the separate launches cost a 240 MB pass forward
+// (fused_dropout) and a 360 MB one backward (masked_scale) per MLP.  Draws: a counter-based hash of (element pair, seed), two 16-bit
+// uniforms per 32-bit hash (lowbias32 finaliser), keep <=> u16 >= round(65536 p); the seed comes from PyTorch's CUDA generator
+// (bf16_ops.gelu_dropout), so torch.manual_seed reproduces a step.
+__device__ __forceinline__ uint32_t drop_hash(size_t pair, uint32_t s0, uint32_t s1) {
+    uint32_t h = (uint32_t)pair * 0x9E3779B1u + s0;
+    h ^= ((uint32_t)(pair >> 32) + s1) * 0x85EBCA77u;
+    h ^= h >> 16; h *= 0x21F0AAADu; h ^= h >> 15; h *= 0x735A2D97u; h ^= h >> 15;
+    return h;
+}
+__device__ __forceinline__ unsigned drop_keep8(size_t u, uint32_t s0, uint32_t s1, uint32_t thr) {
+    unsigned bits = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t h = drop_hash(u * 4 + k, s0, s1);
+        bits |= ((h & 0xFFFFu) >= thr ? 1u : 0u) << (2 * k);
+        bits |= ((h >> 16) >= thr ? 1u : 0u) << (2 * k + 1);
+    }
+    return bits;
+}
+__global__ __launch_bounds__(256) void gelu_dropout_bf16_fwd_kernel(const bf16* __restrict__ x, bf16* __restrict__ y,
+                                                                     unsigned char* __restrict__ keep, size_t units, uint32_t s0, uint32_t s1,
+                                                                     uint32_t thr, float scale) {
+    for (size_t u = blockIdx.x * (size_t)blockDim.x + threadIdx.x; u < units; u += (size_t)gridDim.x * blockDim.x) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + u * 8);
+        const unsigned bits = drop_keep8(u, s0, s1, thr);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float f = bf2f(v[j]);
+            const float g = 0.5f * f * (1.f + erff(f * 0.70710678118654752440f)) * scale;
+            o[j] = (bf16)(((bits >> j) & 1u) ? g : 0.f);
+        }
+        *reinterpret_cast<bf16x8*>(y + u * 8) = o;
+        keep[u] = (unsigned char)bits;
+    }
+}
+__global__ __launch_bounds__(256) void gelu_dropout_bf16_bwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
+                                                                     const unsigned char* __restrict__ keep, bf16* __restrict__ dx,
+                                                                     size_t units, float scale) {
+    for (size_t u = blockIdx.x * (size_t)blockDim.x + threadIdx.x; u < units; u += (size_t)gridDim.x * blockDim.x) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + u * 8), g = *reinterpret_cast<const bf16x8*>(dy + u * 8);
+        const unsigned bits = keep[u];
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float f = bf2f(v[j]);
+            const float cdf = 0.5f * (1.f + erff(f * 0.70710678118654752440f));
+            const float pdf = 0.39894228040143267794f * expf(-0.5f * f * f);
+            o[j] = (bf16)(((bits >> j) & 1u) ? bf2f(g[j]) * scale * (cdf + f * pdf) : 0.f);
+        }
+        *reinterpret_cast<bf16x8*>(dx + u * 8) = o;
+    }
+}
+
 int grid_for(size_t units) {
     size_t g = (units + 255) / 256;
     if (g > 256 * 16) g = 256 * 16;
@@ -1698,6 +1754,26 @@ extern "C" int otp_gelu_bf16_forward(const void* x, void* y, size_t n, void* str
     if (!x || !y || n % 8) return OTP_ERR_BAD_ARG;
     gelu_bf16_fwd_kernel<<<grid_for(n / 8), 256, 0, static_cast<hipStream_t>(stream)>>>(static_cast<const bf16*>(x),
                                                                                           static_cast<bf16*>(y), n / 8);
+    return otp_launch_status();
+}
+
+extern "C" int otp_gelu_dropout_bf16_forward(const void* x, void* y, void* keep_bits, size_t n, float p, unsigned long long seed,
+                                             void* stream) {
+    if (!x || !y || !keep_bits || n % 8 || !(p >= 0.f) || !(p < 1.f)) return OTP_ERR_BAD_ARG;
+    const uint32_t thr = (uint32_t)(p * 65536.f + 0.5f);
+    gelu_dropout_bf16_fwd_kernel<<<grid_for(n / 8), 256, 0, static_cast<hipStream_t>(stream)>>>(
+        static_cast<const bf16*>(x), static_cast<bf16*>(y), static_cast<unsigned char*>(keep_bits), n / 8, (uint32_t)seed,
+        (uint32_t)(seed >> 32), thr, 65536.f / (float)(65536u - thr));
+    return otp_launch_status();
+}
+
+extern "C" int otp_gelu_dropout_bf16_backward(const void* x, const void* grad_y, const void* keep_bits, void* grad_x, size_t n, float p,
+                                              void* stream) {
+    if (!x || !grad_y || !keep_bits || !grad_x || n % 8 || !(p >= 0.f) || !(p < 1.f)) return OTP_ERR_BAD_ARG;
+    const uint32_t thr = (uint32_t)(p * 65536.f + 0.5f);
+    gelu_dropout_bf16_bwd_kernel<<<grid_for(n / 8), 256, 0, static_cast<hipStream_t>(stream)>>>(
+        static_cast<const bf16*>(x), static_cast<const bf16*>(grad_y), static_cast<const unsigned char*>(keep_bits),
+        static_cast<bf16*>(grad_x), n / 8, 65536.f / (float)(65536u - thr));
     return otp_launch_status();
 }
 

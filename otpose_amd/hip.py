@@ -235,6 +235,8 @@ SIGNATURES = {
     "otp_nhwc_channel_sum": (c_int, [c_void_p] * 3 + [c_size_t, c_size_t, c_int, c_int, c_void_p]),
     "otp_gelu_bf16_forward": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "otp_gelu_bf16_backward": (c_int, [c_void_p] * 3 + [c_size_t, c_void_p]),
+    "otp_gelu_dropout_bf16_forward": (c_int, [c_void_p] * 3 + [c_size_t, ctypes.c_float, ctypes.c_ulonglong, c_void_p]),
+    "otp_gelu_dropout_bf16_backward": (c_int, [c_void_p] * 4 + [c_size_t, ctypes.c_float, c_void_p]),
     "otp_loss_joints_mse": (c_int, [c_void_p] * 5 + [c_void_p, c_size_t] + [c_int] * 6 + [c_void_p]),
 }
 

@@ -623,7 +623,7 @@ class TrainGraphBF16(TrainGraph):
             return super().mlp(p, yn, pdrop)                  # the C = 17 flow encoder / odd lengths stay on the fp32 path
         x = B16.to_nhwc_grad(yn.unsqueeze(2))
         h = B16.conv_bias(x, self._w4(p + ".0.weight"), self.P.get(p + ".0.bias"))
-        h = self.dropout(B16.gelu(h), pdrop)
+        h = B16.gelu_dropout(h, pdrop if self.stochastic else 0.0)          # GELU + Dropout(pdrop) as one pass each way
         o = B16.conv_out(h, self._w4(p + ".3.weight"), self.P.get(p + ".3.bias"))
         return self.dropout(o.squeeze(2), pdrop)
 

@@ -302,6 +302,43 @@ def test_conv_dgrad_with_skip_gradient_is_the_separate_add(case):
     assert torch.equal(fused, plain + res)
 
 
+def test_gelu_dropout_is_gelu_then_dropout_with_repeatable_draws():
+    """otp_gelu_dropout_bf16_*: nn.GELU -> nn.Dropout(p) of the TransformerBlock MLP (model/blocks.py:250-251) in one pass: kept
+    elements carry gelu(x) / (1 - p) (one bf16 rounding), the rest are zero, the keep rate is 1 - p, the gradient passes exactly where
+    the forward kept, a seed repeats its draws and PyTorch's generator seeds them."""
+    from otpose_amd import bf16_ops as B
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(4, 1, 1000, 544, generator=g) * 1.5).to(BF).to(_dev())
+    p = 0.1
+    xf = x.float().requires_grad_()
+    ref = F.gelu(xf) / (1 - 6554 / 65536)
+    xs = x.clone().requires_grad_()
+    y = B.gelu_dropout(xs, p, seed=1234)
+    live = x != 0                                    # (gelu(0) = 0: whether such an element was kept cannot be read off y)
+    kept = (y != 0) | ~live
+    rate = float(kept.float().mean())
+    n = x.numel()
+    assert abs(rate - (1 - 6554 / 65536)) < 5 * (p * (1 - p) / n) ** 0.5 + 2e-3, rate        # (gelu(x) == 0 only at x == 0)
+    err = (y.float() - ref.detach())[kept].abs() / ref.detach()[kept].abs().clamp_min(1e-3)
+    assert float(err.max()) <= 2.0 ** -8
+    # per-channel and per-position rates: no structure along either axis
+    assert float((kept.float().mean((0, 1, 2)) - rate).abs().max()) < 0.03 and float((kept.float().mean((0, 1, 3)) - rate).abs().max()) < 0.08
+    gy = torch.randn(x.shape, generator=g).to(BF).to(_dev())
+    y.backward(gy)
+    ref.backward(gy.float() * kept)
+    gerr = ((xs.grad.float() - xf.grad) * live).abs().max() / xf.grad.abs().max()
+    assert float(gerr) <= 2.0 ** -7
+    # (dropped elements pass nothing; a kept x < -5.9 also has y = -0 in fp32 arithmetic - erff = -1 - and a gradient of ~1e-7)
+    assert float(xs.grad[~kept].float().abs().max()) <= 1e-5
+    assert torch.equal(B.gelu_dropout(x, p, seed=1234), y.detach()) and not torch.equal(B.gelu_dropout(x, p, seed=1235), y.detach())
+    torch.manual_seed(7)
+    a1, a2 = B.gelu_dropout(x, p), B.gelu_dropout(x, p)
+    torch.manual_seed(7)
+    b1 = B.gelu_dropout(x, p)
+    assert torch.equal(a1, b1) and not torch.equal(a1, a2)
+    assert torch.equal(B.gelu_dropout(x, 0.0), B.gelu(x))
+
+
 def test_basic_block_node_matches_two_conv_bn_nodes():
     """BasicBlockFunction against the two ConvBnFunction nodes it replaces (model/HRNet.py:500-531): same launches, so
     the output, the running statistics and every gradient agree exactly - dL/dx included, where the fused node adds the skip
