@@ -610,6 +610,7 @@ struct WgradPlan {
     int RW, rowsMax, XC, ldsG, ldsX, lds;
     int tapmode;           // 1: the LDS image of x is [tap][tile pixel][XC] (each tap's shifted copy of the tile) instead of a window of rows
     int nbTot, cbw;        // N-blocks per workgroup = taps * cbw; cbw = 16-channel blocks of ci per workgroup (3 for 3x3 taps)
+    int cg, spg;           // 1x1 kernels (nhwc_wgrad1x1_kernel): 48-channel co groups per workgroup, ci-block slots per wave and group; 0: not used
 };
 
 __device__ __forceinline__ bf16x4 tr_read(const bf16* p) {
@@ -834,6 +835,111 @@ __global__ __launch_bounds__(256) void nhwc_wgrad_kernel(const bf16* __restrict_
     OTP_STAMP(5);
 }
 
+// 1x1 / stride 1 kernels (the TransformerBlock MLP's projections on (N, 1, T, C) sequences, HRNet's bottleneck / fuse 1x1s).  The kernel
+// above gives a 1x1 layer taps x cbw = 4 .. 12 of its 28 N-block slots and multiplies garbage in the rest (136 -> 544: 21 MFMAs per
+// k-step and wave, 7 of them wanted), and re-stages the x tile once per 48 output channels.  Here the idle slots carry more OUTPUT
+// channels: a workgroup owns CG groups of 48 co x all cbw ci blocks, slot i of a wave = (group i / SPG, ci block wave + 4 (i % SPG)) -
+// (2, 3) for 9 - 12 ci blocks, (3, 2) for 5 - 8, (4, 1) up to 4 - one B fragment serves CG groups.  Tiles are TPX consecutive pixels of an
+// image; both operands are [pixel][channel] LDS images read with the transposing ds_read_b64_tr_b16 as above (rows past the image
+// hold zeros: their loads fall off the descriptor).  Partials leave in the same fragment order.
+template <int CG, int SPG>
+__global__ __launch_bounds__(256) void nhwc_wgrad1x1_kernel(const bf16* __restrict__ x, const bf16* __restrict__ gy,
+                                                             float* __restrict__ part, WgradPlan p) {
+    constexpr int GC = 48 * CG + 8, NS = CG * SPG;
+    static_assert(NS <= WG_NBW, "slots per wave");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16* sG = reinterpret_cast<bf16*>(smem);                 // [TPX px][GC]
+    bf16* sX = reinterpret_cast<bf16*>(smem + p.ldsG);        // [TPX px][XC]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+    int bid = blockIdx.x;
+    const int split = bid % p.splits;
+    bid /= p.splits;
+    const int blk = bid;
+    const int cib = bid % p.nCi, cob = bid / p.nCi;
+    const int co0 = cob * 48 * CG, ci0 = cib * 16 * p.cbw;
+    const int npx = p.Ho * p.Wo, TPX = p.TPX;
+    f32x4 acc[3][NS];
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int i = 0; i < NS; ++i) acc[m][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int q = l15 >> 2, pp = l15 & 3;
+    const int xcu = p.XC / 8 - 1, gcu = 6 * CG;
+    const int gunits = TPX * gcu, xunits = TPX * xcu;
+    const otp_rsrc xres = make_rsrc(x, (size_t)p.N * npx * p.CinS * 2);
+    const otp_rsrc gres = make_rsrc(gy, (size_t)p.N * npx * p.CoutS * 2);
+    for (int i = tid; i < TPX; i += 256) {                     // padding channel groups: zero for the whole kernel
+        *reinterpret_cast<u32x4*>(sX + (size_t)i * p.XC + xcu * 8) = u32x4{0u, 0u, 0u, 0u};
+        *reinterpret_cast<u32x4*>(sG + (size_t)i * GC + 48 * CG) = u32x4{0u, 0u, 0u, 0u};
+    }
+    const int t0 = split * p.tilesPerSplit, t1 = min(t0 + p.tilesPerSplit, p.tilesTotal);
+    for (int t = t0; t < t1; ++t) {
+        const int n = t / p.tilesPerImg, p0 = (t - n * p.tilesPerImg) * TPX, p1 = min(p0 + TPX, npx);
+        __syncthreads();                                        // the previous tile's fragments have been read
+        for (int base = 0; base < gunits; base += 256 * 8) {
+            u32x4 v[8];
+            int dst[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int u = base + j * 256 + tid;
+                const int px = u / gcu, cgi = u - px * gcu;
+                dst[j] = u < gunits ? px * GC + cgi * 8 : -1;
+                const bool ok = u < gunits && p0 + px < p1 && co0 + cgi * 8 < p.CoutS;
+                v[j] = bload16(gres, ok ? ((n * npx + p0 + px) * p.CoutS + co0 + cgi * 8) * 2 : OOB);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (dst[j] >= 0) *reinterpret_cast<u32x4*>(sG + dst[j]) = v[j];
+        }
+        for (int base = 0; base < xunits; base += 256 * 8) {
+            u32x4 v[8];
+            int dst[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int u = base + j * 256 + tid;
+                const int px = u / xcu, cgi = u - px * xcu;
+                dst[j] = u < xunits ? px * p.XC + cgi * 8 : -1;
+                const bool ok = u < xunits && p0 + px < p1 && ci0 + cgi * 8 < p.CinS;
+                v[j] = bload16(xres, ok ? ((n * npx + p0 + px) * p.CinS + ci0 + cgi * 8) * 2 : OOB);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (dst[j] >= 0) *reinterpret_cast<u32x4*>(sX + dst[j]) = v[j];
+        }
+        __syncthreads();
+        for (int k0 = 0; k0 < TPX; k0 += 32) {
+            if (p0 + k0 >= p1) break;                           // uniform: the rest of the tile is past the image
+            const int r0 = k0 + 8 * lg + q;                     // the lane's pixel row of the two transposed reads (r0, r0 + 4)
+            bf16x8 a[CG][3];
+#pragma unroll
+            for (int g = 0; g < CG; ++g)
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    const bf16x4 lo = tr_read(sG + r0 * GC + g * 48 + m * 16 + 4 * pp);
+                    const bf16x4 hi = tr_read(sG + (r0 + 4) * GC + g * 48 + m * 16 + 4 * pp);
+                    a[g][m] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+#pragma unroll
+            for (int j = 0; j < SPG; ++j) {
+                const int xo = (wave + 4 * j) * 16 + 4 * pp;    // (a block past the layer's channels: finite neighbours, discarded)
+                const bf16x4 lo = tr_read(sX + r0 * p.XC + xo);
+                const bf16x4 hi = tr_read(sX + (r0 + 4) * p.XC + xo);
+                const bf16x8 b = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+                for (int g = 0; g < CG; ++g)
+#pragma unroll
+                    for (int m = 0; m < 3; ++m)
+                        acc[m][g * SPG + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[g][m], b, acc[m][g * SPG + j], 0, 0, 0);
+            }
+        }
+    }
+    f32x4* dst = reinterpret_cast<f32x4*>(part) + ((size_t)(split * p.nCo * p.nCi + blk) * 4 + wave) * (WG_NBW * 3 * 64);
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+#pragma unroll
+        for (int m = 0; m < 3; ++m) dst[(i * 3 + m) * 64 + lane] = acc[m][i];
+}
+
 // gw[co][ci][tap] = sum over splits of the fragment-ordered partials.  Threads walk the FRAGMENT order (coalesced reads of
 // the splits x fragments slab, 4 split lanes per fragment element, 8 loads in flight) and scatter the few results.
 __global__ __launch_bounds__(256) void nhwc_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw, WgradPlan p,
@@ -865,7 +971,12 @@ __global__ __launch_bounds__(256) void nhwc_wgrad_reduce_kernel(const float* __r
         const int blk = (int)(q >> 2);
         const int cib = blk % p.nCi, cob = blk / p.nCi;
         const int nb = wave + 4 * i;
-        if (nb < p.nbTot) {
+        if (p.cg > 0) {                                          // nhwc_wgrad1x1_kernel: slot i = (co group i / spg, ci block wave + 4 (i % spg))
+            const int g = i / p.spg, cb = wave + 4 * (i - g * p.spg);
+            const int co = (cob * p.cg + g) * 48 + m * 16 + (lane >> 4) * 4 + r, ci = cib * 16 * p.cbw + cb * 16 + (lane & 15);
+            if (i < p.cg * p.spg && cb < p.cbw && co < p.Cout && ci < p.Cin)
+                gw[(size_t)co * p.Cin + ci] = red[0][e] + red[1][e] + red[2][e] + red[3][e];
+        } else if (nb < p.nbTot) {
             const int tap = nb / p.cbw, cb = nb - tap * p.cbw;
             const int co = cob * 48 + m * 16 + (lane >> 4) * 4 + r, ci = cib * 16 * p.cbw + cb * 16 + (lane & 15);
             if (co < p.Cout && ci < p.Cin)
@@ -888,6 +999,17 @@ bool make_wgrad_plan(const otp_nhwc_conv_desc* d, WgradPlan* p) {
     p->cbw = cbw;
     p->nCo = (c.Cout + 47) / 48, p->nCi = (c.Cin + 16 * cbw - 1) / (16 * cbw);
     p->nbTot = taps * cbw;
+    p->cg = p->spg = 0;
+    {
+        const char* e = getenv("OTPOSE_WGRAD1X1");                 // (=0: 1x1 layers on the general kernel; A/B, tests)
+        if (taps == 1 && c.stride == 1 && c.pad == 0 && !(e && atoi(e) == 0)) {
+            p->spg = (cbw + 3) / 4;                                  // 1 .. 3
+            const int cgmax = p->spg == 1 ? 4 : (p->spg == 2 ? 3 : 2);
+            p->cg = p->nCo < cgmax ? p->nCo : cgmax;
+            if (p->cg < 2) p->cg = p->spg = 0;                       // <= 48 output channels: nothing to add to the general kernel
+            else p->nCo = (c.Cout + 48 * p->cg - 1) / (48 * p->cg);
+        }
+    }
     // a pointwise conv sees the image as rows of 128 / 64 / 32 pixels (when that divides it): a tile's window is then the
     // tile itself instead of the full-width image rows it touches
     if (taps == 1 && c.stride == 1 && c.pad == 0) {
@@ -915,12 +1037,12 @@ bool make_wgrad_plan(const otp_nhwc_conv_desc* d, WgradPlan* p) {
             int rowsOut = c.Wo % tpx == 0 ? 1 : (tpx % c.Wo == 0 ? tpx / c.Wo : (tpx - 1 + c.Wo - 1) / c.Wo + 1);
             if (rowsOut > c.Ho) rowsOut = c.Ho;
             const int rows = (rowsOut - 1) * c.stride + (c.kh - 1) * c.dil + 1;
-            const int ldsG = tpx * 56 * 2;
+            const int ldsG = tpx * (p->cg > 0 ? 48 * p->cg + 8 : 56) * 2;
             const int winX = round_up(rows * p->RW * p->XC * 2, 16) + 128, tapX = taps * tpx * p->XC * 2 + 128;
             const int limit = pass == 0 ? 80 * 1024 : OTP_LDS_LIMIT;
             // the window of rows unless each tap's copy of the tile is smaller (wide dilations, strided wide maps)
             const bool tapm = taps > 1 && tapX < winX;
-            const int ldsX = tapm ? tapX : winX;
+            const int ldsX = p->cg > 0 ? tpx * p->XC * 2 + 128 : (tapm ? tapX : winX);      // (1x1 kernel: the tile itself)
             if (ldsG + ldsX <= limit) {
                 p->TPX = tpx, p->rowsMax = rows, p->ldsG = ldsG, p->ldsX = ldsX, p->lds = ldsG + ldsX, p->tapmode = tapm;
                 found = true;
@@ -1579,7 +1701,16 @@ extern "C" int otp_nhwc_wgrad_bf16(const void* x, const void* gy, void* grad_wei
     const int xunits = p.rowsMax * p.RW * (p.XC / 8 - 1);
     const bool pf = !p.tapmode && xunits <= WG_XU * 256 && p.TPX * 6 <= WG_GU * 256;
     const int grid = p.nCo * p.nCi * p.splits;
-    if (pf) {
+    if (p.cg > 0) {
+#define OTP_W1_CASE(CG_, SPG_)                                                                                                  \
+    if (p.cg == CG_ && p.spg == SPG_) {                                                                                         \
+        OTP_ALLOW_BIG_LDS((nhwc_wgrad1x1_kernel<CG_, SPG_>), p.lds);                                                            \
+        nhwc_wgrad1x1_kernel<CG_, SPG_><<<grid, 256, p.lds, st>>>(static_cast<const bf16*>(x), static_cast<const bf16*>(gy),   \
+                                                                  static_cast<float*>(workspace), p);                          \
+    }
+        OTP_W1_CASE(2, 1) OTP_W1_CASE(3, 1) OTP_W1_CASE(4, 1) OTP_W1_CASE(2, 2) OTP_W1_CASE(3, 2) OTP_W1_CASE(2, 3)
+#undef OTP_W1_CASE
+    } else if (pf) {
         OTP_ALLOW_BIG_LDS(nhwc_wgrad_kernel<true>, p.lds);
         nhwc_wgrad_kernel<true><<<grid, 256, p.lds, st>>>(static_cast<const bf16*>(x), static_cast<const bf16*>(gy),
                                                            static_cast<float*>(workspace), p);

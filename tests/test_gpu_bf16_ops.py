@@ -154,10 +154,15 @@ def test_sequence_pointwise_convs_forward_and_input_gradient(case, monkeypatch):
         o32, _, _ = B.conv_forward(xd, wd, bd, 1, 0, 1, out_mode=1)
         gx = B.conv_dgrad(gyd, wd, (1, t), 1, 0, 1)
         gxr = B.conv_dgrad(gyd, wd, (1, t), 1, 0, 1, res=resd)
+        monkeypatch.setenv("OTPOSE_WGRAD1X1", hb)                # (the co-group 1x1 weight-gradient kernel against the general one)
+        gw = B.conv_wgrad(xd, gyd, tuple(wt.shape), 1, 0, 1).cpu()
         torch.cuda.synchronize()
         assert torch.equal(gxr, gx + resd)
+        gwr = torch.nn.grad.conv2d_weight(x.double(), wt.shape, gy.double()).float()
+        assert float((gw - gwr).abs().max()) <= 2e-5 * max(1.0, float(gwr.abs().max())), hb
         got[hb] = (_nchw(o16, cout), o32.cpu(), _nchw(gx, cin))
     monkeypatch.delenv("OTPOSE_NHWC_HB")
+    monkeypatch.delenv("OTPOSE_WGRAD1X1")
     for hb in ("1", "0"):
         o16, o32, gx = got[hb]
         assert float((o16 - ref).abs().max()) <= 2.0 ** -8 * float(ref.abs().max()), hb
