@@ -707,6 +707,7 @@ struct HPw {
     int o_tot, o_off;                                             // fp32 NCHW output: channels of the tensor / first channel
     float post;
     unsigned* rflag;
+    float* stats;                                                 // bf16 build: per-tile channel sums [tiles of 128 pixels][2][Cout] of the stored values, or NULL
 };
 
 template <int BLKB>
@@ -730,8 +731,11 @@ __host__ __device__ constexpr int hpw_blkb(int KS) { return otp_hbpw_blkb(KS); }
 template <int KS>
 __global__ __launch_bounds__(256, KS <= 4 ? 4 : (KS <= 8 ? 3 : 2)) void h16_pointwise_kernel(HPw A) {
     constexpr int BLKB = hpw_blkb(KS);
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];     // 2 BLKB + HPW_MAXC * 4
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];     // 2 BLKB + HPW_MAXC * 4 (+ 4 waves x 2 x 32 floats: statistics)
     float* shl = reinterpret_cast<float*>(lds + 2 * BLKB);
+#ifdef OTP_H16_BF16
+    float* sred = shl + HPW_MAXC;                                            // [2 buffers][4 waves][2][32]
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kq = lane >> 4, n16 = lane & 15;
     hpw_stage<BLKB>(A.packed, lds);
     for (int i = tid; i < HPW_MAXC; i += 256) shl[i] = (A.shift && i < A.Cout) ? A.shift[i] : 0.f;
@@ -791,6 +795,9 @@ __global__ __launch_bounds__(256, KS <= 4 ? 4 : (KS <= 8 ? 3 : 2)) void h16_poin
         }
         const f32x4 sh0 = *reinterpret_cast<const f32x4*>(shl + (c8 & (HPW_MAXC - 1)));
         const f32x4 sh1 = *reinterpret_cast<const f32x4*>(shl + ((c8 + 4) & (HPW_MAXC - 1)));
+#ifdef OTP_H16_BF16
+        float st1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, st2[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#endif
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const f32x2 r0 = hwiden(rq[h][0]), r1 = hwiden(rq[h][1]), r2 = hwiden(rq[h][2]), r3 = hwiden(rq[h][3]);
@@ -819,6 +826,21 @@ __global__ __launch_bounds__(256, KS <= 4 ? 4 : (KS <= 8 ? 3 : 2)) void h16_poin
                 bad |= otp_out_of_range(f[e]);
                 f[e] = fmaxf(f[e], lo_clamp);
             }
+#ifdef OTP_H16_BF16
+            if (A.stats) {
+                // per-tile channel sums of the ROUNDED values (csrc/nhwc.hip's contract: what BatchNorm will normalise): the 16 lanes of
+                // a DPP row hold 16 pixels of the lane's 8 channels
+                const u32x4 qv = hpack8((const float(&)[8])f);
+                const f32x2 w0 = hwiden(qv[0]), w1 = hwiden(qv[1]), w2 = hwiden(qv[2]), w3 = hwiden(qv[3]);
+                const float g[8] = {w0.x, w0.y, w1.x, w1.y, w2.x, w2.y, w3.x, w3.y};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float v = pv[h] ? g[e] : 0.f;
+                    st1[e] += v;
+                    st2[e] += v * v;
+                }
+            }
+#endif
             if (cl && pv[h]) {
                 if (A.f32out) {
                     float* o = reinterpret_cast<float*>(A.out) + ((size_t)img[h] * A.o_tot + A.o_off + c8) * A.HW + pix[h];
@@ -830,9 +852,36 @@ __global__ __launch_bounds__(256, KS <= 4 ? 4 : (KS <= 8 ? 3 : 2)) void h16_poin
                 }
             }
         }
+#ifdef OTP_H16_BF16
+        if (A.stats) {
+            float* sr = sred + (blk & 1) * 256;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float a = hrow16_sum(st1[e]), b = hrow16_sum(st2[e]);
+                if (n16 == 0) {
+                    sr[(wave * 2 + 0) * 32 + 8 * kq + e] = a;
+                    sr[(wave * 2 + 1) * 32 + 8 * kq + e] = b;
+                }
+            }
+        }
+#endif
+#ifdef OTP_H16_BF16
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the next block has landed, this block's stores and partial sums have left
+#else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next block has landed (and this block's stores have left)
+#endif
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+#ifdef OTP_H16_BF16
+        if (A.stats && tid < 64) {
+            // the four waves' partials in a fixed order; the buffer alternates, so the next block's writes cannot overtake these reads
+            const float* sr = sred + (blk & 1) * 256;
+            const int which = tid >> 5, c = tid & 31, co = 32 * blk + c;
+            if (co < A.Cout)
+                A.stats[((size_t)blockIdx.x * 2 + which) * A.Cout + co] =
+                    sr[(0 * 2 + which) * 32 + c] + sr[(1 * 2 + which) * 32 + c] + sr[(2 * 2 + which) * 32 + c] + sr[(3 * 2 + which) * 32 + c];
+        }
+#endif
     }
 #ifndef OTP_H16_BF16
     otp_range_report(A.rflag, bad, OTP_RANGE_H16);
@@ -844,7 +893,11 @@ __global__ __launch_bounds__(256, KS <= 4 ? 4 : (KS <= 8 ? 3 : 2)) void h16_poin
 template <int KS>
 int hpw_launch(const HPw& a, hipStream_t st) {
     auto kern = h16_pointwise_kernel<KS>;
+#ifdef OTP_H16_BF16
+    const size_t need = 2 * (size_t)hpw_blkb(KS) + HPW_MAXC * 4 + 2 * 256 * 4;
+#else
     const size_t need = 2 * (size_t)hpw_blkb(KS) + HPW_MAXC * 4;
+#endif
     OTP_ALLOW_BIG_LDS(kern, need);
     hipLaunchKernelGGL(kern, dim3((unsigned)((a.total + 127) / 128)), dim3(256), need, st, a);
     return otp_launch_status();
@@ -1326,9 +1379,12 @@ bool otp_hbpw_supported(const otp_nhwc_conv_desc* d) {
     return (size_t)d->N * d->H * d->W < (1ull << 31);
 }
 
-int otp_hbpw_conv(const void* x, const void* wpacked, const void* bias, const void* res, void* out, const otp_nhwc_conv_desc* d,
-                  hipStream_t stream) {
+int otp_hbpw_stats_rows(const otp_nhwc_conv_desc* d) { return otp_hbpw_supported(d) ? (d->N * d->H * d->W + 127) / 128 : 0; }
+
+int otp_hbpw_conv(const void* x, const void* wpacked, const void* bias, const void* res, void* out, void* stats,
+                  const otp_nhwc_conv_desc* d, hipStream_t stream) {
     if (!otp_hbpw_supported(d)) return OTP_ERR_UNSUPPORTED;
+    if (stats && d->out_mode != 0) return OTP_ERR_BAD_ARG;
     if (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(wpacked) | reinterpret_cast<uintptr_t>(res)) & 15) ||
         (reinterpret_cast<uintptr_t>(out) & (d->out_mode ? 3 : 15)) || (reinterpret_cast<uintptr_t>(bias) & 3))
         return OTP_ERR_UNSUPPORTED;
@@ -1345,6 +1401,7 @@ int otp_hbpw_conv(const void* x, const void* wpacked, const void* bias, const vo
     a.o_tot = d->Cout, a.o_off = 0;
     a.post = 1.f;
     a.rflag = nullptr;
+    a.stats = static_cast<float*>(stats);
     switch (otp_hbpw_ks(d->Cin)) {
         case 2: return hpw_launch<2>(a, stream);
         case 4: return hpw_launch<4>(a, stream);

@@ -44,8 +44,9 @@ inline int otp_hbpw_ks(int Cin) {               // the instantiated k-step count
     return k <= 2 ? 2 : (k <= 4 ? 4 : (k == 5 ? 5 : (k <= 8 ? 8 : (k <= 12 ? 12 : (k <= 17 ? 17 : 0)))));
 }
 bool otp_hbpw_supported(const otp_nhwc_conv_desc* d);              /* 1x1 / stride 1 / pad 0, Cin % 8 == 0, Cout % 8 == 0, NHWC bf16 or NCHW fp32 result */
-int otp_hbpw_conv(const void* x, const void* wpacked, const void* bias, const void* res, void* out, const otp_nhwc_conv_desc* d,
-                  hipStream_t stream);
+int otp_hbpw_stats_rows(const otp_nhwc_conv_desc* d);              /* rows of the statistics buffer [rows][2][Cout] = 128-pixel tiles */
+int otp_hbpw_conv(const void* x, const void* wpacked, const void* bias, const void* res, void* out, void* stats,
+                  const otp_nhwc_conv_desc* d, hipStream_t stream);
 
 // implemented in csrc/hb.hip
 bool otp_hb_supported(const otp_nhwc_conv_desc* d);                /* 3x3 / pad 1 / dilation 1 / stride 1 or 2, NHWC bf16 result, Cin % 16 == 0, Cout % 8 == 0 */

@@ -185,13 +185,19 @@ bool use_hb(const otp_nhwc_conv_desc* d) {
     return mode != 0 && d && (mode == 2 || otp_hb_pays(d)) && otp_hb_supported(d);
 }
 
-// 1x1 convolutions of (N, 1, T, C) sequences - the two projections of a TransformerBlock's MLP and their input gradients - run on
-// csrc/hb.hip's pointwise kernel (the input register-resident, the weights streamed through the LDS): nhwc_conv_kernel re-stages
+// 1x1 convolutions - the two projections of a TransformerBlock's MLP on (N, 1, T, C) sequences, HRNet's bottleneck / fuse 1x1s, and
+// their input gradients - run on csrc/hb.hip's pointwise kernel (the input register-resident, the weights streamed through the LDS): nhwc_conv_kernel re-stages
 // 46 KB of weights per 128-token tile and 136-channel chunk with one workgroup per CU (134 / 214 us per projection at cfg2).
+// Image-shaped 1x1 layers (HRNet's bottleneck and fuse 1x1s, with BatchNorm statistics) too: forward / input gradient at 80 frames
+// (tools/bf16_conv_bench.py, OTPOSE_NHWC_HB=2 against =0) 256 -> 64 @96x72 80.8 / 94.2 us against 174 / 141, 64 -> 256 106.7 / 81.7 against
+// 156 / 176, 96 -> 48 @48x36 12.1 against 30.0, 384 -> 48 @12x9 8.9 against 31.7 - every shape measured.
+bool hbpw_pays(const otp_nhwc_conv_desc*) { return true; }
 bool use_hbpw(const otp_nhwc_conv_desc* d) {
     const char* e = getenv("OTPOSE_NHWC_HB");
     const char* e2 = getenv("OTPOSE_NHWC_HBPW");                   // (=0: only the 1x1 kernel off)
-    return !(e && atoi(e) == 0) && !(e2 && atoi(e2) == 0) && d && d->H == 1 && otp_hbpw_supported(d);
+    const int mode = e ? atoi(e) : 1;
+    if (mode == 0 || (e2 && atoi(e2) == 0) || !d) return false;
+    return (mode == 2 || d->H == 1 || hbpw_pays(d)) && otp_hbpw_supported(d);
 }
 
 __device__ __forceinline__ float pack_hbpw_value(const float* __restrict__ w, const PackJob& jb, size_t i) {
@@ -1596,6 +1602,7 @@ extern "C" size_t otp_nhwc_conv_weight_bytes(const otp_nhwc_conv_desc* d) {
 extern "C" int otp_nhwc_conv_stats_rows(const otp_nhwc_conv_desc* d) {
     ConvPlan p;
     if (use_hb(d)) return otp_hb_stats_rows(d);
+    if (use_hbpw(d)) return otp_hbpw_stats_rows(d);
     return make_plan(d, &p) ? p.N * p.tilesPerImg : 0;
 }
 
@@ -1669,7 +1676,7 @@ extern "C" int otp_nhwc_conv_bf16_res(const void* x, const void* wpacked, const 
     if (res && (p.out_mode != 0 || stats)) return OTP_ERR_BAD_ARG;   // the sum is an NHWC bf16 tensor; statistics are of conv(x)
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (use_hb(d)) return otp_hb_conv(x, wpacked, bias, res, out, stats, d, st);
-    if (use_hbpw(d)) return stats ? OTP_ERR_UNSUPPORTED : otp_hbpw_conv(x, wpacked, bias, res, out, d, st);
+    if (use_hbpw(d)) return otp_hbpw_conv(x, wpacked, bias, res, out, stats, d, st);
 #define OTP_NHWC_CASE(mb, nb) \
     if (p.MB == mb && p.NB == nb) return launch_conv<mb, nb>(p, x, wpacked, bias, res, out, stats, st)
     OTP_NHWC_CASE(1, 2); OTP_NHWC_CASE(2, 2); OTP_NHWC_CASE(3, 2); OTP_NHWC_CASE(4, 2); OTP_NHWC_CASE(5, 2); OTP_NHWC_CASE(6, 2);
