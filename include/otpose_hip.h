@@ -704,6 +704,16 @@ int otp_gelu_bf16_backward(const void* x, const void* grad_y, void* grad_x, size
  * (n % 8 == 0): y = keep ? gelu(x) / (1 - p') : 0 with p' = round(65536 p) / 65536, rounded once; keep_bits (n / 8 bytes) receives
  * the decisions, bit j of byte u = element 8 u + j.  The draws are a counter-based hash of (element index, seed): the same seed
  * repeats them.  The backward takes the bits: grad_x = keep ? grad_y * gelu'(x) / (1 - p') : 0. */
+/* The same MLP interior with those passes folded into the projections' launches (1x1 convolutions of (N, 1, T, C) sequences):
+ * otp_nhwc_mlp_up_bf16: pre = bf16(conv(x) + bias) and act = dropout(gelu(pre), p) + keep_bits in one launch (gelu through a 6e-5 fit of
+ * the normal CDF - the value is rounded to bfloat16); otp_nhwc_mlp_down_dgrad_bf16: grad_pre = keep ? dgrad(gy) * gelu'(pre) / (1 - p') : 0
+ * in one launch, `desc` / `wpacked` being the input-gradient convolution of the down-projection (otp_nhwc_conv_pack(.., dgrad = 1)).
+ * otp_nhwc_mlp_fused_supported: the shape runs on the kernel that has these epilogues (else the caller keeps the separate launches). */
+int otp_nhwc_mlp_fused_supported(const otp_nhwc_conv_desc* desc);
+int otp_nhwc_mlp_up_bf16(const void* x, const void* wpacked, const void* bias, void* pre, void* act, void* keep_bits, float p,
+                         unsigned long long seed, const otp_nhwc_conv_desc* desc, void* stream);
+int otp_nhwc_mlp_down_dgrad_bf16(const void* gy, const void* wpacked, const void* pre, const void* keep_bits, void* grad_pre, float p,
+                                 const otp_nhwc_conv_desc* desc, void* stream);
 int otp_gelu_dropout_bf16_forward(const void* x, void* y, void* keep_bits, size_t n, float p, unsigned long long seed, void* stream);
 int otp_gelu_dropout_bf16_backward(const void* x, const void* grad_y, const void* keep_bits, void* grad_x, size_t n, float p,
                                    void* stream);

@@ -579,6 +579,74 @@ def gelu_dropout(x, p, seed=None):
     return GeluDropoutFunction.apply(x, p, _draw_seed(x.device) if seed is None else seed)
 
 
+class MlpInteriorFunction(Function):
+    """``conv1x1(W2, dropout(gelu(conv1x1(W1, x) + b1), p)) + b2`` - the interior of a TransformerBlock MLP (model/blocks.py:248-254) on
+    the (B, 1, T, C) bf16 view of a sequence, fp32 (B, C, 1, T) result - as ONE autograd node whose element-wise passes ride in the
+    projections' launches (``otp_nhwc_mlp_up_bf16``: the up-projection stores its result and dropout(gelu(result)) together;
+    ``otp_nhwc_mlp_down_dgrad_bf16``: the down-projection's input gradient leaves multiplied by gelu' and the dropout factor).  Against
+    the chain conv_bias -> gelu_dropout -> conv_out: one 240 MB pass less forward, one 360 MB pass less backward, same saved tensors."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, p, seed):
+        _require_gpu(x, w1, w2)
+        x = x.contiguous()
+        n, h, w, _ = x.shape
+        hid, cin = w1.shape[:2]
+        cout = w2.shape[0]
+        L = hip.lib()
+        ctx.packs = _ACTIVE_PACKS
+        d1 = _desc(n, h, w, cin, hid, 1, 1, 1, 0, 1, 0)
+        wp1 = _pack(w1.contiguous(), d1, 0, ctx.packs)
+        pre = _new((n, h, w, cs(hid)), BF16, x)
+        act = torch.empty_like(pre)
+        keep = torch.empty(pre.numel() // 8, dtype=torch.uint8, device=x.device)
+        hip.check(L.otp_nhwc_mlp_up_bf16(hip.ptr(x), hip.ptr(wp1), hip.ptr(b1), hip.ptr(pre), hip.ptr(act), hip.ptr(keep), float(p),
+                                         int(seed), ctypes.byref(d1), hip.stream_of(x)), "otp_nhwc_mlp_up_bf16")
+        out, _, _ = conv_forward(act, w2, b2, 1, 0, 1, out_mode=1, packs=ctx.packs)
+        ctx.save_for_backward(x, pre, act, keep, w1, w2)
+        ctx.p = float(p)
+        ctx.params = (w1, b1, w2, b2)
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        from .train_ops import channel_sum
+        x, pre, act, keep, w1, w2 = ctx.saved_tensors
+        pw1, pb1, pw2, pb2 = ctx.params
+        n, h, w, _ = x.shape
+        hid, cin = w1.shape[:2]
+        cout = w2.shape[0]
+        L = hip.lib()
+        go = go.contiguous()
+        g = to_nhwc(go)
+        # d(pre) = dropout'/gelu' (.) dgrad of the down-projection: one launch
+        dd = _desc(n, h, w, cout, hid, 1, 1, 1, 0, 1, 0)
+        wpd = _pack(w2.contiguous(), dd, 1, ctx.packs)
+        dpre = torch.empty_like(pre)
+        hip.check(L.otp_nhwc_mlp_down_dgrad_bf16(hip.ptr(g), hip.ptr(wpd), hip.ptr(pre), hip.ptr(keep), hip.ptr(dpre), ctx.p,
+                                                 ctypes.byref(dd), hip.stream_of(g)), "otp_nhwc_mlp_down_dgrad_bf16")
+        gw2 = conv_wgrad(act, g, w2.shape, 1, 0, 1, grad_slot(pw2)) if ctx.needs_input_grad[3] else None
+        gb2 = channel_sum(go, grad_slot(pb2)) if pb2 is not None and ctx.needs_input_grad[4] else None
+        gx = conv_dgrad(dpre, w1, (h, w), 1, 0, 1, ctx.packs) if ctx.needs_input_grad[0] else None
+        gw1 = conv_wgrad(x, dpre, w1.shape, 1, 0, 1, grad_slot(pw1)) if ctx.needs_input_grad[1] else None
+        gb1 = channel_sum_nhwc(dpre, hid, grad_slot(pb1)) if pb1 is not None and ctx.needs_input_grad[2] else None
+        return gx, gw1, gb1, gw2, gb2, None, None
+
+
+def mlp_interior_supported(x, w1, w2):
+    """Both projections of this MLP run on the kernel that carries the fused epilogues (``otp_nhwc_mlp_fused_supported``)."""
+    n, h, w, _ = x.shape
+    hid, cin = w1.shape[:2]
+    L = hip.lib()
+    return bool(L.otp_nhwc_mlp_fused_supported(ctypes.byref(_desc(n, h, w, cin, hid, 1, 1, 1, 0, 1, 0)))
+                and L.otp_nhwc_mlp_fused_supported(ctypes.byref(_desc(n, h, w, w2.shape[0], hid, 1, 1, 1, 0, 1, 0))))
+
+
+def mlp_interior(x, w1, b1, w2, b2, p, seed=None):
+    """The MLP interior on a (B, 1, T, CS) bf16 tensor -> (B, C, 1, T) fp32; ``p`` = dropout rate behind the GELU (0: none)."""
+    return MlpInteriorFunction.apply(x, w1, b1, w2, b2, p, _draw_seed(x.device) if (seed is None and p > 0.0) else (seed or 0))
+
+
 class ToNhwcFunction(Function):
     """(N, C, H, W) fp32 -> (N, H, W, CS) bf16 with the matching gradient conversion (the precision / layout hand-over
     in front of a bf16 sub-graph)."""

@@ -708,6 +708,7 @@ struct HPw {
     float post;
     unsigned* rflag;
     float* stats;                                                 // bf16 build: per-tile channel sums [tiles of 128 pixels][2][Cout] of the stored values, or NULL
+    otp_hbpw_epi epi;                                             // bf16 build: the MLP epilogues (csrc/hb.h); mode 0: none
 };
 
 template <int BLKB>
@@ -827,6 +828,21 @@ __global__ __launch_bounds__(256, KS <= 4 ? 4 : (KS <= 8 ? 3 : 2)) void h16_poin
                 f[e] = fmaxf(f[e], lo_clamp);
             }
 #ifdef OTP_H16_BF16
+            if (A.epi.mode == 2) {
+                // input gradient of the MLP's down-projection: times gelu'(pre-activation) and the dropout factor of the forward
+                const size_t eo = A.o_base + img[h] * A.o_imgB + (c8 >> 3) * A.o_gS + pix[h] * A.o_pS;
+                const bool lv = cl && pv[h];
+                const u32x4 hq = lv ? *reinterpret_cast<const u32x4*>(static_cast<const unsigned char*>(A.epi.aux) + eo) : (u32x4){0u, 0u, 0u, 0u};
+                const unsigned bits = lv ? A.epi.keep[eo >> 4] : 0u;
+                const f32x2 h0 = hwiden(hq[0]), h1 = hwiden(hq[1]), h2 = hwiden(hq[2]), h3 = hwiden(hq[3]);
+                const float hv[8] = {h0.x, h0.y, h1.x, h1.y, h2.x, h2.y, h3.x, h3.y};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float x = hv[e];
+                    const float d = otp_phi_fast(x) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+                    f[e] = ((bits >> e) & 1u) ? f[e] * A.epi.scale * d : 0.f;
+                }
+            }
             if (A.stats) {
                 // per-tile channel sums of the ROUNDED values (csrc/nhwc.hip's contract: what BatchNorm will normalise): the 16 lanes of
                 // a DPP row hold 16 pixels of the lane's 8 channels
@@ -848,7 +864,22 @@ __global__ __launch_bounds__(256, KS <= 4 ? 4 : (KS <= 8 ? 3 : 2)) void h16_poin
                     for (int e = 0; e < 8; ++e)
                         if (c8 + e < A.Cout) o[(size_t)e * A.HW] = f[e];
                 } else {
-                    *reinterpret_cast<u32x4*>(A.out + A.o_base + img[h] * A.o_imgB + (c8 >> 3) * A.o_gS + pix[h] * A.o_pS) = hpack8(f);
+                    const size_t eo = A.o_base + img[h] * A.o_imgB + (c8 >> 3) * A.o_gS + pix[h] * A.o_pS;
+                    const u32x4 rec = hpack8(f);
+                    *reinterpret_cast<u32x4*>(A.out + eo) = rec;
+#ifdef OTP_H16_BF16
+                    if (A.epi.mode == 1) {
+                        // dropout(gelu(.)) of the ROUNDED result (what a separate pass over the stored tensor computes), one rounding
+                        const f32x2 w0 = hwiden(rec[0]), w1 = hwiden(rec[1]), w2 = hwiden(rec[2]), w3 = hwiden(rec[3]);
+                        const float hv[8] = {w0.x, w0.y, w1.x, w1.y, w2.x, w2.y, w3.x, w3.y};
+                        const unsigned bits = otp_drop_keep8(eo >> 4, A.epi.s0, A.epi.s1, A.epi.thr);
+                        float g[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) g[e] = ((bits >> e) & 1u) ? hv[e] * otp_phi_fast(hv[e]) * A.epi.scale : 0.f;
+                        *reinterpret_cast<u32x4*>(static_cast<unsigned char*>(A.epi.out2) + eo) = hpack8(g);
+                        A.epi.keep[eo >> 4] = (unsigned char)bits;
+                    }
+#endif
                 }
             }
         }
@@ -1382,9 +1413,12 @@ bool otp_hbpw_supported(const otp_nhwc_conv_desc* d) {
 int otp_hbpw_stats_rows(const otp_nhwc_conv_desc* d) { return otp_hbpw_supported(d) ? (d->N * d->H * d->W + 127) / 128 : 0; }
 
 int otp_hbpw_conv(const void* x, const void* wpacked, const void* bias, const void* res, void* out, void* stats,
-                  const otp_nhwc_conv_desc* d, hipStream_t stream) {
+                  const otp_nhwc_conv_desc* d, hipStream_t stream, const otp_hbpw_epi* epi) {
     if (!otp_hbpw_supported(d)) return OTP_ERR_UNSUPPORTED;
     if (stats && d->out_mode != 0) return OTP_ERR_BAD_ARG;
+    if (epi && epi->mode && (d->out_mode != 0 || stats || res || !epi->keep || (epi->mode == 1 ? !epi->out2 : !epi->aux) ||
+                             ((reinterpret_cast<uintptr_t>(epi->out2) | reinterpret_cast<uintptr_t>(epi->aux)) & 15)))
+        return OTP_ERR_BAD_ARG;
     if (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(wpacked) | reinterpret_cast<uintptr_t>(res)) & 15) ||
         (reinterpret_cast<uintptr_t>(out) & (d->out_mode ? 3 : 15)) || (reinterpret_cast<uintptr_t>(bias) & 3))
         return OTP_ERR_UNSUPPORTED;
@@ -1402,6 +1436,7 @@ int otp_hbpw_conv(const void* x, const void* wpacked, const void* bias, const vo
     a.post = 1.f;
     a.rflag = nullptr;
     a.stats = static_cast<float*>(stats);
+    if (epi) a.epi = *epi;
     switch (otp_hbpw_ks(d->Cin)) {
         case 2: return hpw_launch<2>(a, stream);
         case 4: return hpw_launch<4>(a, stream);

@@ -43,10 +43,56 @@ inline int otp_hbpw_ks(int Cin) {               // the instantiated k-step count
     const int k = (Cin + 31) / 32;
     return k <= 2 ? 2 : (k <= 4 ? 4 : (k == 5 ? 5 : (k <= 8 ? 8 : (k <= 12 ? 12 : (k <= 17 ? 17 : 0)))));
 }
+// Dropout draws of the bf16 training path (csrc/nhwc.hip: gelu_dropout_bf16_*, csrc/hb.hip: the MLP up-projection's epilogue): a
+// counter-based hash of (element pair, seed), two 16-bit uniforms per 32-bit hash (lowbias32 finaliser), keep <=> u16 >= round(65536 p).
+// Unit u = elements 8 u .. 8 u + 7 of the tensor; bit j of the result = element 8 u + j is kept.
+__device__ __forceinline__ uint32_t otp_drop_hash(size_t pair, uint32_t s0, uint32_t s1) {
+    uint32_t h = (uint32_t)pair * 0x9E3779B1u + s0;
+    h ^= ((uint32_t)(pair >> 32) + s1) * 0x85EBCA77u;
+    h ^= h >> 16; h *= 0x21F0AAADu; h ^= h >> 15; h *= 0x735A2D97u; h ^= h >> 15;
+    return h;
+}
+__device__ __forceinline__ unsigned otp_drop_keep8(size_t u, uint32_t s0, uint32_t s1, uint32_t thr) {
+    unsigned bits = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t h = otp_drop_hash(u * 4 + k, s0, s1);
+        bits |= ((h & 0xFFFFu) >= thr ? 1u : 0u) << (2 * k);
+        bits |= ((h >> 16) >= thr ? 1u : 0u) << (2 * k + 1);
+    }
+    return bits;
+}
+// Phi(x) to 6e-5 (csrc/mlpx.hip: mx_gelu_h's fit, 11 plain vector instructions): 0.5 + xc R(xc^2), xc = clamp(x, +-4.2) - for values that
+// are rounded to bfloat16 (2^-9) afterwards
+__device__ __forceinline__ float otp_phi_fast(float x) {
+    const float xc = __builtin_amdgcn_fmed3f(x, -4.2f, 4.2f), s2 = xc * xc;
+    float r = 4.711542158e-11f;
+    r = r * s2 + -4.627826316e-09f;
+    r = r * s2 + 2.017249231e-07f;
+    r = r * s2 + -5.191738396e-06f;
+    r = r * s2 + 8.882890530e-05f;
+    r = r * s2 + -1.080400373e-03f;
+    r = r * s2 + 9.720675326e-03f;
+    r = r * s2 + -6.618899545e-02f;
+    r = r * s2 + 3.988157481e-01f;
+    return xc * r + 0.5f;
+}
+
+// epilogue of the pointwise kernel for the TransformerBlock MLP (model/blocks.py:248-254): mode 1 = the up-projection, which stores its
+// result (`out`, the pre-activation the backward needs) AND dropout(gelu(result)) (`out2`, + the keep bits); mode 2 = the down-projection's
+// input gradient, multiplied by gelu'(pre-activation `aux`) and the kept / (1 - p) factor before it is stored
+struct otp_hbpw_epi {
+    int mode;
+    void* out2;
+    unsigned char* keep;
+    const void* aux;
+    uint32_t s0, s1, thr;
+    float scale;
+};
 bool otp_hbpw_supported(const otp_nhwc_conv_desc* d);              /* 1x1 / stride 1 / pad 0, Cin % 8 == 0, Cout % 8 == 0, NHWC bf16 or NCHW fp32 result */
 int otp_hbpw_stats_rows(const otp_nhwc_conv_desc* d);              /* rows of the statistics buffer [rows][2][Cout] = 128-pixel tiles */
 int otp_hbpw_conv(const void* x, const void* wpacked, const void* bias, const void* res, void* out, void* stats,
-                  const otp_nhwc_conv_desc* d, hipStream_t stream);
+                  const otp_nhwc_conv_desc* d, hipStream_t stream, const otp_hbpw_epi* epi = nullptr);
 
 // implemented in csrc/hb.hip
 bool otp_hb_supported(const otp_nhwc_conv_desc* d);                /* 3x3 / pad 1 / dilation 1 / stride 1 or 2, NHWC bf16 result, Cin % 16 == 0, Cout % 8 == 0 */

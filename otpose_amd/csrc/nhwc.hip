@@ -1519,30 +1519,14 @@ __global__ __launch_bounds__(256) void gelu_bf16_bwd_kernel(const bf16* __restri
 // GELU followed by Dropout(p) (model/blocks.py:250-251) as one pass: y = keep ? gelu(x) / (1 - p) : 0, one rounding, plus the keep
 // decisions as one bit per element (a byte per 8-element unit) for the backward - the separate launches cost a 240 MB pass forward
 // (fused_dropout) and a 360 MB one backward (masked_scale) per MLP.  Draws: a counter-based hash of (element pair, seed), two 16-bit
-// uniforms per 32-bit hash (lowbias32 finaliser), keep <=> u16 >= round(65536 p); the seed comes from PyTorch's CUDA generator
+// uniforms per 32-bit hash (csrc/hb.h: otp_drop_keep8), keep <=> u16 >= round(65536 p); the seed comes from PyTorch's CUDA generator
 // (bf16_ops.gelu_dropout), so torch.manual_seed reproduces a step.
-__device__ __forceinline__ uint32_t drop_hash(size_t pair, uint32_t s0, uint32_t s1) {
-    uint32_t h = (uint32_t)pair * 0x9E3779B1u + s0;
-    h ^= ((uint32_t)(pair >> 32) + s1) * 0x85EBCA77u;
-    h ^= h >> 16; h *= 0x21F0AAADu; h ^= h >> 15; h *= 0x735A2D97u; h ^= h >> 15;
-    return h;
-}
-__device__ __forceinline__ unsigned drop_keep8(size_t u, uint32_t s0, uint32_t s1, uint32_t thr) {
-    unsigned bits = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t h = drop_hash(u * 4 + k, s0, s1);
-        bits |= ((h & 0xFFFFu) >= thr ? 1u : 0u) << (2 * k);
-        bits |= ((h >> 16) >= thr ? 1u : 0u) << (2 * k + 1);
-    }
-    return bits;
-}
 __global__ __launch_bounds__(256) void gelu_dropout_bf16_fwd_kernel(const bf16* __restrict__ x, bf16* __restrict__ y,
                                                                      unsigned char* __restrict__ keep, size_t units, uint32_t s0, uint32_t s1,
                                                                      uint32_t thr, float scale) {
     for (size_t u = blockIdx.x * (size_t)blockDim.x + threadIdx.x; u < units; u += (size_t)gridDim.x * blockDim.x) {
         const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + u * 8);
-        const unsigned bits = drop_keep8(u, s0, s1, thr);
+        const unsigned bits = otp_drop_keep8(u, s0, s1, thr);
         bf16x8 o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -1893,6 +1877,34 @@ extern "C" int otp_gelu_bf16_forward(const void* x, void* y, size_t n, void* str
     gelu_bf16_fwd_kernel<<<grid_for(n / 8), 256, 0, static_cast<hipStream_t>(stream)>>>(static_cast<const bf16*>(x),
                                                                                           static_cast<bf16*>(y), n / 8);
     return otp_launch_status();
+}
+
+// The TransformerBlock MLP interior with its element-wise passes folded into the projections' epilogues (csrc/hb.hip's pointwise kernel):
+// up: pre = bf16(W1 x + b1) AND act = dropout(gelu(pre), p) (+ keep bits) in one launch; the down-projection's input gradient times
+// gelu'(pre) and the dropout factor in one launch.  desc: the (N, 1, T, C) convolution of that launch (for the gradient: the input-gradient
+// convolution, channels swapped).  OTP_ERR_UNSUPPORTED when the shape is not on the pointwise kernel - the caller keeps the separate launches.
+extern "C" int otp_nhwc_mlp_fused_supported(const otp_nhwc_conv_desc* d) { return (d && d->out_mode == 0 && use_hbpw(d)) ? 1 : 0; }
+
+extern "C" int otp_nhwc_mlp_up_bf16(const void* x, const void* wpacked, const void* bias, void* pre, void* act, void* keep_bits, float p,
+                                    unsigned long long seed, const otp_nhwc_conv_desc* d, void* stream) {
+    if (!x || !wpacked || !pre || !act || !keep_bits || !(p >= 0.f) || !(p < 1.f)) return OTP_ERR_BAD_ARG;
+    if (!otp_nhwc_mlp_fused_supported(d)) return OTP_ERR_UNSUPPORTED;
+    otp_hbpw_epi e{};
+    e.mode = 1, e.out2 = act, e.keep = static_cast<unsigned char*>(keep_bits);
+    e.s0 = (uint32_t)seed, e.s1 = (uint32_t)(seed >> 32), e.thr = (uint32_t)(p * 65536.f + 0.5f);
+    e.scale = 65536.f / (float)(65536u - e.thr);
+    return otp_hbpw_conv(x, wpacked, bias, nullptr, pre, nullptr, d, static_cast<hipStream_t>(stream), &e);
+}
+
+extern "C" int otp_nhwc_mlp_down_dgrad_bf16(const void* gy, const void* wpacked, const void* pre, const void* keep_bits, void* grad_pre,
+                                            float p, const otp_nhwc_conv_desc* d, void* stream) {
+    if (!gy || !wpacked || !pre || !keep_bits || !grad_pre || !(p >= 0.f) || !(p < 1.f)) return OTP_ERR_BAD_ARG;
+    if (!otp_nhwc_mlp_fused_supported(d)) return OTP_ERR_UNSUPPORTED;
+    otp_hbpw_epi e{};
+    e.mode = 2, e.aux = pre, e.keep = const_cast<unsigned char*>(static_cast<const unsigned char*>(keep_bits));
+    e.thr = (uint32_t)(p * 65536.f + 0.5f);
+    e.scale = 65536.f / (float)(65536u - e.thr);
+    return otp_hbpw_conv(gy, wpacked, nullptr, nullptr, grad_pre, nullptr, d, static_cast<hipStream_t>(stream), &e);
 }
 
 extern "C" int otp_gelu_dropout_bf16_forward(const void* x, void* y, void* keep_bits, size_t n, float p, unsigned long long seed,

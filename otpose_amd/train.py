@@ -622,9 +622,17 @@ class TrainGraphBF16(TrainGraph):
         if yn.shape[1] % 8 or yn.shape[2] % 32 or os.environ.get("OTPOSE_BF16_MLP", "1") == "0":
             return super().mlp(p, yn, pdrop)                  # the C = 17 flow encoder / odd lengths stay on the fp32 path
         x = B16.to_nhwc_grad(yn.unsqueeze(2))
-        h = B16.conv_bias(x, self._w4(p + ".0.weight"), self.P.get(p + ".0.bias"))
-        h = B16.gelu_dropout(h, pdrop if self.stochastic else 0.0)          # GELU + Dropout(pdrop) as one pass each way
-        o = B16.conv_out(h, self._w4(p + ".3.weight"), self.P.get(p + ".3.bias"))
+        w1, w2 = self._w4(p + ".0.weight"), self._w4(p + ".3.weight")
+        rate = pdrop if self.stochastic else 0.0
+        if os.environ.get("OTPOSE_MLP_FUSED_TRAIN", "0") == "1" and B16.mlp_interior_supported(x, w1, w2):
+            # GELU / dropout and their derivatives inside the projections' launches (bf16_ops.MlpInteriorFunction): built, tested and
+            # measured NEUTRAL (123.4 against 122.7 ms per step on one box) - the epilogues' ~20 vector instructions per hidden element
+            # cost the pointwise kernel what the two element-wise passes cost the HBM - so the three-node chain stays the default
+            o = B16.mlp_interior(x, w1, self.P.get(p + ".0.bias"), w2, self.P.get(p + ".3.bias"), rate)
+        else:
+            h = B16.conv_bias(x, w1, self.P.get(p + ".0.bias"))
+            h = B16.gelu_dropout(h, rate)                                    # GELU + Dropout(pdrop) as one pass each way
+            o = B16.conv_out(h, w2, self.P.get(p + ".3.bias"))
         return self.dropout(o.squeeze(2), pdrop)
 
     def hrnet_output(self, p, y):

@@ -344,6 +344,38 @@ def test_gelu_dropout_is_gelu_then_dropout_with_repeatable_draws():
     assert torch.equal(B.gelu_dropout(x, 0.0), B.gelu(x))
 
 
+@pytest.mark.parametrize("case", [(136, 544, 2, 6912, 0.1), (136, 544, 3, 200, 0.0), (40, 160, 1, 77, 0.25)])
+def test_mlp_interior_node_matches_the_three_node_chain(case):
+    """MlpInteriorFunction (GELU / dropout and their derivatives inside the projections' launches, otp_nhwc_mlp_*) against
+    conv_bias -> gelu_dropout -> conv_out with the SAME dropout seed: the same keep decisions, results and gradients within the bf16
+    rounding of the hidden tensor (the fused epilogues use a 6e-5 fit of the normal CDF and round once where the chain rounds twice)."""
+    from otpose_amd import bf16_ops as B
+    c, hid, n, t, p = case
+    g = torch.Generator().manual_seed(sum(int(v) for v in case[:4]))
+    x = _nhwc(_rb(torch.randn(n, c, 1, t, generator=g)))
+    w1 = (torch.randn(hid, c, 1, 1, generator=g) / c ** 0.5).to(_dev())
+    b1 = (torch.randn(hid, generator=g) * 0.1).to(_dev())
+    w2 = (torch.randn(c, hid, 1, 1, generator=g) / hid ** 0.5).to(_dev())
+    b2 = (torch.randn(c, generator=g) * 0.1).to(_dev())
+    go = torch.randn(n, c, 1, t, generator=g).to(_dev())
+    assert B.mlp_interior_supported(x, w1, w2)
+    res = []
+    for fused in (True, False):
+        leaves = [v.clone().requires_grad_() for v in (w1, b1, w2, b2)]
+        xi = x.clone().requires_grad_()
+        if fused:
+            o = B.mlp_interior(xi, *leaves, p, seed=99)
+        else:
+            o = B.conv_out(B.gelu_dropout(B.conv_bias(xi, leaves[0], leaves[1]), p, seed=99), leaves[2], leaves[3])
+        o.backward(go)
+        torch.cuda.synchronize()
+        res.append([o.detach().float()] + [xi.grad.float()] + [v.grad.float() for v in leaves])
+    names = ("out", "grad x", "grad w1", "grad b1", "grad w2", "grad b2")
+    for nm, a, b in zip(names, *res):
+        err = float((a - b).norm() / b.norm())
+        assert err <= 6e-3, (nm, err)              # (2^-9 rounding of the 4C-wide hidden tensor on both sides)
+
+
 def test_basic_block_node_matches_two_conv_bn_nodes():
     """BasicBlockFunction against the two ConvBnFunction nodes it replaces (model/HRNet.py:500-531): same launches, so
     the output, the running statistics and every gradient agree exactly - dL/dx included, where the fused node adds the skip
