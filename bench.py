@@ -480,8 +480,9 @@ def train_step_probe(cfg, dev, batch, dtype="bf16", steps=3, dist=None):
                         "traffic": None,
                         "note": "algorithmic 3 x 409 GFLOP per clip; the step is GPU-bound (host side 85-100 ms, hidden; a one-stream "
                                 "hipGraph replays no faster than the one-stream eager step: profiles/r04_train_graph_probe.txt) - "
-                                "~200 ms of kernel time on four streams, the bf16 conv kernel bound by the latency of its "
-                                "staging, not by the matrix pipe (DESIGN.md sections 3.6 and 5)"}}
+                                "~162 ms of kernel time per step (round 5; 189 before), of which the HRNet's convolutions 22, its BatchNorm "
+                                "passes 17 (at their HBM roofline), its weight gradients 21; ~35 ms of the step are temporal-encoder "
+                                "launches running one at a time (profiles/r05_train_timeline.txt, DESIGN.md section 3.6)"}}
     # the exchange's own wall time (an extra, untimed step with the collective bracketed by device synchronisations): what a scaling
     # run loses between the last backward kernel and the optimizer - so that a SCALE line can attribute its lost efficiency
     stats = {}
