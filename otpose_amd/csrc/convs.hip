@@ -799,7 +799,10 @@ bool convs_plan(const otp_conv_desc& d, SPlan& P) {
     // exactness of the magic divisions (numerator * divisor < 2^32) and 31-bit byte offsets
     if ((long)(P.HW + bm) * P.HW >= (1l << 32) || (long)P.HW * d.W >= (1l << 32)) return false;
     if ((long)(d.N + 1) * P.VR * P.VR >= (1l << 32)) return false;
-    if ((long)d.Cin * P.HW * 4 * 8 >= (1l << 31)) return false;    // a tile spans < 8 images: per-lane offsets stay 31-bit
+    {   // images a tile's window may touch (a 256-pixel tile of a small map spans many): (n - n0) * imgB stays below 2^31
+        const long span = (long)(bm) / P.HW + 2;
+        if (span * d.Cin * P.HW * 4 >= (1l << 31)) return false;
+    }
     if (P.HW < 32) return false;
     // operands of the kernel's 24-bit index multiplies (smul)
     if (P.HW >= (1 << 24) || (long)(d.N + 8) * P.VR >= (1l << 24) || (long)(d.N + 8) * (d.Cout / 4 + d.out_ctot) + d.out_coff >= (1l << 24)) return false;

@@ -433,7 +433,10 @@ bool convs2_plan(const otp_conv_desc& d, S2Plan& P, bool nchw) {
     P.mHWo = smagic(P.HWo); P.mWo = smagic(Wo); P.mW1 = smagic(P.W1); P.mVR = smagic(P.VR);
     if ((long)(P.HWo + 256) * P.HWo >= (1l << 32) || (long)P.HWo * Wo >= (1l << 32)) return false;
     if ((long)(d.N + 2) * P.VR * P.VR >= (1l << 32) || (long)(64 * 4 * MAXJ) * P.W1 >= (1l << 32)) return false;
-    if ((long)d.Cin * P.HW * 4 * 8 >= (1l << 31)) return false;    // a tile spans < 8 images: per-lane offsets stay 31-bit
+    {   // images a tile's window may touch (a 256-pixel tile of a small map spans many): (n - n0) * imgB stays below 2^31
+        const long span = (long)(64 * P.NPT) / P.HWo + 2;
+        if (span * d.Cin * P.HW * 4 >= (1l << 31)) return false;
+    }
     if ((size_t)d.N * d.out_ctot * P.HWo * 4 >= (1ull << 31) || (size_t)d.N * (d.res_ctot > 0 ? d.res_ctot : 1) * P.HWo * 4 >= (1ull << 31))
         return false;
     if ((size_t)P.nN * P.nChunks * swch(P.NTW) * 1024 >= (1ull << 31)) return false;
