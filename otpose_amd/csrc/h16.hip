@@ -729,7 +729,9 @@ constexpr int HPW_MAXC = 1024;            // shift table: output channels
 // = 2 KS KB, rounded up to whole 4 KB passes of the 256 threads
 __host__ __device__ constexpr int hpw_blkb(int KS) { return otp_hbpw_blkb(KS); }
 
-template <int KS>
+// EPI (bf16 build; compile time, so that the plain form keeps its registers - as run-time branches the two epilogues below cost
+// the MLP projections 19 registers and 41 -> 58 us): 0 plain, 1 per-tile channel statistics, 2 / 3 the MLP epilogues of csrc/hb.h
+template <int KS, int EPI = 0>
 __global__ __launch_bounds__(256, KS <= 4 ? 4 : (KS <= 8 ? 3 : 2)) void h16_pointwise_kernel(HPw A) {
     constexpr int BLKB = hpw_blkb(KS);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];     // 2 BLKB + HPW_MAXC * 4 (+ 4 waves x 2 x 32 floats: statistics)
@@ -828,7 +830,7 @@ __global__ __launch_bounds__(256, KS <= 4 ? 4 : (KS <= 8 ? 3 : 2)) void h16_poin
                 f[e] = fmaxf(f[e], lo_clamp);
             }
 #ifdef OTP_H16_BF16
-            if (A.epi.mode == 2) {
+            if constexpr (EPI == 3) {
                 // input gradient of the MLP's down-projection: times gelu'(pre-activation) and the dropout factor of the forward
                 const size_t eo = A.o_base + img[h] * A.o_imgB + (c8 >> 3) * A.o_gS + pix[h] * A.o_pS;
                 const bool lv = cl && pv[h];
@@ -843,7 +845,7 @@ __global__ __launch_bounds__(256, KS <= 4 ? 4 : (KS <= 8 ? 3 : 2)) void h16_poin
                     f[e] = ((bits >> e) & 1u) ? f[e] * A.epi.scale * d : 0.f;
                 }
             }
-            if (A.stats) {
+            if constexpr (EPI == 1) {
                 // per-tile channel sums of the ROUNDED values (csrc/nhwc.hip's contract: what BatchNorm will normalise): the 16 lanes of
                 // a DPP row hold 16 pixels of the lane's 8 channels
                 const u32x4 qv = hpack8((const float(&)[8])f);
@@ -868,7 +870,7 @@ __global__ __launch_bounds__(256, KS <= 4 ? 4 : (KS <= 8 ? 3 : 2)) void h16_poin
                     const u32x4 rec = hpack8(f);
                     *reinterpret_cast<u32x4*>(A.out + eo) = rec;
 #ifdef OTP_H16_BF16
-                    if (A.epi.mode == 1) {
+                    if constexpr (EPI == 2) {
                         // dropout(gelu(.)) of the ROUNDED result (what a separate pass over the stored tensor computes), one rounding
                         const f32x2 w0 = hwiden(rec[0]), w1 = hwiden(rec[1]), w2 = hwiden(rec[2]), w3 = hwiden(rec[3]);
                         const float hv[8] = {w0.x, w0.y, w1.x, w1.y, w2.x, w2.y, w3.x, w3.y};
@@ -884,7 +886,7 @@ __global__ __launch_bounds__(256, KS <= 4 ? 4 : (KS <= 8 ? 3 : 2)) void h16_poin
             }
         }
 #ifdef OTP_H16_BF16
-        if (A.stats) {
+        if constexpr (EPI == 1) {
             float* sr = sred + (blk & 1) * 256;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -904,7 +906,7 @@ __global__ __launch_bounds__(256, KS <= 4 ? 4 : (KS <= 8 ? 3 : 2)) void h16_poin
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
 #ifdef OTP_H16_BF16
-        if (A.stats && tid < 64) {
+        if (EPI == 1 && tid < 64) {
             // the four waves' partials in a fixed order; the buffer alternates, so the next block's writes cannot overtake these reads
             const float* sr = sred + (blk & 1) * 256;
             const int which = tid >> 5, c = tid & 31, co = 32 * blk + c;
@@ -921,9 +923,9 @@ __global__ __launch_bounds__(256, KS <= 4 ? 4 : (KS <= 8 ? 3 : 2)) void h16_poin
 #endif
 }
 
-template <int KS>
+template <int KS, int EPI = 0>
 int hpw_launch(const HPw& a, hipStream_t st) {
-    auto kern = h16_pointwise_kernel<KS>;
+    auto kern = h16_pointwise_kernel<KS, EPI>;
 #ifdef OTP_H16_BF16
     const size_t need = 2 * (size_t)hpw_blkb(KS) + HPW_MAXC * 4 + 2 * 256 * 4;
 #else
@@ -1437,14 +1439,18 @@ int otp_hbpw_conv(const void* x, const void* wpacked, const void* bias, const vo
     a.rflag = nullptr;
     a.stats = static_cast<float*>(stats);
     if (epi) a.epi = *epi;
-    switch (otp_hbpw_ks(d->Cin)) {
-        case 2: return hpw_launch<2>(a, stream);
-        case 4: return hpw_launch<4>(a, stream);
-        case 5: return hpw_launch<5>(a, stream);
-        case 8: return hpw_launch<8>(a, stream);
-        case 12: return hpw_launch<12>(a, stream);
-        case 17: return hpw_launch<17>(a, stream);
+    const int ks = otp_hbpw_ks(d->Cin), mode = epi ? epi->mode : 0;
+    if (mode) {                                                    // the MLP epilogues: the up-projection / the down-projection's input gradient (Cin = C)
+#define OTP_HBPW_EPI(KS_)                                                     \
+    if (ks == KS_) return mode == 1 ? hpw_launch<KS_, 2>(a, stream) : hpw_launch<KS_, 3>(a, stream);
+        OTP_HBPW_EPI(2) OTP_HBPW_EPI(4) OTP_HBPW_EPI(5) OTP_HBPW_EPI(8)
+#undef OTP_HBPW_EPI
+        return OTP_ERR_UNSUPPORTED;
     }
+#define OTP_HBPW_CASE(KS_) \
+    if (ks == KS_) return stats ? hpw_launch<KS_, 1>(a, stream) : hpw_launch<KS_, 0>(a, stream);
+    OTP_HBPW_CASE(2) OTP_HBPW_CASE(4) OTP_HBPW_CASE(5) OTP_HBPW_CASE(8) OTP_HBPW_CASE(12) OTP_HBPW_CASE(17)
+#undef OTP_HBPW_CASE
     return OTP_ERR_UNSUPPORTED;
 }
 
