@@ -164,7 +164,9 @@ struct HPlan {
 #ifndef OTP_H16_MINWG
 #define OTP_H16_MINWG 3                   /* development A/B (tools/lib_variant.sh): waves per SIMD the register budget is cut for */
 #endif
-template <int NTW, int NPT, int STRIDE>
+// MODE (bf16 build; compile time - as run-time branches the statistics / residual forms cost the plain one registers): 0 plain,
+// 1 per-tile channel statistics, 2 residual
+template <int NTW, int NPT, int STRIDE, int MODE = 0>
 __global__ __launch_bounds__(256, STRIDE == 1 ? OTP_H16_MINWG : 2) void h16_conv3x3_kernel(const unsigned char* __restrict__ xs,
                                                                                 const unsigned char* __restrict__ wpk,
                                                                                 const float* __restrict__ shift,
@@ -366,8 +368,13 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? OTP_H16_MINWG : 2) void h16_conv
     // (the residual records are loaded here, not held across the chunk loop: 24 registers less is a fourth workgroup per CU, and
     //  another workgroup's MFMAs cover the round trip)
     u32x4 rres[(NTW + 1) / 2][NPT];
+#ifdef OTP_H16_BF16
+    constexpr bool load_res = MODE == 2;
+#else
+    constexpr bool load_res = true;
+#endif
 #pragma unroll
-    for (int t = 0; t < NTW; t += 2) {
+    for (int t = 0; load_res && t < NTW; t += 2) {
         const bool tav = ch0[t] < P.Cout;                          // (per lane: Cout % 8 == 0, a lane's record exists or does not)
         const int go = hmul(ch0[t] >> 3, P.res_gS);
         if (hpaired(co_blk, t, NTW, P.Cout)) {
@@ -406,7 +413,7 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? OTP_H16_MINWG : 2) void h16_conv
                           paired ? acc[t1][p][1] : 0.f, paired ? acc[t1][p][2] : 0.f, paired ? acc[t1][p][3] : 0.f};
             u32x4 rec = hpack8(f);
             const bool pv = offO[p] != HOOB;
-            if (P.stats || res) {
+            if constexpr (MODE != 0) {
                 const f32x2 w0 = hwiden(rec[0]), w1 = hwiden(rec[1]), w2 = hwiden(rec[2]), w3 = hwiden(rec[3]);
                 float fr[8] = {w0.x, w0.y, w1.x, w1.y, w2.x, w2.y, w3.x, w3.y};
 #pragma unroll
@@ -415,7 +422,7 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? OTP_H16_MINWG : 2) void h16_conv
                     s1[e] += v;
                     s2[e] += v * v;
                 }
-                if (res) {
+                if constexpr (MODE == 2) {
                     const u32x4 rq = rres[t >> 1][p];
                     const f32x2 r0 = hwiden(rq[0]), r1 = hwiden(rq[1]), r2 = hwiden(rq[2]), r3 = hwiden(rq[3]);
                     float g[8] = {fr[0] + r0.x, fr[1] + r0.y, fr[2] + r1.x, fr[3] + r1.y, fr[4] + r2.x, fr[5] + r2.y, fr[6] + r3.x, fr[7] + r3.y};
@@ -429,7 +436,7 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? OTP_H16_MINWG : 2) void h16_conv
                 __builtin_amdgcn_raw_buffer_store_b64((u32x2){rec[0], rec[1]}, ro, (tav && pv) ? offO[p] + go + 8 * half : HOOB, 0, 0);
             }
         }
-        if (P.stats) {
+        if constexpr (MODE == 1) {
             const int cl = ch0[t] - co_blk;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -443,7 +450,7 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? OTP_H16_MINWG : 2) void h16_conv
             }
         }
     }
-    if (P.stats) {
+    if constexpr (MODE == 1) {
         __syncthreads();
         for (int i = tid; i < 2 * CB; i += 256) {
             const int which = i / CB, c = i - which * CB, co = co_blk + c;
@@ -622,9 +629,9 @@ bool h16_conv_plan(const otp_h16_conv_desc& d, HPlan& P, bool nhwc = false) {
     return true;
 }
 
-template <int NTW, int NPT, int STRIDE>
+template <int NTW, int NPT, int STRIDE, int MODE = 0>
 int h16_conv_launch(const void* xs, const void* wpk, const float* shift, const void* res, void* out, const HPlan& P, hipStream_t st) {
-    auto kern = h16_conv3x3_kernel<NTW, NPT, STRIDE>;
+    auto kern = h16_conv3x3_kernel<NTW, NPT, STRIDE, MODE>;
     const size_t need = (size_t)(P.CK / 8) * P.pl + hwb(NTW) + hsred(NTW);
     OTP_ALLOW_BIG_LDS(kern, need);
     hipLaunchKernelGGL(kern, dim3(8 * P.tpx * P.nN), dim3(256), need, st, static_cast<const unsigned char*>(xs),
@@ -635,7 +642,14 @@ int h16_conv_launch(const void* xs, const void* wpk, const float* shift, const v
 
 int h16_conv_dispatch(const void* xs, const void* wpk, const float* fs, const void* res, void* out, const HPlan& P, int stride,
                       hipStream_t st) {
+#ifdef OTP_H16_BF16
+#define OTP_H16_GO(NTW_, NPT_, S_)                                                                          \
+    return P.stats ? h16_conv_launch<NTW_, NPT_, S_, 1>(xs, wpk, fs, res, out, P, st)                       \
+                   : (res ? h16_conv_launch<NTW_, NPT_, S_, 2>(xs, wpk, fs, res, out, P, st)                \
+                          : h16_conv_launch<NTW_, NPT_, S_, 0>(xs, wpk, fs, res, out, P, st))
+#else
 #define OTP_H16_GO(NTW_, NPT_, S_) return h16_conv_launch<NTW_, NPT_, S_>(xs, wpk, fs, res, out, P, st)
+#endif
 #define OTP_H16_NPT(NPT_, S_)                                  \
     if (P.NPT == NPT_) {                                       \
         if (P.NTW == 2) OTP_H16_GO(2, NPT_, S_);               \
