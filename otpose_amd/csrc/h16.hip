@@ -368,11 +368,7 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? OTP_H16_MINWG : 2) void h16_conv
     // (the residual records are loaded here, not held across the chunk loop: 24 registers less is a fourth workgroup per CU, and
     //  another workgroup's MFMAs cover the round trip)
     u32x4 rres[(NTW + 1) / 2][NPT];
-#ifdef OTP_H16_BF16
-    constexpr bool load_res = MODE == 2;
-#else
-    constexpr bool load_res = true;
-#endif
+    constexpr bool load_res = MODE == 2;                           // (a template variant: the plain form carries no residual loads / adds)
 #pragma unroll
     for (int t = 0; load_res && t < NTW; t += 2) {
         const bool tav = ch0[t] < P.Cout;                          // (per lane: Cout % 8 == 0, a lane's record exists or does not)
@@ -472,7 +468,7 @@ __global__ __launch_bounds__(256, STRIDE == 1 ? OTP_H16_MINWG : 2) void h16_conv
         const int go = hmul(ch0[t] >> 3, P.out_gS);
 #pragma unroll
         for (int p = 0; p < NPT; ++p) {
-            const u32x4 rq = rres[t >> 1][p];
+            const u32x4 rq = load_res ? rres[t >> 1][p] : (u32x4){0u, 0u, 0u, 0u};
             const f32x2 r0 = hwiden(rq[0]), r1 = hwiden(rq[1]), r2 = hwiden(rq[2]), r3 = hwiden(rq[3]);
             float f[8] = {acc[t][p][0] * P.post + r0.x, acc[t][p][1] * P.post + r0.y, acc[t][p][2] * P.post + r1.x,
                           acc[t][p][3] * P.post + r1.y,
@@ -648,7 +644,9 @@ int h16_conv_dispatch(const void* xs, const void* wpk, const float* fs, const vo
                    : (res ? h16_conv_launch<NTW_, NPT_, S_, 2>(xs, wpk, fs, res, out, P, st)                \
                           : h16_conv_launch<NTW_, NPT_, S_, 0>(xs, wpk, fs, res, out, P, st))
 #else
-#define OTP_H16_GO(NTW_, NPT_, S_) return h16_conv_launch<NTW_, NPT_, S_>(xs, wpk, fs, res, out, P, st)
+#define OTP_H16_GO(NTW_, NPT_, S_)                                                                          \
+    return res ? h16_conv_launch<NTW_, NPT_, S_, 2>(xs, wpk, fs, res, out, P, st)                           \
+               : h16_conv_launch<NTW_, NPT_, S_, 0>(xs, wpk, fs, res, out, P, st)
 #endif
 #define OTP_H16_NPT(NPT_, S_)                                  \
     if (P.NPT == NPT_) {                                       \
