@@ -164,8 +164,15 @@ class TrainGraph:
 
     def __init__(self, model):
         self.model = model
-        # one walk over the module tree per forward (named_parameters / named_buffers / named_modules would be three)
-        self.mods = dict(model.named_modules())
+        # one walk over the module tree (named_parameters / named_buffers / named_modules would be three) - the TREE is kept on the
+        # model between forwards (3 of the 4 ms this constructor took at cfg2: ~1400 modules; a step that synchronises every
+        # iteration, as the reference's loop does for its loss meter, waits for the host at the start of the forward), the parameter
+        # and buffer tables are re-read from the modules every time, so replaced / re-homed tensors are seen.  ``del
+        # model._otp_module_walk`` after adding or removing sub-modules by hand.
+        walk = model.__dict__.get("_otp_module_walk")
+        if walk is None or walk[0] != len(model._modules):
+            walk = model.__dict__["_otp_module_walk"] = (len(model._modules), dict(model.named_modules()))
+        self.mods = walk[1]
         self.P, self.Bf = {}, {}
         for name, mod in self.mods.items():
             pre = name + "." if name else ""
