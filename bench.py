@@ -466,12 +466,29 @@ def train_step_probe(cfg, dev, batch, dtype="bf16", steps=3, dist=None):
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     t = float(t.item())
+    # the same steps back to back (no synchronisation between them: the host enqueues step i + 1 while the device runs step i).  The
+    # synchronised figure above is what a loop sees that reads its results every iteration, as the reference's does (accuracy of the
+    # outputs on the CPU, script/Common.py:147) - there the forward starts with an idle device and is bound by the host's ~35 ms of launches
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(4):
+        loss = PAR.train_step_dp(model, opt, x, margin, g, wt)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    tf = torch.tensor([(time.perf_counter() - t0) / 4], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(tf, op=dist.ReduceOp.MAX)
+    tf = float(tf.item())
     flop = 3.0 * FLOP_PER_CLIP * batch * world               # forward + input gradients + weight gradients
-    res = {"ms_per_step": 1e3 * t, "frames_per_s": 5 * batch * world / t, "clips_per_gpu": batch, "n_gpus": world,
+    res = {"ms_per_step": 1e3 * t, "frames_per_s": 5 * batch * world / t, "ms_per_step_free_running": 1e3 * tf,
+           "clips_per_gpu": batch, "n_gpus": world,
            "dtype": dtype, "collective": ("RCCL all-reduce of the flat fp32 gradient buffers, world %d" % world) if world > 1
            else "none (1 GPU)",
            "what": "forward (train mode) + 2x ST_OHKW loss + backward + grad all-reduce + clip + AdamW, median of %d after "
-                   "1 warm-up, max over ranks" % steps,
+                   "1 warm-up, every step synchronised, max over ranks; ms_per_step_free_running: 4 steps back to back" % steps,
            "loss_finite": bool(torch.isfinite(loss.detach()).all()),
            "peak_mem_GB": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
            "roofline": {"bound": "mfma", "achieved": flop / t / 1e12 / world,

@@ -281,9 +281,11 @@ class _DeviceGuarded:
     def _wrap(fn):
         import torch
 
+        cur = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device      # (the C call: no lazy-init check per launch)
+
         def call(*args):
             dev = getattr(_tls, "dev", None)
-            if dev is not None and dev != torch.cuda.current_device():
+            if dev is not None and dev != cur():
                 with torch.cuda.device(dev):
                     return fn(*args)
             return fn(*args)
