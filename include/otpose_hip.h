@@ -667,6 +667,13 @@ int otp_nhwc_bn_finalize(const void* partials, int rows, int C, int CS, float co
                          float momentum, void* stream);
 int otp_nhwc_bn_apply(const void* x, const void* scale, const void* shift, const void* res, void* y, void* relu_mask,
                       size_t pixels, int CS, int relu, void* stream);
+/* conv (no bias) + BatchNorm2d with batch statistics (+ residual) (+ ReLU) of one HRNet layer as ONE call - the three launches above
+ * in sequence (host time: the training forward issues ~290 of these).  conv_out (N, Ho, Wo, CoutS) bf16 and stats
+ * (otp_nhwc_conv_stats_rows x 2 x CoutS floats) receive the convolution and its per-tile sums, vec (4 x CoutS floats) mean | rstd |
+ * scale | shift, y / relu_mask the layer's result as otp_nhwc_bn_apply writes them. */
+int otp_nhwc_conv_bn_bf16(const void* x, const void* wpacked, const void* res, void* conv_out, void* stats, void* vec,
+                          const void* gamma, const void* beta, void* running_mean, void* running_var, float eps, float momentum,
+                          void* y, void* relu_mask, int relu, const otp_nhwc_conv_desc* desc, void* stream);
 size_t otp_nhwc_bn_backward_workspace(size_t pixels, int CS);
 int otp_nhwc_bn_backward(const void* gy, const void* y, const void* x, const void* mean, const void* rstd, const void* gamma,
                          void* gx, void* gres, void* dgamma, void* dbeta, void* workspace, size_t workspace_bytes,

@@ -323,6 +323,29 @@ def bn_backward(gy, y, x, mean, rstd, gamma, c, relu, want_res, out_gamma=None, 
     return gx, gres, dg, db
 
 
+def conv_bn_forward(x, weight, gamma, beta, res, running_mean, running_var, stride, pad, relu, momentum, eps, packs=None):
+    """conv + BatchNorm (batch statistics) (+ res) (+ ReLU) through ONE library call (``otp_nhwc_conv_bn_bf16``: the same three
+    launches as conv_forward -> bn_finalize -> bn_apply).  Returns (conv output, mask, vec, y)."""
+    cout, cin, kh, kw = weight.shape
+    n, h, w, cins = x.shape
+    assert cins == cs(cin) and x.dtype == BF16 and x.is_contiguous()
+    d = _desc(n, h, w, cin, cout, kh, kw, stride, pad, 1, 0)
+    wp = _pack(weight.contiguous(), d, 0, packs)
+    ho, wo = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
+    L = hip.lib()
+    csz = cs(cout)
+    c = _new((n, ho, wo, csz), BF16, x)
+    rows = L.otp_nhwc_conv_stats_rows(ctypes.byref(d))
+    stats = _new((rows, 2, csz), torch.float32, x)
+    vec = _new((4, csz), torch.float32, x)
+    y = torch.empty_like(c)
+    mask = torch.empty(c.numel() // 8, dtype=torch.uint8, device=x.device) if relu else None
+    hip.check(L.otp_nhwc_conv_bn_bf16(hip.ptr(x), hip.ptr(wp), hip.ptr(res), hip.ptr(c), hip.ptr(stats), hip.ptr(vec), hip.ptr(gamma),
+                                      hip.ptr(beta), hip.ptr(running_mean), hip.ptr(running_var), eps, momentum, hip.ptr(y),
+                                      hip.ptr(mask), int(relu), ctypes.byref(d), hip.stream_of(x)), "otp_nhwc_conv_bn_bf16")
+    return c, mask, vec, y
+
+
 class ConvBnFunction(Function):
     """``relu?(batch_norm(conv2d(x, weight, None, stride, pad)) (+ res))`` - one HRNet conv + BatchNorm2d (training mode:
     batch statistics, running buffers updated) + residual + ReLU (model/HRNet.py:500-571, 192-231, 416-473)."""
@@ -333,11 +356,8 @@ class ConvBnFunction(Function):
         x = x.contiguous()
         cout = weight.shape[0]
         ctx.packs = _ACTIVE_PACKS
-        c, stats, rows = conv_forward(x, weight, None, stride, pad, 1, packs=ctx.packs)
-        count = c.numel() // c.shape[-1]
-        vec = bn_finalize(stats, rows, cout, count, gamma, beta, running_mean, running_var, momentum, eps)
         r = res.contiguous() if res is not None else None
-        y, mask = bn_apply(c, vec[2], vec[3], r, relu, want_mask=True)
+        c, mask, vec, y = conv_bn_forward(x, weight, gamma, beta, r, running_mean, running_var, stride, pad, relu, momentum, eps, ctx.packs)
         ctx.save_for_backward(x, weight, gamma, c, mask, vec)
         ctx.cfg = (stride, pad, relu, res is not None)
         ctx.params = (weight, gamma, beta)             # gradient slots are looked up at backward time
@@ -373,12 +393,8 @@ class BasicBlockFunction(Function):
         _require_gpu(x, w1, w2)
         x = x.contiguous()
         ctx.packs = _ACTIVE_PACKS
-        c1, st1, rows1 = conv_forward(x, w1, None, 1, 1, 1, packs=ctx.packs)
-        vec1 = bn_finalize(st1, rows1, w1.shape[0], c1.numel() // c1.shape[-1], g1, b1, rm1, rv1, momentum, eps)
-        y1, m1 = bn_apply(c1, vec1[2], vec1[3], None, True, want_mask=True)
-        c2, st2, rows2 = conv_forward(y1, w2, None, 1, 1, 1, packs=ctx.packs)
-        vec2 = bn_finalize(st2, rows2, w2.shape[0], c2.numel() // c2.shape[-1], g2, b2, rm2, rv2, momentum, eps)
-        y2, m2 = bn_apply(c2, vec2[2], vec2[3], x, True, want_mask=True)
+        c1, m1, vec1, y1 = conv_bn_forward(x, w1, g1, b1, None, rm1, rv1, 1, 1, True, momentum, eps, ctx.packs)
+        c2, m2, vec2, y2 = conv_bn_forward(y1, w2, g2, b2, x, rm2, rv2, 1, 1, True, momentum, eps, ctx.packs)
         ctx.save_for_backward(x, w1, g1, c1, m1, vec1, y1, w2, g2, c2, m2, vec2)
         ctx.params = (w1, g1, b1, w2, g2, b2)
         return y2

@@ -1758,6 +1758,27 @@ static int bn_bwd_rows(size_t pixels, int* pixPerWg) {
     return (int)((pixels + *pixPerWg - 1) / *pixPerWg);
 }
 
+// conv + BatchNorm (batch statistics) + residual + ReLU as ONE call (three launches: otp_nhwc_conv_bf16 with statistics,
+// otp_nhwc_bn_finalize, otp_nhwc_bn_apply): the training forward issues ~290 of these per step and is bound by the host once a loop
+// synchronises every iteration (a ctypes call costs ~4 us of host time).  vec: 4 x CoutS floats (mean, rstd, scale, shift).
+extern "C" int otp_nhwc_conv_bn_bf16(const void* x, const void* wpacked, const void* res, void* conv_out, void* stats, void* vec,
+                                     const void* gamma, const void* beta, void* running_mean, void* running_var, float eps,
+                                     float momentum, void* y, void* relu_mask, int relu, const otp_nhwc_conv_desc* d, void* stream) {
+    if (!x || !wpacked || !conv_out || !stats || !vec || !gamma || !beta || !y || !d) return OTP_ERR_BAD_ARG;
+    const int rows = otp_nhwc_conv_stats_rows(d);
+    if (rows <= 0) return OTP_ERR_UNSUPPORTED;
+    int rc = otp_nhwc_conv_bf16_res(x, wpacked, nullptr, nullptr, conv_out, stats, d, stream);
+    if (rc != OTP_OK) return rc;
+    const int CS = (d->Cout + 7) / 8 * 8;
+    const int Ho = (d->H + 2 * d->pad - d->dil * (d->kh - 1) - 1) / d->stride + 1, Wo = (d->W + 2 * d->pad - d->dil * (d->kw - 1) - 1) / d->stride + 1;
+    const size_t pixels = (size_t)d->N * Ho * Wo;
+    float* v = static_cast<float*>(vec);
+    rc = otp_nhwc_bn_finalize(stats, rows, d->Cout, CS, (float)pixels, gamma, beta, v, v + CS, v + 2 * CS, v + 3 * CS, running_mean,
+                              running_var, eps, momentum, stream);
+    if (rc != OTP_OK) return rc;
+    return otp_nhwc_bn_apply(conv_out, v + 2 * CS, v + 3 * CS, res, y, relu_mask, pixels, CS, relu, stream);
+}
+
 extern "C" size_t otp_nhwc_bn_backward_workspace(size_t pixels, int CS) {
     int ppw;
     const int rows = bn_bwd_rows(pixels, &ppw);

@@ -235,6 +235,7 @@ SIGNATURES = {
     "otp_nhwc_channel_sum": (c_int, [c_void_p] * 3 + [c_size_t, c_size_t, c_int, c_int, c_void_p]),
     "otp_gelu_bf16_forward": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "otp_gelu_bf16_backward": (c_int, [c_void_p] * 3 + [c_size_t, c_void_p]),
+    "otp_nhwc_conv_bn_bf16": (c_int, [c_void_p] * 10 + [ctypes.c_float, ctypes.c_float, c_void_p, c_void_p, c_int, _ND, c_void_p]),
     "otp_nhwc_mlp_fused_supported": (c_int, [_ND]),
     "otp_nhwc_mlp_up_bf16": (c_int, [c_void_p] * 6 + [ctypes.c_float, ctypes.c_ulonglong, _ND, c_void_p]),
     "otp_nhwc_mlp_down_dgrad_bf16": (c_int, [c_void_p] * 5 + [ctypes.c_float, _ND, c_void_p]),
